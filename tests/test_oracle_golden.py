@@ -1,0 +1,212 @@
+"""Pins oracle/lattice_oracle.py against golden vectors produced by the reference's own kernel
+source (tests/golden/make_goldens.py).  Integer outputs and order-deterministic fp32 outputs are
+compared bit-exactly; the fp32 tolerance for reduction-order-dependent outputs is 1e-5 relative
+(BASELINE.json north_star)."""
+import numpy as np
+import pytest
+
+from oracle import lattice_oracle as O
+
+RTOL = 1e-5
+
+
+def build(g, key_pos="pos_raw", cap_key="capacity", sigma_mul=1.0, write=True):
+    pos = O.scale_positions(g[key_pos], np.full((g[key_pos].shape[1],), g["sigma"] * np.float32(sigma_mul), np.float32))
+    t = O.OracleHashTable(int(g[cap_key]), pos.shape[1])
+    idx, w = O.build_splat(t, pos, write)
+    return t, pos, idx, w
+
+
+def close(a, b, scale=None):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    s = np.max(np.abs(b)) if scale is None else scale
+    np.testing.assert_allclose(a, b, rtol=RTOL, atol=RTOL * max(s, 1e-30))
+
+
+def test_f1_same_level_ops(golden):
+    g = golden("F1_config1")
+    t, pos, idx, w = build(g)
+    m = int(g["nr_filled"])
+    n, v = g["vals"].shape
+    assert t.nr_filled == m
+    np.testing.assert_array_equal(t.keys[:m], g["keys"])
+    np.testing.assert_array_equal(idx, g["idx"])
+    np.testing.assert_array_equal(w, g["w"])  # bit-exact fp32 weights
+    vals = np.zeros((m, v), np.float32)
+    O.splat_accumulate(vals, g["vals"], idx, w)
+    np.testing.assert_array_equal(vals, g["values"])  # same (p, r) summation order -> bit exact
+    nbr = O.neighbour_rows(t.keys[:m], t, 1, 1, 1, False)
+    np.testing.assert_array_equal(O.im2rowindices(nbr, v), g["im2rowindices_d1"])
+    np.testing.assert_array_equal(O.im2row(nbr, vals), g["im2row_d1"])
+    nbr_f = O.neighbour_rows(t.keys[:m], t, 1, 1, 1, True)
+    np.testing.assert_array_equal(O.im2row(nbr_f, vals), g["im2row_d1_flip"])
+    np.testing.assert_array_equal(O.row2im(nbr, g["grad_rowified"], v), g["row2im_d1"])
+    np.testing.assert_array_equal(O.slice_with_precomputation(vals, idx, w, n), g["slice"])
+    qpos = O.scale_positions(g["qpos_raw"], np.full((3,), g["sigma"], np.float32))
+    sl, i2, w2 = O.slice_no_precomputation(t, vals, qpos)
+    np.testing.assert_array_equal(i2, g["idx_nopre"])
+    np.testing.assert_array_equal(w2, g["w_nopre"])
+    np.testing.assert_array_equal(sl, g["slice_nopre"])
+    np.testing.assert_array_equal(O.gather_with_precomputation(vals, idx, w, n), g["gather"])
+    np.testing.assert_array_equal(O.slice_backwards(g["grad_sliced"], idx, w, m), g["slice_bwd"])
+    np.testing.assert_array_equal(O.gather_backwards(g["grad_gathered"], idx, w, m, 3), g["gather_bwd"])
+
+
+def test_f1_row2im_is_adjoint_of_im2row(golden):
+    g = golden("F1_config1")
+    t, pos, idx, w = build(g)
+    m = t.nr_filled
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((m, 4)).astype(np.float32)
+    y = rng.standard_normal((m, 36)).astype(np.float32)
+    nbr = O.neighbour_rows(t.keys[:m], t, 1, 1, 1, False)
+    lhs = np.sum(O.im2row(nbr, x).astype(np.float64) * y)
+    rhs = np.sum(x.astype(np.float64) * O.row2im(nbr, y, 4))
+    assert abs(lhs - rhs) <= 1e-4 * max(abs(lhs), 1.0)
+
+
+def test_f2_boundary_ties(golden):
+    g = golden("F2_boundary")
+    t, pos, idx, w = build(g)
+    m = int(g["nr_filled"])
+    assert t.nr_filled == m
+    np.testing.assert_array_equal(t.keys[:m], g["keys"])
+    np.testing.assert_array_equal(idx, g["idx"])
+    np.testing.assert_array_equal(w, g["w"])
+
+
+def test_simplex_invariants(golden):
+    g = golden("F9_lidar")
+    pos = O.scale_positions(g["pos_raw"], np.full((3,), g["sigma"], np.float32))
+    rem0, rank, bary = O.simplex(pos)
+    d = 3
+    assert np.all(np.sort(rank, axis=1) == np.arange(d + 1)[None, :])  # a permutation
+    assert np.all(rem0.sum(axis=1) == 0)
+    b = bary[:, : d + 1]
+    assert np.all(b >= -1e-5) and np.allclose(b.sum(axis=1), 1.0, atol=1e-5)
+    keys = O.simplex_keys(rem0, rank)
+    full = np.concatenate([keys, -keys.sum(axis=2, keepdims=True)], axis=2)
+    assert np.all((full - full[:, :, :1]) % (d + 1) == 0)  # coordinates congruent mod d+1
+
+
+def test_f3_two_levels(golden):
+    g = golden("F3_two_level")
+    fine, pos, idx, w = build(g)
+    mf = int(g["fine_nr"])
+    assert fine.nr_filled == mf
+    np.testing.assert_array_equal(fine.keys[:mf], g["fine_keys"])
+    fvals = np.zeros((mf, 4), np.float32)
+    O.splat_accumulate(fvals, g["vals"], idx, w)
+    np.testing.assert_array_equal(fvals, g["fine_values"])
+    coarse, _, _, _ = build(g, sigma_mul=2.0, write=False)
+    mc = int(g["coarse_nr"])
+    assert coarse.nr_filled == mc
+    np.testing.assert_array_equal(coarse.keys[:mc], g["coarse_keys"])
+    kc = O.OracleHashTable(int(g["capacity"]), 3)
+    O.coarsen_keys(fine, kc)
+    assert kc.nr_filled == int(g["keycoarse_nr"])
+    np.testing.assert_array_equal(kc.keys[: kc.nr_filled], g["keycoarse_keys"])
+    cvals = g["coarse_values"]
+    for flip in (False, True):
+        s = "_flip" if flip else ""
+        nbr = O.neighbour_rows(coarse.keys[:mc], fine, 2, 1, 1, flip)
+        np.testing.assert_array_equal(O.im2rowindices(nbr, 4), g["idx_coarse_from_fine" + s])
+        np.testing.assert_array_equal(O.im2row(nbr, fvals), g["row_coarse_from_fine" + s])
+        nbr = O.neighbour_rows(fine.keys[:mf], coarse, 1, 2, 1, flip)
+        np.testing.assert_array_equal(O.im2rowindices(nbr, 4), g["idx_fine_from_coarse" + s])
+        np.testing.assert_array_equal(O.im2row(nbr, cvals), g["row_fine_from_coarse" + s])
+
+
+def test_f4_dilation2(golden):
+    g = golden("F4_dilation2")
+    t, pos, idx, w = build(g)
+    m = int(g["nr_filled"])
+    np.testing.assert_array_equal(t.keys[:m], g["keys"])
+    nbr = O.neighbour_rows(t.keys[:m], t, 1, 1, 2, False)
+    np.testing.assert_array_equal(O.im2rowindices(nbr, 2), g["im2rowindices_d2"])
+    np.testing.assert_array_equal(O.im2row(nbr, g["values"]), g["im2row_d2"])
+    np.testing.assert_array_equal(O.row2im(nbr, g["grad_rowified"], 2), g["row2im_d2"])
+
+
+def test_f5_distribute(golden):
+    g = golden("F5_distribute")
+    pos = O.scale_positions(g["pos_raw"], np.full((3,), g["sigma"], np.float32))
+    t = O.OracleHashTable(int(g["capacity"]), 3)
+    dist, idx, w = O.distribute(t, pos, g["vals"])
+    assert t.nr_filled == int(g["nr_filled"])
+    np.testing.assert_array_equal(idx, g["idx"])
+    np.testing.assert_array_equal(w, g["w"])
+    np.testing.assert_array_equal(dist, g["distributed"])
+
+
+def test_f6_slice_classify(golden):
+    g = golden("F6_slice_classify")
+    t, pos, idx, w = build(g)
+    assert t.nr_filled == int(g["nr_filled"])
+    np.testing.assert_array_equal(idx, g["idx"])
+    n = g["pos_raw"].shape[0]
+    logits = O.slice_classify(g["lattice_values"], g["delta_w"], g["lin_w"], g["lin_b"], idx, w, n)
+    np.testing.assert_array_equal(logits, g["logits"])
+    gv, gd, gw, gb = O.slice_classify_backwards(g["grad_logits"], g["lattice_values"], g["delta_w"], g["lin_w"], g["lin_b"],
+                                                idx, w, n)
+    close(gv, g["g_values"])
+    close(gd, g["g_delta_w"])
+    close(gw, g["g_lin_w"], scale=np.max(np.abs(g["g_lin_w"])))
+    close(gb, g["g_lin_b"])
+
+
+def test_f7_near_full_table_probe_cap(golden):
+    g = golden("F7_near_full")
+    t, pos, idx, w = build(g)
+    m = int(g["nr_filled"])
+    assert t.nr_filled == m
+    np.testing.assert_array_equal(t.entries, g["entries"])  # identical slot layout under serial insertion
+    np.testing.assert_array_equal(idx, g["idx"])
+    sl, i2, w2 = O.slice_no_precomputation(t, g["lattice_values"], pos)
+    assert np.any((i2 == -1) & (idx >= 0)), "fixture must exercise the 300-probe give-up (HashTableGPU.cuh:494)"
+    np.testing.assert_array_equal(i2, g["idx_nopre"])
+    np.testing.assert_array_equal(w2, g["w_nopre"])
+    np.testing.assert_array_equal(sl, g["slice_nopre"])
+    nbr = O.neighbour_rows(t.keys[:m], t, 1, 1, 1, False)
+    np.testing.assert_array_equal(O.im2rowindices(nbr, 1), g["im2rowindices_d1"])
+
+
+def test_f8_posdim2_odd_branch(golden):
+    g = golden("F8_posdim2")
+    pos = O.scale_positions(g["pos_raw"], np.full((2,), g["sigma"], np.float32))
+    fine = O.OracleHashTable(int(g["capacity"]), 2)
+    idx, w = O.build_splat(fine, pos)
+    mf = int(g["fine_nr"])
+    assert fine.nr_filled == mf
+    np.testing.assert_array_equal(fine.keys[:mf], g["fine_keys"])
+    np.testing.assert_array_equal(idx, g["idx"])
+    np.testing.assert_array_equal(w, g["w"])
+    coarse = O.OracleHashTable(int(g["capacity"]), 2)
+    O.build_splat(coarse, O.scale_positions(g["pos_raw"], np.full((2,), 2 * g["sigma"], np.float32)), write=False)
+    mc = int(g["coarse_nr"])
+    np.testing.assert_array_equal(coarse.keys[:mc], g["coarse_keys"])
+    nbr = O.neighbour_rows(fine.keys[:mf], fine, 1, 1, 1, False)
+    np.testing.assert_array_equal(O.im2rowindices(nbr, 4), g["idx_same"])
+    np.testing.assert_array_equal(O.im2row(nbr, g["fine_values"]), g["row_same"])
+    nbr = O.neighbour_rows(coarse.keys[:mc], fine, 2, 1, 1, False)
+    np.testing.assert_array_equal(O.im2rowindices(nbr, 4), g["idx_coarse_from_fine"])
+    nbr = O.neighbour_rows(fine.keys[:mf], coarse, 1, 2, 1, False)
+    np.testing.assert_array_equal(O.im2rowindices(nbr, 4), g["idx_fine_from_coarse"])
+    np.testing.assert_array_equal(O.im2row(nbr, g["coarse_values"]), g["row_fine_from_coarse"])
+
+
+def test_f9_lidar_like(golden):
+    g = golden("F9_lidar")
+    t, pos, idx, w = build(g)
+    m = int(g["nr_filled"])
+    assert t.nr_filled == m
+    # set-based vertex count
+    rem0, rank, _ = O.simplex(pos)
+    keys = O.simplex_keys(rem0, rank).reshape(-1, 3)
+    assert len({tuple(k) for k in keys.tolist()}) == m
+    np.testing.assert_array_equal(t.keys[:m], g["keys"])
+    np.testing.assert_array_equal(idx, g["idx"])
+    np.testing.assert_array_equal(w, g["w"])
+    nbr = O.neighbour_rows(t.keys[:m], t, 1, 1, 1, False)
+    np.testing.assert_array_equal(O.im2rowindices(nbr, 1), g["im2rowindices_d1"])
