@@ -1,0 +1,153 @@
+/* latticenet_hip.h — C ABI of the MI355X (gfx950) permutohedral-lattice backend.
+ *
+ * Drop-in boundary for ONE path of AIS-Bonn/lattice_net: everything `latticenet.Lattice`
+ * (src/PyBridge.cxx:41-113) forwards to `LatticeGPU` launch wrappers
+ * (include/lattice_net/kernels/LatticeGPU.cuh:42-412).  Each entry point below names the
+ * reference interface it replaces.  Plain C: device pointers, sizes, a stream handle
+ * (hipStream_t passed as void*), int status.  No torch types.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in `_host`;
+ *   - all tensors are contiguous row-major; positions/values/weights fp32, indices int32;
+ *   - return value 0 = launched OK; <0 = argument / launch error, text via
+ *     ln_last_error_string(); kernels never block the host;
+ *   - asynchronous device-side conditions (table full, key out of packable range) are
+ *     recorded in LnTable.status and must be read back by the caller (ln_status_string).
+ *
+ * Vertex numbering is canonical: rows are numbered by first occurrence in
+ * (point, remainder) order, i.e. what a serial run of HashTableGPU::insert
+ * (HashTableGPU.cuh:425-484) produces.
+ */
+#ifndef LATTICENET_HIP_H
+#define LATTICENET_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LN_OK 0
+#define LN_ERR_ARG (-1)
+#define LN_ERR_UNSUPPORTED (-2)
+#define LN_ERR_LAUNCH (-3)
+#define LN_ERR_WORKSPACE (-4)
+
+/* bits of *LnTable.status (device int32) */
+#define LN_STATUS_TABLE_FULL 1      /* insert probed every slot (reference would spin forever, HashTableGPU.cuh:443) */
+#define LN_STATUS_KEY_RANGE 2       /* a lattice key did not fit the packed 64-bit slot format */
+
+#define LN_MAX_POS_DIM 6
+#define LN_NOT_VISITED (-2)          /* neighbour-list code: traversal never looks at this slot */
+
+/* Device-side open-addressing table.  Replaces HashTableGPU (HashTableGPU.cuh:12-30) and its
+ * host owner HashTable (src/HashTable.cu:21-47).  `keys`, `entries`, `nr_filled` have exactly
+ * the reference's meaning and layout; `slot_keys`/`slot_tok`/`status` are additions:
+ *   slot_keys[h]  the lattice key stored in slot h, packed into 64 bits (all-ones = empty), so
+ *                 claim + key publication is ONE 64-bit CAS (no spin lock, no fence);
+ *   slot_tok[h]   smallest insertion token that touched slot h during the build that created
+ *                 it (0xFFFFFFFF while empty) — defines the canonical row order;
+ *   status        sticky error bits, see LN_STATUS_*. */
+typedef struct LnTable {
+    int capacity;
+    int pos_dim;
+    unsigned long long* slot_keys; /* [capacity] */
+    unsigned int* slot_tok;        /* [capacity] */
+    int* entries;                  /* [capacity]   slot -> row, -1 empty  (m_entries) */
+    int* keys;                     /* [capacity,d] row  -> key            (m_keys)    */
+    int* nr_filled;                /* [1]                                 (m_nr_filled) */
+    int* status;                   /* [1] */
+} LnTable;
+
+const char* ln_last_error_string(void);
+const char* ln_version(void);
+
+/* HashTable::clear (src/HashTable.cu:49-57): entries=-1, keys=0, nr_filled=0 (+ our slots/status)
+ * in one launch.  `values` (may be NULL) is zero-filled too: values_elems floats. */
+int ln_table_clear(const LnTable* t, float* values, long long values_elems, void* stream);
+
+/* Scratch needed by ln_build_splat / ln_coarsen for `tokens` insertions. */
+size_t ln_build_workspace_bytes(long long tokens);
+
+/* kernel_splat (LatticeGPU.cuh:707-842) behind Lattice::splat_standalone / just_create_verts
+ * (src/Lattice.cu:196-290), with `positions_raw / sigmas` (Lattice.cu:226) fused in.
+ * Inserts the d+1 simplex vertices of every point; when write_idx != 0 writes
+ * idx[n*(d+1)] (row ids) and w[n*(d+1)] (barycentric weights).  Both must be pre-sized; rows
+ * that cannot be inserted keep -1 (Lattice.cu:212-215 semantics are produced here, no pre-fill
+ * needed).  idx/w may be NULL when write_idx == 0. */
+int ln_build_splat(const LnTable* t, const float* positions_raw, const float* sigmas_host, int n, int* idx, float* w,
+                   int write_idx, void* workspace, size_t workspace_bytes, void* stream);
+
+/* splatCacheNaive (LatticeGPU.cuh:926-973): table_values[idx] += vals * w. */
+int ln_splat_accumulate(float* table_values, const float* vals, const int* idx, const float* w, int n, int pos_dim,
+                        int val_dim, void* stream);
+
+/* distribute kernel (LatticeGPU.cuh:534-650) behind Lattice::distribute (Lattice.cu:351-410):
+ * ln_build_splat + the dense rows [pos_scaled(d) | val(V) | bary] -> distributed[n*(d+1), d+V+1]. */
+int ln_distribute(const LnTable* t, const float* positions_raw, const float* sigmas_host, const float* vals, int n,
+                  int val_dim, int* idx, float* w, float* distributed, void* workspace, size_t workspace_bytes,
+                  void* stream);
+
+/* coarsen kernel (LatticeGPU.cuh:2314-2514) behind Lattice::create_coarse_verts (Lattice.cu:670-703).
+ * fine_rows_upper bounds the launch; the kernel also honours *fine->nr_filled. */
+int ln_coarsen(const LnTable* fine, int fine_rows_upper, const LnTable* coarse, void* workspace, size_t workspace_bytes,
+               void* stream);
+
+/* Neighbour traversal shared by im2row / im2rowindices / row2im (LatticeGPU.cuh:1479-1684,
+ * 1844-1915, 2187-2284): nbr[query_rows_upper, E] (E = 2(d+1)+1) rows of the neighbour table;
+ * -1 = visited-but-absent, LN_NOT_VISITED = never looked at.  Slot layout as the reference:
+ * axis a: np -> 2a+(flip), nm -> 2a+(1-flip); centre -> E-1. */
+int ln_neighbours(const LnTable* query, int query_rows_upper, const LnTable* neigh, int lvl_query, int lvl_neigh,
+                  int dilation, int flip, int* nbr, void* stream);
+
+/* im2row (LatticeGPU.cuh:1464-1688) from a neighbour list: out[m, E*V]. */
+int ln_im2row(const int* nbr, const float* values_neigh, int m, int filter_extent, int val_dim, float* out, void* stream);
+/* im2rowindices (LatticeGPU.cuh:1690-1920): out[m, E*V] int32, reference fill rules. */
+int ln_im2rowindices(const int* nbr, int m, int filter_extent, int val_dim, int* out, void* stream);
+/* row2im (LatticeGPU.cuh:2067-2305): out[m, V] = adjoint gather of rowified[m_rows, E*V];
+ * `nbr` is the un-flipped list of the OUTPUT lattice against the lattice indexing `rowified`. */
+int ln_row2im(const int* nbr, const float* rowified, int m, int filter_extent, int val_dim, float* out, void* stream);
+
+/* Lattice::convolve_im2row_standalone (Lattice.cu:424-474) without materialising the rowified
+ * tensor: out[m, F] = sum_e values_neigh[nbr[m,e], :] @ filter[e*V:(e+1)*V, :]  (fp32 MFMA). */
+int ln_conv_forward(const int* nbr, const float* values_neigh, const float* filter, int m, int filter_extent, int val_dim,
+                    int nr_filters, float* out, void* stream);
+/* grad_filter = rowified^T @ grad_out (lattice_funcs.py:302) without the rowified tensor.
+ * workspace: ln_conv_grad_filter_workspace_bytes(). */
+size_t ln_conv_grad_filter_workspace_bytes(int m, int filter_extent, int val_dim, int nr_filters);
+int ln_conv_grad_filter(const int* nbr, const float* values_neigh, const float* grad_out, int m, int filter_extent,
+                        int val_dim, int nr_filters, float* grad_filter, void* workspace, size_t workspace_bytes,
+                        void* stream);
+
+/* slice_with_precomputation (LatticeGPU.cuh:2552-2595). */
+int ln_slice_forward(const float* values, const int* idx, const float* w, int n, int pos_dim, int val_dim, float* out,
+                     void* stream);
+/* slice_no_precomputation (LatticeGPU.cuh:2598-2750): also writes idx/w (-1 where absent). */
+int ln_slice_no_precomputation(const LnTable* t, const float* values, const float* positions_raw, const float* sigmas_host,
+                               int n, int val_dim, float* out, int* idx, float* w, void* stream);
+/* slice_backwards_with_precomputation_no_homogeneous (LatticeGPU.cuh:3540-3623);
+ * grad_values[m_rows, V] must be zeroed by the caller (Lattice.cu:1079). */
+int ln_slice_backward(const float* grad_sliced, const int* idx, const float* w, int n, int pos_dim, int val_dim,
+                      float* grad_values, void* stream);
+
+/* gather_with_precomputation (LatticeGPU.cuh:2886-2929): out[n, (d+1)(V+1)] (fully written). */
+int ln_gather_forward(const float* values, const int* idx, const float* w, int n, int pos_dim, int val_dim, float* out,
+                      void* stream);
+/* gather_backwards_with_precomputation (LatticeGPU.cuh:3761-3817); grad_values zeroed by caller. */
+int ln_gather_backward(const float* grad_gathered, const int* idx, const float* w, int n, int pos_dim, int val_dim,
+                       float* grad_values, void* stream);
+
+/* slice_classify_with_precomputation (LatticeGPU.cuh:3387-3464): logits[n, C] (fully written). */
+int ln_slice_classify_forward(const float* values, const float* delta_w, const float* lin_w, const float* lin_b,
+                              const int* idx, const float* w, int n, int pos_dim, int val_dim, int nr_classes,
+                              float* logits, void* stream);
+/* slice_classify_backwards_with_precomputation (LatticeGPU.cuh:3628-3756); the four gradient
+ * buffers are caller-allocated and zeroed (lattice_funcs.py:554-557). */
+int ln_slice_classify_backward(const float* grad_logits, const float* values, const float* delta_w, const float* lin_w,
+                               const int* idx, const float* w, int n, int pos_dim, int val_dim, int nr_classes,
+                               float* g_values, float* g_delta_w, float* g_lin_w, float* g_lin_b, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LATTICENET_HIP_H */

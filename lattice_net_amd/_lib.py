@@ -1,0 +1,111 @@
+"""ctypes binding of the C ABI declared in include/latticenet_hip.h.
+
+The library is the product: if it is missing this module raises — there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (loads torch's libamdhip64 first so both share ONE HIP runtime by SONAME)
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "liblatticenet_hip.so")
+
+LN_STATUS_TABLE_FULL = 1
+LN_STATUS_KEY_RANGE = 2
+LN_NOT_VISITED = -2
+LN_MAX_POS_DIM = 6
+
+
+class LnTable(C.Structure):
+    """Mirror of `struct LnTable` (include/latticenet_hip.h)."""
+
+    _fields_ = [
+        ("capacity", C.c_int),
+        ("pos_dim", C.c_int),
+        ("slot_keys", C.c_void_p),
+        ("slot_tok", C.c_void_p),
+        ("entries", C.c_void_p),
+        ("keys", C.c_void_p),
+        ("nr_filled", C.c_void_p),
+        ("status", C.c_void_p),
+    ]
+
+
+class LatticeNetHipError(RuntimeError):
+    pass
+
+
+_vp, _i, _ll, _sz = C.c_void_p, C.c_int, C.c_longlong, C.c_size_t
+_T = C.POINTER(LnTable)
+
+# name -> (restype, argtypes).  Every symbol the header declares is listed here; tests check the
+# library exports each of them.
+SIGNATURES = {
+    "ln_last_error_string": (C.c_char_p, []),
+    "ln_version": (C.c_char_p, []),
+    "ln_table_clear": (_i, [_T, _vp, _ll, _vp]),
+    "ln_build_workspace_bytes": (_sz, [_ll]),
+    "ln_build_splat": (_i, [_T, _vp, _vp, _i, _vp, _vp, _i, _vp, _sz, _vp]),
+    "ln_splat_accumulate": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "ln_distribute": (_i, [_T, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ln_coarsen": (_i, [_T, _i, _T, _vp, _sz, _vp]),
+    "ln_neighbours": (_i, [_T, _i, _T, _i, _i, _i, _i, _vp, _vp]),
+    "ln_im2row": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "ln_im2rowindices": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "ln_row2im": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "ln_conv_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "ln_conv_grad_filter_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "ln_conv_grad_filter": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "ln_slice_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "ln_slice_no_precomputation": (_i, [_T, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "ln_slice_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "ln_gather_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "ln_gather_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "ln_slice_classify_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "ln_slice_classify_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Loads liblatticenet_hip.so; raises loudly if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LatticeNetHipError(
+            f"{LIB_PATH} is missing: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `python lattice_net_amd/build_ext.py`). There is no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().ln_last_error_string().decode("utf-8", "replace")
+        raise LatticeNetHipError(f"{what or 'latticenet_hip'} failed (code {rc}): {msg}")
+
+
+def ptr(t) -> C.c_void_p:
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return C.c_void_p(0)
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def host_floats(values):
+    arr = (C.c_float * len(values))(*[float(v) for v in values])
+    return arr

@@ -1,0 +1,94 @@
+// Shared device/host helpers for the gfx950 lattice backend.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "latticenet_hip.h"
+
+#define LN_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
+#define LN_EMPTY_TOK 0xFFFFFFFFu
+#define LN_MAX_RETRIEVE_CONFLICTS 300  // HashTableGPU.cuh:494
+
+#if defined(__HIPCC__)
+#define LN_HD __host__ __device__ __forceinline__
+#else
+#define LN_HD inline
+#endif
+
+// ---- error plumbing (host) -------------------------------------------------------------
+void ln_set_error(const char* fmt, ...);
+int ln_check_launch(const char* what);
+
+#define LN_REQUIRE(cond, code, ...)  \
+    do {                             \
+        if (!(cond)) {               \
+            ln_set_error(__VA_ARGS__); \
+            return (code);           \
+        }                            \
+    } while (0)
+
+// ---- key packing -----------------------------------------------------------------------
+// A lattice key (first d coordinates, int32) is packed into one 64-bit word so that a slot can
+// be claimed and its key published by a single 64-bit CAS.  bits per coordinate = min(32, 63/d);
+// d*bits <= 63 for d >= 2 keeps bit 63 clear, so a packed key can never equal LN_EMPTY_KEY.
+template <int D>
+struct KeyPack {
+    static constexpr int BITS = (63 / D) > 32 ? 32 : (63 / D);
+    static constexpr int64_t LO = -(int64_t(1) << (BITS - 1));
+    static constexpr int64_t HI = (int64_t(1) << (BITS - 1)) - 1;
+    static constexpr uint64_t MASK = (BITS == 64) ? ~0ull : ((uint64_t(1) << BITS) - 1);
+
+    static LN_HD bool in_range(const int* key) {
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < D; ++i) ok = ok && (int64_t(key[i]) >= LO) && (int64_t(key[i]) <= HI);
+        return ok;
+    }
+    static LN_HD uint64_t pack(const int* key) {
+        uint64_t p = 0;
+#pragma unroll
+        for (int i = 0; i < D; ++i) p |= (uint64_t(int64_t(key[i])) & MASK) << (i * BITS);
+        return p;
+    }
+    static LN_HD void unpack(uint64_t p, int* key) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            uint64_t f = (p >> (i * BITS)) & MASK;
+            int64_t s = int64_t(f << (64 - BITS)) >> (64 - BITS);  // sign extend
+            key[i] = int(s);
+        }
+    }
+};
+
+// HashTableGPU::hash (HashTableGPU.cuh:35-43): k += key[i]; k *= 2531011 with uint32 wrap.
+template <int D>
+LN_HD uint32_t ln_hash(const int* key) {
+    uint32_t k = 0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        k += uint32_t(key[i]);
+        k *= 2531011u;
+    }
+    return k;
+}
+
+#if defined(__HIPCC__)
+// HashTableGPU::retrieve (HashTableGPU.cuh:491-519) on packed slots: stop at an empty slot or
+// after 300 mismatching probes.
+template <int D>
+__device__ __forceinline__ int ln_retrieve(const LnTable& t, const int* key) {
+    if (!KeyPack<D>::in_range(key)) return -1;  // cannot have been inserted
+    const uint64_t pk = KeyPack<D>::pack(key);
+    int h = int(ln_hash<D>(key) % uint32_t(t.capacity));
+    for (int conflicts = 0; conflicts < LN_MAX_RETRIEVE_CONFLICTS; ++conflicts) {
+        const uint64_t cur = t.slot_keys[h];
+        if (cur == LN_EMPTY_KEY) return -1;
+        if (cur == pk) return t.entries[h];
+        ++h;
+        if (h >= t.capacity) h = 0;
+    }
+    return -1;
+}
+#endif
+
+static inline int ln_div_up(long long a, long long b) { return int((a + b - 1) / b); }

@@ -1,0 +1,295 @@
+// Lattice convolution as a gather-GEMM on the fp32 matrix cores (v_mfma_f32_16x16x4_f32), and
+// the filter gradient as the transposed gather-GEMM.  Replaces im2row + Tensor::mm
+// (reference Lattice.cu:454-462, lattice_funcs.py:298-302) without ever materialising the
+// [M, E*V] rowified tensor in HBM.
+//
+// Forward:  out[m, :] = sum_e values[nbr[m,e], :] @ W[e*V:(e+1)*V, :]
+//   * a wave owns 16 lattice vertices (MFMA rows); 4 waves per workgroup.
+//   * A operand straight from HBM/L2 into registers: lane (i = lane&15, q = lane>>4) reads the
+//     q-th quarter of neighbour row nbr[m0+i, e] as contiguous floats (the K order inside a
+//     neighbour is permuted to k' = q*KQ + kk, which only reorders an exact-arithmetic sum).
+//   * B operand (the filter slice W_e) is staged once per workgroup into LDS in fragment order,
+//     so every ds_read is lane-linear and conflict-free.
+// fp32 in, fp32 accumulate: results are exact-fp32 fmaf chains (1e-5 parity bar).
+#include "ln_common.h"
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+template <int KQ>
+__device__ __forceinline__ void ln_load_quarter(const float* __restrict__ src, float* a) {
+    if constexpr (KQ % 4 == 0) {
+#pragma unroll
+        for (int k = 0; k < KQ; k += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(src + k);
+            a[k] = v.x;
+            a[k + 1] = v.y;
+            a[k + 2] = v.z;
+            a[k + 3] = v.w;
+        }
+    } else if constexpr (KQ % 2 == 0) {
+#pragma unroll
+        for (int k = 0; k < KQ; k += 2) {
+            const float2 v = *reinterpret_cast<const float2*>(src + k);
+            a[k] = v.x;
+            a[k + 1] = v.y;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < KQ; ++k) a[k] = src[k];
+    }
+}
+
+template <int V, int NT>
+__global__ void __launch_bounds__(256)
+    k_conv_mfma(const int* __restrict__ nbr, const float* __restrict__ values, const float* __restrict__ filter, int m, int E,
+                float* __restrict__ out) {
+    constexpr int F = 16 * NT;
+    constexpr int KQ = V / 4;
+    __shared__ __attribute__((aligned(16))) float s_b[V * F];  // W_e in fragment order [(kk*NT+nt)*64 + lane]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int i = lane & 15;
+    const int q = lane >> 4;
+    const int m0 = blockIdx.x * 64 + wave * 16;
+    const int my_row = m0 + i;
+
+    floatx4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    for (int e = 0; e < E; ++e) {
+        // issue the gather first so its latency overlaps the filter staging
+        float a[KQ];
+        const int nb = (my_row < m) ? nbr[(size_t)my_row * E + e] : -1;
+        if (nb >= 0) {
+            ln_load_quarter<KQ>(values + (size_t)nb * V + q * KQ, a);
+        } else {
+#pragma unroll
+            for (int k = 0; k < KQ; ++k) a[k] = 0.f;
+        }
+        __syncthreads();  // previous iteration's reads of s_b are done
+        const float* w_e = filter + (size_t)e * V * F;
+        for (int x = tid; x < V * F; x += 256) {
+            const int k = x / F;
+            const int f = x - k * F;
+            const int qq = k / KQ;
+            const int kk = k - qq * KQ;
+            s_b[((kk * NT) + (f >> 4)) * 64 + qq * 16 + (f & 15)] = w_e[x];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < KQ; ++kk) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float b = s_b[(kk * NT + nt) * 64 + lane];
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], b, acc[nt], 0, 0, 0);
+            }
+        }
+    }
+    // C/D layout: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + q * 4 + r;
+            if (row < m) out[(size_t)row * F + nt * 16 + i] = acc[nt][r];
+        }
+    }
+}
+
+// Any (V, F): one thread per output element.
+__global__ void __launch_bounds__(256)
+    k_conv_generic(const int* __restrict__ nbr, const float* __restrict__ values, const float* __restrict__ filter, long long work,
+                   int E, int V, int F, float* __restrict__ out) {
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= work) return;
+    const long long mrow = g / F;
+    const int f = int(g - mrow * F);
+    float acc = 0.0f;
+    for (int e = 0; e < E; ++e) {
+        const int nb = nbr[mrow * E + e];
+        if (nb < 0) continue;
+        const float* vr = values + (size_t)nb * V;
+        const float* wr = filter + (size_t)e * V * F + f;
+        for (int v = 0; v < V; ++v) acc = fmaf(vr[v], wr[(size_t)v * F], acc);
+    }
+    out[g] = acc;
+}
+
+template <int V>
+static bool ln_conv_launch_v(int nt, const int* nbr, const float* values, const float* filter, int m, int E, float* out,
+                             hipStream_t st) {
+    const dim3 grid(ln_div_up(m, 64)), block(256);
+    switch (nt) {
+        case 1: hipLaunchKernelGGL((k_conv_mfma<V, 1>), grid, block, 0, st, nbr, values, filter, m, E, out); return true;
+        case 2: hipLaunchKernelGGL((k_conv_mfma<V, 2>), grid, block, 0, st, nbr, values, filter, m, E, out); return true;
+        case 4: hipLaunchKernelGGL((k_conv_mfma<V, 4>), grid, block, 0, st, nbr, values, filter, m, E, out); return true;
+        case 8: if constexpr (V <= 64) { hipLaunchKernelGGL((k_conv_mfma<V, 8>), grid, block, 0, st, nbr, values, filter, m, E, out); return true; } return false;
+        default: return false;
+    }
+}
+
+extern "C" int ln_conv_forward(const int* nbr, const float* values_neigh, const float* filter, int m, int filter_extent,
+                               int val_dim, int nr_filters, float* out, void* stream) {
+    LN_REQUIRE(m >= 0 && filter_extent >= 3 && val_dim >= 1 && nr_filters >= 1, LN_ERR_ARG, "ln_conv_forward: bad sizes");
+    LN_REQUIRE(m == 0 || (nbr && values_neigh && filter && out), LN_ERR_ARG, "ln_conv_forward: null buffer");
+    if (m == 0) return LN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    bool done = false;
+    if (nr_filters % 16 == 0) {
+        const int nt = nr_filters / 16;
+        switch (val_dim) {
+            case 8: done = ln_conv_launch_v<8>(nt, nbr, values_neigh, filter, m, filter_extent, out, st); break;
+            case 16: done = ln_conv_launch_v<16>(nt, nbr, values_neigh, filter, m, filter_extent, out, st); break;
+            case 32: done = ln_conv_launch_v<32>(nt, nbr, values_neigh, filter, m, filter_extent, out, st); break;
+            case 64: done = ln_conv_launch_v<64>(nt, nbr, values_neigh, filter, m, filter_extent, out, st); break;
+            case 128: done = ln_conv_launch_v<128>(nt, nbr, values_neigh, filter, m, filter_extent, out, st); break;
+            default: break;
+        }
+    }
+    if (!done) {
+        const long long work = (long long)m * nr_filters;
+        hipLaunchKernelGGL(k_conv_generic, dim3(ln_div_up(work, 256)), dim3(256), 0, st, nbr, values_neigh, filter, work,
+                           filter_extent, val_dim, nr_filters, out);
+    }
+    return ln_check_launch("ln_conv_forward");
+}
+
+// ------------------------------------------------------------------------------------------
+// filter gradient: grad_filter[e*V+v, f] = sum_m values[nbr[m,e], v] * grad_out[m, f]
+// Stage 1: grid (row chunks, E); each wave reduces its rows with MFMA (D[v][f] += A[v][m] B[m][f]),
+//          the 4 waves are combined through LDS and the workgroup writes one partial [V,F] slab.
+// Stage 2: deterministic sum of the slabs.
+// ------------------------------------------------------------------------------------------
+#define LN_GF_ROWS 512  // rows per workgroup (128 per wave)
+
+template <int VT, int FT>
+__global__ void __launch_bounds__(256)
+    k_grad_filter_mfma(const int* __restrict__ nbr, const float* __restrict__ values, const float* __restrict__ grad_out, int m,
+                       int E, float* __restrict__ partial) {
+    constexpr int V = VT * 16;
+    constexpr int F = FT * 16;
+    __shared__ __attribute__((aligned(16))) float s_red[V * F];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int i = lane & 15;
+    const int q = lane >> 4;
+    const int e = blockIdx.y;
+    const int row_begin = blockIdx.x * LN_GF_ROWS + wave * (LN_GF_ROWS / 4);
+    const int row_end = min(row_begin + LN_GF_ROWS / 4, m);
+
+    floatx4 acc[VT][FT];
+#pragma unroll
+    for (int a = 0; a < VT; ++a)
+#pragma unroll
+        for (int b = 0; b < FT; ++b) acc[a][b] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    for (int mb = row_begin; mb < row_end; mb += 4) {
+        const int row = mb + q;
+        int nb = -1;
+        if (row < row_end) nb = nbr[(size_t)row * E + e];
+        float av[VT];
+        float bv[FT];
+#pragma unroll
+        for (int a = 0; a < VT; ++a) av[a] = (nb >= 0) ? values[(size_t)nb * V + a * 16 + i] : 0.f;
+#pragma unroll
+        for (int b = 0; b < FT; ++b) bv[b] = (nb >= 0) ? grad_out[(size_t)row * F + b * 16 + i] : 0.f;
+#pragma unroll
+        for (int a = 0; a < VT; ++a)
+#pragma unroll
+            for (int b = 0; b < FT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+    }
+    // combine the 4 waves in LDS (wave 0 stores, the others add in turn)
+    for (int wv = 0; wv < 4; ++wv) {
+        if (wave == wv) {
+#pragma unroll
+            for (int a = 0; a < VT; ++a)
+#pragma unroll
+                for (int b = 0; b < FT; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int v = a * 16 + q * 4 + r;
+                        const int f = b * 16 + i;
+                        if (wv == 0)
+                            s_red[v * F + f] = acc[a][b][r];
+                        else
+                            s_red[v * F + f] += acc[a][b][r];
+                    }
+        }
+        __syncthreads();
+    }
+    float* dst = partial + ((size_t)blockIdx.x * E + e) * (V * F);
+    for (int x = tid; x < V * F; x += 256) dst[x] = s_red[x];
+}
+
+// generic fallback: thread per (e*V+v, f), loops all rows (slow; small or odd shapes only)
+__global__ void __launch_bounds__(256)
+    k_grad_filter_generic(const int* __restrict__ nbr, const float* __restrict__ values, const float* __restrict__ grad_out, int m,
+                          int E, int V, int F, float* __restrict__ grad_filter) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= E * V * F) return;
+    const int f = g % F;
+    const int ev = g / F;
+    const int v = ev % V;
+    const int e = ev / V;
+    float acc = 0.0f;
+    for (int row = 0; row < m; ++row) {
+        const int nb = nbr[(size_t)row * E + e];
+        if (nb >= 0) acc = fmaf(values[(size_t)nb * V + v], grad_out[(size_t)row * F + f], acc);
+    }
+    grad_filter[g] = acc;
+}
+
+__global__ void __launch_bounds__(256) k_reduce_slabs(const float* __restrict__ partial, int nslabs, int total, float* __restrict__ out) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    float acc = 0.0f;
+    for (int s = 0; s < nslabs; ++s) acc += partial[(size_t)s * total + g];
+    out[g] = acc;
+}
+
+static bool ln_gf_mfma_supported(int val_dim, int nr_filters) {
+    const bool v_ok = (val_dim == 16 || val_dim == 32 || val_dim == 64);
+    const bool f_ok = (nr_filters == 16 || nr_filters == 32 || nr_filters == 64);
+    return v_ok && f_ok && (val_dim / 16) * (nr_filters / 16) <= 16;
+}
+
+extern "C" size_t ln_conv_grad_filter_workspace_bytes(int m, int filter_extent, int val_dim, int nr_filters) {
+    if (!ln_gf_mfma_supported(val_dim, nr_filters) || m <= 0) return 256;
+    return (size_t)ln_div_up(m, LN_GF_ROWS) * filter_extent * val_dim * nr_filters * sizeof(float) + 256;
+}
+
+extern "C" int ln_conv_grad_filter(const int* nbr, const float* values_neigh, const float* grad_out, int m, int filter_extent,
+                                   int val_dim, int nr_filters, float* grad_filter, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
+    LN_REQUIRE(m >= 0 && filter_extent >= 3 && val_dim >= 1 && nr_filters >= 1, LN_ERR_ARG, "ln_conv_grad_filter: bad sizes");
+    LN_REQUIRE(grad_filter && (m == 0 || (nbr && values_neigh && grad_out)), LN_ERR_ARG, "ln_conv_grad_filter: null buffer");
+    hipStream_t st = (hipStream_t)stream;
+    const int total = filter_extent * val_dim * nr_filters;
+    if (m == 0) {
+        (void)hipMemsetAsync(grad_filter, 0, (size_t)total * sizeof(float), st);
+        return ln_check_launch("ln_conv_grad_filter");
+    }
+    if (ln_gf_mfma_supported(val_dim, nr_filters)) {
+        LN_REQUIRE(workspace && workspace_bytes >= ln_conv_grad_filter_workspace_bytes(m, filter_extent, val_dim, nr_filters),
+                   LN_ERR_WORKSPACE, "ln_conv_grad_filter: workspace too small");
+        float* partial = static_cast<float*>(workspace);
+        const int chunks = ln_div_up(m, LN_GF_ROWS);
+        const dim3 grid(chunks, filter_extent), block(256);
+        const int vt = val_dim / 16, ft = nr_filters / 16;
+#define LN_GF_CASE(A, B)                                                                                                    \
+    if (vt == A && ft == B)                                                                                                 \
+        hipLaunchKernelGGL((k_grad_filter_mfma<A, B>), grid, block, 0, st, nbr, values_neigh, grad_out, m, filter_extent, partial);
+        LN_GF_CASE(1, 1) LN_GF_CASE(1, 2) LN_GF_CASE(1, 4) LN_GF_CASE(2, 1) LN_GF_CASE(2, 2) LN_GF_CASE(2, 4) LN_GF_CASE(4, 1)
+        LN_GF_CASE(4, 2) LN_GF_CASE(4, 4)
+#undef LN_GF_CASE
+        // slabs are laid out [chunk][e][V*F]; summing over chunks with stride E*V*F
+        hipLaunchKernelGGL(k_reduce_slabs, dim3(ln_div_up(total, 256)), dim3(256), 0, st, partial, chunks, total, grad_filter);
+    } else {
+        hipLaunchKernelGGL(k_grad_filter_generic, dim3(ln_div_up(total, 256)), dim3(256), 0, st, nbr, values_neigh, grad_out, m,
+                           filter_extent, val_dim, nr_filters, grad_filter);
+    }
+    return ln_check_launch("ln_conv_grad_filter");
+}

@@ -1,0 +1,420 @@
+// Row gather / scatter kernels: splat accumulate, slice, gather, im2row family, fused
+// slice+classify.  All of them move rows of V floats between point space [N, ·] and vertex space
+// [M, V]; lanes are mapped along the channel dimension (float4 chunks when V % 4 == 0) so that a
+// row is read or written as one contiguous segment — the reference maps one thread per point and
+// loops channels, which strides every access by the row length (LatticeGPU.cuh:937-971 etc.).
+//
+// Compiled with -ffp-contract=off: products and sums are rounded separately so the
+// order-deterministic kernels are bit-identical to the CPU oracle.
+#include "ln_common.h"
+
+template <int VEC>
+struct VecT;
+template <>
+struct VecT<1> {
+    using type = float;
+};
+template <>
+struct VecT<4> {
+    using type = float4;
+};
+
+__device__ __forceinline__ float ln_zero(float) { return 0.0f; }
+__device__ __forceinline__ float4 ln_zero(float4) { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float ln_mul(float a, float s) { return a * s; }
+__device__ __forceinline__ float4 ln_mul(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
+__device__ __forceinline__ float ln_add(float a, float b) { return a + b; }
+__device__ __forceinline__ float4 ln_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ void ln_atomic_add(float* dst, float v) {
+    __hip_atomic_fetch_add(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void ln_atomic_add(float* dst, float4 v) {
+    ln_atomic_add(dst + 0, v.x);
+    ln_atomic_add(dst + 1, v.y);
+    ln_atomic_add(dst + 2, v.z);
+    ln_atomic_add(dst + 3, v.w);
+}
+
+#define LN_DISPATCH_VEC(val_dim, ...)                  \
+    if (((val_dim) & 3) == 0) {                        \
+        constexpr int VEC = 4;                         \
+        __VA_ARGS__;                                   \
+    } else {                                           \
+        constexpr int VEC = 1;                         \
+        __VA_ARGS__;                                   \
+    }
+
+static int ln_check_rows(const char* who, const void* a, const void* b, const void* c, int n, int pos_dim, int val_dim) {
+    LN_REQUIRE(n >= 0 && pos_dim >= 1 && pos_dim <= LN_MAX_POS_DIM && val_dim >= 1, LN_ERR_ARG, "%s: bad sizes n=%d d=%d V=%d",
+               who, n, pos_dim, val_dim);
+    LN_REQUIRE(n == 0 || (a && b && c), LN_ERR_ARG, "%s: null buffer", who);
+    return LN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// scatter-add of per-point rows onto vertex rows: splat accumulate and slice backward
+// dst[idx[p,r], :] += src[p, :] * w[p,r]           (LatticeGPU.cuh:937-971 and 3574-3613)
+// ------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ void __launch_bounds__(256)
+    k_scatter_point_rows(float* __restrict__ dst, const float* __restrict__ src, const int* __restrict__ idx,
+                         const float* __restrict__ w, long long work, int dp1, int chunks) {
+    using T = typename VecT<VEC>::type;
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= work) return;
+    const long long p = g / chunks;
+    const int c = int(g - p * chunks);
+    const T x = reinterpret_cast<const T*>(src)[g];
+    const int V = chunks * VEC;
+    for (int r = 0; r < dp1; ++r) {
+        const int row = idx[p * dp1 + r];
+        if (row >= 0) ln_atomic_add(dst + (size_t)row * V + c * VEC, ln_mul(x, w[p * dp1 + r]));
+    }
+}
+
+static int ln_scatter_point_rows(const char* who, float* dst, const float* src, const int* idx, const float* w, int n,
+                                 int pos_dim, int val_dim, void* stream) {
+    int rc = ln_check_rows(who, dst, src, idx, n, pos_dim, val_dim);
+    if (rc) return rc;
+    LN_REQUIRE(n == 0 || w, LN_ERR_ARG, "%s: null weights", who);
+    if (n == 0) return LN_OK;
+    LN_DISPATCH_VEC(val_dim, {
+        const int chunks = val_dim / VEC;
+        const long long work = (long long)n * chunks;
+        hipLaunchKernelGGL(k_scatter_point_rows<VEC>, dim3(ln_div_up(work, 256)), dim3(256), 0, (hipStream_t)stream, dst, src, idx,
+                           w, work, pos_dim + 1, chunks);
+    });
+    return ln_check_launch(who);
+}
+
+extern "C" int ln_splat_accumulate(float* table_values, const float* vals, const int* idx, const float* w, int n, int pos_dim,
+                                   int val_dim, void* stream) {
+    return ln_scatter_point_rows("ln_splat_accumulate", table_values, vals, idx, w, n, pos_dim, val_dim, stream);
+}
+
+extern "C" int ln_slice_backward(const float* grad_sliced, const int* idx, const float* w, int n, int pos_dim, int val_dim,
+                                 float* grad_values, void* stream) {
+    return ln_scatter_point_rows("ln_slice_backward", grad_values, grad_sliced, idx, w, n, pos_dim, val_dim, stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// slice forward (LatticeGPU.cuh:2567-2591): out[p,:] = sum_r values[idx_r,:] * w_r, r ascending
+// ------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ void __launch_bounds__(256)
+    k_slice_forward(const float* __restrict__ values, const int* __restrict__ idx, const float* __restrict__ w, long long work,
+                    int dp1, int chunks, float* __restrict__ out) {
+    using T = typename VecT<VEC>::type;
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= work) return;
+    const long long p = g / chunks;
+    const int c = int(g - p * chunks);
+    T acc = ln_zero(T());
+    for (int r = 0; r < dp1; ++r) {
+        const int row = idx[p * dp1 + r];
+        if (row >= 0) {
+            const T v = reinterpret_cast<const T*>(values)[(size_t)row * chunks + c];
+            acc = ln_add(acc, ln_mul(v, w[p * dp1 + r]));
+        }
+    }
+    reinterpret_cast<T*>(out)[g] = acc;
+}
+
+extern "C" int ln_slice_forward(const float* values, const int* idx, const float* w, int n, int pos_dim, int val_dim, float* out,
+                                void* stream) {
+    int rc = ln_check_rows("ln_slice_forward", values, idx, out, n, pos_dim, val_dim);
+    if (rc) return rc;
+    LN_REQUIRE(n == 0 || w, LN_ERR_ARG, "ln_slice_forward: null weights");
+    if (n == 0) return LN_OK;
+    LN_DISPATCH_VEC(val_dim, {
+        const int chunks = val_dim / VEC;
+        const long long work = (long long)n * chunks;
+        hipLaunchKernelGGL(k_slice_forward<VEC>, dim3(ln_div_up(work, 256)), dim3(256), 0, (hipStream_t)stream, values, idx, w, work,
+                           pos_dim + 1, chunks, out);
+    });
+    return ln_check_launch("ln_slice_forward");
+}
+
+int ln_retrieve_points(const LnTable* t, const float* positions_raw, const float* sigmas_host, int n, int* idx, float* w,
+                       void* stream);
+
+extern "C" int ln_slice_no_precomputation(const LnTable* t, const float* values, const float* positions_raw,
+                                          const float* sigmas_host, int n, int val_dim, float* out, int* idx, float* w,
+                                          void* stream) {
+    LN_REQUIRE(t && (n == 0 || (values && positions_raw && out && idx && w)), LN_ERR_ARG,
+               "ln_slice_no_precomputation: null buffer");
+    int rc = ln_retrieve_points(t, positions_raw, sigmas_host, n, idx, w, stream);
+    if (rc) return rc;
+    // found vertices carry w = barycentric[remainder]; absent ones are skipped (LatticeGPU.cuh:2739-2745)
+    return ln_slice_forward(values, idx, w, n, t->pos_dim, val_dim, out, stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// gather (LatticeGPU.cuh:2901-2925) and its backward (LatticeGPU.cuh:3778-3814)
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+    k_gather_forward(const float* __restrict__ values, const int* __restrict__ idx, const float* __restrict__ w, long long work,
+                     int V, float* __restrict__ out) {
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= work) return;
+    const long long pr = g / (V + 1);  // p*(d+1)+r
+    const int j = int(g - pr * (V + 1));
+    const int row = idx[pr];
+    float o = 0.0f;  // absent vertices stay 0 (Lattice.cu:899)
+    if (row >= 0) {
+        const float wt = w[pr];
+        o = (j < V) ? values[(size_t)row * V + j] * wt : wt;
+    }
+    out[g] = o;
+}
+
+extern "C" int ln_gather_forward(const float* values, const int* idx, const float* w, int n, int pos_dim, int val_dim, float* out,
+                                 void* stream) {
+    int rc = ln_check_rows("ln_gather_forward", values, idx, out, n, pos_dim, val_dim);
+    if (rc) return rc;
+    if (n == 0) return LN_OK;
+    const long long work = (long long)n * (pos_dim + 1) * (val_dim + 1);
+    hipLaunchKernelGGL(k_gather_forward, dim3(ln_div_up(work, 256)), dim3(256), 0, (hipStream_t)stream, values, idx, w, work, val_dim,
+                       out);
+    return ln_check_launch("ln_gather_forward");
+}
+
+__global__ void __launch_bounds__(256)
+    k_gather_backward(const float* __restrict__ grad, const int* __restrict__ idx, const float* __restrict__ w, long long work,
+                      int V, float* __restrict__ grad_values) {
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= work) return;
+    const long long pr = g / (V + 1);
+    const int j = int(g - pr * (V + 1));
+    if (j >= V) return;  // the weight column's gradient is dropped
+    const int row = idx[pr];
+    if (row >= 0) ln_atomic_add(grad_values + (size_t)row * V + j, grad[g] * w[pr]);
+}
+
+extern "C" int ln_gather_backward(const float* grad_gathered, const int* idx, const float* w, int n, int pos_dim, int val_dim,
+                                  float* grad_values, void* stream) {
+    int rc = ln_check_rows("ln_gather_backward", grad_gathered, idx, grad_values, n, pos_dim, val_dim);
+    if (rc) return rc;
+    if (n == 0) return LN_OK;
+    const long long work = (long long)n * (pos_dim + 1) * (val_dim + 1);
+    hipLaunchKernelGGL(k_gather_backward, dim3(ln_div_up(work, 256)), dim3(256), 0, (hipStream_t)stream, grad_gathered, idx, w, work,
+                       val_dim, grad_values);
+    return ln_check_launch("ln_gather_backward");
+}
+
+// ------------------------------------------------------------------------------------------
+// im2row family from a neighbour list
+// ------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ void __launch_bounds__(256)
+    k_im2row(const int* __restrict__ nbr, const float* __restrict__ values, long long work, int chunks, float* __restrict__ out) {
+    using T = typename VecT<VEC>::type;
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= work) return;
+    const long long me = g / chunks;  // m*E+e
+    const int c = int(g - me * chunks);
+    const int row = nbr[me];
+    T v = ln_zero(T());
+    if (row >= 0) v = reinterpret_cast<const T*>(values)[(size_t)row * chunks + c];
+    reinterpret_cast<T*>(out)[g] = v;
+}
+
+extern "C" int ln_im2row(const int* nbr, const float* values_neigh, int m, int filter_extent, int val_dim, float* out,
+                         void* stream) {
+    LN_REQUIRE(m >= 0 && filter_extent >= 3 && val_dim >= 1, LN_ERR_ARG, "ln_im2row: bad sizes");
+    LN_REQUIRE(m == 0 || (nbr && values_neigh && out), LN_ERR_ARG, "ln_im2row: null buffer");
+    if (m == 0) return LN_OK;
+    LN_DISPATCH_VEC(val_dim, {
+        const int chunks = val_dim / VEC;
+        const long long work = (long long)m * filter_extent * chunks;
+        hipLaunchKernelGGL(k_im2row<VEC>, dim3(ln_div_up(work, 256)), dim3(256), 0, (hipStream_t)stream, nbr, values_neigh, work,
+                           chunks, out);
+    });
+    return ln_check_launch("ln_im2row");
+}
+
+__global__ void __launch_bounds__(256) k_im2rowindices(const int* __restrict__ nbr, long long work, int E, int V, int* __restrict__ out) {
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= work) return;
+    const long long me = g / V;
+    const int e = int(me % E);
+    int code = nbr[me];
+    // neighbour slots hold -1 when visited-but-absent; the centre is only written when found;
+    // never-visited slots keep the tensor's initial 0 (LatticeGPU.cuh:1844-1915, Lattice.cu:600)
+    if (code == LN_NOT_VISITED) code = 0;
+    if (e == E - 1 && code < 0) code = 0;
+    out[g] = code;
+}
+
+extern "C" int ln_im2rowindices(const int* nbr, int m, int filter_extent, int val_dim, int* out, void* stream) {
+    LN_REQUIRE(m >= 0 && filter_extent >= 3 && val_dim >= 1, LN_ERR_ARG, "ln_im2rowindices: bad sizes");
+    LN_REQUIRE(m == 0 || (nbr && out), LN_ERR_ARG, "ln_im2rowindices: null buffer");
+    if (m == 0) return LN_OK;
+    const long long work = (long long)m * filter_extent * val_dim;
+    hipLaunchKernelGGL(k_im2rowindices, dim3(ln_div_up(work, 256)), dim3(256), 0, (hipStream_t)stream, nbr, work, filter_extent,
+                       val_dim, out);
+    return ln_check_launch("ln_im2rowindices");
+}
+
+// row2im (LatticeGPU.cuh:2187-2284): out[m] = sum_a rows[np_a][slot 2a+1] + rows[nm_a][slot 2a], then the centre.
+template <int VEC>
+__global__ void __launch_bounds__(256)
+    k_row2im(const int* __restrict__ nbr, const float* __restrict__ rowified, long long work, int E, int chunks,
+             float* __restrict__ out) {
+    using T = typename VecT<VEC>::type;
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= work) return;
+    const long long m = g / chunks;
+    const int c = int(g - m * chunks);
+    const int axes = (E - 1) / 2;
+    const T* rows = reinterpret_cast<const T*>(rowified);
+    T acc = ln_zero(T());
+    for (int a = 0; a < axes; ++a) {
+        int r = nbr[m * E + 2 * a];
+        if (r >= 0) acc = ln_add(acc, rows[((size_t)r * E + 2 * a + 1) * chunks + c]);
+        r = nbr[m * E + 2 * a + 1];
+        if (r >= 0) acc = ln_add(acc, rows[((size_t)r * E + 2 * a) * chunks + c]);
+    }
+    const int r = nbr[m * E + E - 1];
+    if (r >= 0) acc = ln_add(acc, rows[((size_t)r * E + E - 1) * chunks + c]);
+    reinterpret_cast<T*>(out)[g] = acc;
+}
+
+extern "C" int ln_row2im(const int* nbr, const float* rowified, int m, int filter_extent, int val_dim, float* out, void* stream) {
+    LN_REQUIRE(m >= 0 && filter_extent >= 3 && (filter_extent & 1) && val_dim >= 1, LN_ERR_ARG, "ln_row2im: bad sizes");
+    LN_REQUIRE(m == 0 || (nbr && rowified && out), LN_ERR_ARG, "ln_row2im: null buffer");
+    if (m == 0) return LN_OK;
+    LN_DISPATCH_VEC(val_dim, {
+        const int chunks = val_dim / VEC;
+        const long long work = (long long)m * chunks;
+        hipLaunchKernelGGL(k_row2im<VEC>, dim3(ln_div_up(work, 256)), dim3(256), 0, (hipStream_t)stream, nbr, rowified, work,
+                           filter_extent, chunks, out);
+    });
+    return ln_check_launch("ln_row2im");
+}
+
+// ------------------------------------------------------------------------------------------
+// fused slice + linear classifier (LatticeGPU.cuh:3405-3460): one thread per (point, class)
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+    k_slice_classify_forward(const float* __restrict__ values, const float* __restrict__ delta_w, const float* __restrict__ lin_w,
+                             const float* __restrict__ lin_b, const int* __restrict__ idx, const float* __restrict__ w,
+                             long long work, int dp1, int V, int C, float* __restrict__ logits) {
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= work) return;
+    const long long p = g / C;
+    const int c = int(g - p * C);
+    int rows[LN_MAX_POS_DIM + 1];
+    float wts[LN_MAX_POS_DIM + 1];
+    for (int r = 0; r < dp1; ++r) {
+        rows[r] = idx[p * dp1 + r];
+        wts[r] = w[p * dp1 + r] + delta_w[p * dp1 + r];
+    }
+    float acc = 0.0f;
+    for (int v = 0; v < V; ++v) {
+        float h = 0.0f;
+        for (int r = 0; r < dp1; ++r)
+            if (rows[r] >= 0) h = h + values[(size_t)rows[r] * V + v] * wts[r];
+        acc = acc + lin_w[(size_t)c * V + v] * h;
+    }
+    logits[g] = acc + lin_b[c];
+}
+
+extern "C" int ln_slice_classify_forward(const float* values, const float* delta_w, const float* lin_w, const float* lin_b,
+                                         const int* idx, const float* w, int n, int pos_dim, int val_dim, int nr_classes,
+                                         float* logits, void* stream) {
+    int rc = ln_check_rows("ln_slice_classify_forward", values, idx, logits, n, pos_dim, val_dim);
+    if (rc) return rc;
+    LN_REQUIRE(nr_classes >= 1 && (n == 0 || (delta_w && lin_w && lin_b && w)), LN_ERR_ARG, "ln_slice_classify_forward: bad args");
+    if (n == 0) return LN_OK;
+    const long long work = (long long)n * nr_classes;
+    hipLaunchKernelGGL(k_slice_classify_forward, dim3(ln_div_up(work, 256)), dim3(256), 0, (hipStream_t)stream, values, delta_w, lin_w,
+                       lin_b, idx, w, work, pos_dim + 1, val_dim, nr_classes, logits);
+    return ln_check_launch("ln_slice_classify_forward");
+}
+
+// Backward (LatticeGPU.cuh:3648-3751).  One workgroup owns PB points: it stages the sliced
+// features h[PB,V], the incoming gradient g[PB,C] and the classifier W[C,V] in LDS, reduces the
+// classifier gradients over its points in LDS and issues ONE atomic per (c,v) per workgroup
+// (the reference issues N*C*V global atomics onto C*V addresses).
+#define LN_SC_PB 64
+__global__ void __launch_bounds__(256)
+    k_slice_classify_backward(const float* __restrict__ grad_logits, const float* __restrict__ values,
+                              const float* __restrict__ delta_w, const float* __restrict__ lin_w, const int* __restrict__ idx,
+                              const float* __restrict__ w, int n, int dp1, int V, int C, float* __restrict__ g_values,
+                              float* __restrict__ g_delta_w, float* __restrict__ g_lin_w, float* __restrict__ g_lin_b) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_h = smem;                  // [PB, V]
+    float* s_g = s_h + LN_SC_PB * V;    // [PB, C]
+    float* s_w = s_g + LN_SC_PB * C;    // [C, V]
+    const int p0 = blockIdx.x * LN_SC_PB;
+    const int np = min(LN_SC_PB, n - p0);
+    const int tid = threadIdx.x;
+    for (int i = tid; i < C * V; i += 256) s_w[i] = lin_w[i];
+    for (int i = tid; i < np * C; i += 256) s_g[i] = grad_logits[(size_t)p0 * C + i];
+    for (int i = tid; i < np * V; i += 256) {
+        const int lp = i / V, v = i - lp * V;
+        const long long p = p0 + lp;
+        float h = 0.0f;
+        for (int r = 0; r < dp1; ++r) {
+            const int row = idx[p * dp1 + r];
+            if (row >= 0) h = h + values[(size_t)row * V + v] * (w[p * dp1 + r] + delta_w[p * dp1 + r]);
+        }
+        s_h[i] = h;
+    }
+    __syncthreads();
+    // lattice values: g_values[idx_r, v] += (sum_c g[p,c] W[c,v]) (w_r + dw_r)
+    for (int i = tid; i < np * V; i += 256) {
+        const int lp = i / V, v = i - lp * V;
+        const long long p = p0 + lp;
+        float gw = 0.0f;
+        for (int c = 0; c < C; ++c) gw = gw + s_g[lp * C + c] * s_w[c * V + v];
+        for (int r = 0; r < dp1; ++r) {
+            const int row = idx[p * dp1 + r];
+            if (row >= 0) ln_atomic_add(g_values + (size_t)row * V + v, gw * (w[p * dp1 + r] + delta_w[p * dp1 + r]));
+        }
+    }
+    // classifier weight and bias
+    for (int i = tid; i < C * V; i += 256) {
+        const int c = i / V, v = i - c * V;
+        float acc = 0.0f;
+        for (int lp = 0; lp < np; ++lp) acc = acc + s_h[lp * V + v] * s_g[lp * C + c];
+        ln_atomic_add(g_lin_w + i, acc);
+    }
+    for (int c = tid; c < C; c += 256) {
+        float acc = 0.0f;
+        for (int lp = 0; lp < np; ++lp) acc = acc + s_g[lp * C + c];
+        ln_atomic_add(g_lin_b + c, acc);
+    }
+    // delta weights: g_dw[p,r] = sum_c g[p,c] (W[c,:] . values[idx_r,:]); exactly one writer each
+    for (int i = tid; i < np * dp1; i += 256) {
+        const int lp = i / dp1, r = i - lp * dp1;
+        const long long p = p0 + lp;
+        const int row = idx[p * dp1 + r];
+        float grad = 0.0f;
+        if (row >= 0) {
+            for (int c = 0; c < C; ++c) {
+                float dot = 0.0f;
+                for (int v = 0; v < V; ++v) dot = dot + values[(size_t)row * V + v] * s_w[c * V + v];
+                grad = grad + dot * s_g[lp * C + c];
+            }
+        }
+        g_delta_w[p * dp1 + r] += grad;
+    }
+}
+
+extern "C" int ln_slice_classify_backward(const float* grad_logits, const float* values, const float* delta_w, const float* lin_w,
+                                          const int* idx, const float* w, int n, int pos_dim, int val_dim, int nr_classes,
+                                          float* g_values, float* g_delta_w, float* g_lin_w, float* g_lin_b, void* stream) {
+    int rc = ln_check_rows("ln_slice_classify_backward", grad_logits, values, idx, n, pos_dim, val_dim);
+    if (rc) return rc;
+    LN_REQUIRE(nr_classes >= 1 && (n == 0 || (delta_w && lin_w && w && g_values && g_delta_w && g_lin_w && g_lin_b)), LN_ERR_ARG,
+               "ln_slice_classify_backward: bad args");
+    if (n == 0) return LN_OK;
+    const size_t lds = sizeof(float) * ((size_t)LN_SC_PB * (val_dim + nr_classes) + (size_t)nr_classes * val_dim);
+    LN_REQUIRE(lds <= 64 * 1024, LN_ERR_UNSUPPORTED, "ln_slice_classify_backward: V=%d C=%d need %zu B of LDS (max 65536)", val_dim,
+               nr_classes, lds);
+    hipLaunchKernelGGL(k_slice_classify_backward, dim3(ln_div_up(n, LN_SC_PB)), dim3(256), lds, (hipStream_t)stream, grad_logits,
+                       values, delta_w, lin_w, idx, w, n, pos_dim + 1, val_dim, nr_classes, g_values, g_delta_w, g_lin_w, g_lin_b);
+    return ln_check_launch("ln_slice_classify_backward");
+}

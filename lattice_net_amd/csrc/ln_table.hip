@@ -1,0 +1,562 @@
+// Hash-table build (canonical vertex numbering), key-based coarsening, neighbour traversal and
+// simplex retrieval for gfx950.  See include/latticenet_hip.h for the reference interfaces these
+// replace.
+//
+// Build design (differs from the reference's CAS spin lock, HashTableGPU.cuh:425-484):
+//   1. insert   : one 64-bit CAS claims a slot AND publishes its packed key; every insertion
+//                 carries a token (its position in the serial insertion order) and the slot
+//                 remembers the smallest token that touched it (atomicMin).
+//   2. mark     : token t is a "first occurrence" iff it is the smallest token of a NEW slot;
+//                 one __ballot per wave writes 64 flags as a single 8-byte word (no atomics).
+//   3. scan     : exclusive prefix over per-block first-occurrence counts (one workgroup).
+//   4. finalize : row id = nr_filled_before + rank of the slot's smallest token; the first
+//                 occurrence writes entries[slot] and keys[row]; every token gets its row.
+// Rows therefore come out numbered by first occurrence in token order — bit-identical to a
+// serial run of the reference — without any lock, spin or fence.
+#include "ln_common.h"
+#include "ln_simplex.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+// ------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------
+static thread_local char g_ln_error[512] = "";
+
+void ln_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_ln_error, sizeof(g_ln_error), fmt, ap);
+    va_end(ap);
+}
+
+int ln_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        ln_set_error("%s: %s", what, hipGetErrorString(e));
+        return LN_ERR_LAUNCH;
+    }
+    return LN_OK;
+}
+
+extern "C" const char* ln_last_error_string(void) { return g_ln_error; }
+extern "C" const char* ln_version(void) { return "latticenet_hip 0.1 (gfx950)"; }
+
+#define LN_DISPATCH_D(d, ...)                                                    \
+    switch (d) {                                                                 \
+        case 1: { constexpr int D = 1; __VA_ARGS__; } break;                     \
+        case 2: { constexpr int D = 2; __VA_ARGS__; } break;                     \
+        case 3: { constexpr int D = 3; __VA_ARGS__; } break;                     \
+        case 4: { constexpr int D = 4; __VA_ARGS__; } break;                     \
+        case 5: { constexpr int D = 5; __VA_ARGS__; } break;                     \
+        case 6: { constexpr int D = 6; __VA_ARGS__; } break;                     \
+        default:                                                                 \
+            ln_set_error("pos_dim %d unsupported (1..%d)", d, LN_MAX_POS_DIM);   \
+            return LN_ERR_UNSUPPORTED;                                           \
+    }
+
+static int ln_check_table(const LnTable* t, const char* who) {
+    LN_REQUIRE(t != nullptr, LN_ERR_ARG, "%s: null table", who);
+    LN_REQUIRE(t->capacity > 0, LN_ERR_ARG, "%s: capacity %d", who, t->capacity);
+    LN_REQUIRE(t->pos_dim >= 1 && t->pos_dim <= LN_MAX_POS_DIM, LN_ERR_UNSUPPORTED, "%s: pos_dim %d unsupported", who,
+               t->pos_dim);
+    LN_REQUIRE(t->slot_keys && t->slot_tok && t->entries && t->keys && t->nr_filled && t->status, LN_ERR_ARG,
+               "%s: table has a null buffer", who);
+    return LN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// clear
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_table_clear(LnTable t, float* values, long long values_elems) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (long long i = g; i < t.capacity; i += stride) {
+        t.slot_keys[i] = LN_EMPTY_KEY;
+        t.slot_tok[i] = LN_EMPTY_TOK;
+        t.entries[i] = -1;
+    }
+    const long long nk = (long long)t.capacity * t.pos_dim;
+    for (long long i = g; i < nk; i += stride) t.keys[i] = 0;
+    if (values) {
+        const long long n4 = values_elems >> 2;
+        float4* v4 = reinterpret_cast<float4*>(values);
+        for (long long i = g; i < n4; i += stride) v4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (long long i = (n4 << 2) + g; i < values_elems; i += stride) values[i] = 0.f;
+    }
+    if (g == 0) {
+        *t.nr_filled = 0;
+        *t.status = 0;
+    }
+}
+
+extern "C" int ln_table_clear(const LnTable* t, float* values, long long values_elems, void* stream) {
+    int rc = ln_check_table(t, "ln_table_clear");
+    if (rc) return rc;
+    LN_REQUIRE(values == nullptr || (reinterpret_cast<uintptr_t>(values) & 15) == 0, LN_ERR_ARG,
+               "ln_table_clear: values must be 16-byte aligned");
+    long long work = (long long)t->capacity * t->pos_dim;
+    if (values && values_elems / 4 > work) work = values_elems / 4;
+    int blocks = ln_div_up(work, 256);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_table_clear, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *t, values, values_elems);
+    return ln_check_launch("ln_table_clear");
+}
+
+// ------------------------------------------------------------------------------------------
+// insert
+// ------------------------------------------------------------------------------------------
+template <int D>
+__device__ __forceinline__ int ln_insert(const LnTable& t, const int* key, uint32_t token) {
+    if (!KeyPack<D>::in_range(key)) {
+        atomicOr(t.status, LN_STATUS_KEY_RANGE);
+        return -1;
+    }
+    const uint64_t pk = KeyPack<D>::pack(key);
+    int h = int(ln_hash<D>(key) % uint32_t(t.capacity));
+    for (int probes = 0; probes < t.capacity; ++probes) {
+        unsigned long long cur = __hip_atomic_load(&t.slot_keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == LN_EMPTY_KEY) {
+            cur = atomicCAS(&t.slot_keys[h], (unsigned long long)LN_EMPTY_KEY, (unsigned long long)pk);
+            if (cur == LN_EMPTY_KEY) cur = pk;  // we claimed it
+        }
+        if (cur == pk) {
+            if (__hip_atomic_load(&t.slot_tok[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > token)
+                atomicMin(&t.slot_tok[h], token);
+            return h;
+        }
+        ++h;  // linear probing, HashTableGPU.cuh:479-482
+        if (h >= t.capacity) h = 0;
+    }
+    atomicOr(t.status, LN_STATUS_TABLE_FULL);
+    return -1;
+}
+
+// Token producer 1: the d+1 simplex vertices of every point (kernel_splat / distribute).
+template <int D>
+__global__ void __launch_bounds__(256)
+    k_insert_points(LnTable t, const float* __restrict__ pos_raw, LnScale<D> sc, int n, int* __restrict__ tok_slot,
+                    float* __restrict__ w, const float* __restrict__ vals, int val_dim, float* __restrict__ distributed) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    float pr[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) pr[i] = pos_raw[(size_t)p * D + i];
+    LnSimplex<D> s;
+    ln_simplex<D>(pr, sc, s);
+    int hs[D + 1];
+#pragma unroll
+    for (int r = 0; r <= D; ++r) {
+        int key[D];
+        ln_vertex_key<D>(s, r, key);
+        hs[r] = ln_insert<D>(t, key, uint32_t(p) * (D + 1) + r);
+    }
+#pragma unroll
+    for (int r = 0; r <= D; ++r) tok_slot[(size_t)p * (D + 1) + r] = hs[r];
+    if (w) {
+#pragma unroll
+        for (int r = 0; r <= D; ++r) w[(size_t)p * (D + 1) + r] = hs[r] >= 0 ? s.bary[r] : -1.0f;
+    }
+    if (distributed) {  // LatticeGPU.cuh:626-637: [pos_scaled(d) | val(V) | bary[r]] per simplex vertex
+        const int row_len = D + val_dim + 1;
+        float ps[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) ps[i] = pr[i] / sc.sigma[i];
+        for (int r = 0; r <= D; ++r) {
+            float* o = distributed + ((size_t)p * (D + 1) + r) * row_len;
+#pragma unroll
+            for (int i = 0; i < D; ++i) o[i] = ps[i];
+            for (int j = 0; j < val_dim; ++j) o[D + j] = vals[(size_t)p * val_dim + j];
+            o[D + val_dim] = s.bary[r];
+        }
+    }
+}
+
+// Token producer 2: coarsen kernel (LatticeGPU.cuh:2348-2511): per fine vertex with all-even key,
+// token 0 = key/2, token 1+2a / 2+2a = the coarse neighbour matching an EXISTING fine np / nm.
+template <int D>
+__global__ void __launch_bounds__(256) k_insert_coarse(LnTable fine, int fine_rows_upper, LnTable coarse, int* tok_slot) {
+    constexpr int TPR = 2 * (D + 1) + 1;  // tokens per fine row
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    int m = *fine.nr_filled;
+    if (m > fine_rows_upper) m = fine_rows_upper;
+    if (r >= fine_rows_upper) return;
+    int* ts = tok_slot + (size_t)r * TPR;
+    if (r >= m) {
+        for (int j = 0; j < TPR; ++j) ts[j] = -1;
+        return;
+    }
+    int fk[D + 1];
+    int sum = 0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        fk[i] = fine.keys[(size_t)r * D + i];
+        sum += fk[i];
+    }
+    fk[D] = -sum;
+    bool all_even = true;
+#pragma unroll
+    for (int i = 0; i <= D; ++i) all_even = all_even && ((fk[i] & 1) == 0);  // |frac(key/2)| <= 0.1, LatticeGPU.cuh:2376
+    if (!all_even) {
+        for (int j = 0; j < TPR; ++j) ts[j] = -1;
+        return;
+    }
+    int div[D + 1];
+#pragma unroll
+    for (int i = 0; i <= D; ++i) div[i] = fk[i] / 2;  // exact: all even
+    const uint32_t tok0 = uint32_t(r) * TPR;
+    ts[0] = ln_insert<D>(coarse, div, tok0);
+#pragma unroll
+    for (int axis = 0; axis <= D; ++axis) {
+        int nk[D + 1];
+        int ck[D + 1];
+        // np: +1 everywhere, -D on the axis
+#pragma unroll
+        for (int i = 0; i <= D; ++i) {
+            nk[i] = fk[i] + 1;
+            ck[i] = div[i] + 1;
+        }
+        nk[axis] = fk[axis] - D;
+        ck[axis] = div[axis] - D;
+        ts[1 + 2 * axis] = (ln_retrieve<D>(fine, nk) >= 0) ? ln_insert<D>(coarse, ck, tok0 + 1 + 2 * axis) : -1;
+        // nm: -1 everywhere, +D on the axis
+#pragma unroll
+        for (int i = 0; i <= D; ++i) {
+            nk[i] = fk[i] - 1;
+            ck[i] = div[i] - 1;
+        }
+        nk[axis] = fk[axis] + D;
+        ck[axis] = div[axis] + D;
+        ts[2 + 2 * axis] = (ln_retrieve<D>(fine, nk) >= 0) ? ln_insert<D>(coarse, ck, tok0 + 2 + 2 * axis) : -1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// mark / scan / finalize (shared by both producers)
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+    k_mark_first(LnTable t, const int* __restrict__ tok_slot, long long tokens, unsigned long long* __restrict__ bitmap,
+                 int* __restrict__ block_cnt) {
+    __shared__ int s_cnt[4];
+    const long long tk = (long long)blockIdx.x * 256 + threadIdx.x;
+    bool first = false;
+    if (tk < tokens) {
+        const int h = tok_slot[tk];
+        if (h >= 0) first = (t.slot_tok[h] == (unsigned int)tk) && (t.entries[h] < 0);
+    }
+    const unsigned long long mask = __ballot(first);
+    const int lane = threadIdx.x & 63;
+    if (lane == 0) {
+        bitmap[tk >> 6] = mask;
+        s_cnt[threadIdx.x >> 6] = __popcll(mask);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) block_cnt[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+
+__global__ void __launch_bounds__(1024) k_scan_blocks(const int* __restrict__ block_cnt, int nb, int* __restrict__ block_prefix,
+                                                      int* nr_filled) {
+    __shared__ int s_wave[16];
+    __shared__ int s_running;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int base = *nr_filled;
+    if (tid == 0) s_running = 0;
+    __syncthreads();
+    for (int start = 0; start < nb; start += 1024) {
+        const int i = start + tid;
+        const int v = (i < nb) ? block_cnt[i] : 0;
+        int incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        int wave_off = 0;
+        for (int k = 0; k < wave; ++k) wave_off += s_wave[k];
+        const int running = s_running;
+        if (i < nb) block_prefix[i] = base + running + wave_off + incl - v;
+        __syncthreads();
+        if (tid == 1023) s_running = running + wave_off + incl;
+        __syncthreads();
+    }
+    if (tid == 0) *nr_filled = base + s_running;
+}
+
+template <int D>
+__global__ void __launch_bounds__(256)
+    k_finalize(LnTable t, const int* tok_slot, int* idx_out, long long tokens, const unsigned long long* __restrict__ bitmap,
+               const int* __restrict__ block_prefix) {
+    const long long tk = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (tk >= tokens) return;
+    const int h = tok_slot[tk];
+    if (h < 0) {
+        if (idx_out) idx_out[tk] = -1;
+        return;
+    }
+    const int e = t.entries[h];  // >=0: existed before this build (or already finalized — same value)
+    int row = e;
+    const unsigned int ft = t.slot_tok[h];
+    if (e < 0) {
+        const unsigned int blk = ft >> 8;
+        const unsigned int wd = (ft >> 6) & 3;
+        int r = block_prefix[blk];
+        for (unsigned int k = 0; k < wd; ++k) r += __popcll(bitmap[(size_t)blk * 4 + k]);
+        const unsigned long long below = (ft & 63) ? (bitmap[ft >> 6] & ((1ull << (ft & 63)) - 1ull)) : 0ull;
+        r += __popcll(below);
+        row = r;
+        if (ft == (unsigned int)tk) {  // first occurrence publishes the vertex
+            t.entries[h] = row;
+            int key[D];
+            KeyPack<D>::unpack(t.slot_keys[h], key);
+#pragma unroll
+            for (int i = 0; i < D; ++i) t.keys[(size_t)row * D + i] = key[i];
+        }
+    }
+    if (idx_out) idx_out[tk] = row;
+}
+
+struct BuildWs {
+    unsigned long long* bitmap;
+    int* block_cnt;
+    int* block_prefix;
+    int* tok_slot;
+    int nb;
+};
+
+static size_t ln_align256(size_t x) { return (x + 255) & ~size_t(255); }
+
+extern "C" size_t ln_build_workspace_bytes(long long tokens) {
+    if (tokens < 1) tokens = 1;
+    const size_t nb = (size_t)ln_div_up(tokens, 256);
+    return ln_align256(nb * 4 * sizeof(unsigned long long)) + 2 * ln_align256(nb * sizeof(int)) +
+           ln_align256((size_t)tokens * sizeof(int));
+}
+
+static int ln_carve_ws(long long tokens, void* workspace, size_t bytes, BuildWs& ws) {
+    LN_REQUIRE(workspace != nullptr && bytes >= ln_build_workspace_bytes(tokens), LN_ERR_WORKSPACE,
+               "build workspace too small: %zu < %zu", bytes, ln_build_workspace_bytes(tokens));
+    LN_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, LN_ERR_WORKSPACE, "build workspace must be 256-byte aligned");
+    LN_REQUIRE(tokens < 0xFFFFFFFFll, LN_ERR_ARG, "too many insertion tokens: %lld", tokens);
+    char* p = static_cast<char*>(workspace);
+    ws.nb = ln_div_up(tokens, 256);
+    ws.bitmap = reinterpret_cast<unsigned long long*>(p);
+    p += ln_align256((size_t)ws.nb * 4 * sizeof(unsigned long long));
+    ws.block_cnt = reinterpret_cast<int*>(p);
+    p += ln_align256((size_t)ws.nb * sizeof(int));
+    ws.block_prefix = reinterpret_cast<int*>(p);
+    p += ln_align256((size_t)ws.nb * sizeof(int));
+    ws.tok_slot = reinterpret_cast<int*>(p);
+    return LN_OK;
+}
+
+template <int D>
+static int ln_rank_and_finalize(const LnTable& t, const int* tok_slot, int* idx_out, long long tokens, const BuildWs& ws,
+                                hipStream_t st) {
+    hipLaunchKernelGGL(k_mark_first, dim3(ws.nb), dim3(256), 0, st, t, tok_slot, tokens, ws.bitmap, ws.block_cnt);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, ws.block_cnt, ws.nb, ws.block_prefix, t.nr_filled);
+    hipLaunchKernelGGL(k_finalize<D>, dim3(ws.nb), dim3(256), 0, st, t, tok_slot, idx_out, tokens, ws.bitmap, ws.block_prefix);
+    return ln_check_launch("ln build (mark/scan/finalize)");
+}
+
+static int ln_build_points(const LnTable* t, const float* positions_raw, const float* sigmas_host, int n, int* idx, float* w,
+                           int write_idx, const float* vals, int val_dim, float* distributed, void* workspace,
+                           size_t workspace_bytes, void* stream, const char* who) {
+    int rc = ln_check_table(t, who);
+    if (rc) return rc;
+    LN_REQUIRE(n >= 0, LN_ERR_ARG, "%s: n=%d", who, n);
+    LN_REQUIRE(positions_raw != nullptr || n == 0, LN_ERR_ARG, "%s: null positions", who);
+    LN_REQUIRE(!write_idx || (idx && w), LN_ERR_ARG, "%s: write_idx set but idx/w null", who);
+    if (n == 0) return LN_OK;
+    const long long tokens = (long long)n * (t->pos_dim + 1);
+    BuildWs ws;
+    rc = ln_carve_ws(tokens, workspace, workspace_bytes, ws);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    int* tok_slot = write_idx ? idx : ws.tok_slot;  // idx doubles as the token->slot scratch
+    LN_DISPATCH_D(t->pos_dim, {
+        LnScale<D> sc = ln_make_scale<D>(sigmas_host);
+        hipLaunchKernelGGL(k_insert_points<D>, dim3(ln_div_up(n, 256)), dim3(256), 0, st, *t, positions_raw, sc, n, tok_slot,
+                           write_idx ? w : (float*)nullptr, vals, val_dim, distributed);
+        rc = ln_rank_and_finalize<D>(*t, tok_slot, write_idx ? idx : (int*)nullptr, tokens, ws, st);
+    });
+    return rc;
+}
+
+extern "C" int ln_build_splat(const LnTable* t, const float* positions_raw, const float* sigmas_host, int n, int* idx,
+                              float* w, int write_idx, void* workspace, size_t workspace_bytes, void* stream) {
+    return ln_build_points(t, positions_raw, sigmas_host, n, idx, w, write_idx, nullptr, 0, nullptr, workspace,
+                           workspace_bytes, stream, "ln_build_splat");
+}
+
+extern "C" int ln_distribute(const LnTable* t, const float* positions_raw, const float* sigmas_host, const float* vals, int n,
+                             int val_dim, int* idx, float* w, float* distributed, void* workspace, size_t workspace_bytes,
+                             void* stream) {
+    LN_REQUIRE(vals && distributed && idx && w, LN_ERR_ARG, "ln_distribute: null buffer");
+    LN_REQUIRE(val_dim >= 1, LN_ERR_ARG, "ln_distribute: val_dim=%d", val_dim);
+    return ln_build_points(t, positions_raw, sigmas_host, n, idx, w, 1, vals, val_dim, distributed, workspace,
+                           workspace_bytes, stream, "ln_distribute");
+}
+
+extern "C" int ln_coarsen(const LnTable* fine, int fine_rows_upper, const LnTable* coarse, void* workspace,
+                          size_t workspace_bytes, void* stream) {
+    int rc = ln_check_table(fine, "ln_coarsen(fine)");
+    if (rc) return rc;
+    rc = ln_check_table(coarse, "ln_coarsen(coarse)");
+    if (rc) return rc;
+    LN_REQUIRE(fine->pos_dim == coarse->pos_dim, LN_ERR_ARG, "ln_coarsen: pos_dim mismatch");
+    if (fine_rows_upper <= 0) return LN_OK;
+    const long long tokens = (long long)fine_rows_upper * (2 * (fine->pos_dim + 1) + 1);
+    BuildWs ws;
+    rc = ln_carve_ws(tokens, workspace, workspace_bytes, ws);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    LN_DISPATCH_D(fine->pos_dim, {
+        hipLaunchKernelGGL(k_insert_coarse<D>, dim3(ln_div_up(fine_rows_upper, 256)), dim3(256), 0, st, *fine, fine_rows_upper,
+                           *coarse, ws.tok_slot);
+        rc = ln_rank_and_finalize<D>(*coarse, ws.tok_slot, (int*)nullptr, tokens, ws, st);
+    });
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------
+// neighbour traversal (LatticeGPU.cuh:1479-1684): one thread per (query vertex, filter slot)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool ln_coord_is_integer(float v) {
+    float ip;
+    const float frac = fabsf(modff(v, &ip));
+    return !(frac > 0.0001f);  // LatticeGPU.cuh:467
+}
+
+template <int D>
+__global__ void __launch_bounds__(256)
+    k_neighbours(LnTable tq, int query_rows_upper, LnTable tn, float scale, int dilation, int flip, int* __restrict__ nbr) {
+#pragma clang fp contract(off)
+    constexpr int E = 2 * (D + 1) + 1;
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int m = int(g / E);
+    const int e = int(g - (long long)m * E);
+    if (m >= query_rows_upper) return;
+    int mq = *tq.nr_filled;
+    if (m >= mq) {  // rows beyond the filled part: reference kernels return early (LatticeGPU.cuh:1471)
+        nbr[g] = LN_NOT_VISITED;
+        return;
+    }
+    float kf[D + 1];
+    float ksum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        kf[i] = float(tq.keys[(size_t)m * D + i]);
+        ksum = ksum + kf[i];
+    }
+    kf[D] = -ksum;
+    bool all_int = true;
+#pragma unroll
+    for (int i = 0; i <= D; ++i) {
+        kf[i] = kf[i] * scale;
+        if (scale < 1.0f) all_int = all_int && ln_coord_is_integer(kf[i]);
+    }
+    int result = LN_NOT_VISITED;
+    if (e == E - 1) {  // centre, LatticeGPU.cuh:1534-1540
+        if (all_int) {
+            int key[D + 1];
+#pragma unroll
+            for (int i = 0; i <= D; ++i) key[i] = int(roundf(kf[i]));
+            result = ln_retrieve<D>(tn, key);
+        }
+    } else {
+        const bool check = (scale >= 1.0f) || !all_int;  // LatticeGPU.cuh:1547-1554
+        if (check) {
+            const int axis = e >> 1;
+            const bool is_np = ((e & 1) == (flip ? 1 : 0));
+            const float mm = (scale < 1.0f) ? scale : 1.0f;
+            const float step = mm * float(dilation);
+            const float big = mm * float(dilation) * float(D);
+            float nf[D + 1];
+            bool ok = true;
+#pragma unroll
+            for (int i = 0; i <= D; ++i) {
+                nf[i] = is_np ? (kf[i] + step) : (kf[i] - step);
+                if (i == axis) nf[i] = is_np ? (kf[i] - big) : (kf[i] + big);
+            }
+            if ((D + 1) % 2 != 0) {  // odd d+1: the neighbour itself must be all-integer (LatticeGPU.cuh:1581-1601)
+#pragma unroll
+                for (int i = 0; i <= D; ++i) ok = ok && ln_coord_is_integer(nf[i]);
+            }
+            if (ok) {
+                int key[D + 1];
+#pragma unroll
+                for (int i = 0; i <= D; ++i) key[i] = int(roundf(nf[i]));
+                result = ln_retrieve<D>(tn, key);
+            }
+        }
+    }
+    nbr[g] = result;
+}
+
+extern "C" int ln_neighbours(const LnTable* query, int query_rows_upper, const LnTable* neigh, int lvl_query, int lvl_neigh,
+                             int dilation, int flip, int* nbr, void* stream) {
+    int rc = ln_check_table(query, "ln_neighbours(query)");
+    if (rc) return rc;
+    rc = ln_check_table(neigh, "ln_neighbours(neigh)");
+    if (rc) return rc;
+    LN_REQUIRE(query->pos_dim == neigh->pos_dim, LN_ERR_ARG, "ln_neighbours: pos_dim mismatch");
+    const int diff = lvl_query - lvl_neigh;
+    LN_REQUIRE(diff >= -1 && diff <= 1, LN_ERR_ARG,
+               "ln_neighbours: lattices must be at most one level apart (query lvl %d, neighbours lvl %d)", lvl_query,
+               lvl_neigh);  // Lattice.cu:439
+    LN_REQUIRE(dilation >= 1, LN_ERR_ARG, "ln_neighbours: dilation=%d", dilation);
+    LN_REQUIRE(nbr != nullptr || query_rows_upper == 0, LN_ERR_ARG, "ln_neighbours: null output");
+    if (query_rows_upper <= 0) return LN_OK;
+    const float scale = diff == 0 ? 1.0f : (diff > 0 ? 2.0f : 0.5f);  // pow(2, lvl_diff), LatticeGPU.cuh:1488
+    const int E = 2 * (query->pos_dim + 1) + 1;
+    const long long work = (long long)query_rows_upper * E;
+    LN_DISPATCH_D(query->pos_dim, {
+        hipLaunchKernelGGL(k_neighbours<D>, dim3(ln_div_up(work, 256)), dim3(256), 0, (hipStream_t)stream, *query,
+                           query_rows_upper, *neigh, scale, dilation, flip, nbr);
+    });
+    return ln_check_launch("ln_neighbours");
+}
+
+// ------------------------------------------------------------------------------------------
+// simplex retrieval for slice_no_precomputation (LatticeGPU.cuh:2598-2750, index part)
+// ------------------------------------------------------------------------------------------
+template <int D>
+__global__ void __launch_bounds__(256)
+    k_retrieve_points(LnTable t, const float* __restrict__ pos_raw, LnScale<D> sc, int n, int* __restrict__ idx,
+                      float* __restrict__ w) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    float pr[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) pr[i] = pos_raw[(size_t)p * D + i];
+    LnSimplex<D> s;
+    ln_simplex<D>(pr, sc, s);
+#pragma unroll
+    for (int r = 0; r <= D; ++r) {
+        int key[D];
+        ln_vertex_key<D>(s, r, key);
+        const int row = ln_retrieve<D>(t, key);
+        idx[(size_t)p * (D + 1) + r] = row;  // -1 when absent (Lattice.cu:812-815 pre-fill)
+        w[(size_t)p * (D + 1) + r] = row >= 0 ? s.bary[r] : -1.0f;
+    }
+}
+
+int ln_retrieve_points(const LnTable* t, const float* positions_raw, const float* sigmas_host, int n, int* idx, float* w,
+                       void* stream) {
+    int rc = ln_check_table(t, "ln_slice_no_precomputation");
+    if (rc) return rc;
+    if (n <= 0) return LN_OK;
+    LN_DISPATCH_D(t->pos_dim, {
+        LnScale<D> sc = ln_make_scale<D>(sigmas_host);
+        hipLaunchKernelGGL(k_retrieve_points<D>, dim3(ln_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, *t, positions_raw,
+                           sc, n, idx, w);
+    });
+    return ln_check_launch("ln_slice_no_precomputation(retrieve)");
+}

@@ -1,0 +1,727 @@
+"""`Lattice` / `HashTable`: Python host side of the MI355X permutohedral-lattice backend.
+
+Mirrors the pybind11 classes of the reference (src/PyBridge.cxx:33-113) method for method —
+same names, argument meaning and return shapes — on top of the C ABI in
+include/latticenet_hip.h.  Host orchestration follows src/Lattice.cu (cited per method); tensors
+are plain torch tensors on a ROCm device, kernels run on torch's current HIP stream.
+
+Differences that are deliberate:
+  * errors raise Python exceptions instead of glog CHECK aborts;
+  * vertex numbering is canonical (first occurrence in (point, remainder) order);
+  * the 9-probe neighbour traversal is done ONCE per (query, neighbour, dilation, flip) and the
+    [M, E] neighbour list is cached with the table structure, then shared by im2row,
+    im2rowindices, row2im, the fused convolution and its backward;
+  * `convolve_im2row_standalone` never materialises the [M, E*V] rowified tensor.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+
+__all__ = ["Lattice", "HashTable"]
+
+
+def _require_cuda(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise ValueError(f"{name} must live on a ROCm/HIP device (got {t.device}); the lattice backend has no CPU path")
+
+
+class _TableStorage:
+    """Structure buffers shared shallowly between lattice clones (Lattice.cu:88-92)."""
+
+    def __init__(self, capacity: int, pos_dim: int, device):
+        self.capacity = int(capacity)
+        self.pos_dim = int(pos_dim)
+        self.device = device
+        self.keys = torch.empty((capacity, pos_dim), dtype=torch.int32, device=device)
+        self.entries = torch.empty((capacity,), dtype=torch.int32, device=device)
+        self.slot_keys = torch.empty((capacity,), dtype=torch.int64, device=device)
+        self.slot_tok = torch.empty((capacity,), dtype=torch.int32, device=device)
+        self.status = torch.zeros((1,), dtype=torch.int32, device=device)
+        self.version = 0
+        self.nbr_cache = {}
+
+    def clone(self) -> "_TableStorage":
+        s = _TableStorage.__new__(_TableStorage)
+        s.capacity, s.pos_dim, s.device = self.capacity, self.pos_dim, self.device
+        s.keys = self.keys.clone()
+        s.entries = self.entries.clone()
+        s.slot_keys = self.slot_keys.clone()
+        s.slot_tok = self.slot_tok.clone()
+        s.status = self.status.clone()
+        s.version = 0
+        s.nbr_cache = {}
+        return s
+
+    def touch(self):
+        """Structure changed: drop cached neighbour lists."""
+        self.version += 1
+        self.nbr_cache.clear()
+
+
+class HashTable:
+    """Host owner of the table tensors (src/HashTable.cu:11-115)."""
+
+    def __init__(self, capacity: int):
+        self.m_capacity = int(capacity)
+        self._storage: Optional[_TableStorage] = None
+        self.m_values_tensor: Optional[torch.Tensor] = None
+        self.m_nr_filled_tensor: Optional[torch.Tensor] = None
+        self.m_nr_filled_is_dirty = True
+        self.m_nr_filled = -1
+        self._pos_dim_hint = -1  # dimensions known before any CAP-sized buffer exists
+        self._val_dim_hint = 0
+
+    # -- reference-visible tensors (PyBridge.cxx:35-36) --
+    @property
+    def m_keys_tensor(self):
+        return None if self._storage is None else self._storage.keys
+
+    @property
+    def m_entries_tensor(self):
+        return None if self._storage is None else self._storage.entries
+
+    def init(self, pos_dim: int, val_dim: int, device):  # HashTable.cu:21-47
+        self._storage = _TableStorage(self.m_capacity, pos_dim, device)
+        self.m_values_tensor = torch.empty((self.m_capacity, val_dim), dtype=torch.float32, device=device)
+        self.m_nr_filled_tensor = torch.zeros((1,), dtype=torch.int32, device=device)
+        self.m_nr_filled_is_dirty = True
+        self.clear()
+
+    def is_initialized(self) -> bool:
+        return self._storage is not None
+
+    def c_table(self) -> _lib.LnTable:
+        s = self._storage
+        if s is None:
+            raise _lib.LatticeNetHipError("hash table is not initialised (no splat / create_verts happened yet)")
+        return _lib.LnTable(s.capacity, s.pos_dim, s.slot_keys.data_ptr(), s.slot_tok.data_ptr(), s.entries.data_ptr(),
+                            s.keys.data_ptr(), self.m_nr_filled_tensor.data_ptr(), s.status.data_ptr())
+
+    def clear(self):  # HashTable.cu:49-57, one launch instead of four fill_ kernels
+        if not self.is_initialized():
+            return
+        lib = _lib.load()
+        v = self.m_values_tensor
+        if v is not None and not (v.is_contiguous() and v.data_ptr() % 16 == 0):
+            v.zero_()
+            v = None
+        t = self.c_table()
+        _lib.check(lib.ln_table_clear(C.byref(t), _lib.ptr(v), 0 if v is None else v.numel(),
+                                      _lib.stream_ptr(self._storage.device)), "ln_table_clear")
+        self._storage.touch()
+        self.m_nr_filled_is_dirty = True
+
+    def clear_only_values(self):  # HashTable.cu:59-64
+        if self.is_initialized() and self.m_values_tensor is not None:
+            self.m_values_tensor.zero_()
+
+    def pos_dim(self) -> int:
+        return self._storage.pos_dim if self._storage is not None else self._pos_dim_hint
+
+    def val_dim(self) -> int:  # HashTable.cu:102-104: defined as values.size(1)
+        return int(self.m_values_tensor.shape[1]) if self.m_values_tensor is not None else self._val_dim_hint
+
+    def capacity(self) -> int:
+        return self._storage.capacity if self._storage is not None else self.m_capacity
+
+    def set_values(self, new_values: torch.Tensor):  # HashTable.cu:112-115
+        self.m_values_tensor = new_values.contiguous()
+
+
+def _parse_lattice_cfg(path: str) -> dict:
+    """Reads the `lattice_gpu: { ... }` block of a configuru CFG file (Lattice.cu:107-132)."""
+    with open(path, "r") as f:
+        text = f.read()
+    text = re.sub(r"//[^\n]*", "", text)
+    m = re.search(r"lattice_gpu\s*:\s*\{(.*?)\}", text, flags=re.S)
+    if not m:
+        raise ValueError(f"{path}: no lattice_gpu block")
+    out = {}
+    for key, val in re.findall(r"(\w+)\s*:\s*(\"[^\"]*\"|[^\s,]+)", m.group(1)):
+        out[key] = val.strip('"')
+    return out
+
+
+class Lattice:
+    """Drop-in for `latticenet.Lattice` (src/PyBridge.cxx:41-113)."""
+
+    m_expected_position_dimensions = -1  # static, Lattice.cu:44
+
+    # ---------------------------------------------------------------- construction
+    def __init__(self, config_file: Optional[str] = None, name: str = "", *, sigmas: Optional[Sequence[float]] = None,
+                 capacity: Optional[int] = None, device=None):
+        self.m_name = name
+        self.m_lvl = 1
+        self.m_positions = None
+        self.m_sigmas_val_and_extent = []
+        self._device = torch.device(device) if device is not None else None
+        if config_file is not None:
+            self._init_params(config_file)
+        else:
+            if sigmas is None or capacity is None:
+                raise ValueError("Lattice needs either a config file or sigmas= and capacity=")
+            self.m_hash_table = HashTable(int(capacity))
+            self.m_sigmas = [float(s) for s in sigmas]
+            if len(set(self.m_sigmas)) == 1:
+                self.m_sigmas_val_and_extent = [(self.m_sigmas[0], len(self.m_sigmas))]
+            else:
+                self.m_sigmas_val_and_extent = [(s, 1) for s in self.m_sigmas]
+            Lattice.m_expected_position_dimensions = len(self.m_sigmas)
+        self._sigmas_tensor = None
+
+    @staticmethod
+    def create(config_file: str, name: str = "") -> "Lattice":  # PyBridge.cxx:47-48
+        return Lattice(config_file, name)
+
+    def _init_params(self, config_file: str):  # Lattice.cu:107-132
+        path = config_file
+        if not os.path.isabs(path) and not os.path.exists(path):
+            root = os.environ.get("LATTICE_NET_CONFIG_ROOT", os.getcwd())
+            path = os.path.join(root, config_file)
+        cfg = _parse_lattice_cfg(path)
+        self.m_hash_table = HashTable(int(cfg["hash_table_capacity"]))
+        pairs = []
+        for i in range(int(cfg["nr_sigmas"])):
+            tok = cfg[f"sigma_{i}"].split()
+            if len(tok) != 2:
+                raise ValueError(f"sigma_{i} must be '<value> <extent>', got {cfg[f'sigma_{i}']!r}")
+            pairs.append((float(tok[0]), int(float(tok[1]))))
+        self.m_sigmas_val_and_extent = pairs
+        self.set_sigmas(pairs)
+
+    def set_sigmas(self, sigmas_list):  # Lattice.cu:135-161
+        self.m_sigmas = []
+        for sigma, nr_dim in sigmas_list:
+            self.m_sigmas.extend([float(sigma)] * int(nr_dim))
+        Lattice.m_expected_position_dimensions = len(self.m_sigmas)
+        self._sigmas_tensor = None
+
+    @classmethod
+    def _clone_of(cls, other: "Lattice") -> "Lattice":
+        """Lattice(Lattice* other), Lattice.cu:73-101: structure shared shallowly, nr_filled deep-copied."""
+        new = cls.__new__(cls)
+        new.m_name = ""
+        new.m_lvl = other.m_lvl
+        new.m_sigmas = list(other.m_sigmas)
+        new.m_sigmas_val_and_extent = list(other.m_sigmas_val_and_extent)
+        new._sigmas_tensor = None
+        new._device = other._device
+        new.m_positions = other.m_positions
+        ht = HashTable(other.m_hash_table.capacity())
+        oh = other.m_hash_table
+        ht._storage = oh._storage
+        ht.m_values_tensor = oh.m_values_tensor
+        # The reference deep-copies the 1-element counter (Lattice.cu:93) and leaves the clone dirty
+        # (HashTable.cu:15), which costs a copy kernel and a blocking readback per convolution.  Nothing
+        # ever builds into a clone without first replacing its buffers (distribute / expand / coarse),
+        # so the counter is shared and the cached host count is kept.
+        ht.m_nr_filled_tensor = oh.m_nr_filled_tensor
+        ht._pos_dim_hint, ht._val_dim_hint = oh.pos_dim(), oh.val_dim()
+        ht.m_nr_filled_is_dirty = oh.m_nr_filled_is_dirty
+        ht.m_nr_filled = oh.m_nr_filled
+        new.m_hash_table = ht
+        return new
+
+    # ---------------------------------------------------------------- helpers
+    def _dev(self, like: Optional[torch.Tensor] = None):
+        if like is not None and like.is_cuda:
+            self._device = like.device
+        if self._device is None:
+            self._device = torch.device("cuda", torch.cuda.current_device())
+        return self._device
+
+    def _stream(self):
+        return _lib.stream_ptr(self._dev())
+
+    def _sigmas_host(self):
+        return _lib.host_floats(self.m_sigmas)
+
+    def _check_positions(self, positions_raw: torch.Tensor):  # Lattice.cu:162-170
+        if positions_raw.dtype != torch.float32:
+            raise ValueError("positions should be of type float")
+        if positions_raw.dim() != 2:
+            raise ValueError(f"positions should have dim 2 (N x pos_dim), got sizes {tuple(positions_raw.shape)}")
+        pos_dim = positions_raw.shape[1]
+        if len(self.m_sigmas) != pos_dim:
+            raise ValueError(f"one sigma per position dimension is required: {len(self.m_sigmas)} sigmas, pos_dim {pos_dim}")
+        if not positions_raw.is_contiguous():
+            raise ValueError("positions_raw is not contiguous, call .contiguous() on it")
+        if pos_dim > _lib.LN_MAX_POS_DIM:
+            raise ValueError(f"pos_dim {pos_dim} unsupported (max {_lib.LN_MAX_POS_DIM})")
+        _require_cuda(positions_raw, "positions")
+
+    def _check_values(self, values: torch.Tensor):  # Lattice.cu:171-175
+        if values.dtype != torch.float32 or values.dim() != 2 or not values.is_contiguous():
+            raise ValueError("values should be a contiguous 2-D float tensor")
+        _require_cuda(values, "values")
+
+    def _check_positions_and_values(self, positions_raw, values):  # Lattice.cu:176-181
+        if positions_raw.shape[0] != values.shape[0]:
+            raise ValueError(f"positions {tuple(positions_raw.shape)} and values {tuple(values.shape)} must have the same number of rows")
+        self._check_positions(positions_raw)
+        self._check_values(values)
+
+    def _workspace(self, nbytes: int) -> torch.Tensor:
+        return torch.empty((max(int(nbytes), 256),), dtype=torch.uint8, device=self._dev())
+
+    def _ensure_table(self, pos_dim: int, val_dim: int, like: torch.Tensor):
+        if not self.m_hash_table.is_initialized():
+            self.m_hash_table.init(pos_dim, val_dim, self._dev(like))
+
+    def _build(self, positions_raw, write: bool, vals=None, distributed=None):
+        lib = _lib.load()
+        n, d = positions_raw.shape
+        dev = self._dev(positions_raw)
+        ht = self.m_hash_table
+        idx = w = None
+        if write:
+            idx = torch.empty((n * (d + 1),), dtype=torch.int32, device=dev)
+            w = torch.empty((n * (d + 1),), dtype=torch.float32, device=dev)
+        ws_bytes = lib.ln_build_workspace_bytes(n * (d + 1))
+        ws = self._workspace(ws_bytes)
+        t = ht.c_table()
+        if distributed is None:
+            rc = lib.ln_build_splat(C.byref(t), _lib.ptr(positions_raw), self._sigmas_host(), n, _lib.ptr(idx), _lib.ptr(w),
+                                    1 if write else 0, _lib.ptr(ws), ws.numel(), self._stream())
+            _lib.check(rc, "ln_build_splat")
+        else:
+            rc = lib.ln_distribute(C.byref(t), _lib.ptr(positions_raw), self._sigmas_host(), _lib.ptr(vals), n, vals.shape[1],
+                                   _lib.ptr(idx), _lib.ptr(w), _lib.ptr(distributed), _lib.ptr(ws), ws.numel(), self._stream())
+            _lib.check(rc, "ln_distribute")
+        ht._storage.touch()
+        ht.m_nr_filled_is_dirty = True
+        return idx, w
+
+    # ---------------------------------------------------------------- splat family
+    def begin_splat(self, reset_hashmap: bool = True):  # Lattice.cu:185-193
+        if reset_hashmap:
+            self.m_hash_table.clear()
+        else:
+            self.m_hash_table.clear_only_values()
+        self.m_hash_table.m_nr_filled_is_dirty = True
+
+    def splat_standalone(self, positions_raw: torch.Tensor, values: torch.Tensor):  # Lattice.cu:196-241
+        self._check_positions_and_values(positions_raw, values)
+        n, d = positions_raw.shape
+        v = values.shape[1]
+        self.m_positions = positions_raw
+        if not self.m_hash_table.is_initialized():
+            self.m_hash_table.init(d, v, self._dev(positions_raw))
+        idx, w = self._build(positions_raw, True)
+        lib = _lib.load()
+        tv = self.m_hash_table.m_values_tensor
+        if tv.shape[1] != v:
+            raise ValueError(f"table values have val_dim {tv.shape[1]} but {v} were splatted")
+        _lib.check(lib.ln_splat_accumulate(_lib.ptr(tv), _lib.ptr(values), _lib.ptr(idx), _lib.ptr(w), n, d, v, self._stream()),
+                   "ln_splat_accumulate")
+        return idx, w
+
+    def just_create_verts(self, positions_raw: torch.Tensor, return_indices_and_weights: bool):  # Lattice.cu:244-290
+        self._check_positions(positions_raw)
+        d = positions_raw.shape[1]
+        self._ensure_table(d, 1, positions_raw)
+        idx, w = self._build(positions_raw, bool(return_indices_and_weights))
+        return idx, w
+
+    def distribute(self, positions_raw: torch.Tensor, values: torch.Tensor, reset_hashmap: bool = True):  # Lattice.cu:351-410
+        self._check_positions_and_values(positions_raw, values)
+        n, d = positions_raw.shape
+        v = values.shape[1]
+        dev = self._dev(positions_raw)
+        self.m_positions = positions_raw
+        oh = self.m_hash_table
+        if not oh.is_initialized():
+            if reset_hashmap:
+                # the reference allocates CAP-sized buffers here only to clone and clear them below
+                # (Lattice.cu:362-391); this lattice just needs to know its dimensions
+                oh._pos_dim_hint, oh._val_dim_hint = d, v
+            else:
+                oh.init(d, v, dev)
+        distributed = torch.empty((n * (d + 1), d + v + 1), dtype=torch.float32, device=dev)
+        new = Lattice._clone_of(self)
+        new.m_name = "distributed_lattice"
+        nh = new.m_hash_table
+        if reset_hashmap:
+            # deep copy + clear of three CAP-sized tensors (Lattice.cu:376-391) == fresh cleared buffers
+            nh._storage = _TableStorage(oh.capacity(), d, dev)
+            nh.m_values_tensor = torch.empty((oh.capacity(), oh.val_dim() or v), dtype=torch.float32, device=dev)
+            nh.m_nr_filled_tensor = torch.zeros((1,), dtype=torch.int32, device=dev)
+            nh.clear()
+        else:
+            nh._storage = oh._storage.clone()
+            nh.m_values_tensor = torch.zeros_like(oh.m_values_tensor)
+            nh.m_nr_filled_tensor = oh.m_nr_filled_tensor.clone()
+        idx, w = new._build(positions_raw, True, vals=values, distributed=distributed)
+        return new, distributed, idx, w
+
+    def expand(self, positions_raw: torch.Tensor, point_multiplier: int, noise_stddev: float, expand_values: bool):  # Lattice.cu:292-348
+        self._check_positions(positions_raw)
+        d = positions_raw.shape[1]
+        self._ensure_table(d, 1, positions_raw)
+        pos = positions_raw.repeat(point_multiplier, 1)
+        pos = pos + torch.randn_like(pos) * noise_stddev
+        new = Lattice._clone_of(self)
+        new.m_name = "expanded_lattice"
+        oh, nh = self.m_hash_table, new.m_hash_table
+        nh._storage = oh._storage.clone()
+        nh.m_values_tensor = torch.zeros((1, self.val_dim()), dtype=torch.float32, device=self._dev())
+        nh.m_nr_filled_tensor = oh.m_nr_filled_tensor.clone()
+        new.just_create_verts(pos.contiguous(), False)
+        if expand_values:
+            diff = new.nr_lattice_vertices() - self.nr_lattice_vertices()
+            if diff < 0:
+                raise _lib.LatticeNetHipError("expand produced fewer vertices than the source lattice")
+            new.set_values(torch.nn.functional.pad(self.values()[: self.nr_lattice_vertices()], (0, 0, 0, diff)))
+        return new
+
+    # ---------------------------------------------------------------- neighbour list (shared)
+    def neighbours(self, lattice_neighbours: Optional["Lattice"], dilation: int, flip_neighbours: bool) -> torch.Tensor:
+        """[M, E] int32 neighbour list of this (query) lattice in `lattice_neighbours`, cached."""
+        nb = lattice_neighbours if lattice_neighbours is not None else self
+        if abs(self.m_lvl - nb.m_lvl) > 1:  # Lattice.cu:439
+            raise ValueError(f"query lvl {self.m_lvl} and neighbours lvl {nb.m_lvl} must differ by at most 1")
+        m = self.nr_lattice_vertices()
+        if m == 0:
+            raise _lib.LatticeNetHipError("this lattice has zero vertices")
+        sq, sn = self.m_hash_table._storage, nb.m_hash_table._storage
+        key = (id(sn), sn.version, self.m_lvl, nb.m_lvl, int(dilation), bool(flip_neighbours), m)
+        hit = sq.nbr_cache.get(key)
+        if hit is not None:
+            return hit[0]
+        lib = _lib.load()
+        E = self.get_filter_extent(1)
+        nbr = torch.empty((m, E), dtype=torch.int32, device=self._dev())
+        tq, tn = self.m_hash_table.c_table(), nb.m_hash_table.c_table()
+        _lib.check(lib.ln_neighbours(C.byref(tq), m, C.byref(tn), self.m_lvl, nb.m_lvl, int(dilation), 1 if flip_neighbours else 0,
+                                     _lib.ptr(nbr), self._stream()), "ln_neighbours")
+        sq.nbr_cache[key] = (nbr, sn)  # keep sn alive so id() stays unique
+        return nbr
+
+    def _check_filter_extent(self, filter_extent: int):
+        if filter_extent != self.get_filter_extent(1):
+            raise ValueError(f"filter extent should be {self.get_filter_extent(1)} (1-hop neighbourhood + centre), got {filter_extent}")
+
+    # ---------------------------------------------------------------- convolution family
+    def convolve_im2row_standalone(self, filter_bank: torch.Tensor, dilation: int, lattice_neighbours: Optional["Lattice"],
+                                   flip_neighbours: bool) -> "Lattice":  # Lattice.cu:424-474
+        nb = lattice_neighbours if lattice_neighbours is not None else self
+        if filter_bank is None or filter_bank.dim() != 2:
+            raise ValueError("filter bank should be 2-D: (filter_extent * val_dim) x nr_filters")
+        filter_bank = filter_bank.contiguous()
+        v = nb.val_dim()
+        nr_filters = int(filter_bank.shape[1])
+        filter_extent = filter_bank.shape[0] // v
+        self._check_filter_extent(filter_extent)
+        if filter_bank.shape[0] != filter_extent * v:
+            raise ValueError("filter bank rows must be filter_extent * val_dim")
+        nbr = self.neighbours(nb, dilation, flip_neighbours)
+        m = nbr.shape[0]
+        vals = nb.values()
+        out = torch.empty((m, nr_filters), dtype=torch.float32, device=self._dev())
+        lib = _lib.load()
+        _lib.check(lib.ln_conv_forward(_lib.ptr(nbr), _lib.ptr(vals), _lib.ptr(filter_bank), m, filter_extent, v, nr_filters,
+                                       _lib.ptr(out), self._stream()), "ln_conv_forward")
+        conv = Lattice._clone_of(self)
+        conv.m_name = "convolved_lattice"
+        conv.m_hash_table.set_values(out)
+        return conv
+
+    def convolve_im2row_grad_filter(self, grad_out: torch.Tensor, dilation: int, lattice_neighbours: Optional["Lattice"],
+                                    filter_extent: int) -> torch.Tensor:
+        """grad_filter = im2row(...)^T @ grad_out (lattice_funcs.py:298-302) without the rowified tensor."""
+        nb = lattice_neighbours if lattice_neighbours is not None else self
+        self._check_filter_extent(filter_extent)
+        grad_out = grad_out.contiguous()
+        nbr = self.neighbours(nb, dilation, False)
+        m = nbr.shape[0]
+        v = nb.val_dim()
+        f = int(grad_out.shape[1])
+        if grad_out.shape[0] != m:
+            raise ValueError(f"grad_out has {grad_out.shape[0]} rows, lattice has {m} vertices")
+        lib = _lib.load()
+        gf = torch.empty((filter_extent * v, f), dtype=torch.float32, device=self._dev())
+        ws = self._workspace(lib.ln_conv_grad_filter_workspace_bytes(m, filter_extent, v, f))
+        _lib.check(lib.ln_conv_grad_filter(_lib.ptr(nbr), _lib.ptr(nb.values()), _lib.ptr(grad_out), m, filter_extent, v, f,
+                                           _lib.ptr(gf), _lib.ptr(ws), ws.numel(), self._stream()), "ln_conv_grad_filter")
+        return gf
+
+    def im2row(self, lattice_neighbours: Optional["Lattice"], filter_extent: int, dilation: int, flip_neighbours: bool):  # Lattice.cu:612-644
+        nb = lattice_neighbours if lattice_neighbours is not None else self
+        self._check_filter_extent(filter_extent)
+        nbr = self.neighbours(nb, dilation, flip_neighbours)
+        m = nbr.shape[0]
+        v = nb.val_dim()
+        out = torch.empty((m, filter_extent * v), dtype=torch.float32, device=self._dev())
+        lib = _lib.load()
+        _lib.check(lib.ln_im2row(_lib.ptr(nbr), _lib.ptr(nb.values()), m, filter_extent, v, _lib.ptr(out), self._stream()), "ln_im2row")
+        return out
+
+    def im2rowindices(self, lattice_neighbours: Optional["Lattice"], filter_extent: int, dilation: int, flip_neighbours: bool):  # Lattice.cu:578-610
+        nb = lattice_neighbours if lattice_neighbours is not None else self
+        self._check_filter_extent(filter_extent)
+        nbr = self.neighbours(nb, dilation, flip_neighbours)
+        m = nbr.shape[0]
+        v = nb.val_dim()
+        out = torch.empty((m, filter_extent * v), dtype=torch.int32, device=self._dev())
+        lib = _lib.load()
+        _lib.check(lib.ln_im2rowindices(_lib.ptr(nbr), m, filter_extent, v, _lib.ptr(out), self._stream()), "ln_im2rowindices")
+        return out
+
+    def row2im(self, lattice_rowified: torch.Tensor, dilation: int, filter_extent: int, nr_filters: int,
+               lattice_neighbours: Optional["Lattice"]):  # Lattice.cu:646-667
+        nb = lattice_neighbours if lattice_neighbours is not None else self
+        if not lattice_rowified.is_contiguous():
+            raise ValueError("lattice rowified is not contiguous, call .contiguous() on it")
+        v = lattice_rowified.shape[1] // filter_extent
+        if v != self.val_dim():  # Lattice.cu:648
+            raise ValueError(f"each rowified row should be val_dim*filter_extent long: row {lattice_rowified.shape[1]}, val_dim {self.val_dim()}")
+        nbr = self.neighbours(nb, dilation, False)
+        m = nbr.shape[0]
+        out = torch.empty((m, v), dtype=torch.float32, device=self._dev())
+        lib = _lib.load()
+        _lib.check(lib.ln_row2im(_lib.ptr(nbr), _lib.ptr(lattice_rowified), m, filter_extent, v, _lib.ptr(out), self._stream()), "ln_row2im")
+        self.m_hash_table.m_values_tensor = out  # the reference writes the result into this lattice's values
+        return out
+
+    # ---------------------------------------------------------------- coarse levels
+    def _new_coarse(self) -> "Lattice":
+        capacity = self.m_hash_table.capacity()
+        d = self.pos_dim()
+        dev = self._dev()
+        coarse = Lattice._clone_of(self)
+        coarse.m_name = "coarse_lattice"
+        coarse.m_lvl = self.m_lvl + 1
+        coarse.m_sigmas = [s * 2.0 for s in self.m_sigmas]  # Lattice.cu:679-682 / 718-722
+        coarse._sigmas_tensor = None
+        ht = HashTable(capacity)
+        ht._storage = _TableStorage(capacity, d, dev)
+        ht.m_values_tensor = torch.zeros((1, self.val_dim()), dtype=torch.float32, device=dev)
+        ht.m_nr_filled_tensor = torch.zeros((1,), dtype=torch.int32, device=dev)
+        coarse.m_hash_table = ht
+        ht.clear()
+        return coarse
+
+    def create_coarse_verts(self) -> "Lattice":  # Lattice.cu:670-703
+        coarse = self._new_coarse()
+        lib = _lib.load()
+        m = self.nr_lattice_vertices()
+        tokens = m * (2 * (self.pos_dim() + 1) + 1)
+        ws = self._workspace(lib.ln_build_workspace_bytes(tokens))
+        tf, tc = self.m_hash_table.c_table(), coarse.m_hash_table.c_table()
+        _lib.check(lib.ln_coarsen(C.byref(tf), m, C.byref(tc), _lib.ptr(ws), ws.numel(), self._stream()), "ln_coarsen")
+        coarse.m_hash_table._storage.touch()
+        coarse.m_hash_table.m_nr_filled_is_dirty = True
+        nr = coarse.nr_lattice_vertices()
+        coarse.m_hash_table.m_values_tensor = torch.zeros((nr, self.val_dim()), dtype=torch.float32, device=self._dev())
+        return coarse
+
+    def create_coarse_verts_naive(self, positions_raw: torch.Tensor) -> "Lattice":  # Lattice.cu:706-740
+        self._check_positions(positions_raw)
+        coarse = self._new_coarse()
+        coarse.just_create_verts(positions_raw, False)
+        return coarse
+
+    # ---------------------------------------------------------------- slice family
+    def _check_slice_inputs(self, positions_raw, idx, w):
+        self._check_positions(positions_raw)
+        if self.val_dim() <= 0:
+            raise ValueError("val_dim is 0: splat something first")
+        if positions_raw.shape[1] != self.pos_dim():
+            raise ValueError("position dimension does not match the lattice")
+        n = positions_raw.shape[0]
+        expect = n * (self.pos_dim() + 1)
+        if idx is None or w is None or idx.numel() != expect or w.numel() != expect:  # Lattice.cu:771-773
+            raise ValueError(f"indices / weights must have {expect} elements")
+        return n
+
+    def slice_standalone_with_precomputation(self, positions_raw, splatting_indices_tensor, splatting_weights_tensor):  # Lattice.cu:744-786
+        idx, w = splatting_indices_tensor.contiguous(), splatting_weights_tensor.contiguous()
+        n = self._check_slice_inputs(positions_raw, idx, w)
+        vals = self.values()
+        out = torch.empty((n, self.val_dim()), dtype=torch.float32, device=self._dev())
+        lib = _lib.load()
+        _lib.check(lib.ln_slice_forward(_lib.ptr(vals), _lib.ptr(idx), _lib.ptr(w), n, self.pos_dim(), self.val_dim(), _lib.ptr(out),
+                                        self._stream()), "ln_slice_forward")
+        return out
+
+    def slice_standalone_no_precomputation(self, positions_raw):  # Lattice.cu:789-832
+        self._check_positions(positions_raw)
+        if positions_raw.shape[1] != self.pos_dim():
+            raise ValueError("position dimension does not match the lattice")
+        n, d = positions_raw.shape
+        dev = self._dev()
+        out = torch.empty((n, self.val_dim()), dtype=torch.float32, device=dev)
+        idx = torch.empty((n * (d + 1),), dtype=torch.int32, device=dev)
+        w = torch.empty((n * (d + 1),), dtype=torch.float32, device=dev)
+        lib = _lib.load()
+        t = self.m_hash_table.c_table()
+        _lib.check(lib.ln_slice_no_precomputation(C.byref(t), _lib.ptr(self.values()), _lib.ptr(positions_raw), self._sigmas_host(), n,
+                                                  self.val_dim(), _lib.ptr(out), _lib.ptr(idx), _lib.ptr(w), self._stream()),
+                   "ln_slice_no_precomputation")
+        return out, idx, w
+
+    def gather_standalone_with_precomputation(self, positions_raw, splatting_indices_tensor, splatting_weights_tensor):  # Lattice.cu:878-917
+        idx, w = splatting_indices_tensor.contiguous(), splatting_weights_tensor.contiguous()
+        n = self._check_slice_inputs(positions_raw, idx, w)
+        d, v = self.pos_dim(), self.val_dim()
+        out = torch.empty((n, (d + 1) * (v + 1)), dtype=torch.float32, device=self._dev())
+        lib = _lib.load()
+        _lib.check(lib.ln_gather_forward(_lib.ptr(self.values()), _lib.ptr(idx), _lib.ptr(w), n, d, v, _lib.ptr(out), self._stream()),
+                   "ln_gather_forward")
+        return out
+
+    def gather_standalone_no_precomputation(self, positions_raw):  # Lattice.cu:835-876 (kernel cannot compile in the reference)
+        raise NotImplementedError("gather_no_precomputation is dead code in the reference (LatticeGPU.cuh:2875 names an undeclared symbol)")
+
+    def slice_classify_no_precomputation(self, *args, **kwargs):  # Lattice.cu:920-980 (kernel cannot compile in the reference)
+        raise NotImplementedError("slice_classify_no_precomputation is dead code in the reference (LatticeGPU.cuh:3356)")
+
+    def slice_backwards_standalone_with_precomputation(self, *args, **kwargs):  # Lattice.cu:1045-1065, kernel body commented out
+        raise NotImplementedError("the homogeneous slice backward kernel is commented out in the reference (LatticeGPU.cuh:3467-3536)")
+
+    def slice_classify_with_precomputation(self, positions_raw, delta_weights, linear_clasify_weight, linear_clasify_bias, nr_classes,
+                                           splatting_indices_tensor, splatting_weights_tensor):  # Lattice.cu:982-1039
+        idx, w = splatting_indices_tensor.contiguous(), splatting_weights_tensor.contiguous()
+        n = self._check_slice_inputs(positions_raw, idx, w)
+        dw, lw, lb = delta_weights.contiguous(), linear_clasify_weight.contiguous(), linear_clasify_bias.contiguous()
+        logits = torch.empty((n, nr_classes), dtype=torch.float32, device=self._dev())
+        lib = _lib.load()
+        _lib.check(lib.ln_slice_classify_forward(_lib.ptr(self.values()), _lib.ptr(dw), _lib.ptr(lw), _lib.ptr(lb), _lib.ptr(idx),
+                                                 _lib.ptr(w), n, self.pos_dim(), self.val_dim(), int(nr_classes), _lib.ptr(logits),
+                                                 self._stream()), "ln_slice_classify_forward")
+        return logits
+
+    def slice_backwards_standalone_with_precomputation_no_homogeneous(self, positions_raw, grad_sliced_values, splatting_indices_tensor,
+                                                                      splatting_weights_tensor):  # Lattice.cu:1067-1088
+        idx, w = splatting_indices_tensor.contiguous(), splatting_weights_tensor.contiguous()
+        n = self._check_slice_inputs(positions_raw, idx, w)
+        if grad_sliced_values.dim() != 2 or not grad_sliced_values.is_contiguous():
+            raise ValueError("grad_sliced_values should be contiguous nr_positions x val_dim")
+        v = int(grad_sliced_values.shape[1])
+        gv = torch.zeros((self.nr_lattice_vertices(), v), dtype=torch.float32, device=self._dev())
+        lib = _lib.load()
+        _lib.check(lib.ln_slice_backward(_lib.ptr(grad_sliced_values), _lib.ptr(idx), _lib.ptr(w), n, self.pos_dim(), v, _lib.ptr(gv),
+                                         self._stream()), "ln_slice_backward")
+        self.m_hash_table.m_values_tensor = gv  # result is read back through values() (lattice_funcs.py:507)
+
+    def slice_classify_backwards_with_precomputation(self, grad_class_logits, positions_raw, initial_values, delta_weights,
+                                                     linear_clasify_weight, linear_clasify_bias, nr_classes, grad_lattice_values,
+                                                     grad_delta_weights, grad_linear_clasify_weight, grad_linear_clasify_bias,
+                                                     splatting_indices_tensor, splatting_weights_tensor):  # Lattice.cu:1091-1115
+        idx, w = splatting_indices_tensor.contiguous(), splatting_weights_tensor.contiguous()
+        n = self._check_slice_inputs(positions_raw, idx, w)
+        if grad_class_logits.dim() != 2 or not grad_class_logits.is_contiguous():
+            raise ValueError("grad_class_logits should be contiguous nr_positions x nr_classes")
+        for name, g in (("grad_lattice_values", grad_lattice_values), ("grad_delta_weights", grad_delta_weights),
+                        ("grad_linear_clasify_weight", grad_linear_clasify_weight), ("grad_linear_clasify_bias", grad_linear_clasify_bias)):
+            if not g.is_contiguous():
+                raise ValueError(f"{name} must be contiguous (it is filled in place)")
+        iv, dw, lw = initial_values.contiguous(), delta_weights.contiguous(), linear_clasify_weight.contiguous()
+        lib = _lib.load()
+        _lib.check(lib.ln_slice_classify_backward(_lib.ptr(grad_class_logits), _lib.ptr(iv), _lib.ptr(dw), _lib.ptr(lw), _lib.ptr(idx),
+                                                  _lib.ptr(w), n, self.pos_dim(), int(iv.shape[1]), int(nr_classes),
+                                                  _lib.ptr(grad_lattice_values), _lib.ptr(grad_delta_weights),
+                                                  _lib.ptr(grad_linear_clasify_weight), _lib.ptr(grad_linear_clasify_bias),
+                                                  self._stream()), "ln_slice_classify_backward")
+
+    def gather_backwards_standalone_with_precomputation(self, positions_raw, grad_sliced_values, splatting_indices_tensor,
+                                                        splatting_weights_tensor):  # Lattice.cu:1117-1142
+        idx, w = splatting_indices_tensor.contiguous(), splatting_weights_tensor.contiguous()
+        n = self._check_slice_inputs(positions_raw, idx, w)
+        if grad_sliced_values.dim() != 2 or not grad_sliced_values.is_contiguous():
+            raise ValueError("grad_sliced_values should be contiguous nr_positions x ((val_dim+1)*(pos_dim+1))")
+        d = self.pos_dim()
+        v = grad_sliced_values.shape[1] // (d + 1) - 1
+        gv = torch.zeros((self.nr_lattice_vertices(), v), dtype=torch.float32, device=self._dev())
+        lib = _lib.load()
+        _lib.check(lib.ln_gather_backward(_lib.ptr(grad_sliced_values), _lib.ptr(idx), _lib.ptr(w), n, d, v, _lib.ptr(gv), self._stream()),
+                   "ln_gather_backward")
+        self.m_hash_table.m_values_tensor = gv
+
+    # ---------------------------------------------------------------- getters / setters
+    def clone_lattice(self) -> "Lattice":  # Lattice.cu:1146-1149
+        return Lattice._clone_of(self)
+
+    def increase_sigmas(self, stepsize: float):  # Lattice.cu:1150-1155
+        self.m_sigmas = [s + stepsize for s in self.m_sigmas]
+        self._sigmas_tensor = None
+
+    def set_sigma(self, sigma: float):  # Lattice.cu:1383-1390
+        if len(self.m_sigmas_val_and_extent) != 1:
+            raise ValueError("set_sigma assumes exactly one sigma group")
+        self.m_sigmas = [float(sigma)] * len(self.m_sigmas)
+        self._sigmas_tensor = None
+
+    def val_dim(self) -> int:
+        return self.m_hash_table.val_dim()
+
+    def pos_dim(self) -> int:
+        return self.m_hash_table.pos_dim()
+
+    def capacity(self) -> int:
+        return self.m_hash_table.capacity()
+
+    def name(self) -> str:
+        return self.m_name
+
+    def set_name(self, name: str):
+        self.m_name = name
+
+    def lvl(self) -> int:
+        return self.m_lvl
+
+    def nr_lattice_vertices(self) -> int:  # Lattice.cu:1320-1352
+        ht = self.m_hash_table
+        if ht.m_nr_filled_is_dirty:
+            both = torch.stack([ht.m_nr_filled_tensor[0], ht._storage.status[0]]).cpu()  # ONE blocking readback
+            nr, status = int(both[0]), int(both[1])
+            if status & _lib.LN_STATUS_TABLE_FULL:
+                raise _lib.LatticeNetHipError(f"hash table overflow: capacity {ht.capacity()} is too small for this cloud "
+                                              "(the reference would spin forever, HashTableGPU.cuh:443)")
+            if status & _lib.LN_STATUS_KEY_RANGE:
+                raise _lib.LatticeNetHipError("a lattice key does not fit the packed 64-bit slot format (positions/sigma too large)")
+            ht.m_nr_filled = nr
+            ht.m_nr_filled_is_dirty = False
+        if ht.m_nr_filled < 0 or ht.m_nr_filled >= 1e8:
+            raise _lib.LatticeNetHipError(f"implausible vertex count {ht.m_nr_filled}")
+        return ht.m_nr_filled
+
+    def get_filter_extent(self, neighborhood_size: int) -> int:  # Lattice.cu:1353-1358
+        if neighborhood_size != 1:
+            raise ValueError("only a neighbourhood size of 1 is implemented")
+        return 2 * (self.pos_dim() + 1) + 1
+
+    @staticmethod
+    def get_expected_filter_extent(neighborhood_size: int) -> int:  # Lattice.cu:1359-1364
+        if neighborhood_size != 1:
+            raise ValueError("only a neighbourhood size of 1 is implemented")
+        return 2 * (Lattice.m_expected_position_dimensions + 1) + 1
+
+    def sigmas_tensor(self) -> torch.Tensor:
+        if self._sigmas_tensor is None:
+            self._sigmas_tensor = torch.tensor(self.m_sigmas, dtype=torch.float32)
+        return self._sigmas_tensor
+
+    def positions(self):
+        return self.m_positions
+
+    def hash_table(self) -> HashTable:
+        return self.m_hash_table
+
+    def values(self) -> torch.Tensor:
+        return self.m_hash_table.m_values_tensor
+
+    def set_values(self, new_values: torch.Tensor):  # Lattice.cu:1394-1399
+        self.m_hash_table.set_values(new_values)
+        if new_values.shape[0] != self.nr_lattice_vertices():
+            raise ValueError(f"values have {new_values.shape[0]} rows but the lattice has {self.nr_lattice_vertices()} vertices")
+
+    def set_positions(self, positions_raw: torch.Tensor):
+        self.m_positions = positions_raw

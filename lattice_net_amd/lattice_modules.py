@@ -1,0 +1,157 @@
+"""Thin nn.Modules around the lattice operators — the five op modules that sit directly on the hot
+path (reference latticenet_py/lattice/lattice_modules.py:46-96,174-418), same constructor
+arguments, parameter shapes ([E*V, F] filter banks) and initialisation.  Norm / activation / block
+wrappers of the reference are plain PyTorch and out of scope here.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from .lattice import Lattice
+from .lattice_funcs import (CoarsenLattice, ConvIm2RowLattice, DistributeLattice, FinefyLattice, GatherLattice, SliceLattice,
+                            SplatLattice)
+
+__all__ = ["SplatLatticeModule", "DistributeLatticeModule", "ConvLatticeIm2RowModule", "CoarsenLatticeModule", "FinefyLatticeModule",
+           "SliceLatticeModule", "GatherLatticeModule"]
+
+
+def _kaiming_uniform_fan_out_(weight: torch.Tensor, fan_scale: float = 1.0, std_scale: float = 1.0):
+    """lattice_modules.py:202-207 / 277-283: uniform(-b, b), b = sqrt(3) * gain / sqrt(fan_out)."""
+    fan = torch.nn.init._calculate_correct_fan(weight, "fan_out") * fan_scale
+    gain = torch.nn.init.calculate_gain("relu", 1)
+    std = gain / math.sqrt(fan) * std_scale
+    bound = math.sqrt(3.0) * std
+    with torch.no_grad():
+        weight.uniform_(-bound, bound)
+
+
+def _bias_init_(bias: torch.Tensor, weight: torch.Tensor):
+    _, fan_out = torch.nn.init._calculate_fan_in_and_fan_out(weight)
+    torch.nn.init.uniform_(bias, -1 / math.sqrt(fan_out), 1 / math.sqrt(fan_out))
+
+
+class SplatLatticeModule(torch.nn.Module):  # lattice_modules.py:46-51
+    def forward(self, lattice_py, positions, values):
+        lv, ls_wrap, indices, weights = SplatLattice.apply(lattice_py, positions, values)
+        return lv, ls_wrap.lattice, indices, weights
+
+
+class DistributeLatticeModule(torch.nn.Module):  # lattice_modules.py:52-96
+    """torch_scatter.scatter_mean is replaced by index_add_ (torch_scatter is not part of the ROCm image)."""
+
+    def forward(self, lattice, positions, values, reset_hashmap=True):
+        wrap, distributed, splatting_indices, splatting_weights = DistributeLattice.apply(lattice, positions, values, reset_hashmap)
+        distributed_lattice = wrap.lattice
+        pos_dim = positions.shape[1]
+        distributed_positions = distributed[:, :pos_dim]
+        indices_long = splatting_indices.long()
+        indices_long = torch.where(indices_long < 0, torch.zeros_like(indices_long), indices_long)  # -1 -> bucket 0 (mods:72)
+        nr_rows = int(indices_long.max().item()) + 1
+        sums = torch.zeros((nr_rows, pos_dim), dtype=distributed.dtype, device=distributed.device).index_add_(0, indices_long, distributed_positions)
+        counts = torch.zeros((nr_rows,), dtype=distributed.dtype, device=distributed.device).index_add_(
+            0, indices_long, torch.ones_like(indices_long, dtype=distributed.dtype))
+        mean_positions = sums / counts.clamp(min=1).unsqueeze(1)
+        mean_positions[0, :] = 0  # vertex 0 doubles as the "invalid" bucket (mods:79-81)
+        distributed_mean_positions = torch.index_select(mean_positions, 0, indices_long)
+        distributed = torch.cat([distributed_positions - distributed_mean_positions, distributed[:, pos_dim:]], dim=1)
+        invalid = (indices_long == 0).unsqueeze(1)
+        distributed = distributed.masked_fill(invalid, 0)  # mods:88-94
+        return distributed_lattice, distributed, splatting_indices, splatting_weights
+
+
+class ConvLatticeIm2RowModule(torch.nn.Module):  # lattice_modules.py:174-250
+    def __init__(self, in_channels, out_channels, neighbourhood_size=1, dilation=1, bias=True, device="cuda"):
+        super().__init__()
+        self.neighbourhood_size = neighbourhood_size
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.dilation = dilation
+        self.use_bias = bias
+        self.filter_extent = Lattice.get_expected_filter_extent(neighbourhood_size)
+        self.weight = torch.nn.Parameter(torch.empty(self.filter_extent * in_channels, out_channels, device=device))
+        self.bias = torch.nn.Parameter(torch.empty(out_channels, device=device)) if bias else None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        _kaiming_uniform_fan_out_(self.weight)
+        if self.bias is not None:
+            _bias_init_(self.bias, self.weight)
+
+    def forward(self, lattice_values, lattice_structure):
+        lattice_structure.set_values(lattice_values)
+        assert self.in_channels == lattice_structure.val_dim(), \
+            f"in_channels {self.in_channels} does not match the lattice val_dim {lattice_structure.val_dim()}"
+        # im2row + mm of the reference (mods:239-242) == one fused gather-GEMM here; same maths, no [M, E*V] tensor
+        lv, ls_wrap = ConvIm2RowLattice.apply(lattice_values, lattice_structure, self.weight, self.dilation)
+        ls = ls_wrap.lattice
+        if self.use_bias:
+            lv = lv + self.bias
+        ls.set_values(lv)
+        return lv, ls
+
+
+class CoarsenLatticeModule(torch.nn.Module):  # lattice_modules.py:253-319
+    def __init__(self, in_channels, out_channels, bias=False, device="cuda"):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.neighbourhood_size = 1
+        self.use_bias = bias
+        self.filter_extent = Lattice.get_expected_filter_extent(1)
+        self.weight = torch.nn.Parameter(torch.empty(self.filter_extent * in_channels, out_channels, device=device))
+        self.bias = torch.nn.Parameter(torch.empty(out_channels, device=device)) if bias else None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        _kaiming_uniform_fan_out_(self.weight, fan_scale=0.5, std_scale=2.0)  # mods:277-283
+        if self.bias is not None:
+            _bias_init_(self.bias, self.weight)
+
+    def forward(self, lattice_fine_values, lattice_fine_structure, coarsened_lattice=None):
+        lattice_fine_structure.set_values(lattice_fine_values)
+        assert self.in_channels == lattice_fine_structure.val_dim()
+        lv, ls_wrap = CoarsenLattice.apply(lattice_fine_values, lattice_fine_structure, self.weight, coarsened_lattice)
+        ls = ls_wrap.lattice
+        if self.use_bias:
+            lv = lv + self.bias
+        ls.set_values(lv)
+        return lv, ls
+
+
+class FinefyLatticeModule(torch.nn.Module):  # lattice_modules.py:321-387
+    def __init__(self, in_channels, out_channels, bias=False, device="cuda"):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.neighbourhood_size = 1
+        self.use_bias = bias
+        self.filter_extent = Lattice.get_expected_filter_extent(1)
+        self.weight = torch.nn.Parameter(torch.empty(self.filter_extent * in_channels, out_channels, device=device))
+        self.bias = torch.nn.Parameter(torch.empty(out_channels, device=device)) if bias else None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        _kaiming_uniform_fan_out_(self.weight, fan_scale=0.5, std_scale=2.0)
+        if self.bias is not None:
+            _bias_init_(self.bias, self.weight)
+
+    def forward(self, lattice_coarse_values, lattice_coarse_structure, lattice_fine_structure):
+        lattice_coarse_structure.set_values(lattice_coarse_values)
+        assert self.in_channels == lattice_coarse_structure.val_dim()
+        lv, ls_wrap = FinefyLattice.apply(lattice_coarse_values, lattice_coarse_structure, lattice_fine_structure, self.weight)
+        ls = ls_wrap.lattice
+        if self.use_bias:
+            lv = lv + self.bias
+        ls.set_values(lv)
+        return lv, ls
+
+
+class SliceLatticeModule(torch.nn.Module):  # lattice_modules.py:389-397
+    def forward(self, lattice_values, lattice_structure, positions, splatting_indices=None, splatting_weights=None):
+        lattice_structure.set_values(lattice_values)
+        return SliceLattice.apply(lattice_values, lattice_structure, positions, splatting_indices, splatting_weights)
+
+
+class GatherLatticeModule(torch.nn.Module):  # lattice_modules.py:399-408
+    def forward(self, lattice_values, lattice_structure, positions, splatting_indices, splatting_weights):
+        lattice_structure.set_values(lattice_values)
+        return GatherLattice.apply(lattice_values, lattice_structure, positions, splatting_indices, splatting_weights)

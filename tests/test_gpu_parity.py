@@ -1,0 +1,415 @@
+"""GPU parity tests (run on a real MI355X: `pytest -m gpu`).  Every call goes through the C ABI
+(liblatticenet_hip.so via lattice_net_amd.Lattice).  Checkers: the golden vectors produced by the
+reference kernels (tests/golden) and the CPU oracle (oracle/lattice_oracle.py).
+
+Bars (BASELINE.json north_star): lattice keys, splat indices and neighbour lists bit-exact; fp32
+features within 1e-5 relative.  Outputs whose summation order is fixed (slice, gather, im2row,
+row2im, barycentric weights) are additionally required to be bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import lattice_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+
+
+def dev():
+    return torch.device("cuda", 0)
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def make_lattice(sigma, capacity, d=3):
+    from lattice_net_amd import Lattice
+    return Lattice(sigmas=[float(sigma)] * d, capacity=int(capacity), device=dev())
+
+
+def close(a, b, scale=None, rtol=RTOL):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    s = float(np.max(np.abs(b))) if scale is None else scale
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=rtol * max(s, 1e-30))
+
+
+def oracle_build(pos_raw, sigma, cap, write=True):
+    d = pos_raw.shape[1]
+    pos = O.scale_positions(pos_raw, np.full((d,), sigma, np.float32))
+    t = O.OracleHashTable(cap, d)
+    idx, w = O.build_splat(t, pos, write)
+    return t, pos, idx, w
+
+
+def test_library_is_the_hip_build():
+    import lattice_net_amd as L
+    assert b"gfx950" in L.load_library().ln_version()
+    assert torch.cuda.is_available()
+
+
+@pytest.mark.parametrize("name", ["F1_config1", "F2_boundary", "F9_lidar", "F5_distribute", "F6_slice_classify"])
+def test_build_indices_weights_keys_bit_exact(golden, name):
+    g = golden(name)
+    lat = make_lattice(g["sigma"], g["capacity"])
+    lat.begin_splat()
+    idx, w = lat.just_create_verts(T(g["pos_raw"]), True)
+    m = lat.nr_lattice_vertices()
+    assert m == int(g["nr_filled"])
+    np.testing.assert_array_equal(N(idx), g["idx"])
+    np.testing.assert_array_equal(N(w), g["w"])
+    if "keys" in g:
+        np.testing.assert_array_equal(N(lat.hash_table().m_keys_tensor[:m]), g["keys"])
+        assert int(lat.hash_table().m_keys_tensor[m:].abs().sum()) == 0
+    assert int(lat.hash_table().m_nr_filled_tensor.item()) == m
+
+
+def test_f1_splat_slice_gather_and_backwards(golden):
+    g = golden("F1_config1")
+    from lattice_net_amd import SplatLattice
+    lat = make_lattice(g["sigma"], g["capacity"])
+    pos = T(g["pos_raw"])
+    vals = T(g["vals"])
+    n, v = g["vals"].shape
+    lv, wrap, idx, w = SplatLattice.apply(lat, pos, vals)
+    m = lat.nr_lattice_vertices()
+    assert lv.shape[0] == int(g["capacity"])  # splat leaves the table CAP rows tall (HashTable.cu:32)
+    np.testing.assert_array_equal(N(idx), g["idx"])
+    close(N(lv[:m]), g["values"])  # atomic accumulation order differs
+    assert float(lv[m:].abs().max()) == 0.0
+    # from here on use the golden vertex values so downstream comparisons can be bit-exact
+    lat.set_values(T(g["values"]))
+    sl = lat.slice_standalone_with_precomputation(pos, idx, w)
+    np.testing.assert_array_equal(N(sl), g["slice"])
+    ga = lat.gather_standalone_with_precomputation(pos, idx, w)
+    np.testing.assert_array_equal(N(ga), g["gather"])
+    sl2, i2, w2 = lat.slice_standalone_no_precomputation(T(g["qpos_raw"]))
+    np.testing.assert_array_equal(N(i2), g["idx_nopre"])
+    np.testing.assert_array_equal(N(w2), g["w_nopre"])
+    np.testing.assert_array_equal(N(sl2), g["slice_nopre"])
+    lat.slice_backwards_standalone_with_precomputation_no_homogeneous(pos, T(g["grad_sliced"]), idx, w)
+    close(N(lat.values()), g["slice_bwd"])
+    lat.gather_backwards_standalone_with_precomputation(pos, T(g["grad_gathered"]), idx, w)
+    close(N(lat.values()), g["gather_bwd"])
+
+
+@pytest.mark.parametrize("name,dil,v", [("F1_config1", 1, 4), ("F4_dilation2", 2, 2), ("F9_lidar", 1, 1)])
+def test_neighbour_lists_im2row_row2im_bit_exact(golden, name, dil, v):
+    g = golden(name)
+    lat = make_lattice(g["sigma"], g["capacity"])
+    lat.begin_splat()
+    lat.just_create_verts(T(g["pos_raw"]), False)
+    m = lat.nr_lattice_vertices()
+    vals = g["values"] if "values" in g else np.zeros((m, v), np.float32)
+    lat.set_values(T(vals))
+    E = lat.get_filter_extent(1)
+    assert E == 9
+    suffix = f"_d{dil}"
+    np.testing.assert_array_equal(N(lat.im2rowindices(lat, E, dil, False)), g["im2rowindices" + suffix])
+    if "im2row" + suffix in g:
+        np.testing.assert_array_equal(N(lat.im2row(lat, E, dil, False)), g["im2row" + suffix])
+    if "im2row" + suffix + "_flip" in g:
+        np.testing.assert_array_equal(N(lat.im2row(lat, E, dil, True)), g["im2row" + suffix + "_flip"])
+    if "row2im" + suffix in g:
+        out = lat.row2im(T(g["grad_rowified"]), dil, E, 0, lat)
+        np.testing.assert_array_equal(N(out), g["row2im" + suffix])
+
+
+def test_f3_two_levels(golden):
+    g = golden("F3_two_level")
+    pos = T(g["pos_raw"])
+    fine = make_lattice(g["sigma"], g["capacity"])
+    fine.begin_splat()
+    fine.splat_standalone(pos, T(g["vals"]))
+    mf = fine.nr_lattice_vertices()
+    assert mf == int(g["fine_nr"])
+    np.testing.assert_array_equal(N(fine.hash_table().m_keys_tensor[:mf]), g["fine_keys"])
+    fine.set_values(T(g["fine_values"]))
+    coarse = fine.create_coarse_verts_naive(pos)
+    mc = coarse.nr_lattice_vertices()
+    assert mc == int(g["coarse_nr"]) and coarse.lvl() == 2
+    np.testing.assert_array_equal(N(coarse.hash_table().m_keys_tensor[:mc]), g["coarse_keys"])
+    kc = fine.create_coarse_verts()
+    assert kc.nr_lattice_vertices() == int(g["keycoarse_nr"])
+    np.testing.assert_array_equal(N(kc.hash_table().m_keys_tensor[: kc.nr_lattice_vertices()]), g["keycoarse_keys"])
+    assert tuple(kc.values().shape) == (kc.nr_lattice_vertices(), 4)
+    coarse.set_values(T(g["coarse_values"]))
+    for flip in (False, True):
+        s = "_flip" if flip else ""
+        np.testing.assert_array_equal(N(coarse.im2rowindices(fine, 9, 1, flip)), g["idx_coarse_from_fine" + s])
+        np.testing.assert_array_equal(N(coarse.im2row(fine, 9, 1, flip)), g["row_coarse_from_fine" + s])
+        np.testing.assert_array_equal(N(fine.im2rowindices(coarse, 9, 1, flip)), g["idx_fine_from_coarse" + s])
+        np.testing.assert_array_equal(N(fine.im2row(coarse, 9, 1, flip)), g["row_fine_from_coarse" + s])
+
+
+def test_f5_distribute(golden):
+    g = golden("F5_distribute")
+    lat = make_lattice(g["sigma"], g["capacity"])
+    lat.begin_splat()
+    new, dist, idx, w = lat.distribute(T(g["pos_raw"]), T(g["vals"]), True)
+    assert new.nr_lattice_vertices() == int(g["nr_filled"])
+    np.testing.assert_array_equal(N(idx), g["idx"])
+    np.testing.assert_array_equal(N(w), g["w"])
+    np.testing.assert_array_equal(N(dist), g["distributed"])
+    assert lat.pos_dim() == 3 and lat.val_dim() == 2
+
+
+def test_f6_slice_classify(golden):
+    g = golden("F6_slice_classify")
+    lat = make_lattice(g["sigma"], g["capacity"])
+    pos = T(g["pos_raw"])
+    lat.begin_splat()
+    idx, w = lat.just_create_verts(pos, True)
+    lat.set_values(T(g["lattice_values"]))
+    dw, lw, lb = T(g["delta_w"]), T(g["lin_w"]), T(g["lin_b"])
+    logits = lat.slice_classify_with_precomputation(pos, dw, lw, lb, 5, idx, w)
+    np.testing.assert_array_equal(N(logits), g["logits"])
+    gv = torch.zeros_like(lat.values())
+    gdw, glw, glb = torch.zeros_like(dw), torch.zeros_like(lw), torch.zeros_like(lb)
+    lat.slice_classify_backwards_with_precomputation(T(g["grad_logits"]), pos, lat.values(), dw, lw, lb, 5, gv, gdw, glw, glb, idx, w)
+    close(N(gv), g["g_values"])
+    close(N(gdw), g["g_delta_w"])
+    close(N(glw), g["g_lin_w"])
+    close(N(glb), g["g_lin_b"])
+
+
+def test_f8_pos_dim_2(golden):
+    g = golden("F8_posdim2")
+    pos = T(g["pos_raw"])
+    fine = make_lattice(g["sigma"], g["capacity"], d=2)
+    fine.begin_splat()
+    idx, w = fine.splat_standalone(pos, T(g["vals"]))
+    mf = fine.nr_lattice_vertices()
+    assert mf == int(g["fine_nr"])
+    np.testing.assert_array_equal(N(idx), g["idx"])
+    np.testing.assert_array_equal(N(w), g["w"])
+    np.testing.assert_array_equal(N(fine.hash_table().m_keys_tensor[:mf]), g["fine_keys"])
+    fine.set_values(T(g["fine_values"]))
+    E = fine.get_filter_extent(1)
+    assert E == 7
+    np.testing.assert_array_equal(N(fine.im2rowindices(fine, E, 1, False)), g["idx_same"])
+    np.testing.assert_array_equal(N(fine.im2row(fine, E, 1, False)), g["row_same"])
+    coarse = fine.create_coarse_verts_naive(pos)
+    mc = coarse.nr_lattice_vertices()
+    np.testing.assert_array_equal(N(coarse.hash_table().m_keys_tensor[:mc]), g["coarse_keys"])
+    coarse.set_values(T(g["coarse_values"]))
+    np.testing.assert_array_equal(N(coarse.im2rowindices(fine, E, 1, False)), g["idx_coarse_from_fine"])
+    np.testing.assert_array_equal(N(fine.im2rowindices(coarse, E, 1, False)), g["idx_fine_from_coarse"])
+    np.testing.assert_array_equal(N(fine.im2row(coarse, E, 1, False)), g["row_fine_from_coarse"])
+
+
+def test_f7_near_full_table_every_vertex_is_inserted(golden):
+    """Load 0.97: insertion has no probe cap (HashTableGPU.cuh:443), so numbering must still be canonical."""
+    g = golden("F7_near_full")
+    lat = make_lattice(g["sigma"], g["capacity"])
+    lat.begin_splat()
+    idx, w = lat.just_create_verts(T(g["pos_raw"]), True)
+    assert lat.nr_lattice_vertices() == int(g["nr_filled"])
+    np.testing.assert_array_equal(N(idx), g["idx"])
+    np.testing.assert_array_equal(N(lat.hash_table().m_keys_tensor[: int(g["nr_filled"])]), g["keys"])
+    # retrieval under the 300-probe cap depends on the (race-dependent) slot layout: only require that
+    # a found vertex is the right one
+    lat.set_values(T(g["lattice_values"]))
+    _, i2, _ = lat.slice_standalone_no_precomputation(T(g["pos_raw"]))
+    i2 = N(i2)
+    found = i2 >= 0
+    np.testing.assert_array_equal(i2[found], g["idx"][found])
+    assert found.mean() > 0.5
+
+
+def test_table_overflow_is_reported():
+    from lattice_net_amd import LatticeNetHipError
+    from lattice_net_amd.synthetic import cube_cloud
+    lat = make_lattice(0.05, 500)
+    lat.begin_splat()
+    lat.just_create_verts(T(cube_cloud(2000, 1)), False)
+    with pytest.raises(LatticeNetHipError, match="overflow"):
+        lat.nr_lattice_vertices()
+
+
+def test_key_range_overflow_is_reported():
+    from lattice_net_amd import LatticeNetHipError
+    lat = make_lattice(1e-6, 1000)
+    lat.begin_splat()
+    lat.just_create_verts(T(np.array([[1.0, 2.0, 3.0], [5.0, 5.0, 5.0]], np.float32)), False)
+    with pytest.raises(LatticeNetHipError, match="packed"):
+        lat.nr_lattice_vertices()
+
+
+def test_duplicate_points_contention():
+    """Every point identical: 4 slots take all the insertions (worst-case atomic contention)."""
+    n = 50000
+    pos = np.tile(np.array([[0.3, -0.2, 0.7]], np.float32), (n, 1))
+    lat = make_lattice(0.5, 1000)
+    lat.begin_splat()
+    vals = np.ones((n, 2), np.float32)
+    idx, w = lat.splat_standalone(T(pos), T(vals))
+    assert lat.nr_lattice_vertices() == 4
+    idx = N(idx).reshape(n, 4)
+    assert np.all(idx == np.arange(4)[None, :])
+    wsum = N(w).reshape(n, 4)[0].astype(np.float64)
+    close(N(lat.values()[:4, 0]), wsum * n, rtol=2e-3)  # 50k-term fp32 running sums: rounding grows with the count
+
+
+def test_incremental_build_keeps_existing_rows():
+    from lattice_net_amd.synthetic import cube_cloud
+    a, b = cube_cloud(700, 3), cube_cloud(900, 4)
+    lat = make_lattice(0.2, 40000)
+    lat.begin_splat()
+    ia, _ = lat.just_create_verts(T(a), True)
+    ma = lat.nr_lattice_vertices()
+    ib, _ = lat.just_create_verts(T(b), True)
+    t = O.OracleHashTable(40000, 3)
+    sig = np.full((3,), 0.2, np.float32)
+    oa, _ = O.build_splat(t, O.scale_positions(a, sig))
+    assert t.nr_filled == ma
+    ob, _ = O.build_splat(t, O.scale_positions(b, sig))
+    assert lat.nr_lattice_vertices() == t.nr_filled
+    np.testing.assert_array_equal(N(ia), oa)
+    np.testing.assert_array_equal(N(ib), ob)
+    np.testing.assert_array_equal(N(lat.hash_table().m_keys_tensor[: t.nr_filled]), t.keys[: t.nr_filled])
+
+
+@pytest.mark.parametrize("v,f", [(32, 32), (64, 32), (32, 64), (16, 16), (8, 16), (128, 64), (4, 8), (5, 3), (1, 32)])
+def test_conv_forward_and_filter_gradient(v, f):
+    from lattice_net_amd.synthetic import cube_cloud
+    pos = cube_cloud(3000, 5)
+    lat = make_lattice(0.15, 60000)
+    lat.begin_splat()
+    lat.just_create_verts(T(pos), False)
+    m = lat.nr_lattice_vertices()
+    rng = np.random.default_rng(v * 100 + f)
+    vals = rng.standard_normal((m, v)).astype(np.float32)
+    W = (rng.standard_normal((9 * v, f)) / np.sqrt(9 * v)).astype(np.float32)
+    G = rng.standard_normal((m, f)).astype(np.float32)
+    t, _, _, _ = oracle_build(pos, 0.15, 60000)
+    assert t.nr_filled == m
+    lat.set_values(T(vals))
+    for flip in (False, True):
+        nbr = O.neighbour_rows(t.keys[:m], t, 1, 1, 1, flip)
+        conv = lat.convolve_im2row_standalone(T(W), 1, lat, flip)
+        rows = O.im2row(nbr, vals).astype(np.float64)
+        ref = rows @ W.astype(np.float64)
+        scale = float(np.max(np.abs(rows) @ np.abs(W.astype(np.float64))))
+        close(N(conv.values()), ref, scale=scale)
+        assert conv.val_dim() == f and conv.nr_lattice_vertices() == m
+    nbr = O.neighbour_rows(t.keys[:m], t, 1, 1, 1, False)
+    rows = O.im2row(nbr, vals).astype(np.float64)
+    gf = lat.convolve_im2row_grad_filter(T(G), 1, lat, 9)
+    ref = rows.T @ G.astype(np.float64)
+    scale = float(np.max(np.abs(rows).T @ np.abs(G.astype(np.float64))))
+    close(N(gf), ref, scale=scale)
+
+
+def test_conv_autograd_matches_dense_reference():
+    """ConvIm2RowLattice fwd+bwd against autograd through the explicit im2row matrix (fp64)."""
+    from lattice_net_amd import ConvIm2RowLattice
+    from lattice_net_amd.synthetic import cube_cloud
+    pos = cube_cloud(2000, 6)
+    lat = make_lattice(0.15, 60000)
+    lat.begin_splat()
+    lat.just_create_verts(T(pos), False)
+    m = lat.nr_lattice_vertices()
+    v, f = 32, 32
+    rng = np.random.default_rng(0)
+    vals = torch.tensor(rng.standard_normal((m, v)).astype(np.float32), device=dev(), requires_grad=True)
+    W = torch.tensor((rng.standard_normal((9 * v, f)) / 17).astype(np.float32), device=dev(), requires_grad=True)
+    G = torch.tensor(rng.standard_normal((m, f)).astype(np.float32), device=dev())
+    out, wrap = ConvIm2RowLattice.apply(vals, lat, W, 1)
+    (out * G).sum().backward()
+    t, _, _, _ = oracle_build(pos, 0.15, 60000)
+    nbr = torch.from_numpy(O.neighbour_rows(t.keys[:m], t, 1, 1, 1, False).astype(np.int64))
+    v64 = vals.detach().cpu().double().requires_grad_(True)
+    w64 = W.detach().cpu().double().requires_grad_(True)
+    padded = torch.cat([v64, torch.zeros((1, v), dtype=torch.float64)], 0)
+    rows = padded[torch.where(nbr >= 0, nbr, torch.full_like(nbr, m))].reshape(m, 9 * v)
+    ref = rows @ w64
+    (ref * G.cpu().double()).sum().backward()
+    close(N(out), ref.detach().numpy(), scale=float(ref.abs().max()) * 4)
+    close(N(vals.grad), v64.grad.numpy(), scale=float(v64.grad.abs().max()) * 4)
+    close(N(W.grad), w64.grad.numpy(), scale=float(w64.grad.abs().max()) * 4)
+
+
+def test_coarsen_finefy_autograd():
+    from lattice_net_amd import CoarsenLattice, FinefyLattice
+    from lattice_net_amd.synthetic import cube_cloud
+    pos_np = cube_cloud(1500, 7)
+    pos = T(pos_np)
+    fine = make_lattice(0.2, 30000)
+    fine.begin_splat()
+    fine.just_create_verts(pos, False)
+    fine.set_positions(pos)
+    mf = fine.nr_lattice_vertices()
+    v, f = 16, 32
+    rng = np.random.default_rng(1)
+    fv = torch.tensor(rng.standard_normal((mf, v)).astype(np.float32), device=dev(), requires_grad=True)
+    W1 = torch.tensor((rng.standard_normal((9 * v, f)) / 12).astype(np.float32), device=dev(), requires_grad=True)
+    cv, cwrap = CoarsenLattice.apply(fv, fine, W1)
+    coarse = cwrap.lattice
+    mc = coarse.nr_lattice_vertices()
+    W2 = torch.tensor((rng.standard_normal((9 * f, v)) / 17).astype(np.float32), device=dev(), requires_grad=True)
+    up, _ = FinefyLattice.apply(cv, coarse, fine, W2)
+    G = torch.tensor(rng.standard_normal((mf, v)).astype(np.float32), device=dev())
+    (up * G).sum().backward()
+    # fp64 reference through explicit neighbour matrices from the oracle
+    tf, _, _, _ = oracle_build(pos_np, 0.2, 30000)
+    tc, _, _, _ = oracle_build(pos_np, 0.4, 30000, write=False)
+    assert tf.nr_filled == mf and tc.nr_filled == mc
+    n_cf = torch.from_numpy(O.neighbour_rows(tc.keys[:mc], tf, 2, 1, 1, False).astype(np.int64))
+    n_fc = torch.from_numpy(O.neighbour_rows(tf.keys[:mf], tc, 1, 2, 1, False).astype(np.int64))
+
+    def rowify(vals, nbr, rows_in):
+        padded = torch.cat([vals, torch.zeros((1, vals.shape[1]), dtype=vals.dtype)], 0)
+        return padded[torch.where(nbr >= 0, nbr, torch.full_like(nbr, rows_in))].reshape(nbr.shape[0], -1)
+
+    fv64 = fv.detach().cpu().double().requires_grad_(True)
+    w1 = W1.detach().cpu().double().requires_grad_(True)
+    w2 = W2.detach().cpu().double().requires_grad_(True)
+    c64 = rowify(fv64, n_cf, mf) @ w1
+    u64 = rowify(c64, n_fc, mc) @ w2
+    (u64 * G.cpu().double()).sum().backward()
+    close(N(cv), c64.detach().numpy(), scale=float(c64.abs().max()) * 4)
+    close(N(up), u64.detach().numpy(), scale=float(u64.abs().max()) * 4)
+    close(N(fv.grad), fv64.grad.numpy(), scale=float(fv64.grad.abs().max()) * 8)
+    close(N(W1.grad), w1.grad.numpy(), scale=float(w1.grad.abs().max()) * 8)
+    close(N(W2.grad), w2.grad.numpy(), scale=float(w2.grad.abs().max()) * 8)
+
+
+def test_full_size_c3_scan_against_oracle():
+    """BASELINE config C3 at full size: 120k LiDAR-like points, sigma 0.9, capacity 100k."""
+    from lattice_net_amd.synthetic import lidar_cloud
+    pos_np = lidar_cloud(120000, 0)
+    lat = make_lattice(0.9, 100000)
+    pos = T(pos_np)
+    v = 32
+    vals_np = np.random.default_rng(0).standard_normal((120000, v)).astype(np.float32)
+    lat.begin_splat()
+    idx, w = lat.splat_standalone(pos, T(vals_np))
+    m = lat.nr_lattice_vertices()
+    t, _, oidx, ow = oracle_build(pos_np, 0.9, 100000)
+    assert m == t.nr_filled
+    np.testing.assert_array_equal(N(idx), oidx)
+    np.testing.assert_array_equal(N(w), ow)
+    np.testing.assert_array_equal(N(lat.hash_table().m_keys_tensor[:m]), t.keys[:m])
+    ov = np.zeros((m, v), np.float32)
+    O.splat_accumulate(ov, vals_np, oidx, ow)
+    absacc = np.zeros((m, v), np.float32)
+    O.splat_accumulate(absacc, np.abs(vals_np), oidx, ow)
+    lv = N(lat.values()[:m])
+    assert np.all(np.abs(lv.astype(np.float64) - ov) <= 1e-5 * absacc + 1e-30)
+    nbr = O.neighbour_rows(t.keys[:m], t, 1, 1, 1, False)
+    lat.set_values(lat.values()[:m].contiguous())
+    np.testing.assert_array_equal(N(lat.neighbours(lat, 1, False)), nbr)
+    # slice(splat(x)) round trip: size-independent properties
+    sl = lat.slice_standalone_with_precomputation(pos, idx, w)
+    np.testing.assert_array_equal(N(sl), O.slice_with_precomputation(lv, oidx, ow, 120000))
+    _, i2, w2 = lat.slice_standalone_no_precomputation(pos)
+    np.testing.assert_array_equal(N(i2), oidx)  # slicing at the splat positions finds the splat vertices
+    np.testing.assert_array_equal(N(w2), ow)
