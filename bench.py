@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mpoints/s for one pass of the permutohedral-lattice hot path
+{hash build + splat -> neighbour list + one lattice convolution -> slice}, forward + backward, on a
+120k-point SemanticKITTI-like scan (BASELINE.json config C3: d=3, sigma 0.9, capacity 100000,
+V=F=32, fp32).
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One process per GPU; independent clouds are sharded across ranks (weak scaling, no data-path
+collective).  RCCL is used only to broadcast the filter bank once and to reduce timings /
+checksums.  Rank 0 prints ONE JSON line.  Inputs are resident in HBM before the timed region.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32-input MFMA peak (MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    # name: (n_points, val_dim, nr_filters, sigma, capacity, generator)
+    "C3": dict(n=120000, v=32, f=32, sigma=0.9, capacity=100000, gen="lidar",
+               desc="C3 SemanticKITTI-like scan: 120k pts, d=3, sigma 0.9, capacity 100k, V=F=32, splat->conv->slice fwd+bwd"),
+    "C1": dict(n=1000, v=4, f=4, sigma=0.2, capacity=60000, gen="cube", desc="C1 1k-pt cube (parity-size case)"),
+}
+
+
+def make_cloud(kind: str, n: int, seed: int) -> np.ndarray:
+    from lattice_net_amd import synthetic
+    if kind == "lidar":
+        return synthetic.lidar_cloud(n, seed)
+    return synthetic.cube_cloud(n, seed)
+
+
+def algorithmic_work(kernel: str, n: int, m: int, d: int, v: int, f: int, e: int):
+    """(bound, unit, amount per launch) — SURVEY.md §8d per-unit figures x units per launch."""
+    if kernel == "k_conv_mfma":
+        return "mfma", "TFLOP/s", 2.0 * m * e * v * f
+    if kernel == "k_grad_filter_mfma":
+        return "mfma", "TFLOP/s", 2.0 * m * e * v * f
+    if kernel == "k_scatter_point_rows":  # splat accumulate / slice backward: read rows+idx+w, write vertex rows
+        return "hbm", "GB/s", n * (4.0 * v + 8.0 * (d + 1)) + m * 4.0 * v
+    if kernel == "k_slice_forward":
+        return "hbm", "GB/s", n * (8.0 * (d + 1) + 4.0 * v) + m * 4.0 * v
+    if kernel == "k_insert_points":  # read positions, write idx + w, write keys once
+        return "hbm", "GB/s", n * (4.0 * d + 8.0 * (d + 1)) + m * 4.0 * d
+    if kernel == "k_neighbours":
+        return "hbm", "GB/s", m * (4.0 * d + 4.0 * e)
+    raise ValueError(f"no algorithmic model for kernel {kernel}")
+
+
+def cpu_baseline(cfg, seconds: float):
+    """Pure-PyTorch CPU fallback of the same op chain (oracle/torch_fallback.py), all host cores."""
+    from oracle import torch_fallback as TF
+    n, v, f = cfg["n"], cfg["v"], cfg["f"]
+    pos = torch.from_numpy(make_cloud(cfg["gen"], n, 0))
+    rng = np.random.default_rng(0)
+    vals = torch.from_numpy(rng.standard_normal((n, v)).astype(np.float32))
+    W = torch.from_numpy((rng.standard_normal((9 * v, f)) / np.sqrt(9 * v)).astype(np.float32))
+    G = torch.from_numpy(rng.standard_normal((n, f)).astype(np.float32))
+    threads = torch.get_num_threads()
+    TF.hot_path_step(pos, vals, W, G, cfg["sigma"])  # warm-up
+    times = []
+    t_end = time.perf_counter() + seconds
+    while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 200):
+        t0 = time.perf_counter()
+        TF.hot_path_step(pos, vals, W, G, cfg["sigma"])
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    return {"value": n / med / 1e6, "unit": "Mpoints/s", "cores": threads, "kind": "port",
+            "sample": f"{len(times)} full-size steps of the same workload (median {med * 1e3:.1f} ms/step), "
+                      f"pure-PyTorch CPU fallback oracle/torch_fallback.py, torch threads={threads}, os.cpu_count()={os.cpu_count()}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
+    ap.add_argument("--roofline-kernel", default="k_conv_mfma", help="kernel whose launches are timed live with HIP events")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the CPU baseline leg (0 disables)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (the lattice backend has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if args.gpus != world and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world} rank(s)", file=sys.stderr)
+
+    import lattice_net_amd as L
+    lib = L.load_library()
+
+    cfg = WORKLOADS[args.workload]
+    n, v, f, sigma, cap = cfg["n"], cfg["v"], cfg["f"], cfg["sigma"], cfg["capacity"]
+    d, e = 3, 9
+    # independent clouds per rank (weak scaling); parameters broadcast from rank 0 over RCCL
+    rng = np.random.default_rng(rank)
+    pos = torch.from_numpy(make_cloud(cfg["gen"], n, rank)).to(dev)
+    vals = torch.from_numpy(rng.standard_normal((n, v)).astype(np.float32)).to(dev)
+    G = torch.from_numpy(rng.standard_normal((n, f)).astype(np.float32)).to(dev)
+    bound = float(np.sqrt(3.0) * np.sqrt(2.0) / np.sqrt(f))  # kaiming-uniform fan_out (lattice_modules.py:202-207)
+    W = ((torch.rand((e * v, f), device=dev) * 2 - 1) * bound)
+    if dist is not None:
+        dist.broadcast(W, src=0)
+    W.requires_grad_(True)
+    lat = L.Lattice(sigmas=[sigma] * d, capacity=cap, device=dev)
+    state = {}
+
+    def step():
+        W.grad = None
+        lv, wrap, idx, w = L.SplatLattice.apply(lat, pos, vals)       # clear + hash build + accumulate
+        m = lat.nr_lattice_vertices()                                   # the path's one host readback
+        lv = lv[:m].requires_grad_(True)
+        cv, cwrap = L.ConvIm2RowLattice.apply(lv, lat, W, 1)           # neighbour list + gather-GEMM
+        out = L.SliceLattice.apply(cv, cwrap.lattice, pos, idx, w)     # slice
+        out.backward(G)                                                 # slice bwd, conv bwd (values + filter)
+        state.update(m=m, out=out, gv=lv.grad)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    prof_name = args.roofline_kernel.encode()
+    armed = lib.ln_profile_begin(prof_name, 8 * args.steps + 8) == 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    total_ms, launches = C.c_double(0.0), C.c_int(0)
+    if armed:
+        lib.ln_profile_end(C.byref(total_ms), C.byref(launches))
+
+    m = state["m"]
+    checksum = float(state["out"].double().abs().sum().item())
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        sums = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(sums, torch.tensor([checksum], dtype=torch.float64, device=dev))
+        checksum = float(sum(s.item() for s in sums))
+    max_elapsed = float(t.item())
+
+    if rank == 0:
+        value = n * world * args.steps / max_elapsed / 1e6
+        roofline = None
+        if armed and launches.value > 0:
+            bound_kind, unit, amount = algorithmic_work(args.roofline_kernel, n, m, d, v, f, e)
+            avg_s = total_ms.value / launches.value / 1e3
+            if bound_kind == "hbm":
+                achieved, peak = amount / avg_s / 1e9, HBM_PEAK_GBS
+            else:
+                achieved, peak = amount / avg_s / 1e12, MFMA_F32_PEAK_TFLOPS
+            roofline = {"bound": bound_kind, "achieved": round(achieved, 3), "peak": peak, "unit": unit,
+                        "frac": round(achieved / peak, 4), "traffic": None, "kernel": args.roofline_kernel,
+                        "avg_us": round(avg_s * 1e6, 2), "launches_timed": launches.value}
+        cpu = None
+        if world == 1 and args.cpu_seconds > 0:
+            cpu = cpu_baseline(cfg, args.cpu_seconds)
+        line = {
+            "metric": "Mpoints/sec splat+conv+slice fwd+bwd on 120k-pt SemanticKITTI scan",
+            "value": round(value, 3), "unit": "Mpoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(max_elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": cfg["desc"], "points_per_gpu": n, "vertices": m, "val_dim": v, "nr_filters": f,
+                       "sharding": f"{world} independent cloud(s), one per GPU", "checksum": round(checksum, 3)},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -62,6 +62,14 @@ typedef struct LnTable {
 const char* ln_last_error_string(void);
 const char* ln_version(void);
 
+/* Live per-kernel timing with HIP events recorded on the launch stream (used by bench.py for the
+ * roofline line).  ln_profile_begin arms bracketing of every launch of the kernel called
+ * `kernel_name` (see ln_kernel_names), up to max_samples launches; ln_profile_end waits for the
+ * recorded events, returns the summed duration and the number of launches, and disarms. */
+const char* ln_kernel_names(void);
+int ln_profile_begin(const char* kernel_name, int max_samples);
+int ln_profile_end(double* total_ms, int* launches);
+
 /* HashTable::clear (src/HashTable.cu:49-57): entries=-1, keys=0, nr_filled=0 (+ our slots/status)
  * in one launch.  `values` (may be NULL) is zero-filled too: values_elems floats. */
 int ln_table_clear(const LnTable* t, float* values, long long values_elems, void* stream);
@@ -81,6 +89,25 @@ int ln_build_splat(const LnTable* t, const float* positions_raw, const float* si
 /* splatCacheNaive (LatticeGPU.cuh:926-973): table_values[idx] += vals * w. */
 int ln_splat_accumulate(float* table_values, const float* vals, const int* idx, const float* w, int n, int pos_dim,
                         int val_dim, void* stream);
+
+/* Scatter without per-element global atomics.  ln_csr_build transposes splat indices idx[tokens]
+ * (row per token, <0 = skip) into CSR form — row_start[rows_upper+1], csr_tok[tokens] (tokens
+ * grouped by row) — and cuts every row into segments of at most 16 entries: seg_row / seg_beg
+ * [ln_csr_max_segments()] and the device-side segment count seg_count[1].
+ * ln_csr_reduce_rows then ADDS, for every row,
+ *     dst[row, j] += sum_{t in row} src[(t / src_div) * src_stride + j] * w[t],   j < val_dim
+ * (dst zero-initialised by the caller): one lane group per segment, plain stores for rows that
+ * fit one segment, global atomics only to combine the segments of longer rows.
+ * With src_div = d+1, src_stride = V it replaces splatCacheNaive (LatticeGPU.cuh:926-973) and
+ * slice_backwards_..._no_homogeneous (LatticeGPU.cuh:3540-3623); with src_div = 1,
+ * src_stride = V+1 it replaces gather_backwards_with_precomputation (LatticeGPU.cuh:3761-3817). */
+long long ln_csr_max_segments(long long tokens, int rows_upper);
+size_t ln_csr_workspace_bytes(long long tokens, int rows_upper);
+int ln_csr_build(const int* idx, long long tokens, int rows_upper, int* row_start, int* csr_tok, int* seg_row, int* seg_beg,
+                 int* seg_count, void* workspace, size_t workspace_bytes, void* stream);
+int ln_csr_reduce_rows(const int* row_start, const int* csr_tok, const int* seg_row, const int* seg_beg, const int* seg_count,
+                       long long max_segments, const float* src, const float* w, int val_dim, int src_div, int src_stride,
+                       float* dst, void* stream);
 
 /* distribute kernel (LatticeGPU.cuh:534-650) behind Lattice::distribute (Lattice.cu:351-410):
  * ln_build_splat + the dense rows [pos_scaled(d) | val(V) | bary] -> distributed[n*(d+1), d+V+1]. */

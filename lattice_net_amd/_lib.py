@@ -45,10 +45,17 @@ _T = C.POINTER(LnTable)
 SIGNATURES = {
     "ln_last_error_string": (C.c_char_p, []),
     "ln_version": (C.c_char_p, []),
+    "ln_kernel_names": (C.c_char_p, []),
+    "ln_profile_begin": (_i, [C.c_char_p, _i]),
+    "ln_profile_end": (_i, [C.POINTER(C.c_double), C.POINTER(_i)]),
     "ln_table_clear": (_i, [_T, _vp, _ll, _vp]),
     "ln_build_workspace_bytes": (_sz, [_ll]),
     "ln_build_splat": (_i, [_T, _vp, _vp, _i, _vp, _vp, _i, _vp, _sz, _vp]),
     "ln_splat_accumulate": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "ln_csr_workspace_bytes": (_sz, [_ll, _i]),
+    "ln_csr_max_segments": (_ll, [_ll, _i]),
+    "ln_csr_build": (_i, [_vp, _ll, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ln_csr_reduce_rows": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "ln_distribute": (_i, [_T, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ln_coarsen": (_i, [_T, _i, _T, _vp, _sz, _vp]),
     "ln_neighbours": (_i, [_T, _i, _T, _i, _i, _i, _i, _vp, _vp]),

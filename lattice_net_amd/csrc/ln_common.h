@@ -27,6 +27,21 @@ int ln_check_launch(const char* what);
         }                            \
     } while (0)
 
+// ---- per-kernel live timing (ln_profile_begin / ln_profile_end) ------------------------------
+// Every launch goes through LN_LAUNCH.  When profiling is armed for NAME, the launch is bracketed
+// by hipEventRecord on the SAME stream the kernel is launched on.
+struct LnProfScope {
+    bool armed;
+    hipStream_t stream;
+    LnProfScope(const char* name, hipStream_t st);
+    ~LnProfScope();
+};
+#define LN_LAUNCH(NAME, KERNEL, GRID, BLOCK, LDS, STREAM, ...)                  \
+    do {                                                                        \
+        LnProfScope ln_prof_scope_(NAME, STREAM);                               \
+        hipLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, STREAM, __VA_ARGS__);      \
+    } while (0)
+
 // ---- key packing -----------------------------------------------------------------------
 // A lattice key (first d coordinates, int32) is packed into one 64-bit word so that a slot can
 // be claimed and its key published by a single 64-bit CAS.  bits per coordinate = min(32, 63/d);

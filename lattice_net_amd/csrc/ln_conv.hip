@@ -122,10 +122,10 @@ static bool ln_conv_launch_v(int nt, const int* nbr, const float* values, const 
                              hipStream_t st) {
     const dim3 grid(ln_div_up(m, 64)), block(256);
     switch (nt) {
-        case 1: hipLaunchKernelGGL((k_conv_mfma<V, 1>), grid, block, 0, st, nbr, values, filter, m, E, out); return true;
-        case 2: hipLaunchKernelGGL((k_conv_mfma<V, 2>), grid, block, 0, st, nbr, values, filter, m, E, out); return true;
-        case 4: hipLaunchKernelGGL((k_conv_mfma<V, 4>), grid, block, 0, st, nbr, values, filter, m, E, out); return true;
-        case 8: if constexpr (V <= 64) { hipLaunchKernelGGL((k_conv_mfma<V, 8>), grid, block, 0, st, nbr, values, filter, m, E, out); return true; } return false;
+        case 1: LN_LAUNCH("k_conv_mfma", (k_conv_mfma<V, 1>), grid, block, 0, st, nbr, values, filter, m, E, out); return true;
+        case 2: LN_LAUNCH("k_conv_mfma", (k_conv_mfma<V, 2>), grid, block, 0, st, nbr, values, filter, m, E, out); return true;
+        case 4: LN_LAUNCH("k_conv_mfma", (k_conv_mfma<V, 4>), grid, block, 0, st, nbr, values, filter, m, E, out); return true;
+        case 8: if constexpr (V <= 64) { LN_LAUNCH("k_conv_mfma", (k_conv_mfma<V, 8>), grid, block, 0, st, nbr, values, filter, m, E, out); return true; } return false;
         default: return false;
     }
 }
@@ -150,7 +150,7 @@ extern "C" int ln_conv_forward(const int* nbr, const float* values_neigh, const 
     }
     if (!done) {
         const long long work = (long long)m * nr_filters;
-        hipLaunchKernelGGL(k_conv_generic, dim3(ln_div_up(work, 256)), dim3(256), 0, st, nbr, values_neigh, filter, work,
+        LN_LAUNCH("k_conv_generic", k_conv_generic, dim3(ln_div_up(work, 256)), dim3(256), 0, st, nbr, values_neigh, filter, work,
                            filter_extent, val_dim, nr_filters, out);
     }
     return ln_check_launch("ln_conv_forward");
@@ -242,12 +242,18 @@ __global__ void __launch_bounds__(256)
     grad_filter[g] = acc;
 }
 
+// 64 outputs per workgroup; the slabs are split over 4 thread rows and combined through LDS
 __global__ void __launch_bounds__(256) k_reduce_slabs(const float* __restrict__ partial, int nslabs, int total, float* __restrict__ out) {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= total) return;
+    __shared__ float s_part[4][64];
+    const int o = threadIdx.x & 63;
+    const int part = threadIdx.x >> 6;
+    const int g = blockIdx.x * 64 + o;
     float acc = 0.0f;
-    for (int s = 0; s < nslabs; ++s) acc += partial[(size_t)s * total + g];
-    out[g] = acc;
+    if (g < total)
+        for (int s = part; s < nslabs; s += 4) acc += partial[(size_t)s * total + g];
+    s_part[part][o] = acc;
+    __syncthreads();
+    if (part == 0 && g < total) out[g] = (s_part[0][o] + s_part[1][o]) + (s_part[2][o] + s_part[3][o]);
 }
 
 static bool ln_gf_mfma_supported(int val_dim, int nr_filters) {
@@ -281,14 +287,14 @@ extern "C" int ln_conv_grad_filter(const int* nbr, const float* values_neigh, co
         const int vt = val_dim / 16, ft = nr_filters / 16;
 #define LN_GF_CASE(A, B)                                                                                                    \
     if (vt == A && ft == B)                                                                                                 \
-        hipLaunchKernelGGL((k_grad_filter_mfma<A, B>), grid, block, 0, st, nbr, values_neigh, grad_out, m, filter_extent, partial);
+        LN_LAUNCH("k_grad_filter_mfma", (k_grad_filter_mfma<A, B>), grid, block, 0, st, nbr, values_neigh, grad_out, m, filter_extent, partial);
         LN_GF_CASE(1, 1) LN_GF_CASE(1, 2) LN_GF_CASE(1, 4) LN_GF_CASE(2, 1) LN_GF_CASE(2, 2) LN_GF_CASE(2, 4) LN_GF_CASE(4, 1)
         LN_GF_CASE(4, 2) LN_GF_CASE(4, 4)
 #undef LN_GF_CASE
         // slabs are laid out [chunk][e][V*F]; summing over chunks with stride E*V*F
-        hipLaunchKernelGGL(k_reduce_slabs, dim3(ln_div_up(total, 256)), dim3(256), 0, st, partial, chunks, total, grad_filter);
+        LN_LAUNCH("k_reduce_slabs", k_reduce_slabs, dim3(ln_div_up(total, 64)), dim3(256), 0, st, partial, chunks, total, grad_filter);
     } else {
-        hipLaunchKernelGGL(k_grad_filter_generic, dim3(ln_div_up(total, 256)), dim3(256), 0, st, nbr, values_neigh, grad_out, m,
+        LN_LAUNCH("k_grad_filter_generic", k_grad_filter_generic, dim3(ln_div_up(total, 256)), dim3(256), 0, st, nbr, values_neigh, grad_out, m,
                            filter_extent, val_dim, nr_filters, grad_filter);
     }
     return ln_check_launch("ln_conv_grad_filter");

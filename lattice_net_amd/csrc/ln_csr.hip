@@ -1,0 +1,273 @@
+// Vertex -> contributions adjacency (CSR) and the scatter it enables without per-element atomics.
+//
+// The reference scatters point rows onto lattice vertices with one global fp32 atomicAdd per
+// (point, simplex vertex, channel): splatCacheNaive (LatticeGPU.cuh:937-971), slice backward
+// (LatticeGPU.cuh:3574-3613), gather backward (LatticeGPU.cuh:3778-3814).  On MI355X those
+// N*(d+1)*V device-scope float atomics are executed at the memory side and dominate the whole
+// path (291 us per launch at N=120k, V=32).  Here the splat indices are transposed ONCE per
+// lattice build into CSR form (row_start[M+1], csr_tok[T]: the tokens p*(d+1)+r that touch each
+// vertex), costing one int atomic per token, and every scatter becomes a gather-reduce.
+//
+// Vertex degrees are heavily skewed (a LiDAR scan puts thousands of points on the vertices next to
+// the sensor), so the unit of work is a SEGMENT: at most LN_SEG consecutive CSR entries of one row.
+// A lane group reduces one segment in registers; rows that fit one segment are written with a plain
+// store, longer rows combine their segments with global atomicAdd (few, and only on hot rows).
+#include "ln_common.h"
+
+#define LN_SCAN_BLOCK 1024
+#define LN_SEG 16
+
+__global__ void __launch_bounds__(256)
+    k_csr_count(const int* __restrict__ idx, long long tokens, int rows_upper, int* __restrict__ cnt, int* __restrict__ pos) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= tokens) return;
+    const int row = idx[t];
+    pos[t] = (row >= 0 && row < rows_upper) ? atomicAdd(&cnt[row], 1) : -1;
+}
+
+__device__ __forceinline__ int ln_wave_incl_scan(int v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(v, off, 64);
+        if (lane >= off) v += o;
+    }
+    return v;
+}
+
+// exclusive scans inside blocks of 1024 rows of (a) the token counts and (b) the segment counts
+__global__ void __launch_bounds__(LN_SCAN_BLOCK)
+    k_csr_scan_local(const int* __restrict__ cnt, int rows_upper, int* __restrict__ local_tok, int* __restrict__ local_seg,
+                     int* __restrict__ block_tot) {
+    __shared__ int s_tok[16];
+    __shared__ int s_seg[16];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int i = blockIdx.x * LN_SCAN_BLOCK + tid;
+    const int c = (i < rows_upper) ? cnt[i] : 0;
+    const int sg = (c + LN_SEG - 1) / LN_SEG;
+    const int ic = ln_wave_incl_scan(c, lane);
+    const int is = ln_wave_incl_scan(sg, lane);
+    if (lane == 63) {
+        s_tok[wave] = ic;
+        s_seg[wave] = is;
+    }
+    __syncthreads();
+    int off_t = 0, off_s = 0;
+    for (int k = 0; k < wave; ++k) {
+        off_t += s_tok[k];
+        off_s += s_seg[k];
+    }
+    if (i < rows_upper) {
+        local_tok[i] = off_t + ic - c;
+        local_seg[i] = off_s + is - sg;
+    }
+    if (tid == LN_SCAN_BLOCK - 1) {
+        block_tot[2 * blockIdx.x] = off_t + ic;
+        block_tot[2 * blockIdx.x + 1] = off_s + is;
+    }
+}
+
+// single workgroup: exclusive scan of the (token, segment) block totals; totals land at index nb
+__global__ void __launch_bounds__(1024) k_csr_scan_top(const int* __restrict__ block_tot, int nb, int* __restrict__ block_off,
+                                                       int* __restrict__ seg_count) {
+    __shared__ int s_tok[16];
+    __shared__ int s_seg[16];
+    __shared__ int s_run[2];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    if (tid < 2) s_run[tid] = 0;
+    __syncthreads();
+    for (int start = 0; start < nb; start += 1024) {
+        const int i = start + tid;
+        const int c = (i < nb) ? block_tot[2 * i] : 0;
+        const int sg = (i < nb) ? block_tot[2 * i + 1] : 0;
+        const int ic = ln_wave_incl_scan(c, lane);
+        const int is = ln_wave_incl_scan(sg, lane);
+        if (lane == 63) {
+            s_tok[wave] = ic;
+            s_seg[wave] = is;
+        }
+        __syncthreads();
+        int off_t = 0, off_s = 0;
+        for (int k = 0; k < wave; ++k) {
+            off_t += s_tok[k];
+            off_s += s_seg[k];
+        }
+        const int rt = s_run[0], rs = s_run[1];
+        if (i < nb) {
+            block_off[2 * i] = rt + off_t + ic - c;
+            block_off[2 * i + 1] = rs + off_s + is - sg;
+        }
+        __syncthreads();
+        if (tid == 1023) {
+            s_run[0] = rt + off_t + ic;
+            s_run[1] = rs + off_s + is;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        block_off[2 * nb] = s_run[0];
+        block_off[2 * nb + 1] = s_run[1];
+        *seg_count = s_run[1];
+    }
+}
+
+__global__ void __launch_bounds__(256)
+    k_csr_fill(const int* __restrict__ idx, const int* __restrict__ pos, long long tokens, int rows_upper,
+               const int* __restrict__ local_tok, const int* __restrict__ local_seg, const int* __restrict__ block_off, int nb,
+               int* __restrict__ row_start, int* __restrict__ csr_tok, int* __restrict__ seg_row, int* __restrict__ seg_beg) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t <= rows_upper) row_start[t] = (t < rows_upper) ? local_tok[t] + block_off[2 * (t / LN_SCAN_BLOCK)] : block_off[2 * nb];
+    if (t < tokens) {
+        const int p = pos[t];
+        if (p >= 0) {
+            const int row = idx[t];
+            const int blk = row / LN_SCAN_BLOCK;
+            const int rbeg = local_tok[row] + block_off[2 * blk];
+            csr_tok[rbeg + p] = int(t);
+            if (p % LN_SEG == 0) {  // this token opens a segment
+                const int sid = local_seg[row] + block_off[2 * blk + 1] + p / LN_SEG;
+                seg_row[sid] = row;
+                seg_beg[sid] = rbeg + p;
+            }
+        }
+    }
+}
+
+static size_t ln_align256c(size_t x) { return (x + 255) & ~size_t(255); }
+
+extern "C" long long ln_csr_max_segments(long long tokens, int rows_upper) {
+    if (tokens < 0) tokens = 0;
+    const long long rows = tokens < rows_upper ? tokens : rows_upper;
+    return rows + tokens / LN_SEG + 1;
+}
+
+extern "C" size_t ln_csr_workspace_bytes(long long tokens, int rows_upper) {
+    if (tokens < 1) tokens = 1;
+    if (rows_upper < 1) rows_upper = 1;
+    const size_t nb = (size_t)ln_div_up(rows_upper, LN_SCAN_BLOCK);
+    return ln_align256c((size_t)rows_upper * 4) * 3 + ln_align256c((size_t)tokens * 4) + ln_align256c(nb * 8) + ln_align256c((nb + 1) * 8);
+}
+
+extern "C" int ln_csr_build(const int* idx, long long tokens, int rows_upper, int* row_start, int* csr_tok, int* seg_row,
+                            int* seg_beg, int* seg_count, void* workspace, size_t workspace_bytes, void* stream) {
+    LN_REQUIRE(tokens >= 0 && rows_upper >= 1, LN_ERR_ARG, "ln_csr_build: bad sizes");
+    LN_REQUIRE(row_start && seg_count && (tokens == 0 || (idx && csr_tok && seg_row && seg_beg)), LN_ERR_ARG, "ln_csr_build: null buffer");
+    LN_REQUIRE(workspace && workspace_bytes >= ln_csr_workspace_bytes(tokens, rows_upper), LN_ERR_WORKSPACE,
+               "ln_csr_build: workspace too small");
+    LN_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, LN_ERR_WORKSPACE, "ln_csr_build: workspace must be 256-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = ln_div_up(rows_upper, LN_SCAN_BLOCK);
+    char* p = static_cast<char*>(workspace);
+    int* cnt = reinterpret_cast<int*>(p);
+    p += ln_align256c((size_t)rows_upper * 4);
+    int* local_tok = reinterpret_cast<int*>(p);
+    p += ln_align256c((size_t)rows_upper * 4);
+    int* local_seg = reinterpret_cast<int*>(p);
+    p += ln_align256c((size_t)rows_upper * 4);
+    int* pos = reinterpret_cast<int*>(p);
+    p += ln_align256c((size_t)(tokens < 1 ? 1 : tokens) * 4);
+    int* block_tot = reinterpret_cast<int*>(p);
+    p += ln_align256c((size_t)nb * 8);
+    int* block_off = reinterpret_cast<int*>(p);
+    if (hipMemsetAsync(cnt, 0, (size_t)rows_upper * 4, st) != hipSuccess) return ln_check_launch("ln_csr_build(memset)");
+    if (tokens > 0)
+        LN_LAUNCH("k_csr_count", k_csr_count, dim3(ln_div_up(tokens, 256)), dim3(256), 0, st, idx, tokens, rows_upper, cnt, pos);
+    LN_LAUNCH("k_csr_scan_local", k_csr_scan_local, dim3(nb), dim3(LN_SCAN_BLOCK), 0, st, cnt, rows_upper, local_tok, local_seg, block_tot);
+    LN_LAUNCH("k_csr_scan_top", k_csr_scan_top, dim3(1), dim3(1024), 0, st, block_tot, nb, block_off, seg_count);
+    const long long work = (tokens > rows_upper + 1) ? tokens : (long long)rows_upper + 1;
+    LN_LAUNCH("k_csr_fill", k_csr_fill, dim3(ln_div_up(work, 256)), dim3(256), 0, st, idx, pos, tokens, rows_upper, local_tok, local_seg,
+              block_off, nb, row_start, csr_tok, seg_row, seg_beg);
+    return ln_check_launch("ln_csr_build");
+}
+
+// dst[row, j] += sum over the row's tokens t of src[(t / src_div) * src_stride + j] * w[t]   (j < V)
+// One lane group per segment; LN_SEG/U batches of U independent gathers per lane.
+template <int VEC>
+__global__ void __launch_bounds__(256)
+    k_csr_reduce_segments(const int* __restrict__ row_start, const int* __restrict__ csr_tok, const int* __restrict__ seg_row,
+                          const int* __restrict__ seg_beg, const int* __restrict__ seg_count, const float* __restrict__ src,
+                          const float* __restrict__ w, int chunks, int lanes_per_seg, int src_div, int src_stride,
+                          float* __restrict__ dst) {
+    constexpr int U = 4;
+    const long long gt = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long sid = gt / lanes_per_seg;
+    const int lc = int(gt - sid * lanes_per_seg);
+    if (sid >= *seg_count) return;
+    const int row = seg_row[sid];
+    const int beg = seg_beg[sid];
+    const int rbeg = row_start[row];
+    const int rend = row_start[row + 1];
+    const int end = min(beg + LN_SEG, rend);
+    const bool single = (rend - rbeg) <= LN_SEG;
+    const int V = chunks * VEC;
+    for (int c = lc; c < chunks; c += lanes_per_seg) {
+        float acc[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+        for (int e0 = beg; e0 < end; e0 += U) {
+            int tk[U];
+            float wt[U];
+            float x[U][VEC];
+#pragma unroll
+            for (int u = 0; u < U; ++u) tk[u] = (e0 + u < end) ? csr_tok[e0 + u] : -1;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                wt[u] = 0.f;
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) x[u][k] = 0.f;
+                if (tk[u] >= 0) {
+                    wt[u] = w[tk[u]];
+                    const float* sp = src + (size_t)(tk[u] / src_div) * src_stride + c * VEC;
+                    if constexpr (VEC == 4) {
+                        const float4 v4 = *reinterpret_cast<const float4*>(sp);
+                        x[u][0] = v4.x; x[u][1] = v4.y; x[u][2] = v4.z; x[u][3] = v4.w;
+                    } else {
+                        x[u][0] = sp[0];
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) acc[k] = fmaf(x[u][k], wt[u], acc[k]);
+        }
+        float* d = dst + (size_t)row * V + c * VEC;
+        if (single) {
+            if constexpr (VEC == 4) {
+                *reinterpret_cast<float4*>(d) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            } else {
+                d[0] = acc[0];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) __hip_atomic_fetch_add(d + k, acc[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+extern "C" int ln_csr_reduce_rows(const int* row_start, const int* csr_tok, const int* seg_row, const int* seg_beg,
+                                  const int* seg_count, long long max_segments, const float* src, const float* w, int val_dim,
+                                  int src_div, int src_stride, float* dst, void* stream) {
+    LN_REQUIRE(max_segments >= 0 && val_dim >= 1 && src_div >= 1 && src_stride >= val_dim, LN_ERR_ARG, "ln_csr_reduce_rows: bad sizes");
+    LN_REQUIRE(max_segments == 0 || (row_start && csr_tok && seg_row && seg_beg && seg_count && src && w && dst), LN_ERR_ARG,
+               "ln_csr_reduce_rows: null buffer");
+    if (max_segments == 0) return LN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec4 = (val_dim % 4 == 0) && (src_stride % 4 == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0) &&
+                      ((reinterpret_cast<uintptr_t>(dst) & 15) == 0);
+    const int chunks = vec4 ? val_dim / 4 : val_dim;
+    int lanes = 1;
+    while (lanes < chunks && lanes < 64) lanes <<= 1;
+    const long long work = max_segments * lanes;
+    const dim3 grid(ln_div_up(work, 256)), block(256);
+    if (vec4)
+        LN_LAUNCH("k_csr_reduce_segments", k_csr_reduce_segments<4>, grid, block, 0, st, row_start, csr_tok, seg_row, seg_beg, seg_count, src,
+                  w, chunks, lanes, src_div, src_stride, dst);
+    else
+        LN_LAUNCH("k_csr_reduce_segments", k_csr_reduce_segments<1>, grid, block, 0, st, row_start, csr_tok, seg_row, seg_beg, seg_count, src,
+                  w, chunks, lanes, src_div, src_stride, dst);
+    return ln_check_launch("ln_csr_reduce_rows");
+}

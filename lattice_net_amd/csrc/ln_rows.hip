@@ -81,7 +81,7 @@ static int ln_scatter_point_rows(const char* who, float* dst, const float* src, 
     LN_DISPATCH_VEC(val_dim, {
         const int chunks = val_dim / VEC;
         const long long work = (long long)n * chunks;
-        hipLaunchKernelGGL(k_scatter_point_rows<VEC>, dim3(ln_div_up(work, 256)), dim3(256), 0, (hipStream_t)stream, dst, src, idx,
+        LN_LAUNCH("k_scatter_point_rows", k_scatter_point_rows<VEC>, dim3(ln_div_up(work, 256)), dim3(256), 0, (hipStream_t)stream, dst, src, idx,
                            w, work, pos_dim + 1, chunks);
     });
     return ln_check_launch(who);
@@ -129,7 +129,7 @@ extern "C" int ln_slice_forward(const float* values, const int* idx, const float
     LN_DISPATCH_VEC(val_dim, {
         const int chunks = val_dim / VEC;
         const long long work = (long long)n * chunks;
-        hipLaunchKernelGGL(k_slice_forward<VEC>, dim3(ln_div_up(work, 256)), dim3(256), 0, (hipStream_t)stream, values, idx, w, work,
+        LN_LAUNCH("k_slice_forward", k_slice_forward<VEC>, dim3(ln_div_up(work, 256)), dim3(256), 0, (hipStream_t)stream, values, idx, w, work,
                            pos_dim + 1, chunks, out);
     });
     return ln_check_launch("ln_slice_forward");
@@ -174,7 +174,7 @@ extern "C" int ln_gather_forward(const float* values, const int* idx, const floa
     if (rc) return rc;
     if (n == 0) return LN_OK;
     const long long work = (long long)n * (pos_dim + 1) * (val_dim + 1);
-    hipLaunchKernelGGL(k_gather_forward, dim3(ln_div_up(work, 256)), dim3(256), 0, (hipStream_t)stream, values, idx, w, work, val_dim,
+    LN_LAUNCH("k_gather_forward", k_gather_forward, dim3(ln_div_up(work, 256)), dim3(256), 0, (hipStream_t)stream, values, idx, w, work, val_dim,
                        out);
     return ln_check_launch("ln_gather_forward");
 }
@@ -197,7 +197,7 @@ extern "C" int ln_gather_backward(const float* grad_gathered, const int* idx, co
     if (rc) return rc;
     if (n == 0) return LN_OK;
     const long long work = (long long)n * (pos_dim + 1) * (val_dim + 1);
-    hipLaunchKernelGGL(k_gather_backward, dim3(ln_div_up(work, 256)), dim3(256), 0, (hipStream_t)stream, grad_gathered, idx, w, work,
+    LN_LAUNCH("k_gather_backward", k_gather_backward, dim3(ln_div_up(work, 256)), dim3(256), 0, (hipStream_t)stream, grad_gathered, idx, w, work,
                        val_dim, grad_values);
     return ln_check_launch("ln_gather_backward");
 }
@@ -227,7 +227,7 @@ extern "C" int ln_im2row(const int* nbr, const float* values_neigh, int m, int f
     LN_DISPATCH_VEC(val_dim, {
         const int chunks = val_dim / VEC;
         const long long work = (long long)m * filter_extent * chunks;
-        hipLaunchKernelGGL(k_im2row<VEC>, dim3(ln_div_up(work, 256)), dim3(256), 0, (hipStream_t)stream, nbr, values_neigh, work,
+        LN_LAUNCH("k_im2row", k_im2row<VEC>, dim3(ln_div_up(work, 256)), dim3(256), 0, (hipStream_t)stream, nbr, values_neigh, work,
                            chunks, out);
     });
     return ln_check_launch("ln_im2row");
@@ -251,7 +251,7 @@ extern "C" int ln_im2rowindices(const int* nbr, int m, int filter_extent, int va
     LN_REQUIRE(m == 0 || (nbr && out), LN_ERR_ARG, "ln_im2rowindices: null buffer");
     if (m == 0) return LN_OK;
     const long long work = (long long)m * filter_extent * val_dim;
-    hipLaunchKernelGGL(k_im2rowindices, dim3(ln_div_up(work, 256)), dim3(256), 0, (hipStream_t)stream, nbr, work, filter_extent,
+    LN_LAUNCH("k_im2rowindices", k_im2rowindices, dim3(ln_div_up(work, 256)), dim3(256), 0, (hipStream_t)stream, nbr, work, filter_extent,
                        val_dim, out);
     return ln_check_launch("ln_im2rowindices");
 }
@@ -287,7 +287,7 @@ extern "C" int ln_row2im(const int* nbr, const float* rowified, int m, int filte
     LN_DISPATCH_VEC(val_dim, {
         const int chunks = val_dim / VEC;
         const long long work = (long long)m * chunks;
-        hipLaunchKernelGGL(k_row2im<VEC>, dim3(ln_div_up(work, 256)), dim3(256), 0, (hipStream_t)stream, nbr, rowified, work,
+        LN_LAUNCH("k_row2im", k_row2im<VEC>, dim3(ln_div_up(work, 256)), dim3(256), 0, (hipStream_t)stream, nbr, rowified, work,
                            filter_extent, chunks, out);
     });
     return ln_check_launch("ln_row2im");
@@ -328,7 +328,7 @@ extern "C" int ln_slice_classify_forward(const float* values, const float* delta
     LN_REQUIRE(nr_classes >= 1 && (n == 0 || (delta_w && lin_w && lin_b && w)), LN_ERR_ARG, "ln_slice_classify_forward: bad args");
     if (n == 0) return LN_OK;
     const long long work = (long long)n * nr_classes;
-    hipLaunchKernelGGL(k_slice_classify_forward, dim3(ln_div_up(work, 256)), dim3(256), 0, (hipStream_t)stream, values, delta_w, lin_w,
+    LN_LAUNCH("k_slice_classify_forward", k_slice_classify_forward, dim3(ln_div_up(work, 256)), dim3(256), 0, (hipStream_t)stream, values, delta_w, lin_w,
                        lin_b, idx, w, work, pos_dim + 1, val_dim, nr_classes, logits);
     return ln_check_launch("ln_slice_classify_forward");
 }
@@ -414,7 +414,7 @@ extern "C" int ln_slice_classify_backward(const float* grad_logits, const float*
     const size_t lds = sizeof(float) * ((size_t)LN_SC_PB * (val_dim + nr_classes) + (size_t)nr_classes * val_dim);
     LN_REQUIRE(lds <= 64 * 1024, LN_ERR_UNSUPPORTED, "ln_slice_classify_backward: V=%d C=%d need %zu B of LDS (max 65536)", val_dim,
                nr_classes, lds);
-    hipLaunchKernelGGL(k_slice_classify_backward, dim3(ln_div_up(n, LN_SC_PB)), dim3(256), lds, (hipStream_t)stream, grad_logits,
+    LN_LAUNCH("k_slice_classify_backward", k_slice_classify_backward, dim3(ln_div_up(n, LN_SC_PB)), dim3(256), lds, (hipStream_t)stream, grad_logits,
                        values, delta_w, lin_w, idx, w, n, pos_dim + 1, val_dim, nr_classes, g_values, g_delta_w, g_lin_w, g_lin_b);
     return ln_check_launch("ln_slice_classify_backward");
 }

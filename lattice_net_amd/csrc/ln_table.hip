@@ -42,6 +42,80 @@ int ln_check_launch(const char* what) {
 }
 
 extern "C" const char* ln_last_error_string(void) { return g_ln_error; }
+
+// ------------------------------------------------------------------------------------------
+// live per-kernel timing: HIP events recorded around each launch of ONE named kernel, on the
+// stream it is launched on (bench.py's roofline line is computed from these)
+// ------------------------------------------------------------------------------------------
+#include <vector>
+namespace {
+struct LnProfState {
+    char name[64] = "";
+    int max_samples = 0;
+    std::vector<hipEvent_t> starts, stops;
+    size_t used = 0;
+};
+LnProfState g_prof;
+}  // namespace
+
+LnProfScope::LnProfScope(const char* name, hipStream_t st) : armed(false), stream(st) {
+    if (g_prof.max_samples > 0 && g_prof.used < g_prof.starts.size() && strcmp(name, g_prof.name) == 0) {
+        armed = true;
+        (void)hipEventRecord(g_prof.starts[g_prof.used], stream);
+    }
+}
+LnProfScope::~LnProfScope() {
+    if (armed) {
+        (void)hipEventRecord(g_prof.stops[g_prof.used], stream);
+        ++g_prof.used;
+    }
+}
+
+extern "C" const char* ln_kernel_names(void) { return "k_conv_generic,k_conv_mfma,k_csr_count,k_csr_fill,k_csr_reduce_segments,k_csr_scan_local,k_csr_scan_top,k_finalize,k_gather_backward,k_gather_forward,k_grad_filter_generic,k_grad_filter_mfma,k_im2row,k_im2rowindices,k_insert_coarse,k_insert_points,k_mark_first,k_neighbours,k_reduce_slabs,k_retrieve_points,k_row2im,k_scan_blocks,k_scatter_point_rows,k_slice_classify_backward,k_slice_classify_forward,k_slice_forward,k_table_clear"; }
+
+extern "C" int ln_profile_begin(const char* kernel_name, int max_samples) {
+    LN_REQUIRE(kernel_name && strlen(kernel_name) < sizeof(g_prof.name) && max_samples > 0, LN_ERR_ARG, "ln_profile_begin: bad args");
+    LN_REQUIRE(g_prof.max_samples == 0, LN_ERR_ARG, "ln_profile_begin: profiling already armed for %s", g_prof.name);
+    g_prof.starts.resize(max_samples);
+    g_prof.stops.resize(max_samples);
+    for (int i = 0; i < max_samples; ++i) {
+        if (hipEventCreate(&g_prof.starts[i]) != hipSuccess || hipEventCreate(&g_prof.stops[i]) != hipSuccess) {
+            ln_set_error("ln_profile_begin: hipEventCreate failed");
+            return LN_ERR_LAUNCH;
+        }
+    }
+    strcpy(g_prof.name, kernel_name);
+    g_prof.used = 0;
+    g_prof.max_samples = max_samples;
+    return LN_OK;
+}
+
+extern "C" int ln_profile_end(double* total_ms, int* launches) {
+    LN_REQUIRE(total_ms && launches, LN_ERR_ARG, "ln_profile_end: null output");
+    double total = 0.0;
+    int rc = LN_OK;
+    for (size_t i = 0; i < g_prof.used; ++i) {
+        float ms = 0.f;
+        if (hipEventSynchronize(g_prof.stops[i]) != hipSuccess || hipEventElapsedTime(&ms, g_prof.starts[i], g_prof.stops[i]) != hipSuccess) {
+            ln_set_error("ln_profile_end: event query failed");
+            rc = LN_ERR_LAUNCH;
+            break;
+        }
+        total += ms;
+    }
+    *total_ms = total;
+    *launches = int(g_prof.used);
+    for (size_t i = 0; i < g_prof.starts.size(); ++i) {
+        (void)hipEventDestroy(g_prof.starts[i]);
+        (void)hipEventDestroy(g_prof.stops[i]);
+    }
+    g_prof.starts.clear();
+    g_prof.stops.clear();
+    g_prof.used = 0;
+    g_prof.max_samples = 0;
+    g_prof.name[0] = 0;
+    return rc;
+}
 extern "C" const char* ln_version(void) { return "latticenet_hip 0.1 (gfx950)"; }
 
 #define LN_DISPATCH_D(d, ...)                                                    \
@@ -102,7 +176,7 @@ extern "C" int ln_table_clear(const LnTable* t, float* values, long long values_
     int blocks = ln_div_up(work, 256);
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_table_clear, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *t, values, values_elems);
+    LN_LAUNCH("k_table_clear", k_table_clear, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *t, values, values_elems);
     return ln_check_launch("ln_table_clear");
 }
 
@@ -136,42 +210,37 @@ __device__ __forceinline__ int ln_insert(const LnTable& t, const int* key, uint3
 }
 
 // Token producer 1: the d+1 simplex vertices of every point (kernel_splat / distribute).
+// One thread per TOKEN (point, remainder): the d+1 lanes of a point recompute the same cheap simplex
+// arithmetic, but every hash probe chain runs in its own lane, which gives (d+1)x the memory-level
+// parallelism of the reference's thread-per-point loop, and idx / w stores are lane-linear.
 template <int D>
 __global__ void __launch_bounds__(256)
     k_insert_points(LnTable t, const float* __restrict__ pos_raw, LnScale<D> sc, int n, int* __restrict__ tok_slot,
                     float* __restrict__ w, const float* __restrict__ vals, int val_dim, float* __restrict__ distributed) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const long long tk = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int p = int(tk / (D + 1));
+    const int r = int(tk - (long long)p * (D + 1));
     if (p >= n) return;
     float pr[D];
 #pragma unroll
     for (int i = 0; i < D; ++i) pr[i] = pos_raw[(size_t)p * D + i];
     LnSimplex<D> s;
     ln_simplex<D>(pr, sc, s);
-    int hs[D + 1];
+    int key[D];
+    ln_vertex_key<D>(s, r, key);
+    const int h = ln_insert<D>(t, key, uint32_t(tk));
+    tok_slot[tk] = h;
+    float b = s.bary[0];
 #pragma unroll
-    for (int r = 0; r <= D; ++r) {
-        int key[D];
-        ln_vertex_key<D>(s, r, key);
-        hs[r] = ln_insert<D>(t, key, uint32_t(p) * (D + 1) + r);
-    }
-#pragma unroll
-    for (int r = 0; r <= D; ++r) tok_slot[(size_t)p * (D + 1) + r] = hs[r];
-    if (w) {
-#pragma unroll
-        for (int r = 0; r <= D; ++r) w[(size_t)p * (D + 1) + r] = hs[r] >= 0 ? s.bary[r] : -1.0f;
-    }
+    for (int k = 1; k <= D; ++k) b = (r == k) ? s.bary[k] : b;
+    if (w) w[tk] = h >= 0 ? b : -1.0f;
     if (distributed) {  // LatticeGPU.cuh:626-637: [pos_scaled(d) | val(V) | bary[r]] per simplex vertex
         const int row_len = D + val_dim + 1;
-        float ps[D];
+        float* o = distributed + (size_t)tk * row_len;
 #pragma unroll
-        for (int i = 0; i < D; ++i) ps[i] = pr[i] / sc.sigma[i];
-        for (int r = 0; r <= D; ++r) {
-            float* o = distributed + ((size_t)p * (D + 1) + r) * row_len;
-#pragma unroll
-            for (int i = 0; i < D; ++i) o[i] = ps[i];
-            for (int j = 0; j < val_dim; ++j) o[D + j] = vals[(size_t)p * val_dim + j];
-            o[D + val_dim] = s.bary[r];
-        }
+        for (int i = 0; i < D; ++i) o[i] = pr[i] / sc.sigma[i];
+        for (int j = 0; j < val_dim; ++j) o[D + j] = vals[(size_t)p * val_dim + j];
+        o[D + val_dim] = b;
     }
 }
 
@@ -359,9 +428,9 @@ static int ln_carve_ws(long long tokens, void* workspace, size_t bytes, BuildWs&
 template <int D>
 static int ln_rank_and_finalize(const LnTable& t, const int* tok_slot, int* idx_out, long long tokens, const BuildWs& ws,
                                 hipStream_t st) {
-    hipLaunchKernelGGL(k_mark_first, dim3(ws.nb), dim3(256), 0, st, t, tok_slot, tokens, ws.bitmap, ws.block_cnt);
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, ws.block_cnt, ws.nb, ws.block_prefix, t.nr_filled);
-    hipLaunchKernelGGL(k_finalize<D>, dim3(ws.nb), dim3(256), 0, st, t, tok_slot, idx_out, tokens, ws.bitmap, ws.block_prefix);
+    LN_LAUNCH("k_mark_first", k_mark_first, dim3(ws.nb), dim3(256), 0, st, t, tok_slot, tokens, ws.bitmap, ws.block_cnt);
+    LN_LAUNCH("k_scan_blocks", k_scan_blocks, dim3(1), dim3(1024), 0, st, ws.block_cnt, ws.nb, ws.block_prefix, t.nr_filled);
+    LN_LAUNCH("k_finalize", k_finalize<D>, dim3(ws.nb), dim3(256), 0, st, t, tok_slot, idx_out, tokens, ws.bitmap, ws.block_prefix);
     return ln_check_launch("ln build (mark/scan/finalize)");
 }
 
@@ -382,7 +451,7 @@ static int ln_build_points(const LnTable* t, const float* positions_raw, const f
     int* tok_slot = write_idx ? idx : ws.tok_slot;  // idx doubles as the token->slot scratch
     LN_DISPATCH_D(t->pos_dim, {
         LnScale<D> sc = ln_make_scale<D>(sigmas_host);
-        hipLaunchKernelGGL(k_insert_points<D>, dim3(ln_div_up(n, 256)), dim3(256), 0, st, *t, positions_raw, sc, n, tok_slot,
+        LN_LAUNCH("k_insert_points", k_insert_points<D>, dim3(ln_div_up(tokens, 256)), dim3(256), 0, st, *t, positions_raw, sc, n, tok_slot,
                            write_idx ? w : (float*)nullptr, vals, val_dim, distributed);
         rc = ln_rank_and_finalize<D>(*t, tok_slot, write_idx ? idx : (int*)nullptr, tokens, ws, st);
     });
@@ -418,7 +487,7 @@ extern "C" int ln_coarsen(const LnTable* fine, int fine_rows_upper, const LnTabl
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     LN_DISPATCH_D(fine->pos_dim, {
-        hipLaunchKernelGGL(k_insert_coarse<D>, dim3(ln_div_up(fine_rows_upper, 256)), dim3(256), 0, st, *fine, fine_rows_upper,
+        LN_LAUNCH("k_insert_coarse", k_insert_coarse<D>, dim3(ln_div_up(fine_rows_upper, 256)), dim3(256), 0, st, *fine, fine_rows_upper,
                            *coarse, ws.tok_slot);
         rc = ln_rank_and_finalize<D>(*coarse, ws.tok_slot, (int*)nullptr, tokens, ws, st);
     });
@@ -518,7 +587,7 @@ extern "C" int ln_neighbours(const LnTable* query, int query_rows_upper, const L
     const int E = 2 * (query->pos_dim + 1) + 1;
     const long long work = (long long)query_rows_upper * E;
     LN_DISPATCH_D(query->pos_dim, {
-        hipLaunchKernelGGL(k_neighbours<D>, dim3(ln_div_up(work, 256)), dim3(256), 0, (hipStream_t)stream, *query,
+        LN_LAUNCH("k_neighbours", k_neighbours<D>, dim3(ln_div_up(work, 256)), dim3(256), 0, (hipStream_t)stream, *query,
                            query_rows_upper, *neigh, scale, dilation, flip, nbr);
     });
     return ln_check_launch("ln_neighbours");
@@ -555,7 +624,7 @@ int ln_retrieve_points(const LnTable* t, const float* positions_raw, const float
     if (n <= 0) return LN_OK;
     LN_DISPATCH_D(t->pos_dim, {
         LnScale<D> sc = ln_make_scale<D>(sigmas_host);
-        hipLaunchKernelGGL(k_retrieve_points<D>, dim3(ln_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, *t, positions_raw,
+        LN_LAUNCH("k_retrieve_points", k_retrieve_points<D>, dim3(ln_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, *t, positions_raw,
                            sc, n, idx, w);
     });
     return ln_check_launch("ln_slice_no_precomputation(retrieve)");

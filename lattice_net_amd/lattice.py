@@ -43,9 +43,9 @@ class _TableStorage:
         self.entries = torch.empty((capacity,), dtype=torch.int32, device=device)
         self.slot_keys = torch.empty((capacity,), dtype=torch.int64, device=device)
         self.slot_tok = torch.empty((capacity,), dtype=torch.int32, device=device)
-        self.status = torch.zeros((1,), dtype=torch.int32, device=device)
         self.version = 0
         self.nbr_cache = {}
+        self.csr_cache = {}
 
     def clone(self) -> "_TableStorage":
         s = _TableStorage.__new__(_TableStorage)
@@ -54,15 +54,16 @@ class _TableStorage:
         s.entries = self.entries.clone()
         s.slot_keys = self.slot_keys.clone()
         s.slot_tok = self.slot_tok.clone()
-        s.status = self.status.clone()
         s.version = 0
         s.nbr_cache = {}
+        s.csr_cache = {}
         return s
 
     def touch(self):
         """Structure changed: drop cached neighbour lists."""
         self.version += 1
         self.nbr_cache.clear()
+        self.csr_cache.clear()
 
 
 class HashTable:
@@ -72,7 +73,7 @@ class HashTable:
         self.m_capacity = int(capacity)
         self._storage: Optional[_TableStorage] = None
         self.m_values_tensor: Optional[torch.Tensor] = None
-        self.m_nr_filled_tensor: Optional[torch.Tensor] = None
+        self._counters: Optional[torch.Tensor] = None  # int32[2]: [nr_filled, status] -> ONE 8-byte readback
         self.m_nr_filled_is_dirty = True
         self.m_nr_filled = -1
         self._pos_dim_hint = -1  # dimensions known before any CAP-sized buffer exists
@@ -84,13 +85,17 @@ class HashTable:
         return None if self._storage is None else self._storage.keys
 
     @property
+    def m_nr_filled_tensor(self):  # PyBridge.cxx:36
+        return None if self._counters is None else self._counters[0:1]
+
+    @property
     def m_entries_tensor(self):
         return None if self._storage is None else self._storage.entries
 
     def init(self, pos_dim: int, val_dim: int, device):  # HashTable.cu:21-47
         self._storage = _TableStorage(self.m_capacity, pos_dim, device)
         self.m_values_tensor = torch.empty((self.m_capacity, val_dim), dtype=torch.float32, device=device)
-        self.m_nr_filled_tensor = torch.zeros((1,), dtype=torch.int32, device=device)
+        self._counters = torch.zeros((2,), dtype=torch.int32, device=device)
         self.m_nr_filled_is_dirty = True
         self.clear()
 
@@ -102,7 +107,7 @@ class HashTable:
         if s is None:
             raise _lib.LatticeNetHipError("hash table is not initialised (no splat / create_verts happened yet)")
         return _lib.LnTable(s.capacity, s.pos_dim, s.slot_keys.data_ptr(), s.slot_tok.data_ptr(), s.entries.data_ptr(),
-                            s.keys.data_ptr(), self.m_nr_filled_tensor.data_ptr(), s.status.data_ptr())
+                            s.keys.data_ptr(), self._counters.data_ptr(), self._counters.data_ptr() + 4)
 
     def clear(self):  # HashTable.cu:49-57, one launch instead of four fill_ kernels
         if not self.is_initialized():
@@ -222,7 +227,7 @@ class Lattice:
         # (HashTable.cu:15), which costs a copy kernel and a blocking readback per convolution.  Nothing
         # ever builds into a clone without first replacing its buffers (distribute / expand / coarse),
         # so the counter is shared and the cached host count is kept.
-        ht.m_nr_filled_tensor = oh.m_nr_filled_tensor
+        ht._counters = oh._counters
         ht._pos_dim_hint, ht._val_dim_hint = oh.pos_dim(), oh.val_dim()
         ht.m_nr_filled_is_dirty = oh.m_nr_filled_is_dirty
         ht.m_nr_filled = oh.m_nr_filled
@@ -299,6 +304,46 @@ class Lattice:
         ht.m_nr_filled_is_dirty = True
         return idx, w
 
+    # ---------------------------------------------------------------- atomics-free scatter (CSR)
+    def _csr(self, idx: torch.Tensor):
+        """CSR adjacency (vertex -> contributing tokens, cut into segments) of a splat-index tensor, cached
+        with the table structure.  The entry keeps `idx` alive, so (data_ptr, version, numel) cannot be
+        recycled by another tensor while cached."""
+        st = self.m_hash_table._storage
+        key = (idx.data_ptr(), idx._version, idx.numel())
+        hit = st.csr_cache.get(key)
+        if hit is not None:
+            return hit
+        lib = _lib.load()
+        dev = self._dev()
+        tokens = idx.numel()
+        rows_upper = self.m_hash_table.capacity()
+        max_seg = int(lib.ln_csr_max_segments(tokens, rows_upper))
+        # one allocation: row_start[rows_upper+1] | csr_tok[tokens] | seg_row[max_seg] | seg_beg[max_seg] | seg_count[1]
+        buf = torch.empty((rows_upper + 1 + max(tokens, 1) + 2 * max_seg + 1,), dtype=torch.int32, device=dev)
+        o1 = rows_upper + 1
+        o2 = o1 + max(tokens, 1)
+        o3 = o2 + max_seg
+        o4 = o3 + max_seg
+        row_start, csr_tok, seg_row, seg_beg, seg_count = buf[:o1], buf[o1:o2], buf[o2:o3], buf[o3:o4], buf[o4:]
+        ws = self._workspace(lib.ln_csr_workspace_bytes(tokens, rows_upper))
+        _lib.check(lib.ln_csr_build(_lib.ptr(idx), tokens, rows_upper, _lib.ptr(row_start), _lib.ptr(csr_tok), _lib.ptr(seg_row),
+                                    _lib.ptr(seg_beg), _lib.ptr(seg_count), _lib.ptr(ws), ws.numel(), self._stream()), "ln_csr_build")
+        if len(st.csr_cache) >= 4:
+            st.csr_cache.pop(next(iter(st.csr_cache)))
+        entry = (row_start, csr_tok, seg_row, seg_beg, seg_count, max_seg, idx)
+        st.csr_cache[key] = entry
+        return entry
+
+    def _scatter_rows(self, src: torch.Tensor, idx: torch.Tensor, w: torch.Tensor, dst: torch.Tensor, val_dim: int, src_div: int,
+                      src_stride: int):
+        """dst[row] += sum of the row's contributions (segment-balanced reduce over the CSR adjacency); dst pre-zeroed."""
+        row_start, csr_tok, seg_row, seg_beg, seg_count, max_seg, _ = self._csr(idx)
+        lib = _lib.load()
+        _lib.check(lib.ln_csr_reduce_rows(_lib.ptr(row_start), _lib.ptr(csr_tok), _lib.ptr(seg_row), _lib.ptr(seg_beg), _lib.ptr(seg_count),
+                                          max_seg, _lib.ptr(src), _lib.ptr(w), val_dim, src_div, src_stride, _lib.ptr(dst),
+                                          self._stream()), "ln_csr_reduce_rows")
+
     # ---------------------------------------------------------------- splat family
     def begin_splat(self, reset_hashmap: bool = True):  # Lattice.cu:185-193
         if reset_hashmap:
@@ -315,12 +360,11 @@ class Lattice:
         if not self.m_hash_table.is_initialized():
             self.m_hash_table.init(d, v, self._dev(positions_raw))
         idx, w = self._build(positions_raw, True)
-        lib = _lib.load()
         tv = self.m_hash_table.m_values_tensor
         if tv.shape[1] != v:
             raise ValueError(f"table values have val_dim {tv.shape[1]} but {v} were splatted")
-        _lib.check(lib.ln_splat_accumulate(_lib.ptr(tv), _lib.ptr(values), _lib.ptr(idx), _lib.ptr(w), n, d, v, self._stream()),
-                   "ln_splat_accumulate")
+        # splatCacheNaive (LatticeGPU.cuh:926-973) as a token-balanced reduce; begin_splat zeroed the table values
+        self._scatter_rows(values, idx, w, tv, v, d + 1, v)
         return idx, w
 
     def just_create_verts(self, positions_raw: torch.Tensor, return_indices_and_weights: bool):  # Lattice.cu:244-290
@@ -352,12 +396,12 @@ class Lattice:
             # deep copy + clear of three CAP-sized tensors (Lattice.cu:376-391) == fresh cleared buffers
             nh._storage = _TableStorage(oh.capacity(), d, dev)
             nh.m_values_tensor = torch.empty((oh.capacity(), oh.val_dim() or v), dtype=torch.float32, device=dev)
-            nh.m_nr_filled_tensor = torch.zeros((1,), dtype=torch.int32, device=dev)
+            nh._counters = torch.zeros((2,), dtype=torch.int32, device=dev)
             nh.clear()
         else:
             nh._storage = oh._storage.clone()
             nh.m_values_tensor = torch.zeros_like(oh.m_values_tensor)
-            nh.m_nr_filled_tensor = oh.m_nr_filled_tensor.clone()
+            nh._counters = oh._counters.clone()
         idx, w = new._build(positions_raw, True, vals=values, distributed=distributed)
         return new, distributed, idx, w
 
@@ -372,7 +416,7 @@ class Lattice:
         oh, nh = self.m_hash_table, new.m_hash_table
         nh._storage = oh._storage.clone()
         nh.m_values_tensor = torch.zeros((1, self.val_dim()), dtype=torch.float32, device=self._dev())
-        nh.m_nr_filled_tensor = oh.m_nr_filled_tensor.clone()
+        nh._counters = oh._counters.clone()
         new.just_create_verts(pos.contiguous(), False)
         if expand_values:
             diff = new.nr_lattice_vertices() - self.nr_lattice_vertices()
@@ -503,7 +547,7 @@ class Lattice:
         ht = HashTable(capacity)
         ht._storage = _TableStorage(capacity, d, dev)
         ht.m_values_tensor = torch.zeros((1, self.val_dim()), dtype=torch.float32, device=dev)
-        ht.m_nr_filled_tensor = torch.zeros((1,), dtype=torch.int32, device=dev)
+        ht._counters = torch.zeros((2,), dtype=torch.int32, device=dev)
         coarse.m_hash_table = ht
         ht.clear()
         return coarse
@@ -605,10 +649,9 @@ class Lattice:
         if grad_sliced_values.dim() != 2 or not grad_sliced_values.is_contiguous():
             raise ValueError("grad_sliced_values should be contiguous nr_positions x val_dim")
         v = int(grad_sliced_values.shape[1])
-        gv = torch.zeros((self.nr_lattice_vertices(), v), dtype=torch.float32, device=self._dev())
-        lib = _lib.load()
-        _lib.check(lib.ln_slice_backward(_lib.ptr(grad_sliced_values), _lib.ptr(idx), _lib.ptr(w), n, self.pos_dim(), v, _lib.ptr(gv),
-                                         self._stream()), "ln_slice_backward")
+        m = self.nr_lattice_vertices()
+        gv = torch.zeros((m, v), dtype=torch.float32, device=self._dev())
+        self._scatter_rows(grad_sliced_values, idx, w, gv, v, self.pos_dim() + 1, v)
         self.m_hash_table.m_values_tensor = gv  # result is read back through values() (lattice_funcs.py:507)
 
     def slice_classify_backwards_with_precomputation(self, grad_class_logits, positions_raw, initial_values, delta_weights,
@@ -639,10 +682,9 @@ class Lattice:
             raise ValueError("grad_sliced_values should be contiguous nr_positions x ((val_dim+1)*(pos_dim+1))")
         d = self.pos_dim()
         v = grad_sliced_values.shape[1] // (d + 1) - 1
-        gv = torch.zeros((self.nr_lattice_vertices(), v), dtype=torch.float32, device=self._dev())
-        lib = _lib.load()
-        _lib.check(lib.ln_gather_backward(_lib.ptr(grad_sliced_values), _lib.ptr(idx), _lib.ptr(w), n, d, v, _lib.ptr(gv), self._stream()),
-                   "ln_gather_backward")
+        m = self.nr_lattice_vertices()
+        gv = torch.zeros((m, v), dtype=torch.float32, device=self._dev())
+        self._scatter_rows(grad_sliced_values, idx, w, gv, v, 1, v + 1)  # one (V+1)-wide source row per token
         self.m_hash_table.m_values_tensor = gv
 
     # ---------------------------------------------------------------- getters / setters
@@ -680,7 +722,7 @@ class Lattice:
     def nr_lattice_vertices(self) -> int:  # Lattice.cu:1320-1352
         ht = self.m_hash_table
         if ht.m_nr_filled_is_dirty:
-            both = torch.stack([ht.m_nr_filled_tensor[0], ht._storage.status[0]]).cpu()  # ONE blocking readback
+            both = ht._counters.tolist()  # ONE blocking 8-byte readback: [nr_filled, status]
             nr, status = int(both[0]), int(both[1])
             if status & _lib.LN_STATUS_TABLE_FULL:
                 raise _lib.LatticeNetHipError(f"hash table overflow: capacity {ht.capacity()} is too small for this cloud "
