@@ -96,18 +96,13 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the CPU baseline leg (0 disables)")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from lattice_net_amd import sharding
+    world, rank, local_rank = sharding.env_world()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the lattice backend has no CPU path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    dist = sharding.init("nccl", dev)  # RCCL over xGMI; None for a single rank
     if args.gpus != world and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world} rank(s)", file=sys.stderr)
 
@@ -119,13 +114,12 @@ def main():
     d, e = 3, 9
     # independent clouds per rank (weak scaling); parameters broadcast from rank 0 over RCCL
     rng = np.random.default_rng(rank)
-    pos = torch.from_numpy(make_cloud(cfg["gen"], n, rank)).to(dev)
+    pos = torch.from_numpy(make_cloud(cfg["gen"], n, sharding.cloud_seed(rank))).to(dev)
     vals = torch.from_numpy(rng.standard_normal((n, v)).astype(np.float32)).to(dev)
     G = torch.from_numpy(rng.standard_normal((n, f)).astype(np.float32)).to(dev)
     bound = float(np.sqrt(3.0) * np.sqrt(2.0) / np.sqrt(f))  # kaiming-uniform fan_out (lattice_modules.py:202-207)
     W = ((torch.rand((e * v, f), device=dev) * 2 - 1) * bound)
-    if dist is not None:
-        dist.broadcast(W, src=0)
+    sharding.broadcast_parameters(dist, [W], src=0)
     W.requires_grad_(True)
     lat = L.Lattice(sigmas=[sigma] * d, capacity=cap, device=dev)
     state = {}
@@ -141,8 +135,7 @@ def main():
         state.update(m=m, out=out, gv=lv.grad)
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
+        sharding.barrier(dist)
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -161,13 +154,8 @@ def main():
 
     m = state["m"]
     checksum = float(state["out"].double().abs().sum().item())
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        sums = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
-        dist.all_gather(sums, torch.tensor([checksum], dtype=torch.float64, device=dev))
-        checksum = float(sum(s.item() for s in sums))
-    max_elapsed = float(t.item())
+    max_elapsed = sharding.max_over_ranks(dist, elapsed, dev)
+    checksum = sharding.gather_sum(dist, checksum, dev)
 
     if rank == 0:
         value = n * world * args.steps / max_elapsed / 1e6

@@ -1,0 +1,67 @@
+"""Data-parallel sharding of independent point clouds: one process per GPU, cloud i -> rank i mod G,
+no data-path collective (each cloud owns its hash table).  torch.distributed ("nccl" = RCCL over xGMI
+on ROCm, "gloo" on CPU for tests) is used only to broadcast parameters once and to reduce timings /
+checksums."""
+from __future__ import annotations
+
+import os
+from typing import Iterable, List
+
+import torch
+
+
+def env_world():
+    return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init(backend: str, device=None):
+    """Initialises torch.distributed from the launcher's environment; returns the module or None for 1 rank."""
+    world, rank, _ = env_world()
+    if world <= 1:
+        return None
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    kwargs = {}
+    if backend == "nccl" and device is not None:
+        kwargs["device_id"] = device
+    dist.init_process_group(backend, rank=rank, world_size=world, **kwargs)
+    return dist
+
+
+def clouds_of_rank(num_clouds: int, world: int, rank: int) -> List[int]:
+    """Cloud i is processed by rank i mod world."""
+    return [i for i in range(num_clouds) if i % world == rank]
+
+
+def cloud_seed(rank: int, step_cloud: int = 0) -> int:
+    """Seed of the synthetic cloud a rank works on (distinct clouds per rank: weak scaling)."""
+    return rank + 1000 * step_cloud
+
+
+def broadcast_parameters(dist, tensors: Iterable[torch.Tensor], src: int = 0):
+    if dist is None:
+        return
+    for t in tensors:
+        dist.broadcast(t, src=src)
+
+
+def max_over_ranks(dist, value: float, device) -> float:
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_sum(dist, value: float, device) -> float:
+    if dist is None:
+        return float(value)
+    world = dist.get_world_size()
+    outs = [torch.zeros(1, dtype=torch.float64, device=device) for _ in range(world)]
+    dist.all_gather(outs, torch.tensor([value], dtype=torch.float64, device=device))
+    return float(sum(o.item() for o in outs))
+
+
+def barrier(dist):
+    if dist is not None:
+        dist.barrier()

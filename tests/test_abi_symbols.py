@@ -1,0 +1,74 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every function the
+public header declares, and rejects bad arguments without touching a GPU."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import lattice_net_amd
+from lattice_net_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "latticenet_hip.h")
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ln_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    lib = _lib.load()
+    names = declared_functions()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in latticenet_hip.h but not exported by the library"
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
+    assert set(_lib.SIGNATURES) == set(names)
+
+
+def test_struct_layout_matches_header():
+    # int, int, 6 pointers -> 8 + 6*8 bytes on LP64
+    assert C.sizeof(_lib.LnTable) == 56
+    assert [f[0] for f in _lib.LnTable._fields_] == ["capacity", "pos_dim", "slot_keys", "slot_tok", "entries", "keys", "nr_filled", "status"]
+
+
+def test_version_and_kernel_names():
+    lib = _lib.load()
+    assert b"gfx950" in lib.ln_version()
+    names = lib.ln_kernel_names().decode().split(",")
+    assert "k_conv_mfma" in names and "k_insert_points" in names and "k_csr_reduce_segments" in names
+
+
+def test_argument_errors_are_reported_not_fatal():
+    lib = _lib.load()
+    assert lib.ln_conv_forward(None, None, None, -1, 9, 32, 32, None, None) == -1
+    assert b"bad sizes" in lib.ln_last_error_string()
+    assert lib.ln_neighbours(None, 10, None, 1, 1, 1, 0, None, None) == -1
+    assert b"null table" in lib.ln_last_error_string()
+    t = _lib.LnTable(100, 9, 1, 1, 1, 1, 1, 1)  # pos_dim 9 is unsupported
+    assert lib.ln_table_clear(C.byref(t), None, 0, None) == -2
+    with pytest.raises(_lib.LatticeNetHipError, match="unsupported"):
+        _lib.check(-2, "ln_table_clear")
+
+
+def test_workspace_queries_are_pure_host_functions():
+    lib = _lib.load()
+    assert lib.ln_build_workspace_bytes(480000) >= 480000 * 4
+    assert lib.ln_csr_workspace_bytes(480000, 100000) >= 480000 * 4 + 3 * 100000 * 4
+    assert lib.ln_csr_max_segments(480000, 100000) == 100000 + 480000 // 16 + 1
+    assert lib.ln_conv_grad_filter_workspace_bytes(46538, 9, 32, 32) >= 91 * 9 * 32 * 32 * 4
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/liblatticenet_hip.so")
+    with pytest.raises(_lib.LatticeNetHipError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_reference_module_alias():
+    import latticenet
+    assert latticenet.Lattice is lattice_net_amd.Lattice and latticenet.HashTable is lattice_net_amd.HashTable

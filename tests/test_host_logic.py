@@ -1,0 +1,103 @@
+"""Host-side logic that needs no GPU: config parsing, shapes, argument checks, autograd glue."""
+import numpy as np
+import pytest
+import torch
+
+from lattice_net_amd import Lattice, LatticeWrapper
+from lattice_net_amd.lattice_funcs import _backward_filter
+from oracle import lattice_oracle as O
+
+CFG = """
+core: { loguru_verbosity: 3 }
+lattice_gpu: {
+    hash_table_capacity: 100000 //good for semantic kitti
+    nr_sigmas: 1
+    // sigma_0: "0.6 3"
+    sigma_0: "0.9 3" //sigma of X affecting Y dimensions of the positions vector
+}
+loader: { x: 1 }
+"""
+
+
+def test_create_from_reference_style_cfg(tmp_path):
+    p = tmp_path / "lnn.cfg"
+    p.write_text(CFG)
+    lat = Lattice.create(str(p), "lattice")
+    assert lat.name() == "lattice"
+    assert lat.capacity() == 100000
+    assert lat.m_sigmas == [0.9, 0.9, 0.9]
+    assert Lattice.get_expected_filter_extent(1) == 9  # static, driven by the last set_sigmas (Lattice.cu:44)
+    assert lat.sigmas_tensor().tolist() == pytest.approx([0.9] * 3)
+    lat.increase_sigmas(0.1)
+    assert lat.m_sigmas == pytest.approx([1.0] * 3)
+    lat.set_sigma(0.5)
+    assert lat.m_sigmas == [0.5] * 3
+    with pytest.raises(ValueError):
+        Lattice.get_expected_filter_extent(2)
+
+
+def test_two_sigma_groups(tmp_path):
+    p = tmp_path / "two.cfg"
+    p.write_text('lattice_gpu: {\n hash_table_capacity: 10\n nr_sigmas: 2\n sigma_0: "0.5 3"\n sigma_1: "0.1 2"\n}\n')
+    lat = Lattice.create(str(p))
+    assert lat.m_sigmas == [0.5, 0.5, 0.5, 0.1, 0.1]
+    with pytest.raises(ValueError):
+        lat.set_sigma(1.0)  # only defined for a single sigma group (Lattice.cu:1385)
+
+
+def test_cpu_tensors_are_rejected_no_fallback():
+    lat = Lattice(sigmas=[0.5] * 3, capacity=100)
+    pos = torch.zeros((4, 3))
+    with pytest.raises(ValueError, match="no CPU path"):
+        lat.just_create_verts(pos, True)
+    with pytest.raises(ValueError, match="float"):
+        lat.just_create_verts(pos.double(), True)
+    with pytest.raises(ValueError, match="sigma"):
+        lat.just_create_verts(torch.zeros((4, 2)), True)
+    with pytest.raises(ValueError, match="contiguous"):
+        lat.just_create_verts(torch.zeros((3, 4)).t(), True)
+
+
+def test_dead_reference_kernels_raise():
+    lat = Lattice(sigmas=[0.5] * 3, capacity=100)
+    for name in ("gather_standalone_no_precomputation", "slice_classify_no_precomputation",
+                 "slice_backwards_standalone_with_precomputation"):
+        with pytest.raises(NotImplementedError):
+            getattr(lat, name)(None)
+
+
+def test_backward_filter_layout_matches_reference_formula():
+    rng = np.random.default_rng(0)
+    e, v, f = 9, 5, 7
+    w = rng.standard_normal((e * v, f)).astype(np.float32)
+    ours = _backward_filter(torch.from_numpy(w), f, e, v).numpy()
+    np.testing.assert_array_equal(ours, O.backward_filter_layout(w, v))
+    # element (slot, f) x v of the backward bank is W[slot*V + v, f]
+    assert ours[3 * f + 2, 4] == w[3 * v + 4, 2]
+
+
+def test_lattice_wrapper_carries_object_through_autograd_function():
+    class F(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x * 2, LatticeWrapper.wrap({"tag": 7})
+
+        @staticmethod
+        def backward(ctx, g, g2):
+            return g * 2
+
+    x = torch.ones(3, requires_grad=True)
+    y, wrap = F.apply(x)
+    assert wrap.lattice == {"tag": 7}
+    y.sum().backward()
+    assert x.grad.tolist() == [2.0, 2.0, 2.0]
+
+
+def test_synthetic_clouds_are_seeded_and_shaped():
+    from lattice_net_amd import synthetic
+    a, b = synthetic.lidar_cloud(1000, 3), synthetic.lidar_cloud(1000, 3)
+    np.testing.assert_array_equal(a, b)
+    assert a.dtype == np.float32 and a.shape == (1000, 3)
+    assert np.hypot(a[:, 0], a[:, 1]).max() <= 60.0 + 1e-3
+    assert not np.array_equal(a, synthetic.lidar_cloud(1000, 4))
+    assert synthetic.planes_cloud(500, 1).shape == (500, 3) and synthetic.box_surface_cloud(500, 1).shape == (500, 3)
