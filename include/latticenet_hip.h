@@ -47,17 +47,31 @@ extern "C" {
  *                 claim + key publication is ONE 64-bit CAS (no spin lock, no fence);
  *   slot_tok[h]   smallest insertion token that touched slot h during the build that created
  *                 it (0xFFFFFFFF while empty) — defines the canonical row order;
+ *   slot_cnt[h]   how many tokens of the current build landed on slot h;
  *   status        sticky error bits, see LN_STATUS_*. */
 typedef struct LnTable {
     int capacity;
     int pos_dim;
     unsigned long long* slot_keys; /* [capacity] */
     unsigned int* slot_tok;        /* [capacity] */
+    int* slot_cnt;                 /* [capacity] tokens of the current build per slot (scratch) */
     int* entries;                  /* [capacity]   slot -> row, -1 empty  (m_entries) */
     int* keys;                     /* [capacity,d] row  -> key            (m_keys)    */
     int* nr_filled;                /* [1]                                 (m_nr_filled) */
     int* status;                   /* [1] */
 } LnTable;
+
+/* Adjacency "group -> the tokens that touch it" in CSR form, cut into segments of at most 16
+ * entries (the unit of work of ln_csr_reduce_rows).  A group is a hash slot for the CSR that
+ * ln_build_splat / ln_distribute / ln_coarsen emit as a by-product (row of a group = entries[slot]),
+ * or a row for ln_csr_build (row of a group = the group). */
+typedef struct LnCsr {
+    int* grp_start; /* [groups_upper + 1] */
+    int* csr_tok;   /* [tokens]           tokens grouped by group */
+    int* seg_grp;   /* [max_segments]     group of each segment */
+    int* seg_beg;   /* [max_segments]     first CSR entry of each segment */
+    int* seg_count; /* [1]                device-side number of segments */
+} LnCsr;
 
 const char* ln_last_error_string(void);
 const char* ln_version(void);
@@ -74,51 +88,52 @@ int ln_profile_end(double* total_ms, int* launches);
  * in one launch.  `values` (may be NULL) is zero-filled too: values_elems floats. */
 int ln_table_clear(const LnTable* t, float* values, long long values_elems, void* stream);
 
-/* Scratch needed by ln_build_splat / ln_coarsen for `tokens` insertions. */
-size_t ln_build_workspace_bytes(long long tokens);
+/* Scratch needed by ln_build_splat / ln_distribute / ln_coarsen for `tokens` insertions. */
+size_t ln_build_workspace_bytes(long long tokens, int capacity);
 
 /* kernel_splat (LatticeGPU.cuh:707-842) behind Lattice::splat_standalone / just_create_verts
  * (src/Lattice.cu:196-290), with `positions_raw / sigmas` (Lattice.cu:226) fused in.
  * Inserts the d+1 simplex vertices of every point; when write_idx != 0 writes
  * idx[n*(d+1)] (row ids) and w[n*(d+1)] (barycentric weights).  Both must be pre-sized; rows
  * that cannot be inserted keep -1 (Lattice.cu:212-215 semantics are produced here, no pre-fill
- * needed).  idx/w may be NULL when write_idx == 0. */
+ * needed).  idx/w may be NULL when write_idx == 0.
+ * `csr` (required; groups = hash slots, groups_upper = capacity, sized with ln_csr_max_segments)
+ * receives the slot -> tokens adjacency of this build: the build needs it to find each vertex's
+ * first occurrence, and the caller reuses it for every scatter onto the vertices
+ * (ln_csr_reduce_rows with grp_row = t->entries). */
 int ln_build_splat(const LnTable* t, const float* positions_raw, const float* sigmas_host, int n, int* idx, float* w,
-                   int write_idx, void* workspace, size_t workspace_bytes, void* stream);
+                   int write_idx, const LnCsr* csr, void* workspace, size_t workspace_bytes, void* stream);
 
 /* splatCacheNaive (LatticeGPU.cuh:926-973): table_values[idx] += vals * w. */
 int ln_splat_accumulate(float* table_values, const float* vals, const int* idx, const float* w, int n, int pos_dim,
                         int val_dim, void* stream);
 
 /* Scatter without per-element global atomics.  ln_csr_build transposes splat indices idx[tokens]
- * (row per token, <0 = skip) into CSR form — row_start[rows_upper+1], csr_tok[tokens] (tokens
- * grouped by row) — and cuts every row into segments of at most 16 entries: seg_row / seg_beg
- * [ln_csr_max_segments()] and the device-side segment count seg_count[1].
- * ln_csr_reduce_rows then ADDS, for every row,
- *     dst[row, j] += sum_{t in row} src[(t / src_div) * src_stride + j] * w[t],   j < val_dim
- * (dst zero-initialised by the caller): one lane group per segment, plain stores for rows that
- * fit one segment, global atomics only to combine the segments of longer rows.
+ * (row per token, <0 = skip) into an LnCsr whose groups are rows (groups_upper = rows_upper).
+ * ln_csr_reduce_rows then ADDS, for every group g with row r = grp_row ? grp_row[g] : g,
+ *     dst[r, j] += sum_{t in g} src[(t / src_div) * src_stride + j] * w[t],   j < val_dim
+ * (dst zero-initialised by the caller): one lane group per segment, plain stores for groups that
+ * fit one segment, global atomics only to combine the segments of longer ones.
  * With src_div = d+1, src_stride = V it replaces splatCacheNaive (LatticeGPU.cuh:926-973) and
  * slice_backwards_..._no_homogeneous (LatticeGPU.cuh:3540-3623); with src_div = 1,
  * src_stride = V+1 it replaces gather_backwards_with_precomputation (LatticeGPU.cuh:3761-3817). */
-long long ln_csr_max_segments(long long tokens, int rows_upper);
-size_t ln_csr_workspace_bytes(long long tokens, int rows_upper);
-int ln_csr_build(const int* idx, long long tokens, int rows_upper, int* row_start, int* csr_tok, int* seg_row, int* seg_beg,
-                 int* seg_count, void* workspace, size_t workspace_bytes, void* stream);
-int ln_csr_reduce_rows(const int* row_start, const int* csr_tok, const int* seg_row, const int* seg_beg, const int* seg_count,
-                       long long max_segments, const float* src, const float* w, int val_dim, int src_div, int src_stride,
-                       float* dst, void* stream);
+long long ln_csr_max_segments(long long tokens, int groups_upper);
+size_t ln_csr_workspace_bytes(long long tokens, int groups_upper);
+int ln_csr_build(const int* idx, long long tokens, int groups_upper, const LnCsr* csr, void* workspace, size_t workspace_bytes,
+                 void* stream);
+int ln_csr_reduce_rows(const LnCsr* csr, const int* grp_row, long long max_segments, const float* src, const float* w, int val_dim,
+                       int src_div, int src_stride, float* dst, void* stream);
 
 /* distribute kernel (LatticeGPU.cuh:534-650) behind Lattice::distribute (Lattice.cu:351-410):
  * ln_build_splat + the dense rows [pos_scaled(d) | val(V) | bary] -> distributed[n*(d+1), d+V+1]. */
 int ln_distribute(const LnTable* t, const float* positions_raw, const float* sigmas_host, const float* vals, int n,
-                  int val_dim, int* idx, float* w, float* distributed, void* workspace, size_t workspace_bytes,
-                  void* stream);
+                  int val_dim, int* idx, float* w, float* distributed, const LnCsr* csr, void* workspace,
+                  size_t workspace_bytes, void* stream);
 
 /* coarsen kernel (LatticeGPU.cuh:2314-2514) behind Lattice::create_coarse_verts (Lattice.cu:670-703).
  * fine_rows_upper bounds the launch; the kernel also honours *fine->nr_filled. */
-int ln_coarsen(const LnTable* fine, int fine_rows_upper, const LnTable* coarse, void* workspace, size_t workspace_bytes,
-               void* stream);
+int ln_coarsen(const LnTable* fine, int fine_rows_upper, const LnTable* coarse, const LnCsr* csr, void* workspace,
+               size_t workspace_bytes, void* stream);
 
 /* Neighbour traversal shared by im2row / im2rowindices / row2im (LatticeGPU.cuh:1479-1684,
  * 1844-1915, 2187-2284): nbr[query_rows_upper, E] (E = 2(d+1)+1) rows of the neighbour table;

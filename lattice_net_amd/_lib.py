@@ -26,10 +26,23 @@ class LnTable(C.Structure):
         ("pos_dim", C.c_int),
         ("slot_keys", C.c_void_p),
         ("slot_tok", C.c_void_p),
+        ("slot_cnt", C.c_void_p),
         ("entries", C.c_void_p),
         ("keys", C.c_void_p),
         ("nr_filled", C.c_void_p),
         ("status", C.c_void_p),
+    ]
+
+
+class LnCsr(C.Structure):
+    """Mirror of `struct LnCsr` (include/latticenet_hip.h)."""
+
+    _fields_ = [
+        ("grp_start", C.c_void_p),
+        ("csr_tok", C.c_void_p),
+        ("seg_grp", C.c_void_p),
+        ("seg_beg", C.c_void_p),
+        ("seg_count", C.c_void_p),
     ]
 
 
@@ -39,6 +52,7 @@ class LatticeNetHipError(RuntimeError):
 
 _vp, _i, _ll, _sz = C.c_void_p, C.c_int, C.c_longlong, C.c_size_t
 _T = C.POINTER(LnTable)
+_CSR = C.POINTER(LnCsr)
 
 # name -> (restype, argtypes).  Every symbol the header declares is listed here; tests check the
 # library exports each of them.
@@ -49,15 +63,15 @@ SIGNATURES = {
     "ln_profile_begin": (_i, [C.c_char_p, _i]),
     "ln_profile_end": (_i, [C.POINTER(C.c_double), C.POINTER(_i)]),
     "ln_table_clear": (_i, [_T, _vp, _ll, _vp]),
-    "ln_build_workspace_bytes": (_sz, [_ll]),
-    "ln_build_splat": (_i, [_T, _vp, _vp, _i, _vp, _vp, _i, _vp, _sz, _vp]),
+    "ln_build_workspace_bytes": (_sz, [_ll, _i]),
+    "ln_build_splat": (_i, [_T, _vp, _vp, _i, _vp, _vp, _i, _CSR, _vp, _sz, _vp]),
     "ln_splat_accumulate": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "ln_csr_workspace_bytes": (_sz, [_ll, _i]),
     "ln_csr_max_segments": (_ll, [_ll, _i]),
-    "ln_csr_build": (_i, [_vp, _ll, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "ln_csr_reduce_rows": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _vp, _vp, _i, _i, _i, _vp, _vp]),
-    "ln_distribute": (_i, [_T, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "ln_coarsen": (_i, [_T, _i, _T, _vp, _sz, _vp]),
+    "ln_csr_build": (_i, [_vp, _ll, _i, _CSR, _vp, _sz, _vp]),
+    "ln_csr_reduce_rows": (_i, [_CSR, _vp, _ll, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "ln_distribute": (_i, [_T, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _CSR, _vp, _sz, _vp]),
+    "ln_coarsen": (_i, [_T, _i, _T, _CSR, _vp, _sz, _vp]),
     "ln_neighbours": (_i, [_T, _i, _T, _i, _i, _i, _i, _vp, _vp]),
     "ln_im2row": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "ln_im2rowindices": (_i, [_vp, _i, _i, _i, _vp, _vp]),

@@ -12,10 +12,10 @@
 // the sensor), so the unit of work is a SEGMENT: at most LN_SEG consecutive CSR entries of one row.
 // A lane group reduces one segment in registers; rows that fit one segment are written with a plain
 // store, longer rows combine their segments with global atomicAdd (few, and only on hot rows).
-#include "ln_common.h"
+#include "ln_csr.h"
 
 #define LN_SCAN_BLOCK 1024
-#define LN_SEG 16
+#define LN_SEG LN_CSR_SEG
 
 __global__ void __launch_bounds__(256)
     k_csr_count(const int* __restrict__ idx, long long tokens, int rows_upper, int* __restrict__ cnt, int* __restrict__ pos) {
@@ -138,68 +138,83 @@ __global__ void __launch_bounds__(256)
 
 static size_t ln_align256c(size_t x) { return (x + 255) & ~size_t(255); }
 
-extern "C" long long ln_csr_max_segments(long long tokens, int rows_upper) {
+extern "C" long long ln_csr_max_segments(long long tokens, int groups_upper) {
     if (tokens < 0) tokens = 0;
-    const long long rows = tokens < rows_upper ? tokens : rows_upper;
-    return rows + tokens / LN_SEG + 1;
+    const long long g = tokens < groups_upper ? tokens : groups_upper;
+    return g + tokens / LN_SEG + 1;
 }
 
-extern "C" size_t ln_csr_workspace_bytes(long long tokens, int rows_upper) {
-    if (tokens < 1) tokens = 1;
-    if (rows_upper < 1) rows_upper = 1;
-    const size_t nb = (size_t)ln_div_up(rows_upper, LN_SCAN_BLOCK);
-    return ln_align256c((size_t)rows_upper * 4) * 3 + ln_align256c((size_t)tokens * 4) + ln_align256c(nb * 8) + ln_align256c((nb + 1) * 8);
+size_t ln_csr_scan_workspace_bytes(int groups_upper) {
+    if (groups_upper < 1) groups_upper = 1;
+    const size_t nb = (size_t)ln_div_up(groups_upper, LN_SCAN_BLOCK);
+    return ln_align256c((size_t)groups_upper * 4) * 2 + ln_align256c(nb * 8) + ln_align256c((nb + 1) * 8);
 }
 
-extern "C" int ln_csr_build(const int* idx, long long tokens, int rows_upper, int* row_start, int* csr_tok, int* seg_row,
-                            int* seg_beg, int* seg_count, void* workspace, size_t workspace_bytes, void* stream) {
-    LN_REQUIRE(tokens >= 0 && rows_upper >= 1, LN_ERR_ARG, "ln_csr_build: bad sizes");
-    LN_REQUIRE(row_start && seg_count && (tokens == 0 || (idx && csr_tok && seg_row && seg_beg)), LN_ERR_ARG, "ln_csr_build: null buffer");
-    LN_REQUIRE(workspace && workspace_bytes >= ln_csr_workspace_bytes(tokens, rows_upper), LN_ERR_WORKSPACE,
-               "ln_csr_build: workspace too small");
-    LN_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, LN_ERR_WORKSPACE, "ln_csr_build: workspace must be 256-byte aligned");
-    hipStream_t st = (hipStream_t)stream;
-    const int nb = ln_div_up(rows_upper, LN_SCAN_BLOCK);
+int ln_csr_from_counts(const int* tok_grp, const int* tok_pos, long long tokens, const int* grp_cnt, int groups_upper,
+                       const LnCsr& csr, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    LN_REQUIRE(workspace && workspace_bytes >= ln_csr_scan_workspace_bytes(groups_upper), LN_ERR_WORKSPACE, "csr scan workspace too small");
+    const int nb = ln_div_up(groups_upper, LN_SCAN_BLOCK);
     char* p = static_cast<char*>(workspace);
-    int* cnt = reinterpret_cast<int*>(p);
-    p += ln_align256c((size_t)rows_upper * 4);
     int* local_tok = reinterpret_cast<int*>(p);
-    p += ln_align256c((size_t)rows_upper * 4);
+    p += ln_align256c((size_t)groups_upper * 4);
     int* local_seg = reinterpret_cast<int*>(p);
-    p += ln_align256c((size_t)rows_upper * 4);
-    int* pos = reinterpret_cast<int*>(p);
-    p += ln_align256c((size_t)(tokens < 1 ? 1 : tokens) * 4);
+    p += ln_align256c((size_t)groups_upper * 4);
     int* block_tot = reinterpret_cast<int*>(p);
     p += ln_align256c((size_t)nb * 8);
     int* block_off = reinterpret_cast<int*>(p);
-    if (hipMemsetAsync(cnt, 0, (size_t)rows_upper * 4, st) != hipSuccess) return ln_check_launch("ln_csr_build(memset)");
+    LN_LAUNCH("k_csr_scan_local", k_csr_scan_local, dim3(nb), dim3(LN_SCAN_BLOCK), 0, st, grp_cnt, groups_upper, local_tok, local_seg, block_tot);
+    LN_LAUNCH("k_csr_scan_top", k_csr_scan_top, dim3(1), dim3(1024), 0, st, block_tot, nb, block_off, csr.seg_count);
+    const long long work = (tokens > groups_upper + 1) ? tokens : (long long)groups_upper + 1;
+    LN_LAUNCH("k_csr_fill", k_csr_fill, dim3(ln_div_up(work, 256)), dim3(256), 0, st, tok_grp, tok_pos, tokens, groups_upper, local_tok, local_seg,
+              block_off, nb, csr.grp_start, csr.csr_tok, csr.seg_grp, csr.seg_beg);
+    return ln_check_launch("ln_csr_from_counts");
+}
+
+extern "C" size_t ln_csr_workspace_bytes(long long tokens, int groups_upper) {
+    if (tokens < 1) tokens = 1;
+    if (groups_upper < 1) groups_upper = 1;
+    return ln_align256c((size_t)groups_upper * 4) + ln_align256c((size_t)tokens * 4) + ln_csr_scan_workspace_bytes(groups_upper);
+}
+
+extern "C" int ln_csr_build(const int* idx, long long tokens, int groups_upper, const LnCsr* csr, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+    LN_REQUIRE(tokens >= 0 && groups_upper >= 1, LN_ERR_ARG, "ln_csr_build: bad sizes");
+    LN_REQUIRE(csr && csr->grp_start && csr->seg_count && (tokens == 0 || (idx && csr->csr_tok && csr->seg_grp && csr->seg_beg)), LN_ERR_ARG,
+               "ln_csr_build: null buffer");
+    LN_REQUIRE(workspace && workspace_bytes >= ln_csr_workspace_bytes(tokens, groups_upper), LN_ERR_WORKSPACE,
+               "ln_csr_build: workspace too small");
+    LN_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, LN_ERR_WORKSPACE, "ln_csr_build: workspace must be 256-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    char* p = static_cast<char*>(workspace);
+    int* cnt = reinterpret_cast<int*>(p);
+    p += ln_align256c((size_t)groups_upper * 4);
+    int* pos = reinterpret_cast<int*>(p);
+    p += ln_align256c((size_t)(tokens < 1 ? 1 : tokens) * 4);
+    if (hipMemsetAsync(cnt, 0, (size_t)groups_upper * 4, st) != hipSuccess) return ln_check_launch("ln_csr_build(memset)");
     if (tokens > 0)
-        LN_LAUNCH("k_csr_count", k_csr_count, dim3(ln_div_up(tokens, 256)), dim3(256), 0, st, idx, tokens, rows_upper, cnt, pos);
-    LN_LAUNCH("k_csr_scan_local", k_csr_scan_local, dim3(nb), dim3(LN_SCAN_BLOCK), 0, st, cnt, rows_upper, local_tok, local_seg, block_tot);
-    LN_LAUNCH("k_csr_scan_top", k_csr_scan_top, dim3(1), dim3(1024), 0, st, block_tot, nb, block_off, seg_count);
-    const long long work = (tokens > rows_upper + 1) ? tokens : (long long)rows_upper + 1;
-    LN_LAUNCH("k_csr_fill", k_csr_fill, dim3(ln_div_up(work, 256)), dim3(256), 0, st, idx, pos, tokens, rows_upper, local_tok, local_seg,
-              block_off, nb, row_start, csr_tok, seg_row, seg_beg);
-    return ln_check_launch("ln_csr_build");
+        LN_LAUNCH("k_csr_count", k_csr_count, dim3(ln_div_up(tokens, 256)), dim3(256), 0, st, idx, tokens, groups_upper, cnt, pos);
+    return ln_csr_from_counts(idx, pos, tokens, cnt, groups_upper, *csr, p, ln_csr_scan_workspace_bytes(groups_upper), st);
 }
 
 // dst[row, j] += sum over the row's tokens t of src[(t / src_div) * src_stride + j] * w[t]   (j < V)
 // One lane group per segment; LN_SEG/U batches of U independent gathers per lane.
 template <int VEC>
 __global__ void __launch_bounds__(256)
-    k_csr_reduce_segments(const int* __restrict__ row_start, const int* __restrict__ csr_tok, const int* __restrict__ seg_row,
-                          const int* __restrict__ seg_beg, const int* __restrict__ seg_count, const float* __restrict__ src,
-                          const float* __restrict__ w, int chunks, int lanes_per_seg, int src_div, int src_stride,
-                          float* __restrict__ dst) {
+    k_csr_reduce_segments(const int* __restrict__ grp_start, const int* __restrict__ csr_tok, const int* __restrict__ seg_grp,
+                          const int* __restrict__ seg_beg, const int* __restrict__ seg_count, const int* __restrict__ grp_row,
+                          const float* __restrict__ src, const float* __restrict__ w, int chunks, int lanes_per_seg, int src_div,
+                          int src_stride, float* __restrict__ dst) {
     constexpr int U = 4;
     const long long gt = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long sid = gt / lanes_per_seg;
     const int lc = int(gt - sid * lanes_per_seg);
     if (sid >= *seg_count) return;
-    const int row = seg_row[sid];
+    const int grp = seg_grp[sid];
     const int beg = seg_beg[sid];
-    const int rbeg = row_start[row];
-    const int rend = row_start[row + 1];
+    const int rbeg = grp_start[grp];
+    const int rend = grp_start[grp + 1];
+    const int row = grp_row ? grp_row[grp] : grp;  // groups are hash slots (row = entries[slot]) or rows themselves
+    if (row < 0) return;
     const int end = min(beg + LN_SEG, rend);
     const bool single = (rend - rbeg) <= LN_SEG;
     const int V = chunks * VEC;
@@ -248,12 +263,11 @@ __global__ void __launch_bounds__(256)
     }
 }
 
-extern "C" int ln_csr_reduce_rows(const int* row_start, const int* csr_tok, const int* seg_row, const int* seg_beg,
-                                  const int* seg_count, long long max_segments, const float* src, const float* w, int val_dim,
-                                  int src_div, int src_stride, float* dst, void* stream) {
+extern "C" int ln_csr_reduce_rows(const LnCsr* csr, const int* grp_row, long long max_segments, const float* src, const float* w,
+                                  int val_dim, int src_div, int src_stride, float* dst, void* stream) {
     LN_REQUIRE(max_segments >= 0 && val_dim >= 1 && src_div >= 1 && src_stride >= val_dim, LN_ERR_ARG, "ln_csr_reduce_rows: bad sizes");
-    LN_REQUIRE(max_segments == 0 || (row_start && csr_tok && seg_row && seg_beg && seg_count && src && w && dst), LN_ERR_ARG,
-               "ln_csr_reduce_rows: null buffer");
+    LN_REQUIRE(max_segments == 0 || (csr && csr->grp_start && csr->csr_tok && csr->seg_grp && csr->seg_beg && csr->seg_count && src && w && dst),
+               LN_ERR_ARG, "ln_csr_reduce_rows: null buffer");
     if (max_segments == 0) return LN_OK;
     hipStream_t st = (hipStream_t)stream;
     const bool vec4 = (val_dim % 4 == 0) && (src_stride % 4 == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0) &&
@@ -264,10 +278,10 @@ extern "C" int ln_csr_reduce_rows(const int* row_start, const int* csr_tok, cons
     const long long work = max_segments * lanes;
     const dim3 grid(ln_div_up(work, 256)), block(256);
     if (vec4)
-        LN_LAUNCH("k_csr_reduce_segments", k_csr_reduce_segments<4>, grid, block, 0, st, row_start, csr_tok, seg_row, seg_beg, seg_count, src,
-                  w, chunks, lanes, src_div, src_stride, dst);
+        LN_LAUNCH("k_csr_reduce_segments", k_csr_reduce_segments<4>, grid, block, 0, st, csr->grp_start, csr->csr_tok, csr->seg_grp, csr->seg_beg,
+                  csr->seg_count, grp_row, src, w, chunks, lanes, src_div, src_stride, dst);
     else
-        LN_LAUNCH("k_csr_reduce_segments", k_csr_reduce_segments<1>, grid, block, 0, st, row_start, csr_tok, seg_row, seg_beg, seg_count, src,
-                  w, chunks, lanes, src_div, src_stride, dst);
+        LN_LAUNCH("k_csr_reduce_segments", k_csr_reduce_segments<1>, grid, block, 0, st, csr->grp_start, csr->csr_tok, csr->seg_grp, csr->seg_beg,
+                  csr->seg_count, grp_row, src, w, chunks, lanes, src_div, src_stride, dst);
     return ln_check_launch("ln_csr_reduce_rows");
 }

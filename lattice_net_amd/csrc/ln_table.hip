@@ -15,6 +15,7 @@
 // serial run of the reference — without any lock, spin or fence.
 #include "ln_common.h"
 #include "ln_simplex.h"
+#include "ln_csr.h"
 
 #include <stdarg.h>
 #include <stdio.h>
@@ -71,7 +72,7 @@ LnProfScope::~LnProfScope() {
     }
 }
 
-extern "C" const char* ln_kernel_names(void) { return "k_conv_generic,k_conv_mfma,k_csr_count,k_csr_fill,k_csr_reduce_segments,k_csr_scan_local,k_csr_scan_top,k_finalize,k_gather_backward,k_gather_forward,k_grad_filter_generic,k_grad_filter_mfma,k_im2row,k_im2rowindices,k_insert_coarse,k_insert_points,k_mark_first,k_neighbours,k_reduce_slabs,k_retrieve_points,k_row2im,k_scan_blocks,k_scatter_point_rows,k_slice_classify_backward,k_slice_classify_forward,k_slice_forward,k_table_clear"; }
+extern "C" const char* ln_kernel_names(void) { return "k_conv_generic,k_conv_mfma,k_csr_count,k_csr_fill,k_csr_reduce_segments,k_csr_scan_local,k_csr_scan_top,k_finalize,k_gather_backward,k_gather_forward,k_grad_filter_generic,k_grad_filter_mfma,k_im2row,k_im2rowindices,k_insert_coarse,k_insert_points,k_mark_first,k_neighbours,k_reduce_slabs,k_retrieve_points,k_row2im,k_scan_blocks,k_scatter_point_rows,k_seg_min,k_slice_classify_backward,k_slice_classify_forward,k_slice_forward,k_table_clear"; }
 
 extern "C" int ln_profile_begin(const char* kernel_name, int max_samples) {
     LN_REQUIRE(kernel_name && strlen(kernel_name) < sizeof(g_prof.name) && max_samples > 0, LN_ERR_ARG, "ln_profile_begin: bad args");
@@ -136,7 +137,7 @@ static int ln_check_table(const LnTable* t, const char* who) {
     LN_REQUIRE(t->capacity > 0, LN_ERR_ARG, "%s: capacity %d", who, t->capacity);
     LN_REQUIRE(t->pos_dim >= 1 && t->pos_dim <= LN_MAX_POS_DIM, LN_ERR_UNSUPPORTED, "%s: pos_dim %d unsupported", who,
                t->pos_dim);
-    LN_REQUIRE(t->slot_keys && t->slot_tok && t->entries && t->keys && t->nr_filled && t->status, LN_ERR_ARG,
+    LN_REQUIRE(t->slot_keys && t->slot_tok && t->slot_cnt && t->entries && t->keys && t->nr_filled && t->status, LN_ERR_ARG,
                "%s: table has a null buffer", who);
     return LN_OK;
 }
@@ -150,6 +151,7 @@ __global__ void __launch_bounds__(256) k_table_clear(LnTable t, float* values, l
     for (long long i = g; i < t.capacity; i += stride) {
         t.slot_keys[i] = LN_EMPTY_KEY;
         t.slot_tok[i] = LN_EMPTY_TOK;
+        t.slot_cnt[i] = 0;
         t.entries[i] = -1;
     }
     const long long nk = (long long)t.capacity * t.pos_dim;
@@ -183,8 +185,12 @@ extern "C" int ln_table_clear(const LnTable* t, float* values, long long values_
 // ------------------------------------------------------------------------------------------
 // insert
 // ------------------------------------------------------------------------------------------
+// Returns the slot of `key` (inserting it if new) and, in `pos`, this token's rank among the tokens
+// of the current build that landed on that slot (one returning int atomic: it is both the CSR
+// position of the token and, summed, the slot's degree).
 template <int D>
-__device__ __forceinline__ int ln_insert(const LnTable& t, const int* key, uint32_t token) {
+__device__ __forceinline__ int ln_insert(const LnTable& t, const int* key, int& pos) {
+    pos = -1;
     if (!KeyPack<D>::in_range(key)) {
         atomicOr(t.status, LN_STATUS_KEY_RANGE);
         return -1;
@@ -192,14 +198,16 @@ __device__ __forceinline__ int ln_insert(const LnTable& t, const int* key, uint3
     const uint64_t pk = KeyPack<D>::pack(key);
     int h = int(ln_hash<D>(key) % uint32_t(t.capacity));
     for (int probes = 0; probes < t.capacity; ++probes) {
-        unsigned long long cur = __hip_atomic_load(&t.slot_keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // Plain (cacheable) pre-check: a slot only ever changes EMPTY -> key, so a stale read can only
+        // show EMPTY, in which case the CAS below decides.  Duplicates of an already-inserted key are
+        // then served by L1/L2 instead of each costing a memory-side atomic.
+        unsigned long long cur = t.slot_keys[h];
         if (cur == LN_EMPTY_KEY) {
             cur = atomicCAS(&t.slot_keys[h], (unsigned long long)LN_EMPTY_KEY, (unsigned long long)pk);
             if (cur == LN_EMPTY_KEY) cur = pk;  // we claimed it
         }
         if (cur == pk) {
-            if (__hip_atomic_load(&t.slot_tok[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > token)
-                atomicMin(&t.slot_tok[h], token);
+            pos = atomicAdd(&t.slot_cnt[h], 1);
             return h;
         }
         ++h;  // linear probing, HashTableGPU.cuh:479-482
@@ -216,7 +224,8 @@ __device__ __forceinline__ int ln_insert(const LnTable& t, const int* key, uint3
 template <int D>
 __global__ void __launch_bounds__(256)
     k_insert_points(LnTable t, const float* __restrict__ pos_raw, LnScale<D> sc, int n, int* __restrict__ tok_slot,
-                    float* __restrict__ w, const float* __restrict__ vals, int val_dim, float* __restrict__ distributed) {
+                    int* __restrict__ tok_pos, float* __restrict__ w, const float* __restrict__ vals, int val_dim,
+                    float* __restrict__ distributed) {
     const long long tk = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int p = int(tk / (D + 1));
     const int r = int(tk - (long long)p * (D + 1));
@@ -228,8 +237,10 @@ __global__ void __launch_bounds__(256)
     ln_simplex<D>(pr, sc, s);
     int key[D];
     ln_vertex_key<D>(s, r, key);
-    const int h = ln_insert<D>(t, key, uint32_t(tk));
+    int pos;
+    const int h = ln_insert<D>(t, key, pos);
     tok_slot[tk] = h;
+    tok_pos[tk] = pos;
     float b = s.bary[0];
 #pragma unroll
     for (int k = 1; k <= D; ++k) b = (r == k) ? s.bary[k] : b;
@@ -247,17 +258,20 @@ __global__ void __launch_bounds__(256)
 // Token producer 2: coarsen kernel (LatticeGPU.cuh:2348-2511): per fine vertex with all-even key,
 // token 0 = key/2, token 1+2a / 2+2a = the coarse neighbour matching an EXISTING fine np / nm.
 template <int D>
-__global__ void __launch_bounds__(256) k_insert_coarse(LnTable fine, int fine_rows_upper, LnTable coarse, int* tok_slot) {
+__global__ void __launch_bounds__(256)
+    k_insert_coarse(LnTable fine, int fine_rows_upper, LnTable coarse, int* __restrict__ tok_slot, int* __restrict__ tok_pos) {
     constexpr int TPR = 2 * (D + 1) + 1;  // tokens per fine row
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     int m = *fine.nr_filled;
     if (m > fine_rows_upper) m = fine_rows_upper;
     if (r >= fine_rows_upper) return;
     int* ts = tok_slot + (size_t)r * TPR;
-    if (r >= m) {
-        for (int j = 0; j < TPR; ++j) ts[j] = -1;
-        return;
+    int* tp = tok_pos + (size_t)r * TPR;
+    for (int j = 0; j < TPR; ++j) {
+        ts[j] = -1;
+        tp[j] = -1;
     }
+    if (r >= m) return;
     int fk[D + 1];
     int sum = 0;
 #pragma unroll
@@ -269,15 +283,11 @@ __global__ void __launch_bounds__(256) k_insert_coarse(LnTable fine, int fine_ro
     bool all_even = true;
 #pragma unroll
     for (int i = 0; i <= D; ++i) all_even = all_even && ((fk[i] & 1) == 0);  // |frac(key/2)| <= 0.1, LatticeGPU.cuh:2376
-    if (!all_even) {
-        for (int j = 0; j < TPR; ++j) ts[j] = -1;
-        return;
-    }
+    if (!all_even) return;
     int div[D + 1];
 #pragma unroll
     for (int i = 0; i <= D; ++i) div[i] = fk[i] / 2;  // exact: all even
-    const uint32_t tok0 = uint32_t(r) * TPR;
-    ts[0] = ln_insert<D>(coarse, div, tok0);
+    ts[0] = ln_insert<D>(coarse, div, tp[0]);
 #pragma unroll
     for (int axis = 0; axis <= D; ++axis) {
         int nk[D + 1];
@@ -290,7 +300,7 @@ __global__ void __launch_bounds__(256) k_insert_coarse(LnTable fine, int fine_ro
         }
         nk[axis] = fk[axis] - D;
         ck[axis] = div[axis] - D;
-        ts[1 + 2 * axis] = (ln_retrieve<D>(fine, nk) >= 0) ? ln_insert<D>(coarse, ck, tok0 + 1 + 2 * axis) : -1;
+        if (ln_retrieve<D>(fine, nk) >= 0) ts[1 + 2 * axis] = ln_insert<D>(coarse, ck, tp[1 + 2 * axis]);
         // nm: -1 everywhere, +D on the axis
 #pragma unroll
         for (int i = 0; i <= D; ++i) {
@@ -299,8 +309,29 @@ __global__ void __launch_bounds__(256) k_insert_coarse(LnTable fine, int fine_ro
         }
         nk[axis] = fk[axis] + D;
         ck[axis] = div[axis] + D;
-        ts[2 + 2 * axis] = (ln_retrieve<D>(fine, nk) >= 0) ? ln_insert<D>(coarse, ck, tok0 + 2 + 2 * axis) : -1;
+        if (ln_retrieve<D>(fine, nk) >= 0) ts[2 + 2 * axis] = ln_insert<D>(coarse, ck, tp[2 + 2 * axis]);
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// segment minimum -> smallest token per slot (defines the canonical row order)
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+    k_seg_min(LnTable t, const int* __restrict__ slot_start, const int* __restrict__ csr_tok, const int* __restrict__ seg_slot,
+              const int* __restrict__ seg_beg, const int* __restrict__ seg_count) {
+    const int sid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sid >= *seg_count) return;
+    const int h = seg_slot[sid];
+    const int beg = seg_beg[sid];
+    const int sbeg = slot_start[h];
+    const int send = slot_start[h + 1];
+    const int end = min(beg + LN_CSR_SEG, send);
+    unsigned int mn = LN_EMPTY_TOK;
+    for (int e = beg; e < end; ++e) mn = min(mn, (unsigned int)csr_tok[e]);
+    if (send - sbeg <= LN_CSR_SEG)
+        t.slot_tok[h] = mn;  // the slot's only segment
+    else
+        atomicMin(&t.slot_tok[h], mn);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -391,28 +422,33 @@ __global__ void __launch_bounds__(256)
     if (idx_out) idx_out[tk] = row;
 }
 
+// Workspace of one build: first-occurrence bitmap + block counts/prefixes, token->slot scratch,
+// token->position, and the scratch of the slot-CSR construction (ln_csr.hip).
 struct BuildWs {
     unsigned long long* bitmap;
     int* block_cnt;
     int* block_prefix;
     int* tok_slot;
+    int* tok_pos;
+    void* csr_ws;
+    size_t csr_ws_bytes;
     int nb;
 };
 
 static size_t ln_align256(size_t x) { return (x + 255) & ~size_t(255); }
 
-extern "C" size_t ln_build_workspace_bytes(long long tokens) {
+extern "C" size_t ln_build_workspace_bytes(long long tokens, int capacity) {
     if (tokens < 1) tokens = 1;
     const size_t nb = (size_t)ln_div_up(tokens, 256);
     return ln_align256(nb * 4 * sizeof(unsigned long long)) + 2 * ln_align256(nb * sizeof(int)) +
-           ln_align256((size_t)tokens * sizeof(int));
+           2 * ln_align256((size_t)tokens * sizeof(int)) + ln_align256(ln_csr_scan_workspace_bytes(capacity));
 }
 
-static int ln_carve_ws(long long tokens, void* workspace, size_t bytes, BuildWs& ws) {
-    LN_REQUIRE(workspace != nullptr && bytes >= ln_build_workspace_bytes(tokens), LN_ERR_WORKSPACE,
-               "build workspace too small: %zu < %zu", bytes, ln_build_workspace_bytes(tokens));
+static int ln_carve_ws(long long tokens, int capacity, void* workspace, size_t bytes, BuildWs& ws) {
+    LN_REQUIRE(workspace != nullptr && bytes >= ln_build_workspace_bytes(tokens, capacity), LN_ERR_WORKSPACE,
+               "build workspace too small: %zu < %zu", bytes, ln_build_workspace_bytes(tokens, capacity));
     LN_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, LN_ERR_WORKSPACE, "build workspace must be 256-byte aligned");
-    LN_REQUIRE(tokens < 0xFFFFFFFFll, LN_ERR_ARG, "too many insertion tokens: %lld", tokens);
+    LN_REQUIRE(tokens < 0x7FFFFFFFll, LN_ERR_ARG, "too many insertion tokens: %lld", tokens);
     char* p = static_cast<char*>(workspace);
     ws.nb = ln_div_up(tokens, 256);
     ws.bitmap = reinterpret_cast<unsigned long long*>(p);
@@ -422,22 +458,40 @@ static int ln_carve_ws(long long tokens, void* workspace, size_t bytes, BuildWs&
     ws.block_prefix = reinterpret_cast<int*>(p);
     p += ln_align256((size_t)ws.nb * sizeof(int));
     ws.tok_slot = reinterpret_cast<int*>(p);
+    p += ln_align256((size_t)tokens * sizeof(int));
+    ws.tok_pos = reinterpret_cast<int*>(p);
+    p += ln_align256((size_t)tokens * sizeof(int));
+    ws.csr_ws = p;
+    ws.csr_ws_bytes = ln_csr_scan_workspace_bytes(capacity);
     return LN_OK;
 }
 
+// After the producer: slot CSR (scan of slot_cnt + fill) -> per-slot smallest token -> canonical rank.
 template <int D>
-static int ln_rank_and_finalize(const LnTable& t, const int* tok_slot, int* idx_out, long long tokens, const BuildWs& ws,
-                                hipStream_t st) {
+static int ln_rank_and_finalize(const LnTable& t, const int* tok_slot, const int* tok_pos, int* idx_out, long long tokens,
+                                const BuildWs& ws, const LnCsr& csr, hipStream_t st) {
+    int rc = ln_csr_from_counts(tok_slot, tok_pos, tokens, t.slot_cnt, t.capacity, csr, ws.csr_ws, ws.csr_ws_bytes, st);
+    if (rc) return rc;
+    const long long max_seg = ln_csr_max_segments(tokens, t.capacity);
+    LN_LAUNCH("k_seg_min", k_seg_min, dim3(ln_div_up(max_seg, 256)), dim3(256), 0, st, t, csr.grp_start, csr.csr_tok, csr.seg_grp,
+              csr.seg_beg, csr.seg_count);
     LN_LAUNCH("k_mark_first", k_mark_first, dim3(ws.nb), dim3(256), 0, st, t, tok_slot, tokens, ws.bitmap, ws.block_cnt);
     LN_LAUNCH("k_scan_blocks", k_scan_blocks, dim3(1), dim3(1024), 0, st, ws.block_cnt, ws.nb, ws.block_prefix, t.nr_filled);
     LN_LAUNCH("k_finalize", k_finalize<D>, dim3(ws.nb), dim3(256), 0, st, t, tok_slot, idx_out, tokens, ws.bitmap, ws.block_prefix);
-    return ln_check_launch("ln build (mark/scan/finalize)");
+    return ln_check_launch("ln build (csr/segmin/mark/scan/finalize)");
+}
+
+static int ln_check_csr(const LnCsr* c, const char* who) {
+    LN_REQUIRE(c && c->grp_start && c->csr_tok && c->seg_grp && c->seg_beg && c->seg_count, LN_ERR_ARG, "%s: CSR output has a null buffer", who);
+    return LN_OK;
 }
 
 static int ln_build_points(const LnTable* t, const float* positions_raw, const float* sigmas_host, int n, int* idx, float* w,
-                           int write_idx, const float* vals, int val_dim, float* distributed, void* workspace,
+                           int write_idx, const float* vals, int val_dim, float* distributed, const LnCsr* csr, void* workspace,
                            size_t workspace_bytes, void* stream, const char* who) {
     int rc = ln_check_table(t, who);
+    if (rc) return rc;
+    rc = ln_check_csr(csr, who);
     if (rc) return rc;
     LN_REQUIRE(n >= 0, LN_ERR_ARG, "%s: n=%d", who, n);
     LN_REQUIRE(positions_raw != nullptr || n == 0, LN_ERR_ARG, "%s: null positions", who);
@@ -445,51 +499,55 @@ static int ln_build_points(const LnTable* t, const float* positions_raw, const f
     if (n == 0) return LN_OK;
     const long long tokens = (long long)n * (t->pos_dim + 1);
     BuildWs ws;
-    rc = ln_carve_ws(tokens, workspace, workspace_bytes, ws);
+    rc = ln_carve_ws(tokens, t->capacity, workspace, workspace_bytes, ws);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     int* tok_slot = write_idx ? idx : ws.tok_slot;  // idx doubles as the token->slot scratch
+    if (hipMemsetAsync(t->slot_cnt, 0, (size_t)t->capacity * sizeof(int), st) != hipSuccess) return ln_check_launch(who);
     LN_DISPATCH_D(t->pos_dim, {
         LnScale<D> sc = ln_make_scale<D>(sigmas_host);
         LN_LAUNCH("k_insert_points", k_insert_points<D>, dim3(ln_div_up(tokens, 256)), dim3(256), 0, st, *t, positions_raw, sc, n, tok_slot,
-                           write_idx ? w : (float*)nullptr, vals, val_dim, distributed);
-        rc = ln_rank_and_finalize<D>(*t, tok_slot, write_idx ? idx : (int*)nullptr, tokens, ws, st);
+                  ws.tok_pos, write_idx ? w : (float*)nullptr, vals, val_dim, distributed);
+        rc = ln_rank_and_finalize<D>(*t, tok_slot, ws.tok_pos, write_idx ? idx : (int*)nullptr, tokens, ws, *csr, st);
     });
     return rc;
 }
 
 extern "C" int ln_build_splat(const LnTable* t, const float* positions_raw, const float* sigmas_host, int n, int* idx,
-                              float* w, int write_idx, void* workspace, size_t workspace_bytes, void* stream) {
-    return ln_build_points(t, positions_raw, sigmas_host, n, idx, w, write_idx, nullptr, 0, nullptr, workspace,
+                              float* w, int write_idx, const LnCsr* csr, void* workspace, size_t workspace_bytes, void* stream) {
+    return ln_build_points(t, positions_raw, sigmas_host, n, idx, w, write_idx, nullptr, 0, nullptr, csr, workspace,
                            workspace_bytes, stream, "ln_build_splat");
 }
 
 extern "C" int ln_distribute(const LnTable* t, const float* positions_raw, const float* sigmas_host, const float* vals, int n,
-                             int val_dim, int* idx, float* w, float* distributed, void* workspace, size_t workspace_bytes,
-                             void* stream) {
+                             int val_dim, int* idx, float* w, float* distributed, const LnCsr* csr, void* workspace,
+                             size_t workspace_bytes, void* stream) {
     LN_REQUIRE(vals && distributed && idx && w, LN_ERR_ARG, "ln_distribute: null buffer");
     LN_REQUIRE(val_dim >= 1, LN_ERR_ARG, "ln_distribute: val_dim=%d", val_dim);
-    return ln_build_points(t, positions_raw, sigmas_host, n, idx, w, 1, vals, val_dim, distributed, workspace,
+    return ln_build_points(t, positions_raw, sigmas_host, n, idx, w, 1, vals, val_dim, distributed, csr, workspace,
                            workspace_bytes, stream, "ln_distribute");
 }
 
-extern "C" int ln_coarsen(const LnTable* fine, int fine_rows_upper, const LnTable* coarse, void* workspace,
+extern "C" int ln_coarsen(const LnTable* fine, int fine_rows_upper, const LnTable* coarse, const LnCsr* csr, void* workspace,
                           size_t workspace_bytes, void* stream) {
     int rc = ln_check_table(fine, "ln_coarsen(fine)");
     if (rc) return rc;
     rc = ln_check_table(coarse, "ln_coarsen(coarse)");
     if (rc) return rc;
+    rc = ln_check_csr(csr, "ln_coarsen");
+    if (rc) return rc;
     LN_REQUIRE(fine->pos_dim == coarse->pos_dim, LN_ERR_ARG, "ln_coarsen: pos_dim mismatch");
     if (fine_rows_upper <= 0) return LN_OK;
     const long long tokens = (long long)fine_rows_upper * (2 * (fine->pos_dim + 1) + 1);
     BuildWs ws;
-    rc = ln_carve_ws(tokens, workspace, workspace_bytes, ws);
+    rc = ln_carve_ws(tokens, coarse->capacity, workspace, workspace_bytes, ws);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(coarse->slot_cnt, 0, (size_t)coarse->capacity * sizeof(int), st) != hipSuccess) return ln_check_launch("ln_coarsen");
     LN_DISPATCH_D(fine->pos_dim, {
         LN_LAUNCH("k_insert_coarse", k_insert_coarse<D>, dim3(ln_div_up(fine_rows_upper, 256)), dim3(256), 0, st, *fine, fine_rows_upper,
-                           *coarse, ws.tok_slot);
-        rc = ln_rank_and_finalize<D>(*coarse, ws.tok_slot, (int*)nullptr, tokens, ws, st);
+                  *coarse, ws.tok_slot, ws.tok_pos);
+        rc = ln_rank_and_finalize<D>(*coarse, ws.tok_slot, ws.tok_pos, (int*)nullptr, tokens, ws, *csr, st);
     });
     return rc;
 }

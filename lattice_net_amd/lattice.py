@@ -43,6 +43,7 @@ class _TableStorage:
         self.entries = torch.empty((capacity,), dtype=torch.int32, device=device)
         self.slot_keys = torch.empty((capacity,), dtype=torch.int64, device=device)
         self.slot_tok = torch.empty((capacity,), dtype=torch.int32, device=device)
+        self.slot_cnt = torch.empty((capacity,), dtype=torch.int32, device=device)
         self.version = 0
         self.nbr_cache = {}
         self.csr_cache = {}
@@ -54,6 +55,7 @@ class _TableStorage:
         s.entries = self.entries.clone()
         s.slot_keys = self.slot_keys.clone()
         s.slot_tok = self.slot_tok.clone()
+        s.slot_cnt = self.slot_cnt.clone()
         s.version = 0
         s.nbr_cache = {}
         s.csr_cache = {}
@@ -106,7 +108,7 @@ class HashTable:
         s = self._storage
         if s is None:
             raise _lib.LatticeNetHipError("hash table is not initialised (no splat / create_verts happened yet)")
-        return _lib.LnTable(s.capacity, s.pos_dim, s.slot_keys.data_ptr(), s.slot_tok.data_ptr(), s.entries.data_ptr(),
+        return _lib.LnTable(s.capacity, s.pos_dim, s.slot_keys.data_ptr(), s.slot_tok.data_ptr(), s.slot_cnt.data_ptr(), s.entries.data_ptr(),
                             s.keys.data_ptr(), self._counters.data_ptr(), self._counters.data_ptr() + 4)
 
     def clear(self):  # HashTable.cu:49-57, one launch instead of four fill_ kernels
@@ -280,6 +282,20 @@ class Lattice:
         if not self.m_hash_table.is_initialized():
             self.m_hash_table.init(pos_dim, val_dim, self._dev(like))
 
+    def _alloc_csr(self, tokens: int, groups_upper: int):
+        """One int32 allocation: grp_start[groups+1] | csr_tok[tokens] | seg_grp[S] | seg_beg[S] | seg_count[1]."""
+        lib = _lib.load()
+        max_seg = int(lib.ln_csr_max_segments(tokens, groups_upper))
+        tk = max(tokens, 1)
+        buf = torch.empty((groups_upper + 1 + tk + 2 * max_seg + 1,), dtype=torch.int32, device=self._dev())
+        base = buf.data_ptr()
+        o1 = groups_upper + 1
+        o2 = o1 + tk
+        o3 = o2 + max_seg
+        o4 = o3 + max_seg
+        c = _lib.LnCsr(base, base + 4 * o1, base + 4 * o2, base + 4 * o3, base + 4 * o4)
+        return buf, c, max_seg
+
     def _build(self, positions_raw, write: bool, vals=None, distributed=None):
         lib = _lib.load()
         n, d = positions_raw.shape
@@ -289,60 +305,57 @@ class Lattice:
         if write:
             idx = torch.empty((n * (d + 1),), dtype=torch.int32, device=dev)
             w = torch.empty((n * (d + 1),), dtype=torch.float32, device=dev)
-        ws_bytes = lib.ln_build_workspace_bytes(n * (d + 1))
-        ws = self._workspace(ws_bytes)
+        tokens = n * (d + 1)
+        cap = ht.capacity()
+        ws = self._workspace(lib.ln_build_workspace_bytes(tokens, cap))
+        csr_buf, csr, max_seg = self._alloc_csr(tokens, cap)
         t = ht.c_table()
         if distributed is None:
             rc = lib.ln_build_splat(C.byref(t), _lib.ptr(positions_raw), self._sigmas_host(), n, _lib.ptr(idx), _lib.ptr(w),
-                                    1 if write else 0, _lib.ptr(ws), ws.numel(), self._stream())
+                                    1 if write else 0, C.byref(csr), _lib.ptr(ws), ws.numel(), self._stream())
             _lib.check(rc, "ln_build_splat")
         else:
             rc = lib.ln_distribute(C.byref(t), _lib.ptr(positions_raw), self._sigmas_host(), _lib.ptr(vals), n, vals.shape[1],
-                                   _lib.ptr(idx), _lib.ptr(w), _lib.ptr(distributed), _lib.ptr(ws), ws.numel(), self._stream())
+                                   _lib.ptr(idx), _lib.ptr(w), _lib.ptr(distributed), C.byref(csr), _lib.ptr(ws), ws.numel(),
+                                   self._stream())
             _lib.check(rc, "ln_distribute")
         ht._storage.touch()
         ht.m_nr_filled_is_dirty = True
+        if write:
+            # the build's slot -> tokens adjacency serves every scatter that uses these indices (groups = slots,
+            # row of a group = entries[slot]); `idx` is kept alive by the entry so its address cannot be recycled
+            st = ht._storage
+            st.csr_cache[(idx.data_ptr(), idx._version, idx.numel())] = (csr_buf, csr, max_seg, st.entries, idx)
         return idx, w
 
     # ---------------------------------------------------------------- atomics-free scatter (CSR)
     def _csr(self, idx: torch.Tensor):
-        """CSR adjacency (vertex -> contributing tokens, cut into segments) of a splat-index tensor, cached
-        with the table structure.  The entry keeps `idx` alive, so (data_ptr, version, numel) cannot be
-        recycled by another tensor while cached."""
+        """CSR adjacency (group -> contributing tokens, cut into segments) for a splat-index tensor, cached with
+        the table structure: the one emitted by the build that produced `idx`, else built from `idx` itself."""
         st = self.m_hash_table._storage
         key = (idx.data_ptr(), idx._version, idx.numel())
         hit = st.csr_cache.get(key)
         if hit is not None:
             return hit
         lib = _lib.load()
-        dev = self._dev()
         tokens = idx.numel()
         rows_upper = self.m_hash_table.capacity()
-        max_seg = int(lib.ln_csr_max_segments(tokens, rows_upper))
-        # one allocation: row_start[rows_upper+1] | csr_tok[tokens] | seg_row[max_seg] | seg_beg[max_seg] | seg_count[1]
-        buf = torch.empty((rows_upper + 1 + max(tokens, 1) + 2 * max_seg + 1,), dtype=torch.int32, device=dev)
-        o1 = rows_upper + 1
-        o2 = o1 + max(tokens, 1)
-        o3 = o2 + max_seg
-        o4 = o3 + max_seg
-        row_start, csr_tok, seg_row, seg_beg, seg_count = buf[:o1], buf[o1:o2], buf[o2:o3], buf[o3:o4], buf[o4:]
+        csr_buf, csr, max_seg = self._alloc_csr(tokens, rows_upper)
         ws = self._workspace(lib.ln_csr_workspace_bytes(tokens, rows_upper))
-        _lib.check(lib.ln_csr_build(_lib.ptr(idx), tokens, rows_upper, _lib.ptr(row_start), _lib.ptr(csr_tok), _lib.ptr(seg_row),
-                                    _lib.ptr(seg_beg), _lib.ptr(seg_count), _lib.ptr(ws), ws.numel(), self._stream()), "ln_csr_build")
+        _lib.check(lib.ln_csr_build(_lib.ptr(idx), tokens, rows_upper, C.byref(csr), _lib.ptr(ws), ws.numel(), self._stream()), "ln_csr_build")
         if len(st.csr_cache) >= 4:
             st.csr_cache.pop(next(iter(st.csr_cache)))
-        entry = (row_start, csr_tok, seg_row, seg_beg, seg_count, max_seg, idx)
+        entry = (csr_buf, csr, max_seg, None, idx)  # groups are rows: no indirection
         st.csr_cache[key] = entry
         return entry
 
     def _scatter_rows(self, src: torch.Tensor, idx: torch.Tensor, w: torch.Tensor, dst: torch.Tensor, val_dim: int, src_div: int,
                       src_stride: int):
         """dst[row] += sum of the row's contributions (segment-balanced reduce over the CSR adjacency); dst pre-zeroed."""
-        row_start, csr_tok, seg_row, seg_beg, seg_count, max_seg, _ = self._csr(idx)
+        _, csr, max_seg, grp_row, _ = self._csr(idx)
         lib = _lib.load()
-        _lib.check(lib.ln_csr_reduce_rows(_lib.ptr(row_start), _lib.ptr(csr_tok), _lib.ptr(seg_row), _lib.ptr(seg_beg), _lib.ptr(seg_count),
-                                          max_seg, _lib.ptr(src), _lib.ptr(w), val_dim, src_div, src_stride, _lib.ptr(dst),
-                                          self._stream()), "ln_csr_reduce_rows")
+        _lib.check(lib.ln_csr_reduce_rows(C.byref(csr), _lib.ptr(grp_row), max_seg, _lib.ptr(src), _lib.ptr(w), val_dim, src_div,
+                                          src_stride, _lib.ptr(dst), self._stream()), "ln_csr_reduce_rows")
 
     # ---------------------------------------------------------------- splat family
     def begin_splat(self, reset_hashmap: bool = True):  # Lattice.cu:185-193
@@ -557,9 +570,11 @@ class Lattice:
         lib = _lib.load()
         m = self.nr_lattice_vertices()
         tokens = m * (2 * (self.pos_dim() + 1) + 1)
-        ws = self._workspace(lib.ln_build_workspace_bytes(tokens))
+        cap = coarse.m_hash_table.capacity()
+        ws = self._workspace(lib.ln_build_workspace_bytes(tokens, cap))
+        csr_buf, csr, _ = self._alloc_csr(tokens, cap)
         tf, tc = self.m_hash_table.c_table(), coarse.m_hash_table.c_table()
-        _lib.check(lib.ln_coarsen(C.byref(tf), m, C.byref(tc), _lib.ptr(ws), ws.numel(), self._stream()), "ln_coarsen")
+        _lib.check(lib.ln_coarsen(C.byref(tf), m, C.byref(tc), C.byref(csr), _lib.ptr(ws), ws.numel(), self._stream()), "ln_coarsen")
         coarse.m_hash_table._storage.touch()
         coarse.m_hash_table.m_nr_filled_is_dirty = True
         nr = coarse.nr_lattice_vertices()

@@ -30,9 +30,11 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 
 def test_struct_layout_matches_header():
-    # int, int, 6 pointers -> 8 + 6*8 bytes on LP64
-    assert C.sizeof(_lib.LnTable) == 56
-    assert [f[0] for f in _lib.LnTable._fields_] == ["capacity", "pos_dim", "slot_keys", "slot_tok", "entries", "keys", "nr_filled", "status"]
+    # int, int, 7 pointers -> 8 + 7*8 bytes on LP64
+    assert C.sizeof(_lib.LnTable) == 64
+    assert [f[0] for f in _lib.LnTable._fields_] == ["capacity", "pos_dim", "slot_keys", "slot_tok", "slot_cnt", "entries", "keys",
+                                                     "nr_filled", "status"]
+    assert C.sizeof(_lib.LnCsr) == 40
 
 
 def test_version_and_kernel_names():
@@ -48,7 +50,7 @@ def test_argument_errors_are_reported_not_fatal():
     assert b"bad sizes" in lib.ln_last_error_string()
     assert lib.ln_neighbours(None, 10, None, 1, 1, 1, 0, None, None) == -1
     assert b"null table" in lib.ln_last_error_string()
-    t = _lib.LnTable(100, 9, 1, 1, 1, 1, 1, 1)  # pos_dim 9 is unsupported
+    t = _lib.LnTable(100, 9, 1, 1, 1, 1, 1, 1, 1)  # pos_dim 9 is unsupported
     assert lib.ln_table_clear(C.byref(t), None, 0, None) == -2
     with pytest.raises(_lib.LatticeNetHipError, match="unsupported"):
         _lib.check(-2, "ln_table_clear")
@@ -56,7 +58,7 @@ def test_argument_errors_are_reported_not_fatal():
 
 def test_workspace_queries_are_pure_host_functions():
     lib = _lib.load()
-    assert lib.ln_build_workspace_bytes(480000) >= 480000 * 4
+    assert lib.ln_build_workspace_bytes(480000, 100000) >= 2 * 480000 * 4
     assert lib.ln_csr_workspace_bytes(480000, 100000) >= 480000 * 4 + 3 * 100000 * 4
     assert lib.ln_csr_max_segments(480000, 100000) == 100000 + 480000 // 16 + 1
     assert lib.ln_conv_grad_filter_workspace_bytes(46538, 9, 32, 32) >= 91 * 9 * 32 * 32 * 4
