@@ -98,6 +98,88 @@ __global__ void __launch_bounds__(256)
     }
 }
 
+// Small-filter fast path (E*V*F*4 <= 64 KiB, e.g. V = F = 32 with E = 9): the WHOLE filter bank is
+// staged into LDS once per workgroup (one barrier), and every lane issues the gathers of all E
+// neighbour rows up front, so the kernel pays one memory latency instead of E.
+template <int V, int NT, int E>
+__global__ void __launch_bounds__(256)
+    k_conv_mfma_full(const int* __restrict__ nbr, const float* __restrict__ values, const float* __restrict__ filter, int m,
+                     float* __restrict__ out) {
+    constexpr int F = 16 * NT;
+    constexpr int KQ = V / 4;
+    static_assert(E * V * F * 4 <= 64 * 1024, "filter bank must fit 64 KiB of LDS");
+    __shared__ __attribute__((aligned(16))) float s_b[E * V * F];  // [((e*KQ + kk)*NT + nt)*64 + lane]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int i = lane & 15;
+    const int q = lane >> 4;
+    const int m0 = blockIdx.x * 64 + wave * 16;
+    const int my_row = m0 + i;
+
+    int nb[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) nb[e] = (my_row < m) ? nbr[(size_t)my_row * E + e] : -1;
+    // unconditional gathers (absent neighbours read row 0 and are zeroed afterwards): no branch, so all
+    // E gathers are in flight together
+    float a[E][KQ];
+#pragma unroll
+    for (int e = 0; e < E; ++e) ln_load_quarter<KQ>(values + (size_t)(nb[e] >= 0 ? nb[e] : 0) * V + q * KQ, a[e]);
+    // stage the filter bank: coalesced float4 reads of [E*V, F] rows, scattered into fragment order.
+    // All loads are issued before the first LDS write so the workgroup pays ONE memory latency.
+    constexpr int N4 = E * V * F / 4;
+    constexpr int NST = (N4 + 255) / 256;
+    float4 wv[NST];
+#pragma unroll
+    for (int s = 0; s < NST; ++s) {
+        const int x4 = tid + s * 256;
+        wv[s] = (x4 < N4) ? reinterpret_cast<const float4*>(filter)[x4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int s = 0; s < NST; ++s) {
+        const int x4 = tid + s * 256;
+        if (x4 < N4) {
+            const int x = x4 * 4;
+            const int ek = x / F;       // e*V + k
+            const int f = x - ek * F;   // multiple of 4
+            const int e = ek / V;
+            const int k = ek - e * V;
+            const int qq = k / KQ;
+            const int kk = k - qq * KQ;
+            float* dst = s_b + (((e * KQ + kk) * NT + (f >> 4)) * 64 + qq * 16 + (f & 15));
+            *reinterpret_cast<float4*>(dst) = wv[s];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+#pragma unroll
+        for (int k = 0; k < KQ; ++k) a[e][k] = nb[e] >= 0 ? a[e][k] : 0.f;
+
+    floatx4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+#pragma unroll
+        for (int kk = 0; kk < KQ; ++kk) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float b = s_b[((e * KQ + kk) * NT + nt) * 64 + lane];
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e][kk], b, acc[nt], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + q * 4 + r;
+            if (row < m) out[(size_t)row * F + nt * 16 + i] = acc[nt][r];
+        }
+    }
+}
+
 // Any (V, F): one thread per output element.
 __global__ void __launch_bounds__(256)
     k_conv_generic(const int* __restrict__ nbr, const float* __restrict__ values, const float* __restrict__ filter, long long work,
@@ -137,7 +219,18 @@ extern "C" int ln_conv_forward(const int* nbr, const float* values_neigh, const 
     if (m == 0) return LN_OK;
     hipStream_t st = (hipStream_t)stream;
     bool done = false;
-    if (nr_filters % 16 == 0) {
+    if (filter_extent == 9 && (reinterpret_cast<uintptr_t>(filter) & 15) == 0) {  // d = 3 small-filter fast path
+        const dim3 grid(ln_div_up(m, 64)), block(256);
+#define LN_CONV_FULL(VV, NN)                                                                                                       \
+    if (!done && val_dim == VV && nr_filters == 16 * NN) {                                                                         \
+        LN_LAUNCH("k_conv_mfma", (k_conv_mfma_full<VV, NN, 9>), grid, block, 0, st, nbr, values_neigh, filter, m, out);             \
+        done = true;                                                                                                               \
+    }
+        LN_CONV_FULL(32, 2) LN_CONV_FULL(32, 1) LN_CONV_FULL(16, 1) LN_CONV_FULL(16, 2) LN_CONV_FULL(16, 4) LN_CONV_FULL(8, 1)
+        LN_CONV_FULL(8, 2) LN_CONV_FULL(8, 4) LN_CONV_FULL(8, 8)
+#undef LN_CONV_FULL
+    }
+    if (!done && nr_filters % 16 == 0) {
         const int nt = nr_filters / 16;
         switch (val_dim) {
             case 8: done = ln_conv_launch_v<8>(nt, nbr, values_neigh, filter, m, filter_extent, out, st); break;

@@ -197,7 +197,10 @@ extern "C" int ln_csr_build(const int* idx, long long tokens, int groups_upper, 
 }
 
 // dst[row, j] += sum over the row's tokens t of src[(t / src_div) * src_stride + j] * w[t]   (j < V)
-// One lane group per segment; LN_SEG/U batches of U independent gathers per lane.
+// One lane group per segment; LN_SEG/U batches of U independent gathers per lane.  Segments of one
+// group have consecutive ids, so neighbouring lane groups of a wave often hold partial sums of the
+// same (hot) vertex: they are combined with a segmented shuffle reduction and only the head of each
+// run writes — a plain store when the run covers the whole group, one atomicAdd otherwise.
 template <int VEC>
 __global__ void __launch_bounds__(256)
     k_csr_reduce_segments(const int* __restrict__ grp_start, const int* __restrict__ csr_tok, const int* __restrict__ seg_grp,
@@ -208,57 +211,85 @@ __global__ void __launch_bounds__(256)
     const long long gt = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long sid = gt / lanes_per_seg;
     const int lc = int(gt - sid * lanes_per_seg);
-    if (sid >= *seg_count) return;
-    const int grp = seg_grp[sid];
-    const int beg = seg_beg[sid];
-    const int rbeg = grp_start[grp];
-    const int rend = grp_start[grp + 1];
-    const int row = grp_row ? grp_row[grp] : grp;  // groups are hash slots (row = entries[slot]) or rows themselves
-    if (row < 0) return;
-    const int end = min(beg + LN_SEG, rend);
-    const bool single = (rend - rbeg) <= LN_SEG;
+    const int lane = threadIdx.x & 63;
+    const int grp_in_wave = lane / lanes_per_seg;
+    const int groups_per_wave = 64 / lanes_per_seg;
+    const bool active = sid < *seg_count;
+    int grp = -1, beg = 0, rbeg = 0, rend = 0, end = 0, row = -1;
+    if (active) {
+        grp = seg_grp[sid];
+        beg = seg_beg[sid];
+        rbeg = grp_start[grp];
+        rend = grp_start[grp + 1];
+        end = min(beg + LN_SEG, rend);
+        row = grp_row ? grp_row[grp] : grp;  // groups are hash slots (row = entries[slot]) or rows themselves
+    }
     const int V = chunks * VEC;
-    for (int c = lc; c < chunks; c += lanes_per_seg) {
+    const int nchunk_iter = (chunks + lanes_per_seg - 1) / lanes_per_seg;  // wave-uniform trip count (shuffles inside)
+    for (int it = 0; it < nchunk_iter; ++it) {
+        const int c = lc + it * lanes_per_seg;
+        const bool cok = active && row >= 0 && c < chunks;
         float acc[VEC];
 #pragma unroll
         for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
-        for (int e0 = beg; e0 < end; e0 += U) {
-            int tk[U];
-            float wt[U];
-            float x[U][VEC];
+        if (cok) {
+            for (int e0 = beg; e0 < end; e0 += U) {
+                int tk[U];
+                float wt[U];
+                float x[U][VEC];
 #pragma unroll
-            for (int u = 0; u < U; ++u) tk[u] = (e0 + u < end) ? csr_tok[e0 + u] : -1;
+                for (int u = 0; u < U; ++u) tk[u] = (e0 + u < end) ? csr_tok[e0 + u] : -1;
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                wt[u] = 0.f;
+                for (int u = 0; u < U; ++u) {
+                    wt[u] = 0.f;
 #pragma unroll
-                for (int k = 0; k < VEC; ++k) x[u][k] = 0.f;
-                if (tk[u] >= 0) {
-                    wt[u] = w[tk[u]];
-                    const float* sp = src + (size_t)(tk[u] / src_div) * src_stride + c * VEC;
-                    if constexpr (VEC == 4) {
-                        const float4 v4 = *reinterpret_cast<const float4*>(sp);
-                        x[u][0] = v4.x; x[u][1] = v4.y; x[u][2] = v4.z; x[u][3] = v4.w;
-                    } else {
-                        x[u][0] = sp[0];
+                    for (int k = 0; k < VEC; ++k) x[u][k] = 0.f;
+                    if (tk[u] >= 0) {
+                        wt[u] = w[tk[u]];
+                        const float* sp = src + (size_t)(tk[u] / src_div) * src_stride + c * VEC;
+                        if constexpr (VEC == 4) {
+                            const float4 v4 = *reinterpret_cast<const float4*>(sp);
+                            x[u][0] = v4.x; x[u][1] = v4.y; x[u][2] = v4.z; x[u][3] = v4.w;
+                        } else {
+                            x[u][0] = sp[0];
+                        }
                     }
                 }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) acc[k] = fmaf(x[u][k], wt[u], acc[k]);
             }
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) acc[k] = fmaf(x[u][k], wt[u], acc[k]);
         }
-        float* d = dst + (size_t)row * V + c * VEC;
-        if (single) {
-            if constexpr (VEC == 4) {
-                *reinterpret_cast<float4*>(d) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-            } else {
-                d[0] = acc[0];
-            }
-        } else {
+        // segmented suffix reduction over the lane groups of this wave (runs of equal group id are contiguous)
+        int run_end = end;
+        for (int off = 1; off < groups_per_wave; off <<= 1) {
+            const int delta = off * lanes_per_seg;
+            const int o_grp = __shfl_down(grp, delta, 64);
+            const int o_end = __shfl_down(run_end, delta, 64);
+            float o_acc[VEC];
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) __hip_atomic_fetch_add(d + k, acc[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int k = 0; k < VEC; ++k) o_acc[k] = __shfl_down(acc[k], delta, 64);
+            if (grp_in_wave + off < groups_per_wave && o_grp == grp && grp >= 0) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) acc[k] += o_acc[k];
+                run_end = max(run_end, o_end);
+            }
+        }
+        const int prev_grp = __shfl_up(grp, lanes_per_seg, 64);
+        const bool head = (grp_in_wave == 0) || (prev_grp != grp);
+        if (cok && head) {
+            float* d = dst + (size_t)row * V + c * VEC;
+            if (beg == rbeg && run_end == rend) {  // this run is the whole group: no other writer
+                if constexpr (VEC == 4) {
+                    *reinterpret_cast<float4*>(d) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                } else {
+                    d[0] = acc[0];
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) __hip_atomic_fetch_add(d + k, acc[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 }
