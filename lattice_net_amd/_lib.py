@@ -116,15 +116,15 @@ def check(rc: int, what: str = ""):
         raise LatticeNetHipError(f"{what or 'latticenet_hip'} failed (code {rc}): {msg}")
 
 
-def ptr(t) -> C.c_void_p:
-    """Device pointer of a tensor (None -> NULL)."""
-    if t is None:
-        return C.c_void_p(0)
-    return C.c_void_p(t.data_ptr())
+def ptr(t):
+    """Device pointer of a tensor as an int (None -> NULL); ctypes converts it to void*."""
+    return None if t is None else t.data_ptr()
 
 
-def stream_ptr(device) -> C.c_void_p:
-    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+def stream_ptr(device) -> int:
+    """Raw hipStream_t of torch's current stream on `device` (fast path: no Stream object is built)."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    return torch._C._cuda_getCurrentRawStream(idx)
 
 
 def host_floats(values):

@@ -106,4 +106,28 @@ __device__ __forceinline__ int ln_retrieve(const LnTable& t, const int* key) {
 }
 #endif
 
+#if defined(__HIPCC__)
+// Exclusive prefix sum of one int per thread over a 256-thread workgroup (4 waves): shuffle scan inside
+// each wave, wave totals through 4 LDS words.  `s_tmp` needs 5 ints; *total receives the block sum.
+__device__ __forceinline__ int ln_block_excl_scan_256(int v, int* s_tmp, int* total) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    if (lane == 63) s_tmp[wave] = incl;
+    __syncthreads();
+    int wave_off = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (k < wave) wave_off += s_tmp[k];
+    *total = s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3];
+    __syncthreads();
+    return wave_off + incl - v;
+}
+#endif
+
 static inline int ln_div_up(long long a, long long b) { return int((a + b - 1) / b); }

@@ -68,67 +68,50 @@ __global__ void __launch_bounds__(LN_SCAN_BLOCK)
     }
 }
 
-// single workgroup: exclusive scan of the (token, segment) block totals; totals land at index nb
-__global__ void __launch_bounds__(1024) k_csr_scan_top(const int* __restrict__ block_tot, int nb, int* __restrict__ block_off,
-                                                       int* __restrict__ seg_count) {
-    __shared__ int s_tok[16];
-    __shared__ int s_seg[16];
-    __shared__ int s_run[2];
+// Exclusive scan of `n` ints of `src` (stride `stride`) into LDS array `dst[0..n]` (dst[n] = total),
+// done redundantly by every workgroup that needs the top level of the two-level scan: n is the number
+// of 1024-row blocks (98 for a 100k-slot table), so this is far cheaper than one more kernel launch.
+__device__ __forceinline__ void ln_block_excl_scan_to_lds(const int* __restrict__ src, int stride, int n, int* dst, int* s_part) {
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    if (tid < 2) s_run[tid] = 0;
+    const int per = (n + 255) / 256;
+    const int b = tid * per;
+    int sum = 0;
+    for (int k = 0; k < per; ++k)
+        if (b + k < n) sum += src[(size_t)(b + k) * stride];
+    int total;
+    int run = ln_block_excl_scan_256(sum, s_part, &total);
+    if (tid == 0) dst[n] = total;
+    for (int k = 0; k < per; ++k)
+        if (b + k < n) {
+            dst[b + k] = run;
+            run += src[(size_t)(b + k) * stride];
+        }
     __syncthreads();
-    for (int start = 0; start < nb; start += 1024) {
-        const int i = start + tid;
-        const int c = (i < nb) ? block_tot[2 * i] : 0;
-        const int sg = (i < nb) ? block_tot[2 * i + 1] : 0;
-        const int ic = ln_wave_incl_scan(c, lane);
-        const int is = ln_wave_incl_scan(sg, lane);
-        if (lane == 63) {
-            s_tok[wave] = ic;
-            s_seg[wave] = is;
-        }
-        __syncthreads();
-        int off_t = 0, off_s = 0;
-        for (int k = 0; k < wave; ++k) {
-            off_t += s_tok[k];
-            off_s += s_seg[k];
-        }
-        const int rt = s_run[0], rs = s_run[1];
-        if (i < nb) {
-            block_off[2 * i] = rt + off_t + ic - c;
-            block_off[2 * i + 1] = rs + off_s + is - sg;
-        }
-        __syncthreads();
-        if (tid == 1023) {
-            s_run[0] = rt + off_t + ic;
-            s_run[1] = rs + off_s + is;
-        }
-        __syncthreads();
-    }
-    if (tid == 0) {
-        block_off[2 * nb] = s_run[0];
-        block_off[2 * nb + 1] = s_run[1];
-        *seg_count = s_run[1];
-    }
 }
 
 __global__ void __launch_bounds__(256)
     k_csr_fill(const int* __restrict__ idx, const int* __restrict__ pos, long long tokens, int rows_upper,
-               const int* __restrict__ local_tok, const int* __restrict__ local_seg, const int* __restrict__ block_off, int nb,
-               int* __restrict__ row_start, int* __restrict__ csr_tok, int* __restrict__ seg_row, int* __restrict__ seg_beg) {
+               const int* __restrict__ local_tok, const int* __restrict__ local_seg, const int* __restrict__ block_tot, int nb,
+               int* __restrict__ row_start, int* __restrict__ csr_tok, int* __restrict__ seg_row, int* __restrict__ seg_beg,
+               int* __restrict__ seg_count) {
+    extern __shared__ int s_fill[];  // off_tok[nb+1] | off_seg[nb+1] | part[256]
+    int* off_tok = s_fill;
+    int* off_seg = s_fill + (nb + 1);
+    int* part = s_fill + 2 * (nb + 1);
+    ln_block_excl_scan_to_lds(block_tot, 2, nb, off_tok, part);
+    ln_block_excl_scan_to_lds(block_tot + 1, 2, nb, off_seg, part);
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t <= rows_upper) row_start[t] = (t < rows_upper) ? local_tok[t] + block_off[2 * (t / LN_SCAN_BLOCK)] : block_off[2 * nb];
+    if (t == 0) *seg_count = off_seg[nb];
+    if (t <= rows_upper) row_start[t] = (t < rows_upper) ? local_tok[t] + off_tok[t / LN_SCAN_BLOCK] : off_tok[nb];
     if (t < tokens) {
         const int p = pos[t];
         if (p >= 0) {
             const int row = idx[t];
             const int blk = row / LN_SCAN_BLOCK;
-            const int rbeg = local_tok[row] + block_off[2 * blk];
+            const int rbeg = local_tok[row] + off_tok[blk];
             csr_tok[rbeg + p] = int(t);
             if (p % LN_SEG == 0) {  // this token opens a segment
-                const int sid = local_seg[row] + block_off[2 * blk + 1] + p / LN_SEG;
+                const int sid = local_seg[row] + off_seg[blk] + p / LN_SEG;
                 seg_row[sid] = row;
                 seg_beg[sid] = rbeg + p;
             }
@@ -147,7 +130,7 @@ extern "C" long long ln_csr_max_segments(long long tokens, int groups_upper) {
 size_t ln_csr_scan_workspace_bytes(int groups_upper) {
     if (groups_upper < 1) groups_upper = 1;
     const size_t nb = (size_t)ln_div_up(groups_upper, LN_SCAN_BLOCK);
-    return ln_align256c((size_t)groups_upper * 4) * 2 + ln_align256c(nb * 8) + ln_align256c((nb + 1) * 8);
+    return ln_align256c((size_t)groups_upper * 4) * 2 + ln_align256c(nb * 8);
 }
 
 int ln_csr_from_counts(const int* tok_grp, const int* tok_pos, long long tokens, const int* grp_cnt, int groups_upper,
@@ -160,13 +143,12 @@ int ln_csr_from_counts(const int* tok_grp, const int* tok_pos, long long tokens,
     int* local_seg = reinterpret_cast<int*>(p);
     p += ln_align256c((size_t)groups_upper * 4);
     int* block_tot = reinterpret_cast<int*>(p);
-    p += ln_align256c((size_t)nb * 8);
-    int* block_off = reinterpret_cast<int*>(p);
+    const size_t lds = (size_t)(2 * (nb + 1) + 256) * sizeof(int);
+    LN_REQUIRE(lds <= 64 * 1024, LN_ERR_UNSUPPORTED, "capacity %d too large for the in-LDS top-level scan", groups_upper);
     LN_LAUNCH("k_csr_scan_local", k_csr_scan_local, dim3(nb), dim3(LN_SCAN_BLOCK), 0, st, grp_cnt, groups_upper, local_tok, local_seg, block_tot);
-    LN_LAUNCH("k_csr_scan_top", k_csr_scan_top, dim3(1), dim3(1024), 0, st, block_tot, nb, block_off, csr.seg_count);
     const long long work = (tokens > groups_upper + 1) ? tokens : (long long)groups_upper + 1;
-    LN_LAUNCH("k_csr_fill", k_csr_fill, dim3(ln_div_up(work, 256)), dim3(256), 0, st, tok_grp, tok_pos, tokens, groups_upper, local_tok, local_seg,
-              block_off, nb, csr.grp_start, csr.csr_tok, csr.seg_grp, csr.seg_beg);
+    LN_LAUNCH("k_csr_fill", k_csr_fill, dim3(ln_div_up(work, 256)), dim3(256), lds, st, tok_grp, tok_pos, tokens, groups_upper, local_tok, local_seg,
+              block_tot, nb, csr.grp_start, csr.csr_tok, csr.seg_grp, csr.seg_beg, csr.seg_count);
     return ln_check_launch("ln_csr_from_counts");
 }
 

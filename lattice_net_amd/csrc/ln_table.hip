@@ -72,7 +72,7 @@ LnProfScope::~LnProfScope() {
     }
 }
 
-extern "C" const char* ln_kernel_names(void) { return "k_conv_generic,k_conv_mfma,k_csr_count,k_csr_fill,k_csr_reduce_segments,k_csr_scan_local,k_csr_scan_top,k_finalize,k_gather_backward,k_gather_forward,k_grad_filter_generic,k_grad_filter_mfma,k_im2row,k_im2rowindices,k_insert_coarse,k_insert_points,k_mark_first,k_neighbours,k_reduce_slabs,k_retrieve_points,k_row2im,k_scan_blocks,k_scatter_point_rows,k_seg_min,k_slice_classify_backward,k_slice_classify_forward,k_slice_forward,k_table_clear"; }
+extern "C" const char* ln_kernel_names(void) { return "k_conv_generic,k_conv_mfma,k_csr_count,k_csr_fill,k_csr_reduce_segments,k_csr_scan_local,k_finalize,k_gather_backward,k_gather_forward,k_grad_filter_generic,k_grad_filter_mfma,k_im2row,k_im2rowindices,k_insert_coarse,k_insert_points,k_mark_first,k_neighbours,k_reduce_slabs,k_retrieve_points,k_row2im,k_scan_blocks,k_scatter_point_rows,k_seg_min,k_slice_classify_backward,k_slice_classify_forward,k_slice_forward,k_table_clear"; }
 
 extern "C" int ln_profile_begin(const char* kernel_name, int max_samples) {
     LN_REQUIRE(kernel_name && strlen(kernel_name) < sizeof(g_prof.name) && max_samples > 0, LN_ERR_ARG, "ln_profile_begin: bad args");
@@ -328,6 +328,7 @@ __global__ void __launch_bounds__(256)
     const int end = min(beg + LN_CSR_SEG, send);
     unsigned int mn = LN_EMPTY_TOK;
     for (int e = beg; e < end; ++e) mn = min(mn, (unsigned int)csr_tok[e]);
+    t.slot_cnt[h] = 0;  // the counts were consumed by the scan: keep the invariant "all zero between builds"
     if (send - sbeg <= LN_CSR_SEG)
         t.slot_tok[h] = mn;  // the slot's only segment
     else
@@ -357,6 +358,7 @@ __global__ void __launch_bounds__(256)
     if (threadIdx.x == 0) block_cnt[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
 }
 
+// single workgroup: exclusive scan of the per-block first-occurrence counts (+ rows that existed before)
 __global__ void __launch_bounds__(1024) k_scan_blocks(const int* __restrict__ block_cnt, int nb, int* __restrict__ block_prefix,
                                                       int* nr_filled) {
     __shared__ int s_wave[16];
@@ -503,7 +505,6 @@ static int ln_build_points(const LnTable* t, const float* positions_raw, const f
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     int* tok_slot = write_idx ? idx : ws.tok_slot;  // idx doubles as the token->slot scratch
-    if (hipMemsetAsync(t->slot_cnt, 0, (size_t)t->capacity * sizeof(int), st) != hipSuccess) return ln_check_launch(who);
     LN_DISPATCH_D(t->pos_dim, {
         LnScale<D> sc = ln_make_scale<D>(sigmas_host);
         LN_LAUNCH("k_insert_points", k_insert_points<D>, dim3(ln_div_up(tokens, 256)), dim3(256), 0, st, *t, positions_raw, sc, n, tok_slot,
@@ -543,7 +544,6 @@ extern "C" int ln_coarsen(const LnTable* fine, int fine_rows_upper, const LnTabl
     rc = ln_carve_ws(tokens, coarse->capacity, workspace, workspace_bytes, ws);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(coarse->slot_cnt, 0, (size_t)coarse->capacity * sizeof(int), st) != hipSuccess) return ln_check_launch("ln_coarsen");
     LN_DISPATCH_D(fine->pos_dim, {
         LN_LAUNCH("k_insert_coarse", k_insert_coarse<D>, dim3(ln_div_up(fine_rows_upper, 256)), dim3(256), 0, st, *fine, fine_rows_upper,
                   *coarse, ws.tok_slot, ws.tok_pos);

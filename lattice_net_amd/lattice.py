@@ -108,6 +108,14 @@ class HashTable:
         s = self._storage
         if s is None:
             raise _lib.LatticeNetHipError("hash table is not initialised (no splat / create_verts happened yet)")
+        key = (id(s), self._counters.data_ptr())
+        if getattr(self, "_c_table_key", None) == key:
+            return self._c_table
+        self._c_table_key = key
+        self._c_table = self._make_c_table(s)
+        return self._c_table
+
+    def _make_c_table(self, s) -> _lib.LnTable:
         return _lib.LnTable(s.capacity, s.pos_dim, s.slot_keys.data_ptr(), s.slot_tok.data_ptr(), s.slot_cnt.data_ptr(), s.entries.data_ptr(),
                             s.keys.data_ptr(), self._counters.data_ptr(), self._counters.data_ptr() + 4)
 
