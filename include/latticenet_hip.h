@@ -151,9 +151,18 @@ int ln_im2rowindices(const int* nbr, int m, int filter_extent, int val_dim, int*
 int ln_row2im(const int* nbr, const float* rowified, int m, int filter_extent, int val_dim, float* out, void* stream);
 
 /* Lattice::convolve_im2row_standalone (Lattice.cu:424-474) without materialising the rowified
- * tensor: out[m, F] = sum_e values_neigh[nbr[m,e], :] @ filter[e*V:(e+1)*V, :]  (fp32 MFMA). */
+ * tensor: out[m, F] = sum_e values_neigh[nbr[m,e'], :] @ B_e   (fp32 MFMA), with
+ *   flags & LN_CONV_FLIP_NEIGHBOURS   : e' = e^1 for the neighbour slots (what the reference's
+ *        flip_neighbours traversal produces, LatticeGPU.cuh:1622-1626) — lets the backward pass reuse
+ *        the forward neighbour list;
+ *   flags & LN_CONV_TRANSPOSED_FILTER : `filter` is the [E*F, V] bank of the convolution being
+ *        differentiated and B_e is its per-slot transpose, i.e. the filter_bank_backwards of
+ *        lattice_funcs.py:307-311 without building it; otherwise `filter` is [E*V, F] and
+ *        B_e = filter[e*V:(e+1)*V, :]. */
+#define LN_CONV_FLIP_NEIGHBOURS 1
+#define LN_CONV_TRANSPOSED_FILTER 2
 int ln_conv_forward(const int* nbr, const float* values_neigh, const float* filter, int m, int filter_extent, int val_dim,
-                    int nr_filters, float* out, void* stream);
+                    int nr_filters, int flags, float* out, void* stream);
 /* grad_filter = rowified^T @ grad_out (lattice_funcs.py:302) without the rowified tensor.
  * workspace: ln_conv_grad_filter_workspace_bytes(). */
 size_t ln_conv_grad_filter_workspace_bytes(int m, int filter_extent, int val_dim, int nr_filters);

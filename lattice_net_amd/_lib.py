@@ -15,6 +15,8 @@ LIB_PATH = os.path.join(_PKG, "liblatticenet_hip.so")
 LN_STATUS_TABLE_FULL = 1
 LN_STATUS_KEY_RANGE = 2
 LN_NOT_VISITED = -2
+LN_CONV_FLIP_NEIGHBOURS = 1
+LN_CONV_TRANSPOSED_FILTER = 2
 LN_MAX_POS_DIM = 6
 
 
@@ -76,7 +78,7 @@ SIGNATURES = {
     "ln_im2row": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "ln_im2rowindices": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "ln_row2im": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
-    "ln_conv_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "ln_conv_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "ln_conv_grad_filter_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "ln_conv_grad_filter": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "ln_slice_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),

@@ -39,7 +39,10 @@ __device__ __forceinline__ void ln_load_quarter(const float* __restrict__ src, f
     }
 }
 
-template <int V, int NT>
+// FLIP: read slot e^1 of an un-flipped neighbour list (the flipped traversal only swaps the np/nm slots
+// of every axis, LatticeGPU.cuh:1622-1626).  WT: `filter` is the bank of the op being differentiated,
+// [E*F, V]; the contraction uses its per-slot transpose (lattice_funcs.py:307-311) without materialising it.
+template <int V, int NT, bool FLIP, bool WT>
 __global__ void __launch_bounds__(256)
     k_conv_mfma(const int* __restrict__ nbr, const float* __restrict__ values, const float* __restrict__ filter, int m, int E,
                 float* __restrict__ out) {
@@ -61,7 +64,8 @@ __global__ void __launch_bounds__(256)
     for (int e = 0; e < E; ++e) {
         // issue the gather first so its latency overlaps the filter staging
         float a[KQ];
-        const int nb = (my_row < m) ? nbr[(size_t)my_row * E + e] : -1;
+        const int es = (FLIP && e < E - 1) ? (e ^ 1) : e;
+        const int nb = (my_row < m) ? nbr[(size_t)my_row * E + es] : -1;
         if (nb >= 0) {
             ln_load_quarter<KQ>(values + (size_t)nb * V + q * KQ, a);
         } else {
@@ -71,8 +75,8 @@ __global__ void __launch_bounds__(256)
         __syncthreads();  // previous iteration's reads of s_b are done
         const float* w_e = filter + (size_t)e * V * F;
         for (int x = tid; x < V * F; x += 256) {
-            const int k = x / F;
-            const int f = x - k * F;
+            const int k = WT ? (x % V) : (x / F);
+            const int f = WT ? (x / V) : (x - k * F);
             const int qq = k / KQ;
             const int kk = k - qq * KQ;
             s_b[((kk * NT) + (f >> 4)) * 64 + qq * 16 + (f & 15)] = w_e[x];
@@ -101,7 +105,7 @@ __global__ void __launch_bounds__(256)
 // Small-filter fast path (E*V*F*4 <= 64 KiB, e.g. V = F = 32 with E = 9): the WHOLE filter bank is
 // staged into LDS once per workgroup (one barrier), and every lane issues the gathers of all E
 // neighbour rows up front, so the kernel pays one memory latency instead of E.
-template <int V, int NT, int E>
+template <int V, int NT, int E, bool FLIP, bool WT>
 __global__ void __launch_bounds__(256)
     k_conv_mfma_full(const int* __restrict__ nbr, const float* __restrict__ values, const float* __restrict__ filter, int m,
                      float* __restrict__ out) {
@@ -119,7 +123,7 @@ __global__ void __launch_bounds__(256)
 
     int nb[E];
 #pragma unroll
-    for (int e = 0; e < E; ++e) nb[e] = (my_row < m) ? nbr[(size_t)my_row * E + e] : -1;
+    for (int e = 0; e < E; ++e) nb[e] = (my_row < m) ? nbr[(size_t)my_row * E + ((FLIP && e < E - 1) ? (e ^ 1) : e)] : -1;
     // unconditional gathers (absent neighbours read row 0 and are zeroed afterwards): no branch, so all
     // E gathers are in flight together
     float a[E][KQ];
@@ -140,14 +144,29 @@ __global__ void __launch_bounds__(256)
         const int x4 = tid + s * 256;
         if (x4 < N4) {
             const int x = x4 * 4;
-            const int ek = x / F;       // e*V + k
-            const int f = x - ek * F;   // multiple of 4
-            const int e = ek / V;
-            const int k = ek - e * V;
-            const int qq = k / KQ;
-            const int kk = k - qq * KQ;
-            float* dst = s_b + (((e * KQ + kk) * NT + (f >> 4)) * 64 + qq * 16 + (f & 15));
-            *reinterpret_cast<float4*>(dst) = wv[s];
+            if constexpr (!WT) {
+                const int ek = x / F;       // e*V + k
+                const int f = x - ek * F;   // multiple of 4
+                const int e = ek / V;
+                const int k = ek - e * V;
+                const int qq = k / KQ;
+                const int kk = k - qq * KQ;
+                float* dst = s_b + (((e * KQ + kk) * NT + (f >> 4)) * 64 + qq * 16 + (f & 15));
+                *reinterpret_cast<float4*>(dst) = wv[s];
+            } else {
+                const int ef = x / V;       // e*F + f  (rows of the differentiated op's bank)
+                const int k0 = x - ef * V;  // multiple of 4
+                const int e = ef / F;
+                const int f = ef - e * F;
+                const float vals4[4] = {wv[s].x, wv[s].y, wv[s].z, wv[s].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = k0 + j;
+                    const int qq = k / KQ;
+                    const int kk = k - qq * KQ;
+                    s_b[((e * KQ + kk) * NT + (f >> 4)) * 64 + qq * 16 + (f & 15)] = vals4[j];
+                }
+            }
         }
     }
     __syncthreads();
@@ -183,48 +202,50 @@ __global__ void __launch_bounds__(256)
 // Any (V, F): one thread per output element.
 __global__ void __launch_bounds__(256)
     k_conv_generic(const int* __restrict__ nbr, const float* __restrict__ values, const float* __restrict__ filter, long long work,
-                   int E, int V, int F, float* __restrict__ out) {
+                   int E, int V, int F, int flip, int wt, float* __restrict__ out) {
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= work) return;
     const long long mrow = g / F;
     const int f = int(g - mrow * F);
     float acc = 0.0f;
     for (int e = 0; e < E; ++e) {
-        const int nb = nbr[mrow * E + e];
+        const int nb = nbr[mrow * E + ((flip && e < E - 1) ? (e ^ 1) : e)];
         if (nb < 0) continue;
         const float* vr = values + (size_t)nb * V;
-        const float* wr = filter + (size_t)e * V * F + f;
-        for (int v = 0; v < V; ++v) acc = fmaf(vr[v], wr[(size_t)v * F], acc);
+        if (wt) {
+            const float* wr = filter + ((size_t)e * F + f) * V;
+            for (int v = 0; v < V; ++v) acc = fmaf(vr[v], wr[v], acc);
+        } else {
+            const float* wr = filter + (size_t)e * V * F + f;
+            for (int v = 0; v < V; ++v) acc = fmaf(vr[v], wr[(size_t)v * F], acc);
+        }
     }
     out[g] = acc;
 }
 
-template <int V>
+template <int V, bool FLIP, bool WT>
 static bool ln_conv_launch_v(int nt, const int* nbr, const float* values, const float* filter, int m, int E, float* out,
                              hipStream_t st) {
     const dim3 grid(ln_div_up(m, 64)), block(256);
     switch (nt) {
-        case 1: LN_LAUNCH("k_conv_mfma", (k_conv_mfma<V, 1>), grid, block, 0, st, nbr, values, filter, m, E, out); return true;
-        case 2: LN_LAUNCH("k_conv_mfma", (k_conv_mfma<V, 2>), grid, block, 0, st, nbr, values, filter, m, E, out); return true;
-        case 4: LN_LAUNCH("k_conv_mfma", (k_conv_mfma<V, 4>), grid, block, 0, st, nbr, values, filter, m, E, out); return true;
-        case 8: if constexpr (V <= 64) { LN_LAUNCH("k_conv_mfma", (k_conv_mfma<V, 8>), grid, block, 0, st, nbr, values, filter, m, E, out); return true; } return false;
+        case 1: LN_LAUNCH("k_conv_mfma", (k_conv_mfma<V, 1, FLIP, WT>), grid, block, 0, st, nbr, values, filter, m, E, out); return true;
+        case 2: LN_LAUNCH("k_conv_mfma", (k_conv_mfma<V, 2, FLIP, WT>), grid, block, 0, st, nbr, values, filter, m, E, out); return true;
+        case 4: LN_LAUNCH("k_conv_mfma", (k_conv_mfma<V, 4, FLIP, WT>), grid, block, 0, st, nbr, values, filter, m, E, out); return true;
+        case 8: if constexpr (V <= 64) { LN_LAUNCH("k_conv_mfma", (k_conv_mfma<V, 8, FLIP, WT>), grid, block, 0, st, nbr, values, filter, m, E, out); return true; } return false;
         default: return false;
     }
 }
 
-extern "C" int ln_conv_forward(const int* nbr, const float* values_neigh, const float* filter, int m, int filter_extent,
-                               int val_dim, int nr_filters, float* out, void* stream) {
-    LN_REQUIRE(m >= 0 && filter_extent >= 3 && val_dim >= 1 && nr_filters >= 1, LN_ERR_ARG, "ln_conv_forward: bad sizes");
-    LN_REQUIRE(m == 0 || (nbr && values_neigh && filter && out), LN_ERR_ARG, "ln_conv_forward: null buffer");
-    if (m == 0) return LN_OK;
-    hipStream_t st = (hipStream_t)stream;
+template <bool FLIP, bool WT>
+static int ln_conv_dispatch(const int* nbr, const float* values_neigh, const float* filter, int m, int filter_extent, int val_dim,
+                            int nr_filters, float* out, hipStream_t st) {
     bool done = false;
     if (filter_extent == 9 && (reinterpret_cast<uintptr_t>(filter) & 15) == 0) {  // d = 3 small-filter fast path
         const dim3 grid(ln_div_up(m, 64)), block(256);
-#define LN_CONV_FULL(VV, NN)                                                                                                       \
-    if (!done && val_dim == VV && nr_filters == 16 * NN) {                                                                         \
-        LN_LAUNCH("k_conv_mfma", (k_conv_mfma_full<VV, NN, 9>), grid, block, 0, st, nbr, values_neigh, filter, m, out);             \
-        done = true;                                                                                                               \
+#define LN_CONV_FULL(VV, NN)                                                                                                        \
+    if (!done && val_dim == VV && nr_filters == 16 * NN) {                                                                          \
+        LN_LAUNCH("k_conv_mfma", (k_conv_mfma_full<VV, NN, 9, FLIP, WT>), grid, block, 0, st, nbr, values_neigh, filter, m, out);  \
+        done = true;                                                                                                                \
     }
         LN_CONV_FULL(32, 2) LN_CONV_FULL(32, 1) LN_CONV_FULL(16, 1) LN_CONV_FULL(16, 2) LN_CONV_FULL(16, 4) LN_CONV_FULL(8, 1)
         LN_CONV_FULL(8, 2) LN_CONV_FULL(8, 4) LN_CONV_FULL(8, 8)
@@ -233,20 +254,35 @@ extern "C" int ln_conv_forward(const int* nbr, const float* values_neigh, const 
     if (!done && nr_filters % 16 == 0) {
         const int nt = nr_filters / 16;
         switch (val_dim) {
-            case 8: done = ln_conv_launch_v<8>(nt, nbr, values_neigh, filter, m, filter_extent, out, st); break;
-            case 16: done = ln_conv_launch_v<16>(nt, nbr, values_neigh, filter, m, filter_extent, out, st); break;
-            case 32: done = ln_conv_launch_v<32>(nt, nbr, values_neigh, filter, m, filter_extent, out, st); break;
-            case 64: done = ln_conv_launch_v<64>(nt, nbr, values_neigh, filter, m, filter_extent, out, st); break;
-            case 128: done = ln_conv_launch_v<128>(nt, nbr, values_neigh, filter, m, filter_extent, out, st); break;
+            case 8: done = ln_conv_launch_v<8, FLIP, WT>(nt, nbr, values_neigh, filter, m, filter_extent, out, st); break;
+            case 16: done = ln_conv_launch_v<16, FLIP, WT>(nt, nbr, values_neigh, filter, m, filter_extent, out, st); break;
+            case 32: done = ln_conv_launch_v<32, FLIP, WT>(nt, nbr, values_neigh, filter, m, filter_extent, out, st); break;
+            case 64: done = ln_conv_launch_v<64, FLIP, WT>(nt, nbr, values_neigh, filter, m, filter_extent, out, st); break;
+            case 128: done = ln_conv_launch_v<128, FLIP, WT>(nt, nbr, values_neigh, filter, m, filter_extent, out, st); break;
             default: break;
         }
     }
     if (!done) {
         const long long work = (long long)m * nr_filters;
         LN_LAUNCH("k_conv_generic", k_conv_generic, dim3(ln_div_up(work, 256)), dim3(256), 0, st, nbr, values_neigh, filter, work,
-                           filter_extent, val_dim, nr_filters, out);
+                  filter_extent, val_dim, nr_filters, FLIP ? 1 : 0, WT ? 1 : 0, out);
     }
     return ln_check_launch("ln_conv_forward");
+}
+
+extern "C" int ln_conv_forward(const int* nbr, const float* values_neigh, const float* filter, int m, int filter_extent,
+                               int val_dim, int nr_filters, int flags, float* out, void* stream) {
+    LN_REQUIRE(m >= 0 && filter_extent >= 3 && val_dim >= 1 && nr_filters >= 1, LN_ERR_ARG, "ln_conv_forward: bad sizes");
+    LN_REQUIRE(m == 0 || (nbr && values_neigh && filter && out), LN_ERR_ARG, "ln_conv_forward: null buffer");
+    LN_REQUIRE((flags & ~3) == 0, LN_ERR_ARG, "ln_conv_forward: unknown flags %d", flags);
+    if (m == 0) return LN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    switch (flags) {
+        case 0: return ln_conv_dispatch<false, false>(nbr, values_neigh, filter, m, filter_extent, val_dim, nr_filters, out, st);
+        case LN_CONV_FLIP_NEIGHBOURS: return ln_conv_dispatch<true, false>(nbr, values_neigh, filter, m, filter_extent, val_dim, nr_filters, out, st);
+        case LN_CONV_TRANSPOSED_FILTER: return ln_conv_dispatch<false, true>(nbr, values_neigh, filter, m, filter_extent, val_dim, nr_filters, out, st);
+        default: return ln_conv_dispatch<true, true>(nbr, values_neigh, filter, m, filter_extent, val_dim, nr_filters, out, st);
+    }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -448,7 +448,8 @@ class Lattice:
 
     # ---------------------------------------------------------------- neighbour list (shared)
     def neighbours(self, lattice_neighbours: Optional["Lattice"], dilation: int, flip_neighbours: bool) -> torch.Tensor:
-        """[M, E] int32 neighbour list of this (query) lattice in `lattice_neighbours`, cached."""
+        """[M, E] int32 neighbour list of this (query) lattice in `lattice_neighbours`, cached.  The flipped list
+        is the un-flipped one with the np/nm slots of every axis swapped (LatticeGPU.cuh:1622-1626,1645-1649)."""
         nb = lattice_neighbours if lattice_neighbours is not None else self
         if abs(self.m_lvl - nb.m_lvl) > 1:  # Lattice.cu:439
             raise ValueError(f"query lvl {self.m_lvl} and neighbours lvl {nb.m_lvl} must differ by at most 1")
@@ -460,12 +461,17 @@ class Lattice:
         hit = sq.nbr_cache.get(key)
         if hit is not None:
             return hit[0]
-        lib = _lib.load()
         E = self.get_filter_extent(1)
-        nbr = torch.empty((m, E), dtype=torch.int32, device=self._dev())
-        tq, tn = self.m_hash_table.c_table(), nb.m_hash_table.c_table()
-        _lib.check(lib.ln_neighbours(C.byref(tq), m, C.byref(tn), self.m_lvl, nb.m_lvl, int(dilation), 1 if flip_neighbours else 0,
-                                     _lib.ptr(nbr), self._stream()), "ln_neighbours")
+        if flip_neighbours:
+            base = self.neighbours(nb, dilation, False)
+            perm = [e ^ 1 for e in range(E - 1)] + [E - 1]
+            nbr = base[:, perm].contiguous()
+        else:
+            lib = _lib.load()
+            nbr = torch.empty((m, E), dtype=torch.int32, device=self._dev())
+            tq, tn = self.m_hash_table.c_table(), nb.m_hash_table.c_table()
+            _lib.check(lib.ln_neighbours(C.byref(tq), m, C.byref(tn), self.m_lvl, nb.m_lvl, int(dilation), 0, _lib.ptr(nbr),
+                                         self._stream()), "ln_neighbours")
         sq.nbr_cache[key] = (nbr, sn)  # keep sn alive so id() stays unique
         return nbr
 
@@ -475,23 +481,34 @@ class Lattice:
 
     # ---------------------------------------------------------------- convolution family
     def convolve_im2row_standalone(self, filter_bank: torch.Tensor, dilation: int, lattice_neighbours: Optional["Lattice"],
-                                   flip_neighbours: bool) -> "Lattice":  # Lattice.cu:424-474
+                                   flip_neighbours: bool, filter_is_transposed: bool = False) -> "Lattice":  # Lattice.cu:424-474
+        """`filter_is_transposed=True` (extension): `filter_bank` is the [E*F, V] bank of the convolution being
+        differentiated; its per-slot transpose — the reference's filter_bank_backwards (lattice_funcs.py:307-311) —
+        is applied inside the kernel instead of being materialised."""
         nb = lattice_neighbours if lattice_neighbours is not None else self
         if filter_bank is None or filter_bank.dim() != 2:
             raise ValueError("filter bank should be 2-D: (filter_extent * val_dim) x nr_filters")
         filter_bank = filter_bank.contiguous()
         v = nb.val_dim()
-        nr_filters = int(filter_bank.shape[1])
-        filter_extent = filter_bank.shape[0] // v
-        self._check_filter_extent(filter_extent)
-        if filter_bank.shape[0] != filter_extent * v:
-            raise ValueError("filter bank rows must be filter_extent * val_dim")
-        nbr = self.neighbours(nb, dilation, flip_neighbours)
+        E = self.get_filter_extent(1)
+        if filter_is_transposed:
+            if filter_bank.shape[1] != v or filter_bank.shape[0] % E != 0:
+                raise ValueError(f"transposed filter bank should be (filter_extent * nr_filters) x val_dim={v}, got {tuple(filter_bank.shape)}")
+            nr_filters = int(filter_bank.shape[0]) // E
+            filter_extent = E
+        else:
+            nr_filters = int(filter_bank.shape[1])
+            filter_extent = filter_bank.shape[0] // v
+            self._check_filter_extent(filter_extent)
+            if filter_bank.shape[0] != filter_extent * v:
+                raise ValueError("filter bank rows must be filter_extent * val_dim")
+        nbr = self.neighbours(nb, dilation, False)  # the flipped traversal is applied in-kernel
         m = nbr.shape[0]
         vals = nb.values()
         out = torch.empty((m, nr_filters), dtype=torch.float32, device=self._dev())
+        flags = (_lib.LN_CONV_FLIP_NEIGHBOURS if flip_neighbours else 0) | (_lib.LN_CONV_TRANSPOSED_FILTER if filter_is_transposed else 0)
         lib = _lib.load()
-        _lib.check(lib.ln_conv_forward(_lib.ptr(nbr), _lib.ptr(vals), _lib.ptr(filter_bank), m, filter_extent, v, nr_filters,
+        _lib.check(lib.ln_conv_forward(_lib.ptr(nbr), _lib.ptr(vals), _lib.ptr(filter_bank), m, filter_extent, v, nr_filters, flags,
                                        _lib.ptr(out), self._stream()), "ln_conv_forward")
         conv = Lattice._clone_of(self)
         conv.m_name = "convolved_lattice"

@@ -130,9 +130,9 @@ class ConvIm2RowLattice(Function):  # lattice_funcs.py:250-320
         grad_lattice_values = grad_lattice_values.contiguous()
         lattice.set_values(lattice_values)
         grad_filter = lattice.convolve_im2row_grad_filter(grad_lattice_values, dilation, lattice, filter_extent)  # funcs:298-302
-        filter_bank_backwards = _backward_filter(filter_bank, nr_filters, filter_extent, val_dim)
         lattice.set_values(grad_lattice_values)
-        grad_lattice = lattice.convolve_im2row_standalone(filter_bank_backwards, dilation, lattice, True)  # funcs:312
+        # funcs:307-313: convolve the gradient with flipped neighbours and the re-laid-out bank (applied in-kernel)
+        grad_lattice = lattice.convolve_im2row_standalone(filter_bank, dilation, lattice, True, filter_is_transposed=True)
         ctx.lattice = 0
         return grad_lattice.values(), None, grad_filter, None
 
@@ -165,10 +165,10 @@ class CoarsenLattice(Function):  # lattice_funcs.py:323-398
         grad_lattice_values = grad_lattice_values.contiguous()
         lattice_fine_structure.set_values(lattice_fine_values)
         grad_filter = coarsened_lattice.convolve_im2row_grad_filter(grad_lattice_values, dilation, lattice_fine_structure, filter_extent)
-        filter_bank_backwards = _backward_filter(filter_bank, nr_filters, filter_extent, val_dim)
         coarsened_lattice.set_values(grad_lattice_values)
-        # convolve at the fine vertices with the coarse ones (which carry the errors) as neighbours, funcs:387
-        grad_lattice = lattice_fine_structure.convolve_im2row_standalone(filter_bank_backwards, dilation, coarsened_lattice, True)
+        # convolve at the fine vertices with the coarse ones (which carry the errors) as neighbours, funcs:380-387
+        grad_lattice = lattice_fine_structure.convolve_im2row_standalone(filter_bank, dilation, coarsened_lattice, True,
+                                                                         filter_is_transposed=True)
         ctx.coarsened_lattice = 0
         ctx.lattice_fine_structure = 0
         return grad_lattice.values(), None, grad_filter, None
@@ -200,9 +200,9 @@ class FinefyLattice(Function):  # lattice_funcs.py:401-462
         lattice_coarse_structure.set_values(lattice_coarse_values)
         grad_filter = lattice_fine_structure.convolve_im2row_grad_filter(grad_lattice_values, dilation, lattice_coarse_structure,
                                                                          filter_extent)
-        filter_bank_backwards = _backward_filter(filter_bank, nr_filters, filter_extent, val_dim)
         lattice_fine_structure.set_values(grad_lattice_values)
-        grad_lattice = lattice_coarse_structure.convolve_im2row_standalone(filter_bank_backwards, dilation, lattice_fine_structure, True)
+        grad_lattice = lattice_coarse_structure.convolve_im2row_standalone(filter_bank, dilation, lattice_fine_structure, True,
+                                                                           filter_is_transposed=True)
         ctx.lattice_coarse_structure = 0
         ctx.lattice_fine_structure = 0
         return grad_lattice.values(), None, None, grad_filter

@@ -46,7 +46,7 @@ def test_version_and_kernel_names():
 
 def test_argument_errors_are_reported_not_fatal():
     lib = _lib.load()
-    assert lib.ln_conv_forward(None, None, None, -1, 9, 32, 32, None, None) == -1
+    assert lib.ln_conv_forward(None, None, None, -1, 9, 32, 32, 0, None, None) == -1
     assert b"bad sizes" in lib.ln_last_error_string()
     assert lib.ln_neighbours(None, 10, None, 1, 1, 1, 0, None, None) == -1
     assert b"null table" in lib.ln_last_error_string()
