@@ -291,66 +291,111 @@ extern "C" int ln_conv_forward(const int* nbr, const float* values_neigh, const 
 //          the 4 waves are combined through LDS and the workgroup writes one partial [V,F] slab.
 // Stage 2: deterministic sum of the slabs.
 // ------------------------------------------------------------------------------------------
-#define LN_GF_ROWS 512  // rows per workgroup (128 per wave)
+#define LN_GF_ROWS 1024  // lattice vertices per workgroup (one slab each)
+#define LN_GF_SUB 128    // vertices staged in LDS at a time
 
+// Stage 1.  grid = (row chunks, E).  A workgroup walks its chunk in sub-tiles of LN_GF_SUB vertices: the
+// gathered neighbour rows A[sub, V] and the gradient rows G[sub, F] are staged in LDS with float4 loads
+// (row stride +16 floats so that the k-strided MFMA operand reads are bank-conflict free), the loads of
+// the next sub-tile are issued before the MFMAs of the current one, and each wave owns whole 16x16
+// output tiles D[v, f] += sum_rows A[row, v] * G[row, f] with two accumulators per tile.
 template <int VT, int FT>
 __global__ void __launch_bounds__(256)
     k_grad_filter_mfma(const int* __restrict__ nbr, const float* __restrict__ values, const float* __restrict__ grad_out, int m,
                        int E, float* __restrict__ partial) {
     constexpr int V = VT * 16;
     constexpr int F = FT * 16;
-    __shared__ __attribute__((aligned(16))) float s_red[V * F];
+    constexpr int SA = V + 16;  // LDS row strides (floats), = 16 mod 32
+    constexpr int SG = F + 16;
+    constexpr int TILES = VT * FT;
+    constexpr int TPW = (TILES + 3) / 4;     // output tiles per wave
+    constexpr int A4 = LN_GF_SUB * V / 4 / 256;  // float4 staged per thread
+    constexpr int G4 = LN_GF_SUB * F / 4 / 256;
+    static_assert(A4 >= 1 && G4 >= 1, "tile too small for 256 staging threads");
+    __shared__ __attribute__((aligned(16))) float s_a[LN_GF_SUB * SA];
+    __shared__ __attribute__((aligned(16))) float s_g[LN_GF_SUB * SG];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int i = lane & 15;
     const int q = lane >> 4;
     const int e = blockIdx.y;
-    const int row_begin = blockIdx.x * LN_GF_ROWS + wave * (LN_GF_ROWS / 4);
-    const int row_end = min(row_begin + LN_GF_ROWS / 4, m);
+    const int chunk_begin = blockIdx.x * LN_GF_ROWS;
+    const int chunk_end = min(chunk_begin + LN_GF_ROWS, m);
 
-    floatx4 acc[VT][FT];
+    floatx4 acc[TPW][2];
 #pragma unroll
-    for (int a = 0; a < VT; ++a)
-#pragma unroll
-        for (int b = 0; b < FT; ++b) acc[a][b] = floatx4{0.f, 0.f, 0.f, 0.f};
-
-    for (int mb = row_begin; mb < row_end; mb += 4) {
-        const int row = mb + q;
-        int nb = -1;
-        if (row < row_end) nb = nbr[(size_t)row * E + e];
-        float av[VT];
-        float bv[FT];
-#pragma unroll
-        for (int a = 0; a < VT; ++a) av[a] = (nb >= 0) ? values[(size_t)nb * V + a * 16 + i] : 0.f;
-#pragma unroll
-        for (int b = 0; b < FT; ++b) bv[b] = (nb >= 0) ? grad_out[(size_t)row * F + b * 16 + i] : 0.f;
-#pragma unroll
-        for (int a = 0; a < VT; ++a)
-#pragma unroll
-            for (int b = 0; b < FT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+    for (int t = 0; t < TPW; ++t) {
+        acc[t][0] = floatx4{0.f, 0.f, 0.f, 0.f};
+        acc[t][1] = floatx4{0.f, 0.f, 0.f, 0.f};
     }
-    // combine the 4 waves in LDS (wave 0 stores, the others add in turn)
-    for (int wv = 0; wv < 4; ++wv) {
-        if (wave == wv) {
+    float4 ra[A4], rg[G4];
+    auto issue_loads = [&](int sub_begin) {
 #pragma unroll
-            for (int a = 0; a < VT; ++a)
+        for (int s = 0; s < A4; ++s) {
+            const int x4 = tid + s * 256;
+            const int r = x4 / (V / 4);
+            const int c = x4 - r * (V / 4);
+            const int row = sub_begin + r;
+            const int nb = (row < chunk_end) ? nbr[(size_t)row * E + e] : -1;
+            ra[s] = reinterpret_cast<const float4*>(values)[(size_t)(nb >= 0 ? nb : 0) * (V / 4) + c];
+            if (nb < 0) ra[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
 #pragma unroll
-                for (int b = 0; b < FT; ++b)
+        for (int s = 0; s < G4; ++s) {
+            const int x4 = tid + s * 256;
+            const int r = x4 / (F / 4);
+            const int c = x4 - r * (F / 4);
+            const int row = sub_begin + r;
+            rg[s] = (row < chunk_end) ? reinterpret_cast<const float4*>(grad_out)[(size_t)row * (F / 4) + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    if (chunk_begin < chunk_end) issue_loads(chunk_begin);
+    for (int sub = chunk_begin; sub < chunk_end; sub += LN_GF_SUB) {
+        __syncthreads();  // previous sub-tile fully consumed
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int v = a * 16 + q * 4 + r;
-                        const int f = b * 16 + i;
-                        if (wv == 0)
-                            s_red[v * F + f] = acc[a][b][r];
-                        else
-                            s_red[v * F + f] += acc[a][b][r];
-                    }
+        for (int s = 0; s < A4; ++s) {
+            const int x4 = tid + s * 256;
+            const int r = x4 / (V / 4);
+            const int c = x4 - r * (V / 4);
+            *reinterpret_cast<float4*>(s_a + r * SA + c * 4) = ra[s];
+        }
+#pragma unroll
+        for (int s = 0; s < G4; ++s) {
+            const int x4 = tid + s * 256;
+            const int r = x4 / (F / 4);
+            const int c = x4 - r * (F / 4);
+            *reinterpret_cast<float4*>(s_g + r * SG + c * 4) = rg[s];
         }
         __syncthreads();
+        if (sub + LN_GF_SUB < chunk_end) issue_loads(sub + LN_GF_SUB);  // in flight during the MFMAs below
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+            const int tile = wave + 4 * t;
+            if (tile < TILES) {
+                const int vt = tile / FT;
+                const int ft = tile - vt * FT;
+                const float* pa = s_a + q * SA + vt * 16 + i;
+                const float* pg = s_g + q * SG + ft * 16 + i;
+#pragma unroll 8
+                for (int k = 0; k < LN_GF_SUB / 4; k += 2) {
+                    acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[(k * 4) * SA], pg[(k * 4) * SG], acc[t][0], 0, 0, 0);
+                    acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[(k * 4 + 4) * SA], pg[(k * 4 + 4) * SG], acc[t][1], 0, 0, 0);
+                }
+            }
+        }
     }
     float* dst = partial + ((size_t)blockIdx.x * E + e) * (V * F);
-    for (int x = tid; x < V * F; x += 256) dst[x] = s_red[x];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int tile = wave + 4 * t;
+        if (tile < TILES) {
+            const int vt = tile / FT;
+            const int ft = tile - vt * FT;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[(vt * 16 + q * 4 + r) * F + ft * 16 + i] = acc[t][0][r] + acc[t][1][r];
+        }
+    }
 }
 
 // generic fallback: thread per (e*V+v, f), loops all rows (slow; small or odd shapes only)

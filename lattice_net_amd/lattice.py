@@ -27,6 +27,21 @@ from . import _lib
 __all__ = ["Lattice", "HashTable"]
 
 
+_SIZE_CACHE = {}
+
+
+def _build_sizes(tokens: int, capacity: int):
+    """(build workspace bytes, csr workspace bytes, max segments) — pure functions of the sizes, memoised."""
+    key = (tokens, capacity)
+    hit = _SIZE_CACHE.get(key)
+    if hit is None:
+        lib = _lib.load()
+        hit = (int(lib.ln_build_workspace_bytes(tokens, capacity)), int(lib.ln_csr_workspace_bytes(tokens, capacity)),
+               int(lib.ln_csr_max_segments(tokens, capacity)))
+        _SIZE_CACHE[key] = hit
+    return hit
+
+
 def _require_cuda(t: torch.Tensor, name: str):
     if not t.is_cuda:
         raise ValueError(f"{name} must live on a ROCm/HIP device (got {t.device}); the lattice backend has no CPU path")
@@ -256,7 +271,11 @@ class Lattice:
         return _lib.stream_ptr(self._dev())
 
     def _sigmas_host(self):
-        return _lib.host_floats(self.m_sigmas)
+        key = tuple(self.m_sigmas)
+        if getattr(self, "_sig_key", None) != key:
+            self._sig_key = key
+            self._sig_arr = _lib.host_floats(self.m_sigmas)
+        return self._sig_arr
 
     def _check_positions(self, positions_raw: torch.Tensor):  # Lattice.cu:162-170
         if positions_raw.dtype != torch.float32:
@@ -284,7 +303,14 @@ class Lattice:
         self._check_values(values)
 
     def _workspace(self, nbytes: int) -> torch.Tensor:
-        return torch.empty((max(int(nbytes), 256),), dtype=torch.uint8, device=self._dev())
+        """Scratch for one C-ABI call.  Reused across calls of this object (all launches are ordered on
+        torch's current stream, so the next call cannot start before the previous one has finished with it)."""
+        nbytes = max(int(nbytes), 256)
+        ws = getattr(self, "_ws", None)
+        if ws is None or ws.numel() < nbytes or ws.device != self._dev():
+            ws = torch.empty((nbytes,), dtype=torch.uint8, device=self._dev())
+            self._ws = ws
+        return ws
 
     def _ensure_table(self, pos_dim: int, val_dim: int, like: torch.Tensor):
         if not self.m_hash_table.is_initialized():
@@ -292,8 +318,7 @@ class Lattice:
 
     def _alloc_csr(self, tokens: int, groups_upper: int):
         """One int32 allocation: grp_start[groups+1] | csr_tok[tokens] | seg_grp[S] | seg_beg[S] | seg_count[1]."""
-        lib = _lib.load()
-        max_seg = int(lib.ln_csr_max_segments(tokens, groups_upper))
+        max_seg = _build_sizes(tokens, groups_upper)[2]
         tk = max(tokens, 1)
         buf = torch.empty((groups_upper + 1 + tk + 2 * max_seg + 1,), dtype=torch.int32, device=self._dev())
         base = buf.data_ptr()
@@ -315,7 +340,7 @@ class Lattice:
             w = torch.empty((n * (d + 1),), dtype=torch.float32, device=dev)
         tokens = n * (d + 1)
         cap = ht.capacity()
-        ws = self._workspace(lib.ln_build_workspace_bytes(tokens, cap))
+        ws = self._workspace(_build_sizes(tokens, cap)[0])
         csr_buf, csr, max_seg = self._alloc_csr(tokens, cap)
         t = ht.c_table()
         if distributed is None:
@@ -349,7 +374,7 @@ class Lattice:
         tokens = idx.numel()
         rows_upper = self.m_hash_table.capacity()
         csr_buf, csr, max_seg = self._alloc_csr(tokens, rows_upper)
-        ws = self._workspace(lib.ln_csr_workspace_bytes(tokens, rows_upper))
+        ws = self._workspace(_build_sizes(tokens, rows_upper)[1])
         _lib.check(lib.ln_csr_build(_lib.ptr(idx), tokens, rows_upper, C.byref(csr), _lib.ptr(ws), ws.numel(), self._stream()), "ln_csr_build")
         if len(st.csr_cache) >= 4:
             st.csr_cache.pop(next(iter(st.csr_cache)))
@@ -596,7 +621,7 @@ class Lattice:
         m = self.nr_lattice_vertices()
         tokens = m * (2 * (self.pos_dim() + 1) + 1)
         cap = coarse.m_hash_table.capacity()
-        ws = self._workspace(lib.ln_build_workspace_bytes(tokens, cap))
+        ws = self._workspace(_build_sizes(tokens, cap)[0])
         csr_buf, csr, _ = self._alloc_csr(tokens, cap)
         tf, tc = self.m_hash_table.c_table(), coarse.m_hash_table.c_table()
         _lib.check(lib.ln_coarsen(C.byref(tf), m, C.byref(tc), C.byref(csr), _lib.ptr(ws), ws.numel(), self._stream()), "ln_coarsen")
