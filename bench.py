@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
     ap.add_argument("--roofline-kernel", default="k_conv_mfma", help="kernel whose launches are timed live with HIP events")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the CPU baseline leg (0 disables)")
+    ap.add_argument("--autograd-threads", type=int, default=0, help="1 = leave torch's per-device autograd worker thread on")
     args = ap.parse_args()
 
     from lattice_net_amd import sharding
@@ -108,6 +109,10 @@ def main():
 
     import lattice_net_amd as L
     lib = L.load_library()
+    if not args.autograd_threads:
+        # run backward on the calling thread: the hand-off to torch's per-device autograd worker costs tens of
+        # microseconds per step, which is comparable to the whole GPU time of this path
+        torch.autograd.set_multithreading_enabled(False)
 
     cfg = WORKLOADS[args.workload]
     n, v, f, sigma, cap = cfg["n"], cfg["v"], cfg["f"], cfg["sigma"], cfg["capacity"]
