@@ -147,6 +147,27 @@ class HashTable:
                                       _lib.stream_ptr(self._storage.device)), "ln_table_clear")
         self._storage.touch()
         self.m_nr_filled_is_dirty = True
+        self._readback_pending = False
+
+    def start_count_readback(self):
+        """Enqueues the 8-byte {nr_filled, status} copy to pinned host memory right behind the build, so that
+        nr_lattice_vertices() only waits for the build itself and not for kernels issued after it."""
+        if self._counters is None:
+            return
+        if getattr(self, "_pinned", None) is None:
+            self._pinned = torch.empty((2,), dtype=torch.int32, pin_memory=True)
+            self._readback_event = torch.cuda.Event()
+        self._pinned.copy_(self._counters, non_blocking=True)
+        self._readback_event.record(torch.cuda.current_stream(self._counters.device))
+        self._readback_pending = True
+
+    def read_counters(self):
+        """[nr_filled, status]; one blocking wait (on the readback event if a build enqueued one)."""
+        if getattr(self, "_readback_pending", False):
+            self._readback_event.synchronize()
+            self._readback_pending = False
+            return self._pinned.tolist()
+        return self._counters.tolist()
 
     def clear_only_values(self):  # HashTable.cu:59-64
         if self.is_initialized() and self.m_values_tensor is not None:
@@ -354,6 +375,7 @@ class Lattice:
             _lib.check(rc, "ln_distribute")
         ht._storage.touch()
         ht.m_nr_filled_is_dirty = True
+        ht.start_count_readback()
         if write:
             # the build's slot -> tokens adjacency serves every scatter that uses these indices (groups = slots,
             # row of a group = entries[slot]); `idx` is kept alive by the entry so its address cannot be recycled
@@ -411,6 +433,7 @@ class Lattice:
             raise ValueError(f"table values have val_dim {tv.shape[1]} but {v} were splatted")
         # splatCacheNaive (LatticeGPU.cuh:926-973) as a token-balanced reduce; begin_splat zeroed the table values
         self._scatter_rows(values, idx, w, tv, v, d + 1, v)
+        self._prefetch_neighbours(n * (d + 1))
         return idx, w
 
     def just_create_verts(self, positions_raw: torch.Tensor, return_indices_and_weights: bool):  # Lattice.cu:244-290
@@ -449,6 +472,7 @@ class Lattice:
             nh.m_values_tensor = torch.zeros_like(oh.m_values_tensor)
             nh._counters = oh._counters.clone()
         idx, w = new._build(positions_raw, True, vals=values, distributed=distributed)
+        new._prefetch_neighbours(n * (d + 1))
         return new, distributed, idx, w
 
     def expand(self, positions_raw: torch.Tensor, point_multiplier: int, noise_stddev: float, expand_values: bool):  # Lattice.cu:292-348
@@ -472,6 +496,24 @@ class Lattice:
         return new
 
     # ---------------------------------------------------------------- neighbour list (shared)
+    def _prefetch_neighbours(self, tokens: int):
+        """Launches the same-level, dilation-1 neighbour traversal right behind a build, sized by an upper bound on
+        the vertex count (the kernel stops at the device-side nr_filled).  Every lattice convolution starts with
+        this list; issuing it here keeps it off the critical path that follows the host readback of nr_filled."""
+        ht = self.m_hash_table
+        st = ht._storage
+        rows_upper = min(ht.capacity(), tokens)
+        if rows_upper <= 0:
+            return
+        lib = _lib.load()
+        E = self.get_filter_extent(1)
+        nbr = torch.empty((rows_upper, E), dtype=torch.int32, device=self._dev())
+        t = ht.c_table()
+        _lib.check(lib.ln_neighbours(C.byref(t), rows_upper, C.byref(t), self.m_lvl, self.m_lvl, 1, 0, _lib.ptr(nbr), self._stream()),
+                   "ln_neighbours")
+        st.nbr_cache[("prefetch", id(st), st.version, self.m_lvl)] = (nbr, st)
+
+
     def neighbours(self, lattice_neighbours: Optional["Lattice"], dilation: int, flip_neighbours: bool) -> torch.Tensor:
         """[M, E] int32 neighbour list of this (query) lattice in `lattice_neighbours`, cached.  The flipped list
         is the un-flipped one with the np/nm slots of every axis swapped (LatticeGPU.cuh:1622-1626,1645-1649)."""
@@ -487,6 +529,12 @@ class Lattice:
         if hit is not None:
             return hit[0]
         E = self.get_filter_extent(1)
+        pre = sq.nbr_cache.get(("prefetch", id(sn), sn.version, self.m_lvl)) if (sn is sq and not flip_neighbours and dilation == 1 and
+                                                                                  nb.m_lvl == self.m_lvl) else None
+        if pre is not None and pre[0].shape[0] >= m:
+            nbr = pre[0][:m]
+            sq.nbr_cache[key] = (nbr, sn)
+            return nbr
         if flip_neighbours:
             base = self.neighbours(nb, dilation, False)
             perm = [e ^ 1 for e in range(E - 1)] + [E - 1]
@@ -787,7 +835,7 @@ class Lattice:
     def nr_lattice_vertices(self) -> int:  # Lattice.cu:1320-1352
         ht = self.m_hash_table
         if ht.m_nr_filled_is_dirty:
-            both = ht._counters.tolist()  # ONE blocking 8-byte readback: [nr_filled, status]
+            both = ht.read_counters()  # ONE blocking 8-byte readback: [nr_filled, status]
             nr, status = int(both[0]), int(both[1])
             if status & _lib.LN_STATUS_TABLE_FULL:
                 raise _lib.LatticeNetHipError(f"hash table overflow: capacity {ht.capacity()} is too small for this cloud "
