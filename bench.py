@@ -63,6 +63,16 @@ def algorithmic_work(kernel: str, n: int, m: int, d: int, v: int, f: int, e: int
     raise ValueError(f"no algorithmic model for kernel {kernel}")
 
 
+def pmc_traffic(kernel: str):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r1_pmc_traffic.json), or None."""
+    path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(kernel, {}).get("traffic_bytes")
+    except OSError:
+        return None
+
+
 def cpu_baseline(cfg, seconds: float):
     """Pure-PyTorch CPU fallback of the same op chain (oracle/torch_fallback.py), all host cores."""
     from oracle import torch_fallback as TF
@@ -173,7 +183,8 @@ def main():
             else:
                 achieved, peak = amount / avg_s / 1e12, MFMA_F32_PEAK_TFLOPS
             roofline = {"bound": bound_kind, "achieved": round(achieved, 3), "peak": peak, "unit": unit,
-                        "frac": round(achieved / peak, 4), "traffic": None, "kernel": args.roofline_kernel,
+                        "frac": round(achieved / peak, 4), "traffic": pmc_traffic(args.roofline_kernel) if args.workload == "C3" else None,
+                        "kernel": args.roofline_kernel,
                         "avg_us": round(avg_s * 1e6, 2), "launches_timed": launches.value}
         cpu = None
         if world == 1 and args.cpu_seconds > 0:
