@@ -52,7 +52,7 @@ def algorithmic_work(kernel: str, n: int, m: int, d: int, v: int, f: int, e: int
         return "mfma", "TFLOP/s", 2.0 * m * e * v * f
     if kernel == "k_grad_filter_mfma":
         return "mfma", "TFLOP/s", 2.0 * m * e * v * f
-    if kernel == "k_scatter_point_rows":  # splat accumulate / slice backward: read rows+idx+w, write vertex rows
+    if kernel in ("k_scatter_point_rows", "k_csr_reduce_segments"):  # splat accumulate / slice backward: read rows+idx+w, write vertex rows
         return "hbm", "GB/s", n * (4.0 * v + 8.0 * (d + 1)) + m * 4.0 * v
     if kernel == "k_slice_forward":
         return "hbm", "GB/s", n * (8.0 * (d + 1) + 4.0 * v) + m * 4.0 * v
@@ -102,7 +102,11 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
-    ap.add_argument("--roofline-kernel", default="k_conv_mfma", help="kernel whose launches are timed live with HIP events")
+    ap.add_argument("--roofline-kernel", default="k_insert_points",
+                    help="dominant kernel (largest share of GPU time in profiles/r1_kernel_stats.csv): its launches are timed live "
+                         "with HIP events during the timed region")
+    ap.add_argument("--extra-kernels", default="k_conv_mfma,k_csr_reduce_segments,k_grad_filter_mfma,k_slice_forward,k_neighbours",
+                    help="kernels timed the same way in extra untimed steps AFTER the timed region (reported under roofline_others)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the CPU baseline leg (0 disables)")
     ap.add_argument("--autograd-threads", type=int, default=0, help="1 = leave torch's per-device autograd worker thread on")
     args = ap.parse_args()
@@ -172,20 +176,40 @@ def main():
     max_elapsed = sharding.max_over_ranks(dist, elapsed, dev)
     checksum = sharding.gather_sum(dist, checksum, dev)
 
+    def roofline_entry(kernel, total_ms_v, launches_v):
+        bound_kind, unit, amount = algorithmic_work(kernel, n, m, d, v, f, e)
+        avg_s = total_ms_v / launches_v / 1e3
+        if bound_kind == "hbm":
+            achieved, peak = amount / avg_s / 1e9, HBM_PEAK_GBS
+        else:
+            achieved, peak = amount / avg_s / 1e12, MFMA_F32_PEAK_TFLOPS
+        return {"bound": bound_kind, "achieved": round(achieved, 3), "peak": peak, "unit": unit, "frac": round(achieved / peak, 4),
+                "traffic": pmc_traffic(kernel) if args.workload == "C3" else None, "kernel": kernel,
+                "avg_us": round(avg_s * 1e6, 2), "launches_timed": launches_v}
+
+    # other kernels of the path, timed the same way in a few extra steps outside the timed region
+    others = []
+    if rank == 0:
+        for name in [k for k in args.extra_kernels.split(",") if k and k != args.roofline_kernel]:
+            if lib.ln_profile_begin(name.encode(), 64) != 0:
+                continue
+            for _ in range(5):
+                step()
+            torch.cuda.synchronize()
+            tms, cnt = C.c_double(0.0), C.c_int(0)
+            lib.ln_profile_end(C.byref(tms), C.byref(cnt))
+            if cnt.value > 0:
+                try:
+                    others.append(roofline_entry(name, tms.value, cnt.value))
+                except ValueError:
+                    pass
+    barrier()
+
     if rank == 0:
         value = n * world * args.steps / max_elapsed / 1e6
         roofline = None
         if armed and launches.value > 0:
-            bound_kind, unit, amount = algorithmic_work(args.roofline_kernel, n, m, d, v, f, e)
-            avg_s = total_ms.value / launches.value / 1e3
-            if bound_kind == "hbm":
-                achieved, peak = amount / avg_s / 1e9, HBM_PEAK_GBS
-            else:
-                achieved, peak = amount / avg_s / 1e12, MFMA_F32_PEAK_TFLOPS
-            roofline = {"bound": bound_kind, "achieved": round(achieved, 3), "peak": peak, "unit": unit,
-                        "frac": round(achieved / peak, 4), "traffic": pmc_traffic(args.roofline_kernel) if args.workload == "C3" else None,
-                        "kernel": args.roofline_kernel,
-                        "avg_us": round(avg_s * 1e6, 2), "launches_timed": launches.value}
+            roofline = roofline_entry(args.roofline_kernel, total_ms.value, launches.value)
         cpu = None
         if world == 1 and args.cpu_seconds > 0:
             cpu = cpu_baseline(cfg, args.cpu_seconds)
@@ -196,7 +220,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": cfg["desc"], "points_per_gpu": n, "vertices": m, "val_dim": v, "nr_filters": f,
                        "sharding": f"{world} independent cloud(s), one per GPU", "checksum": round(checksum, 3)},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "roofline_others": others, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
     if dist is not None:
