@@ -1,0 +1,246 @@
+"""GPU tests of the operator surface beyond the raw kernels: autograd Functions, nn.Modules, Lattice
+object semantics, and the remaining BASELINE.json configs (C2 ShapeNet-like U-Net level chain, C4
+ScanNet-like 200k-point scene with a 5M-slot table) — all against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import lattice_oracle as O
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-5
+
+
+def dev():
+    return torch.device("cuda", 0)
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def make_lattice(sigma, capacity, d=3):
+    from lattice_net_amd import Lattice
+    return Lattice(sigmas=[float(sigma)] * d, capacity=int(capacity), device=dev())
+
+
+def close(a, b, scale=None, rtol=RTOL):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    s = float(np.max(np.abs(b))) if scale is None else scale
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=rtol * max(s, 1e-30))
+
+
+def oracle_table(pos_np, sigma, cap):
+    t = O.OracleHashTable(cap, pos_np.shape[1])
+    idx, w = O.build_splat(t, O.scale_positions(pos_np, np.full((pos_np.shape[1],), sigma, np.float32)))
+    return t, idx, w
+
+
+def test_slice_and_gather_autograd_against_oracle():
+    from lattice_net_amd import GatherLattice, SliceLattice
+    from lattice_net_amd.synthetic import cube_cloud
+    pos_np = cube_cloud(2500, 11)
+    lat = make_lattice(0.2, 40000)
+    lat.begin_splat()
+    idx, w = lat.just_create_verts(T(pos_np), True)
+    m = lat.nr_lattice_vertices()
+    t, oidx, ow = oracle_table(pos_np, 0.2, 40000)
+    rng = np.random.default_rng(0)
+    v = 8
+    vals_np = rng.standard_normal((m, v)).astype(np.float32)
+    g_np = rng.standard_normal((2500, v)).astype(np.float32)
+    vals = T(vals_np).requires_grad_(True)
+    out = SliceLattice.apply(vals, lat, T(pos_np), idx, w)
+    np.testing.assert_array_equal(N(out), O.slice_with_precomputation(vals_np, oidx, ow, 2500))
+    out.backward(T(g_np))
+    close(N(vals.grad), O.slice_backwards(g_np, oidx, ow, m))
+    # slicing without precomputed indices (new positions): backward builds the CSR from the returned indices
+    q_np = cube_cloud(700, 12, -1.05, 1.05)
+    vals2 = T(vals_np).requires_grad_(True)
+    out2 = SliceLattice.apply(vals2, lat, T(q_np))
+    o2, i2, w2 = O.slice_no_precomputation(t, vals_np, O.scale_positions(q_np, np.full((3,), 0.2, np.float32)))
+    np.testing.assert_array_equal(N(out2), o2)
+    g2 = rng.standard_normal((700, v)).astype(np.float32)
+    out2.backward(T(g2))
+    close(N(vals2.grad), O.slice_backwards(g2, i2, np.where(i2 >= 0, w2, 0).astype(np.float32), m))
+    # gather
+    vals3 = T(vals_np).requires_grad_(True)
+    ga = GatherLattice.apply(vals3, lat, T(pos_np), idx, w)
+    np.testing.assert_array_equal(N(ga), O.gather_with_precomputation(vals_np, oidx, ow, 2500))
+    gg = rng.standard_normal(tuple(ga.shape)).astype(np.float32)
+    ga.backward(T(gg))
+    close(N(vals3.grad), O.gather_backwards(gg, oidx, ow, m, 3))
+
+
+def test_slice_classify_autograd_against_oracle():
+    from lattice_net_amd import SliceClassifyLattice
+    from lattice_net_amd.synthetic import cube_cloud
+    pos_np = cube_cloud(1500, 21)
+    n, v, c = 1500, 8, 20
+    lat = make_lattice(0.25, 30000)
+    lat.begin_splat()
+    idx, w = lat.just_create_verts(T(pos_np), True)
+    m = lat.nr_lattice_vertices()
+    _, oidx, ow = oracle_table(pos_np, 0.25, 30000)
+    rng = np.random.default_rng(2)
+    vals_np = rng.standard_normal((m, v)).astype(np.float32)
+    dw_np = (0.1 * rng.standard_normal((n, 4))).astype(np.float32)
+    lw_np = rng.standard_normal((c, v)).astype(np.float32)
+    lb_np = rng.standard_normal((c,)).astype(np.float32)
+    gl_np = rng.standard_normal((n, c)).astype(np.float32)
+    vals, dw, lw, lb = (T(x).requires_grad_(True) for x in (vals_np, dw_np, lw_np, lb_np))
+    logits = SliceClassifyLattice.apply(vals, lat, T(pos_np), dw, lw, lb, c, idx, w)
+    np.testing.assert_array_equal(N(logits), O.slice_classify(vals_np, dw_np, lw_np, lb_np, oidx, ow, n))
+    logits.backward(T(gl_np))
+    gv, gd, gw, gb = O.slice_classify_backwards(gl_np, vals_np, dw_np, lw_np, lb_np, oidx, ow, n)
+    close(N(vals.grad), gv)
+    close(N(dw.grad), gd)
+    close(N(lw.grad), gw)
+    close(N(lb.grad), gb)
+
+
+def test_modules_level_chain_c2_shapenet_like():
+    """C2: ~2.5k-point surface cloud, sigma 0.05, capacity 60000; distribute -> conv -> coarsen x3 -> finefy -> slice, fwd+bwd."""
+    from lattice_net_amd import Lattice
+    from lattice_net_amd.lattice_modules import (CoarsenLatticeModule, ConvLatticeIm2RowModule, DistributeLatticeModule,
+                                                 FinefyLatticeModule, SliceLatticeModule)
+    from lattice_net_amd.synthetic import box_surface_cloud
+    torch.manual_seed(0)
+    pos_np = box_surface_cloud(2500, 5)
+    pos = T(pos_np)
+    vals = torch.ones((2500, 1), device=dev())
+    lat = Lattice(sigmas=[0.05] * 3, capacity=60000, device=dev())
+    dist_lat, distributed, idx, w = DistributeLatticeModule()(lat, pos, vals)
+    m0 = dist_lat.nr_lattice_vertices()
+    t, oidx, ow = oracle_table(pos_np, 0.05, 60000)
+    assert m0 == t.nr_filled
+    np.testing.assert_array_equal(N(idx), oidx)
+    # post-processing of mods:66-94: per-vertex mean of the scaled positions removed, vertex 0 = invalid bucket
+    raw, _, _ = O.distribute(O.OracleHashTable(60000, 3), O.scale_positions(pos_np, np.full((3,), 0.05, np.float32)),
+                             np.ones((2500, 1), np.float32))
+    sums = np.zeros((m0, 3), np.float64)
+    cnt = np.zeros((m0,), np.float64)
+    np.add.at(sums, oidx, raw[:, :3].astype(np.float64))
+    np.add.at(cnt, oidx, 1.0)
+    mean = sums / cnt[:, None]
+    mean[0] = 0
+    exp = raw.astype(np.float64).copy()
+    exp[:, :3] -= mean[oidx]
+    exp[oidx == 0] = 0
+    close(N(distributed), exp, scale=np.abs(exp).max())
+    # feature lift so the convs have something to chew on
+    feat = torch.randn((m0, 16), device=dev(), requires_grad=True)
+    dist_lat.set_values(feat.detach())
+    conv = ConvLatticeIm2RowModule(16, 16)
+    lv, ls = conv(feat, dist_lat)
+    levels = [(lv, ls)]
+    chans = 16
+    coarsens = []
+    for _ in range(3):
+        cm = CoarsenLatticeModule(chans, chans * 2)
+        coarsens.append(cm)
+        lv, ls = cm(lv, ls)
+        chans *= 2
+        levels.append((lv, ls))
+        assert ls.lvl() == len(levels)
+    assert levels[1][1].nr_lattice_vertices() < m0
+    for k in range(3, 0, -1):
+        fm = FinefyLatticeModule(chans, chans // 2)
+        lv, ls = fm(lv, levels[k][1], levels[k - 1][1])
+        chans //= 2
+        assert lv.shape == (levels[k - 1][1].nr_lattice_vertices(), chans)
+    out = SliceLatticeModule()(lv, ls, pos, idx, w)
+    assert out.shape == (2500, 16) and torch.isfinite(out).all()
+    out.square().mean().backward()
+    for mod in [conv] + coarsens:
+        assert mod.weight.grad is not None and torch.isfinite(mod.weight.grad).all() and mod.weight.grad.abs().sum() > 0
+    assert feat.grad is not None and torch.isfinite(feat.grad).all()
+    # coarse level keys against the oracle (sigma doubles per level, L.cu:718-722)
+    tc, _, _ = oracle_table(pos_np, 0.1, 60000)
+    l1 = levels[1][1]
+    np.testing.assert_array_equal(N(l1.hash_table().m_keys_tensor[: l1.nr_lattice_vertices()]), tc.keys[: tc.nr_filled])
+
+
+def test_c4_scannet_like_scene_large_table():
+    """C4: 200k points on planes in an 8x3x8 m box, sigma 0.08, capacity 5,000,000, V=32 (one cloud per GPU)."""
+    from lattice_net_amd.synthetic import planes_cloud
+    pos_np = planes_cloud(200000, 4)
+    lat = make_lattice(0.08, 5000000)
+    lat.begin_splat()
+    vals_np = np.random.default_rng(4).standard_normal((200000, 4)).astype(np.float32)
+    idx, w = lat.splat_standalone(T(pos_np), T(vals_np))
+    m = lat.nr_lattice_vertices()
+    t, oidx, ow = oracle_table(pos_np, 0.08, 5000000)
+    assert m == t.nr_filled
+    np.testing.assert_array_equal(N(idx), oidx)
+    np.testing.assert_array_equal(N(w), ow)
+    nbr = O.neighbour_rows(t.keys[:m], t, 1, 1, 1, False)
+    lat.set_values(lat.values()[:m].contiguous())
+    np.testing.assert_array_equal(N(lat.neighbours(lat, 1, False)), nbr)
+    ov = np.zeros((m, 4), np.float32)
+    O.splat_accumulate(ov, vals_np, oidx, ow)
+    absv = np.zeros((m, 4), np.float32)
+    O.splat_accumulate(absv, np.abs(vals_np), oidx, ow)
+    assert np.all(np.abs(N(lat.values()).astype(np.float64) - ov) <= 1e-5 * absv + 1e-30)
+
+
+def test_lattice_object_semantics():
+    from lattice_net_amd.synthetic import cube_cloud
+    pos = T(cube_cloud(600, 31))
+    lat = make_lattice(0.3, 10000)
+    lat.begin_splat()
+    lat.splat_standalone(pos, torch.ones((600, 2), device=dev()))
+    m = lat.nr_lattice_vertices()
+    assert lat.pos_dim() == 3 and lat.val_dim() == 2 and lat.capacity() == 10000 and lat.get_filter_extent(1) == 9
+    assert tuple(lat.values().shape) == (10000, 2)            # splat leaves CAP rows (HashTable.cu:32)
+    with pytest.raises(ValueError, match="rows"):
+        lat.set_values(lat.values())                          # set_values checks rows == nr_lattice_vertices (L.cu:1398)
+    lat.set_values(lat.values()[:m].contiguous())
+    clone = lat.clone_lattice()                               # structure shared shallowly (L.cu:88-92)
+    assert clone.hash_table().m_keys_tensor.data_ptr() == lat.hash_table().m_keys_tensor.data_ptr()
+    clone.set_values(torch.zeros((m, 7), device=dev()))
+    assert clone.val_dim() == 7 and lat.val_dim() == 2        # val_dim is defined by the values tensor (HashTable.cu:102)
+    assert lat.positions() is pos
+    coarse = lat.create_coarse_verts_naive(pos)
+    assert coarse.lvl() == 2 and coarse.m_sigmas == pytest.approx([0.6] * 3)
+    with pytest.raises(ValueError, match="differ by at most 1"):
+        coarse.create_coarse_verts_naive(pos).neighbours(lat, 1, False)
+    with pytest.raises(ValueError, match="filter extent"):
+        lat.im2row(lat, 7, 1, False)
+
+
+def test_expand_adds_vertices_and_keeps_rows():
+    from lattice_net_amd.synthetic import cube_cloud
+    pos = T(cube_cloud(500, 41))
+    lat = make_lattice(0.3, 20000)
+    lat.begin_splat()
+    lat.splat_standalone(pos, torch.ones((500, 3), device=dev()))
+    m = lat.nr_lattice_vertices()
+    lat.set_values(lat.values()[:m].contiguous())
+    keys_before = N(lat.hash_table().m_keys_tensor[:m]).copy()
+    torch.manual_seed(0)
+    ex = lat.expand(pos, 4, 0.2, True)
+    m2 = ex.nr_lattice_vertices()
+    assert m2 > m and lat.nr_lattice_vertices() == m
+    np.testing.assert_array_equal(N(ex.hash_table().m_keys_tensor[:m]), keys_before)  # existing rows keep their ids
+    assert tuple(ex.values().shape) == (m2, 3)
+    np.testing.assert_array_equal(N(ex.values()[:m]), N(lat.values()))
+    assert float(ex.values()[m:].abs().sum()) == 0.0
+
+
+def test_create_from_cfg_and_splat(tmp_path):
+    from lattice_net_amd import Lattice, SplatLattice
+    from lattice_net_amd.synthetic import lidar_cloud
+    cfg = tmp_path / "kitti.cfg"
+    cfg.write_text('lattice_gpu: {\n    hash_table_capacity: 100000 //comment\n    nr_sigmas: 1\n    sigma_0: "0.9 3" //x\n}\n')
+    lat = Lattice.create(str(cfg), "lattice")
+    pos_np = lidar_cloud(5000, 2)
+    lv, wrap, idx, w = SplatLattice.apply(lat, T(pos_np), torch.ones((5000, 1), device=dev()))
+    t, oidx, ow = oracle_table(pos_np, 0.9, 100000)
+    assert wrap.lattice is lat and lat.nr_lattice_vertices() == t.nr_filled
+    np.testing.assert_array_equal(N(idx), oidx)
