@@ -291,8 +291,8 @@ extern "C" int ln_conv_forward(const int* nbr, const float* values_neigh, const 
 //          the 4 waves are combined through LDS and the workgroup writes one partial [V,F] slab.
 // Stage 2: deterministic sum of the slabs.
 // ------------------------------------------------------------------------------------------
-#define LN_GF_ROWS 1024  // lattice vertices per workgroup (one slab each)
-#define LN_GF_SUB 128    // vertices staged in LDS at a time
+#define LN_GF_ROWS 320   // lattice vertices per workgroup (one slab each)
+#define LN_GF_SUB 64     // vertices staged in LDS at a time (25 KiB of LDS -> 6 workgroups per CU)
 
 // Stage 1.  grid = (row chunks, E).  A workgroup walks its chunk in sub-tiles of LN_GF_SUB vertices: the
 // gathered neighbour rows A[sub, V] and the gradient rows G[sub, F] are staged in LDS with float4 loads
@@ -416,18 +416,23 @@ __global__ void __launch_bounds__(256)
     grad_filter[g] = acc;
 }
 
-// 64 outputs per workgroup; the slabs are split over 4 thread rows and combined through LDS
+// 16 outputs per workgroup; the slabs are split over 16 thread rows and combined through LDS
 __global__ void __launch_bounds__(256) k_reduce_slabs(const float* __restrict__ partial, int nslabs, int total, float* __restrict__ out) {
-    __shared__ float s_part[4][64];
-    const int o = threadIdx.x & 63;
-    const int part = threadIdx.x >> 6;
-    const int g = blockIdx.x * 64 + o;
+    __shared__ float s_part[16][17];
+    const int o = threadIdx.x & 15;
+    const int part = threadIdx.x >> 4;
+    const int g = blockIdx.x * 16 + o;
     float acc = 0.0f;
     if (g < total)
-        for (int s = part; s < nslabs; s += 4) acc += partial[(size_t)s * total + g];
+        for (int s = part; s < nslabs; s += 16) acc += partial[(size_t)s * total + g];
     s_part[part][o] = acc;
     __syncthreads();
-    if (part == 0 && g < total) out[g] = (s_part[0][o] + s_part[1][o]) + (s_part[2][o] + s_part[3][o]);
+    if (part == 0 && g < total) {
+        float r = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) r += s_part[k][o];
+        out[g] = r;
+    }
 }
 
 static bool ln_gf_mfma_supported(int val_dim, int nr_filters) {
@@ -466,7 +471,7 @@ extern "C" int ln_conv_grad_filter(const int* nbr, const float* values_neigh, co
         LN_GF_CASE(4, 2) LN_GF_CASE(4, 4)
 #undef LN_GF_CASE
         // slabs are laid out [chunk][e][V*F]; summing over chunks with stride E*V*F
-        LN_LAUNCH("k_reduce_slabs", k_reduce_slabs, dim3(ln_div_up(total, 64)), dim3(256), 0, st, partial, chunks, total, grad_filter);
+        LN_LAUNCH("k_reduce_slabs", k_reduce_slabs, dim3(ln_div_up(total, 16)), dim3(256), 0, st, partial, chunks, total, grad_filter);
     } else {
         LN_LAUNCH("k_grad_filter_generic", k_grad_filter_generic, dim3(ln_div_up(total, 256)), dim3(256), 0, st, nbr, values_neigh, grad_out, m,
                            filter_extent, val_dim, nr_filters, grad_filter);
