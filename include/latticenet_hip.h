@@ -124,6 +124,16 @@ int ln_csr_build(const int* idx, long long tokens, int groups_upper, const LnCsr
 int ln_csr_reduce_rows(const LnCsr* csr, const int* grp_row, long long max_segments, const float* src, const float* w, int val_dim,
                        int src_div, int src_stride, float* dst, void* stream);
 
+/* "Next" row: the vertex-wise aggregations PointNetModule runs on the distributed
+ * rows — torch_scatter.scatter_max with argmax (lattice_modules.py:688) and scatter_add of ones
+ * (lattice_modules.py:692) — on the same adjacency.
+ * ln_csr_segment_max: out_max[r, c] = max over the tokens t of row r of src[t, c], out_arg[r, c] = the
+ * token attaining it (smallest token on ties); rows without tokens get 0 / -1.
+ * packed_ws: rows*channels*8 bytes of scratch.  ln_csr_group_sizes: counts[r] = tokens of row r. */
+int ln_csr_segment_max(const LnCsr* csr, const int* grp_row, long long max_segments, const float* src, int channels, int rows,
+                       void* packed_ws, float* out_max, int* out_arg, void* stream);
+int ln_csr_group_sizes(const LnCsr* csr, const int* grp_row, int groups_upper, int rows, int* counts, void* stream);
+
 /* distribute kernel (LatticeGPU.cuh:534-650) behind Lattice::distribute (Lattice.cu:351-410):
  * ln_build_splat + the dense rows [pos_scaled(d) | val(V) | bary] -> distributed[n*(d+1), d+V+1]. */
 int ln_distribute(const LnTable* t, const float* positions_raw, const float* sigmas_host, const float* vals, int n,

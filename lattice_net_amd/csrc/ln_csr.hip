@@ -298,3 +298,106 @@ extern "C" int ln_csr_reduce_rows(const LnCsr* csr, const int* grp_row, long lon
                   csr->seg_count, grp_row, src, w, chunks, lanes, src_div, src_stride, dst);
     return ln_check_launch("ln_csr_reduce_rows");
 }
+
+// ------------------------------------------------------------------------------------------
+// segment max with argmax (the PointNet aggregation of the reference's first stage:
+// torch_scatter.scatter_max over splat indices, lattice_modules.py:688) and vertex degrees
+// (torch_scatter.scatter_add of ones, lattice_modules.py:692) on the same CSR adjacency.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned int ln_float_to_ordered(float f) {
+    f = (f == 0.0f) ? 0.0f : f;  // -0 and +0 compare equal: give them one code so ties go to the smallest token
+    const unsigned int u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ln_ordered_to_float(unsigned int o) {
+    const unsigned int u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+    return __uint_as_float(u);
+}
+
+// one lane per (segment, channel): running max over <=16 tokens; value and token are packed into 64 bits
+// (ordered value in the high word, ~token in the low word -> ties go to the smallest token) so that the
+// segments of a hot vertex combine with one 64-bit atomicMax.
+__global__ void __launch_bounds__(256)
+    k_csr_segment_max(const int* __restrict__ grp_start, const int* __restrict__ csr_tok, const int* __restrict__ seg_grp,
+                      const int* __restrict__ seg_beg, const int* __restrict__ seg_count, const int* __restrict__ grp_row,
+                      const float* __restrict__ src, int channels, unsigned long long* __restrict__ packed) {
+    const long long gt = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long sid = gt / channels;
+    const int c = int(gt - sid * channels);
+    if (sid >= *seg_count) return;
+    const int grp = seg_grp[sid];
+    const int row = grp_row ? grp_row[grp] : grp;
+    if (row < 0) return;
+    const int beg = seg_beg[sid];
+    const int rbeg = grp_start[grp];
+    const int rend = grp_start[grp + 1];
+    const int end = min(beg + LN_SEG, rend);
+    unsigned long long best = 0ull;
+    for (int e = beg; e < end; ++e) {
+        const int t = csr_tok[e];
+        const unsigned long long p = ((unsigned long long)ln_float_to_ordered(src[(size_t)t * channels + c]) << 32) |
+                                     (unsigned long long)(0xFFFFFFFFu - (unsigned int)t);
+        best = p > best ? p : best;
+    }
+    unsigned long long* d = packed + (size_t)row * channels + c;
+    if (rend - rbeg <= LN_SEG)
+        *d = best;
+    else
+        atomicMax(d, best);
+}
+
+__global__ void __launch_bounds__(256)
+    k_csr_segment_max_decode(const unsigned long long* __restrict__ packed, long long work, float* __restrict__ out_max,
+                             int* __restrict__ out_arg) {
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= work) return;
+    const unsigned long long p = packed[g];
+    if (p == 0ull) {  // vertex without any token
+        out_max[g] = 0.f;
+        out_arg[g] = -1;
+    } else {
+        out_max[g] = ln_ordered_to_float((unsigned int)(p >> 32));
+        out_arg[g] = int(0xFFFFFFFFu - (unsigned int)(p & 0xFFFFFFFFull));
+    }
+}
+
+extern "C" int ln_csr_segment_max(const LnCsr* csr, const int* grp_row, long long max_segments, const float* src, int channels,
+                                  int rows, void* packed_ws, float* out_max, int* out_arg, void* stream) {
+    LN_REQUIRE(max_segments >= 0 && channels >= 1 && rows >= 0, LN_ERR_ARG, "ln_csr_segment_max: bad sizes");
+    LN_REQUIRE(rows == 0 || (csr && csr->grp_start && csr->csr_tok && csr->seg_grp && csr->seg_beg && csr->seg_count && src && packed_ws &&
+                             out_max && out_arg),
+               LN_ERR_ARG, "ln_csr_segment_max: null buffer");
+    if (rows == 0) return LN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const long long work = (long long)rows * channels;
+    if (hipMemsetAsync(packed_ws, 0, (size_t)work * sizeof(unsigned long long), st) != hipSuccess)
+        return ln_check_launch("ln_csr_segment_max(memset)");
+    if (max_segments > 0)
+        LN_LAUNCH("k_csr_segment_max", k_csr_segment_max, dim3(ln_div_up(max_segments * channels, 256)), dim3(256), 0, st, csr->grp_start,
+                  csr->csr_tok, csr->seg_grp, csr->seg_beg, csr->seg_count, grp_row, src, channels, static_cast<unsigned long long*>(packed_ws));
+    LN_LAUNCH("k_csr_segment_max_decode", k_csr_segment_max_decode, dim3(ln_div_up(work, 256)), dim3(256), 0, st,
+              static_cast<const unsigned long long*>(packed_ws), work, out_max, out_arg);
+    return ln_check_launch("ln_csr_segment_max");
+}
+
+// degree of every row: number of tokens whose group maps to it
+__global__ void __launch_bounds__(256)
+    k_csr_group_sizes(const int* __restrict__ grp_start, const int* __restrict__ grp_row, int groups_upper, int* __restrict__ counts) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= groups_upper) return;
+    const int c = grp_start[g + 1] - grp_start[g];
+    if (c == 0) return;
+    const int row = grp_row ? grp_row[g] : g;
+    if (row >= 0) counts[row] = c;  // one group per row: no conflicts
+}
+
+extern "C" int ln_csr_group_sizes(const LnCsr* csr, const int* grp_row, int groups_upper, int rows, int* counts, void* stream) {
+    LN_REQUIRE(groups_upper >= 1 && rows >= 0, LN_ERR_ARG, "ln_csr_group_sizes: bad sizes");
+    LN_REQUIRE(rows == 0 || (csr && csr->grp_start && counts), LN_ERR_ARG, "ln_csr_group_sizes: null buffer");
+    if (rows == 0) return LN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(counts, 0, (size_t)rows * sizeof(int), st) != hipSuccess) return ln_check_launch("ln_csr_group_sizes(memset)");
+    LN_LAUNCH("k_csr_group_sizes", k_csr_group_sizes, dim3(ln_div_up(groups_upper, 256)), dim3(256), 0, st, csr->grp_start, grp_row, groups_upper,
+              counts);
+    return ln_check_launch("ln_csr_group_sizes");
+}

@@ -412,6 +412,34 @@ class Lattice:
         _lib.check(lib.ln_csr_reduce_rows(C.byref(csr), _lib.ptr(grp_row), max_seg, _lib.ptr(src), _lib.ptr(w), val_dim, src_div,
                                           src_stride, _lib.ptr(dst), self._stream()), "ln_csr_reduce_rows")
 
+    def scatter_max(self, src: torch.Tensor, idx: torch.Tensor):
+        """Per-vertex maximum of per-token rows src[T, C] with its argmax token (torch_scatter.scatter_max over the
+        splat indices, lattice_modules.py:688).  Vertices without tokens get 0 / -1; ties go to the smallest token."""
+        if src.dim() != 2 or src.dtype != torch.float32 or not src.is_contiguous() or src.shape[0] != idx.numel():
+            raise ValueError("src must be a contiguous float [nr_tokens, C] tensor matching the splat indices")
+        _require_cuda(src, "src")
+        m = self.nr_lattice_vertices()
+        c = int(src.shape[1])
+        _, csr, max_seg, grp_row, _ = self._csr(idx)
+        dev = self._dev()
+        out_max = torch.empty((m, c), dtype=torch.float32, device=dev)
+        out_arg = torch.empty((m, c), dtype=torch.int32, device=dev)
+        packed = torch.empty((m * c,), dtype=torch.int64, device=dev)
+        lib = _lib.load()
+        _lib.check(lib.ln_csr_segment_max(C.byref(csr), _lib.ptr(grp_row), max_seg, _lib.ptr(src), c, m, _lib.ptr(packed), _lib.ptr(out_max),
+                                          _lib.ptr(out_arg), self._stream()), "ln_csr_segment_max")
+        return out_max, out_arg
+
+    def vertex_point_counts(self, idx: torch.Tensor) -> torch.Tensor:
+        """Number of tokens on every vertex (torch_scatter.scatter_add of ones, lattice_modules.py:692): int32 [M]."""
+        m = self.nr_lattice_vertices()
+        _, csr, _, grp_row, _ = self._csr(idx)
+        counts = torch.empty((m,), dtype=torch.int32, device=self._dev())
+        lib = _lib.load()
+        _lib.check(lib.ln_csr_group_sizes(C.byref(csr), _lib.ptr(grp_row), self.m_hash_table.capacity(), m, _lib.ptr(counts), self._stream()),
+                   "ln_csr_group_sizes")
+        return counts
+
     # ---------------------------------------------------------------- splat family
     def begin_splat(self, reset_hashmap: bool = True):  # Lattice.cu:185-193
         if reset_hashmap:

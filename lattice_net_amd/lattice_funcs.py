@@ -12,7 +12,7 @@ from torch.autograd import Function
 from .lattice import Lattice  # noqa: F401
 from .lattice_wrapper import LatticeWrapper
 
-__all__ = ["SplatLattice", "DistributeLattice", "ExpandLattice", "Im2RowIndicesLattice", "Im2RowLattice", "ConvIm2RowLattice",
+__all__ = ["ScatterMaxLattice", "SplatLattice", "DistributeLattice", "ExpandLattice", "Im2RowIndicesLattice", "Im2RowLattice", "ConvIm2RowLattice",
            "CoarsenLattice", "FinefyLattice", "SliceLattice", "SliceClassifyLattice", "GatherLattice"]
 
 
@@ -21,6 +21,30 @@ def _backward_filter(filter_bank: torch.Tensor, nr_filters: int, filter_extent: 
     neighbours yields grad wrt the input values."""
     fb = filter_bank.transpose(0, 1).reshape(nr_filters, filter_extent, val_dim)
     return fb.transpose(0, 1).contiguous().reshape(filter_extent * nr_filters, val_dim)
+
+
+class ScatterMaxLattice(Function):
+    """Vertex-wise max of per-token feature rows with argmax — the aggregation PointNetModule performs with
+    torch_scatter.scatter_max (lattice_modules.py:688), computed on the CSR adjacency of the splat indices.
+    Not part of the reference's lattice_funcs.py (torch_scatter is not available on the ROCm image)."""
+
+    @staticmethod
+    def forward(ctx, features, lattice, splatting_indices):
+        features = features.contiguous()
+        vmax, arg = lattice.scatter_max(features, splatting_indices)
+        ctx.save_for_backward(arg)
+        ctx.nr_tokens = features.shape[0]
+        ctx.mark_non_differentiable(arg)
+        return vmax, arg
+
+    @staticmethod
+    def backward(ctx, grad_max, grad_arg):
+        (arg,) = ctx.saved_tensors
+        valid = arg >= 0
+        grad_src = torch.zeros((ctx.nr_tokens, grad_max.shape[1]), dtype=grad_max.dtype, device=grad_max.device)
+        # every (vertex, channel) picked exactly one token of that vertex: a conflict-free scatter
+        grad_src.scatter_(0, torch.where(valid, arg, torch.zeros_like(arg)).long(), torch.where(valid, grad_max, torch.zeros_like(grad_max)))
+        return grad_src, None, None
 
 
 class SplatLattice(Function):  # lattice_funcs.py:30-43

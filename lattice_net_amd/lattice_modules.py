@@ -10,11 +10,11 @@ import math
 import torch
 
 from .lattice import Lattice
-from .lattice_funcs import (CoarsenLattice, ConvIm2RowLattice, DistributeLattice, FinefyLattice, GatherLattice, SliceLattice,
-                            SplatLattice)
+from .lattice_funcs import (CoarsenLattice, ConvIm2RowLattice, DistributeLattice, FinefyLattice, GatherLattice, ScatterMaxLattice,
+                            SliceLattice, SplatLattice)
 
-__all__ = ["SplatLatticeModule", "DistributeLatticeModule", "ConvLatticeIm2RowModule", "CoarsenLatticeModule", "FinefyLatticeModule",
-           "SliceLatticeModule", "GatherLatticeModule"]
+__all__ = ["SplatLatticeModule", "DistributeLatticeModule", "PointNetModule", "ConvLatticeIm2RowModule", "CoarsenLatticeModule",
+           "FinefyLatticeModule", "SliceLatticeModule", "GatherLatticeModule"]
 
 
 def _kaiming_uniform_fan_out_(weight: torch.Tensor, fan_scale: float = 1.0, std_scale: float = 1.0):
@@ -59,6 +59,51 @@ class DistributeLatticeModule(torch.nn.Module):  # lattice_modules.py:52-96
         invalid = (indices_long == 0).unsqueeze(1)
         distributed = distributed.masked_fill(invalid, 0)  # mods:88-94
         return distributed_lattice, distributed, splatting_indices, splatting_weights
+
+
+class PointNetModule(torch.nn.Module):  # lattice_modules.py:618-733 (the step right before the hot path in LNN)
+    """Per-token MLP -> vertex-wise max (+ the barycentric weight of the winning token) -> rows with fewer than 4
+    points and vertex 0 zeroed -> lattice convolution.  The reference's weight-normalised layers (LinearWN,
+    ConvLatticeIm2RowWNModule) are plain Linear / ConvLatticeIm2RowModule here (weight norm is a re-parametrisation,
+    not part of the lattice path)."""
+
+    def __init__(self, nr_output_channels_per_layer, nr_outputs_last_layer, nr_input_channels=None, device="cuda"):
+        super().__init__()
+        self.nr_output_channels_per_layer = list(nr_output_channels_per_layer)
+        self.nr_outputs_last_layer = nr_outputs_last_layer
+        self.layers = torch.nn.ModuleList([])
+        self.act = torch.nn.LeakyReLU(0.2)
+        self.device = device
+        self.last_conv = ConvLatticeIm2RowModule(self.nr_output_channels_per_layer[-1] * 2, nr_outputs_last_layer, 1, 1, True, device=device)
+        if nr_input_channels is not None:
+            self._make_layers(nr_input_channels)
+
+    def _make_layers(self, nr_input_channels):
+        for nr_out in self.nr_output_channels_per_layer:  # created lazily from the first input, mods:636-647
+            self.layers.append(torch.nn.Linear(nr_input_channels, nr_out, bias=True).to(self.device))
+            nr_input_channels = nr_out
+
+    def forward(self, lattice_py, distributed, indices):
+        if len(self.layers) == 0:
+            self._make_layers(distributed.shape[1] - 1)
+        barycentric_weights = distributed[:, -1]
+        x = distributed[:, : distributed.shape[1] - 1]
+        for layer in self.layers:
+            x = self.act(layer(x))
+        reduced, argmax = ScatterMaxLattice.apply(x, lattice_py, indices)               # mods:688
+        nr_points = lattice_py.vertex_point_counts(indices).unsqueeze(1)                  # mods:692
+        safe = torch.where(argmax >= 0, argmax, torch.zeros_like(argmax)).long()
+        bary = torch.index_select(barycentric_weights, 0, safe.flatten()).view(argmax.shape[0], argmax.shape[1])  # mods:696-698
+        reduced = torch.cat((reduced, bary), 1)
+        reduced = reduced.masked_fill(nr_points < 4, 0)                                   # mods:705-707
+        keep = torch.ones((reduced.shape[0], 1), dtype=reduced.dtype, device=reduced.device)
+        keep[0] = 0                                                                       # vertex 0 = invalid bucket, mods:711-712
+        reduced = reduced * keep
+        lattice_py.set_values(reduced)
+        reduced, lattice_py = self.last_conv(reduced, lattice_py)
+        reduced = self.act(reduced)
+        lattice_py.set_values(reduced)
+        return reduced, lattice_py
 
 
 class ConvLatticeIm2RowModule(torch.nn.Module):  # lattice_modules.py:174-250

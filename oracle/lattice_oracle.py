@@ -514,3 +514,33 @@ def backward_filter_layout(filter_bank: np.ndarray, val_dim: int) -> np.ndarray:
     ev, f = filter_bank.shape
     e = ev // val_dim
     return np.ascontiguousarray(filter_bank.T.reshape(f, e, val_dim).transpose(1, 0, 2)).reshape(e * f, val_dim)
+
+
+# --------------------------------------------------------------------------------------
+# "next" row: vertex-wise aggregations of PointNetModule (lattice_modules.py:688-692)
+# --------------------------------------------------------------------------------------
+def scatter_max(src: np.ndarray, idx: np.ndarray, m: int):
+    """torch_scatter.scatter_max(src, idx, dim=0) restated: per vertex and channel the maximum over its tokens and
+    the token attaining it (smallest token on ties); vertices without tokens get 0 / -1.  Tokens with idx < 0 are
+    ignored (the reference sends them to vertex 0, which PointNetModule zeroes afterwards, mods:711-712)."""
+    t, c = src.shape
+    out = np.zeros((m, c), dtype=F32)
+    arg = np.full((m, c), -1, dtype=np.int32)
+    seen = np.zeros((m,), dtype=bool)
+    for tok in range(t):
+        r = idx[tok]
+        if r < 0:
+            continue
+        if not seen[r]:
+            out[r] = src[tok]
+            arg[r] = tok
+            seen[r] = True
+        else:
+            better = src[tok] > out[r]
+            out[r][better] = src[tok][better]
+            arg[r][better] = tok
+    return out, arg
+
+
+def vertex_point_counts(idx: np.ndarray, m: int) -> np.ndarray:
+    return np.bincount(idx[idx >= 0], minlength=m).astype(np.int32)
