@@ -616,6 +616,43 @@ class Lattice:
         conv.m_hash_table.set_values(out)
         return conv
 
+    def convolve_im2row_backward(self, grad_out: torch.Tensor, filter_bank: torch.Tensor, dilation: int,
+                                 query: Optional["Lattice"], neighbours: Optional["Lattice"]):
+        """Both gradients of `query.convolve_im2row_standalone(filter_bank, dilation, neighbours, False)` in one call:
+        (grad wrt the neighbour values, grad wrt the filter bank), both as gather-GEMMs on the current stream.
+        `self` is unused beyond device bookkeeping; `query` / `neighbours` default to self."""
+        q = query if query is not None else self
+        nb = neighbours if neighbours is not None else self
+        lib = _lib.load()
+        main = self._stream()
+        E = q.get_filter_extent(1)
+        grad_out = grad_out.contiguous()
+        filter_bank = filter_bank.contiguous()
+        v = nb.val_dim()               # forward input channels
+        f = int(filter_bank.shape[1])  # forward output channels
+        if filter_bank.shape[0] != E * v or grad_out.shape[1] != f:
+            raise ValueError("filter bank / gradient shapes do not match the forward convolution")
+        # ---- filter gradient on the side stream: needs nbr(query -> neighbours), neighbour values, grad_out
+        nbr_q = q.neighbours(nb, dilation, False)
+        mq = nbr_q.shape[0]
+        if grad_out.shape[0] != mq:
+            raise ValueError(f"grad_out has {grad_out.shape[0]} rows, the query lattice has {mq} vertices")
+        dev = self._dev()
+        gf = torch.empty((E * v, f), dtype=torch.float32, device=dev)
+        ws = torch.empty((max(int(lib.ln_conv_grad_filter_workspace_bytes(mq, E, v, f)), 256),), dtype=torch.uint8, device=dev)
+        # ---- value gradient on the main stream: the query and neighbour roles swap (funcs:307-313, 380-387)
+        nbr_n = nb.neighbours(q, dilation, False)
+        mn = nbr_n.shape[0]
+        gvals = torch.empty((mn, v), dtype=torch.float32, device=dev)
+        # (Measured on MI355X: running the filter gradient on a second stream made the step SLOWER, 0.254 -> 0.286 ms:
+        # both kernels already fill the chip and the event hand-offs cost more than the overlap.)
+        _lib.check(lib.ln_conv_grad_filter(_lib.ptr(nbr_q), _lib.ptr(nb.values()), _lib.ptr(grad_out), mq, E, v, f, _lib.ptr(gf), _lib.ptr(ws),
+                                           ws.numel(), main), "ln_conv_grad_filter")
+        flags = _lib.LN_CONV_FLIP_NEIGHBOURS | _lib.LN_CONV_TRANSPOSED_FILTER
+        _lib.check(lib.ln_conv_forward(_lib.ptr(nbr_n), _lib.ptr(grad_out), _lib.ptr(filter_bank), mn, E, f, v, flags, _lib.ptr(gvals), main),
+                   "ln_conv_forward")
+        return gvals, gf
+
     def convolve_im2row_grad_filter(self, grad_out: torch.Tensor, dilation: int, lattice_neighbours: Optional["Lattice"],
                                     filter_extent: int) -> torch.Tensor:
         """grad_filter = im2row(...)^T @ grad_out (lattice_funcs.py:298-302) without the rowified tensor."""

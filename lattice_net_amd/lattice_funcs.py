@@ -151,14 +151,13 @@ class ConvIm2RowLattice(Function):  # lattice_funcs.py:250-320
         nr_filters, dilation, val_dim = ctx.nr_filters, ctx.dilation, ctx.val_dim
         filter_bank, lattice_values = ctx.saved_tensors
         filter_extent = int(filter_bank.shape[0] / val_dim)
-        grad_lattice_values = grad_lattice_values.contiguous()
         lattice.set_values(lattice_values)
-        grad_filter = lattice.convolve_im2row_grad_filter(grad_lattice_values, dilation, lattice, filter_extent)  # funcs:298-302
-        lattice.set_values(grad_lattice_values)
-        # funcs:307-313: convolve the gradient with flipped neighbours and the re-laid-out bank (applied in-kernel)
-        grad_lattice = lattice.convolve_im2row_standalone(filter_bank, dilation, lattice, True, filter_is_transposed=True)
+        # funcs:298-313: grad_filter = im2row^T @ grad, grad_values = conv(grad, flipped neighbours, re-laid-out bank);
+        # both run as gather-GEMMs
+        grad_values, grad_filter = lattice.convolve_im2row_backward(grad_lattice_values, filter_bank, dilation, lattice, lattice)
+        lattice.set_values(grad_values)  # the reference leaves the gradient in the lattice (funcs:312-313)
         ctx.lattice = 0
-        return grad_lattice.values(), None, grad_filter, None
+        return grad_values, None, grad_filter, None
 
 
 class CoarsenLattice(Function):  # lattice_funcs.py:323-398
@@ -186,16 +185,15 @@ class CoarsenLattice(Function):  # lattice_funcs.py:323-398
         nr_filters, dilation, val_dim = ctx.nr_filters, ctx.dilation, ctx.val_dim
         filter_bank, lattice_fine_values = ctx.saved_tensors
         filter_extent = int(filter_bank.shape[0] / val_dim)
-        grad_lattice_values = grad_lattice_values.contiguous()
         lattice_fine_structure.set_values(lattice_fine_values)
-        grad_filter = coarsened_lattice.convolve_im2row_grad_filter(grad_lattice_values, dilation, lattice_fine_structure, filter_extent)
-        coarsened_lattice.set_values(grad_lattice_values)
-        # convolve at the fine vertices with the coarse ones (which carry the errors) as neighbours, funcs:380-387
-        grad_lattice = lattice_fine_structure.convolve_im2row_standalone(filter_bank, dilation, coarsened_lattice, True,
-                                                                         filter_is_transposed=True)
+        # funcs:375-387: the filter gradient gathers fine values at the coarse vertices; the value gradient convolves at
+        # the fine vertices with the coarse ones (which carry the errors) as neighbours
+        grad_values, grad_filter = coarsened_lattice.convolve_im2row_backward(grad_lattice_values, filter_bank, dilation, coarsened_lattice,
+                                                                              lattice_fine_structure)
+        coarsened_lattice.set_values(grad_lattice_values.contiguous())
         ctx.coarsened_lattice = 0
         ctx.lattice_fine_structure = 0
-        return grad_lattice.values(), None, grad_filter, None
+        return grad_values, None, grad_filter, None
 
 
 class FinefyLattice(Function):  # lattice_funcs.py:401-462
@@ -220,16 +218,13 @@ class FinefyLattice(Function):  # lattice_funcs.py:401-462
         nr_filters, dilation, val_dim = ctx.nr_filters, ctx.dilation, ctx.val_dim
         filter_bank, lattice_coarse_values = ctx.saved_tensors
         filter_extent = int(filter_bank.shape[0] / val_dim)
-        grad_lattice_values = grad_lattice_values.contiguous()
         lattice_coarse_structure.set_values(lattice_coarse_values)
-        grad_filter = lattice_fine_structure.convolve_im2row_grad_filter(grad_lattice_values, dilation, lattice_coarse_structure,
-                                                                         filter_extent)
-        lattice_fine_structure.set_values(grad_lattice_values)
-        grad_lattice = lattice_coarse_structure.convolve_im2row_standalone(filter_bank, dilation, lattice_fine_structure, True,
-                                                                           filter_is_transposed=True)
+        grad_values, grad_filter = lattice_fine_structure.convolve_im2row_backward(grad_lattice_values, filter_bank, dilation,
+                                                                                   lattice_fine_structure, lattice_coarse_structure)
+        lattice_fine_structure.set_values(grad_lattice_values.contiguous())
         ctx.lattice_coarse_structure = 0
         ctx.lattice_fine_structure = 0
-        return grad_lattice.values(), None, None, grad_filter
+        return grad_values, None, None, grad_filter
 
 
 class SliceLattice(Function):  # lattice_funcs.py:467-516
