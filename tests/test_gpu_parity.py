@@ -413,3 +413,96 @@ def test_full_size_c3_scan_against_oracle():
     _, i2, w2 = lat.slice_standalone_no_precomputation(pos)
     np.testing.assert_array_equal(N(i2), oidx)  # slicing at the splat positions finds the splat vertices
     np.testing.assert_array_equal(N(w2), ow)
+
+
+@pytest.mark.parametrize("d", [1, 2, 4, 5, 6])
+def test_other_position_dimensions_against_oracle(d):
+    """pos_dim is a template parameter of the reference kernels (any d); the goldens cover d = 2, 3, the generic
+    oracle covers the rest."""
+    rng = np.random.default_rng(100 + d)
+    n = 1500
+    pos_np = rng.uniform(-1, 1, (n, d)).astype(np.float32)
+    sigma = 0.5 if d >= 4 else 0.1
+    cap = 60000
+    lat = make_lattice(sigma, cap, d=d)
+    lat.begin_splat()
+    vals_np = rng.standard_normal((n, 3)).astype(np.float32)
+    idx, w = lat.splat_standalone(T(pos_np), T(vals_np))
+    m = lat.nr_lattice_vertices()
+    t, _, oidx, ow = oracle_build(pos_np, sigma, cap)
+    assert m == t.nr_filled
+    np.testing.assert_array_equal(N(idx), oidx)
+    np.testing.assert_array_equal(N(w), ow)
+    np.testing.assert_array_equal(N(lat.hash_table().m_keys_tensor[:m]), t.keys[:m])
+    E = 2 * (d + 1) + 1
+    assert lat.get_filter_extent(1) == E
+    lat.set_values(lat.values()[:m].contiguous())
+    for flip in (False, True):
+        np.testing.assert_array_equal(N(lat.neighbours(lat, 1, flip)), O.neighbour_rows(t.keys[:m], t, 1, 1, 1, flip))
+    coarse = lat.create_coarse_verts_naive(T(pos_np))
+    tc, _, _, _ = oracle_build(pos_np, 2 * sigma, cap, write=False)
+    mc = coarse.nr_lattice_vertices()
+    assert mc == tc.nr_filled
+    coarse.set_values(torch.zeros((mc, 3), device=dev()))
+    np.testing.assert_array_equal(N(coarse.neighbours(lat, 1, False)), O.neighbour_rows(tc.keys[:mc], t, 2, 1, 1, False))
+    np.testing.assert_array_equal(N(lat.neighbours(coarse, 1, False)), O.neighbour_rows(t.keys[:m], tc, 1, 2, 1, False))
+    # generic-shape convolution through the C ABI for this filter extent
+    W = (rng.standard_normal((E * 3, 5)) / 4).astype(np.float32)
+    conv = lat.convolve_im2row_standalone(T(W), 1, lat, False)
+    ov = np.zeros((m, 3), np.float32)
+    O.splat_accumulate(ov, vals_np, oidx, ow)
+    rows = O.im2row(O.neighbour_rows(t.keys[:m], t, 1, 1, 1, False), N(lat.values())).astype(np.float64)
+    ref = rows @ W.astype(np.float64)
+    close(N(conv.values()), ref, scale=float(np.max(np.abs(rows) @ np.abs(W.astype(np.float64)))))
+
+
+def test_build_is_deterministic_across_runs():
+    """Canonical numbering: repeated builds of the same cloud give bit-identical indices, keys and neighbour lists
+    (the reference's CUDA build numbers vertices by thread arrival order and differs run to run)."""
+    from lattice_net_amd.synthetic import lidar_cloud
+    pos = T(lidar_cloud(60000, 5))
+    ref = None
+    for _ in range(8):
+        lat = make_lattice(0.9, 100000)
+        lat.begin_splat()
+        idx, w = lat.just_create_verts(pos, True)
+        m = lat.nr_lattice_vertices()
+        lat.set_values(torch.zeros((m, 1), device=dev()))
+        cur = (N(idx), N(w), N(lat.hash_table().m_keys_tensor[:m]), N(lat.neighbours(lat, 1, False)))
+        if ref is None:
+            ref = cur
+        else:
+            for a, b in zip(ref, cur):
+                np.testing.assert_array_equal(a, b)
+
+
+def test_c5_aggregated_scans_size():
+    """C5-sized input: 4 aggregated LiDAR-like scans (480k points), capacity 400000, V = 64 (fp32 here)."""
+    from lattice_net_amd.synthetic import lidar_cloud
+    parts = [lidar_cloud(120000, s) + np.array([3.0 * s, -2.0 * s, 0.0], np.float32) for s in range(4)]
+    pos_np = np.ascontiguousarray(np.concatenate(parts, 0))
+    lat = make_lattice(0.9, 400000)
+    lat.begin_splat()
+    vals = torch.randn((pos_np.shape[0], 64), device=dev())
+    idx, w = lat.splat_standalone(T(pos_np), vals)
+    m = lat.nr_lattice_vertices()
+    t, _, oidx, ow = oracle_build(pos_np, 0.9, 400000)
+    assert m == t.nr_filled
+    np.testing.assert_array_equal(N(idx), oidx)
+    np.testing.assert_array_equal(N(w), ow)
+    lat.set_values(lat.values()[:m].contiguous())
+    W = torch.randn((9 * 64, 64), device=dev()) / 24
+    conv = lat.convolve_im2row_standalone(W, 1, lat, False)
+    nbr = O.neighbour_rows(t.keys[:m], t, 1, 1, 1, False)
+    np.testing.assert_array_equal(N(lat.neighbours(lat, 1, False)), nbr)
+    # spot-check 2000 output rows of the 64x64 convolution in fp64
+    rng = np.random.default_rng(0)
+    pick = rng.choice(m, 2000, replace=False)
+    lv = N(lat.values()).astype(np.float64)
+    rows = np.zeros((2000, 9, 64))
+    for e in range(9):
+        ok = nbr[pick, e] >= 0
+        rows[ok, e] = lv[nbr[pick[ok], e]]
+    ref = rows.reshape(2000, -1) @ N(W).astype(np.float64)
+    scale = float(np.max(np.abs(rows.reshape(2000, -1)) @ np.abs(N(W).astype(np.float64))))
+    close(N(conv.values())[pick], ref, scale=scale)
