@@ -100,9 +100,14 @@ size_t ln_build_workspace_bytes(long long tokens, int capacity);
  * `csr` (required; groups = hash slots, groups_upper = capacity, sized with ln_csr_max_segments)
  * receives the slot -> tokens adjacency of this build: the build needs it to find each vertex's
  * first occurrence, and the caller reuses it for every scatter onto the vertices
- * (ln_csr_reduce_rows with grp_row = t->entries). */
+ * (ln_csr_reduce_rows with grp_row = t->entries).
+ * write_idx flags: bit 0 = write idx / w; bit 1 (LN_BUILD_CLEAR_FIRST) = run ln_table_clear(t, clear_values,
+ * clear_values_elems) first, in the same call (begin_splat + splat in one host round trip). */
+#define LN_BUILD_WRITE_IDX 1
+#define LN_BUILD_CLEAR_FIRST 2
 int ln_build_splat(const LnTable* t, const float* positions_raw, const float* sigmas_host, int n, int* idx, float* w,
-                   int write_idx, const LnCsr* csr, void* workspace, size_t workspace_bytes, void* stream);
+                   int write_idx, const LnCsr* csr, void* workspace, size_t workspace_bytes, float* clear_values,
+                   long long clear_values_elems, void* stream);
 
 /* splatCacheNaive (LatticeGPU.cuh:926-973): table_values[idx] += vals * w. */
 int ln_splat_accumulate(float* table_values, const float* vals, const int* idx, const float* w, int n, int pos_dim,

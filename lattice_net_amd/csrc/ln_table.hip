@@ -515,8 +515,13 @@ static int ln_build_points(const LnTable* t, const float* positions_raw, const f
 }
 
 extern "C" int ln_build_splat(const LnTable* t, const float* positions_raw, const float* sigmas_host, int n, int* idx,
-                              float* w, int write_idx, const LnCsr* csr, void* workspace, size_t workspace_bytes, void* stream) {
-    return ln_build_points(t, positions_raw, sigmas_host, n, idx, w, write_idx, nullptr, 0, nullptr, csr, workspace,
+                              float* w, int write_idx, const LnCsr* csr, void* workspace, size_t workspace_bytes, float* clear_values,
+                              long long clear_values_elems, void* stream) {
+    if (write_idx & LN_BUILD_CLEAR_FIRST) {
+        const int rc = ln_table_clear(t, clear_values, clear_values_elems, stream);
+        if (rc) return rc;
+    }
+    return ln_build_points(t, positions_raw, sigmas_host, n, idx, w, write_idx & LN_BUILD_WRITE_IDX, nullptr, 0, nullptr, csr, workspace,
                            workspace_bytes, stream, "ln_build_splat");
 }
 

@@ -96,17 +96,25 @@ class HashTable:
         self._pos_dim_hint = -1  # dimensions known before any CAP-sized buffer exists
         self._val_dim_hint = 0
 
+    def flush(self):
+        """Issues a deferred begin_splat clear, if any (every reader of table state goes through this)."""
+        if getattr(self, "_clear_pending", False):
+            self.clear()
+
     # -- reference-visible tensors (PyBridge.cxx:35-36) --
     @property
     def m_keys_tensor(self):
+        self.flush()
         return None if self._storage is None else self._storage.keys
 
     @property
     def m_nr_filled_tensor(self):  # PyBridge.cxx:36
+        self.flush()
         return None if self._counters is None else self._counters[0:1]
 
     @property
     def m_entries_tensor(self):
+        self.flush()
         return None if self._storage is None else self._storage.entries
 
     def init(self, pos_dim: int, val_dim: int, device):  # HashTable.cu:21-47
@@ -123,6 +131,8 @@ class HashTable:
         s = self._storage
         if s is None:
             raise _lib.LatticeNetHipError("hash table is not initialised (no splat / create_verts happened yet)")
+        if getattr(self, "_clear_pending", False):
+            self.clear()  # a deferred begin_splat must land before anybody looks at the table
         key = (id(s), self._counters.data_ptr())
         if getattr(self, "_c_table_key", None) == key:
             return self._c_table
@@ -134,9 +144,18 @@ class HashTable:
         return _lib.LnTable(s.capacity, s.pos_dim, s.slot_keys.data_ptr(), s.slot_tok.data_ptr(), s.slot_cnt.data_ptr(), s.entries.data_ptr(),
                             s.keys.data_ptr(), self._counters.data_ptr(), self._counters.data_ptr() + 4)
 
-    def clear(self):  # HashTable.cu:49-57, one launch instead of four fill_ kernels
+    def clear(self, lazy: bool = False):  # HashTable.cu:49-57, one launch instead of four fill_ kernels
+        """`lazy=True` only records that a clear is due: the next build issues it inside its own C call (no host
+        round trip between the two launches); anything else that reads the table flushes it first."""
         if not self.is_initialized():
             return
+        if lazy:
+            self._clear_pending = True
+            self._storage.touch()
+            self.m_nr_filled_is_dirty = True
+            self._readback_pending = False
+            return
+        self._clear_pending = False
         lib = _lib.load()
         v = self.m_values_tensor
         if v is not None and not (v.is_contiguous() and v.data_ptr() % 16 == 0):
@@ -163,13 +182,26 @@ class HashTable:
 
     def read_counters(self):
         """[nr_filled, status]; one blocking wait (on the readback event if a build enqueued one)."""
+        self.flush()
         if getattr(self, "_readback_pending", False):
             self._readback_event.synchronize()
             self._readback_pending = False
             return self._pinned.tolist()
         return self._counters.tolist()
 
+    def take_pending_clear(self):
+        """(values tensor to zero or None, flag) for a build that will issue the deferred clear itself."""
+        if not getattr(self, "_clear_pending", False):
+            return None, False
+        self._clear_pending = False
+        v = self.m_values_tensor
+        if v is not None and not (v.is_contiguous() and v.data_ptr() % 16 == 0):
+            v.zero_()
+            v = None
+        return v, True
+
     def clear_only_values(self):  # HashTable.cu:59-64
+        self.flush()
         if self.is_initialized() and self.m_values_tensor is not None:
             self.m_values_tensor.zero_()
 
@@ -183,6 +215,7 @@ class HashTable:
         return self._storage.capacity if self._storage is not None else self.m_capacity
 
     def set_values(self, new_values: torch.Tensor):  # HashTable.cu:112-115
+        self.flush()  # a deferred clear must hit the OLD values tensor, not the one being installed
         self.m_values_tensor = new_values.contiguous()
 
 
@@ -267,6 +300,7 @@ class Lattice:
         new.m_positions = other.m_positions
         ht = HashTable(other.m_hash_table.capacity())
         oh = other.m_hash_table
+        oh.flush()
         ht._storage = oh._storage
         ht.m_values_tensor = oh.m_values_tensor
         # The reference deep-copies the 1-element counter (Lattice.cu:93) and leaves the clone dirty
@@ -363,12 +397,16 @@ class Lattice:
         cap = ht.capacity()
         ws = self._workspace(_build_sizes(tokens, cap)[0])
         csr_buf, csr, max_seg = self._alloc_csr(tokens, cap)
-        t = ht.c_table()
         if distributed is None:
-            rc = lib.ln_build_splat(C.byref(t), _lib.ptr(positions_raw), self._sigmas_host(), n, _lib.ptr(idx), _lib.ptr(w),
-                                    1 if write else 0, C.byref(csr), _lib.ptr(ws), ws.numel(), self._stream())
+            clear_vals, do_clear = ht.take_pending_clear()  # begin_splat's clear rides in the same C call
+            t = ht.c_table()
+            flags = (1 if write else 0) | (2 if do_clear else 0)
+            rc = lib.ln_build_splat(C.byref(t), _lib.ptr(positions_raw), self._sigmas_host(), n, _lib.ptr(idx), _lib.ptr(w), flags,
+                                    C.byref(csr), _lib.ptr(ws), ws.numel(), _lib.ptr(clear_vals),
+                                    0 if clear_vals is None else clear_vals.numel(), self._stream())
             _lib.check(rc, "ln_build_splat")
         else:
+            t = ht.c_table()
             rc = lib.ln_distribute(C.byref(t), _lib.ptr(positions_raw), self._sigmas_host(), _lib.ptr(vals), n, vals.shape[1],
                                    _lib.ptr(idx), _lib.ptr(w), _lib.ptr(distributed), C.byref(csr), _lib.ptr(ws), ws.numel(),
                                    self._stream())
@@ -443,7 +481,7 @@ class Lattice:
     # ---------------------------------------------------------------- splat family
     def begin_splat(self, reset_hashmap: bool = True):  # Lattice.cu:185-193
         if reset_hashmap:
-            self.m_hash_table.clear()
+            self.m_hash_table.clear(lazy=True)
         else:
             self.m_hash_table.clear_only_values()
         self.m_hash_table.m_nr_filled_is_dirty = True
@@ -936,6 +974,7 @@ class Lattice:
         return self.m_hash_table
 
     def values(self) -> torch.Tensor:
+        self.m_hash_table.flush()
         return self.m_hash_table.m_values_tensor
 
     def set_values(self, new_values: torch.Tensor):  # Lattice.cu:1394-1399

@@ -20,6 +20,7 @@ vals = torch.from_numpy(rng.standard_normal((n, v)).astype(np.float32)).to(dev)
 G = torch.from_numpy(rng.standard_normal((n, f)).astype(np.float32)).to(dev)
 W = (torch.rand((9 * v, f), device=dev) - 0.5).requires_grad_(True)
 lat = L.Lattice(sigmas=[0.9] * 3, capacity=100000, device=dev)
+torch.autograd.set_multithreading_enabled(False)
 
 
 def step():
@@ -42,4 +43,4 @@ for _ in range(200):
 torch.cuda.synchronize()
 pr.disable()
 st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(28)
+st.sort_stats("tottime").print_stats(32)
