@@ -491,12 +491,22 @@ class Lattice:
         n, d = positions_raw.shape
         v = values.shape[1]
         self.m_positions = positions_raw
-        if not self.m_hash_table.is_initialized():
-            self.m_hash_table.init(d, v, self._dev(positions_raw))
+        ht = self.m_hash_table
+        if not ht.is_initialized():
+            ht.init(d, v, self._dev(positions_raw))
+        tv = ht.m_values_tensor
+        cap = ht.capacity()
+        if tv is None or tuple(tv.shape) != (cap, v) or tv.requires_grad or tv._base is not None or not tv.is_contiguous():
+            # The table must own a plain [capacity, V] accumulator (HashTable.cu:32).  Python code re-points the
+            # values of this object between ops (set_values in every Function); the reference would then splat into
+            # whatever tensor was left there (out of bounds if it is shorter, Lattice.cu:230).  Install a fresh one.
+            pending = getattr(ht, "_clear_pending", False)
+            ht._clear_pending = False
+            ht.m_values_tensor = torch.empty((cap, v), dtype=torch.float32, device=self._dev(positions_raw)) if pending else \
+                torch.zeros((cap, v), dtype=torch.float32, device=self._dev(positions_raw))
+            ht._clear_pending = pending  # a deferred begin_splat clear zeroes the new accumulator inside the build call
         idx, w = self._build(positions_raw, True)
-        tv = self.m_hash_table.m_values_tensor
-        if tv.shape[1] != v:
-            raise ValueError(f"table values have val_dim {tv.shape[1]} but {v} were splatted")
+        tv = ht.m_values_tensor
         # splatCacheNaive (LatticeGPU.cuh:926-973) as a token-balanced reduce; begin_splat zeroed the table values
         self._scatter_rows(values, idx, w, tv, v, d + 1, v)
         self._prefetch_neighbours(n * (d + 1))

@@ -155,7 +155,6 @@ class ConvIm2RowLattice(Function):  # lattice_funcs.py:250-320
         # funcs:298-313: grad_filter = im2row^T @ grad, grad_values = conv(grad, flipped neighbours, re-laid-out bank);
         # both run as gather-GEMMs
         grad_values, grad_filter = lattice.convolve_im2row_backward(grad_lattice_values, filter_bank, dilation, lattice, lattice)
-        lattice.set_values(grad_values)  # the reference leaves the gradient in the lattice (funcs:312-313)
         ctx.lattice = 0
         return grad_values, None, grad_filter, None
 
@@ -190,7 +189,6 @@ class CoarsenLattice(Function):  # lattice_funcs.py:323-398
         # the fine vertices with the coarse ones (which carry the errors) as neighbours
         grad_values, grad_filter = coarsened_lattice.convolve_im2row_backward(grad_lattice_values, filter_bank, dilation, coarsened_lattice,
                                                                               lattice_fine_structure)
-        coarsened_lattice.set_values(grad_lattice_values.contiguous())
         ctx.coarsened_lattice = 0
         ctx.lattice_fine_structure = 0
         return grad_values, None, grad_filter, None
@@ -221,7 +219,6 @@ class FinefyLattice(Function):  # lattice_funcs.py:401-462
         lattice_coarse_structure.set_values(lattice_coarse_values)
         grad_values, grad_filter = lattice_fine_structure.convolve_im2row_backward(grad_lattice_values, filter_bank, dilation,
                                                                                    lattice_fine_structure, lattice_coarse_structure)
-        lattice_fine_structure.set_values(grad_lattice_values.contiguous())
         ctx.lattice_coarse_structure = 0
         ctx.lattice_fine_structure = 0
         return grad_values, None, None, grad_filter
