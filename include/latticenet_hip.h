@@ -36,6 +36,8 @@ extern "C" {
 /* bits of *LnTable.status (device int32) */
 #define LN_STATUS_TABLE_FULL 1      /* insert probed every slot (reference would spin forever, HashTableGPU.cuh:443) */
 #define LN_STATUS_KEY_RANGE 2       /* a lattice key did not fit the packed 64-bit slot format */
+#define LN_STATUS_BUCKET_OVERFLOW 4 /* bucketed build: one LDS-staged bucket filled up; nothing of this build is valid,
+                                       re-run it with LN_BUILD_ATOMIC_PATH (whose inserts spill past a full bucket) */
 
 #define LN_MAX_POS_DIM 6
 #define LN_NOT_VISITED (-2)          /* neighbour-list code: traversal never looks at this slot */
@@ -93,20 +95,26 @@ size_t ln_build_workspace_bytes(long long tokens, int capacity);
 
 /* kernel_splat (LatticeGPU.cuh:707-842) behind Lattice::splat_standalone / just_create_verts
  * (src/Lattice.cu:196-290), with `positions_raw / sigmas` (Lattice.cu:226) fused in.
- * Inserts the d+1 simplex vertices of every point; when write_idx != 0 writes
+ * Inserts the d+1 simplex vertices of every point; when flags has LN_BUILD_WRITE_IDX writes
  * idx[n*(d+1)] (row ids) and w[n*(d+1)] (barycentric weights).  Both must be pre-sized; rows
  * that cannot be inserted keep -1 (Lattice.cu:212-215 semantics are produced here, no pre-fill
- * needed).  idx/w may be NULL when write_idx == 0.
+ * needed).  idx/w may be NULL without that flag.
  * `csr` (required; groups = hash slots, groups_upper = capacity, sized with ln_csr_max_segments)
  * receives the slot -> tokens adjacency of this build: the build needs it to find each vertex's
  * first occurrence, and the caller reuses it for every scatter onto the vertices
  * (ln_csr_reduce_rows with grp_row = t->entries).
- * write_idx flags: bit 0 = write idx / w; bit 1 (LN_BUILD_CLEAR_FIRST) = run ln_table_clear(t, clear_values,
- * clear_values_elems) first, in the same call (begin_splat + splat in one host round trip). */
+ * flags: LN_BUILD_WRITE_IDX = write idx / w; LN_BUILD_CLEAR_FIRST = run ln_table_clear(t, clear_values,
+ * clear_values_elems) first, in the same call (begin_splat + splat in one host round trip).
+ * Two build paths produce the same table, rows, idx and CSR semantics:
+ *   bucketed (taken when LN_BUILD_CLEAR_FIRST is set and LN_BUILD_ATOMIC_PATH is not): tokens are partitioned by
+ *     hash bucket and each bucket is resolved by one workgroup in LDS, no per-token global atomics.  A bucket
+ *     of ~512 slots that fills up (tables loaded beyond ~0.85) sets LN_STATUS_BUCKET_OVERFLOW.
+ *   atomic (any table state, any load < 1): one 64-bit CAS per new vertex + one returning add per token. */
 #define LN_BUILD_WRITE_IDX 1
 #define LN_BUILD_CLEAR_FIRST 2
+#define LN_BUILD_ATOMIC_PATH 4
 int ln_build_splat(const LnTable* t, const float* positions_raw, const float* sigmas_host, int n, int* idx, float* w,
-                   int write_idx, const LnCsr* csr, void* workspace, size_t workspace_bytes, float* clear_values,
+                   int flags, const LnCsr* csr, void* workspace, size_t workspace_bytes, float* clear_values,
                    long long clear_values_elems, void* stream);
 
 /* splatCacheNaive (LatticeGPU.cuh:926-973): table_values[idx] += vals * w. */
@@ -140,10 +148,11 @@ int ln_csr_segment_max(const LnCsr* csr, const int* grp_row, long long max_segme
 int ln_csr_group_sizes(const LnCsr* csr, const int* grp_row, int groups_upper, int rows, int* counts, void* stream);
 
 /* distribute kernel (LatticeGPU.cuh:534-650) behind Lattice::distribute (Lattice.cu:351-410):
- * ln_build_splat + the dense rows [pos_scaled(d) | val(V) | bary] -> distributed[n*(d+1), d+V+1]. */
+ * ln_build_splat + the dense rows [pos_scaled(d) | val(V) | bary] -> distributed[n*(d+1), d+V+1].
+ * flags: LN_BUILD_CLEAR_FIRST / LN_BUILD_ATOMIC_PATH as for ln_build_splat (idx / w are always written). */
 int ln_distribute(const LnTable* t, const float* positions_raw, const float* sigmas_host, const float* vals, int n,
-                  int val_dim, int* idx, float* w, float* distributed, const LnCsr* csr, void* workspace,
-                  size_t workspace_bytes, void* stream);
+                  int val_dim, int* idx, float* w, float* distributed, int flags, const LnCsr* csr, void* workspace,
+                  size_t workspace_bytes, float* clear_values, long long clear_values_elems, void* stream);
 
 /* coarsen kernel (LatticeGPU.cuh:2314-2514) behind Lattice::create_coarse_verts (Lattice.cu:670-703).
  * fine_rows_upper bounds the launch; the kernel also honours *fine->nr_filled. */

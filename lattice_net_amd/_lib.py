@@ -14,6 +14,10 @@ LIB_PATH = os.path.join(_PKG, "liblatticenet_hip.so")
 
 LN_STATUS_TABLE_FULL = 1
 LN_STATUS_KEY_RANGE = 2
+LN_STATUS_BUCKET_OVERFLOW = 4
+LN_BUILD_WRITE_IDX = 1
+LN_BUILD_CLEAR_FIRST = 2
+LN_BUILD_ATOMIC_PATH = 4
 LN_NOT_VISITED = -2
 LN_CONV_FLIP_NEIGHBOURS = 1
 LN_CONV_TRANSPOSED_FILTER = 2
@@ -74,7 +78,7 @@ SIGNATURES = {
     "ln_csr_reduce_rows": (_i, [_CSR, _vp, _ll, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "ln_csr_segment_max": (_i, [_CSR, _vp, _ll, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "ln_csr_group_sizes": (_i, [_CSR, _vp, _i, _i, _vp, _vp]),
-    "ln_distribute": (_i, [_T, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _CSR, _vp, _sz, _vp]),
+    "ln_distribute": (_i, [_T, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _CSR, _vp, _sz, _vp, _ll, _vp]),
     "ln_coarsen": (_i, [_T, _i, _T, _CSR, _vp, _sz, _vp]),
     "ln_neighbours": (_i, [_T, _i, _T, _i, _i, _i, _i, _vp, _vp]),
     "ln_im2row": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),

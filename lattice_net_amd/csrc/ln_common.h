@@ -87,6 +87,46 @@ LN_HD uint32_t ln_hash(const int* key) {
     return k;
 }
 
+// ---- probe sequence ----------------------------------------------------------------------
+// The table is cut into buckets of ln_bucket_slots(capacity) consecutive slots (the unit one
+// workgroup stages in LDS during a build).  A key whose hash lands in bucket [lo, lo+size) probes
+// that bucket first (linear, wrapping inside the bucket) and only when the bucket holds no empty
+// slot continues linearly through the rest of the table:  probe i -> lo + (off+i) % size for
+// i < size, (lo + i) % capacity afterwards.  Every slot is visited exactly once in `capacity`
+// probes, as with the reference's plain linear probing (HashTableGPU.cuh:479-482).
+#define LN_BKT_SLOTS 512
+#define LN_BKT_MAX 2048
+LN_HD int ln_bucket_slots(int capacity) {
+    int nb = (capacity + LN_BKT_SLOTS - 1) / LN_BKT_SLOTS;
+    if (nb > LN_BKT_MAX) nb = LN_BKT_MAX;
+    if (nb < 1) nb = 1;
+    return (capacity + nb - 1) / nb;
+}
+LN_HD int ln_bucket_count(int capacity) {
+    const int sb = ln_bucket_slots(capacity);
+    return (capacity + sb - 1) / sb;
+}
+struct LnProbe {
+    int lo, size, off, cap;
+    LN_HD LnProbe(uint32_t hash, int capacity, int sb) {
+        const int h0 = int(hash % uint32_t(capacity));
+        cap = capacity;
+        lo = (h0 / sb) * sb;
+        size = (capacity - lo < sb) ? (capacity - lo) : sb;
+        off = h0 - lo;
+    }
+    LN_HD int slot(int i) const {
+        if (i < size) {
+            int o = off + i;
+            if (o >= size) o -= size;
+            return lo + o;
+        }
+        int s = lo + i;
+        if (s >= cap) s -= cap;
+        return s;
+    }
+};
+
 #if defined(__HIPCC__)
 // HashTableGPU::retrieve (HashTableGPU.cuh:491-519) on packed slots: stop at an empty slot or
 // after 300 mismatching probes.
@@ -94,13 +134,13 @@ template <int D>
 __device__ __forceinline__ int ln_retrieve(const LnTable& t, const int* key) {
     if (!KeyPack<D>::in_range(key)) return -1;  // cannot have been inserted
     const uint64_t pk = KeyPack<D>::pack(key);
-    int h = int(ln_hash<D>(key) % uint32_t(t.capacity));
-    for (int conflicts = 0; conflicts < LN_MAX_RETRIEVE_CONFLICTS; ++conflicts) {
+    const LnProbe pr(ln_hash<D>(key), t.capacity, ln_bucket_slots(t.capacity));
+    const int limit = t.capacity < LN_MAX_RETRIEVE_CONFLICTS ? t.capacity : LN_MAX_RETRIEVE_CONFLICTS;
+    for (int conflicts = 0; conflicts < limit; ++conflicts) {
+        const int h = pr.slot(conflicts);
         const uint64_t cur = t.slot_keys[h];
         if (cur == LN_EMPTY_KEY) return -1;
         if (cur == pk) return t.entries[h];
-        ++h;
-        if (h >= t.capacity) h = 0;
     }
     return -1;
 }

@@ -72,7 +72,7 @@ LnProfScope::~LnProfScope() {
     }
 }
 
-extern "C" const char* ln_kernel_names(void) { return "k_conv_generic,k_conv_mfma,k_csr_count,k_csr_fill,k_csr_group_sizes,k_csr_reduce_segments,k_csr_scan_local,k_csr_segment_max,k_csr_segment_max_decode,k_finalize,k_gather_backward,k_gather_forward,k_grad_filter_generic,k_grad_filter_mfma,k_im2row,k_im2rowindices,k_insert_coarse,k_insert_points,k_mark_first,k_neighbours,k_reduce_slabs,k_retrieve_points,k_row2im,k_scan_blocks,k_scatter_point_rows,k_seg_min,k_slice_classify_backward,k_slice_classify_forward,k_slice_forward,k_table_clear"; }
+extern "C" const char* ln_kernel_names(void) { return "k_bucket_build,k_bucket_scan,k_bucket_scatter,k_conv_generic,k_conv_mfma,k_csr_count,k_csr_fill,k_csr_group_sizes,k_csr_reduce_segments,k_csr_scan_local,k_csr_segment_max,k_csr_segment_max_decode,k_finalize,k_gather_backward,k_gather_forward,k_grad_filter_generic,k_grad_filter_mfma,k_im2row,k_im2rowindices,k_insert_coarse,k_insert_points,k_mark_first,k_neighbours,k_point_keys,k_reduce_slabs,k_retrieve_points,k_row2im,k_scan_blocks,k_scatter_point_rows,k_seg_min,k_slice_classify_backward,k_slice_classify_forward,k_slice_forward,k_table_clear"; }
 
 extern "C" int ln_profile_begin(const char* kernel_name, int max_samples) {
     LN_REQUIRE(kernel_name && strlen(kernel_name) < sizeof(g_prof.name) && max_samples > 0, LN_ERR_ARG, "ln_profile_begin: bad args");
@@ -145,9 +145,10 @@ static int ln_check_table(const LnTable* t, const char* who) {
 // ------------------------------------------------------------------------------------------
 // clear
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_table_clear(LnTable t, float* values, long long values_elems) {
+__global__ void __launch_bounds__(256) k_table_clear(LnTable t, float* values, long long values_elems, int* zero_ints, int zero_count) {
     const long long stride = (long long)gridDim.x * blockDim.x;
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (long long i = g; i < zero_count; i += stride) zero_ints[i] = 0;
     for (long long i = g; i < t.capacity; i += stride) {
         t.slot_keys[i] = LN_EMPTY_KEY;
         t.slot_tok[i] = LN_EMPTY_TOK;
@@ -168,7 +169,7 @@ __global__ void __launch_bounds__(256) k_table_clear(LnTable t, float* values, l
     }
 }
 
-extern "C" int ln_table_clear(const LnTable* t, float* values, long long values_elems, void* stream) {
+static int ln_table_clear_impl(const LnTable* t, float* values, long long values_elems, int* zero_ints, int zero_count, void* stream) {
     int rc = ln_check_table(t, "ln_table_clear");
     if (rc) return rc;
     LN_REQUIRE(values == nullptr || (reinterpret_cast<uintptr_t>(values) & 15) == 0, LN_ERR_ARG,
@@ -178,8 +179,13 @@ extern "C" int ln_table_clear(const LnTable* t, float* values, long long values_
     int blocks = ln_div_up(work, 256);
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
-    LN_LAUNCH("k_table_clear", k_table_clear, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *t, values, values_elems);
+    LN_LAUNCH("k_table_clear", k_table_clear, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *t, values, values_elems, zero_ints,
+              zero_count);
     return ln_check_launch("ln_table_clear");
+}
+
+extern "C" int ln_table_clear(const LnTable* t, float* values, long long values_elems, void* stream) {
+    return ln_table_clear_impl(t, values, values_elems, nullptr, 0, stream);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -196,8 +202,9 @@ __device__ __forceinline__ int ln_insert(const LnTable& t, const int* key, int& 
         return -1;
     }
     const uint64_t pk = KeyPack<D>::pack(key);
-    int h = int(ln_hash<D>(key) % uint32_t(t.capacity));
+    const LnProbe pr(ln_hash<D>(key), t.capacity, ln_bucket_slots(t.capacity));
     for (int probes = 0; probes < t.capacity; ++probes) {
+        const int h = pr.slot(probes);
         // Plain (cacheable) pre-check: a slot only ever changes EMPTY -> key, so a stale read can only
         // show EMPTY, in which case the CAS below decides.  Duplicates of an already-inserted key are
         // then served by L1/L2 instead of each costing a memory-side atomic.
@@ -210,8 +217,6 @@ __device__ __forceinline__ int ln_insert(const LnTable& t, const int* key, int& 
             pos = atomicAdd(&t.slot_cnt[h], 1);
             return h;
         }
-        ++h;  // linear probing, HashTableGPU.cuh:479-482
-        if (h >= t.capacity) h = 0;
     }
     atomicOr(t.status, LN_STATUS_TABLE_FULL);
     return -1;
@@ -252,6 +257,278 @@ __global__ void __launch_bounds__(256)
         for (int i = 0; i < D; ++i) o[i] = pr[i] / sc.sigma[i];
         for (int j = 0; j < val_dim; ++j) o[D + j] = vals[(size_t)p * val_dim + j];
         o[D + val_dim] = b;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Bucketed build of a freshly cleared table (the splat / distribute hot path)
+// ------------------------------------------------------------------------------------------
+// Memory-side atomics are the scarce resource on this part (every device-scope atomic executes at
+// the memory controller), and the insert above spends one returning atomic per TOKEN.  Here the
+// tokens are first partitioned by the bucket their hash lands in (two LDS-histogram passes; one
+// global atomic per (block, bucket) instead of one per token); then ONE workgroup per bucket stages
+// the bucket's slots in LDS and resolves everything there — claim (64-bit LDS CAS), per-slot token
+// count and position (LDS add), smallest token (LDS min) — and emits the slot range, the slot CSR
+// and its segments directly.  A bucket that fills up raises LN_STATUS_BUCKET_OVERFLOW: the caller
+// re-runs the build with LN_BUILD_ATOMIC_PATH, whose inserts spill past the bucket.
+
+// Pass 1: thread per point -> the d+1 packed keys, weights, (distribute rows) + bucket histogram.
+#define LN_KEYS_PTS_PER_BLOCK 512
+template <int D>
+__global__ void __launch_bounds__(256)
+    k_point_keys(LnTable t, const float* __restrict__ pos_raw, LnScale<D> sc, int n, int sb, int nbk,
+                 unsigned long long* __restrict__ tok_pk, float* __restrict__ w, int* __restrict__ hist, const float* __restrict__ vals,
+                 int val_dim, float* __restrict__ distributed) {
+    __shared__ int s_hist[LN_BKT_MAX];
+    for (int b = threadIdx.x; b < nbk; b += 256) s_hist[b] = 0;
+    __syncthreads();
+    for (int it = 0; it < LN_KEYS_PTS_PER_BLOCK / 256; ++it) {
+        const int p = blockIdx.x * LN_KEYS_PTS_PER_BLOCK + it * 256 + threadIdx.x;
+        if (p >= n) break;
+        float pr[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) pr[i] = pos_raw[(size_t)p * D + i];
+        LnSimplex<D> s;
+        ln_simplex<D>(pr, sc, s);
+#pragma unroll
+        for (int r = 0; r <= D; ++r) {
+            int key[D];
+            ln_vertex_key<D>(s, r, key);
+            const size_t tk = (size_t)p * (D + 1) + r;
+            unsigned long long pk = LN_EMPTY_KEY;
+            if (KeyPack<D>::in_range(key)) {
+                pk = KeyPack<D>::pack(key);
+                const int h0 = int(ln_hash<D>(key) % uint32_t(t.capacity));
+                atomicAdd(&s_hist[h0 / sb], 1);
+            } else {
+                atomicOr(t.status, LN_STATUS_KEY_RANGE);
+            }
+            tok_pk[tk] = pk;
+            if (w) w[tk] = pk != LN_EMPTY_KEY ? s.bary[r] : -1.0f;
+            if (distributed) {  // LatticeGPU.cuh:626-637: [pos_scaled(d) | val(V) | bary[r]] per simplex vertex
+                const int row_len = D + val_dim + 1;
+                float* o = distributed + tk * row_len;
+#pragma unroll
+                for (int i = 0; i < D; ++i) o[i] = pr[i] / sc.sigma[i];
+                for (int j = 0; j < val_dim; ++j) o[D + j] = vals[(size_t)p * val_dim + j];
+                o[D + val_dim] = s.bary[r];
+            }
+        }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < nbk; b += 256) {
+        const int c = s_hist[b];
+        if (c) atomicAdd(&hist[b], c);
+    }
+}
+
+// Pass 2 (one workgroup): bucket_start = exclusive scan of the histogram; resets the cursors and the
+// segment counter of the CSR.
+__global__ void __launch_bounds__(1024) k_bucket_scan(const int* __restrict__ hist, int nbk, int* __restrict__ bucket_start,
+                                                      int* __restrict__ cursor, int* __restrict__ seg_count) {
+    __shared__ int s_wave[16];
+    __shared__ int s_running;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    if (tid == 0) {
+        s_running = 0;
+        *seg_count = 0;
+    }
+    __syncthreads();
+    for (int start = 0; start < nbk; start += 1024) {
+        const int i = start + tid;
+        const int v = (i < nbk) ? hist[i] : 0;
+        int incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        int wave_off = 0;
+        for (int k = 0; k < wave; ++k) wave_off += s_wave[k];
+        const int running = s_running;
+        if (i < nbk) {
+            bucket_start[i] = running + wave_off + incl - v;
+            cursor[i] = 0;
+        }
+        __syncthreads();
+        if (tid == 1023) s_running = running + wave_off + incl;
+        __syncthreads();
+    }
+    if (tid == 0) bucket_start[nbk] = s_running;
+}
+
+// Pass 3: scatter (token, packed key) into bucket-major order.
+#define LN_SCATTER_TOK_PER_THREAD 8
+template <int D>
+__global__ void __launch_bounds__(256)
+    k_bucket_scatter(const unsigned long long* __restrict__ tok_pk, long long tokens, int capacity, int sb, int nbk,
+                     const int* __restrict__ bucket_start, int* __restrict__ cursor, int* __restrict__ part_tok,
+                     unsigned long long* __restrict__ part_pk) {
+    __shared__ int s_cnt[LN_BKT_MAX];
+    for (int b = threadIdx.x; b < nbk; b += 256) s_cnt[b] = 0;
+    __syncthreads();
+    const long long base_tk = (long long)blockIdx.x * (256 * LN_SCATTER_TOK_PER_THREAD);
+    unsigned long long pk[LN_SCATTER_TOK_PER_THREAD];
+    int bkt[LN_SCATTER_TOK_PER_THREAD];
+    int rank[LN_SCATTER_TOK_PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < LN_SCATTER_TOK_PER_THREAD; ++k) {
+        const long long tk = base_tk + k * 256 + threadIdx.x;
+        pk[k] = tk < tokens ? tok_pk[tk] : LN_EMPTY_KEY;
+    }
+#pragma unroll
+    for (int k = 0; k < LN_SCATTER_TOK_PER_THREAD; ++k) {
+        bkt[k] = -1;
+        if (pk[k] != LN_EMPTY_KEY) {
+            int key[D];
+            KeyPack<D>::unpack(pk[k], key);
+            bkt[k] = int(ln_hash<D>(key) % uint32_t(capacity)) / sb;
+            rank[k] = atomicAdd(&s_cnt[bkt[k]], 1);
+        }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < nbk; b += 256) {
+        const int c = s_cnt[b];
+        if (c) s_cnt[b] = bucket_start[b] + atomicAdd(&cursor[b], c);  // one global atomic per (block, bucket)
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < LN_SCATTER_TOK_PER_THREAD; ++k) {
+        if (bkt[k] >= 0) {
+            const int dst = s_cnt[bkt[k]] + rank[k];
+            part_tok[dst] = int(base_tk + k * 256 + threadIdx.x);
+            part_pk[dst] = pk[k];
+        }
+    }
+}
+
+// Pass 4: one workgroup per bucket.  LDS: keys[sb] | count[sb] | min token[sb] | token offset[sb] | segment offset[sb].
+#define LN_BKT_THREADS 1024
+template <int D>
+__global__ void __launch_bounds__(LN_BKT_THREADS)
+    k_bucket_build(LnTable t, int sb, int nbk, const int* __restrict__ bucket_start, const int* __restrict__ part_tok,
+                   const unsigned long long* __restrict__ part_pk, int* __restrict__ part_slot, int* __restrict__ part_pos,
+                   int* __restrict__ tok_slot, LnCsr csr) {
+    extern __shared__ unsigned long long s_mem[];
+    unsigned long long* skeys = s_mem;
+    int* scnt = reinterpret_cast<int*>(skeys + sb);
+    unsigned int* smin = reinterpret_cast<unsigned int*>(scnt + sb);
+    int* soff = reinterpret_cast<int*>(smin + sb);
+    int* sseg = soff + sb;
+    __shared__ int s_wave_tok[16], s_wave_seg[16];
+    __shared__ int s_run_tok, s_run_seg, s_seg_base;
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x;
+    const int lo = b * sb;
+    const int size = min(sb, t.capacity - lo);
+    for (int i = tid; i < size; i += LN_BKT_THREADS) {
+        skeys[i] = LN_EMPTY_KEY;  // the table was cleared by this build call
+        scnt[i] = 0;
+        smin[i] = LN_EMPTY_TOK;
+    }
+    if (tid == 0) {
+        s_run_tok = 0;
+        s_run_seg = 0;
+    }
+    __syncthreads();
+    const int base = bucket_start[b];
+    const int ntok = bucket_start[b + 1] - base;
+    for (int j = tid; j < ntok; j += LN_BKT_THREADS) {
+        const int tk = part_tok[base + j];
+        const unsigned long long pk = part_pk[base + j];
+        int key[D];
+        KeyPack<D>::unpack(pk, key);
+        int o = int(ln_hash<D>(key) % uint32_t(t.capacity)) - lo;
+        int ls = -1;
+        for (int i = 0; i < size; ++i) {
+            unsigned long long cur = skeys[o];
+            if (cur == LN_EMPTY_KEY) {
+                cur = atomicCAS(&skeys[o], (unsigned long long)LN_EMPTY_KEY, pk);
+                if (cur == LN_EMPTY_KEY) cur = pk;
+            }
+            if (cur == pk) {
+                ls = o;
+                break;
+            }
+            if (++o >= size) o = 0;
+        }
+        int pos = -1;
+        if (ls >= 0) {
+            pos = atomicAdd(&scnt[ls], 1);
+            atomicMin(&smin[ls], (unsigned int)tk);
+        } else {
+            atomicOr(t.status, LN_STATUS_BUCKET_OVERFLOW);
+        }
+        tok_slot[tk] = ls >= 0 ? lo + ls : -1;
+        part_slot[base + j] = ls;
+        part_pos[base + j] = pos;
+    }
+    __syncthreads();
+    // exclusive scans of the per-slot token and segment counts
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    for (int start = 0; start < size; start += LN_BKT_THREADS) {
+        const int i = start + tid;
+        const int c = (i < size) ? scnt[i] : 0;
+        const int g = (c + LN_CSR_SEG - 1) / LN_CSR_SEG;
+        int ic = c, ig = g;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int oc = __shfl_up(ic, off, 64);
+            const int og = __shfl_up(ig, off, 64);
+            if (lane >= off) {
+                ic += oc;
+                ig += og;
+            }
+        }
+        if (lane == 63) {
+            s_wave_tok[wave] = ic;
+            s_wave_seg[wave] = ig;
+        }
+        __syncthreads();
+        int wt = 0, wg = 0;
+        for (int k = 0; k < wave; ++k) {
+            wt += s_wave_tok[k];
+            wg += s_wave_seg[k];
+        }
+        const int rt = s_run_tok, rg = s_run_seg;
+        if (i < size) {
+            soff[i] = rt + wt + ic - c;
+            sseg[i] = rg + wg + ig - g;
+        }
+        __syncthreads();
+        if (tid == LN_BKT_THREADS - 1) {
+            s_run_tok = rt + wt + ic;
+            s_run_seg = rg + wg + ig;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) s_seg_base = s_run_seg ? atomicAdd(csr.seg_count, s_run_seg) : 0;
+    __syncthreads();
+    const int seg_base = s_seg_base;
+    const int placed = s_run_tok;
+    for (int i = tid; i < size; i += LN_BKT_THREADS) {
+        const int h = lo + i;
+        const int beg = base + soff[i];
+        csr.grp_start[h] = beg;
+        t.slot_keys[h] = skeys[i];
+        t.slot_tok[h] = smin[i];
+        const int c = scnt[i];
+        int sid = seg_base + sseg[i];
+        for (int e = 0; e < c; e += LN_CSR_SEG, ++sid) {
+            csr.seg_grp[sid] = h;
+            csr.seg_beg[sid] = beg + e;
+        }
+    }
+    if (b == nbk - 1 && tid == 0) csr.grp_start[t.capacity] = bucket_start[nbk];
+    for (int j = tid; j < ntok; j += LN_BKT_THREADS) {
+        const int ls = part_slot[base + j];
+        if (ls >= 0) csr.csr_tok[base + soff[ls] + part_pos[base + j]] = part_tok[base + j];
+        if (j >= placed) csr.csr_tok[base + j] = -1;  // only after an overflow: keeps readers in bounds until the rebuild
     }
 }
 
@@ -435,6 +712,14 @@ struct BuildWs {
     void* csr_ws;
     size_t csr_ws_bytes;
     int nb;
+    // bucketed build
+    unsigned long long* tok_pk;
+    unsigned long long* part_pk;
+    int* part_tok;
+    int* part_slot;
+    int* bkt_hist;   // [LN_BKT_MAX]      zero before k_point_keys
+    int* bkt_start;  // [LN_BKT_MAX + 1]
+    int* bkt_cursor; // [LN_BKT_MAX]
 };
 
 static size_t ln_align256(size_t x) { return (x + 255) & ~size_t(255); }
@@ -443,7 +728,9 @@ extern "C" size_t ln_build_workspace_bytes(long long tokens, int capacity) {
     if (tokens < 1) tokens = 1;
     const size_t nb = (size_t)ln_div_up(tokens, 256);
     return ln_align256(nb * 4 * sizeof(unsigned long long)) + 2 * ln_align256(nb * sizeof(int)) +
-           2 * ln_align256((size_t)tokens * sizeof(int)) + ln_align256(ln_csr_scan_workspace_bytes(capacity));
+           2 * ln_align256((size_t)tokens * sizeof(int)) + ln_align256(ln_csr_scan_workspace_bytes(capacity)) +
+           2 * ln_align256((size_t)tokens * sizeof(unsigned long long)) + 2 * ln_align256((size_t)tokens * sizeof(int)) +
+           3 * ln_align256((LN_BKT_MAX + 1) * sizeof(int));
 }
 
 static int ln_carve_ws(long long tokens, int capacity, void* workspace, size_t bytes, BuildWs& ws) {
@@ -465,8 +752,25 @@ static int ln_carve_ws(long long tokens, int capacity, void* workspace, size_t b
     p += ln_align256((size_t)tokens * sizeof(int));
     ws.csr_ws = p;
     ws.csr_ws_bytes = ln_csr_scan_workspace_bytes(capacity);
+    p += ln_align256(ws.csr_ws_bytes);
+    ws.tok_pk = reinterpret_cast<unsigned long long*>(p);
+    p += ln_align256((size_t)tokens * sizeof(unsigned long long));
+    ws.part_pk = reinterpret_cast<unsigned long long*>(p);
+    p += ln_align256((size_t)tokens * sizeof(unsigned long long));
+    ws.part_tok = reinterpret_cast<int*>(p);
+    p += ln_align256((size_t)tokens * sizeof(int));
+    ws.part_slot = reinterpret_cast<int*>(p);
+    p += ln_align256((size_t)tokens * sizeof(int));
+    ws.bkt_hist = reinterpret_cast<int*>(p);
+    p += ln_align256((LN_BKT_MAX + 1) * sizeof(int));
+    ws.bkt_start = reinterpret_cast<int*>(p);
+    p += ln_align256((LN_BKT_MAX + 1) * sizeof(int));
+    ws.bkt_cursor = reinterpret_cast<int*>(p);
     return LN_OK;
 }
+
+template <int D>
+static int ln_rank_rows(const LnTable& t, const int* tok_slot, int* idx_out, long long tokens, const BuildWs& ws, hipStream_t st);
 
 // After the producer: slot CSR (scan of slot_cnt + fill) -> per-slot smallest token -> canonical rank.
 template <int D>
@@ -477,6 +781,12 @@ static int ln_rank_and_finalize(const LnTable& t, const int* tok_slot, const int
     const long long max_seg = ln_csr_max_segments(tokens, t.capacity);
     LN_LAUNCH("k_seg_min", k_seg_min, dim3(ln_div_up(max_seg, 256)), dim3(256), 0, st, t, csr.grp_start, csr.csr_tok, csr.seg_grp,
               csr.seg_beg, csr.seg_count);
+    return ln_rank_rows<D>(t, tok_slot, idx_out, tokens, ws, st);
+}
+
+// slot_tok (smallest token per slot) -> canonical row numbers
+template <int D>
+static int ln_rank_rows(const LnTable& t, const int* tok_slot, int* idx_out, long long tokens, const BuildWs& ws, hipStream_t st) {
     LN_LAUNCH("k_mark_first", k_mark_first, dim3(ws.nb), dim3(256), 0, st, t, tok_slot, tokens, ws.bitmap, ws.block_cnt);
     LN_LAUNCH("k_scan_blocks", k_scan_blocks, dim3(1), dim3(1024), 0, st, ws.block_cnt, ws.nb, ws.block_prefix, t.nr_filled);
     LN_LAUNCH("k_finalize", k_finalize<D>, dim3(ws.nb), dim3(256), 0, st, t, tok_slot, idx_out, tokens, ws.bitmap, ws.block_prefix);
@@ -489,49 +799,68 @@ static int ln_check_csr(const LnCsr* c, const char* who) {
 }
 
 static int ln_build_points(const LnTable* t, const float* positions_raw, const float* sigmas_host, int n, int* idx, float* w,
-                           int write_idx, const float* vals, int val_dim, float* distributed, const LnCsr* csr, void* workspace,
-                           size_t workspace_bytes, void* stream, const char* who) {
+                           int flags, const float* vals, int val_dim, float* distributed, const LnCsr* csr, void* workspace,
+                           size_t workspace_bytes, float* clear_values, long long clear_values_elems, void* stream, const char* who) {
     int rc = ln_check_table(t, who);
     if (rc) return rc;
     rc = ln_check_csr(csr, who);
     if (rc) return rc;
+    const int write_idx = flags & LN_BUILD_WRITE_IDX;
     LN_REQUIRE(n >= 0, LN_ERR_ARG, "%s: n=%d", who, n);
     LN_REQUIRE(positions_raw != nullptr || n == 0, LN_ERR_ARG, "%s: null positions", who);
     LN_REQUIRE(!write_idx || (idx && w), LN_ERR_ARG, "%s: write_idx set but idx/w null", who);
-    if (n == 0) return LN_OK;
     const long long tokens = (long long)n * (t->pos_dim + 1);
     BuildWs ws;
-    rc = ln_carve_ws(tokens, t->capacity, workspace, workspace_bytes, ws);
-    if (rc) return rc;
+    if (n > 0) {
+        rc = ln_carve_ws(tokens, t->capacity, workspace, workspace_bytes, ws);
+        if (rc) return rc;
+    }
+    // the bucketed path needs a table it knows to be empty: the clear rides in this call
+    const bool bucketed = n > 0 && (flags & LN_BUILD_CLEAR_FIRST) && !(flags & LN_BUILD_ATOMIC_PATH);
+    if (flags & LN_BUILD_CLEAR_FIRST) {
+        rc = ln_table_clear_impl(t, clear_values, clear_values_elems, bucketed ? ws.bkt_hist : nullptr, bucketed ? LN_BKT_MAX : 0, stream);
+        if (rc) return rc;
+    }
+    if (n == 0) return LN_OK;
     hipStream_t st = (hipStream_t)stream;
     int* tok_slot = write_idx ? idx : ws.tok_slot;  // idx doubles as the token->slot scratch
     LN_DISPATCH_D(t->pos_dim, {
         LnScale<D> sc = ln_make_scale<D>(sigmas_host);
-        LN_LAUNCH("k_insert_points", k_insert_points<D>, dim3(ln_div_up(tokens, 256)), dim3(256), 0, st, *t, positions_raw, sc, n, tok_slot,
-                  ws.tok_pos, write_idx ? w : (float*)nullptr, vals, val_dim, distributed);
-        rc = ln_rank_and_finalize<D>(*t, tok_slot, ws.tok_pos, write_idx ? idx : (int*)nullptr, tokens, ws, *csr, st);
+        if (bucketed) {
+            const int sb = ln_bucket_slots(t->capacity);
+            const int nbk = ln_bucket_count(t->capacity);
+            const size_t lds = (size_t)sb * (sizeof(unsigned long long) + 4 * sizeof(int));
+            LN_LAUNCH("k_point_keys", k_point_keys<D>, dim3(ln_div_up(n, LN_KEYS_PTS_PER_BLOCK)), dim3(256), 0, st, *t, positions_raw, sc, n, sb,
+                      nbk, ws.tok_pk, write_idx ? w : (float*)nullptr, ws.bkt_hist, vals, val_dim, distributed);
+            LN_LAUNCH("k_bucket_scan", k_bucket_scan, dim3(1), dim3(1024), 0, st, ws.bkt_hist, nbk, ws.bkt_start, ws.bkt_cursor, csr->seg_count);
+            LN_LAUNCH("k_bucket_scatter", k_bucket_scatter<D>, dim3(ln_div_up(tokens, 256 * LN_SCATTER_TOK_PER_THREAD)), dim3(256), 0, st,
+                      ws.tok_pk, tokens, t->capacity, sb, nbk, ws.bkt_start, ws.bkt_cursor, ws.part_tok, ws.part_pk);
+            LN_LAUNCH("k_bucket_build", k_bucket_build<D>, dim3(nbk), dim3(LN_BKT_THREADS), lds, st, *t, sb, nbk, ws.bkt_start, ws.part_tok,
+                      ws.part_pk, ws.part_slot, ws.tok_pos, tok_slot, *csr);
+            rc = ln_rank_rows<D>(*t, tok_slot, write_idx ? idx : (int*)nullptr, tokens, ws, st);
+        } else {
+            LN_LAUNCH("k_insert_points", k_insert_points<D>, dim3(ln_div_up(tokens, 256)), dim3(256), 0, st, *t, positions_raw, sc, n, tok_slot,
+                      ws.tok_pos, write_idx ? w : (float*)nullptr, vals, val_dim, distributed);
+            rc = ln_rank_and_finalize<D>(*t, tok_slot, ws.tok_pos, write_idx ? idx : (int*)nullptr, tokens, ws, *csr, st);
+        }
     });
     return rc;
 }
 
 extern "C" int ln_build_splat(const LnTable* t, const float* positions_raw, const float* sigmas_host, int n, int* idx,
-                              float* w, int write_idx, const LnCsr* csr, void* workspace, size_t workspace_bytes, float* clear_values,
+                              float* w, int flags, const LnCsr* csr, void* workspace, size_t workspace_bytes, float* clear_values,
                               long long clear_values_elems, void* stream) {
-    if (write_idx & LN_BUILD_CLEAR_FIRST) {
-        const int rc = ln_table_clear(t, clear_values, clear_values_elems, stream);
-        if (rc) return rc;
-    }
-    return ln_build_points(t, positions_raw, sigmas_host, n, idx, w, write_idx & LN_BUILD_WRITE_IDX, nullptr, 0, nullptr, csr, workspace,
-                           workspace_bytes, stream, "ln_build_splat");
+    return ln_build_points(t, positions_raw, sigmas_host, n, idx, w, flags, nullptr, 0, nullptr, csr, workspace, workspace_bytes,
+                           clear_values, clear_values_elems, stream, "ln_build_splat");
 }
 
 extern "C" int ln_distribute(const LnTable* t, const float* positions_raw, const float* sigmas_host, const float* vals, int n,
-                             int val_dim, int* idx, float* w, float* distributed, const LnCsr* csr, void* workspace,
-                             size_t workspace_bytes, void* stream) {
+                             int val_dim, int* idx, float* w, float* distributed, int flags, const LnCsr* csr, void* workspace,
+                             size_t workspace_bytes, float* clear_values, long long clear_values_elems, void* stream) {
     LN_REQUIRE(vals && distributed && idx && w, LN_ERR_ARG, "ln_distribute: null buffer");
     LN_REQUIRE(val_dim >= 1, LN_ERR_ARG, "ln_distribute: val_dim=%d", val_dim);
-    return ln_build_points(t, positions_raw, sigmas_host, n, idx, w, 1, vals, val_dim, distributed, csr, workspace,
-                           workspace_bytes, stream, "ln_distribute");
+    return ln_build_points(t, positions_raw, sigmas_host, n, idx, w, flags | LN_BUILD_WRITE_IDX, vals, val_dim, distributed, csr, workspace,
+                           workspace_bytes, clear_values, clear_values_elems, stream, "ln_distribute");
 }
 
 extern "C" int ln_coarsen(const LnTable* fine, int fine_rows_upper, const LnTable* coarse, const LnCsr* csr, void* workspace,

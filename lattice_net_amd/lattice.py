@@ -28,6 +28,7 @@ __all__ = ["Lattice", "HashTable"]
 
 
 _SIZE_CACHE = {}
+_FORCE_ATOMIC_BUILD = os.environ.get("LATTICE_BUILD_PATH", "") == "atomic"  # A/B switch: skip the bucketed build
 
 
 def _build_sizes(tokens: int, capacity: int):
@@ -62,6 +63,7 @@ class _TableStorage:
         self.version = 0
         self.nbr_cache = {}
         self.csr_cache = {}
+        self.replay = None  # [rebuild on the atomic path, then the work queued behind the build], see Lattice._build
 
     def clone(self) -> "_TableStorage":
         s = _TableStorage.__new__(_TableStorage)
@@ -74,6 +76,7 @@ class _TableStorage:
         s.version = 0
         s.nbr_cache = {}
         s.csr_cache = {}
+        s.replay = None
         return s
 
     def touch(self):
@@ -122,7 +125,7 @@ class HashTable:
         self.m_values_tensor = torch.empty((self.m_capacity, val_dim), dtype=torch.float32, device=device)
         self._counters = torch.zeros((2,), dtype=torch.int32, device=device)
         self.m_nr_filled_is_dirty = True
-        self.clear()
+        self.clear(lazy=True)  # rides in the first build call; every other reader flushes it
 
     def is_initialized(self) -> bool:
         return self._storage is not None
@@ -385,7 +388,6 @@ class Lattice:
         return buf, c, max_seg
 
     def _build(self, positions_raw, write: bool, vals=None, distributed=None):
-        lib = _lib.load()
         n, d = positions_raw.shape
         dev = self._dev(positions_raw)
         ht = self.m_hash_table
@@ -395,31 +397,47 @@ class Lattice:
             w = torch.empty((n * (d + 1),), dtype=torch.float32, device=dev)
         tokens = n * (d + 1)
         cap = ht.capacity()
-        ws = self._workspace(_build_sizes(tokens, cap)[0])
         csr_buf, csr, max_seg = self._alloc_csr(tokens, cap)
-        if distributed is None:
-            clear_vals, do_clear = ht.take_pending_clear()  # begin_splat's clear rides in the same C call
+        clear_vals, do_clear = ht.take_pending_clear()  # begin_splat's clear rides in the same C call
+        st = ht._storage
+
+        def issue(force_atomic: bool):
+            lib = _lib.load()
+            ws = self._workspace(_build_sizes(tokens, cap)[0])
             t = ht.c_table()
-            flags = (1 if write else 0) | (2 if do_clear else 0)
-            rc = lib.ln_build_splat(C.byref(t), _lib.ptr(positions_raw), self._sigmas_host(), n, _lib.ptr(idx), _lib.ptr(w), flags,
-                                    C.byref(csr), _lib.ptr(ws), ws.numel(), _lib.ptr(clear_vals),
-                                    0 if clear_vals is None else clear_vals.numel(), self._stream())
-            _lib.check(rc, "ln_build_splat")
-        else:
-            t = ht.c_table()
-            rc = lib.ln_distribute(C.byref(t), _lib.ptr(positions_raw), self._sigmas_host(), _lib.ptr(vals), n, vals.shape[1],
-                                   _lib.ptr(idx), _lib.ptr(w), _lib.ptr(distributed), C.byref(csr), _lib.ptr(ws), ws.numel(),
-                                   self._stream())
-            _lib.check(rc, "ln_distribute")
-        ht._storage.touch()
-        ht.m_nr_filled_is_dirty = True
-        ht.start_count_readback()
-        if write:
-            # the build's slot -> tokens adjacency serves every scatter that uses these indices (groups = slots,
-            # row of a group = entries[slot]); `idx` is kept alive by the entry so its address cannot be recycled
-            st = ht._storage
-            st.csr_cache[(idx.data_ptr(), idx._version, idx.numel())] = (csr_buf, csr, max_seg, st.entries, idx)
+            flags = (_lib.LN_BUILD_WRITE_IDX if write else 0) | (_lib.LN_BUILD_CLEAR_FIRST if do_clear else 0)
+            if force_atomic or _FORCE_ATOMIC_BUILD:
+                flags |= _lib.LN_BUILD_ATOMIC_PATH
+            cv, cn = _lib.ptr(clear_vals), (0 if clear_vals is None else clear_vals.numel())
+            if distributed is None:
+                rc = lib.ln_build_splat(C.byref(t), _lib.ptr(positions_raw), self._sigmas_host(), n, _lib.ptr(idx), _lib.ptr(w), flags,
+                                        C.byref(csr), _lib.ptr(ws), ws.numel(), cv, cn, self._stream())
+                _lib.check(rc, "ln_build_splat")
+            else:
+                rc = lib.ln_distribute(C.byref(t), _lib.ptr(positions_raw), self._sigmas_host(), _lib.ptr(vals), n, vals.shape[1],
+                                       _lib.ptr(idx), _lib.ptr(w), _lib.ptr(distributed), flags, C.byref(csr), _lib.ptr(ws), ws.numel(),
+                                       cv, cn, self._stream())
+                _lib.check(rc, "ln_distribute")
+            st.touch()
+            ht.m_nr_filled_is_dirty = True
+            ht.start_count_readback()
+            if write:
+                # the build's slot -> tokens adjacency serves every scatter that uses these indices (groups = slots,
+                # row of a group = entries[slot]); `idx` is kept alive by the entry so its address cannot be recycled
+                st.csr_cache[(idx.data_ptr(), idx._version, idx.numel())] = (csr_buf, csr, max_seg, st.entries, idx)
+
+        issue(False)
+        # A bucketed build that reports LN_STATUS_BUCKET_OVERFLOW is replayed on the atomic path, together with the
+        # work that was queued behind it (nr_lattice_vertices() is where the status is read).
+        st.replay = [lambda: issue(True)] if do_clear else None
         return idx, w
+
+    def _after_build(self, fn):
+        """Runs fn() now and again if the build it depends on has to be replayed."""
+        fn()
+        st = self.m_hash_table._storage
+        if getattr(st, "replay", None) is not None:
+            st.replay.append(fn)
 
     # ---------------------------------------------------------------- atomics-free scatter (CSR)
     def _csr(self, idx: torch.Tensor):
@@ -508,8 +526,8 @@ class Lattice:
         idx, w = self._build(positions_raw, True)
         tv = ht.m_values_tensor
         # splatCacheNaive (LatticeGPU.cuh:926-973) as a token-balanced reduce; begin_splat zeroed the table values
-        self._scatter_rows(values, idx, w, tv, v, d + 1, v)
-        self._prefetch_neighbours(n * (d + 1))
+        self._after_build(lambda: self._scatter_rows(values, idx, w, tv, v, d + 1, v))
+        self._after_build(lambda: self._prefetch_neighbours(n * (d + 1)))
         return idx, w
 
     def just_create_verts(self, positions_raw: torch.Tensor, return_indices_and_weights: bool):  # Lattice.cu:244-290
@@ -542,13 +560,13 @@ class Lattice:
             nh._storage = _TableStorage(oh.capacity(), d, dev)
             nh.m_values_tensor = torch.empty((oh.capacity(), oh.val_dim() or v), dtype=torch.float32, device=dev)
             nh._counters = torch.zeros((2,), dtype=torch.int32, device=dev)
-            nh.clear()
+            nh.clear(lazy=True)  # issued inside the build call
         else:
             nh._storage = oh._storage.clone()
             nh.m_values_tensor = torch.zeros_like(oh.m_values_tensor)
             nh._counters = oh._counters.clone()
         idx, w = new._build(positions_raw, True, vals=values, distributed=distributed)
-        new._prefetch_neighbours(n * (d + 1))
+        new._after_build(lambda: new._prefetch_neighbours(n * (d + 1)))
         return new, distributed, idx, w
 
     def expand(self, positions_raw: torch.Tensor, point_multiplier: int, noise_stddev: float, expand_values: bool):  # Lattice.cu:292-348
@@ -950,6 +968,18 @@ class Lattice:
         if ht.m_nr_filled_is_dirty:
             both = ht.read_counters()  # ONE blocking 8-byte readback: [nr_filled, status]
             nr, status = int(both[0]), int(both[1])
+            if status & _lib.LN_STATUS_BUCKET_OVERFLOW:
+                # one LDS-staged bucket of the fast build filled up (table loaded beyond ~0.85): redo the build with
+                # global atomics, which spill past a full bucket, and re-issue what was queued behind it
+                st = ht._storage
+                replay, st.replay = st.replay, None
+                if not replay:
+                    raise _lib.LatticeNetHipError("bucketed build overflowed and cannot be replayed")
+                for fn in replay:
+                    fn()
+                st.replay = None
+                both = ht.read_counters()
+                nr, status = int(both[0]), int(both[1])
             if status & _lib.LN_STATUS_TABLE_FULL:
                 raise _lib.LatticeNetHipError(f"hash table overflow: capacity {ht.capacity()} is too small for this cloud "
                                               "(the reference would spin forever, HashTableGPU.cuh:443)")
