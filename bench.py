@@ -46,7 +46,7 @@ def make_cloud(kind: str, n: int, seed: int) -> np.ndarray:
     return synthetic.cube_cloud(n, seed)
 
 
-def algorithmic_work(kernel: str, n: int, m: int, d: int, v: int, f: int, e: int):
+def algorithmic_work(kernel: str, n: int, m: int, d: int, v: int, f: int, e: int, cap: int = 0):
     """(bound, unit, amount per launch) — SURVEY.md §8d per-unit figures x units per launch."""
     if kernel == "k_conv_mfma":
         return "mfma", "TFLOP/s", 2.0 * m * e * v * f
@@ -58,6 +58,10 @@ def algorithmic_work(kernel: str, n: int, m: int, d: int, v: int, f: int, e: int
         return "hbm", "GB/s", n * (8.0 * (d + 1) + 4.0 * v) + m * 4.0 * v
     if kernel == "k_insert_points":  # read positions, write idx + w, write keys once
         return "hbm", "GB/s", n * (4.0 * d + 8.0 * (d + 1)) + m * 4.0 * d
+    if kernel == "k_point_keys":  # read positions; write w and one (token, packed key) entry per simplex vertex
+        return "hbm", "GB/s", n * (4.0 * d + (4.0 + 12.0) * (d + 1))
+    if kernel == "k_bucket_build":  # read the entries; write token->slot, the slot CSR and the slot range (keys, first token, start)
+        return "hbm", "GB/s", n * (12.0 + 4.0 + 4.0) * (d + 1) + cap * 16.0
     if kernel == "k_neighbours":
         return "hbm", "GB/s", m * (4.0 * d + 4.0 * e)
     raise ValueError(f"no algorithmic model for kernel {kernel}")
@@ -102,10 +106,10 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
-    ap.add_argument("--roofline-kernel", default="k_insert_points",
+    ap.add_argument("--roofline-kernel", default="k_csr_reduce_segments",
                     help="dominant kernel (largest share of GPU time in profiles/r1_kernel_stats.csv): its launches are timed live "
                          "with HIP events during the timed region")
-    ap.add_argument("--extra-kernels", default="k_conv_mfma,k_csr_reduce_segments,k_grad_filter_mfma,k_slice_forward,k_neighbours",
+    ap.add_argument("--extra-kernels", default="k_conv_mfma,k_grad_filter_mfma,k_bucket_build,k_point_keys,k_slice_forward,k_neighbours",
                     help="kernels timed the same way in extra untimed steps AFTER the timed region (reported under roofline_others)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the CPU baseline leg (0 disables)")
     ap.add_argument("--autograd-threads", type=int, default=0, help="1 = leave torch's per-device autograd worker thread on")
@@ -177,7 +181,7 @@ def main():
     checksum = sharding.gather_sum(dist, checksum, dev)
 
     def roofline_entry(kernel, total_ms_v, launches_v):
-        bound_kind, unit, amount = algorithmic_work(kernel, n, m, d, v, f, e)
+        bound_kind, unit, amount = algorithmic_work(kernel, n, m, d, v, f, e, cap)
         avg_s = total_ms_v / launches_v / 1e3
         if bound_kind == "hbm":
             achieved, peak = amount / avg_s / 1e9, HBM_PEAK_GBS

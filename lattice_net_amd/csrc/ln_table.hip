@@ -72,7 +72,7 @@ LnProfScope::~LnProfScope() {
     }
 }
 
-extern "C" const char* ln_kernel_names(void) { return "k_bucket_build,k_bucket_scan,k_bucket_scatter,k_conv_generic,k_conv_mfma,k_csr_count,k_csr_fill,k_csr_group_sizes,k_csr_reduce_segments,k_csr_scan_local,k_csr_segment_max,k_csr_segment_max_decode,k_finalize,k_gather_backward,k_gather_forward,k_grad_filter_generic,k_grad_filter_mfma,k_im2row,k_im2rowindices,k_insert_coarse,k_insert_points,k_mark_first,k_neighbours,k_point_keys,k_reduce_slabs,k_retrieve_points,k_row2im,k_scan_blocks,k_scatter_point_rows,k_seg_min,k_slice_classify_backward,k_slice_classify_forward,k_slice_forward,k_table_clear"; }
+extern "C" const char* ln_kernel_names(void) { return "k_bucket_build,k_conv_generic,k_conv_mfma,k_csr_count,k_csr_fill,k_csr_group_sizes,k_csr_reduce_segments,k_csr_scan_local,k_csr_segment_max,k_csr_segment_max_decode,k_finalize,k_gather_backward,k_gather_forward,k_grad_filter_generic,k_grad_filter_mfma,k_im2row,k_im2rowindices,k_insert_coarse,k_insert_points,k_mark_first,k_neighbours,k_point_keys,k_reduce_slabs,k_retrieve_points,k_row2im,k_scan_blocks,k_scatter_point_rows,k_seg_min,k_slice_classify_backward,k_slice_classify_forward,k_slice_forward,k_table_clear"; }
 
 extern "C" int ln_profile_begin(const char* kernel_name, int max_samples) {
     LN_REQUIRE(kernel_name && strlen(kernel_name) < sizeof(g_prof.name) && max_samples > 0, LN_ERR_ARG, "ln_profile_begin: bad args");
@@ -272,19 +272,30 @@ __global__ void __launch_bounds__(256)
 // and its segments directly.  A bucket that fills up raises LN_STATUS_BUCKET_OVERFLOW: the caller
 // re-runs the build with LN_BUILD_ATOMIC_PATH, whose inserts spill past the bucket.
 
-// Pass 1: thread per point -> the d+1 packed keys, weights, (distribute rows) + bucket histogram.
-#define LN_KEYS_PTS_PER_BLOCK 512
+// Pass 1: thread per point -> the d+1 packed keys and weights (+ distribute rows), scattered straight into the
+// fixed-capacity region of the bucket each key hashes to.  Positions inside a region come from an LDS count per
+// (block, bucket) plus ONE returning global atomic per (block, bucket) on the bucket's cursor.
+#define LN_KEYS_PTS_PER_THREAD 2
+#define LN_KEYS_PTS_PER_BLOCK (256 * LN_KEYS_PTS_PER_THREAD)
 template <int D>
 __global__ void __launch_bounds__(256)
-    k_point_keys(LnTable t, const float* __restrict__ pos_raw, LnScale<D> sc, int n, int sb, int nbk,
-                 unsigned long long* __restrict__ tok_pk, float* __restrict__ w, int* __restrict__ hist, const float* __restrict__ vals,
-                 int val_dim, float* __restrict__ distributed) {
-    __shared__ int s_hist[LN_BKT_MAX];
-    for (int b = threadIdx.x; b < nbk; b += 256) s_hist[b] = 0;
+    k_point_keys(LnTable t, const float* __restrict__ pos_raw, LnScale<D> sc, int n, int sb, int nbk, int capb,
+                 int* __restrict__ cursor, int* __restrict__ part_tok, unsigned long long* __restrict__ part_pk,
+                 int* __restrict__ tok_slot, float* __restrict__ w, const float* __restrict__ vals, int val_dim,
+                 float* __restrict__ distributed, int* __restrict__ seg_count) {
+    __shared__ int s_cnt[LN_BKT_MAX];
+    for (int b = threadIdx.x; b < nbk; b += 256) s_cnt[b] = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *seg_count = 0;  // the bucket workgroups of the next launch add to it
     __syncthreads();
-    for (int it = 0; it < LN_KEYS_PTS_PER_BLOCK / 256; ++it) {
+    unsigned long long pk[LN_KEYS_PTS_PER_THREAD][D + 1];
+    int bkt[LN_KEYS_PTS_PER_THREAD][D + 1];
+    int rank[LN_KEYS_PTS_PER_THREAD][D + 1];
+#pragma unroll
+    for (int it = 0; it < LN_KEYS_PTS_PER_THREAD; ++it) {
         const int p = blockIdx.x * LN_KEYS_PTS_PER_BLOCK + it * 256 + threadIdx.x;
-        if (p >= n) break;
+#pragma unroll
+        for (int r = 0; r <= D; ++r) bkt[it][r] = -1;
+        if (p >= n) continue;
         float pr[D];
 #pragma unroll
         for (int i = 0; i < D; ++i) pr[i] = pos_raw[(size_t)p * D + i];
@@ -295,16 +306,16 @@ __global__ void __launch_bounds__(256)
             int key[D];
             ln_vertex_key<D>(s, r, key);
             const size_t tk = (size_t)p * (D + 1) + r;
-            unsigned long long pk = LN_EMPTY_KEY;
-            if (KeyPack<D>::in_range(key)) {
-                pk = KeyPack<D>::pack(key);
-                const int h0 = int(ln_hash<D>(key) % uint32_t(t.capacity));
-                atomicAdd(&s_hist[h0 / sb], 1);
+            const bool ok = KeyPack<D>::in_range(key);
+            if (ok) {
+                pk[it][r] = KeyPack<D>::pack(key);
+                bkt[it][r] = int(ln_hash<D>(key) % uint32_t(t.capacity)) / sb;
+                rank[it][r] = atomicAdd(&s_cnt[bkt[it][r]], 1);
             } else {
                 atomicOr(t.status, LN_STATUS_KEY_RANGE);
+                tok_slot[tk] = -1;
             }
-            tok_pk[tk] = pk;
-            if (w) w[tk] = pk != LN_EMPTY_KEY ? s.bary[r] : -1.0f;
+            if (w) w[tk] = ok ? s.bary[r] : -1.0f;
             if (distributed) {  // LatticeGPU.cuh:626-637: [pos_scaled(d) | val(V) | bary[r]] per simplex vertex
                 const int row_len = D + val_dim + 1;
                 float* o = distributed + tk * row_len;
@@ -317,102 +328,40 @@ __global__ void __launch_bounds__(256)
     }
     __syncthreads();
     for (int b = threadIdx.x; b < nbk; b += 256) {
-        const int c = s_hist[b];
-        if (c) atomicAdd(&hist[b], c);
-    }
-}
-
-// Pass 2 (one workgroup): bucket_start = exclusive scan of the histogram; resets the cursors and the
-// segment counter of the CSR.
-__global__ void __launch_bounds__(1024) k_bucket_scan(const int* __restrict__ hist, int nbk, int* __restrict__ bucket_start,
-                                                      int* __restrict__ cursor, int* __restrict__ seg_count) {
-    __shared__ int s_wave[16];
-    __shared__ int s_running;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    if (tid == 0) {
-        s_running = 0;
-        *seg_count = 0;
-    }
-    __syncthreads();
-    for (int start = 0; start < nbk; start += 1024) {
-        const int i = start + tid;
-        const int v = (i < nbk) ? hist[i] : 0;
-        int incl = v;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int o = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += o;
-        }
-        if (lane == 63) s_wave[wave] = incl;
-        __syncthreads();
-        int wave_off = 0;
-        for (int k = 0; k < wave; ++k) wave_off += s_wave[k];
-        const int running = s_running;
-        if (i < nbk) {
-            bucket_start[i] = running + wave_off + incl - v;
-            cursor[i] = 0;
-        }
-        __syncthreads();
-        if (tid == 1023) s_running = running + wave_off + incl;
-        __syncthreads();
-    }
-    if (tid == 0) bucket_start[nbk] = s_running;
-}
-
-// Pass 3: scatter (token, packed key) into bucket-major order.
-#define LN_SCATTER_TOK_PER_THREAD 8
-template <int D>
-__global__ void __launch_bounds__(256)
-    k_bucket_scatter(const unsigned long long* __restrict__ tok_pk, long long tokens, int capacity, int sb, int nbk,
-                     const int* __restrict__ bucket_start, int* __restrict__ cursor, int* __restrict__ part_tok,
-                     unsigned long long* __restrict__ part_pk) {
-    __shared__ int s_cnt[LN_BKT_MAX];
-    for (int b = threadIdx.x; b < nbk; b += 256) s_cnt[b] = 0;
-    __syncthreads();
-    const long long base_tk = (long long)blockIdx.x * (256 * LN_SCATTER_TOK_PER_THREAD);
-    unsigned long long pk[LN_SCATTER_TOK_PER_THREAD];
-    int bkt[LN_SCATTER_TOK_PER_THREAD];
-    int rank[LN_SCATTER_TOK_PER_THREAD];
-#pragma unroll
-    for (int k = 0; k < LN_SCATTER_TOK_PER_THREAD; ++k) {
-        const long long tk = base_tk + k * 256 + threadIdx.x;
-        pk[k] = tk < tokens ? tok_pk[tk] : LN_EMPTY_KEY;
-    }
-#pragma unroll
-    for (int k = 0; k < LN_SCATTER_TOK_PER_THREAD; ++k) {
-        bkt[k] = -1;
-        if (pk[k] != LN_EMPTY_KEY) {
-            int key[D];
-            KeyPack<D>::unpack(pk[k], key);
-            bkt[k] = int(ln_hash<D>(key) % uint32_t(capacity)) / sb;
-            rank[k] = atomicAdd(&s_cnt[bkt[k]], 1);
-        }
-    }
-    __syncthreads();
-    for (int b = threadIdx.x; b < nbk; b += 256) {
         const int c = s_cnt[b];
-        if (c) s_cnt[b] = bucket_start[b] + atomicAdd(&cursor[b], c);  // one global atomic per (block, bucket)
+        if (c) s_cnt[b] = atomicAdd(&cursor[b], c);
     }
     __syncthreads();
+    bool dropped = false;
 #pragma unroll
-    for (int k = 0; k < LN_SCATTER_TOK_PER_THREAD; ++k) {
-        if (bkt[k] >= 0) {
-            const int dst = s_cnt[bkt[k]] + rank[k];
-            part_tok[dst] = int(base_tk + k * 256 + threadIdx.x);
-            part_pk[dst] = pk[k];
+    for (int it = 0; it < LN_KEYS_PTS_PER_THREAD; ++it) {
+        const int p = blockIdx.x * LN_KEYS_PTS_PER_BLOCK + it * 256 + threadIdx.x;
+#pragma unroll
+        for (int r = 0; r <= D; ++r) {
+            if (bkt[it][r] < 0) continue;
+            const int tk = p * (D + 1) + r;
+            const int at = s_cnt[bkt[it][r]] + rank[it][r];
+            if (at < capb) {
+                const size_t dst = (size_t)bkt[it][r] * capb + at;
+                part_tok[dst] = tk;
+                part_pk[dst] = pk[it][r];
+            } else {
+                dropped = true;  // region full (heavily skewed cloud): the whole build is replayed on the atomic path
+                tok_slot[tk] = -1;
+            }
         }
     }
+    if (dropped) atomicOr(t.status, LN_STATUS_BUCKET_OVERFLOW);
 }
 
-// Pass 4: one workgroup per bucket.  LDS: keys[sb] | count[sb] | min token[sb] | token offset[sb] | segment offset[sb].
+// Pass 2: one workgroup per bucket.  LDS: keys[sb] | count[sb] | min token[sb] | token offset[sb] | segment offset[sb].
 #define LN_BKT_THREADS 1024
+#define LN_BKT_REG_TOK 4  // tokens per thread whose (token, slot, position) stay in registers between the two sweeps
 template <int D>
 __global__ void __launch_bounds__(LN_BKT_THREADS)
-    k_bucket_build(LnTable t, int sb, int nbk, const int* __restrict__ bucket_start, const int* __restrict__ part_tok,
+    k_bucket_build(LnTable t, int sb, int nbk, int capb, const int* __restrict__ cursor, const int* __restrict__ part_tok,
                    const unsigned long long* __restrict__ part_pk, int* __restrict__ part_slot, int* __restrict__ part_pos,
-                   int* __restrict__ tok_slot, LnCsr csr) {
+                   int* __restrict__ tok_slot, LnCsr csr, unsigned long long* __restrict__ bitmap) {
     extern __shared__ unsigned long long s_mem[];
     unsigned long long* skeys = s_mem;
     int* scnt = reinterpret_cast<int*>(skeys + sb);
@@ -422,6 +371,8 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
     __shared__ int s_wave_tok[16], s_wave_seg[16];
     __shared__ int s_run_tok, s_run_seg, s_seg_base;
     const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
     const int b = blockIdx.x;
     const int lo = b * sb;
     const int size = min(sb, t.capacity - lo);
@@ -430,20 +381,41 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
         scnt[i] = 0;
         smin[i] = LN_EMPTY_TOK;
     }
+    // CSR offset of this bucket = tokens of all buckets before it
+    int before = 0;
+    for (int i = tid; i < b; i += LN_BKT_THREADS) before += min(cursor[i], capb);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) before += __shfl_xor(before, off, 64);
+    if (lane == 0) s_wave_tok[wave] = before;
     if (tid == 0) {
         s_run_tok = 0;
         s_run_seg = 0;
     }
+    const int ntok = min(cursor[b], capb);
+    const size_t in0 = (size_t)b * capb;
+    // issue the loads of the register-resident tokens before the barrier
+    int r_tk[LN_BKT_REG_TOK], r_ls[LN_BKT_REG_TOK], r_pos[LN_BKT_REG_TOK];
+    unsigned long long r_pk[LN_BKT_REG_TOK];
+#pragma unroll
+    for (int k = 0; k < LN_BKT_REG_TOK; ++k) {
+        const int j = tid + k * LN_BKT_THREADS;
+        r_ls[k] = -1;
+        r_pos[k] = -1;
+        r_tk[k] = j < ntok ? part_tok[in0 + j] : -1;
+        r_pk[k] = j < ntok ? part_pk[in0 + j] : LN_EMPTY_KEY;
+    }
     __syncthreads();
-    const int base = bucket_start[b];
-    const int ntok = bucket_start[b + 1] - base;
-    for (int j = tid; j < ntok; j += LN_BKT_THREADS) {
-        const int tk = part_tok[base + j];
-        const unsigned long long pk = part_pk[base + j];
+    int base = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) base += s_wave_tok[k];
+    __syncthreads();  // s_wave_tok is reused by the scans below
+
+    auto place = [&](int tk, unsigned long long pk, int& ls, int& pos) {
         int key[D];
         KeyPack<D>::unpack(pk, key);
         int o = int(ln_hash<D>(key) % uint32_t(t.capacity)) - lo;
-        int ls = -1;
+        ls = -1;
+        pos = -1;
         for (int i = 0; i < size; ++i) {
             unsigned long long cur = skeys[o];
             if (cur == LN_EMPTY_KEY) {
@@ -456,7 +428,6 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
             }
             if (++o >= size) o = 0;
         }
-        int pos = -1;
         if (ls >= 0) {
             pos = atomicAdd(&scnt[ls], 1);
             atomicMin(&smin[ls], (unsigned int)tk);
@@ -464,13 +435,18 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
             atomicOr(t.status, LN_STATUS_BUCKET_OVERFLOW);
         }
         tok_slot[tk] = ls >= 0 ? lo + ls : -1;
-        part_slot[base + j] = ls;
-        part_pos[base + j] = pos;
+    };
+#pragma unroll
+    for (int k = 0; k < LN_BKT_REG_TOK; ++k)
+        if (r_tk[k] >= 0) place(r_tk[k], r_pk[k], r_ls[k], r_pos[k]);
+    for (int j = tid + LN_BKT_REG_TOK * LN_BKT_THREADS; j < ntok; j += LN_BKT_THREADS) {
+        int ls, pos;
+        place(part_tok[in0 + j], part_pk[in0 + j], ls, pos);
+        part_slot[in0 + j] = ls;
+        part_pos[in0 + j] = pos;
     }
     __syncthreads();
     // exclusive scans of the per-slot token and segment counts
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
     for (int start = 0; start < size; start += LN_BKT_THREADS) {
         const int i = start + tid;
         const int c = (i < size) ? scnt[i] : 0;
@@ -516,20 +492,26 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
         const int beg = base + soff[i];
         csr.grp_start[h] = beg;
         t.slot_keys[h] = skeys[i];
-        t.slot_tok[h] = smin[i];
+        const unsigned int ft = smin[i];
+        t.slot_tok[h] = ft;
         const int c = scnt[i];
+        if (c) atomicOr(&bitmap[ft >> 6], 1ull << (ft & 63));  // the slot's first occurrence (every slot is new)
         int sid = seg_base + sseg[i];
         for (int e = 0; e < c; e += LN_CSR_SEG, ++sid) {
             csr.seg_grp[sid] = h;
             csr.seg_beg[sid] = beg + e;
         }
     }
-    if (b == nbk - 1 && tid == 0) csr.grp_start[t.capacity] = bucket_start[nbk];
-    for (int j = tid; j < ntok; j += LN_BKT_THREADS) {
-        const int ls = part_slot[base + j];
-        if (ls >= 0) csr.csr_tok[base + soff[ls] + part_pos[base + j]] = part_tok[base + j];
-        if (j >= placed) csr.csr_tok[base + j] = -1;  // only after an overflow: keeps readers in bounds until the rebuild
+    if (b == nbk - 1 && tid == 0) csr.grp_start[t.capacity] = base + ntok;
+#pragma unroll
+    for (int k = 0; k < LN_BKT_REG_TOK; ++k)
+        if (r_ls[k] >= 0) csr.csr_tok[base + soff[r_ls[k]] + r_pos[k]] = r_tk[k];
+    for (int j = tid + LN_BKT_REG_TOK * LN_BKT_THREADS; j < ntok; j += LN_BKT_THREADS) {
+        const int ls = part_slot[in0 + j];
+        if (ls >= 0) csr.csr_tok[base + soff[ls] + part_pos[in0 + j]] = part_tok[in0 + j];
     }
+    for (int j = placed + tid; j < ntok; j += LN_BKT_THREADS)
+        csr.csr_tok[base + j] = -1;  // only after an overflow: keeps readers in bounds until the rebuild
 }
 
 // Token producer 2: coarsen kernel (LatticeGPU.cuh:2348-2511): per fine vertex with all-even key,
@@ -636,8 +618,8 @@ __global__ void __launch_bounds__(256)
 }
 
 // single workgroup: exclusive scan of the per-block first-occurrence counts (+ rows that existed before)
-__global__ void __launch_bounds__(1024) k_scan_blocks(const int* __restrict__ block_cnt, int nb, int* __restrict__ block_prefix,
-                                                      int* nr_filled) {
+__global__ void __launch_bounds__(1024) k_scan_blocks(const int* __restrict__ block_cnt, const unsigned long long* __restrict__ bitmap, int nb,
+                                                      int* __restrict__ block_prefix, int* nr_filled) {
     __shared__ int s_wave[16];
     __shared__ int s_running;
     const int tid = threadIdx.x;
@@ -648,7 +630,16 @@ __global__ void __launch_bounds__(1024) k_scan_blocks(const int* __restrict__ bl
     __syncthreads();
     for (int start = 0; start < nb; start += 1024) {
         const int i = start + tid;
-        const int v = (i < nb) ? block_cnt[i] : 0;
+        int v = 0;
+        if (i < nb) {
+            if (block_cnt) {
+                v = block_cnt[i];
+            } else {  // bucketed build: the first-occurrence bits were set directly, count them here
+                const ulonglong2 a = *reinterpret_cast<const ulonglong2*>(bitmap + (size_t)i * 4);
+                const ulonglong2 c = *reinterpret_cast<const ulonglong2*>(bitmap + (size_t)i * 4 + 2);
+                v = __popcll(a.x) + __popcll(a.y) + __popcll(c.x) + __popcll(c.y);
+            }
+        }
         int incl = v;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -701,10 +692,12 @@ __global__ void __launch_bounds__(256)
     if (idx_out) idx_out[tk] = row;
 }
 
-// Workspace of one build: first-occurrence bitmap + block counts/prefixes, token->slot scratch,
-// token->position, and the scratch of the slot-CSR construction (ln_csr.hip).
+// Workspace of one build: bucket cursors + first-occurrence bitmap (one zero-filled range), block counts/prefixes,
+// token->slot scratch, token->position, the scratch of the slot-CSR construction (ln_csr.hip) and the bucket regions.
 struct BuildWs {
-    unsigned long long* bitmap;
+    int* bkt_cursor;  // [LN_BKT_MAX]  tokens scattered into each bucket region     } zeroed together by the clear
+    unsigned long long* bitmap;  //                                                   } that opens a bucketed build
+    size_t zero_ints;
     int* block_cnt;
     int* block_prefix;
     int* tok_slot;
@@ -712,25 +705,33 @@ struct BuildWs {
     void* csr_ws;
     size_t csr_ws_bytes;
     int nb;
-    // bucketed build
-    unsigned long long* tok_pk;
+    // bucket regions: nbk x capb entries
+    int capb;
     unsigned long long* part_pk;
     int* part_tok;
     int* part_slot;
-    int* bkt_hist;   // [LN_BKT_MAX]      zero before k_point_keys
-    int* bkt_start;  // [LN_BKT_MAX + 1]
-    int* bkt_cursor; // [LN_BKT_MAX]
+    int* part_pos;
 };
 
 static size_t ln_align256(size_t x) { return (x + 255) & ~size_t(255); }
 
+// Entries reserved per bucket region: 4x the mean bucket population + slack.  Clouds so skewed that one bucket
+// receives more (e.g. all points identical) are rebuilt on the atomic path (LN_STATUS_BUCKET_OVERFLOW).
+static int ln_bucket_region(long long tokens, int capacity) {
+    const int nbk = ln_bucket_count(capacity);
+    long long capb = 4 * ((tokens + nbk - 1) / nbk) + 1024;
+    capb = (capb + 63) & ~63ll;
+    return int(capb);
+}
+
 extern "C" size_t ln_build_workspace_bytes(long long tokens, int capacity) {
     if (tokens < 1) tokens = 1;
+    if (capacity < 1) capacity = 1;
     const size_t nb = (size_t)ln_div_up(tokens, 256);
-    return ln_align256(nb * 4 * sizeof(unsigned long long)) + 2 * ln_align256(nb * sizeof(int)) +
+    const size_t region = (size_t)ln_bucket_count(capacity) * ln_bucket_region(tokens, capacity);
+    return ln_align256(LN_BKT_MAX * sizeof(int)) + ln_align256(nb * 4 * sizeof(unsigned long long)) + 2 * ln_align256(nb * sizeof(int)) +
            2 * ln_align256((size_t)tokens * sizeof(int)) + ln_align256(ln_csr_scan_workspace_bytes(capacity)) +
-           2 * ln_align256((size_t)tokens * sizeof(unsigned long long)) + 2 * ln_align256((size_t)tokens * sizeof(int)) +
-           3 * ln_align256((LN_BKT_MAX + 1) * sizeof(int));
+           ln_align256(region * sizeof(unsigned long long)) + 3 * ln_align256(region * sizeof(int));
 }
 
 static int ln_carve_ws(long long tokens, int capacity, void* workspace, size_t bytes, BuildWs& ws) {
@@ -740,8 +741,11 @@ static int ln_carve_ws(long long tokens, int capacity, void* workspace, size_t b
     LN_REQUIRE(tokens < 0x7FFFFFFFll, LN_ERR_ARG, "too many insertion tokens: %lld", tokens);
     char* p = static_cast<char*>(workspace);
     ws.nb = ln_div_up(tokens, 256);
+    ws.bkt_cursor = reinterpret_cast<int*>(p);
+    p += ln_align256(LN_BKT_MAX * sizeof(int));
     ws.bitmap = reinterpret_cast<unsigned long long*>(p);
     p += ln_align256((size_t)ws.nb * 4 * sizeof(unsigned long long));
+    ws.zero_ints = size_t(p - static_cast<char*>(workspace)) / sizeof(int);
     ws.block_cnt = reinterpret_cast<int*>(p);
     p += ln_align256((size_t)ws.nb * sizeof(int));
     ws.block_prefix = reinterpret_cast<int*>(p);
@@ -753,24 +757,20 @@ static int ln_carve_ws(long long tokens, int capacity, void* workspace, size_t b
     ws.csr_ws = p;
     ws.csr_ws_bytes = ln_csr_scan_workspace_bytes(capacity);
     p += ln_align256(ws.csr_ws_bytes);
-    ws.tok_pk = reinterpret_cast<unsigned long long*>(p);
-    p += ln_align256((size_t)tokens * sizeof(unsigned long long));
+    ws.capb = ln_bucket_region(tokens, capacity);
+    const size_t region = (size_t)ln_bucket_count(capacity) * ws.capb;
     ws.part_pk = reinterpret_cast<unsigned long long*>(p);
-    p += ln_align256((size_t)tokens * sizeof(unsigned long long));
+    p += ln_align256(region * sizeof(unsigned long long));
     ws.part_tok = reinterpret_cast<int*>(p);
-    p += ln_align256((size_t)tokens * sizeof(int));
+    p += ln_align256(region * sizeof(int));
     ws.part_slot = reinterpret_cast<int*>(p);
-    p += ln_align256((size_t)tokens * sizeof(int));
-    ws.bkt_hist = reinterpret_cast<int*>(p);
-    p += ln_align256((LN_BKT_MAX + 1) * sizeof(int));
-    ws.bkt_start = reinterpret_cast<int*>(p);
-    p += ln_align256((LN_BKT_MAX + 1) * sizeof(int));
-    ws.bkt_cursor = reinterpret_cast<int*>(p);
+    p += ln_align256(region * sizeof(int));
+    ws.part_pos = reinterpret_cast<int*>(p);
     return LN_OK;
 }
 
 template <int D>
-static int ln_rank_rows(const LnTable& t, const int* tok_slot, int* idx_out, long long tokens, const BuildWs& ws, hipStream_t st);
+static int ln_rank_rows(const LnTable& t, const int* tok_slot, int* idx_out, long long tokens, const BuildWs& ws, bool marked, hipStream_t st);
 
 // After the producer: slot CSR (scan of slot_cnt + fill) -> per-slot smallest token -> canonical rank.
 template <int D>
@@ -781,16 +781,18 @@ static int ln_rank_and_finalize(const LnTable& t, const int* tok_slot, const int
     const long long max_seg = ln_csr_max_segments(tokens, t.capacity);
     LN_LAUNCH("k_seg_min", k_seg_min, dim3(ln_div_up(max_seg, 256)), dim3(256), 0, st, t, csr.grp_start, csr.csr_tok, csr.seg_grp,
               csr.seg_beg, csr.seg_count);
-    return ln_rank_rows<D>(t, tok_slot, idx_out, tokens, ws, st);
+    return ln_rank_rows<D>(t, tok_slot, idx_out, tokens, ws, false, st);
 }
 
 // slot_tok (smallest token per slot) -> canonical row numbers
 template <int D>
-static int ln_rank_rows(const LnTable& t, const int* tok_slot, int* idx_out, long long tokens, const BuildWs& ws, hipStream_t st) {
-    LN_LAUNCH("k_mark_first", k_mark_first, dim3(ws.nb), dim3(256), 0, st, t, tok_slot, tokens, ws.bitmap, ws.block_cnt);
-    LN_LAUNCH("k_scan_blocks", k_scan_blocks, dim3(1), dim3(1024), 0, st, ws.block_cnt, ws.nb, ws.block_prefix, t.nr_filled);
+static int ln_rank_rows(const LnTable& t, const int* tok_slot, int* idx_out, long long tokens, const BuildWs& ws, bool marked, hipStream_t st) {
+    if (!marked)  // the bucketed build sets the first-occurrence bits itself
+        LN_LAUNCH("k_mark_first", k_mark_first, dim3(ws.nb), dim3(256), 0, st, t, tok_slot, tokens, ws.bitmap, ws.block_cnt);
+    LN_LAUNCH("k_scan_blocks", k_scan_blocks, dim3(1), dim3(1024), 0, st, marked ? (const int*)nullptr : ws.block_cnt, ws.bitmap, ws.nb,
+              ws.block_prefix, t.nr_filled);
     LN_LAUNCH("k_finalize", k_finalize<D>, dim3(ws.nb), dim3(256), 0, st, t, tok_slot, idx_out, tokens, ws.bitmap, ws.block_prefix);
-    return ln_check_launch("ln build (csr/segmin/mark/scan/finalize)");
+    return ln_check_launch("ln build (mark/scan/finalize)");
 }
 
 static int ln_check_csr(const LnCsr* c, const char* who) {
@@ -818,7 +820,8 @@ static int ln_build_points(const LnTable* t, const float* positions_raw, const f
     // the bucketed path needs a table it knows to be empty: the clear rides in this call
     const bool bucketed = n > 0 && (flags & LN_BUILD_CLEAR_FIRST) && !(flags & LN_BUILD_ATOMIC_PATH);
     if (flags & LN_BUILD_CLEAR_FIRST) {
-        rc = ln_table_clear_impl(t, clear_values, clear_values_elems, bucketed ? ws.bkt_hist : nullptr, bucketed ? LN_BKT_MAX : 0, stream);
+        rc = ln_table_clear_impl(t, clear_values, clear_values_elems, bucketed ? ws.bkt_cursor : nullptr, bucketed ? int(ws.zero_ints) : 0,
+                                 stream);
         if (rc) return rc;
     }
     if (n == 0) return LN_OK;
@@ -831,13 +834,11 @@ static int ln_build_points(const LnTable* t, const float* positions_raw, const f
             const int nbk = ln_bucket_count(t->capacity);
             const size_t lds = (size_t)sb * (sizeof(unsigned long long) + 4 * sizeof(int));
             LN_LAUNCH("k_point_keys", k_point_keys<D>, dim3(ln_div_up(n, LN_KEYS_PTS_PER_BLOCK)), dim3(256), 0, st, *t, positions_raw, sc, n, sb,
-                      nbk, ws.tok_pk, write_idx ? w : (float*)nullptr, ws.bkt_hist, vals, val_dim, distributed);
-            LN_LAUNCH("k_bucket_scan", k_bucket_scan, dim3(1), dim3(1024), 0, st, ws.bkt_hist, nbk, ws.bkt_start, ws.bkt_cursor, csr->seg_count);
-            LN_LAUNCH("k_bucket_scatter", k_bucket_scatter<D>, dim3(ln_div_up(tokens, 256 * LN_SCATTER_TOK_PER_THREAD)), dim3(256), 0, st,
-                      ws.tok_pk, tokens, t->capacity, sb, nbk, ws.bkt_start, ws.bkt_cursor, ws.part_tok, ws.part_pk);
-            LN_LAUNCH("k_bucket_build", k_bucket_build<D>, dim3(nbk), dim3(LN_BKT_THREADS), lds, st, *t, sb, nbk, ws.bkt_start, ws.part_tok,
-                      ws.part_pk, ws.part_slot, ws.tok_pos, tok_slot, *csr);
-            rc = ln_rank_rows<D>(*t, tok_slot, write_idx ? idx : (int*)nullptr, tokens, ws, st);
+                      nbk, ws.capb, ws.bkt_cursor, ws.part_tok, ws.part_pk, tok_slot, write_idx ? w : (float*)nullptr, vals, val_dim,
+                      distributed, csr->seg_count);
+            LN_LAUNCH("k_bucket_build", k_bucket_build<D>, dim3(nbk), dim3(LN_BKT_THREADS), lds, st, *t, sb, nbk, ws.capb, ws.bkt_cursor,
+                      ws.part_tok, ws.part_pk, ws.part_slot, ws.part_pos, tok_slot, *csr, ws.bitmap);
+            rc = ln_rank_rows<D>(*t, tok_slot, write_idx ? idx : (int*)nullptr, tokens, ws, true, st);
         } else {
             LN_LAUNCH("k_insert_points", k_insert_points<D>, dim3(ln_div_up(tokens, 256)), dim3(256), 0, st, *t, positions_raw, sc, n, tok_slot,
                       ws.tok_pos, write_idx ? w : (float*)nullptr, vals, val_dim, distributed);
