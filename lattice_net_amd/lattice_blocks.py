@@ -1,0 +1,364 @@
+"""Norm / activation / residual blocks and the classification head that LNN is assembled from
+(reference latticenet_py/lattice/lattice_modules.py:26-43, 424-616, 788-1360).
+
+These are compositions of the lattice operator modules (lattice_modules.py) with plain torch layers; they contain
+no kernels of their own.  Class names, constructor arguments and sub-module attribute names follow the reference so
+that model definitions and `state_dict` keys carry over (`...conv1.norm.gn.weight`, `...coarse.weight`, ...).
+Every pre-activation block is one `_PreActBlock`: optional GroupNorm -> activation -> optional channel dropout ->
+the wrapped operator; the named classes only choose the pieces.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from .lattice_funcs import GatherLattice, SliceClassifyLattice
+from .lattice_modules import CoarsenLatticeModule, ConvLatticeIm2RowModule, FinefyLatticeModule
+
+__all__ = ["DropoutLattice", "BatchNormLatticeModule", "GroupNormLatticeModule", "Conv1x1", "GnRelu1x1", "GnGelu1x1", "Gn", "ConvAct",
+           "GnReluConv", "GnGeluConv", "BnReluConv", "CoarsenAct", "GnCoarsen", "GnReluCoarsen", "GnGeluCoarsen", "FinefyAct", "GnFinefy",
+           "GnReluFinefy", "GnGeluFinefy", "ResnetBlock", "BottleneckBlock", "SliceFastCUDALatticeModule"]
+
+
+def _require_2d(lv: torch.Tensor):
+    if lv.dim() != 2:
+        raise ValueError(f"lattice values must be [nr_vertices, val_dim], got {tuple(lv.shape)}")
+
+
+class DropoutLattice(torch.nn.Module):  # mods:26-43: drops whole channels of the [M, C] value matrix
+    def __init__(self, prob: float):
+        super().__init__()
+        self.dropout = torch.nn.Dropout2d(p=prob)
+
+    def forward(self, lv):
+        _require_2d(lv)
+        return self.dropout(lv.t()[None, :, :, None])[0, :, :, 0].t()
+
+
+class BatchNormLatticeModule(torch.nn.Module):  # mods:570-583
+    def __init__(self, nr_params: int, affine: bool = True, device="cuda"):
+        super().__init__()
+        self.bn = torch.nn.BatchNorm1d(num_features=nr_params, momentum=0.1, affine=affine).to(device)
+
+    def forward(self, lattice_values, lattice_py):
+        _require_2d(lattice_values)
+        lattice_values = self.bn(lattice_values)
+        lattice_py.set_values(lattice_values)
+        return lattice_values, lattice_py
+
+
+class GroupNormLatticeModule(torch.nn.Module):  # mods:585-616: 32 groups, or C/2 groups when 32 does not divide C
+    def __init__(self, nr_params: int, affine: bool = True, device="cuda"):
+        super().__init__()
+        nr_groups = 32 if nr_params % 32 == 0 else max(int(nr_params / 2), 1)
+        self.gn = torch.nn.GroupNorm(nr_groups, nr_params, affine=affine).to(device)
+
+    def forward(self, lattice_values, lattice_py, do_set_values: bool = True):
+        _require_2d(lattice_values)
+        # GroupNorm normalises over (channels of a group) x (all vertices): [1, C, M] layout
+        lattice_values = self.gn(lattice_values.t().unsqueeze(0)).squeeze(0).t()
+        if do_set_values:
+            lattice_py.set_values(lattice_values)
+        return lattice_values, lattice_py
+
+
+class Conv1x1(torch.nn.Module):  # mods:788-804 (the linear layer is created from the first input)
+    def __init__(self, out_channels: int, bias: bool, in_channels: Optional[int] = None, device="cuda"):
+        super().__init__()
+        self.out_channels, self.use_bias, self.device = out_channels, bias, device
+        self.linear = None
+        if in_channels is not None:
+            self._make(in_channels)
+
+    def _make(self, in_channels):
+        self.linear = torch.nn.Linear(in_channels, self.out_channels, bias=self.use_bias).to(self.device)
+        torch.nn.init.kaiming_normal_(self.linear.weight, mode="fan_in", nonlinearity="relu")
+
+    def forward(self, lv):
+        if self.linear is None:
+            self._make(lv.shape[1])
+        return self.linear(lv)
+
+
+_ACTS = {"relu": lambda: torch.nn.ReLU(inplace=False), "gelu": torch.nn.GELU, "leaky": lambda: torch.nn.LeakyReLU(0.2), None: None}
+
+
+class _PreActBlock(torch.nn.Module):
+    """[norm] -> [act] -> [dropout] -> op, or op -> act when `act_after` (the *Act variants)."""
+
+    def _setup(self, in_channels, norm: Optional[str], act: Optional[str], with_dropout: bool = False, act_after: bool = False, device="cuda"):
+        if norm == "gn":
+            self.norm = GroupNormLatticeModule(in_channels, device=device)
+        elif norm == "bn":
+            self.bn = BatchNormLatticeModule(in_channels, device=device)
+        self._norm_kind = norm
+        # attribute names as in the reference: `relu` for pre-activations, `act` for post-activations
+        self._act_name = None if act is None else ("act" if act_after else "relu")
+        if act is not None:
+            setattr(self, self._act_name, _ACTS[act]())
+        self._act_after = act_after
+        self.with_dropout = with_dropout
+        if with_dropout:
+            self.drop = DropoutLattice(0.2)
+
+    def _pre(self, lv, ls):
+        ls.set_values(lv)
+        if self._norm_kind == "gn":
+            lv, ls = self.norm(lv, ls)
+        elif self._norm_kind == "bn":
+            lv, ls = self.bn(lv, ls)
+        if self._act_name is not None and not self._act_after:
+            lv = getattr(self, self._act_name)(lv)
+        if self.with_dropout:
+            lv = self.drop(lv)
+        ls.set_values(lv)
+        return lv, ls
+
+    def _post(self, lv, ls):
+        if self._act_name is not None and self._act_after:
+            lv = getattr(self, self._act_name)(lv)
+        ls.set_values(lv)
+        return lv, ls
+
+
+# ---- 1x1 (per-vertex linear) -------------------------------------------------------------------------------------
+class _Pre1x1(_PreActBlock):
+    def __init__(self, in_channels, out_channels, bias, norm, act, device="cuda"):
+        super().__init__()
+        self._setup(in_channels, norm, act, device=device)
+        self.linear = torch.nn.Linear(in_channels, out_channels, bias=bias).to(device)
+        torch.nn.init.kaiming_normal_(self.linear.weight, mode="fan_in", nonlinearity="relu")
+
+    def forward(self, lv, ls):
+        lv, ls = self._pre(lv, ls)
+        lv = self.linear(lv)
+        ls.set_values(lv)
+        return lv, ls
+
+
+class GnRelu1x1(_Pre1x1):  # mods:806-832
+    def __init__(self, in_channels, out_channels, bias, device="cuda"):
+        super().__init__(in_channels, out_channels, bias, "gn", "relu", device)
+
+
+class GnGelu1x1(_Pre1x1):  # mods:834-861 (explicit in_channels instead of lazy creation)
+    def __init__(self, in_channels, out_channels, bias, device="cuda"):
+        super().__init__(in_channels, out_channels, bias, "gn", "gelu", device)
+
+
+class Gn(_PreActBlock):  # mods:863-878
+    def __init__(self, in_channels, device="cuda"):
+        super().__init__()
+        self._setup(in_channels, "gn", None, device=device)
+
+    def forward(self, lv, ls):
+        return self._pre(lv, ls)
+
+
+# ---- same-level convolution ----------------------------------------------------------------------------------------
+class _PreConv(_PreActBlock):
+    def __init__(self, in_channels, out_channels, dilation, bias, with_dropout, norm, act, act_after=False, device="cuda"):
+        super().__init__()
+        self._setup(in_channels, norm, act, with_dropout, act_after, device)
+        self.conv = ConvLatticeIm2RowModule(in_channels=in_channels, out_channels=out_channels, neighbourhood_size=1, dilation=dilation,
+                                            bias=bias, device=device)
+
+    def forward(self, lv, ls):
+        lv, ls = self._pre(lv, ls)
+        lv_1, ls_1 = self.conv(lv, ls)
+        return self._post(lv_1, ls_1)
+
+
+class ConvAct(_PreConv):  # mods:908-933: [dropout] -> conv -> LeakyReLU(0.2)
+    def __init__(self, in_channels, out_channels, dilation, bias, with_dropout, device="cuda"):
+        super().__init__(in_channels, out_channels, dilation, bias, with_dropout, None, "leaky", True, device)
+
+
+class GnReluConv(_PreConv):  # mods:935-960
+    def __init__(self, in_channels, out_channels, dilation, bias, with_dropout, device="cuda"):
+        super().__init__(in_channels, out_channels, dilation, bias, with_dropout, "gn", "relu", False, device)
+
+
+class GnGeluConv(_PreConv):  # mods:962-986
+    def __init__(self, in_channels, out_channels, dilation, bias, with_dropout, device="cuda"):
+        super().__init__(in_channels, out_channels, dilation, bias, with_dropout, "gn", "gelu", False, device)
+
+
+class BnReluConv(_PreConv):  # mods:988-1009
+    def __init__(self, in_channels, out_channels, dilation, bias, device="cuda"):
+        super().__init__(in_channels, out_channels, dilation, bias, False, "bn", "relu", False, device)
+
+
+# ---- coarsen ---------------------------------------------------------------------------------------------------
+class _PreCoarsen(_PreActBlock):
+    def __init__(self, in_channels, out_channels, norm, act, act_after=False, device="cuda"):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self._setup(in_channels, norm, act, False, act_after, device)
+        self.coarse = CoarsenLatticeModule(in_channels=in_channels, out_channels=out_channels, device=device)
+
+    def forward(self, lv, ls, concat_connection=None):
+        lv, ls = self._pre(lv, ls)
+        lv_1, ls_1 = self.coarse(lv, ls)
+        lv_1, ls_1 = self._post(lv_1, ls_1)
+        if concat_connection is not None:
+            lv_1 = torch.cat((lv_1, concat_connection), 1)
+            ls_1.set_values(lv_1)
+        return lv_1, ls_1
+
+
+class CoarsenAct(_PreCoarsen):  # mods:1011-1041
+    def __init__(self, in_channels, out_channels, device="cuda"):
+        super().__init__(in_channels, out_channels, None, "leaky", True, device)
+
+
+class GnCoarsen(_PreCoarsen):  # mods:1043-1066
+    def __init__(self, in_channels, out_channels, device="cuda"):
+        super().__init__(in_channels, out_channels, "gn", None, False, device)
+
+
+class GnReluCoarsen(_PreCoarsen):  # mods:1068-1095
+    def __init__(self, in_channels, out_channels, device="cuda"):
+        super().__init__(in_channels, out_channels, "gn", "relu", False, device)
+
+
+class GnGeluCoarsen(_PreCoarsen):  # mods:1097-1122
+    def __init__(self, in_channels, out_channels, device="cuda"):
+        super().__init__(in_channels, out_channels, "gn", "gelu", False, device)
+
+
+# ---- finefy ----------------------------------------------------------------------------------------------------
+class _PreFinefy(_PreActBlock):
+    def __init__(self, in_channels, out_channels, norm, act, act_after=False, device="cuda"):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self._setup(in_channels, norm, act, False, act_after, device)
+        self.fine = FinefyLatticeModule(in_channels=in_channels, out_channels=out_channels, device=device)
+
+    def forward(self, lv_coarse, ls_coarse, ls_fine):
+        lv_coarse, ls_coarse = self._pre(lv_coarse, ls_coarse)
+        lv_1, ls_1 = self.fine(lv_coarse, ls_coarse, ls_fine)
+        return self._post(lv_1, ls_1)
+
+
+class FinefyAct(_PreFinefy):  # mods:1124-1150
+    def __init__(self, in_channels, out_channels, device="cuda"):
+        super().__init__(in_channels, out_channels, None, "leaky", True, device)
+
+
+class GnFinefy(_PreFinefy):  # mods:1198-1219
+    def __init__(self, in_channels, out_channels, device="cuda"):
+        super().__init__(in_channels, out_channels, "gn", None, False, device)
+
+
+class GnReluFinefy(_PreFinefy):  # mods:1152-1174
+    def __init__(self, in_channels, out_channels, device="cuda"):
+        super().__init__(in_channels, out_channels, "gn", "relu", False, device)
+
+
+class GnGeluFinefy(_PreFinefy):  # mods:1176-1196
+    def __init__(self, in_channels, out_channels, device="cuda"):
+        super().__init__(in_channels, out_channels, "gn", "gelu", False, device)
+
+
+# ---- residual blocks -----------------------------------------------------------------------------------------------
+class ResnetBlock(torch.nn.Module):  # mods:1255-1289: two pre-activation convolutions + identity
+    def __init__(self, in_channels, out_channels, dilations, biases, with_dropout, device="cuda"):
+        super().__init__()
+        self.conv1 = GnReluConv(in_channels, out_channels, dilations[0], biases[0], with_dropout=False, device=device)
+        self.conv2 = GnReluConv(in_channels, out_channels, dilations[1], biases[1], with_dropout=with_dropout, device=device)
+
+    def forward(self, lv, ls):
+        identity = lv
+        ls.set_values(lv)
+        lv, ls = self.conv1(lv, ls)
+        lv, ls = self.conv2(lv, ls)
+        lv = lv + identity
+        ls.set_values(lv)
+        return lv, ls
+
+
+class BottleneckBlock(torch.nn.Module):  # mods:1336-1361: 1x1 contract (C/4) -> conv -> 1x1 expand + identity
+    def __init__(self, in_channels, out_channels, biases, device="cuda"):
+        super().__init__()
+        self.downsample = 4
+        mid = int(out_channels / self.downsample)
+        self.contract = GnRelu1x1(in_channels=in_channels, out_channels=mid, bias=biases[0], device=device)
+        self.conv = GnReluConv(in_channels=mid, out_channels=mid, dilation=1, bias=biases[1], with_dropout=False, device=device)
+        self.expand = GnRelu1x1(in_channels=mid, out_channels=out_channels, bias=biases[2], device=device)
+
+    def forward(self, lv, ls):
+        ls.set_values(lv)
+        identity = lv
+        lv, ls = self.contract(lv, ls)
+        lv, ls = self.conv(lv, ls)
+        lv, ls = self.expand(lv, ls)
+        lv = lv + identity
+        ls.set_values(lv)
+        return lv, ls
+
+
+# ---- classification head ---------------------------------------------------------------------------------------------
+class SliceFastCUDALatticeModule(torch.nn.Module):
+    """DeformSlice head (mods:424-567): two 1x1 step-downs (C, C/2) and an 8-channel bottleneck on the lattice, gather
+    of the d+1 vertex rows per point, per-vertex barycentric offsets predicted from the max-centred gathered
+    features, then the fused slice + linear classifier (`SliceClassifyLattice`).
+
+    The reference creates `linear_deltaW`, `gamma`, `beta` and `linear_clasify` inside the first forward; their
+    shapes only depend on constructor arguments (bottleneck 8 -> 9 gathered values per vertex), so they are created
+    here, under the same names — `load_state_dict` of a reference checkpoint then works before any forward."""
+
+    def __init__(self, in_channels, nr_classes, dropout_prob, experiment, device="cuda"):
+        super().__init__()
+        self.in_channels, self.nr_classes = in_channels, nr_classes
+        self.bottleneck_size = 8
+        self.dropout_prob = dropout_prob
+        self.experiment = experiment
+        self.tanh = torch.nn.Tanh()
+        if dropout_prob > 0.0:
+            self.dropout = DropoutLattice(dropout_prob)
+        self.stepdown = torch.nn.ModuleList([])
+        cur = in_channels
+        for i in range(2):
+            nr_out = int(in_channels / (2 ** i))
+            if nr_out < self.bottleneck_size:
+                raise ValueError(f"{in_channels} input channels are too few for two step-downs above a bottleneck of {self.bottleneck_size}")
+            self.stepdown.append(GnRelu1x1(cur, nr_out, False, device=device))
+            cur = nr_out
+        self.bottleneck = GnRelu1x1(cur, self.bottleneck_size, False, device=device)
+        per_vertex = self.bottleneck_size + 1  # gather appends the barycentric weight to every vertex row (LG:2901-2925)
+        self.linear_deltaW = torch.nn.Linear(per_vertex, 1, bias=True).to(device)
+        with torch.no_grad():
+            torch.nn.init.kaiming_uniform_(self.linear_deltaW.weight, mode="fan_in", nonlinearity="tanh")
+            self.linear_deltaW.weight *= 0.1  # start close to "no deformation"
+            torch.nn.init.zeros_(self.linear_deltaW.bias)
+        self.gamma = torch.nn.Parameter(torch.ones(per_vertex, device=device))
+        self.beta = torch.nn.Parameter(torch.zeros(per_vertex, device=device))
+        self.linear_clasify = torch.nn.Linear(in_channels, nr_classes, bias=True).to(device)
+        with torch.no_grad():  # utils.leaky_relu_init(m, 1.0) (utils.py:381-462): U(-b, b), b = sqrt(3)*sqrt(2/(n_in+n_out)); zero bias
+            torch.nn.init.xavier_uniform_(self.linear_clasify.weight, gain=1.0)
+            torch.nn.init.zeros_(self.linear_clasify.bias)
+
+    def forward(self, lv, ls, positions, splatting_indices, splatting_weights):
+        ls.set_values(lv)
+        assert self.in_channels == ls.val_dim(), f"in_channels {self.in_channels} != lattice val_dim {ls.val_dim()}"
+        nr_positions = positions.shape[0]
+        lv_b, ls_b = lv, ls
+        for step in self.stepdown:
+            lv_b, ls_b = step(lv_b, ls_b)
+        lv_b, ls_b = self.bottleneck(lv_b, ls_b)
+        gathered = GatherLattice.apply(lv_b, ls_b, positions, splatting_indices, splatting_weights)
+        nr_vertices_per_simplex = ls.pos_dim() + 1
+        per_vertex = gathered.shape[1] // nr_vertices_per_simplex
+        gathered = gathered.view(nr_positions, nr_vertices_per_simplex, per_vertex)
+        max_vals = gathered.max(1, keepdim=True)[0]
+        gathered = gathered - (self.gamma * max_vals + self.beta)
+        delta_weights = self.linear_deltaW(gathered).reshape(nr_positions, nr_vertices_per_simplex)
+        if self.experiment == "slice_no_deform":
+            delta_weights = delta_weights * 0
+        if self.dropout_prob > 0.0:
+            lv = self.dropout(lv)
+        ls.set_values(lv)
+        return SliceClassifyLattice.apply(lv, ls, positions, delta_weights, self.linear_clasify.weight, self.linear_clasify.bias,
+                                          self.nr_classes, splatting_indices, splatting_weights)

@@ -1,0 +1,117 @@
+"""cfg reader for the `model:` block and the LNN assembly (channel bookkeeping and state_dict key
+names as in reference latticenet_py/lattice/models.py:70-197).  CPU only: no kernels run here."""
+import textwrap
+
+import pytest
+import torch
+
+from lattice_net_amd.model_params import ModelParams, read_cfg_block
+
+KITTI_TINY = textwrap.dedent("""
+    core: { loguru_verbosity: 3 }
+    model: {
+        //SHOULD BE USED WITH A SIGMA OF 0.6
+        // pointnet_layers: [16,32,64]
+        positions_mode: "xyz"
+        values_mode: "none"
+        pointnet_layers: [16,32]
+        pointnet_start_nr_channels: 32
+        nr_downsamples: 2
+        nr_blocks_down_stage: [1,1,1]
+        nr_blocks_bottleneck: 1
+        nr_blocks_up_stage: [1,1,1]
+        nr_levels_down_with_normal_resnet: 3
+        nr_levels_up_with_normal_resnet: 3
+        compression_factor: 1.0
+        dropout_last_layer: 0.0
+        experiment: "none" // a comment with a "quote"
+    }
+    lattice_gpu: {
+        hash_table_capacity: 100000 //good for kitti
+        nr_sigmas: 1
+        sigma_0: "0.9 3" //sigma of X affecting Y dimensions
+    }
+""")
+
+
+@pytest.fixture
+def cfg_path(tmp_path):
+    p = tmp_path / "net.cfg"
+    p.write_text(KITTI_TINY)
+    return str(p)
+
+
+def test_model_block_is_parsed_with_both_pointnet_spellings(cfg_path, tmp_path):
+    mp = ModelParams.create(cfg_path)
+    assert mp.positions_mode() == "xyz" and mp.values_mode() == "none"
+    assert mp.pointnet_channels_per_layer() == [16, 32]
+    assert mp.pointnet_start_nr_channels() == 32
+    assert mp.nr_downsamples() == 2
+    assert mp.nr_blocks_down_stage() == [1, 1, 1] and mp.nr_blocks_up_stage() == [1, 1, 1]
+    assert mp.nr_blocks_bottleneck() == 1
+    assert mp.nr_levels_down_with_normal_resnet() == 3 and mp.nr_levels_up_with_normal_resnet() == 3
+    assert mp.compression_factor() == 1.0 and mp.dropout_last_layer() == 0.0
+    p2 = tmp_path / "other.cfg"
+    p2.write_text(KITTI_TINY.replace("pointnet_layers: [16,32]", "pointnet_channels_per_layer: [8, 16, 24]"))
+    assert ModelParams.create(str(p2)).pointnet_channels_per_layer() == [8, 16, 24]
+
+
+def test_cfg_reader_handles_comments_strings_and_missing_blocks(cfg_path):
+    lat = read_cfg_block(cfg_path, "lattice_gpu")
+    assert lat == {"hash_table_capacity": 100000, "nr_sigmas": 1, "sigma_0": "0.9 3"}
+    with pytest.raises(ValueError, match="no `train` block"):
+        read_cfg_block(cfg_path, "train")
+    with pytest.raises(KeyError, match="values_mode"):
+        import os
+        bad = os.path.join(os.path.dirname(cfg_path), "bad.cfg")
+        open(bad, "w").write(KITTI_TINY.replace('values_mode: "none"', ""))
+        ModelParams.create(bad)
+
+
+def test_lattice_create_reads_the_same_file(cfg_path):
+    from lattice_net_amd import Lattice
+    lat = Lattice.create(cfg_path, "lattice")
+    assert lat.capacity() == 100000 and lat.name() == "lattice" and list(lat.sigmas_tensor().cpu().numpy()) == [pytest.approx(0.9)] * 3
+    assert Lattice.get_expected_filter_extent(1) == 9
+
+
+def test_lnn_assembly_channels_and_state_dict_names(cfg_path):
+    from lattice_net_amd.models import LNN
+    torch.manual_seed(0)
+    net = LNN(20, ModelParams.create(cfg_path), device="cpu")
+    # 32 -> coarsen 64 -> coarsen 128 | finefy 64 (+64 skip = 128) | finefy 64 (+32 skip = 96) -> head on 96 channels
+    assert [c.coarse.weight.shape for c in net.coarsens_list] == [(9 * 32, 64), (9 * 64, 128)]
+    assert [f.fine.weight.shape for f in net.finefy_list] == [(9 * 128, 64), (9 * 128, 64)]
+    assert net.slice_fast_cuda.in_channels == 96
+    assert [s.linear.weight.shape for s in net.slice_fast_cuda.stepdown] == [(96, 96), (48, 96)]
+    assert net.slice_fast_cuda.bottleneck.linear.weight.shape == (8, 48)
+    assert net.slice_fast_cuda.linear_clasify.weight.shape == (20, 96)
+    assert net.slice_fast_cuda.linear_deltaW.weight.shape == (1, 9)
+    # group norm: 32 groups when divisible, else C/2 (mods:585-599)
+    assert net.slice_fast_cuda.stepdown[1].norm.gn.num_groups == 32 and net.slice_fast_cuda.bottleneck.norm.gn.num_groups == 24
+    keys = set(net.state_dict().keys())
+    for k in ["point_net.last_conv.weight", "point_net.last_conv.bias",
+              "resnet_blocks_per_down_lvl_list.0.0.conv1.norm.gn.weight", "resnet_blocks_per_down_lvl_list.0.0.conv1.conv.weight",
+              "resnet_blocks_per_down_lvl_list.1.0.conv2.conv.weight", "coarsens_list.1.coarse.weight",
+              "resnet_blocks_bottleneck.0.contract.linear.weight", "resnet_blocks_bottleneck.0.conv.conv.weight",
+              "resnet_blocks_bottleneck.0.expand.norm.gn.bias", "finefy_list.0.norm.gn.weight", "finefy_list.1.fine.weight",
+              "resnet_blocks_per_up_lvl_list.1.0.conv2.conv.bias", "slice_fast_cuda.stepdown.0.linear.weight",
+              "slice_fast_cuda.bottleneck.norm.gn.weight", "slice_fast_cuda.linear_deltaW.bias", "slice_fast_cuda.gamma",
+              "slice_fast_cuda.beta", "slice_fast_cuda.linear_clasify.weight"]:
+        assert k in keys, k
+    # only the last convolution of the decoder carries a bias (models.py:176)
+    assert "resnet_blocks_per_up_lvl_list.0.0.conv2.conv.bias" not in keys
+    assert "resnet_blocks_per_down_lvl_list.0.0.conv1.conv.bias" not in keys
+
+
+def test_blocks_reject_non_matrix_values():
+    from lattice_net_amd.lattice_blocks import DropoutLattice, GroupNormLatticeModule
+    with pytest.raises(ValueError):
+        DropoutLattice(0.1)(torch.zeros(3))
+    with pytest.raises(ValueError):
+        GroupNormLatticeModule(8, device="cpu")(torch.zeros(2, 3, 8), None)
+    gn = GroupNormLatticeModule(8, device="cpu")
+    x = torch.randn(50, 8)
+    y, _ = gn(x, None, do_set_values=False)
+    ref = torch.nn.functional.group_norm(x.t().unsqueeze(0), gn.gn.num_groups, gn.gn.weight, gn.gn.bias).squeeze(0).t()
+    assert torch.allclose(y, ref)

@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Whole-network timing: LNN forward + backward + AdamW step on one synthetic LiDAR-like scan with
+the reference's SemanticKITTI model shape (config/lnn_train_semantic_kitti.cfg:36-47,62-69).  Secondary number; the
+headline metric stays bench.py's op chain."""
+import argparse
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from lattice_net_amd import Lattice, ModelParams, synthetic  # noqa: E402
+from lattice_net_amd.models import LNN  # noqa: E402
+
+CFG = """
+model: {
+    positions_mode: "xyz"
+    values_mode: "none"
+    pointnet_layers: [16,32]
+    pointnet_start_nr_channels: 32
+    nr_downsamples: 2
+    nr_blocks_down_stage: [1,1,1]
+    nr_blocks_bottleneck: 1
+    nr_blocks_up_stage: [1,1,1]
+    nr_levels_down_with_normal_resnet: 3
+    nr_levels_up_with_normal_resnet: 3
+    compression_factor: 1.0
+    dropout_last_layer: 0.0
+}
+lattice_gpu: {
+    hash_table_capacity: 100000
+    nr_sigmas: 1
+    sigma_0: "0.9 3"
+}
+"""
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=120000)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--classes", type=int, default=20)
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    with tempfile.NamedTemporaryFile("w", suffix=".cfg", delete=False) as f:
+        f.write(CFG)
+        path = f.name
+    torch.manual_seed(0)
+    torch.autograd.set_multithreading_enabled(False)
+    mp = ModelParams.create(path)
+    lattice = Lattice.create(path, "lattice")
+    net = LNN(args.classes, mp)
+    pos = torch.from_numpy(synthetic.lidar_cloud(args.n, 0)).to(dev)
+    vals = torch.zeros((args.n, 1), device=dev)
+    target = torch.from_numpy(np.random.default_rng(0).integers(0, args.classes, args.n)).to(dev)
+    opt = None
+
+    def step():
+        nonlocal opt
+        logsoftmax, _ = net(lattice, pos, vals)
+        loss = torch.nn.functional.nll_loss(logsoftmax, target)
+        if opt is None:  # parameters of the PointNet MLP exist only after the first forward (ln_train.py:162-165)
+            opt = torch.optim.AdamW(net.parameters(), lr=1e-3, weight_decay=1e-4, amsgrad=True)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    nparams = sum(p.numel() for p in net.parameters())
+    print(f"LNN train step: {dt * 1e3:.2f} ms  ({args.n / dt / 1e6:.2f} Mpoints/s), {nparams} parameters, loss {loss.item():.4f}")
+
+
+if __name__ == "__main__":
+    main()
