@@ -45,7 +45,8 @@ __device__ __forceinline__ void ln_load_quarter(const float* __restrict__ src, f
 template <int V, int NT, bool FLIP, bool WT>
 __global__ void __launch_bounds__(256)
     k_conv_mfma(const int* __restrict__ nbr, const float* __restrict__ values, const float* __restrict__ filter, int m, int E,
-                float* __restrict__ out) {
+                float* __restrict__ out, int f_total, int f_off) {
+    // computes output columns [f_off, f_off + 16*NT) of an [.., f_total]-wide convolution
     constexpr int F = 16 * NT;
     constexpr int KQ = V / 4;
     __shared__ __attribute__((aligned(16))) float s_b[V * F];  // W_e in fragment order [(kk*NT+nt)*64 + lane]
@@ -73,13 +74,13 @@ __global__ void __launch_bounds__(256)
             for (int k = 0; k < KQ; ++k) a[k] = 0.f;
         }
         __syncthreads();  // previous iteration's reads of s_b are done
-        const float* w_e = filter + (size_t)e * V * F;
         for (int x = tid; x < V * F; x += 256) {
             const int k = WT ? (x % V) : (x / F);
             const int f = WT ? (x / V) : (x - k * F);
             const int qq = k / KQ;
             const int kk = k - qq * KQ;
-            s_b[((kk * NT) + (f >> 4)) * 64 + qq * 16 + (f & 15)] = w_e[x];
+            const size_t src = WT ? ((size_t)e * f_total + f_off + f) * V + k : ((size_t)e * V + k) * f_total + f_off + f;
+            s_b[((kk * NT) + (f >> 4)) * 64 + qq * 16 + (f & 15)] = filter[src];
         }
         __syncthreads();
 #pragma unroll
@@ -97,7 +98,7 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = m0 + q * 4 + r;
-            if (row < m) out[(size_t)row * F + nt * 16 + i] = acc[nt][r];
+            if (row < m) out[(size_t)row * f_total + f_off + nt * 16 + i] = acc[nt][r];
         }
     }
 }
@@ -223,17 +224,31 @@ __global__ void __launch_bounds__(256)
     out[g] = acc;
 }
 
+// Output columns are produced in chunks of 16*NT (NT in {8, 4, 2, 1}; the per-slot filter slice V x 16NT must fit LDS),
+// so any nr_filters that is a multiple of 16 runs on the matrix cores.
 template <int V, bool FLIP, bool WT>
-static bool ln_conv_launch_v(int nt, const int* nbr, const float* values, const float* filter, int m, int E, float* out,
+static bool ln_conv_launch_v(int nr_filters, const int* nbr, const float* values, const float* filter, int m, int E, float* out,
                              hipStream_t st) {
     const dim3 grid(ln_div_up(m, 64)), block(256);
-    switch (nt) {
-        case 1: LN_LAUNCH("k_conv_mfma", (k_conv_mfma<V, 1, FLIP, WT>), grid, block, 0, st, nbr, values, filter, m, E, out); return true;
-        case 2: LN_LAUNCH("k_conv_mfma", (k_conv_mfma<V, 2, FLIP, WT>), grid, block, 0, st, nbr, values, filter, m, E, out); return true;
-        case 4: LN_LAUNCH("k_conv_mfma", (k_conv_mfma<V, 4, FLIP, WT>), grid, block, 0, st, nbr, values, filter, m, E, out); return true;
-        case 8: if constexpr (V <= 64) { LN_LAUNCH("k_conv_mfma", (k_conv_mfma<V, 8, FLIP, WT>), grid, block, 0, st, nbr, values, filter, m, E, out); return true; } return false;
-        default: return false;
+    constexpr int NT_MAX = (V * 16 * 8 * 4 <= 32 * 1024) ? 8 : ((V * 16 * 4 * 4 <= 48 * 1024) ? 4 : 2);
+    int f_off = 0;
+    while (f_off < nr_filters) {
+        const int left = (nr_filters - f_off) / 16;
+        if (NT_MAX >= 8 && left >= 8) {
+            if constexpr (NT_MAX >= 8) LN_LAUNCH("k_conv_mfma", (k_conv_mfma<V, 8, FLIP, WT>), grid, block, 0, st, nbr, values, filter, m, E, out, nr_filters, f_off);
+            f_off += 128;
+        } else if (NT_MAX >= 4 && left >= 4) {
+            if constexpr (NT_MAX >= 4) LN_LAUNCH("k_conv_mfma", (k_conv_mfma<V, 4, FLIP, WT>), grid, block, 0, st, nbr, values, filter, m, E, out, nr_filters, f_off);
+            f_off += 64;
+        } else if (left >= 2) {
+            LN_LAUNCH("k_conv_mfma", (k_conv_mfma<V, 2, FLIP, WT>), grid, block, 0, st, nbr, values, filter, m, E, out, nr_filters, f_off);
+            f_off += 32;
+        } else {
+            LN_LAUNCH("k_conv_mfma", (k_conv_mfma<V, 1, FLIP, WT>), grid, block, 0, st, nbr, values, filter, m, E, out, nr_filters, f_off);
+            f_off += 16;
+        }
     }
+    return true;
 }
 
 template <bool FLIP, bool WT>
@@ -251,14 +266,18 @@ static int ln_conv_dispatch(const int* nbr, const float* values_neigh, const flo
         LN_CONV_FULL(8, 2) LN_CONV_FULL(8, 4) LN_CONV_FULL(8, 8)
 #undef LN_CONV_FULL
     }
-    if (!done && nr_filters % 16 == 0) {
-        const int nt = nr_filters / 16;
+    if (!done && nr_filters % 16 == 0 && (reinterpret_cast<uintptr_t>(values_neigh) & 15) == 0) {
+        const int nf = nr_filters;
         switch (val_dim) {
-            case 8: done = ln_conv_launch_v<8, FLIP, WT>(nt, nbr, values_neigh, filter, m, filter_extent, out, st); break;
-            case 16: done = ln_conv_launch_v<16, FLIP, WT>(nt, nbr, values_neigh, filter, m, filter_extent, out, st); break;
-            case 32: done = ln_conv_launch_v<32, FLIP, WT>(nt, nbr, values_neigh, filter, m, filter_extent, out, st); break;
-            case 64: done = ln_conv_launch_v<64, FLIP, WT>(nt, nbr, values_neigh, filter, m, filter_extent, out, st); break;
-            case 128: done = ln_conv_launch_v<128, FLIP, WT>(nt, nbr, values_neigh, filter, m, filter_extent, out, st); break;
+            case 8: done = ln_conv_launch_v<8, FLIP, WT>(nf, nbr, values_neigh, filter, m, filter_extent, out, st); break;
+            case 16: done = ln_conv_launch_v<16, FLIP, WT>(nf, nbr, values_neigh, filter, m, filter_extent, out, st); break;
+            case 32: done = ln_conv_launch_v<32, FLIP, WT>(nf, nbr, values_neigh, filter, m, filter_extent, out, st); break;
+            case 48: done = ln_conv_launch_v<48, FLIP, WT>(nf, nbr, values_neigh, filter, m, filter_extent, out, st); break;
+            case 64: done = ln_conv_launch_v<64, FLIP, WT>(nf, nbr, values_neigh, filter, m, filter_extent, out, st); break;
+            case 96: done = ln_conv_launch_v<96, FLIP, WT>(nf, nbr, values_neigh, filter, m, filter_extent, out, st); break;
+            case 128: done = ln_conv_launch_v<128, FLIP, WT>(nf, nbr, values_neigh, filter, m, filter_extent, out, st); break;
+            case 192: done = ln_conv_launch_v<192, FLIP, WT>(nf, nbr, values_neigh, filter, m, filter_extent, out, st); break;
+            case 256: done = ln_conv_launch_v<256, FLIP, WT>(nf, nbr, values_neigh, filter, m, filter_extent, out, st); break;
             default: break;
         }
     }
@@ -302,7 +321,8 @@ extern "C" int ln_conv_forward(const int* nbr, const float* values_neigh, const 
 template <int VT, int FT>
 __global__ void __launch_bounds__(256)
     k_grad_filter_mfma(const int* __restrict__ nbr, const float* __restrict__ values, const float* __restrict__ grad_out, int m,
-                       int E, float* __restrict__ partial) {
+                       int E, float* __restrict__ partial, int v_total, int v_off, int f_total, int f_off) {
+    // rows [v_off, v_off + 16*VT) x columns [f_off, f_off + 16*FT) of every slot's [v_total, f_total] block
     constexpr int V = VT * 16;
     constexpr int F = FT * 16;
     constexpr int SA = V + 16;  // LDS row strides (floats), = 16 mod 32
@@ -338,7 +358,7 @@ __global__ void __launch_bounds__(256)
             const int c = x4 - r * (V / 4);
             const int row = sub_begin + r;
             const int nb = (row < chunk_end) ? nbr[(size_t)row * E + e] : -1;
-            ra[s] = reinterpret_cast<const float4*>(values)[(size_t)(nb >= 0 ? nb : 0) * (V / 4) + c];
+            ra[s] = *reinterpret_cast<const float4*>(values + (size_t)(nb >= 0 ? nb : 0) * v_total + v_off + c * 4);
             if (nb < 0) ra[s] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
@@ -347,7 +367,8 @@ __global__ void __launch_bounds__(256)
             const int r = x4 / (F / 4);
             const int c = x4 - r * (F / 4);
             const int row = sub_begin + r;
-            rg[s] = (row < chunk_end) ? reinterpret_cast<const float4*>(grad_out)[(size_t)row * (F / 4) + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            rg[s] = (row < chunk_end) ? *reinterpret_cast<const float4*>(grad_out + (size_t)row * f_total + f_off + c * 4)
+                                      : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     if (chunk_begin < chunk_end) issue_loads(chunk_begin);
@@ -385,7 +406,7 @@ __global__ void __launch_bounds__(256)
             }
         }
     }
-    float* dst = partial + ((size_t)blockIdx.x * E + e) * (V * F);
+    float* dst = partial + ((size_t)blockIdx.x * E + e) * ((size_t)v_total * f_total) + (size_t)v_off * f_total + f_off;
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
         const int tile = wave + 4 * t;
@@ -393,7 +414,7 @@ __global__ void __launch_bounds__(256)
             const int vt = tile / FT;
             const int ft = tile - vt * FT;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dst[(vt * 16 + q * 4 + r) * F + ft * 16 + i] = acc[t][0][r] + acc[t][1][r];
+            for (int r = 0; r < 4; ++r) dst[(size_t)(vt * 16 + q * 4 + r) * f_total + ft * 16 + i] = acc[t][0][r] + acc[t][1][r];
         }
     }
 }
@@ -435,11 +456,8 @@ __global__ void __launch_bounds__(256) k_reduce_slabs(const float* __restrict__ 
     }
 }
 
-static bool ln_gf_mfma_supported(int val_dim, int nr_filters) {
-    const bool v_ok = (val_dim == 16 || val_dim == 32 || val_dim == 64);
-    const bool f_ok = (nr_filters == 16 || nr_filters == 32 || nr_filters == 64);
-    return v_ok && f_ok && (val_dim / 16) * (nr_filters / 16) <= 16;
-}
+// Any multiple of 16 in both dimensions: the [V, F] block of a slot is covered by sub-blocks of {64, 32, 16} x {64, 32, 16}.
+static bool ln_gf_mfma_supported(int val_dim, int nr_filters) { return val_dim % 16 == 0 && nr_filters % 16 == 0; }
 
 extern "C" size_t ln_conv_grad_filter_workspace_bytes(int m, int filter_extent, int val_dim, int nr_filters) {
     if (!ln_gf_mfma_supported(val_dim, nr_filters) || m <= 0) return 256;
@@ -463,13 +481,25 @@ extern "C" int ln_conv_grad_filter(const int* nbr, const float* values_neigh, co
         float* partial = static_cast<float*>(workspace);
         const int chunks = ln_div_up(m, LN_GF_ROWS);
         const dim3 grid(chunks, filter_extent), block(256);
-        const int vt = val_dim / 16, ft = nr_filters / 16;
-#define LN_GF_CASE(A, B)                                                                                                    \
-    if (vt == A && ft == B)                                                                                                 \
-        LN_LAUNCH("k_grad_filter_mfma", (k_grad_filter_mfma<A, B>), grid, block, 0, st, nbr, values_neigh, grad_out, m, filter_extent, partial);
-        LN_GF_CASE(1, 1) LN_GF_CASE(1, 2) LN_GF_CASE(1, 4) LN_GF_CASE(2, 1) LN_GF_CASE(2, 2) LN_GF_CASE(2, 4) LN_GF_CASE(4, 1)
-        LN_GF_CASE(4, 2) LN_GF_CASE(4, 4)
+        LN_REQUIRE((reinterpret_cast<uintptr_t>(values_neigh) & 15) == 0 && (reinterpret_cast<uintptr_t>(grad_out) & 15) == 0, LN_ERR_ARG,
+                   "ln_conv_grad_filter: values / grad_out must be 16-byte aligned");
+        for (int v_off = 0; v_off < val_dim;) {
+            const int vleft = (val_dim - v_off) / 16;
+            const int vt = vleft >= 4 ? 4 : (vleft >= 2 ? 2 : 1);
+            for (int f_off = 0; f_off < nr_filters;) {
+                const int fleft = (nr_filters - f_off) / 16;
+                const int ft = fleft >= 4 ? 4 : (fleft >= 2 ? 2 : 1);
+#define LN_GF_CASE(A, B)                                                                                                          \
+    if (vt == A && ft == B)                                                                                                       \
+        LN_LAUNCH("k_grad_filter_mfma", (k_grad_filter_mfma<A, B>), grid, block, 0, st, nbr, values_neigh, grad_out, m, filter_extent, \
+                  partial, val_dim, v_off, nr_filters, f_off);
+                LN_GF_CASE(1, 1) LN_GF_CASE(1, 2) LN_GF_CASE(1, 4) LN_GF_CASE(2, 1) LN_GF_CASE(2, 2) LN_GF_CASE(2, 4) LN_GF_CASE(4, 1)
+                LN_GF_CASE(4, 2) LN_GF_CASE(4, 4)
 #undef LN_GF_CASE
+                f_off += ft * 16;
+            }
+            v_off += vt * 16;
+        }
         // slabs are laid out [chunk][e][V*F]; summing over chunks with stride E*V*F
         LN_LAUNCH("k_reduce_slabs", k_reduce_slabs, dim3(ln_div_up(total, 16)), dim3(256), 0, st, partial, chunks, total, grad_filter);
     } else {

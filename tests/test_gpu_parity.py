@@ -277,7 +277,10 @@ def test_incremental_build_keeps_existing_rows():
     np.testing.assert_array_equal(N(lat.hash_table().m_keys_tensor[: t.nr_filled]), t.keys[: t.nr_filled])
 
 
-@pytest.mark.parametrize("v,f", [(32, 32), (64, 32), (32, 64), (16, 16), (8, 16), (128, 64), (4, 8), (5, 3), (1, 32)])
+@pytest.mark.parametrize("v,f", [(32, 32), (64, 32), (32, 64), (16, 16), (8, 16), (128, 64), (4, 8), (5, 3), (1, 32),
+                                 # the LNN shapes (models.py:125-190 with the SemanticKITTI cfg) and other multiples of 16:
+                                 # column-chunked launches of the MFMA kernels
+                                 (96, 96), (128, 128), (64, 128), (48, 80), (192, 48), (256, 32), (32, 160)])
 def test_conv_forward_and_filter_gradient(v, f):
     from lattice_net_amd.synthetic import cube_cloud
     pos = cube_cloud(3000, 5)
@@ -308,7 +311,8 @@ def test_conv_forward_and_filter_gradient(v, f):
     close(N(gf), ref, scale=scale)
 
 
-def test_conv_autograd_matches_dense_reference():
+@pytest.mark.parametrize("v,f", [(32, 32), (96, 64), (128, 128), (48, 96)])
+def test_conv_autograd_matches_dense_reference(v, f):
     """ConvIm2RowLattice fwd+bwd against autograd through the explicit im2row matrix (fp64)."""
     from lattice_net_amd import ConvIm2RowLattice
     from lattice_net_amd.synthetic import cube_cloud
@@ -317,7 +321,6 @@ def test_conv_autograd_matches_dense_reference():
     lat.begin_splat()
     lat.just_create_verts(T(pos), False)
     m = lat.nr_lattice_vertices()
-    v, f = 32, 32
     rng = np.random.default_rng(0)
     vals = torch.tensor(rng.standard_normal((m, v)).astype(np.float32), device=dev(), requires_grad=True)
     W = torch.tensor((rng.standard_normal((9 * v, f)) / 17).astype(np.float32), device=dev(), requires_grad=True)
