@@ -216,11 +216,17 @@ int ln_gather_backward(const float* grad_gathered, const int* idx, const float* 
 int ln_slice_classify_forward(const float* values, const float* delta_w, const float* lin_w, const float* lin_b,
                               const int* idx, const float* w, int n, int pos_dim, int val_dim, int nr_classes,
                               float* logits, void* stream);
-/* slice_classify_backwards_with_precomputation (LatticeGPU.cuh:3628-3756); the four gradient
- * buffers are caller-allocated and zeroed (lattice_funcs.py:554-557). */
+/* slice_classify_backwards_with_precomputation (LatticeGPU.cuh:3628-3756).  g_delta_w, g_lin_w, g_lin_b are
+ * caller-allocated, zeroed (lattice_funcs.py:554-557) and accumulated into.  The gradient wrt the lattice values
+ * is a scatter of grad_sliced[n, V] (= dL/d sliced features, written here) with weights w_eff[n*(d+1)] (= w +
+ * delta_w, written here): pass g_values = NULL and run ln_csr_reduce_rows(csr, grp_row, .., grad_sliced, w_eff, V,
+ * d+1, V, g_values) on the adjacency of `idx` (no atomics), or pass g_values (zeroed [M, V]) to have it scattered
+ * here with global atomics.  workspace: ln_slice_classify_backward_workspace_bytes. */
+size_t ln_slice_classify_backward_workspace_bytes(int n, int pos_dim, int val_dim, int nr_classes);
 int ln_slice_classify_backward(const float* grad_logits, const float* values, const float* delta_w, const float* lin_w,
                                const int* idx, const float* w, int n, int pos_dim, int val_dim, int nr_classes,
-                               float* g_values, float* g_delta_w, float* g_lin_w, float* g_lin_b, void* stream);
+                               float* g_values, float* g_delta_w, float* g_lin_w, float* g_lin_b, float* grad_sliced,
+                               float* w_eff, void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

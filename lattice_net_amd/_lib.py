@@ -93,7 +93,8 @@ SIGNATURES = {
     "ln_gather_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "ln_gather_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "ln_slice_classify_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
-    "ln_slice_classify_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "ln_slice_classify_backward_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "ln_slice_classify_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
 }
 
 _lib = None

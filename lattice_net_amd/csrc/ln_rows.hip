@@ -294,30 +294,62 @@ extern "C" int ln_row2im(const int* nbr, const float* rowified, int m, int filte
 }
 
 // ------------------------------------------------------------------------------------------
-// fused slice + linear classifier (LatticeGPU.cuh:3405-3460): one thread per (point, class)
+// fused slice + linear classifier (LatticeGPU.cuh:3405-3460, 3648-3751)
 // ------------------------------------------------------------------------------------------
+// A workgroup walks tiles of PB points.  The sliced features h[PB, V] (barycentric weights w + delta_w) are
+// computed ONCE per point into LDS — the reference recomputes the d+1 row gathers for every class — next to the
+// classifier W[C, V] (row stride V+1: conflict-free when lanes run over classes).  The per-(point, class) sums
+// keep the reference's order (rows r ascending, then channels v ascending; separate multiply and add), so the
+// logits are bit-identical to the serial evaluation.
+template <int PB>
 __global__ void __launch_bounds__(256)
     k_slice_classify_forward(const float* __restrict__ values, const float* __restrict__ delta_w, const float* __restrict__ lin_w,
-                             const float* __restrict__ lin_b, const int* __restrict__ idx, const float* __restrict__ w,
-                             long long work, int dp1, int V, int C, float* __restrict__ logits) {
-    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= work) return;
-    const long long p = g / C;
-    const int c = int(g - p * C);
-    int rows[LN_MAX_POS_DIM + 1];
-    float wts[LN_MAX_POS_DIM + 1];
-    for (int r = 0; r < dp1; ++r) {
-        rows[r] = idx[p * dp1 + r];
-        wts[r] = w[p * dp1 + r] + delta_w[p * dp1 + r];
+                             const float* __restrict__ lin_b, const int* __restrict__ idx, const float* __restrict__ w, int n,
+                             int dp1, int V, int C, float* __restrict__ logits) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_w = smem;                 // [C, V+1]
+    float* s_h = s_w + C * (V + 1);    // [PB, V]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < C * V; i += 256) {
+        const int c = i / V;
+        s_w[c * (V + 1) + (i - c * V)] = lin_w[i];
     }
-    float acc = 0.0f;
-    for (int v = 0; v < V; ++v) {
-        float h = 0.0f;
-        for (int r = 0; r < dp1; ++r)
-            if (rows[r] >= 0) h = h + values[(size_t)rows[r] * V + v] * wts[r];
-        acc = acc + lin_w[(size_t)c * V + v] * h;
+    const int tiles = (n + PB - 1) / PB;
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const long long p0 = (long long)tile * PB;
+        __syncthreads();  // s_w staged / previous tile's s_h consumed
+        for (int i = tid; i < PB * V; i += 256) {
+            const int lp = i / V, v = i - lp * V;
+            const long long p = p0 + lp;
+            float h = 0.0f;
+            if (p < n) {
+                for (int r = 0; r < dp1; ++r) {
+                    const int row = idx[p * dp1 + r];
+                    if (row >= 0) h = h + values[(size_t)row * V + v] * (w[p * dp1 + r] + delta_w[p * dp1 + r]);
+                }
+            }
+            s_h[i] = h;
+        }
+        __syncthreads();
+        for (int o = tid; o < PB * C; o += 256) {
+            const int lp = o / C, c = o - lp * C;
+            const long long p = p0 + lp;
+            if (p >= n) continue;
+            float acc = 0.0f;
+            const float* hw = s_h + lp * V;
+            const float* ww = s_w + c * (V + 1);
+            for (int v = 0; v < V; ++v) acc = acc + ww[v] * hw[v];
+            logits[p * C + c] = acc + lin_b[c];
+        }
     }
-    logits[g] = acc + lin_b[c];
+}
+
+static int ln_sc_points_per_tile(int V, int C, int arrays_of_v) {  // largest PB in {64,32,16,8} whose tiles fit 64 KiB of LDS
+    for (int pb = 64; pb >= 8; pb >>= 1) {
+        const size_t lds = sizeof(float) * ((size_t)C * (V + 1) + (size_t)pb * ((size_t)arrays_of_v * V + C));
+        if (lds <= 64 * 1024) return pb;
+    }
+    return 0;
 }
 
 extern "C" int ln_slice_classify_forward(const float* values, const float* delta_w, const float* lin_w, const float* lin_b,
@@ -327,94 +359,185 @@ extern "C" int ln_slice_classify_forward(const float* values, const float* delta
     if (rc) return rc;
     LN_REQUIRE(nr_classes >= 1 && (n == 0 || (delta_w && lin_w && lin_b && w)), LN_ERR_ARG, "ln_slice_classify_forward: bad args");
     if (n == 0) return LN_OK;
-    const long long work = (long long)n * nr_classes;
-    LN_LAUNCH("k_slice_classify_forward", k_slice_classify_forward, dim3(ln_div_up(work, 256)), dim3(256), 0, (hipStream_t)stream, values, delta_w, lin_w,
-                       lin_b, idx, w, work, pos_dim + 1, val_dim, nr_classes, logits);
+    const int pb = ln_sc_points_per_tile(val_dim, nr_classes, 1);
+    LN_REQUIRE(pb > 0, LN_ERR_UNSUPPORTED, "ln_slice_classify_forward: V=%d C=%d do not fit 64 KiB of LDS", val_dim, nr_classes);
+    const size_t lds = sizeof(float) * ((size_t)nr_classes * (val_dim + 1) + (size_t)pb * val_dim);
+    int grid = ln_div_up(n, pb);
+    if (grid > 2048) grid = 2048;
+    hipStream_t st = (hipStream_t)stream;
+#define LN_SC_FWD(P)                                                                                                          \
+    if (pb == P)                                                                                                                \
+        LN_LAUNCH("k_slice_classify_forward", k_slice_classify_forward<P>, dim3(grid), dim3(256), lds, st, values, delta_w, lin_w, lin_b, idx, w, \
+                  n, pos_dim + 1, val_dim, nr_classes, logits);
+    LN_SC_FWD(64) LN_SC_FWD(32) LN_SC_FWD(16) LN_SC_FWD(8)
+#undef LN_SC_FWD
     return ln_check_launch("ln_slice_classify_forward");
 }
 
-// Backward (LatticeGPU.cuh:3648-3751).  One workgroup owns PB points: it stages the sliced
-// features h[PB,V], the incoming gradient g[PB,C] and the classifier W[C,V] in LDS, reduces the
-// classifier gradients over its points in LDS and issues ONE atomic per (c,v) per workgroup
-// (the reference issues N*C*V global atomics onto C*V addresses).
-#define LN_SC_PB 64
+// Backward.  Per tile of PB points, in LDS: h[PB,V] (as forward), g[PB,C] (incoming gradient), W[C,V+1] and
+// gh[PB,V] = g @ W (the gradient wrt the sliced features).  Outputs:
+//   grad_sliced[p,:] = gh            -> the caller scatters it onto the lattice with weights w_eff = w + delta_w
+//                                       (ln_csr_reduce_rows: no atomics; the reference issues N(d+1)V of them)
+//   g_delta_w[p,r]  += values[idx[p,r],:] . gh[p,:]                       (one writer each)
+//   classifier weight / bias gradients: accumulated in registers over all tiles of the workgroup, written as one
+//   slab per workgroup and summed by k_sc_reduce_slabs (the reference: N*C*V atomics onto C*V addresses).
+#define LN_SC_MAX_ACC 16  // C*V <= 256 * LN_SC_MAX_ACC
+template <int PB>
 __global__ void __launch_bounds__(256)
     k_slice_classify_backward(const float* __restrict__ grad_logits, const float* __restrict__ values,
                               const float* __restrict__ delta_w, const float* __restrict__ lin_w, const int* __restrict__ idx,
-                              const float* __restrict__ w, int n, int dp1, int V, int C, float* __restrict__ g_values,
-                              float* __restrict__ g_delta_w, float* __restrict__ g_lin_w, float* __restrict__ g_lin_b) {
+                              const float* __restrict__ w, int n, int dp1, int V, int C, float* __restrict__ g_delta_w,
+                              float* __restrict__ grad_sliced, float* __restrict__ w_eff, float* __restrict__ slabs) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* s_h = smem;                  // [PB, V]
-    float* s_g = s_h + LN_SC_PB * V;    // [PB, C]
-    float* s_w = s_g + LN_SC_PB * C;    // [C, V]
-    const int p0 = blockIdx.x * LN_SC_PB;
-    const int np = min(LN_SC_PB, n - p0);
+    float* s_w = smem;                  // [C, V+1]
+    float* s_h = s_w + C * (V + 1);     // [PB, V]
+    float* s_gh = s_h + PB * V;         // [PB, V]
+    float* s_g = s_gh + PB * V;         // [PB, C]
     const int tid = threadIdx.x;
-    for (int i = tid; i < C * V; i += 256) s_w[i] = lin_w[i];
-    for (int i = tid; i < np * C; i += 256) s_g[i] = grad_logits[(size_t)p0 * C + i];
-    for (int i = tid; i < np * V; i += 256) {
-        const int lp = i / V, v = i - lp * V;
-        const long long p = p0 + lp;
-        float h = 0.0f;
-        for (int r = 0; r < dp1; ++r) {
-            const int row = idx[p * dp1 + r];
-            if (row >= 0) h = h + values[(size_t)row * V + v] * (w[p * dp1 + r] + delta_w[p * dp1 + r]);
+    const int CV = C * V;
+    for (int i = tid; i < CV; i += 256) {
+        const int c = i / V;
+        s_w[c * (V + 1) + (i - c * V)] = lin_w[i];
+    }
+    float acc_w[LN_SC_MAX_ACC];
+#pragma unroll
+    for (int k = 0; k < LN_SC_MAX_ACC; ++k) acc_w[k] = 0.0f;
+    float acc_b = 0.0f;
+    const int tiles = (n + PB - 1) / PB;
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const long long p0 = (long long)tile * PB;
+        __syncthreads();
+        for (int i = tid; i < PB * C; i += 256) {
+            const long long p = p0 + i / C;
+            s_g[i] = p < n ? grad_logits[p0 * C + i] : 0.0f;
         }
-        s_h[i] = h;
-    }
-    __syncthreads();
-    // lattice values: g_values[idx_r, v] += (sum_c g[p,c] W[c,v]) (w_r + dw_r)
-    for (int i = tid; i < np * V; i += 256) {
-        const int lp = i / V, v = i - lp * V;
-        const long long p = p0 + lp;
-        float gw = 0.0f;
-        for (int c = 0; c < C; ++c) gw = gw + s_g[lp * C + c] * s_w[c * V + v];
-        for (int r = 0; r < dp1; ++r) {
-            const int row = idx[p * dp1 + r];
-            if (row >= 0) ln_atomic_add(g_values + (size_t)row * V + v, gw * (w[p * dp1 + r] + delta_w[p * dp1 + r]));
+        for (int i = tid; i < PB * V; i += 256) {
+            const int lp = i / V, v = i - lp * V;
+            const long long p = p0 + lp;
+            float h = 0.0f;
+            if (p < n) {
+                for (int r = 0; r < dp1; ++r) {
+                    const int row = idx[p * dp1 + r];
+                    if (row >= 0) h = h + values[(size_t)row * V + v] * (w[p * dp1 + r] + delta_w[p * dp1 + r]);
+                }
+            }
+            s_h[i] = h;
         }
-    }
-    // classifier weight and bias
-    for (int i = tid; i < C * V; i += 256) {
-        const int c = i / V, v = i - c * V;
-        float acc = 0.0f;
-        for (int lp = 0; lp < np; ++lp) acc = acc + s_h[lp * V + v] * s_g[lp * C + c];
-        ln_atomic_add(g_lin_w + i, acc);
-    }
-    for (int c = tid; c < C; c += 256) {
-        float acc = 0.0f;
-        for (int lp = 0; lp < np; ++lp) acc = acc + s_g[lp * C + c];
-        ln_atomic_add(g_lin_b + c, acc);
-    }
-    // delta weights: g_dw[p,r] = sum_c g[p,c] (W[c,:] . values[idx_r,:]); exactly one writer each
-    for (int i = tid; i < np * dp1; i += 256) {
-        const int lp = i / dp1, r = i - lp * dp1;
-        const long long p = p0 + lp;
-        const int row = idx[p * dp1 + r];
-        float grad = 0.0f;
-        if (row >= 0) {
-            for (int c = 0; c < C; ++c) {
-                float dot = 0.0f;
-                for (int v = 0; v < V; ++v) dot = dot + values[(size_t)row * V + v] * s_w[c * V + v];
-                grad = grad + dot * s_g[lp * C + c];
+        for (int i = tid; i < PB * dp1; i += 256) {
+            const long long t = p0 * dp1 + i;
+            if (t < (long long)n * dp1) w_eff[t] = w[t] + delta_w[t];
+        }
+        __syncthreads();
+        for (int i = tid; i < PB * V; i += 256) {
+            const int lp = i / V, v = i - lp * V;
+            float gw = 0.0f;
+            for (int c = 0; c < C; ++c) gw = gw + s_g[lp * C + c] * s_w[c * (V + 1) + v];
+            s_gh[i] = gw;
+            if (p0 + lp < n) grad_sliced[(size_t)(p0 + lp) * V + v] = gw;
+        }
+        __syncthreads();
+        for (int i = tid; i < PB * dp1; i += 256) {
+            const int lp = i / dp1, r = i - lp * dp1;
+            const long long p = p0 + lp;
+            if (p >= n) continue;
+            const int row = idx[p * dp1 + r];
+            if (row < 0) continue;
+            const float* vr = values + (size_t)row * V;
+            const float* gh = s_gh + lp * V;
+            float dot = 0.0f;
+            for (int v = 0; v < V; ++v) dot = dot + vr[v] * gh[v];
+            g_delta_w[p * dp1 + r] += dot;
+        }
+#pragma unroll
+        for (int k = 0; k < LN_SC_MAX_ACC; ++k) {
+            const int j = tid + k * 256;
+            if (j < CV) {
+                const int c = j / V, v = j - c * V;
+                float a = acc_w[k];
+                for (int lp = 0; lp < PB; ++lp) a = a + s_h[lp * V + v] * s_g[lp * C + c];
+                acc_w[k] = a;
             }
         }
-        g_delta_w[p * dp1 + r] += grad;
+        if (tid < C)
+            for (int lp = 0; lp < PB; ++lp) acc_b = acc_b + s_g[lp * C + tid];
     }
+    float* slab = slabs + (size_t)blockIdx.x * (CV + C);
+#pragma unroll
+    for (int k = 0; k < LN_SC_MAX_ACC; ++k) {
+        const int j = tid + k * 256;
+        if (j < CV) slab[j] = acc_w[k];
+    }
+    if (tid < C) slab[CV + tid] = acc_b;
+}
+
+// out_w[j] += sum over slabs (j < CV), out_b[c] += ... (the gradient tensors are accumulated into, Lattice.cu:1091-1115)
+__global__ void __launch_bounds__(256)
+    k_sc_reduce_slabs(const float* __restrict__ slabs, int nslabs, int CV, int C, float* __restrict__ out_w, float* __restrict__ out_b) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= CV + C) return;
+    float acc = 0.0f;
+    for (int s = 0; s < nslabs; ++s) acc = acc + slabs[(size_t)s * (CV + C) + j];
+    if (j < CV)
+        out_w[j] += acc;
+    else
+        out_b[j - CV] += acc;
+}
+
+// grad_sliced rows scattered with global atomics (callers without a CSR adjacency)
+__global__ void __launch_bounds__(256)
+    k_sc_scatter_atomic(const float* __restrict__ grad_sliced, const float* __restrict__ w_eff, const int* __restrict__ idx, long long work,
+                        int dp1, int V, float* __restrict__ g_values) {
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= work) return;
+    const long long t = g / V;
+    const int v = int(g - t * V);
+    const int row = idx[t];
+    if (row >= 0) ln_atomic_add(g_values + (size_t)row * V + v, grad_sliced[(t / dp1) * V + v] * w_eff[t]);
+}
+
+static int ln_sc_backward_grid(int n, int pb) {
+    int grid = ln_div_up(n, pb);
+    return grid > 512 ? 512 : grid;
+}
+
+extern "C" size_t ln_slice_classify_backward_workspace_bytes(int n, int pos_dim, int val_dim, int nr_classes) {
+    if (n < 1) n = 1;
+    return (size_t)512 * ((size_t)nr_classes * val_dim + nr_classes) * sizeof(float) + 256;
 }
 
 extern "C" int ln_slice_classify_backward(const float* grad_logits, const float* values, const float* delta_w, const float* lin_w,
                                           const int* idx, const float* w, int n, int pos_dim, int val_dim, int nr_classes,
-                                          float* g_values, float* g_delta_w, float* g_lin_w, float* g_lin_b, void* stream) {
+                                          float* g_values, float* g_delta_w, float* g_lin_w, float* g_lin_b, float* grad_sliced,
+                                          float* w_eff, void* workspace, size_t workspace_bytes, void* stream) {
     int rc = ln_check_rows("ln_slice_classify_backward", grad_logits, values, idx, n, pos_dim, val_dim);
     if (rc) return rc;
-    LN_REQUIRE(nr_classes >= 1 && (n == 0 || (delta_w && lin_w && w && g_values && g_delta_w && g_lin_w && g_lin_b)), LN_ERR_ARG,
+    LN_REQUIRE(nr_classes >= 1 && (n == 0 || (delta_w && lin_w && w && g_delta_w && g_lin_w && g_lin_b && grad_sliced && w_eff)), LN_ERR_ARG,
                "ln_slice_classify_backward: bad args");
     if (n == 0) return LN_OK;
-    const size_t lds = sizeof(float) * ((size_t)LN_SC_PB * (val_dim + nr_classes) + (size_t)nr_classes * val_dim);
-    LN_REQUIRE(lds <= 64 * 1024, LN_ERR_UNSUPPORTED, "ln_slice_classify_backward: V=%d C=%d need %zu B of LDS (max 65536)", val_dim,
-               nr_classes, lds);
-    LN_LAUNCH("k_slice_classify_backward", k_slice_classify_backward, dim3(ln_div_up(n, LN_SC_PB)), dim3(256), lds, (hipStream_t)stream, grad_logits,
-                       values, delta_w, lin_w, idx, w, n, pos_dim + 1, val_dim, nr_classes, g_values, g_delta_w, g_lin_w, g_lin_b);
+    LN_REQUIRE(workspace && workspace_bytes >= ln_slice_classify_backward_workspace_bytes(n, pos_dim, val_dim, nr_classes), LN_ERR_WORKSPACE,
+               "ln_slice_classify_backward: workspace too small");
+    LN_REQUIRE((long long)nr_classes * val_dim <= 256 * LN_SC_MAX_ACC, LN_ERR_UNSUPPORTED,
+               "ln_slice_classify_backward: nr_classes*val_dim = %d exceeds %d", nr_classes * val_dim, 256 * LN_SC_MAX_ACC);
+    const int pb = ln_sc_points_per_tile(val_dim, nr_classes, 2);
+    LN_REQUIRE(pb > 0, LN_ERR_UNSUPPORTED, "ln_slice_classify_backward: V=%d C=%d do not fit 64 KiB of LDS", val_dim, nr_classes);
+    const size_t lds = sizeof(float) * ((size_t)nr_classes * (val_dim + 1) + (size_t)pb * (2 * val_dim + nr_classes));
+    const int grid = ln_sc_backward_grid(n, pb);
+    float* slabs = static_cast<float*>(workspace);
+    hipStream_t st = (hipStream_t)stream;
+    const int dp1 = pos_dim + 1;
+#define LN_SC_BWD(P)                                                                                                               \
+    if (pb == P)                                                                                                                     \
+        LN_LAUNCH("k_slice_classify_backward", k_slice_classify_backward<P>, dim3(grid), dim3(256), lds, st, grad_logits, values, delta_w, lin_w, \
+                  idx, w, n, dp1, val_dim, nr_classes, g_delta_w, grad_sliced, w_eff, slabs);
+    LN_SC_BWD(64) LN_SC_BWD(32) LN_SC_BWD(16) LN_SC_BWD(8)
+#undef LN_SC_BWD
+    const int cvc = nr_classes * val_dim + nr_classes;
+    LN_LAUNCH("k_sc_reduce_slabs", k_sc_reduce_slabs, dim3(ln_div_up(cvc, 256)), dim3(256), 0, st, slabs, grid, nr_classes * val_dim, nr_classes,
+              g_lin_w, g_lin_b);
+    if (g_values) {
+        const long long work = (long long)n * dp1 * val_dim;
+        LN_LAUNCH("k_sc_scatter_atomic", k_sc_scatter_atomic, dim3(ln_div_up(work, 256)), dim3(256), 0, st, grad_sliced, w_eff, idx, work, dp1,
+                  val_dim, g_values);
+    }
     return ln_check_launch("ln_slice_classify_backward");
 }

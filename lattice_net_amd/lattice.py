@@ -912,11 +912,19 @@ class Lattice:
                 raise ValueError(f"{name} must be contiguous (it is filled in place)")
         iv, dw, lw = initial_values.contiguous(), delta_weights.contiguous(), linear_clasify_weight.contiguous()
         lib = _lib.load()
+        v, c, d = int(iv.shape[1]), int(nr_classes), self.pos_dim()
+        dev = self._dev()
+        grad_sliced = torch.empty((n, v), dtype=torch.float32, device=dev)
+        w_eff = torch.empty((n * (d + 1),), dtype=torch.float32, device=dev)
+        ws = self._workspace(lib.ln_slice_classify_backward_workspace_bytes(n, d, v, c))
+        # classifier / delta-weight gradients + dL/d(sliced features); the lattice-value gradient is then the same
+        # CSR segment reduce as every other scatter onto the vertices (no N(d+1)V atomics, LG:3714-3719)
         _lib.check(lib.ln_slice_classify_backward(_lib.ptr(grad_class_logits), _lib.ptr(iv), _lib.ptr(dw), _lib.ptr(lw), _lib.ptr(idx),
-                                                  _lib.ptr(w), n, self.pos_dim(), int(iv.shape[1]), int(nr_classes),
-                                                  _lib.ptr(grad_lattice_values), _lib.ptr(grad_delta_weights),
+                                                  _lib.ptr(w), n, d, v, c, None, _lib.ptr(grad_delta_weights),
                                                   _lib.ptr(grad_linear_clasify_weight), _lib.ptr(grad_linear_clasify_bias),
-                                                  self._stream()), "ln_slice_classify_backward")
+                                                  _lib.ptr(grad_sliced), _lib.ptr(w_eff), _lib.ptr(ws), ws.numel(), self._stream()),
+                   "ln_slice_classify_backward")
+        self._scatter_rows(grad_sliced, idx, w_eff, grad_lattice_values, v, d + 1, v)
 
     def gather_backwards_standalone_with_precomputation(self, positions_raw, grad_sliced_values, splatting_indices_tensor,
                                                         splatting_weights_tensor):  # Lattice.cu:1117-1142

@@ -77,11 +77,13 @@ def test_slice_and_gather_autograd_against_oracle():
     close(N(vals3.grad), O.gather_backwards(gg, oidx, ow, m, 3))
 
 
-def test_slice_classify_autograd_against_oracle():
+@pytest.mark.parametrize("n,v,c", [(1500, 8, 20), (5000, 96, 20), (777, 128, 13), (300, 5, 3)])
+def test_slice_classify_autograd_against_oracle(n, v, c):
+    """(5000, 96, 20) is the head of the SemanticKITTI LNN: several tiles per workgroup; (777, 128, 13) takes the
+    32-point tile; ragged last tiles everywhere."""
     from lattice_net_amd import SliceClassifyLattice
     from lattice_net_amd.synthetic import cube_cloud
-    pos_np = cube_cloud(1500, 21)
-    n, v, c = 1500, 8, 20
+    pos_np = cube_cloud(n, 21)
     lat = make_lattice(0.25, 30000)
     lat.begin_splat()
     idx, w = lat.just_create_verts(T(pos_np), True)
@@ -102,6 +104,22 @@ def test_slice_classify_autograd_against_oracle():
     close(N(dw.grad), gd)
     close(N(lw.grad), gw)
     close(N(lb.grad), gb)
+    # the C entry point can also scatter the lattice-value gradient itself (callers without a CSR adjacency)
+    import ctypes as C
+    from lattice_net_amd import _lib
+    lib = _lib.load()
+    g_vals = torch.zeros((m, v), device=dev())
+    g_dw, g_lw, g_lb = torch.zeros((n, 4), device=dev()), torch.zeros((c, v), device=dev()), torch.zeros((c,), device=dev())
+    gs, weff = torch.empty((n, v), device=dev()), torch.empty((n * 4,), device=dev())
+    ws = torch.empty((lib.ln_slice_classify_backward_workspace_bytes(n, 3, v, c),), dtype=torch.uint8, device=dev())
+    rc = lib.ln_slice_classify_backward(_lib.ptr(T(gl_np)), _lib.ptr(vals.detach()), _lib.ptr(dw.detach()), _lib.ptr(lw.detach()),
+                                        _lib.ptr(idx), _lib.ptr(w), n, 3, v, c, _lib.ptr(g_vals), _lib.ptr(g_dw), _lib.ptr(g_lw),
+                                        _lib.ptr(g_lb), _lib.ptr(gs), _lib.ptr(weff), _lib.ptr(ws), ws.numel(),
+                                        _lib.stream_ptr(dev()))
+    assert rc == 0, lib.ln_last_error_string()
+    close(N(g_vals), gv)
+    close(N(g_lw), gw)
+    np.testing.assert_array_equal(N(weff), ow + dw_np.reshape(-1))
 
 
 def test_modules_level_chain_c2_shapenet_like():
