@@ -228,6 +228,20 @@ int ln_slice_classify_backward(const float* grad_logits, const float* values, co
                                float* g_values, float* g_delta_w, float* g_lin_w, float* g_lin_b, float* grad_sliced,
                                float* w_eff, void* workspace, size_t workspace_bytes, void* stream);
 
+/* "Next" row: GroupNorm (+ optional fused ReLU) of the LNN blocks on the native [m, channels]
+ * value layout (lattice_modules.py:585-616 runs torch.nn.GroupNorm on a transposed [1, C, M] view).  Statistics
+ * per group over (all rows) x (channels of the group), biased variance, as torch.nn.GroupNorm.
+ * forward:  y = act(x * a[c] + b[c]),  a = gamma*rstd[g], b = beta - mean[g]*a;  also writes mean_rstd[2*groups]
+ *           (means then rstds) and scale_shift[2*channels] (a then b) for the backward pass.
+ * backward: grad_x (and grad_gamma / grad_beta when non-NULL) from x, grad_y and the two saved vectors.
+ * channels % 4 == 0, channels <= 1024, 16-byte aligned tensors; workspace = ln_group_norm_workspace_bytes(channels). */
+size_t ln_group_norm_workspace_bytes(int channels);
+int ln_group_norm_forward(const float* x, const float* gamma, const float* beta, int m, int channels, int groups, float eps, int relu,
+                          float* y, float* mean_rstd, float* scale_shift, void* workspace, size_t workspace_bytes, void* stream);
+int ln_group_norm_backward(const float* x, const float* grad_y, const float* gamma, const float* mean_rstd, const float* scale_shift, int m,
+                           int channels, int groups, int relu, float* grad_x, float* grad_gamma, float* grad_beta, void* workspace,
+                           size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

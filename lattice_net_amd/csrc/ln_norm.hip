@@ -1,0 +1,238 @@
+// GroupNorm (+ fused ReLU) on the native [M, C] lattice-value layout, forward and backward.
+// The reference runs torch.nn.GroupNorm on a transposed [1, C, M] view (lattice_modules.py:585-616), which on a
+// row-major value matrix costs two transposed copies in each direction; the LNN blocks (GnRelu1x1, GnReluConv,
+// GnReluFinefy, ...) apply it before every operator, so it sits between any two lattice kernels of the U-Net.
+//   statistics : per-channel partial sums over a slab of rows per workgroup (lanes run along the channels of a row:
+//                coalesced), combined across workgroups with one fp64 atomic per (workgroup, channel)
+//   apply      : every workgroup rebuilds the per-channel scale/shift from the C channel sums in LDS, then one
+//                float4 pass over its slab
+// Backward uses the same two shapes: per-channel sums of gy*x and gy, then dx = gy*gamma*rstd + x*c2[g] + c3[g].
+#include "ln_common.h"
+
+#define LN_GN_MAX_C 1024
+#define LN_GN_PASSES 64
+
+// acc[c*2 + 0] += sum_rows p(row, c), acc[c*2 + 1] += sum_rows q(row, c)
+//   forward  (gy == nullptr): p = x,  q = x*x
+//   backward               : p = gy' * x, q = gy'   with gy' = gy masked by (x*a[c] + b[c] > 0) when relu
+__global__ void __launch_bounds__(256)
+    k_gn_stats(const float* __restrict__ x, const float* __restrict__ gy, const float* __restrict__ scale_shift, int relu, int m, int c,
+               double* __restrict__ acc) {
+    __shared__ float s_p[256], s_q[256];
+    const int tid = threadIdx.x;
+    const int rows_per_pass = c <= 256 ? 256 / c : 1;
+    const int cols_per_thread = c <= 256 ? 1 : (c + 255) / 256;
+    const int row_in_pass = c <= 256 ? tid / c : 0;
+    const int slab = rows_per_pass * LN_GN_PASSES;
+    const long long r0 = (long long)blockIdx.x * slab;
+    for (int j = 0; j < cols_per_thread; ++j) {
+        const int col = c <= 256 ? tid - row_in_pass * c : tid + j * 256;
+        const bool live = col < c && row_in_pass < rows_per_pass;
+        float p = 0.f, q = 0.f;
+        if (live) {
+            const float a = (gy && relu) ? scale_shift[col] : 0.f;
+            const float b = (gy && relu) ? scale_shift[c + col] : 0.f;
+#pragma unroll 4
+            for (int k = 0; k < LN_GN_PASSES; ++k) {
+                const long long row = r0 + (long long)k * rows_per_pass + row_in_pass;
+                if (row < m) {
+                    const float xv = x[row * c + col];
+                    if (gy) {
+                        float g = gy[row * c + col];
+                        if (relu && !(xv * a + b > 0.f)) g = 0.f;
+                        p += g * xv;
+                        q += g;
+                    } else {
+                        p += xv;
+                        q += xv * xv;
+                    }
+                }
+            }
+        }
+        if (c <= 256 && rows_per_pass > 1) {  // fold the threads that share a channel
+            s_p[tid] = p;
+            s_q[tid] = q;
+            __syncthreads();
+            if (live && row_in_pass == 0) {
+                for (int r = 1; r < rows_per_pass; ++r) {
+                    p += s_p[r * c + col];
+                    q += s_q[r * c + col];
+                }
+            }
+            __syncthreads();
+        }
+        if (live && row_in_pass == 0) {
+            atomicAdd(&acc[2 * col], (double)p);
+            atomicAdd(&acc[2 * col + 1], (double)q);
+        }
+    }
+}
+
+// per-channel scale a[c] = gamma*rstd[g], shift b[c] = beta - mean[g]*a[c] from the channel sums; block 0 also
+// publishes mean/rstd per group and scale/shift per channel for the backward pass
+__device__ __forceinline__ void ln_gn_channel_affine(const double* __restrict__ acc, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, int m, int c, int groups, float eps, float* s_a,
+                                                     float* s_b, float* __restrict__ mean_rstd, float* __restrict__ scale_shift) {
+    const int cg = c / groups;
+    for (int col = threadIdx.x; col < c; col += 256) {
+        const int g = col / cg;
+        double s = 0.0, ss = 0.0;
+        for (int k = 0; k < cg; ++k) {
+            s += acc[2 * (g * cg + k)];
+            ss += acc[2 * (g * cg + k) + 1];
+        }
+        const double cnt = (double)m * cg;
+        const double mean = s / cnt;
+        double var = ss / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float a = (gamma ? gamma[col] : 1.f) * rstd;
+        const float b = (beta ? beta[col] : 0.f) - (float)mean * a;
+        s_a[col] = a;
+        s_b[col] = b;
+        if (blockIdx.x == 0) {
+            scale_shift[col] = a;
+            scale_shift[c + col] = b;
+            if (col == g * cg) {
+                mean_rstd[g] = (float)mean;
+                mean_rstd[groups + g] = rstd;
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+    k_gn_apply(const float* __restrict__ x, const double* __restrict__ acc, const float* __restrict__ gamma, const float* __restrict__ beta,
+               int m, int c, int groups, float eps, int relu, float* __restrict__ y, float* __restrict__ mean_rstd,
+               float* __restrict__ scale_shift) {
+    __shared__ float s_a[LN_GN_MAX_C], s_b[LN_GN_MAX_C];
+    ln_gn_channel_affine(acc, gamma, beta, m, c, groups, eps, s_a, s_b, mean_rstd, scale_shift);
+    __syncthreads();
+    const long long total4 = (long long)m * c / 4;  // c % 4 == 0 checked by the host
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += stride) {
+        const int col = int((i * 4) % c);
+        float4 v = reinterpret_cast<const float4*>(x)[i];
+        v.x = v.x * s_a[col] + s_b[col];
+        v.y = v.y * s_a[col + 1] + s_b[col + 1];
+        v.z = v.z * s_a[col + 2] + s_b[col + 2];
+        v.w = v.w * s_a[col + 3] + s_b[col + 3];
+        if (relu) {
+            v.x = fmaxf(v.x, 0.f);
+            v.y = fmaxf(v.y, 0.f);
+            v.z = fmaxf(v.z, 0.f);
+            v.w = fmaxf(v.w, 0.f);
+        }
+        reinterpret_cast<float4*>(y)[i] = v;
+    }
+}
+
+// dx = gy' * gamma * rstd + x * c2[g] + c3[g];   block 0 writes dgamma = (ds - db*mean)*rstd, dbeta = db
+__global__ void __launch_bounds__(256)
+    k_gn_backward_apply(const float* __restrict__ x, const float* __restrict__ gy, const double* __restrict__ acc,
+                        const float* __restrict__ gamma, const float* __restrict__ mean_rstd, const float* __restrict__ scale_shift, int m,
+                        int c, int groups, int relu, float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ float s_gr[LN_GN_MAX_C], s_c2[LN_GN_MAX_C], s_c3[LN_GN_MAX_C], s_a[LN_GN_MAX_C], s_b[LN_GN_MAX_C];
+    const int cg = c / groups;
+    for (int col = threadIdx.x; col < c; col += 256) {
+        const int g = col / cg;
+        const float mean = mean_rstd[g], rstd = mean_rstd[groups + g];
+        double sum1 = 0.0, sum2 = 0.0;  // sum over the group's channels of ds*gamma, db*gamma
+        for (int k = 0; k < cg; ++k) {
+            const int cc = g * cg + k;
+            const double gm = gamma ? (double)gamma[cc] : 1.0;
+            sum1 += acc[2 * cc] * gm;
+            sum2 += acc[2 * cc + 1] * gm;
+        }
+        const double cnt = (double)m * cg;
+        const double c2 = (sum2 * mean - sum1) * (double)rstd * rstd * rstd / cnt;
+        const double c3 = -c2 * mean - sum2 * (double)rstd / cnt;
+        s_gr[col] = (gamma ? gamma[col] : 1.f) * rstd;
+        s_c2[col] = (float)c2;
+        s_c3[col] = (float)c3;
+        s_a[col] = scale_shift[col];
+        s_b[col] = scale_shift[c + col];
+        if (blockIdx.x == 0) {
+            if (dgamma) dgamma[col] = (float)((acc[2 * col] - acc[2 * col + 1] * mean) * rstd);
+            if (dbeta) dbeta[col] = (float)acc[2 * col + 1];
+        }
+    }
+    __syncthreads();
+    const long long total4 = (long long)m * c / 4;
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += stride) {
+        const int col = int((i * 4) % c);
+        const float4 xv = reinterpret_cast<const float4*>(x)[i];
+        float4 g = reinterpret_cast<const float4*>(gy)[i];
+        if (relu) {
+            if (!(xv.x * s_a[col] + s_b[col] > 0.f)) g.x = 0.f;
+            if (!(xv.y * s_a[col + 1] + s_b[col + 1] > 0.f)) g.y = 0.f;
+            if (!(xv.z * s_a[col + 2] + s_b[col + 2] > 0.f)) g.z = 0.f;
+            if (!(xv.w * s_a[col + 3] + s_b[col + 3] > 0.f)) g.w = 0.f;
+        }
+        float4 o;
+        o.x = g.x * s_gr[col] + xv.x * s_c2[col] + s_c3[col];
+        o.y = g.y * s_gr[col + 1] + xv.y * s_c2[col + 1] + s_c3[col + 1];
+        o.z = g.z * s_gr[col + 2] + xv.z * s_c2[col + 2] + s_c3[col + 2];
+        o.w = g.w * s_gr[col + 3] + xv.w * s_c2[col + 3] + s_c3[col + 3];
+        reinterpret_cast<float4*>(dx)[i] = o;
+    }
+}
+
+static int ln_gn_check(const char* who, int m, int c, int groups) {
+    LN_REQUIRE(m >= 1 && c >= 4 && c <= LN_GN_MAX_C && c % 4 == 0, LN_ERR_UNSUPPORTED, "%s: need 1 <= rows, channels %% 4 == 0 and <= %d (got %d x %d)",
+               who, LN_GN_MAX_C, m, c);
+    LN_REQUIRE(groups >= 1 && c % groups == 0, LN_ERR_ARG, "%s: %d groups do not divide %d channels", who, groups, c);
+    return LN_OK;
+}
+
+static int ln_gn_stats_grid(int m, int c) {
+    const int rows_per_pass = c <= 256 ? 256 / c : 1;
+    return ln_div_up(m, rows_per_pass * LN_GN_PASSES);
+}
+
+static int ln_gn_apply_grid(int m, int c) {
+    const long long total4 = (long long)m * c / 4;
+    int grid = ln_div_up(total4, 256 * 4);
+    if (grid > 2048) grid = 2048;
+    return grid < 1 ? 1 : grid;
+}
+
+extern "C" size_t ln_group_norm_workspace_bytes(int channels) { return (size_t)2 * channels * sizeof(double); }
+
+extern "C" int ln_group_norm_forward(const float* x, const float* gamma, const float* beta, int m, int channels, int groups, float eps,
+                                     int relu, float* y, float* mean_rstd, float* scale_shift, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
+    int rc = ln_gn_check("ln_group_norm_forward", m, channels, groups);
+    if (rc) return rc;
+    LN_REQUIRE(x && y && mean_rstd && scale_shift && workspace && workspace_bytes >= ln_group_norm_workspace_bytes(channels), LN_ERR_ARG,
+               "ln_group_norm_forward: null buffer or workspace too small");
+    LN_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0 && (reinterpret_cast<uintptr_t>(workspace) & 7) == 0,
+               LN_ERR_ARG, "ln_group_norm_forward: x / y must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    double* acc = static_cast<double*>(workspace);
+    if (hipMemsetAsync(acc, 0, ln_group_norm_workspace_bytes(channels), st) != hipSuccess) return ln_check_launch("ln_group_norm_forward(memset)");
+    LN_LAUNCH("k_gn_stats", k_gn_stats, dim3(ln_gn_stats_grid(m, channels)), dim3(256), 0, st, x, (const float*)nullptr, (const float*)nullptr, 0, m,
+              channels, acc);
+    LN_LAUNCH("k_gn_apply", k_gn_apply, dim3(ln_gn_apply_grid(m, channels)), dim3(256), 0, st, x, acc, gamma, beta, m, channels, groups, eps, relu, y,
+              mean_rstd, scale_shift);
+    return ln_check_launch("ln_group_norm_forward");
+}
+
+extern "C" int ln_group_norm_backward(const float* x, const float* grad_y, const float* gamma, const float* mean_rstd,
+                                      const float* scale_shift, int m, int channels, int groups, int relu, float* grad_x, float* grad_gamma,
+                                      float* grad_beta, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = ln_gn_check("ln_group_norm_backward", m, channels, groups);
+    if (rc) return rc;
+    LN_REQUIRE(x && grad_y && mean_rstd && scale_shift && grad_x && workspace && workspace_bytes >= ln_group_norm_workspace_bytes(channels),
+               LN_ERR_ARG, "ln_group_norm_backward: null buffer or workspace too small");
+    LN_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(grad_y) | reinterpret_cast<uintptr_t>(grad_x)) & 15) == 0, LN_ERR_ARG,
+               "ln_group_norm_backward: x / grad_y / grad_x must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    double* acc = static_cast<double*>(workspace);
+    if (hipMemsetAsync(acc, 0, ln_group_norm_workspace_bytes(channels), st) != hipSuccess) return ln_check_launch("ln_group_norm_backward(memset)");
+    LN_LAUNCH("k_gn_stats", k_gn_stats, dim3(ln_gn_stats_grid(m, channels)), dim3(256), 0, st, x, grad_y, scale_shift, relu, m, channels, acc);
+    LN_LAUNCH("k_gn_backward_apply", k_gn_backward_apply, dim3(ln_gn_apply_grid(m, channels)), dim3(256), 0, st, x, grad_y, acc, gamma, mean_rstd,
+              scale_shift, m, channels, groups, relu, grad_x, grad_gamma, grad_beta);
+    return ln_check_launch("ln_group_norm_backward");
+}

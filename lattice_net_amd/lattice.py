@@ -791,7 +791,7 @@ class Lattice:
         ht.m_values_tensor = torch.zeros((1, self.val_dim()), dtype=torch.float32, device=dev)
         ht._counters = torch.zeros((2,), dtype=torch.int32, device=dev)
         coarse.m_hash_table = ht
-        ht.clear()
+        ht.clear(lazy=True)  # rides in the build call of create_coarse_verts_naive; c_table() flushes it for ln_coarsen
         return coarse
 
     def create_coarse_verts(self) -> "Lattice":  # Lattice.cu:670-703

@@ -13,6 +13,7 @@ from typing import Optional
 
 import torch
 
+from . import _lib
 from .lattice_funcs import GatherLattice, SliceClassifyLattice
 from .lattice_modules import CoarsenLatticeModule, ConvLatticeIm2RowModule, FinefyLatticeModule
 
@@ -48,16 +49,60 @@ class BatchNormLatticeModule(torch.nn.Module):  # mods:570-583
         return lattice_values, lattice_py
 
 
+class GroupNormReluFunction(torch.autograd.Function):
+    """GroupNorm (+ optional fused ReLU) over an [M, C] value matrix on the HIP kernels of csrc/ln_norm.hip
+    (ln_group_norm_forward / _backward): statistics per group over all vertices x the group's channels."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, num_groups, eps, relu):
+        lib = _lib.load()
+        x = x.contiguous()
+        m, c = x.shape
+        y = torch.empty_like(x)
+        mean_rstd = torch.empty((2 * num_groups,), dtype=torch.float32, device=x.device)
+        scale_shift = torch.empty((2 * c,), dtype=torch.float32, device=x.device)
+        ws = torch.empty((2 * c,), dtype=torch.float64, device=x.device)
+        _lib.check(lib.ln_group_norm_forward(_lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), m, c, num_groups, float(eps), int(relu),
+                                             _lib.ptr(y), _lib.ptr(mean_rstd), _lib.ptr(scale_shift), _lib.ptr(ws), ws.numel() * 8,
+                                             _lib.stream_ptr(x.device)), "ln_group_norm_forward")
+        ctx.save_for_backward(x, weight, mean_rstd, scale_shift)
+        ctx.args = (num_groups, bool(relu), bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        lib = _lib.load()
+        x, weight, mean_rstd, scale_shift = ctx.saved_tensors
+        num_groups, relu, has_bias = ctx.args
+        grad_y = grad_y.contiguous()
+        m, c = x.shape
+        grad_x = torch.empty_like(x)
+        grad_w = torch.empty((c,), dtype=torch.float32, device=x.device) if weight is not None else None
+        grad_b = torch.empty((c,), dtype=torch.float32, device=x.device) if has_bias else None
+        ws = torch.empty((2 * c,), dtype=torch.float64, device=x.device)
+        _lib.check(lib.ln_group_norm_backward(_lib.ptr(x), _lib.ptr(grad_y), _lib.ptr(weight), _lib.ptr(mean_rstd), _lib.ptr(scale_shift), m, c,
+                                              num_groups, int(relu), _lib.ptr(grad_x), _lib.ptr(grad_w), _lib.ptr(grad_b), _lib.ptr(ws),
+                                              ws.numel() * 8, _lib.stream_ptr(x.device)), "ln_group_norm_backward")
+        return grad_x, grad_w, grad_b, None, None, None
+
+
+def group_norm_rows(x: torch.Tensor, gn: torch.nn.GroupNorm, relu: bool = False) -> torch.Tensor:
+    """GroupNorm of an [M, C] matrix with the parameters of `gn` (statistics over rows x group channels)."""
+    if x.is_cuda and x.dtype == torch.float32 and x.shape[1] % 4 == 0 and x.shape[1] <= 1024 and x.shape[0] > 0:
+        return GroupNormReluFunction.apply(x, gn.weight, gn.bias, gn.num_groups, gn.eps, relu)
+    y = gn(x.t().unsqueeze(0)).squeeze(0).t()  # torch's layout: [1, C, M]
+    return torch.relu(y) if relu else y
+
+
 class GroupNormLatticeModule(torch.nn.Module):  # mods:585-616: 32 groups, or C/2 groups when 32 does not divide C
     def __init__(self, nr_params: int, affine: bool = True, device="cuda"):
         super().__init__()
         nr_groups = 32 if nr_params % 32 == 0 else max(int(nr_params / 2), 1)
         self.gn = torch.nn.GroupNorm(nr_groups, nr_params, affine=affine).to(device)
 
-    def forward(self, lattice_values, lattice_py, do_set_values: bool = True):
+    def forward(self, lattice_values, lattice_py, do_set_values: bool = True, fuse_relu: bool = False):
         _require_2d(lattice_values)
-        # GroupNorm normalises over (channels of a group) x (all vertices): [1, C, M] layout
-        lattice_values = self.gn(lattice_values.t().unsqueeze(0)).squeeze(0).t()
+        lattice_values = group_norm_rows(lattice_values, self.gn, fuse_relu)
         if do_set_values:
             lattice_py.set_values(lattice_values)
         return lattice_values, lattice_py
@@ -104,12 +149,16 @@ class _PreActBlock(torch.nn.Module):
 
     def _pre(self, lv, ls):
         ls.set_values(lv)
+        pre_act = getattr(self, self._act_name) if (self._act_name is not None and not self._act_after) else None
         if self._norm_kind == "gn":
-            lv, ls = self.norm(lv, ls)
+            fuse = isinstance(pre_act, torch.nn.ReLU)  # GroupNorm + ReLU in one pass over the values
+            lv, ls = self.norm(lv, ls, fuse_relu=fuse)
+            if fuse:
+                pre_act = None
         elif self._norm_kind == "bn":
             lv, ls = self.bn(lv, ls)
-        if self._act_name is not None and not self._act_after:
-            lv = getattr(self, self._act_name)(lv)
+        if pre_act is not None:
+            lv = pre_act(lv)
         if self.with_dropout:
             lv = self.drop(lv)
         ls.set_values(lv)

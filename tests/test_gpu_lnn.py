@@ -102,3 +102,34 @@ def test_lnn_overfits_one_cloud(tmp_path):
     assert losses[-1] < 0.6 * losses[0], losses
     acc = float((logsoftmax.argmax(1) == target).float().mean())
     assert acc > 0.5, acc
+
+
+@pytest.mark.parametrize("m,c,relu", [(5000, 32, False), (46538, 96, True), (777, 128, True), (100, 48, False), (3, 8, True),
+                                      (20000, 64, True), (901, 320, False)])
+def test_group_norm_kernels_match_torch(m, c, relu):
+    """ln_group_norm_forward / _backward on the [M, C] layout against torch.nn.functional.group_norm (fp64 reference)."""
+    from lattice_net_amd.lattice_blocks import GroupNormLatticeModule
+    torch.manual_seed(m + c)
+    dev = torch.device("cuda", 0)
+    mod = GroupNormLatticeModule(c)
+    with torch.no_grad():
+        mod.gn.weight.uniform_(0.5, 2.0)
+        mod.gn.bias.uniform_(-1.0, 1.0)
+    x = (torch.randn((m, c), device=dev) * 2 + 0.5).requires_grad_(True)
+    gy = torch.randn((m, c), device=dev)
+    y, _ = mod(x, None, do_set_values=False, fuse_relu=relu)
+    y.backward(gy)
+    x64 = x.detach().double().cpu().requires_grad_(True)
+    w64 = mod.gn.weight.detach().double().cpu().requires_grad_(True)
+    b64 = mod.gn.bias.detach().double().cpu().requires_grad_(True)
+    ref = torch.nn.functional.group_norm(x64.t().unsqueeze(0), mod.gn.num_groups, w64, b64, mod.gn.eps).squeeze(0).t()
+    if relu:
+        ref = torch.relu(ref)
+    ref.backward(gy.double().cpu())
+    torch.testing.assert_close(y.detach().cpu().double(), ref.detach(), rtol=1e-4, atol=1e-5)
+    # elements that sit on the ReLU kink within rounding can flip their mask: compare gradients in aggregate too
+    gx = x.grad.cpu().double()
+    mism = (gx - x64.grad).abs() > 1e-4 + 1e-3 * x64.grad.abs()
+    assert mism.float().mean() < 1e-4, float(mism.float().mean())
+    torch.testing.assert_close(mod.gn.weight.grad.cpu().double(), w64.grad, rtol=2e-4, atol=2e-4 * float(w64.grad.abs().max()))
+    torch.testing.assert_close(mod.gn.bias.grad.cpu().double(), b64.grad, rtol=2e-4, atol=2e-4 * float(b64.grad.abs().max()))

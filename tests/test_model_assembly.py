@@ -111,7 +111,15 @@ def test_blocks_reject_non_matrix_values():
     with pytest.raises(ValueError):
         GroupNormLatticeModule(8, device="cpu")(torch.zeros(2, 3, 8), None)
     gn = GroupNormLatticeModule(8, device="cpu")
-    x = torch.randn(50, 8)
+    with torch.no_grad():
+        gn.gn.weight.uniform_(0.5, 2.0)
+        gn.gn.bias.uniform_(-1.0, 1.0)
+    x = (torch.randn(50, 8) * 3 + 1).requires_grad_(True)
     y, _ = gn(x, None, do_set_values=False)
     ref = torch.nn.functional.group_norm(x.t().unsqueeze(0), gn.gn.num_groups, gn.gn.weight, gn.gn.bias).squeeze(0).t()
-    assert torch.allclose(y, ref)
+    assert torch.allclose(y, ref, rtol=1e-5, atol=1e-5)
+    gy = torch.randn_like(y)
+    g1 = torch.autograd.grad(y, [x, gn.gn.weight, gn.gn.bias], gy, retain_graph=True)
+    g2 = torch.autograd.grad(ref, [x, gn.gn.weight, gn.gn.bias], gy)
+    for a, b in zip(g1, g2):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-5)
