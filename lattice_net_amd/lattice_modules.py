@@ -14,7 +14,8 @@ from .lattice_funcs import (CoarsenLattice, ConvIm2RowLattice, DistributeLattice
                             SliceLattice, SplatLattice)
 
 __all__ = ["SplatLatticeModule", "DistributeLatticeModule", "PointNetModule", "ConvLatticeIm2RowModule", "CoarsenLatticeModule",
-           "FinefyLatticeModule", "SliceLatticeModule", "GatherLatticeModule"]
+           "FinefyLatticeModule", "SliceLatticeModule", "GatherLatticeModule", "LinearWN", "ConvLatticeIm2RowWNModule",
+           "CoarsenLatticeWNModule", "FinefyLatticeWNModule"]
 
 
 def _kaiming_uniform_fan_out_(weight: torch.Tensor, fan_scale: float = 1.0, std_scale: float = 1.0):
@@ -30,6 +31,41 @@ def _kaiming_uniform_fan_out_(weight: torch.Tensor, fan_scale: float = 1.0, std_
 def _bias_init_(bias: torch.Tensor, weight: torch.Tensor):
     _, fan_out = torch.nn.init._calculate_fan_in_and_fan_out(weight)
     torch.nn.init.uniform_(bias, -1 / math.sqrt(fan_out), 1 / math.sqrt(fan_out))
+
+
+def _leaky_relu_init_bound(n_in: int, n_out: int, extent: int = 1, alpha: float = 0.2) -> float:
+    """utils.leaky_relu_init (utils.py:381-462): U(-b, b) with b = sqrt(3) * gain * sqrt(2 / ((n_in + n_out) * extent))."""
+    gain = math.sqrt(2.0 / (1.0 + alpha ** 2))
+    return math.sqrt(3.0) * gain * math.sqrt(2.0 / ((n_in + n_out) * extent))
+
+
+class _WeightNormed:
+    """The reference's weight_norm_wrapper (utils.py:72-158) with v_dim=None: parameters `weight_v` (direction, the
+    layer's weight shape) and `weight_g` (one magnitude per output unit, kept along `g_dim`), effective weight
+    = weight_v * weight_g / ||weight_v||_F.  Same parameter names as torch's WeightNorm, so reference checkpoints
+    (`...weight_g`, `...weight_v`) load unchanged."""
+
+    def _install_weight_norm(self, v: torch.Tensor, g_dim: int):
+        g_shape = [1] * v.dim()
+        g_shape[g_dim] = v.shape[g_dim]
+        self.weight_v = torch.nn.Parameter(v)
+        self.weight_g = torch.nn.Parameter(torch.full(g_shape, float(v.norm()), dtype=v.dtype, device=v.device))  # unfuse(): g := ||v||
+
+    @property
+    def weight(self) -> torch.Tensor:
+        return self.weight_v * (self.weight_g / self.weight_v.norm())
+
+
+class LinearWN(_WeightNormed, torch.nn.Module):  # utils.py:291 (weight_norm_wrapper(Linear, g_dim=0, v_dim=None))
+    def __init__(self, in_features: int, out_features: int, bias: bool = True, device=None):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        b = _leaky_relu_init_bound(in_features, out_features)  # PointNetModule applies leaky_relu_init to its layers (mods:651)
+        self._install_weight_norm(torch.empty((out_features, in_features), device=device).uniform_(-b, b), g_dim=0)
+        self.bias = torch.nn.Parameter(torch.zeros(out_features, device=device)) if bias else None
+
+    def forward(self, x):
+        return torch.nn.functional.linear(x, self.weight, self.bias)
 
 
 class SplatLatticeModule(torch.nn.Module):  # lattice_modules.py:46-51
@@ -63,9 +99,8 @@ class DistributeLatticeModule(torch.nn.Module):  # lattice_modules.py:52-96
 
 class PointNetModule(torch.nn.Module):  # lattice_modules.py:618-733 (the step right before the hot path in LNN)
     """Per-token MLP -> vertex-wise max (+ the barycentric weight of the winning token) -> rows with fewer than 4
-    points and vertex 0 zeroed -> lattice convolution.  The reference's weight-normalised layers (LinearWN,
-    ConvLatticeIm2RowWNModule) are plain Linear / ConvLatticeIm2RowModule here (weight norm is a re-parametrisation,
-    not part of the lattice path)."""
+    points and vertex 0 zeroed -> lattice convolution.  Layers are weight-normalised as in the reference (LinearWN,
+    ConvLatticeIm2RowWNModule), with its parameter names."""
 
     def __init__(self, nr_output_channels_per_layer, nr_outputs_last_layer, nr_input_channels=None, device="cuda"):
         super().__init__()
@@ -74,13 +109,13 @@ class PointNetModule(torch.nn.Module):  # lattice_modules.py:618-733 (the step r
         self.layers = torch.nn.ModuleList([])
         self.act = torch.nn.LeakyReLU(0.2)
         self.device = device
-        self.last_conv = ConvLatticeIm2RowModule(self.nr_output_channels_per_layer[-1] * 2, nr_outputs_last_layer, 1, 1, True, device=device)
+        self.last_conv = ConvLatticeIm2RowWNModule(self.nr_output_channels_per_layer[-1] * 2, nr_outputs_last_layer, 1, 1, True, device=device)
         if nr_input_channels is not None:
             self._make_layers(nr_input_channels)
 
     def _make_layers(self, nr_input_channels):
         for nr_out in self.nr_output_channels_per_layer:  # created lazily from the first input, mods:636-647
-            self.layers.append(torch.nn.Linear(nr_input_channels, nr_out, bias=True).to(self.device))
+            self.layers.append(LinearWN(nr_input_channels, nr_out, bias=True, device=self.device))
             nr_input_channels = nr_out
 
     def forward(self, lattice_py, distributed, indices):
@@ -188,6 +223,37 @@ class FinefyLatticeModule(torch.nn.Module):  # lattice_modules.py:321-387
             lv = lv + self.bias
         ls.set_values(lv)
         return lv, ls
+
+
+class _LatticeWN(_WeightNormed):
+    """lattice_modules.py:413-415: weight_norm_wrapper(<lattice op module>, g_dim=1, v_dim=None) — one magnitude per
+    output filter (column of the [E*V, F] bank)."""
+
+    def _to_weight_norm(self, extent_scale: int = 1):
+        v = self._parameters.pop("weight").data
+        b = _leaky_relu_init_bound(self.in_channels, self.out_channels, max(self.filter_extent // extent_scale, 1))
+        v.uniform_(-b, b)  # leaky_relu_init on the fused module (utils.py:424-462), then unfuse
+        if self.bias is not None:
+            torch.nn.init.zeros_(self.bias)
+        self._install_weight_norm(v, g_dim=1)
+
+
+class ConvLatticeIm2RowWNModule(_LatticeWN, ConvLatticeIm2RowModule):
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._to_weight_norm()
+
+
+class CoarsenLatticeWNModule(_LatticeWN, CoarsenLatticeModule):
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._to_weight_norm(extent_scale=8)  # utils.py:437-443
+
+
+class FinefyLatticeWNModule(_LatticeWN, FinefyLatticeModule):
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._to_weight_norm(extent_scale=8)  # utils.py:444-452
 
 
 class SliceLatticeModule(torch.nn.Module):  # lattice_modules.py:389-397

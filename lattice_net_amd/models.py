@@ -69,7 +69,13 @@ class LNN(torch.nn.Module):
         self.distribute = DistributeLatticeModule()
         self.pointnet_channels_per_layer = model_params.pointnet_channels_per_layer()
         self.start_nr_filters = model_params.pointnet_start_nr_channels()
-        self.point_net = PointNetModule(self.pointnet_channels_per_layer, self.start_nr_filters, device=device)
+        # distributed rows are [positions | values | barycentric weight]; the MLP sees all but the last column.  The
+        # reference creates these layers inside the first forward (mods:636-651); the width only depends on the cfg,
+        # so they exist from construction here (checkpoints load, optimizers see them, before any forward)
+        pos_ch = {"xyz": 3, "xyz+rgb": 6, "xyz+intensity": 4}.get(model_params.positions_mode())
+        val_ch = {"none": 1, "intensity": 1, "rgb": 3, "rgb+height": 4, "rgb+xyz": 6, "height": 1, "xyz": 3}.get(model_params.values_mode())
+        nr_in = pos_ch + val_ch if (pos_ch is not None and val_ch is not None) else None
+        self.point_net = PointNetModule(self.pointnet_channels_per_layer, self.start_nr_filters, nr_input_channels=nr_in, device=device)
 
         # ---- encoder
         self.resnet_blocks_per_down_lvl_list = torch.nn.ModuleList([])

@@ -296,4 +296,4 @@ def test_scatter_max_and_pointnet_aggregation():
     assert lv.shape == (m, 32) and ls.val_dim() == 32 and torch.isfinite(lv).all()
     lv.square().mean().backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in pn.parameters())
-    assert pn.layers[0].weight.grad.abs().sum() > 0
+    assert pn.layers[0].weight_v.grad.abs().sum() > 0 and pn.layers[0].weight_g.grad.abs().sum() > 0

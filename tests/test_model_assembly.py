@@ -90,7 +90,8 @@ def test_lnn_assembly_channels_and_state_dict_names(cfg_path):
     # group norm: 32 groups when divisible, else C/2 (mods:585-599)
     assert net.slice_fast_cuda.stepdown[1].norm.gn.num_groups == 32 and net.slice_fast_cuda.bottleneck.norm.gn.num_groups == 24
     keys = set(net.state_dict().keys())
-    for k in ["point_net.last_conv.weight", "point_net.last_conv.bias",
+    for k in ["point_net.layers.0.weight_g", "point_net.layers.0.weight_v", "point_net.layers.1.bias",
+              "point_net.last_conv.weight_g", "point_net.last_conv.weight_v", "point_net.last_conv.bias",
               "resnet_blocks_per_down_lvl_list.0.0.conv1.norm.gn.weight", "resnet_blocks_per_down_lvl_list.0.0.conv1.conv.weight",
               "resnet_blocks_per_down_lvl_list.1.0.conv2.conv.weight", "coarsens_list.1.coarse.weight",
               "resnet_blocks_bottleneck.0.contract.linear.weight", "resnet_blocks_bottleneck.0.conv.conv.weight",
@@ -99,6 +100,8 @@ def test_lnn_assembly_channels_and_state_dict_names(cfg_path):
               "slice_fast_cuda.bottleneck.norm.gn.weight", "slice_fast_cuda.linear_deltaW.bias", "slice_fast_cuda.gamma",
               "slice_fast_cuda.beta", "slice_fast_cuda.linear_clasify.weight"]:
         assert k in keys, k
+    assert net.point_net.layers[0].weight_v.shape == (16, 4) and net.point_net.layers[0].weight_g.shape == (16, 1)  # xyz + 1 dummy value
+    assert net.point_net.last_conv.weight_v.shape == (9 * 64, 32) and net.point_net.last_conv.weight_g.shape == (1, 32)
     # only the last convolution of the decoder carries a bias (models.py:176)
     assert "resnet_blocks_per_up_lvl_list.0.0.conv2.conv.bias" not in keys
     assert "resnet_blocks_per_down_lvl_list.0.0.conv1.conv.bias" not in keys
@@ -123,3 +126,36 @@ def test_blocks_reject_non_matrix_values():
     g2 = torch.autograd.grad(ref, [x, gn.gn.weight, gn.gn.bias], gy)
     for a, b in zip(g1, g2):
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-5)
+
+
+def test_weight_norm_layers_follow_the_reference_parametrisation():
+    """weight = weight_v * weight_g / ||weight_v||_F, g per output unit, initialised to ||v|| (utils.py:72-158, 291)."""
+    from lattice_net_amd.lattice_modules import LinearWN
+    torch.manual_seed(0)
+    lin = LinearWN(5, 7)
+    assert torch.allclose(lin.weight, lin.weight_v)  # g == ||v|| at construction
+    with torch.no_grad():
+        lin.weight_g.mul_(torch.linspace(0.5, 2.0, 7).unsqueeze(1))
+    x = torch.randn(11, 5)
+    w = lin.weight_v * (lin.weight_g / lin.weight_v.norm())
+    assert torch.allclose(lin(x), x @ w.t() + lin.bias)
+    lin(x).sum().backward()
+    assert lin.weight_g.grad is not None and lin.weight_v.grad is not None
+    # a checkpoint written by the reference (torch WeightNorm parameter names) loads with strict key matching
+    sd = {"weight_g": torch.ones(7, 1), "weight_v": torch.randn(7, 5), "bias": torch.zeros(7)}
+    lin.load_state_dict(sd, strict=True)
+
+
+def test_reference_style_checkpoint_round_trip(cfg_path, tmp_path):
+    """a state_dict saved from one LNN loads into a freshly built one before any forward pass."""
+    from lattice_net_amd.models import LNN
+    torch.manual_seed(1)
+    a = LNN(20, ModelParams.create(cfg_path), device="cpu")
+    path = tmp_path / "model_e_1.pt"
+    torch.save(a.state_dict(), path)
+    torch.manual_seed(2)
+    b = LNN(20, ModelParams.create(cfg_path), device="cpu")
+    missing, unexpected = b.load_state_dict(torch.load(path), strict=True)
+    assert not missing and not unexpected
+    for (ka, va), (kb, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert ka == kb and torch.equal(va, vb)
