@@ -1,0 +1,115 @@
+"""Training-side pieces of SURVEY.md §8f-4: the Lovasz-Softmax loss used next to NLL (ln_train.py:128-157, reference
+latticenet_py/lattice/lovasz_loss.py:17-57) and the intersection-over-union bookkeeping (callbacks/scores.py).
+
+The loss is the Lovasz extension of the per-class Jaccard index (Berman et al., CVPR 2018): for class c the errors
+e_i = |1[y_i = c] - p_i(c)| are sorted in decreasing order and dotted with the discrete gradient of the Jaccard loss
+along that order; classes absent from the cloud and the ignore class are skipped, the rest averaged.  All classes are
+processed at once ([N, C] sort / cumsum) with no host synchronisation — the reference loops over classes and reads one
+scalar per class back to the host.
+"""
+from __future__ import annotations
+
+import torch
+
+__all__ = ["LovaszSoftmax", "Scores"]
+
+
+class LovaszSoftmax(torch.nn.Module):
+    def __init__(self, ignore_index, reduction: str = "mean"):
+        super().__init__()
+        self.ignore_index = ignore_index
+        self.reduction = reduction
+
+    def forward(self, inputs, targets):
+        """inputs: log-probabilities [N, C] (the model's log-softmax, ln_train.py:156); targets: int64 [N]."""
+        if inputs.dim() != 2:
+            raise ValueError("LovaszSoftmax expects [N, C] log-probabilities")
+        probs = inputs.exp()
+        n, c = probs.shape
+        targets = targets.reshape(-1)
+        onehot = torch.zeros((n, c), dtype=probs.dtype, device=probs.device).scatter_(1, targets.clamp(0, c - 1).unsqueeze(1), 1.0)
+        # class-major [C, N] so that every class is one contiguous row: row-wise sort / cumsum are far faster than
+        # column-wise ones on an [N, C] matrix
+        onehot = onehot.t().contiguous()
+        errors = (onehot - probs.t()).abs()
+        errors_sorted, order = torch.sort(errors, dim=1, descending=True)
+        fg_sorted = torch.gather(onehot, 1, order)
+        # gradient of the Jaccard loss along the sorted order: J_k = 1 - (G - cumsum fg) / (G + cumsum (1 - fg))
+        gts = fg_sorted.sum(1, keepdim=True)
+        intersection = gts - fg_sorted.cumsum(1)
+        union = gts + (1.0 - fg_sorted).cumsum(1)
+        jaccard = 1.0 - intersection / union
+        grad = torch.cat((jaccard[:, :1], jaccard[:, 1:] - jaccard[:, :-1]), 1)
+        per_class = (errors_sorted * grad).sum(1)
+        present = gts.squeeze(1) > 0
+        if self.ignore_index is not None and 0 <= int(self.ignore_index) < c:
+            keep = torch.ones(c, dtype=torch.bool, device=probs.device)
+            keep[int(self.ignore_index)] = False
+            present = present & keep
+        if self.reduction == "none":
+            return per_class[present]
+        total = (per_class * present).sum()
+        if self.reduction == "sum":
+            return total
+        return total / present.sum().clamp(min=1)
+
+
+class Scores:
+    """Per-class intersection / union accumulated over clouds (callbacks/scores.py): IoU_c = I_c / U_c over the classes
+    that occur (union > 0), mean over those.  Counts stay on the device; `all_reduce(dist)` sums them over ranks."""
+
+    def __init__(self):
+        self.clear()
+
+    def clear(self):
+        self.start_fresh_eval()
+        self.best_iou = -99999999
+        self.best_iou_dict = {}
+
+    def start_fresh_eval(self):
+        self.intersection_per_class = None
+        self.union_per_class = None
+        self.nr_classes = None
+
+    def accumulate_scores(self, pred_softmax, gt, unlabeled_idx):
+        c = pred_softmax.shape[1]
+        pred = pred_softmax.detach().argmax(1)
+        gt = gt.detach().reshape(-1)
+        if self.intersection_per_class is None:
+            self.nr_classes = c
+            self.intersection_per_class = torch.zeros(c, dtype=torch.int64, device=gt.device)
+            self.union_per_class = torch.zeros(c, dtype=torch.int64, device=gt.device)
+        hit = torch.bincount(gt[pred == gt], minlength=c)[:c]
+        n_gt = torch.bincount(gt.clamp(0, c - 1), minlength=c)[:c]
+        n_pred = torch.bincount(pred, minlength=c)[:c]
+        in_gt = n_gt > 0  # the reference only scores the classes present in this cloud's ground truth
+        if unlabeled_idx is not None and 0 <= int(unlabeled_idx) < c:
+            in_gt[int(unlabeled_idx)] = False
+        self.intersection_per_class += hit * in_gt
+        self.union_per_class += (n_gt + n_pred - hit) * in_gt
+
+    def all_reduce(self, dist):
+        if dist is not None and self.intersection_per_class is not None:
+            dist.all_reduce(self.intersection_per_class, op=dist.ReduceOp.SUM)
+            dist.all_reduce(self.union_per_class, op=dist.ReduceOp.SUM)
+
+    def compute_stats(self, print_per_class_iou=False):
+        inter = self.intersection_per_class.tolist()
+        union = self.union_per_class.tolist()
+        iou_dict = {i: inter[i] / union[i] for i in range(self.nr_classes) if union[i] > 0}
+        if print_per_class_iou:
+            for i, v in iou_dict.items():
+                print("class iou for idx", i, " is ", v)
+        avg = sum(iou_dict.values()) / max(len(iou_dict), 1)
+        return avg, iou_dict
+
+    def avg_class_iou(self, print_per_class_iou=False):
+        return self.compute_stats(print_per_class_iou)[0]
+
+    def iou_per_class(self, print_per_class_iou=False):
+        return self.compute_stats(print_per_class_iou)[1]
+
+    def update_best(self):
+        avg, d = self.compute_stats()
+        if avg > self.best_iou:
+            self.best_iou, self.best_iou_dict = avg, d

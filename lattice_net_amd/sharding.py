@@ -65,3 +65,47 @@ def gather_sum(dist, value: float, device) -> float:
 def barrier(dist):
     if dist is not None:
         dist.barrier()
+
+
+def allreduce_gradients(dist, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 64 << 20):
+    """Data-parallel gradient exchange of the training step: every rank has run forward/backward
+    on its own cloud; gradients are averaged with bucketed all-reduces (RCCL rings over xGMI are per-link bound, so few
+    large messages: the whole LNN is < 4 MB, i.e. one bucket).  Parameters that received no gradient on this rank
+    (none in LNN) contribute zeros so that all ranks issue the same collectives."""
+    if dist is None:
+        return
+    world = dist.get_world_size()
+    params = [p for p in params if p.requires_grad]
+    bucket, size = [], 0
+
+    def flush():
+        nonlocal bucket, size
+        if not bucket:
+            return
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in bucket])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.div_(world)
+        off = 0
+        for p in bucket:
+            n = p.numel()
+            g = flat[off:off + n].view_as(p)
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.copy_(g)
+            off += n
+        bucket, size = [], 0
+
+    for p in params:
+        nbytes = p.numel() * p.element_size()
+        if bucket and (size + nbytes > bucket_bytes or p.dtype != bucket[0].dtype):
+            flush()
+        bucket.append(p)
+        size += nbytes
+    flush()
+
+
+def allreduce_sum_(dist, t: torch.Tensor) -> torch.Tensor:
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
