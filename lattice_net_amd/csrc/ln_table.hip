@@ -410,40 +410,65 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
     for (int k = 0; k < 16; ++k) base += s_wave_tok[k];
     __syncthreads();  // s_wave_tok is reused by the scans below
 
-    auto place = [&](int tk, unsigned long long pk, int& ls, int& pos) {
-        int key[D];
-        KeyPack<D>::unpack(pk, key);
-        int o = int(ln_hash<D>(key) % uint32_t(t.capacity)) - lo;
+    // Called by every lane of the wave (invalid lanes carry no token): the wave-level grouping below uses shuffles.
+    auto place = [&](bool valid, int tk, unsigned long long pk, int& ls, int& pos) {
         ls = -1;
         pos = -1;
-        for (int i = 0; i < size; ++i) {
-            unsigned long long cur = skeys[o];
-            if (cur == LN_EMPTY_KEY) {
-                cur = atomicCAS(&skeys[o], (unsigned long long)LN_EMPTY_KEY, pk);
-                if (cur == LN_EMPTY_KEY) cur = pk;
+        if (valid) {
+            int key[D];
+            KeyPack<D>::unpack(pk, key);
+            int o = int(ln_hash<D>(key) % uint32_t(t.capacity)) - lo;
+            for (int i = 0; i < size; ++i) {
+                unsigned long long cur = skeys[o];
+                if (cur == LN_EMPTY_KEY) {
+                    cur = atomicCAS(&skeys[o], (unsigned long long)LN_EMPTY_KEY, pk);
+                    if (cur == LN_EMPTY_KEY) cur = pk;
+                }
+                if (cur == pk) {
+                    ls = o;
+                    break;
+                }
+                if (++o >= size) o = 0;
             }
-            if (cur == pk) {
-                ls = o;
-                break;
-            }
-            if (++o >= size) o = 0;
+            if (ls < 0) atomicOr(t.status, LN_STATUS_BUCKET_OVERFLOW);
         }
-        if (ls >= 0) {
+        // Hot vertices (coarse lattices: thousands of tokens on one slot) would serialise on one LDS address.  When a
+        // large part of the wave landed on the slot of its first placed lane, that group takes its positions with ONE
+        // add and ONE min (ballot + rank among the matching lanes); everybody else issues its own pair.
+        const unsigned long long placed_mask = __ballot(ls >= 0);
+        const int lead = placed_mask ? __ffsll((long long)placed_mask) - 1 : 0;
+        const int lead_ls = __shfl(ls, lead, 64);
+        const unsigned long long match = __ballot(ls >= 0 && ls == lead_ls);
+        const bool grouped = __popcll(match) >= 16 && ls >= 0 && ls == lead_ls;
+        if (__popcll(match) >= 16) {  // wave-uniform
+            unsigned int mn = grouped ? (unsigned int)tk : 0xFFFFFFFFu;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) mn = min(mn, (unsigned int)__shfl_xor((int)mn, off, 64));
+            int base_pos = 0;
+            if ((threadIdx.x & 63) == lead) {
+                base_pos = atomicAdd(&scnt[lead_ls], __popcll(match));
+                atomicMin(&smin[lead_ls], mn);
+            }
+            base_pos = __shfl(base_pos, lead, 64);
+            if (grouped) pos = base_pos + __popcll(match & ((1ull << (threadIdx.x & 63)) - 1ull));
+        }
+        if (ls >= 0 && !grouped) {
             pos = atomicAdd(&scnt[ls], 1);
             atomicMin(&smin[ls], (unsigned int)tk);
-        } else {
-            atomicOr(t.status, LN_STATUS_BUCKET_OVERFLOW);
         }
-        tok_slot[tk] = ls >= 0 ? lo + ls : -1;
+        if (valid) tok_slot[tk] = ls >= 0 ? lo + ls : -1;
     };
 #pragma unroll
-    for (int k = 0; k < LN_BKT_REG_TOK; ++k)
-        if (r_tk[k] >= 0) place(r_tk[k], r_pk[k], r_ls[k], r_pos[k]);
-    for (int j = tid + LN_BKT_REG_TOK * LN_BKT_THREADS; j < ntok; j += LN_BKT_THREADS) {
+    for (int k = 0; k < LN_BKT_REG_TOK; ++k) place(r_tk[k] >= 0, r_tk[k], r_pk[k], r_ls[k], r_pos[k]);
+    for (int j0 = LN_BKT_REG_TOK * LN_BKT_THREADS; j0 < ntok; j0 += LN_BKT_THREADS) {
+        const int j = j0 + tid;
+        const bool valid = j < ntok;
         int ls, pos;
-        place(part_tok[in0 + j], part_pk[in0 + j], ls, pos);
-        part_slot[in0 + j] = ls;
-        part_pos[in0 + j] = pos;
+        place(valid, valid ? part_tok[in0 + j] : -1, valid ? part_pk[in0 + j] : LN_EMPTY_KEY, ls, pos);
+        if (valid) {
+            part_slot[in0 + j] = ls;
+            part_pos[in0 + j] = pos;
+        }
     }
     __syncthreads();
     // exclusive scans of the per-slot token and segment counts
@@ -715,11 +740,12 @@ struct BuildWs {
 
 static size_t ln_align256(size_t x) { return (x + 255) & ~size_t(255); }
 
-// Entries reserved per bucket region: 4x the mean bucket population + slack.  Clouds so skewed that one bucket
-// receives more (e.g. all points identical) are rebuilt on the atomic path (LN_STATUS_BUCKET_OVERFLOW).
+// Entries reserved per bucket region: 16x the mean bucket population + slack (coarse lattices put thousands of tokens
+// on single vertices; HBM is plentiful: 320 B per token).  Clouds so skewed that one bucket receives more (e.g. all
+// points identical) are rebuilt on the atomic path (LN_STATUS_BUCKET_OVERFLOW).
 static int ln_bucket_region(long long tokens, int capacity) {
     const int nbk = ln_bucket_count(capacity);
-    long long capb = 4 * ((tokens + nbk - 1) / nbk) + 1024;
+    long long capb = 16 * ((tokens + nbk - 1) / nbk) + 1024;
     capb = (capb + 63) & ~63ll;
     return int(capb);
 }
