@@ -10,61 +10,72 @@
 #include "ln_common.h"
 
 #define LN_GN_MAX_C 1024
-#define LN_GN_PASSES 64
+#define LN_GN_PASSES 16
+#define LN_GN_REPLICAS 32  // accumulator copies: memory-side atomics serialise per cache line, so spread the workgroups
 
 // acc[c*2 + 0] += sum_rows p(row, c), acc[c*2 + 1] += sum_rows q(row, c)
 //   forward  (gy == nullptr): p = x,  q = x*x
 //   backward               : p = gy' * x, q = gy'   with gy' = gy masked by (x*a[c] + b[c] > 0) when relu
+// A thread owns one float4 (4 channels) of a row; 256 / (c/4) rows are read per pass and LN_GN_PASSES independent
+// passes are in flight per thread.
 __global__ void __launch_bounds__(256)
     k_gn_stats(const float* __restrict__ x, const float* __restrict__ gy, const float* __restrict__ scale_shift, int relu, int m, int c,
                double* __restrict__ acc) {
-    __shared__ float s_p[256], s_q[256];
+    __shared__ float4 s_p[256], s_q[256];
     const int tid = threadIdx.x;
-    const int rows_per_pass = c <= 256 ? 256 / c : 1;
-    const int cols_per_thread = c <= 256 ? 1 : (c + 255) / 256;
-    const int row_in_pass = c <= 256 ? tid / c : 0;
-    const int slab = rows_per_pass * LN_GN_PASSES;
-    const long long r0 = (long long)blockIdx.x * slab;
-    for (int j = 0; j < cols_per_thread; ++j) {
-        const int col = c <= 256 ? tid - row_in_pass * c : tid + j * 256;
-        const bool live = col < c && row_in_pass < rows_per_pass;
-        float p = 0.f, q = 0.f;
-        if (live) {
-            const float a = (gy && relu) ? scale_shift[col] : 0.f;
-            const float b = (gy && relu) ? scale_shift[c + col] : 0.f;
-#pragma unroll 4
-            for (int k = 0; k < LN_GN_PASSES; ++k) {
-                const long long row = r0 + (long long)k * rows_per_pass + row_in_pass;
-                if (row < m) {
-                    const float xv = x[row * c + col];
-                    if (gy) {
-                        float g = gy[row * c + col];
-                        if (relu && !(xv * a + b > 0.f)) g = 0.f;
-                        p += g * xv;
-                        q += g;
-                    } else {
-                        p += xv;
-                        q += xv * xv;
-                    }
+    const int quads = c >> 2;                 // c % 4 == 0, c <= 1024  ->  quads <= 256
+    const int rows_per_pass = 256 / quads;
+    const int rp = tid / quads;
+    const int qi = tid - rp * quads;
+    const bool live = rp < rows_per_pass;
+    const long long r0 = (long long)blockIdx.x * rows_per_pass * LN_GN_PASSES;
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f), q = p;
+    if (live) {
+        float4 a = p, b = p;
+        if (gy && relu) {
+            a = reinterpret_cast<const float4*>(scale_shift)[qi];
+            b = reinterpret_cast<const float4*>(scale_shift + c)[qi];
+        }
+        float4 xv[LN_GN_PASSES], gv[LN_GN_PASSES];
+#pragma unroll
+        for (int k = 0; k < LN_GN_PASSES; ++k) {
+            const long long row = r0 + (long long)k * rows_per_pass + rp;
+            const bool ok = row < m;
+            xv[k] = ok ? reinterpret_cast<const float4*>(x + row * c)[qi] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy) gv[k] = ok ? reinterpret_cast<const float4*>(gy + row * c)[qi] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < LN_GN_PASSES; ++k) {
+            if (gy) {
+                float4 g = gv[k];
+                if (relu) {
+                    if (!(xv[k].x * a.x + b.x > 0.f)) g.x = 0.f;
+                    if (!(xv[k].y * a.y + b.y > 0.f)) g.y = 0.f;
+                    if (!(xv[k].z * a.z + b.z > 0.f)) g.z = 0.f;
+                    if (!(xv[k].w * a.w + b.w > 0.f)) g.w = 0.f;
                 }
+                p.x += g.x * xv[k].x; p.y += g.y * xv[k].y; p.z += g.z * xv[k].z; p.w += g.w * xv[k].w;
+                q.x += g.x; q.y += g.y; q.z += g.z; q.w += g.w;
+            } else {
+                p.x += xv[k].x; p.y += xv[k].y; p.z += xv[k].z; p.w += xv[k].w;
+                q.x += xv[k].x * xv[k].x; q.y += xv[k].y * xv[k].y; q.z += xv[k].z * xv[k].z; q.w += xv[k].w * xv[k].w;
             }
         }
-        if (c <= 256 && rows_per_pass > 1) {  // fold the threads that share a channel
-            s_p[tid] = p;
-            s_q[tid] = q;
-            __syncthreads();
-            if (live && row_in_pass == 0) {
-                for (int r = 1; r < rows_per_pass; ++r) {
-                    p += s_p[r * c + col];
-                    q += s_q[r * c + col];
-                }
-            }
-            __syncthreads();
+    }
+    s_p[tid] = p;
+    s_q[tid] = q;
+    __syncthreads();
+    if (live && rp == 0) {  // fold the threads that share a channel quad, then one fp64 atomic per channel sum
+        for (int r = 1; r < rows_per_pass; ++r) {
+            const float4 pp = s_p[r * quads + qi], qq = s_q[r * quads + qi];
+            p.x += pp.x; p.y += pp.y; p.z += pp.z; p.w += pp.w;
+            q.x += qq.x; q.y += qq.y; q.z += qq.z; q.w += qq.w;
         }
-        if (live && row_in_pass == 0) {
-            atomicAdd(&acc[2 * col], (double)p);
-            atomicAdd(&acc[2 * col + 1], (double)q);
-        }
+        double* dst = acc + (size_t)(blockIdx.x % LN_GN_REPLICAS) * 2 * c + 8 * qi;
+        atomicAdd(dst + 0, (double)p.x); atomicAdd(dst + 1, (double)q.x);
+        atomicAdd(dst + 2, (double)p.y); atomicAdd(dst + 3, (double)q.y);
+        atomicAdd(dst + 4, (double)p.z); atomicAdd(dst + 5, (double)q.z);
+        atomicAdd(dst + 6, (double)p.w); atomicAdd(dst + 7, (double)q.w);
     }
 }
 
@@ -74,12 +85,30 @@ __device__ __forceinline__ void ln_gn_channel_affine(const double* __restrict__ 
                                                      const float* __restrict__ beta, int m, int c, int groups, float eps, float* s_a,
                                                      float* s_b, float* __restrict__ mean_rstd, float* __restrict__ scale_shift) {
     const int cg = c / groups;
+    __shared__ double s_sum[LN_GN_MAX_C], s_sq[LN_GN_MAX_C];
+    for (int col = threadIdx.x; col < c; col += 256) {  // channel sums over the accumulator replicas
+        double v0[LN_GN_REPLICAS], v1[LN_GN_REPLICAS];
+#pragma unroll
+        for (int r = 0; r < LN_GN_REPLICAS; ++r) {
+            v0[r] = acc[(size_t)r * 2 * c + 2 * col];
+            v1[r] = acc[(size_t)r * 2 * c + 2 * col + 1];
+        }
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int r = 0; r < LN_GN_REPLICAS; ++r) {
+            a0 += v0[r];
+            a1 += v1[r];
+        }
+        s_sum[col] = a0;
+        s_sq[col] = a1;
+    }
+    __syncthreads();
     for (int col = threadIdx.x; col < c; col += 256) {
         const int g = col / cg;
         double s = 0.0, ss = 0.0;
         for (int k = 0; k < cg; ++k) {
-            s += acc[2 * (g * cg + k)];
-            ss += acc[2 * (g * cg + k) + 1];
+            s += s_sum[g * cg + k];
+            ss += s_sq[g * cg + k];
         }
         const double cnt = (double)m * cg;
         const double mean = s / cnt;
@@ -134,6 +163,24 @@ __global__ void __launch_bounds__(256)
                         int c, int groups, int relu, float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta) {
     __shared__ float s_gr[LN_GN_MAX_C], s_c2[LN_GN_MAX_C], s_c3[LN_GN_MAX_C], s_a[LN_GN_MAX_C], s_b[LN_GN_MAX_C];
     const int cg = c / groups;
+    __shared__ double s_ds[LN_GN_MAX_C], s_db[LN_GN_MAX_C];
+    for (int col = threadIdx.x; col < c; col += 256) {  // channel sums over the accumulator replicas
+        double v0[LN_GN_REPLICAS], v1[LN_GN_REPLICAS];
+#pragma unroll
+        for (int r = 0; r < LN_GN_REPLICAS; ++r) {
+            v0[r] = acc[(size_t)r * 2 * c + 2 * col];
+            v1[r] = acc[(size_t)r * 2 * c + 2 * col + 1];
+        }
+        double ds = 0.0, db = 0.0;
+#pragma unroll
+        for (int r = 0; r < LN_GN_REPLICAS; ++r) {
+            ds += v0[r];
+            db += v1[r];
+        }
+        s_ds[col] = ds;
+        s_db[col] = db;
+    }
+    __syncthreads();
     for (int col = threadIdx.x; col < c; col += 256) {
         const int g = col / cg;
         const float mean = mean_rstd[g], rstd = mean_rstd[groups + g];
@@ -141,8 +188,8 @@ __global__ void __launch_bounds__(256)
         for (int k = 0; k < cg; ++k) {
             const int cc = g * cg + k;
             const double gm = gamma ? (double)gamma[cc] : 1.0;
-            sum1 += acc[2 * cc] * gm;
-            sum2 += acc[2 * cc + 1] * gm;
+            sum1 += s_ds[cc] * gm;
+            sum2 += s_db[cc] * gm;
         }
         const double cnt = (double)m * cg;
         const double c2 = (sum2 * mean - sum1) * (double)rstd * rstd * rstd / cnt;
@@ -153,8 +200,8 @@ __global__ void __launch_bounds__(256)
         s_a[col] = scale_shift[col];
         s_b[col] = scale_shift[c + col];
         if (blockIdx.x == 0) {
-            if (dgamma) dgamma[col] = (float)((acc[2 * col] - acc[2 * col + 1] * mean) * rstd);
-            if (dbeta) dbeta[col] = (float)acc[2 * col + 1];
+            if (dgamma) dgamma[col] = (float)((s_ds[col] - s_db[col] * mean) * rstd);
+            if (dbeta) dbeta[col] = (float)s_db[col];
         }
     }
     __syncthreads();
@@ -187,7 +234,7 @@ static int ln_gn_check(const char* who, int m, int c, int groups) {
 }
 
 static int ln_gn_stats_grid(int m, int c) {
-    const int rows_per_pass = c <= 256 ? 256 / c : 1;
+    const int rows_per_pass = 256 / (c / 4);
     return ln_div_up(m, rows_per_pass * LN_GN_PASSES);
 }
 
@@ -198,7 +245,7 @@ static int ln_gn_apply_grid(int m, int c) {
     return grid < 1 ? 1 : grid;
 }
 
-extern "C" size_t ln_group_norm_workspace_bytes(int channels) { return (size_t)2 * channels * sizeof(double); }
+extern "C" size_t ln_group_norm_workspace_bytes(int channels) { return (size_t)LN_GN_REPLICAS * 2 * channels * sizeof(double); }
 
 extern "C" int ln_group_norm_forward(const float* x, const float* gamma, const float* beta, int m, int channels, int groups, float eps,
                                      int relu, float* y, float* mean_rstd, float* scale_shift, void* workspace, size_t workspace_bytes,

@@ -61,7 +61,7 @@ class GroupNormReluFunction(torch.autograd.Function):
         y = torch.empty_like(x)
         mean_rstd = torch.empty((2 * num_groups,), dtype=torch.float32, device=x.device)
         scale_shift = torch.empty((2 * c,), dtype=torch.float32, device=x.device)
-        ws = torch.empty((2 * c,), dtype=torch.float64, device=x.device)
+        ws = torch.empty((lib.ln_group_norm_workspace_bytes(c) // 8,), dtype=torch.float64, device=x.device)
         _lib.check(lib.ln_group_norm_forward(_lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), m, c, num_groups, float(eps), int(relu),
                                              _lib.ptr(y), _lib.ptr(mean_rstd), _lib.ptr(scale_shift), _lib.ptr(ws), ws.numel() * 8,
                                              _lib.stream_ptr(x.device)), "ln_group_norm_forward")
@@ -79,7 +79,7 @@ class GroupNormReluFunction(torch.autograd.Function):
         grad_x = torch.empty_like(x)
         grad_w = torch.empty((c,), dtype=torch.float32, device=x.device) if weight is not None else None
         grad_b = torch.empty((c,), dtype=torch.float32, device=x.device) if has_bias else None
-        ws = torch.empty((2 * c,), dtype=torch.float64, device=x.device)
+        ws = torch.empty((lib.ln_group_norm_workspace_bytes(c) // 8,), dtype=torch.float64, device=x.device)
         _lib.check(lib.ln_group_norm_backward(_lib.ptr(x), _lib.ptr(grad_y), _lib.ptr(weight), _lib.ptr(mean_rstd), _lib.ptr(scale_shift), m, c,
                                               num_groups, int(relu), _lib.ptr(grad_x), _lib.ptr(grad_w), _lib.ptr(grad_b), _lib.ptr(ws),
                                               ws.numel() * 8, _lib.stream_ptr(x.device)), "ln_group_norm_backward")
