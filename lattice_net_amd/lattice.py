@@ -995,6 +995,8 @@ class Lattice:
                 raise _lib.LatticeNetHipError("a lattice key does not fit the packed 64-bit slot format (positions/sigma too large)")
             ht.m_nr_filled = nr
             ht.m_nr_filled_is_dirty = False
+            if ht._storage is not None:
+                ht._storage.replay = None  # build accepted: drop the replay closures (they keep the build's tensors alive)
         if ht.m_nr_filled < 0 or ht.m_nr_filled >= 1e8:
             raise _lib.LatticeNetHipError(f"implausible vertex count {ht.m_nr_filled}")
         return ht.m_nr_filled

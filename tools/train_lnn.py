@@ -73,7 +73,7 @@ def main():
     lattice = Lattice.create(path, "lattice")
     net = LNN(args.classes, mp)
     sharding.broadcast_parameters(dist, list(net.parameters()) + list(net.buffers()))
-    opt = torch.optim.AdamW(net.parameters(), lr=args.lr, weight_decay=1e-4, amsgrad=True)  # ln_train.py:165
+    opt = torch.optim.AdamW(net.parameters(), lr=args.lr, weight_decay=1e-4, amsgrad=True, fused=True)  # ln_train.py:165 (+ fused update)
     lovasz, nll = LovaszSoftmax(ignore_index=0), torch.nn.NLLLoss(ignore_index=0)
     clouds = []
     for k in range(args.clouds):
