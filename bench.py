@@ -209,6 +209,41 @@ def main():
                     pass
     barrier()
 
+    # Per-stage GPU time ("report each stage separately and splat+slice alone"), measured with events on
+    # the launch stream in extra, untimed steps; the HBM fraction of splat+slice uses the algorithmic bytes of 8d.
+    stages = None
+    if rank == 0:
+        names = ["splat", "conv", "slice", "backward"]
+        acc_ms = dict.fromkeys(names, 0.0)
+        reps = 10
+        for _ in range(reps):
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+            W.grad = None
+            ev[0].record()
+            lv, wrap, idx, w = L.SplatLattice.apply(lat, pos, vals)
+            ev[1].record()
+            mm = lat.nr_lattice_vertices()
+            lv = lv[:mm].requires_grad_(True)
+            cv, cwrap = L.ConvIm2RowLattice.apply(lv, lat, W, 1)
+            ev[2].record()
+            out = L.SliceLattice.apply(cv, cwrap.lattice, pos, idx, w)
+            ev[3].record()
+            out.backward(G)
+            ev[4].record()
+            torch.cuda.synchronize()
+            for k, nm in enumerate(names):
+                acc_ms[nm] += ev[k].elapsed_time(ev[k + 1])
+        us = {nm: acc_ms[nm] / reps * 1e3 for nm in names}
+        splat_bytes = n * (4.0 * d + 4.0 * v + 8.0 * (d + 1)) + m * (4.0 * d + 4.0 * v)
+        slice_bytes = n * (8.0 * (d + 1) + 4.0 * v) + m * 4.0 * v
+        ss_us = us["splat"] + us["slice"]
+        stages = {"us": {k: round(x, 1) for k, x in us.items()},
+                  "note": "event-to-event on the launch stream; `splat` = clear + hash build + accumulate (+ the neighbour prefetch "
+                          "issued behind it), `conv` includes the wait for the vertex-count readback",
+                  "splat_plus_slice": {"us": round(ss_us, 1), "algorithmic_bytes": int(splat_bytes + slice_bytes),
+                                       "achieved_GBs": round((splat_bytes + slice_bytes) / ss_us / 1e3, 1),
+                                       "frac_of_hbm_peak": round((splat_bytes + slice_bytes) / ss_us / 1e3 / HBM_PEAK_GBS, 4)}}
+
     if rank == 0:
         value = n * world * args.steps / max_elapsed / 1e6
         roofline = None
@@ -224,7 +259,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": cfg["desc"], "points_per_gpu": n, "vertices": m, "val_dim": v, "nr_filters": f,
                        "sharding": f"{world} independent cloud(s), one per GPU", "checksum": round(checksum, 3)},
-            "roofline": roofline, "roofline_others": others, "cpu_baseline": cpu,
+            "roofline": roofline, "roofline_others": others, "stages": stages, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
     if dist is not None:
