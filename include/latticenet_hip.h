@@ -61,6 +61,9 @@ typedef struct LnTable {
     int* keys;                     /* [capacity,d] row  -> key            (m_keys)    */
     int* nr_filled;                /* [1]                                 (m_nr_filled) */
     int* status;                   /* [1] */
+    int* host_counters;            /* NULL, or 2 ints of pinned, device-visible host memory: every build writes
+                                      {nr_filled, status} there from its scan kernel, so the host reads the vertex
+                                      count by waiting for the build (an event) instead of enqueueing a copy */
 } LnTable;
 
 /* Adjacency "group -> the tokens that touch it" in CSR form, cut into segments of at most 16

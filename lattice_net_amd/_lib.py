@@ -37,6 +37,7 @@ class LnTable(C.Structure):
         ("keys", C.c_void_p),
         ("nr_filled", C.c_void_p),
         ("status", C.c_void_p),
+        ("host_counters", C.c_void_p),
     ]
 
 

@@ -644,7 +644,8 @@ __global__ void __launch_bounds__(256)
 
 // single workgroup: exclusive scan of the per-block first-occurrence counts (+ rows that existed before)
 __global__ void __launch_bounds__(1024) k_scan_blocks(const int* __restrict__ block_cnt, const unsigned long long* __restrict__ bitmap, int nb,
-                                                      int* __restrict__ block_prefix, int* nr_filled) {
+                                                      int* __restrict__ block_prefix, int* nr_filled, const int* __restrict__ status,
+                                                      int* __restrict__ host_counters) {
     __shared__ int s_wave[16];
     __shared__ int s_running;
     const int tid = threadIdx.x;
@@ -681,7 +682,13 @@ __global__ void __launch_bounds__(1024) k_scan_blocks(const int* __restrict__ bl
         if (tid == 1023) s_running = running + wave_off + incl;
         __syncthreads();
     }
-    if (tid == 0) *nr_filled = base + s_running;
+    if (tid == 0) {
+        *nr_filled = base + s_running;
+        if (host_counters) {  // pinned host memory: visible to the host once this build's event has completed
+            host_counters[0] = base + s_running;
+            host_counters[1] = *status;  // every producer kernel ran before this one
+        }
+    }
 }
 
 template <int D>
@@ -816,7 +823,7 @@ static int ln_rank_rows(const LnTable& t, const int* tok_slot, int* idx_out, lon
     if (!marked)  // the bucketed build sets the first-occurrence bits itself
         LN_LAUNCH("k_mark_first", k_mark_first, dim3(ws.nb), dim3(256), 0, st, t, tok_slot, tokens, ws.bitmap, ws.block_cnt);
     LN_LAUNCH("k_scan_blocks", k_scan_blocks, dim3(1), dim3(1024), 0, st, marked ? (const int*)nullptr : ws.block_cnt, ws.bitmap, ws.nb,
-              ws.block_prefix, t.nr_filled);
+              ws.block_prefix, t.nr_filled, t.status, t.host_counters);
     LN_LAUNCH("k_finalize", k_finalize<D>, dim3(ws.nb), dim3(256), 0, st, t, tok_slot, idx_out, tokens, ws.bitmap, ws.block_prefix);
     return ln_check_launch("ln build (mark/scan/finalize)");
 }

@@ -136,6 +136,10 @@ class HashTable:
             raise _lib.LatticeNetHipError("hash table is not initialised (no splat / create_verts happened yet)")
         if getattr(self, "_clear_pending", False):
             self.clear()  # a deferred begin_splat must land before anybody looks at the table
+        if getattr(self, "_pinned", None) is None:
+            # builds write {nr_filled, status} straight into this pinned (device-visible) pair from their scan kernel
+            self._pinned = torch.empty((2,), dtype=torch.int32, pin_memory=True)
+            self._readback_event = torch.cuda.Event()
         key = (id(s), self._counters.data_ptr())
         if getattr(self, "_c_table_key", None) == key:
             return self._c_table
@@ -145,7 +149,7 @@ class HashTable:
 
     def _make_c_table(self, s) -> _lib.LnTable:
         return _lib.LnTable(s.capacity, s.pos_dim, s.slot_keys.data_ptr(), s.slot_tok.data_ptr(), s.slot_cnt.data_ptr(), s.entries.data_ptr(),
-                            s.keys.data_ptr(), self._counters.data_ptr(), self._counters.data_ptr() + 4)
+                            s.keys.data_ptr(), self._counters.data_ptr(), self._counters.data_ptr() + 4, self._pinned.data_ptr())
 
     def clear(self, lazy: bool = False):  # HashTable.cu:49-57, one launch instead of four fill_ kernels
         """`lazy=True` only records that a clear is due: the next build issues it inside its own C call (no host
@@ -172,14 +176,10 @@ class HashTable:
         self._readback_pending = False
 
     def start_count_readback(self):
-        """Enqueues the 8-byte {nr_filled, status} copy to pinned host memory right behind the build, so that
-        nr_lattice_vertices() only waits for the build itself and not for kernels issued after it."""
-        if self._counters is None:
+        """Marks the end of a build on the stream: the build's scan kernel has written {nr_filled, status} into the pinned
+        pair, so nr_lattice_vertices() only waits for the build itself and not for kernels issued after it."""
+        if self._counters is None or getattr(self, "_pinned", None) is None:
             return
-        if getattr(self, "_pinned", None) is None:
-            self._pinned = torch.empty((2,), dtype=torch.int32, pin_memory=True)
-            self._readback_event = torch.cuda.Event()
-        self._pinned.copy_(self._counters, non_blocking=True)
         self._readback_event.record(torch.cuda.current_stream(self._counters.device))
         self._readback_pending = True
 
