@@ -145,10 +145,9 @@ static int ln_check_table(const LnTable* t, const char* who) {
 // ------------------------------------------------------------------------------------------
 // clear
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_table_clear(LnTable t, float* values, long long values_elems, int* zero_ints, int zero_count) {
+__global__ void __launch_bounds__(256) k_table_clear(LnTable t, float* values, long long values_elems) {
     const long long stride = (long long)gridDim.x * blockDim.x;
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    for (long long i = g; i < zero_count; i += stride) zero_ints[i] = 0;
     for (long long i = g; i < t.capacity; i += stride) {
         t.slot_keys[i] = LN_EMPTY_KEY;
         t.slot_tok[i] = LN_EMPTY_TOK;
@@ -169,7 +168,7 @@ __global__ void __launch_bounds__(256) k_table_clear(LnTable t, float* values, l
     }
 }
 
-static int ln_table_clear_impl(const LnTable* t, float* values, long long values_elems, int* zero_ints, int zero_count, void* stream) {
+extern "C" int ln_table_clear(const LnTable* t, float* values, long long values_elems, void* stream) {
     int rc = ln_check_table(t, "ln_table_clear");
     if (rc) return rc;
     LN_REQUIRE(values == nullptr || (reinterpret_cast<uintptr_t>(values) & 15) == 0, LN_ERR_ARG,
@@ -179,13 +178,8 @@ static int ln_table_clear_impl(const LnTable* t, float* values, long long values
     int blocks = ln_div_up(work, 256);
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
-    LN_LAUNCH("k_table_clear", k_table_clear, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *t, values, values_elems, zero_ints,
-              zero_count);
+    LN_LAUNCH("k_table_clear", k_table_clear, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *t, values, values_elems);
     return ln_check_launch("ln_table_clear");
-}
-
-extern "C" int ln_table_clear(const LnTable* t, float* values, long long values_elems, void* stream) {
-    return ln_table_clear_impl(t, values, values_elems, nullptr, 0, stream);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -275,21 +269,45 @@ __global__ void __launch_bounds__(256)
 // Pass 1: thread per point -> the d+1 packed keys and weights (+ distribute rows), scattered straight into the
 // fixed-capacity region of the bucket each key hashes to.  Positions inside a region come from an LDS count per
 // (block, bucket) plus ONE returning global atomic per (block, bucket) on the bucket's cursor.
+// The kernel also does what HashTable::clear would (HT.cu:49-57) for everything the later passes do not overwrite
+// anyway: values and keys zeroed, nr_filled = status = 0, and this build's first-occurrence bitmap.  The bucket
+// cursors live in the first words of t.slot_cnt (zero between builds: the scan pass resets them), word nbk of
+// it collects "a key did not fit the packed format".
 #define LN_KEYS_PTS_PER_THREAD 2
 #define LN_KEYS_PTS_PER_BLOCK (256 * LN_KEYS_PTS_PER_THREAD)
 template <int D>
 __global__ void __launch_bounds__(256)
     k_point_keys(LnTable t, const float* __restrict__ pos_raw, LnScale<D> sc, int n, int sb, int nbk, int capb,
-                 int* __restrict__ cursor, int* __restrict__ part_tok, unsigned long long* __restrict__ part_pk,
-                 int* __restrict__ tok_slot, float* __restrict__ w, const float* __restrict__ vals, int val_dim,
-                 float* __restrict__ distributed, int* __restrict__ seg_count) {
+                 int* __restrict__ part_tok, unsigned long long* __restrict__ part_pk, int* __restrict__ tok_slot,
+                 float* __restrict__ w, const float* __restrict__ vals, int val_dim, float* __restrict__ distributed,
+                 int* __restrict__ seg_count, float* __restrict__ clear_values, long long clear_values_elems,
+                 unsigned long long* __restrict__ bitmap, long long bitmap_words) {
     __shared__ int s_cnt[LN_BKT_MAX];
+    int* cursor = t.slot_cnt;
     for (int b = threadIdx.x; b < nbk; b += 256) s_cnt[b] = 0;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *seg_count = 0;  // the bucket workgroups of the next launch add to it
+    {  // clear duties (independent of everything below)
+        const long long stride = (long long)gridDim.x * 256;
+        const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+        if (clear_values) {
+            const long long n4 = clear_values_elems >> 2;
+            float4* v4 = reinterpret_cast<float4*>(clear_values);
+            for (long long i = g; i < n4; i += stride) v4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (long long i = (n4 << 2) + g; i < clear_values_elems; i += stride) clear_values[i] = 0.f;
+        }
+        const long long nk = (long long)t.capacity * D;
+        for (long long i = g; i < nk; i += stride) t.keys[i] = 0;
+        for (long long i = g; i < bitmap_words; i += stride) bitmap[i] = 0ull;
+        if (g == 0) {
+            *t.nr_filled = 0;
+            *t.status = 0;   // later passes (bucket build, scan) raise the error bits of this build
+            *seg_count = 0;  // the bucket workgroups of the next launch add to it
+        }
+    }
     __syncthreads();
     unsigned long long pk[LN_KEYS_PTS_PER_THREAD][D + 1];
     int bkt[LN_KEYS_PTS_PER_THREAD][D + 1];
     int rank[LN_KEYS_PTS_PER_THREAD][D + 1];
+    bool bad_key = false;
 #pragma unroll
     for (int it = 0; it < LN_KEYS_PTS_PER_THREAD; ++it) {
         const int p = blockIdx.x * LN_KEYS_PTS_PER_BLOCK + it * 256 + threadIdx.x;
@@ -312,7 +330,7 @@ __global__ void __launch_bounds__(256)
                 bkt[it][r] = int(ln_hash<D>(key) % uint32_t(t.capacity)) / sb;
                 rank[it][r] = atomicAdd(&s_cnt[bkt[it][r]], 1);
             } else {
-                atomicOr(t.status, LN_STATUS_KEY_RANGE);
+                bad_key = true;
                 tok_slot[tk] = -1;
             }
             if (w) w[tk] = ok ? s.bary[r] : -1.0f;
@@ -326,13 +344,13 @@ __global__ void __launch_bounds__(256)
             }
         }
     }
+    if (bad_key) atomicOr(&t.slot_cnt[nbk], 1);
     __syncthreads();
     for (int b = threadIdx.x; b < nbk; b += 256) {
         const int c = s_cnt[b];
         if (c) s_cnt[b] = atomicAdd(&cursor[b], c);
     }
     __syncthreads();
-    bool dropped = false;
 #pragma unroll
     for (int it = 0; it < LN_KEYS_PTS_PER_THREAD; ++it) {
         const int p = blockIdx.x * LN_KEYS_PTS_PER_BLOCK + it * 256 + threadIdx.x;
@@ -346,12 +364,10 @@ __global__ void __launch_bounds__(256)
                 part_tok[dst] = tk;
                 part_pk[dst] = pk[it][r];
             } else {
-                dropped = true;  // region full (heavily skewed cloud): the whole build is replayed on the atomic path
-                tok_slot[tk] = -1;
+                tok_slot[tk] = -1;  // region full (heavily skewed cloud): the bucket workgroup reports it, the build is replayed
             }
         }
     }
-    if (dropped) atomicOr(t.status, LN_STATUS_BUCKET_OVERFLOW);
 }
 
 // Pass 2: one workgroup per bucket.  LDS: keys[sb] | count[sb] | min token[sb] | token offset[sb] | segment offset[sb].
@@ -392,6 +408,7 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
         s_run_seg = 0;
     }
     const int ntok = min(cursor[b], capb);
+    if (tid == 0 && cursor[b] > capb) atomicOr(t.status, LN_STATUS_BUCKET_OVERFLOW);  // region overflow: tokens were dropped
     const size_t in0 = (size_t)b * capb;
     // issue the loads of the register-resident tokens before the barrier
     int r_tk[LN_BKT_REG_TOK], r_ls[LN_BKT_REG_TOK], r_pos[LN_BKT_REG_TOK];
@@ -517,6 +534,7 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
         const int beg = base + soff[i];
         csr.grp_start[h] = beg;
         t.slot_keys[h] = skeys[i];
+        t.entries[h] = -1;  // the clear's share of this slot range; finalize publishes the rows of the new vertices
         const unsigned int ft = smin[i];
         t.slot_tok[h] = ft;
         const int c = scnt[i];
@@ -644,8 +662,8 @@ __global__ void __launch_bounds__(256)
 
 // single workgroup: exclusive scan of the per-block first-occurrence counts (+ rows that existed before)
 __global__ void __launch_bounds__(1024) k_scan_blocks(const int* __restrict__ block_cnt, const unsigned long long* __restrict__ bitmap, int nb,
-                                                      int* __restrict__ block_prefix, int* nr_filled, const int* __restrict__ status,
-                                                      int* __restrict__ host_counters) {
+                                                      int* __restrict__ block_prefix, int* nr_filled, int* __restrict__ status,
+                                                      int* __restrict__ host_counters, int* __restrict__ cursor, int nbk) {
     __shared__ int s_wave[16];
     __shared__ int s_running;
     const int tid = threadIdx.x;
@@ -653,6 +671,11 @@ __global__ void __launch_bounds__(1024) k_scan_blocks(const int* __restrict__ bl
     const int wave = tid >> 6;
     const int base = *nr_filled;
     if (tid == 0) s_running = 0;
+    if (cursor) {  // bucketed build: its bucket cursors (+ the key-range word behind them) go back to zero for the next build
+        if (tid == 0 && cursor[nbk]) atomicOr(status, LN_STATUS_KEY_RANGE);
+        __syncthreads();
+        for (int i = tid; i <= nbk; i += 1024) cursor[i] = 0;
+    }
     __syncthreads();
     for (int start = 0; start < nb; start += 1024) {
         const int i = start + tid;
@@ -691,7 +714,8 @@ __global__ void __launch_bounds__(1024) k_scan_blocks(const int* __restrict__ bl
     }
 }
 
-template <int D>
+// FRESH: the table was cleared by this build call, so every slot is new (no entries[] gather per token)
+template <int D, bool FRESH>
 __global__ void __launch_bounds__(256)
     k_finalize(LnTable t, const int* tok_slot, int* idx_out, long long tokens, const unsigned long long* __restrict__ bitmap,
                const int* __restrict__ block_prefix) {
@@ -702,7 +726,7 @@ __global__ void __launch_bounds__(256)
         if (idx_out) idx_out[tk] = -1;
         return;
     }
-    const int e = t.entries[h];  // >=0: existed before this build (or already finalized — same value)
+    const int e = FRESH ? -1 : t.entries[h];  // >=0: existed before this build (or already finalized — same value)
     int row = e;
     const unsigned int ft = t.slot_tok[h];
     if (e < 0) {
@@ -724,12 +748,10 @@ __global__ void __launch_bounds__(256)
     if (idx_out) idx_out[tk] = row;
 }
 
-// Workspace of one build: bucket cursors + first-occurrence bitmap (one zero-filled range), block counts/prefixes,
+// Workspace of one build: first-occurrence bitmap, block counts/prefixes,
 // token->slot scratch, token->position, the scratch of the slot-CSR construction (ln_csr.hip) and the bucket regions.
 struct BuildWs {
-    int* bkt_cursor;  // [LN_BKT_MAX]  tokens scattered into each bucket region     } zeroed together by the clear
-    unsigned long long* bitmap;  //                                                   } that opens a bucketed build
-    size_t zero_ints;
+    unsigned long long* bitmap;
     int* block_cnt;
     int* block_prefix;
     int* tok_slot;
@@ -762,7 +784,7 @@ extern "C" size_t ln_build_workspace_bytes(long long tokens, int capacity) {
     if (capacity < 1) capacity = 1;
     const size_t nb = (size_t)ln_div_up(tokens, 256);
     const size_t region = (size_t)ln_bucket_count(capacity) * ln_bucket_region(tokens, capacity);
-    return ln_align256(LN_BKT_MAX * sizeof(int)) + ln_align256(nb * 4 * sizeof(unsigned long long)) + 2 * ln_align256(nb * sizeof(int)) +
+    return ln_align256(nb * 4 * sizeof(unsigned long long)) + 2 * ln_align256(nb * sizeof(int)) +
            2 * ln_align256((size_t)tokens * sizeof(int)) + ln_align256(ln_csr_scan_workspace_bytes(capacity)) +
            ln_align256(region * sizeof(unsigned long long)) + 3 * ln_align256(region * sizeof(int));
 }
@@ -774,11 +796,8 @@ static int ln_carve_ws(long long tokens, int capacity, void* workspace, size_t b
     LN_REQUIRE(tokens < 0x7FFFFFFFll, LN_ERR_ARG, "too many insertion tokens: %lld", tokens);
     char* p = static_cast<char*>(workspace);
     ws.nb = ln_div_up(tokens, 256);
-    ws.bkt_cursor = reinterpret_cast<int*>(p);
-    p += ln_align256(LN_BKT_MAX * sizeof(int));
     ws.bitmap = reinterpret_cast<unsigned long long*>(p);
     p += ln_align256((size_t)ws.nb * 4 * sizeof(unsigned long long));
-    ws.zero_ints = size_t(p - static_cast<char*>(workspace)) / sizeof(int);
     ws.block_cnt = reinterpret_cast<int*>(p);
     p += ln_align256((size_t)ws.nb * sizeof(int));
     ws.block_prefix = reinterpret_cast<int*>(p);
@@ -823,8 +842,11 @@ static int ln_rank_rows(const LnTable& t, const int* tok_slot, int* idx_out, lon
     if (!marked)  // the bucketed build sets the first-occurrence bits itself
         LN_LAUNCH("k_mark_first", k_mark_first, dim3(ws.nb), dim3(256), 0, st, t, tok_slot, tokens, ws.bitmap, ws.block_cnt);
     LN_LAUNCH("k_scan_blocks", k_scan_blocks, dim3(1), dim3(1024), 0, st, marked ? (const int*)nullptr : ws.block_cnt, ws.bitmap, ws.nb,
-              ws.block_prefix, t.nr_filled, t.status, t.host_counters);
-    LN_LAUNCH("k_finalize", k_finalize<D>, dim3(ws.nb), dim3(256), 0, st, t, tok_slot, idx_out, tokens, ws.bitmap, ws.block_prefix);
+              ws.block_prefix, t.nr_filled, t.status, t.host_counters, marked ? t.slot_cnt : (int*)nullptr, ln_bucket_count(t.capacity));
+    if (marked)  // bucketed build of a table cleared in the same call
+        LN_LAUNCH("k_finalize", (k_finalize<D, true>), dim3(ws.nb), dim3(256), 0, st, t, tok_slot, idx_out, tokens, ws.bitmap, ws.block_prefix);
+    else
+        LN_LAUNCH("k_finalize", (k_finalize<D, false>), dim3(ws.nb), dim3(256), 0, st, t, tok_slot, idx_out, tokens, ws.bitmap, ws.block_prefix);
     return ln_check_launch("ln build (mark/scan/finalize)");
 }
 
@@ -850,11 +872,13 @@ static int ln_build_points(const LnTable* t, const float* positions_raw, const f
         rc = ln_carve_ws(tokens, t->capacity, workspace, workspace_bytes, ws);
         if (rc) return rc;
     }
-    // the bucketed path needs a table it knows to be empty: the clear rides in this call
-    const bool bucketed = n > 0 && (flags & LN_BUILD_CLEAR_FIRST) && !(flags & LN_BUILD_ATOMIC_PATH);
-    if (flags & LN_BUILD_CLEAR_FIRST) {
-        rc = ln_table_clear_impl(t, clear_values, clear_values_elems, bucketed ? ws.bkt_cursor : nullptr, bucketed ? int(ws.zero_ints) : 0,
-                                 stream);
+    // The bucketed path needs a table it knows to be empty: it is taken when the clear rides in this call, and then does
+    // the clearing itself (no k_table_clear launch).  Its cursors use the first nbk+1 words of slot_cnt.
+    const bool bucketed = n > 0 && (flags & LN_BUILD_CLEAR_FIRST) && !(flags & LN_BUILD_ATOMIC_PATH) &&
+                          t->capacity > ln_bucket_count(t->capacity);
+    LN_REQUIRE(clear_values == nullptr || (reinterpret_cast<uintptr_t>(clear_values) & 15) == 0, LN_ERR_ARG, "%s: clear_values must be 16-byte aligned", who);
+    if ((flags & LN_BUILD_CLEAR_FIRST) && !bucketed) {
+        rc = ln_table_clear(t, clear_values, clear_values_elems, stream);
         if (rc) return rc;
     }
     if (n == 0) return LN_OK;
@@ -867,9 +891,9 @@ static int ln_build_points(const LnTable* t, const float* positions_raw, const f
             const int nbk = ln_bucket_count(t->capacity);
             const size_t lds = (size_t)sb * (sizeof(unsigned long long) + 4 * sizeof(int));
             LN_LAUNCH("k_point_keys", k_point_keys<D>, dim3(ln_div_up(n, LN_KEYS_PTS_PER_BLOCK)), dim3(256), 0, st, *t, positions_raw, sc, n, sb,
-                      nbk, ws.capb, ws.bkt_cursor, ws.part_tok, ws.part_pk, tok_slot, write_idx ? w : (float*)nullptr, vals, val_dim,
-                      distributed, csr->seg_count);
-            LN_LAUNCH("k_bucket_build", k_bucket_build<D>, dim3(nbk), dim3(LN_BKT_THREADS), lds, st, *t, sb, nbk, ws.capb, ws.bkt_cursor,
+                      nbk, ws.capb, ws.part_tok, ws.part_pk, tok_slot, write_idx ? w : (float*)nullptr, vals, val_dim, distributed,
+                      csr->seg_count, clear_values, clear_values_elems, ws.bitmap, (long long)ws.nb * 4);
+            LN_LAUNCH("k_bucket_build", k_bucket_build<D>, dim3(nbk), dim3(LN_BKT_THREADS), lds, st, *t, sb, nbk, ws.capb, t->slot_cnt,
                       ws.part_tok, ws.part_pk, ws.part_slot, ws.part_pos, tok_slot, *csr, ws.bitmap);
             rc = ln_rank_rows<D>(*t, tok_slot, write_idx ? idx : (int*)nullptr, tokens, ws, true, st);
         } else {

@@ -59,7 +59,7 @@ class _TableStorage:
         self.entries = torch.empty((capacity,), dtype=torch.int32, device=device)
         self.slot_keys = torch.empty((capacity,), dtype=torch.int64, device=device)
         self.slot_tok = torch.empty((capacity,), dtype=torch.int32, device=device)
-        self.slot_cnt = torch.empty((capacity,), dtype=torch.int32, device=device)
+        self.slot_cnt = torch.zeros((capacity,), dtype=torch.int32, device=device)  # scratch that is all-zero between builds
         self.version = 0
         self.nbr_cache = {}
         self.csr_cache = {}
