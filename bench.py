@@ -30,12 +30,15 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32-input MFMA peak (MI355X_MICROARCH.md)
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16 / bf16 MFMA peak (no sparsity)
 
 WORKLOADS = {
     # name: (n_points, val_dim, nr_filters, sigma, capacity, generator)
     "C3": dict(n=120000, v=32, f=32, sigma=0.9, capacity=100000, gen="lidar",
                desc="C3 SemanticKITTI-like scan: 120k pts, d=3, sigma 0.9, capacity 100k, V=F=32, splat->conv->slice fwd+bwd"),
     "C1": dict(n=1000, v=4, f=4, sigma=0.2, capacity=60000, gen="cube", desc="C1 1k-pt cube (parity-size case)"),
+    "C5": dict(n=480000, v=64, f=64, sigma=0.9, capacity=400000, gen="lidar4", half=True,
+               desc="C5 4 aggregated scans: 480k pts, capacity 400k, V=F=64, fp16 features / fp32 accumulate in the convolution"),
 }
 
 
@@ -43,6 +46,13 @@ def make_cloud(kind: str, n: int, seed: int) -> np.ndarray:
     from lattice_net_amd import synthetic
     if kind == "lidar":
         return synthetic.lidar_cloud(n, seed)
+    if kind == "lidar4":  # four scans taken 6 m apart along x, aggregated
+        parts = []
+        for k in range(4):
+            c = synthetic.lidar_cloud(n // 4, seed * 4 + k)
+            c[:, 0] += 6.0 * k
+            parts.append(c)
+        return np.ascontiguousarray(np.concatenate(parts, 0))
     return synthetic.cube_cloud(n, seed)
 
 
@@ -50,6 +60,8 @@ def algorithmic_work(kernel: str, n: int, m: int, d: int, v: int, f: int, e: int
     """(bound, unit, amount per launch) — SURVEY.md §8d per-unit figures x units per launch."""
     if kernel == "k_conv_mfma":
         return "mfma", "TFLOP/s", 2.0 * m * e * v * f
+    if kernel == "k_conv_mfma_f16":
+        return "mfma_f16", "TFLOP/s", 2.0 * m * e * v * f
     if kernel == "k_grad_filter_mfma":
         return "mfma", "TFLOP/s", 2.0 * m * e * v * f
     if kernel in ("k_scatter_point_rows", "k_csr_reduce_segments"):  # splat accumulate / slice backward: read rows+idx+w, write vertex rows
@@ -135,6 +147,7 @@ def main():
     cfg = WORKLOADS[args.workload]
     n, v, f, sigma, cap = cfg["n"], cfg["v"], cfg["f"], cfg["sigma"], cfg["capacity"]
     d, e = 3, 9
+    half = bool(cfg.get("half"))
     # independent clouds per rank (weak scaling); parameters broadcast from rank 0 over RCCL
     rng = np.random.default_rng(rank)
     pos = torch.from_numpy(make_cloud(cfg["gen"], n, sharding.cloud_seed(rank))).to(dev)
@@ -152,7 +165,11 @@ def main():
         lv, wrap, idx, w = L.SplatLattice.apply(lat, pos, vals)       # clear + hash build + accumulate
         m = lat.nr_lattice_vertices()                                   # the path's one host readback
         lv = lv[:m].requires_grad_(True)
-        cv, cwrap = L.ConvIm2RowLattice.apply(lv, lat, W, 1)           # neighbour list + gather-GEMM
+        if half:  # fp16 feature path: fp16 operands on the matrix cores, fp32 accumulation
+            cv, cwrap = L.ConvIm2RowLattice.apply(lv.half(), lat, W.half(), 1)
+            cv = cv.float()
+        else:
+            cv, cwrap = L.ConvIm2RowLattice.apply(lv, lat, W, 1)       # neighbour list + gather-GEMM
         out = L.SliceLattice.apply(cv, cwrap.lattice, pos, idx, w)     # slice
         out.backward(G)                                                 # slice bwd, conv bwd (values + filter)
         state.update(m=m, out=out, gv=lv.grad)
@@ -185,6 +202,8 @@ def main():
         avg_s = total_ms_v / launches_v / 1e3
         if bound_kind == "hbm":
             achieved, peak = amount / avg_s / 1e9, HBM_PEAK_GBS
+        elif bound_kind == "mfma_f16":
+            achieved, peak, bound_kind = amount / avg_s / 1e12, MFMA_F16_PEAK_TFLOPS, "mfma"
         else:
             achieved, peak = amount / avg_s / 1e12, MFMA_F32_PEAK_TFLOPS
         return {"bound": bound_kind, "achieved": round(achieved, 3), "peak": peak, "unit": unit, "frac": round(achieved / peak, 4),
@@ -224,7 +243,11 @@ def main():
             ev[1].record()
             mm = lat.nr_lattice_vertices()
             lv = lv[:mm].requires_grad_(True)
-            cv, cwrap = L.ConvIm2RowLattice.apply(lv, lat, W, 1)
+            if half:
+                cv, cwrap = L.ConvIm2RowLattice.apply(lv.half(), lat, W.half(), 1)
+                cv = cv.float()
+            else:
+                cv, cwrap = L.ConvIm2RowLattice.apply(lv, lat, W, 1)
             ev[2].record()
             out = L.SliceLattice.apply(cv, cwrap.lattice, pos, idx, w)
             ev[3].record()
@@ -256,7 +279,7 @@ def main():
             "metric": "Mpoints/sec splat+conv+slice fwd+bwd on 120k-pt SemanticKITTI scan",
             "value": round(value, 3), "unit": "Mpoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(max_elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f16 features / f32 accumulate" if half else "f32", "data": "synthetic",
             "config": {"workload": cfg["desc"], "points_per_gpu": n, "vertices": m, "val_dim": v, "nr_filters": f,
                        "sharding": f"{world} independent cloud(s), one per GPU", "checksum": round(checksum, 3)},
             "roofline": roofline, "roofline_others": others, "stages": stages, "cpu_baseline": cpu,

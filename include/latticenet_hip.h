@@ -231,6 +231,16 @@ int ln_slice_classify_backward(const float* grad_logits, const float* values, co
                                float* g_values, float* g_delta_w, float* g_lin_w, float* g_lin_b, float* grad_sliced,
                                float* w_eff, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Half-precision feature path of the convolution (BASELINE.json config 5 / SURVEY.md 8d C5: features fp16, accumulate
+ * fp32).  Same arguments and flags as ln_conv_forward / ln_conv_grad_filter; values, filter bank, grad_out and out are
+ * IEEE fp16 (`_Float16`), accumulation is fp32 (v_mfma_f32_16x16x16_f16 for val_dim in {16,32,64,96,128,256} and
+ * nr_filters % 16 == 0; any other shape on a scalar kernel), the filter gradient is returned in fp32. */
+int ln_conv_forward_f16(const int* nbr, const void* values_neigh, const void* filter, int m, int filter_extent, int val_dim,
+                        int nr_filters, int flags, void* out, void* stream);
+size_t ln_conv_grad_filter_f16_workspace_bytes(int m, int filter_extent, int val_dim, int nr_filters);
+int ln_conv_grad_filter_f16(const int* nbr, const void* values_neigh, const void* grad_out, int m, int filter_extent, int val_dim,
+                            int nr_filters, float* grad_filter, void* workspace, size_t workspace_bytes, void* stream);
+
 /* "Next" row: GroupNorm (+ optional fused ReLU) of the LNN blocks on the native [m, channels]
  * value layout (lattice_modules.py:585-616 runs torch.nn.GroupNorm on a transposed [1, C, M] view).  Statistics
  * per group over (all rows) x (channels of the group), biased variance, as torch.nn.GroupNorm.

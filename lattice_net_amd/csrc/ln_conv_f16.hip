@@ -1,0 +1,357 @@
+// Half-precision feature path of the lattice convolution (BASELINE.json config 5 / SURVEY.md §8d C5: "features fp16,
+// accumulate fp32"): the same gather-GEMM as ln_conv.hip on v_mfma_f32_16x16x16_f16 — fp16 operands, fp32 accumulators
+// — for the forward pass and the gradient wrt the values, and the filter gradient accumulated in fp32 (fmaf) from fp16
+// activations and gradients.
+//
+// Forward:  out[m, :] = sum_e values[nbr[m,e], :] @ W[e*V:(e+1)*V, :]        values / W / out in fp16
+//   * a wave owns 16 vertices; lane (i = lane&15, q = lane>>4) reads the q-th quarter of neighbour row nbr[m0+i, e]
+//     as V/4 contiguous halfs.  One MFMA consumes 16 k-values: lane group q supplies its halfs [4s, 4s+4) at step s, so
+//     the K order inside a neighbour is permuted (k = q*V/4 + 4s + j), which only reorders the fp32 accumulation.
+//   * W_e is staged per slot into LDS in that fragment order: 8 bytes per lane per MFMA, lane-linear.
+#include "ln_common.h"
+
+#include <hip/hip_fp16.h>
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef _Float16 halfx4 __attribute__((ext_vector_type(4)));
+
+template <int V, int NT, bool FLIP, bool WT>
+__global__ void __launch_bounds__(256)
+    k_conv_mfma_f16(const int* __restrict__ nbr, const _Float16* __restrict__ values, const _Float16* __restrict__ filter, int m, int E,
+                    _Float16* __restrict__ out, int f_total, int f_off) {
+    constexpr int F = 16 * NT;
+    constexpr int KQ = V / 4;   // halfs per lane per neighbour
+    constexpr int S = KQ / 4;   // MFMA steps per neighbour
+    static_assert(V % 16 == 0, "V must be a multiple of 16");
+    __shared__ __attribute__((aligned(16))) _Float16 s_b[V * F];  // [((s*NT + nt)*64 + lane)*4 + j]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int i = lane & 15;
+    const int q = lane >> 4;
+    const int m0 = blockIdx.x * 64 + wave * 16;
+    const int my_row = m0 + i;
+
+    floatx4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    for (int e = 0; e < E; ++e) {
+        halfx4 a[S];
+        const int es = (FLIP && e < E - 1) ? (e ^ 1) : e;
+        const int nb = (my_row < m) ? nbr[(size_t)my_row * E + es] : -1;
+        if (nb >= 0) {
+            const halfx4* src = reinterpret_cast<const halfx4*>(values + (size_t)nb * V + q * KQ);
+#pragma unroll
+            for (int s = 0; s < S; ++s) a[s] = src[s];
+        } else {
+#pragma unroll
+            for (int s = 0; s < S; ++s) a[s] = halfx4{0, 0, 0, 0};
+        }
+        __syncthreads();  // previous iteration's reads of s_b are done
+        for (int x = tid; x < V * F; x += 256) {
+            const int k = WT ? (x % V) : (x / F);
+            const int f = WT ? (x / V) : (x - k * F);
+            const int qq = k / KQ;
+            const int r = k - qq * KQ;
+            const size_t src = WT ? ((size_t)e * f_total + f_off + f) * V + k : ((size_t)e * V + k) * f_total + f_off + f;
+            s_b[((((r >> 2) * NT) + (f >> 4)) * 64 + qq * 16 + (f & 15)) * 4 + (r & 3)] = filter[src];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const halfx4 b = *reinterpret_cast<const halfx4*>(s_b + ((s * NT + nt) * 64 + lane) * 4);
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a[s], b, acc[nt], 0, 0, 0);
+            }
+        }
+    }
+    // C/D layout: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + q * 4 + r;
+            if (row < m) out[(size_t)row * f_total + f_off + nt * 16 + i] = (_Float16)acc[nt][r];
+        }
+    }
+}
+
+// any shape: one thread per output element, fp32 accumulation
+__global__ void __launch_bounds__(256)
+    k_conv_generic_f16(const int* __restrict__ nbr, const _Float16* __restrict__ values, const _Float16* __restrict__ filter, long long work,
+                       int E, int V, int F, int flip, int wt, _Float16* __restrict__ out) {
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= work) return;
+    const long long mrow = g / F;
+    const int f = int(g - mrow * F);
+    float acc = 0.0f;
+    for (int e = 0; e < E; ++e) {
+        const int nb = nbr[mrow * E + ((flip && e < E - 1) ? (e ^ 1) : e)];
+        if (nb < 0) continue;
+        const _Float16* vr = values + (size_t)nb * V;
+        for (int v = 0; v < V; ++v) {
+            const float wv = wt ? (float)filter[((size_t)e * F + f) * V + v] : (float)filter[((size_t)e * V + v) * F + f];
+            acc = fmaf((float)vr[v], wv, acc);
+        }
+    }
+    out[g] = (_Float16)acc;
+}
+
+template <int V, bool FLIP, bool WT>
+static void ln_conv_f16_launch_v(int nr_filters, const int* nbr, const _Float16* values, const _Float16* filter, int m, int E, _Float16* out,
+                                 hipStream_t st) {
+    const dim3 grid(ln_div_up(m, 64)), block(256);
+    constexpr int NT_MAX = (V * 128 * 2 <= 32 * 1024) ? 8 : 4;  // LDS of one slot's filter slice
+    int f_off = 0;
+    while (f_off < nr_filters) {
+        const int left = (nr_filters - f_off) / 16;
+        if (NT_MAX >= 8 && left >= 8) {
+            if constexpr (NT_MAX >= 8) LN_LAUNCH("k_conv_mfma_f16", (k_conv_mfma_f16<V, 8, FLIP, WT>), grid, block, 0, st, nbr, values, filter, m, E, out, nr_filters, f_off);
+            f_off += 128;
+        } else if (left >= 4) {
+            LN_LAUNCH("k_conv_mfma_f16", (k_conv_mfma_f16<V, 4, FLIP, WT>), grid, block, 0, st, nbr, values, filter, m, E, out, nr_filters, f_off);
+            f_off += 64;
+        } else if (left >= 2) {
+            LN_LAUNCH("k_conv_mfma_f16", (k_conv_mfma_f16<V, 2, FLIP, WT>), grid, block, 0, st, nbr, values, filter, m, E, out, nr_filters, f_off);
+            f_off += 32;
+        } else {
+            LN_LAUNCH("k_conv_mfma_f16", (k_conv_mfma_f16<V, 1, FLIP, WT>), grid, block, 0, st, nbr, values, filter, m, E, out, nr_filters, f_off);
+            f_off += 16;
+        }
+    }
+}
+
+template <bool FLIP, bool WT>
+static int ln_conv_f16_dispatch(const int* nbr, const _Float16* values, const _Float16* filter, int m, int E, int val_dim, int nr_filters,
+                                _Float16* out, hipStream_t st) {
+    bool done = false;
+    if (nr_filters % 16 == 0 && (reinterpret_cast<uintptr_t>(values) & 7) == 0) {
+        done = true;
+        switch (val_dim) {
+            case 16: ln_conv_f16_launch_v<16, FLIP, WT>(nr_filters, nbr, values, filter, m, E, out, st); break;
+            case 32: ln_conv_f16_launch_v<32, FLIP, WT>(nr_filters, nbr, values, filter, m, E, out, st); break;
+            case 64: ln_conv_f16_launch_v<64, FLIP, WT>(nr_filters, nbr, values, filter, m, E, out, st); break;
+            case 96: ln_conv_f16_launch_v<96, FLIP, WT>(nr_filters, nbr, values, filter, m, E, out, st); break;
+            case 128: ln_conv_f16_launch_v<128, FLIP, WT>(nr_filters, nbr, values, filter, m, E, out, st); break;
+            case 256: ln_conv_f16_launch_v<256, FLIP, WT>(nr_filters, nbr, values, filter, m, E, out, st); break;
+            default: done = false; break;
+        }
+    }
+    if (!done) {
+        const long long work = (long long)m * nr_filters;
+        LN_LAUNCH("k_conv_generic_f16", k_conv_generic_f16, dim3(ln_div_up(work, 256)), dim3(256), 0, st, nbr, values, filter, work, E, val_dim,
+                  nr_filters, FLIP ? 1 : 0, WT ? 1 : 0, out);
+    }
+    return ln_check_launch("ln_conv_forward_f16");
+}
+
+extern "C" int ln_conv_forward_f16(const int* nbr, const void* values_neigh, const void* filter, int m, int filter_extent, int val_dim,
+                                   int nr_filters, int flags, void* out, void* stream) {
+    LN_REQUIRE(m >= 0 && filter_extent >= 3 && val_dim >= 1 && nr_filters >= 1, LN_ERR_ARG, "ln_conv_forward_f16: bad sizes");
+    LN_REQUIRE(m == 0 || (nbr && values_neigh && filter && out), LN_ERR_ARG, "ln_conv_forward_f16: null buffer");
+    LN_REQUIRE((flags & ~3) == 0, LN_ERR_ARG, "ln_conv_forward_f16: unknown flags %d", flags);
+    if (m == 0) return LN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const _Float16* v = static_cast<const _Float16*>(values_neigh);
+    const _Float16* w = static_cast<const _Float16*>(filter);
+    _Float16* o = static_cast<_Float16*>(out);
+    switch (flags) {
+        case 0: return ln_conv_f16_dispatch<false, false>(nbr, v, w, m, filter_extent, val_dim, nr_filters, o, st);
+        case LN_CONV_FLIP_NEIGHBOURS: return ln_conv_f16_dispatch<true, false>(nbr, v, w, m, filter_extent, val_dim, nr_filters, o, st);
+        case LN_CONV_TRANSPOSED_FILTER: return ln_conv_f16_dispatch<false, true>(nbr, v, w, m, filter_extent, val_dim, nr_filters, o, st);
+        default: return ln_conv_f16_dispatch<true, true>(nbr, v, w, m, filter_extent, val_dim, nr_filters, o, st);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// filter gradient from fp16 activations / gradients, accumulated in fp32:
+//   grad_filter[e*V+v, f] = sum_m values[nbr[m,e], v] * grad_out[m, f]
+// grid = (row chunks, E).  The contraction runs over lattice vertices (rows), so both MFMA operands are read
+// "down the rows": a sub-tile of 64 rows is staged TRANSPOSED in LDS (s_at[v][row], s_gt[f][row], row stride padded to
+// 68 halfs) and lane (i, q) reads 4 consecutive rows of column i as one 8-byte word.  Each wave owns whole 16x16 output
+// tiles D[v, f]; partial [V, F] blocks per row chunk go to slabs, summed by k_reduce_slabs_f32 (deterministic).
+// ------------------------------------------------------------------------------------------
+#define LN_GF16_ROWS 512
+#define LN_GF16_SUB 64
+#define LN_GF16_STRIDE 68  // halfs per staged column: 34 words -> the 4 q-groups of a wave hit different banks
+template <int VT, int FT>
+__global__ void __launch_bounds__(256)
+    k_grad_filter_mfma_f16(const int* __restrict__ nbr, const _Float16* __restrict__ values, const _Float16* __restrict__ grad_out, int m,
+                           int E, float* __restrict__ partial, int v_total, int v_off, int f_total, int f_off) {
+    constexpr int V = VT * 16, F = FT * 16;
+    constexpr int TILES = VT * FT;
+    constexpr int TPW = (TILES + 3) / 4;
+    __shared__ __attribute__((aligned(16))) _Float16 s_at[V * LN_GF16_STRIDE];
+    __shared__ __attribute__((aligned(16))) _Float16 s_gt[F * LN_GF16_STRIDE];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int i = lane & 15;
+    const int q = lane >> 4;
+    const int e = blockIdx.y;
+    const int chunk_begin = blockIdx.x * LN_GF16_ROWS;
+    const int chunk_end = min(chunk_begin + LN_GF16_ROWS, m);
+    floatx4 acc[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) acc[t] = floatx4{0.f, 0.f, 0.f, 0.f};
+    for (int sub = chunk_begin; sub < chunk_end; sub += LN_GF16_SUB) {
+        __syncthreads();
+        // stage transposed: a thread moves 4 consecutive channels of one row
+        for (int x = tid; x < LN_GF16_SUB * (V / 4); x += 256) {
+            const int r = x / (V / 4), c4 = x - r * (V / 4);
+            const int row = sub + r;
+            const int nb = row < chunk_end ? nbr[(size_t)row * E + e] : -1;
+            halfx4 v = halfx4{0, 0, 0, 0};
+            if (nb >= 0) v = *reinterpret_cast<const halfx4*>(values + (size_t)nb * v_total + v_off + c4 * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s_at[(c4 * 4 + j) * LN_GF16_STRIDE + r] = v[j];
+        }
+        for (int x = tid; x < LN_GF16_SUB * (F / 4); x += 256) {
+            const int r = x / (F / 4), c4 = x - r * (F / 4);
+            const int row = sub + r;
+            halfx4 g = halfx4{0, 0, 0, 0};
+            if (row < chunk_end) g = *reinterpret_cast<const halfx4*>(grad_out + (size_t)row * f_total + f_off + c4 * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s_gt[(c4 * 4 + j) * LN_GF16_STRIDE + r] = g[j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+            const int tile = wave + 4 * t;
+            if (tile < TILES) {
+                const int vt = tile / FT, ft = tile - vt * FT;
+                const _Float16* pa = s_at + (vt * 16 + i) * LN_GF16_STRIDE + 4 * q;
+                const _Float16* pg = s_gt + (ft * 16 + i) * LN_GF16_STRIDE + 4 * q;
+#pragma unroll
+                for (int s = 0; s < LN_GF16_SUB / 16; ++s) {
+                    const halfx4 a = *reinterpret_cast<const halfx4*>(pa + 16 * s);
+                    const halfx4 b = *reinterpret_cast<const halfx4*>(pg + 16 * s);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, acc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    float* dst = partial + ((size_t)blockIdx.x * E + e) * ((size_t)v_total * f_total) + (size_t)v_off * f_total + f_off;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int tile = wave + 4 * t;
+        if (tile < TILES) {
+            const int vt = tile / FT, ft = tile - vt * FT;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[(size_t)(vt * 16 + q * 4 + r) * f_total + ft * 16 + i] = acc[t][r];
+        }
+    }
+}
+
+// any shape (fallback): lanes own (v, f) pairs, rows staged through LDS as floats
+#define LN_GF16_GSUB 32
+__global__ void __launch_bounds__(256)
+    k_grad_filter_f16(const int* __restrict__ nbr, const _Float16* __restrict__ values, const _Float16* __restrict__ grad_out, int m, int E,
+                      int V, int F, float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float s_mem16[];
+    float* s_a = s_mem16;                    // [SUB, V]
+    float* s_g = s_a + LN_GF16_GSUB * V;     // [SUB, F]
+    const int tid = threadIdx.x;
+    const int e = blockIdx.y;
+    const int chunk_begin = blockIdx.x * LN_GF16_ROWS;
+    const int chunk_end = min(chunk_begin + LN_GF16_ROWS, m);
+    const int VF = V * F;
+    constexpr int MAXP = 16;                 // (v, f) pairs per thread; blockIdx.z walks V*F in chunks of 4096 pairs
+    float acc[MAXP];
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) acc[k] = 0.f;
+    for (int sub = chunk_begin; sub < chunk_end; sub += LN_GF16_GSUB) {
+        __syncthreads();
+        for (int x = tid; x < LN_GF16_GSUB * V; x += 256) {
+            const int r = x / V, c = x - r * V;
+            const int row = sub + r;
+            const int nb = row < chunk_end ? nbr[(size_t)row * E + e] : -1;
+            s_a[x] = nb >= 0 ? (float)values[(size_t)nb * V + c] : 0.f;
+        }
+        for (int x = tid; x < LN_GF16_GSUB * F; x += 256) {
+            const int r = x / F, c = x - r * F;
+            const int row = sub + r;
+            s_g[x] = row < chunk_end ? (float)grad_out[(size_t)row * F + c] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k) {
+            const int j = blockIdx.z * (MAXP * 256) + tid + k * 256;
+            if (j < VF) {
+                const int v = j / F, f = j - v * F;
+                float a = acc[k];
+#pragma unroll 8
+                for (int r = 0; r < LN_GF16_GSUB; ++r) a = fmaf(s_a[r * V + v], s_g[r * F + f], a);
+                acc[k] = a;
+            }
+        }
+    }
+    float* dst = partial + ((size_t)blockIdx.x * E + e) * VF;
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+        const int j = blockIdx.z * (MAXP * 256) + tid + k * 256;
+        if (j < VF) dst[j] = acc[k];
+    }
+}
+
+__global__ void __launch_bounds__(256) k_reduce_slabs_f32(const float* __restrict__ partial, int nslabs, int total, float* __restrict__ out) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    float acc = 0.f;
+    for (int s = 0; s < nslabs; ++s) acc += partial[(size_t)s * total + g];
+    out[g] = acc;
+}
+
+extern "C" size_t ln_conv_grad_filter_f16_workspace_bytes(int m, int filter_extent, int val_dim, int nr_filters) {
+    if (m <= 0) return 256;
+    return (size_t)ln_div_up(m, LN_GF16_ROWS) * filter_extent * val_dim * nr_filters * sizeof(float) + 256;
+}
+
+extern "C" int ln_conv_grad_filter_f16(const int* nbr, const void* values_neigh, const void* grad_out, int m, int filter_extent, int val_dim,
+                                       int nr_filters, float* grad_filter, void* workspace, size_t workspace_bytes, void* stream) {
+    LN_REQUIRE(m >= 0 && filter_extent >= 3 && val_dim >= 1 && nr_filters >= 1, LN_ERR_ARG, "ln_conv_grad_filter_f16: bad sizes");
+    LN_REQUIRE(grad_filter && (m == 0 || (nbr && values_neigh && grad_out)), LN_ERR_ARG, "ln_conv_grad_filter_f16: null buffer");
+    hipStream_t st = (hipStream_t)stream;
+    const int total = filter_extent * val_dim * nr_filters;
+    if (m == 0) {
+        (void)hipMemsetAsync(grad_filter, 0, (size_t)total * sizeof(float), st);
+        return ln_check_launch("ln_conv_grad_filter_f16");
+    }
+    LN_REQUIRE(workspace && workspace_bytes >= ln_conv_grad_filter_f16_workspace_bytes(m, filter_extent, val_dim, nr_filters), LN_ERR_WORKSPACE,
+               "ln_conv_grad_filter_f16: workspace too small");
+    const int chunks = ln_div_up(m, LN_GF16_ROWS);
+    float* partial = static_cast<float*>(workspace);
+    const bool aligned = ((reinterpret_cast<uintptr_t>(values_neigh) | reinterpret_cast<uintptr_t>(grad_out)) & 7) == 0;
+    if (val_dim % 16 == 0 && nr_filters % 16 == 0 && aligned) {
+        const dim3 grid(chunks, filter_extent), block(256);
+        const _Float16* vv = static_cast<const _Float16*>(values_neigh);
+        const _Float16* gg = static_cast<const _Float16*>(grad_out);
+        for (int v_off = 0; v_off < val_dim;) {
+            const int vleft = (val_dim - v_off) / 16;
+            const int vt = vleft >= 4 ? 4 : (vleft >= 2 ? 2 : 1);
+            for (int f_off = 0; f_off < nr_filters;) {
+                const int fleft = (nr_filters - f_off) / 16;
+                const int ft = fleft >= 4 ? 4 : (fleft >= 2 ? 2 : 1);
+#define LN_GF16_CASE(A, B)                                                                                                          \
+    if (vt == A && ft == B)                                                                                                         \
+        LN_LAUNCH("k_grad_filter_mfma_f16", (k_grad_filter_mfma_f16<A, B>), grid, block, 0, st, nbr, vv, gg, m, filter_extent, partial, val_dim, \
+                  v_off, nr_filters, f_off);
+                LN_GF16_CASE(1, 1) LN_GF16_CASE(1, 2) LN_GF16_CASE(1, 4) LN_GF16_CASE(2, 1) LN_GF16_CASE(2, 2) LN_GF16_CASE(2, 4)
+                LN_GF16_CASE(4, 1) LN_GF16_CASE(4, 2) LN_GF16_CASE(4, 4)
+#undef LN_GF16_CASE
+                f_off += ft * 16;
+            }
+            v_off += vt * 16;
+        }
+    } else {
+        const size_t lds = sizeof(float) * LN_GF16_GSUB * ((size_t)val_dim + nr_filters);
+        LN_REQUIRE(lds <= 64 * 1024, LN_ERR_UNSUPPORTED, "ln_conv_grad_filter_f16: val_dim + nr_filters = %d too large", val_dim + nr_filters);
+        LN_LAUNCH("k_grad_filter_f16", k_grad_filter_f16, dim3(chunks, filter_extent, ln_div_up((long long)val_dim * nr_filters, 4096)), dim3(256),
+                  lds, st, nbr, static_cast<const _Float16*>(values_neigh), static_cast<const _Float16*>(grad_out), m, filter_extent, val_dim,
+                  nr_filters, partial);
+    }
+    LN_LAUNCH("k_reduce_slabs_f32", k_reduce_slabs_f32, dim3(ln_div_up(total, 256)), dim3(256), 0, st, partial, chunks, total, grad_filter);
+    return ln_check_launch("ln_conv_grad_filter_f16");
+}

@@ -672,11 +672,15 @@ class Lattice:
         nbr = self.neighbours(nb, dilation, False)  # the flipped traversal is applied in-kernel
         m = nbr.shape[0]
         vals = nb.values()
-        out = torch.empty((m, nr_filters), dtype=torch.float32, device=self._dev())
+        half = vals.dtype == torch.float16  # fp16 feature path (C5): fp16 operands, fp32 accumulation
+        if filter_bank.dtype != vals.dtype:
+            raise ValueError(f"filter bank is {filter_bank.dtype}, lattice values are {vals.dtype}")
+        out = torch.empty((m, nr_filters), dtype=vals.dtype, device=self._dev())
         flags = (_lib.LN_CONV_FLIP_NEIGHBOURS if flip_neighbours else 0) | (_lib.LN_CONV_TRANSPOSED_FILTER if filter_is_transposed else 0)
         lib = _lib.load()
-        _lib.check(lib.ln_conv_forward(_lib.ptr(nbr), _lib.ptr(vals), _lib.ptr(filter_bank), m, filter_extent, v, nr_filters, flags,
-                                       _lib.ptr(out), self._stream()), "ln_conv_forward")
+        fn, what = (lib.ln_conv_forward_f16, "ln_conv_forward_f16") if half else (lib.ln_conv_forward, "ln_conv_forward")
+        _lib.check(fn(_lib.ptr(nbr), _lib.ptr(vals), _lib.ptr(filter_bank), m, filter_extent, v, nr_filters, flags, _lib.ptr(out),
+                      self._stream()), what)
         conv = Lattice._clone_of(self)
         conv.m_name = "convolved_lattice"
         conv.m_hash_table.set_values(out)
@@ -704,12 +708,23 @@ class Lattice:
         if grad_out.shape[0] != mq:
             raise ValueError(f"grad_out has {grad_out.shape[0]} rows, the query lattice has {mq} vertices")
         dev = self._dev()
+        half = grad_out.dtype == torch.float16
+        if filter_bank.dtype != grad_out.dtype or nb.values().dtype != grad_out.dtype:
+            raise ValueError("grad_out, filter bank and lattice values must share one dtype (float32 or float16)")
         gf = torch.empty((E * v, f), dtype=torch.float32, device=dev)
-        ws = torch.empty((max(int(lib.ln_conv_grad_filter_workspace_bytes(mq, E, v, f)), 256),), dtype=torch.uint8, device=dev)
+        ws_bytes = lib.ln_conv_grad_filter_f16_workspace_bytes(mq, E, v, f) if half else lib.ln_conv_grad_filter_workspace_bytes(mq, E, v, f)
+        ws = torch.empty((max(int(ws_bytes), 256),), dtype=torch.uint8, device=dev)
         # ---- value gradient on the main stream: the query and neighbour roles swap (funcs:307-313, 380-387)
         nbr_n = nb.neighbours(q, dilation, False)
         mn = nbr_n.shape[0]
-        gvals = torch.empty((mn, v), dtype=torch.float32, device=dev)
+        gvals = torch.empty((mn, v), dtype=grad_out.dtype, device=dev)
+        if half:
+            _lib.check(lib.ln_conv_grad_filter_f16(_lib.ptr(nbr_q), _lib.ptr(nb.values()), _lib.ptr(grad_out), mq, E, v, f, _lib.ptr(gf),
+                                                   _lib.ptr(ws), ws.numel(), main), "ln_conv_grad_filter_f16")
+            flags = _lib.LN_CONV_FLIP_NEIGHBOURS | _lib.LN_CONV_TRANSPOSED_FILTER
+            _lib.check(lib.ln_conv_forward_f16(_lib.ptr(nbr_n), _lib.ptr(grad_out), _lib.ptr(filter_bank), mn, E, f, v, flags, _lib.ptr(gvals),
+                                               main), "ln_conv_forward_f16")
+            return gvals, gf.to(torch.float16)
         # (Measured on MI355X: running the filter gradient on a second stream made the step SLOWER, 0.254 -> 0.286 ms:
         # both kernels already fill the chip and the event hand-offs cost more than the overlap.)
         _lib.check(lib.ln_conv_grad_filter(_lib.ptr(nbr_q), _lib.ptr(nb.values()), _lib.ptr(grad_out), mq, E, v, f, _lib.ptr(gf), _lib.ptr(ws),

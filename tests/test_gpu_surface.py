@@ -297,3 +297,36 @@ def test_scatter_max_and_pointnet_aggregation():
     lv.square().mean().backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in pn.parameters())
     assert pn.layers[0].weight_v.grad.abs().sum() > 0 and pn.layers[0].weight_g.grad.abs().sum() > 0
+
+
+@pytest.mark.parametrize("v,f", [(64, 64), (32, 32), (96, 64), (128, 128), (16, 48), (20, 24)])
+def test_conv_fp16_feature_path_matches_fp64_reference(v, f):
+    """BASELINE config 5 (C5): fp16 features, fp32 accumulation.  Forward, gradient wrt values and wrt the filter bank of
+    ConvIm2RowLattice on half tensors against an fp64 evaluation of the same fp16 inputs."""
+    from lattice_net_amd import ConvIm2RowLattice
+    from lattice_net_amd.synthetic import cube_cloud
+    pos = cube_cloud(6000, 31)
+    lat = make_lattice(0.12, 120000)
+    lat.begin_splat()
+    lat.just_create_verts(T(pos), False)
+    m = lat.nr_lattice_vertices()
+    rng = np.random.default_rng(v * 7 + f)
+    vals = torch.tensor(rng.standard_normal((m, v)), dtype=torch.float16, device=dev(), requires_grad=True)
+    W = torch.tensor(rng.standard_normal((9 * v, f)) / np.sqrt(9 * v), dtype=torch.float16, device=dev(), requires_grad=True)
+    G = torch.tensor(rng.standard_normal((m, f)), dtype=torch.float16, device=dev())
+    out, wrap = ConvIm2RowLattice.apply(vals, lat, W, 1)
+    assert out.dtype == torch.float16 and out.shape == (m, f)
+    (out.float() * G.float()).sum().backward()
+    assert vals.grad.dtype == torch.float16 and W.grad.dtype == torch.float16
+    t, _, _ = oracle_table(pos, 0.12, 120000)
+    nbr = torch.from_numpy(O.neighbour_rows(t.keys[:m], t, 1, 1, 1, False).astype(np.int64))
+    v64 = vals.detach().cpu().double().requires_grad_(True)
+    w64 = W.detach().cpu().double().requires_grad_(True)
+    padded = torch.cat([v64, torch.zeros((1, v), dtype=torch.float64)], 0)
+    rows = padded[torch.where(nbr >= 0, nbr, torch.full_like(nbr, m))].reshape(m, 9 * v)
+    ref = rows @ w64
+    (ref * G.cpu().double()).sum().backward()
+    # results are rounded to fp16 once (rel 2^-11); the accumulation itself is fp32
+    close(N(out.float()), ref.detach().numpy(), scale=float(ref.abs().max()), rtol=2e-3)
+    close(N(vals.grad.float()), v64.grad.numpy(), scale=float(v64.grad.abs().max()), rtol=2e-3)
+    close(N(W.grad.float()), w64.grad.numpy(), scale=float(w64.grad.abs().max()), rtol=2e-3)
