@@ -37,6 +37,9 @@ WORKLOADS = {
     "C3": dict(n=120000, v=32, f=32, sigma=0.9, capacity=100000, gen="lidar",
                desc="C3 SemanticKITTI-like scan: 120k pts, d=3, sigma 0.9, capacity 100k, V=F=32, splat->conv->slice fwd+bwd"),
     "C1": dict(n=1000, v=4, f=4, sigma=0.2, capacity=60000, gen="cube", desc="C1 1k-pt cube (parity-size case)"),
+    "C2": dict(n=2500, v=32, f=32, sigma=0.05, capacity=60000, gen="box", desc="C2 ShapeNet-like surface cloud: 2.5k pts, sigma 0.05, capacity 60k, V=F=32"),
+    "C4": dict(n=200000, v=32, f=32, sigma=0.08, capacity=5000000, gen="planes",
+               desc="C4 ScanNet-like scene: 200k pts on planes, sigma 0.08, capacity 5M, V=F=32"),
     "C5": dict(n=480000, v=64, f=64, sigma=0.9, capacity=400000, gen="lidar4", half=True,
                desc="C5 4 aggregated scans: 480k pts, capacity 400k, V=F=64, fp16 features / fp32 accumulate in the convolution"),
 }
@@ -46,6 +49,10 @@ def make_cloud(kind: str, n: int, seed: int) -> np.ndarray:
     from lattice_net_amd import synthetic
     if kind == "lidar":
         return synthetic.lidar_cloud(n, seed)
+    if kind == "box":
+        return synthetic.box_surface_cloud(n, seed)
+    if kind == "planes":
+        return synthetic.planes_cloud(n, seed)
     if kind == "lidar4":  # four scans taken 6 m apart along x, aggregated
         parts = []
         for k in range(4):
