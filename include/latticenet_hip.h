@@ -241,6 +241,17 @@ size_t ln_conv_grad_filter_f16_workspace_bytes(int m, int filter_extent, int val
 int ln_conv_grad_filter_f16(const int* nbr, const void* values_neigh, const void* grad_out, int m, int filter_extent, int val_dim,
                             int nr_filters, float* grad_filter, void* workspace, size_t workspace_bytes, void* stream);
 
+/* "Next" row: the per-token MLP of PointNetModule (lattice_modules.py:636-676) on the distributed rows —
+ * y[rows, cout] = act(x[rows, cin] @ w[cout, cin]^T + b), act = LeakyReLU(slope) (slope < 0: identity).  Streaming
+ * kernels for rows ~ 10^5..10^6 and cin, cout <= 128 (cout % 4 == 0), where a BLAS GEMM with K = 4..32 is far off the
+ * memory roofline.  backward: grad_x may be NULL (inputs that need no gradient; otherwise cin % 4 == 0), grad_b may be
+ * NULL; `y` is the forward output (the activation mask is its sign); cin * cout <= 4096. */
+int ln_linear_act_forward(const float* x, const float* w, const float* b, long long rows, int cin, int cout, float slope, float* y,
+                          void* stream);
+size_t ln_linear_act_backward_workspace_bytes(int cin, int cout);
+int ln_linear_act_backward(const float* x, const float* w, const float* y, const float* grad_y, long long rows, int cin, int cout,
+                           float slope, float* grad_x, float* grad_w, float* grad_b, void* workspace, size_t workspace_bytes, void* stream);
+
 /* "Next" row: GroupNorm (+ optional fused ReLU) of the LNN blocks on the native [m, channels]
  * value layout (lattice_modules.py:585-616 runs torch.nn.GroupNorm on a transposed [1, C, M] view).  Statistics
  * per group over (all rows) x (channels of the group), biased variance, as torch.nn.GroupNorm.

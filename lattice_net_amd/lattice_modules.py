@@ -9,6 +9,7 @@ import math
 
 import torch
 
+from . import _lib
 from .lattice import Lattice
 from .lattice_funcs import (CoarsenLattice, ConvIm2RowLattice, DistributeLattice, FinefyLattice, GatherLattice, ScatterMaxLattice,
                             SliceLattice, SplatLattice)
@@ -68,6 +69,53 @@ class LinearWN(_WeightNormed, torch.nn.Module):  # utils.py:291 (weight_norm_wra
         return torch.nn.functional.linear(x, self.weight, self.bias)
 
 
+class LinearLeakyReluFunction(torch.autograd.Function):
+    """y = LeakyReLU(x @ w^T + b) for tall-and-skinny x ([tokens, <=128 channels]) on the streaming kernels of
+    csrc/ln_mlp.hip (ln_linear_act_forward / _backward) instead of a BLAS GEMM with K = 4..32."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, slope):
+        lib = _lib.load()
+        x, w = x.contiguous(), w.contiguous()
+        rows, cin = x.shape
+        cout = w.shape[0]
+        y = torch.empty((rows, cout), dtype=torch.float32, device=x.device)
+        _lib.check(lib.ln_linear_act_forward(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), rows, cin, cout, float(slope), _lib.ptr(y),
+                                             _lib.stream_ptr(x.device)), "ln_linear_act_forward")
+        ctx.save_for_backward(x, w, y)
+        ctx.slope = float(slope)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        lib = _lib.load()
+        x, w, y = ctx.saved_tensors
+        grad_y = grad_y.contiguous()
+        rows, cin = x.shape
+        cout = w.shape[0]
+        dev = x.device
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gw = torch.empty_like(w)
+        gb = torch.empty((cout,), dtype=torch.float32, device=dev) if ctx.has_bias else None
+        ws = torch.empty((lib.ln_linear_act_backward_workspace_bytes(cin, cout),), dtype=torch.uint8, device=dev)
+        _lib.check(lib.ln_linear_act_backward(_lib.ptr(x), _lib.ptr(w), _lib.ptr(y), _lib.ptr(grad_y), rows, cin, cout, ctx.slope, _lib.ptr(gx),
+                                              _lib.ptr(gw), _lib.ptr(gb), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)),
+                   "ln_linear_act_backward")
+        return gx, gw, gb, None
+
+
+def linear_leaky_relu(x, weight, bias, slope: float):
+    """LeakyReLU(linear(x)); the fused kernels take float32 CUDA rows with <= 128 channels (cout % 4 == 0, cin % 4 == 0 when
+    x needs a gradient), everything else goes through torch."""
+    cin, cout = x.shape[1], weight.shape[0]
+    ok = (x.is_cuda and x.dtype == torch.float32 and cout % 4 == 0 and cin <= 128 and cout <= 128 and cin * cout <= 4096
+          and (not x.requires_grad or cin % 4 == 0))
+    if ok:
+        return LinearLeakyReluFunction.apply(x, weight, bias, slope)
+    return torch.nn.functional.leaky_relu(torch.nn.functional.linear(x, weight, bias), slope)
+
+
 class SplatLatticeModule(torch.nn.Module):  # lattice_modules.py:46-51
     def forward(self, lattice_py, positions, values):
         lv, ls_wrap, indices, weights = SplatLattice.apply(lattice_py, positions, values)
@@ -123,8 +171,8 @@ class PointNetModule(torch.nn.Module):  # lattice_modules.py:618-733 (the step r
             self._make_layers(distributed.shape[1] - 1)
         barycentric_weights = distributed[:, -1]
         x = distributed[:, : distributed.shape[1] - 1]
-        for layer in self.layers:
-            x = self.act(layer(x))
+        for layer in self.layers:  # linear + LeakyReLU(0.2) per token, fused (mods:669-671)
+            x = linear_leaky_relu(x, layer.weight, layer.bias, self.act.negative_slope)
         reduced, argmax = ScatterMaxLattice.apply(x, lattice_py, indices)               # mods:688
         nr_points = lattice_py.vertex_point_counts(indices).unsqueeze(1)                  # mods:692
         safe = torch.where(argmax >= 0, argmax, torch.zeros_like(argmax)).long()

@@ -13,7 +13,7 @@ import lattice_net_amd as L  # noqa: E402
 from lattice_net_amd import synthetic  # noqa: E402
 
 dev = torch.device("cuda", 0)
-n, v, f = 120000, 32, 32
+n, v, f = int(os.environ.get("HP_N", "120000")), 32, 32
 rng = np.random.default_rng(0)
 pos = torch.from_numpy(synthetic.lidar_cloud(n, 0)).to(dev)
 vals = torch.from_numpy(rng.standard_normal((n, v)).astype(np.float32)).to(dev)
