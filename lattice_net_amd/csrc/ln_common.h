@@ -170,4 +170,29 @@ __device__ __forceinline__ int ln_block_excl_scan_256(int v, int* s_tmp, int* to
 }
 #endif
 
+#if defined(__HIPCC__)
+// out[g] (+)= sum over slabs of partial[s * stride + g], g < total.  16 outputs per workgroup, the slabs split over 16
+// thread rows and combined through LDS (a single thread walking hundreds of slabs is latency-bound).  Launch with
+// grid = ceil(total / 16), block = 256.
+template <bool ACCUMULATE>
+__global__ void __launch_bounds__(256)
+    ln_k_sum_slabs(const float* __restrict__ partial, int nslabs, long long stride, int total, float* __restrict__ out) {
+    __shared__ float s_part[16][17];
+    const int o = threadIdx.x & 15;
+    const int part = threadIdx.x >> 4;
+    const int g = blockIdx.x * 16 + o;
+    float acc = 0.0f;
+    if (g < total)
+        for (int s = part; s < nslabs; s += 16) acc += partial[(size_t)s * stride + g];
+    s_part[part][o] = acc;
+    __syncthreads();
+    if (part == 0 && g < total) {
+        float r = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) r += s_part[k][o];
+        out[g] = ACCUMULATE ? out[g] + r : r;
+    }
+}
+#endif
+
 static inline int ln_div_up(long long a, long long b) { return int((a + b - 1) / b); }

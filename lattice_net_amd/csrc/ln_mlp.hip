@@ -136,18 +136,6 @@ __global__ void __launch_bounds__(256)
     if (tid < cout) slab[pairs + tid] = acc_b;
 }
 
-__global__ void __launch_bounds__(256)
-    k_linear_reduce_slabs(const float* __restrict__ slabs, int nslabs, int pairs, int cout, float* __restrict__ gw, float* __restrict__ gb) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= pairs + cout) return;
-    float acc = 0.f;
-    for (int s = 0; s < nslabs; ++s) acc += slabs[(size_t)s * (pairs + cout) + j];
-    if (j < pairs)
-        gw[j] = acc;
-    else if (gb)
-        gb[j - pairs] = acc;
-}
-
 static int ln_mlp_check(const char* who, long long rows, int cin, int cout) {
     LN_REQUIRE(rows >= 0 && cin >= 1 && cout >= 4 && cout % 4 == 0 && cin <= LN_MLP_MAX_C && cout <= LN_MLP_MAX_C, LN_ERR_UNSUPPORTED,
                "%s: need cin <= %d, cout %% 4 == 0 and <= %d (got %d -> %d)", who, LN_MLP_MAX_C, LN_MLP_MAX_C, cin, cout);
@@ -207,7 +195,10 @@ extern "C" int ln_linear_act_backward(const float* x, const float* w, const floa
     const int grid = int(tiles < LN_MLP_W_GRID ? tiles : LN_MLP_W_GRID);
     const size_t lds = sizeof(float) * LN_MLP_TILE * ((size_t)cin + cout + 1);
     LN_LAUNCH("k_linear_act_backward_w", k_linear_act_backward_w, dim3(grid), dim3(256), lds, st, x, y, grad_y, rows, cin, cout, slope, slabs);
-    LN_LAUNCH("k_linear_reduce_slabs", k_linear_reduce_slabs, dim3(ln_div_up(pairs + cout, 256)), dim3(256), 0, st, slabs, grid, pairs, cout, grad_w,
-              grad_b);
+    LN_LAUNCH("k_linear_reduce_slabs", ln_k_sum_slabs<false>, dim3(ln_div_up(pairs, 16)), dim3(256), 0, st, slabs, grid, (long long)(pairs + cout),
+              pairs, grad_w);
+    if (grad_b)
+        LN_LAUNCH("k_linear_reduce_slabs", ln_k_sum_slabs<false>, dim3(ln_div_up(cout, 16)), dim3(256), 0, st, slabs + pairs, grid,
+                  (long long)(pairs + cout), cout, grad_b);
     return ln_check_launch("ln_linear_act_backward");
 }

@@ -470,19 +470,6 @@ __global__ void __launch_bounds__(256)
     if (tid < C) slab[CV + tid] = acc_b;
 }
 
-// out_w[j] += sum over slabs (j < CV), out_b[c] += ... (the gradient tensors are accumulated into, Lattice.cu:1091-1115)
-__global__ void __launch_bounds__(256)
-    k_sc_reduce_slabs(const float* __restrict__ slabs, int nslabs, int CV, int C, float* __restrict__ out_w, float* __restrict__ out_b) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= CV + C) return;
-    float acc = 0.0f;
-    for (int s = 0; s < nslabs; ++s) acc = acc + slabs[(size_t)s * (CV + C) + j];
-    if (j < CV)
-        out_w[j] += acc;
-    else
-        out_b[j - CV] += acc;
-}
-
 // grad_sliced rows scattered with global atomics (callers without a CSR adjacency)
 __global__ void __launch_bounds__(256)
     k_sc_scatter_atomic(const float* __restrict__ grad_sliced, const float* __restrict__ w_eff, const int* __restrict__ idx, long long work,
@@ -531,9 +518,12 @@ extern "C" int ln_slice_classify_backward(const float* grad_logits, const float*
                   idx, w, n, dp1, val_dim, nr_classes, g_delta_w, grad_sliced, w_eff, slabs);
     LN_SC_BWD(64) LN_SC_BWD(32) LN_SC_BWD(16) LN_SC_BWD(8)
 #undef LN_SC_BWD
-    const int cvc = nr_classes * val_dim + nr_classes;
-    LN_LAUNCH("k_sc_reduce_slabs", k_sc_reduce_slabs, dim3(ln_div_up(cvc, 256)), dim3(256), 0, st, slabs, grid, nr_classes * val_dim, nr_classes,
-              g_lin_w, g_lin_b);
+    // the gradient tensors are accumulated into (Lattice.cu:1091-1115)
+    const int cv = nr_classes * val_dim;
+    LN_LAUNCH("k_sc_reduce_slabs", ln_k_sum_slabs<true>, dim3(ln_div_up(cv, 16)), dim3(256), 0, st, slabs, grid, (long long)(cv + nr_classes), cv,
+              g_lin_w);
+    LN_LAUNCH("k_sc_reduce_slabs", ln_k_sum_slabs<true>, dim3(ln_div_up(nr_classes, 16)), dim3(256), 0, st, slabs + cv, grid,
+              (long long)(cv + nr_classes), nr_classes, g_lin_b);
     if (g_values) {
         const long long work = (long long)n * dp1 * val_dim;
         LN_LAUNCH("k_sc_scatter_atomic", k_sc_scatter_atomic, dim3(ln_div_up(work, 256)), dim3(256), 0, st, grad_sliced, w_eff, idx, work, dp1,
