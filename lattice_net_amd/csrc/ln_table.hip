@@ -865,7 +865,7 @@ static int ln_build_points(const LnTable* t, const float* positions_raw, const f
     const int write_idx = flags & LN_BUILD_WRITE_IDX;
     LN_REQUIRE(n >= 0, LN_ERR_ARG, "%s: n=%d", who, n);
     LN_REQUIRE(positions_raw != nullptr || n == 0, LN_ERR_ARG, "%s: null positions", who);
-    LN_REQUIRE(!write_idx || (idx && w), LN_ERR_ARG, "%s: write_idx set but idx/w null", who);
+    LN_REQUIRE(!write_idx || n == 0 || (idx && w), LN_ERR_ARG, "%s: write_idx set but idx/w null", who);
     const long long tokens = (long long)n * (t->pos_dim + 1);
     BuildWs ws;
     if (n > 0) {

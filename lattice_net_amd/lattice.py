@@ -420,7 +420,10 @@ class Lattice:
                 _lib.check(rc, "ln_distribute")
             st.touch()
             ht.m_nr_filled_is_dirty = True
-            ht.start_count_readback()
+            if n > 0:
+                ht.start_count_readback()
+            else:
+                ht._readback_pending = False  # nothing was launched that writes the pinned pair: read the device counters
             if write:
                 # the build's slot -> tokens adjacency serves every scatter that uses these indices (groups = slots,
                 # row of a group = entries[slot]); `idx` is kept alive by the entry so its address cannot be recycled

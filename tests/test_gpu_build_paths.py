@@ -119,3 +119,43 @@ def test_distribute_rows_identical_on_both_paths(monkeypatch):
     assert out[0][0] == out[1][0]
     for a, b in zip(out[0][1:], out[1][1:]):
         assert torch.equal(a, b)
+
+
+def test_degenerate_cloud_overflows_a_bucket_region_and_is_replayed(monkeypatch):
+    """All points identical: d+1 vertices receive every token, far beyond the 16x-mean bucket regions.  The build flags
+    it and the replay on the atomic path produces the canonical result."""
+    n = 60000
+    pos_np = np.tile(np.array([[0.3, -0.2, 0.7]], np.float32), (n, 1))
+    vals_np = np.ones((n, 2), np.float32)
+    lat, idx, w, m, status = build(pos_np, 0.5, 50000, False, monkeypatch, vals_np)
+    from lattice_net_amd import _lib
+    assert status & _lib.LN_STATUS_BUCKET_OVERFLOW
+    assert m == 4
+    t = O.OracleHashTable(50000, 3)
+    oidx, ow = O.build_splat(t, O.scale_positions(pos_np[:8], np.full((3,), 0.5, np.float32)))
+    np.testing.assert_array_equal(N(idx).reshape(n, 4), np.tile(oidx.reshape(8, 4)[:1], (n, 1)))
+    np.testing.assert_array_equal(N(w).reshape(n, 4)[:8], ow.reshape(8, 4))
+    got = N(lat.values()[:4])
+    np.testing.assert_allclose(got[:, 0], n * ow.reshape(8, 4)[0], rtol=1e-4)
+
+
+def test_tiny_tables_and_empty_clouds(monkeypatch):
+    import lattice_net_amd.lattice as LM
+    monkeypatch.setattr(LM, "_FORCE_ATOMIC_BUILD", False)
+    # capacity 2: too small for the bucket cursors -> atomic build behind the scenes; one point needs 4 slots -> overflow error
+    lat = make_lattice(0.5, 2)
+    lat.begin_splat()
+    lat.just_create_verts(T(np.zeros((1, 3), np.float32)), False)
+    from lattice_net_amd import LatticeNetHipError
+    with pytest.raises(LatticeNetHipError, match="overflow"):
+        lat.nr_lattice_vertices()
+    # capacity 8 holds the 4 vertices of one point
+    lat = make_lattice(0.5, 8)
+    lat.begin_splat()
+    idx, w = lat.just_create_verts(T(np.array([[0.1, 0.2, 0.3]], np.float32)), True)
+    assert lat.nr_lattice_vertices() == 4 and sorted(N(idx).tolist()) == [0, 1, 2, 3]
+    # empty cloud: nothing inserted, table cleared
+    lat = make_lattice(0.5, 1000)
+    lat.begin_splat()
+    idx, w = lat.just_create_verts(T(np.zeros((0, 3), np.float32)), True)
+    assert lat.nr_lattice_vertices() == 0 and idx.numel() == 0
