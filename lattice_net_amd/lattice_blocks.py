@@ -15,11 +15,12 @@ import torch
 
 from . import _lib
 from .lattice_funcs import GatherLattice, SliceClassifyLattice
-from .lattice_modules import CoarsenLatticeModule, ConvLatticeIm2RowModule, FinefyLatticeModule
+from .lattice_modules import CoarsenLatticeModule, ConvLatticeIm2RowModule, FinefyLatticeModule, LinearWN
 
 __all__ = ["DropoutLattice", "BatchNormLatticeModule", "GroupNormLatticeModule", "Conv1x1", "GnRelu1x1", "GnGelu1x1", "Gn", "ConvAct",
            "GnReluConv", "GnGeluConv", "BnReluConv", "CoarsenAct", "GnCoarsen", "GnReluCoarsen", "GnGeluCoarsen", "FinefyAct", "GnFinefy",
-           "GnReluFinefy", "GnGeluFinefy", "ResnetBlock", "BottleneckBlock", "SliceFastCUDALatticeModule"]
+           "GnReluFinefy", "GnGeluFinefy", "ResnetBlock", "BottleneckBlock", "SliceFastCUDALatticeModule", "Conv1x1WN", "Conv1x1WNAct",
+           "TwoConv", "ResnetBlock2", "DensenetBlock"]
 
 
 def _require_2d(lv: torch.Tensor):
@@ -346,6 +347,88 @@ class BottleneckBlock(torch.nn.Module):  # mods:1336-1361: 1x1 contract (C/4) ->
         lv = lv + identity
         ls.set_values(lv)
         return lv, ls
+
+
+class Conv1x1WN(torch.nn.Module):  # mods:736-759: weight-normalised per-vertex linear layer
+    def __init__(self, in_channels, out_channels, bias, device="cuda"):
+        super().__init__()
+        self.linear = LinearWN(in_channels, out_channels, bias=bias, device=device)
+
+    def forward(self, lv, ls):
+        ls.set_values(lv)
+        lv = self.linear(lv)
+        ls.set_values(lv)
+        return lv, ls
+
+
+class Conv1x1WNAct(Conv1x1WN):  # mods:761-786: ... followed by LeakyReLU(0.2)
+    def __init__(self, in_channels, out_channels, bias, device="cuda"):
+        super().__init__(in_channels, out_channels, bias, device)
+        self.act = torch.nn.LeakyReLU(0.2)
+
+    def forward(self, lv, ls):
+        lv, ls = super().forward(lv, ls)
+        lv = self.act(lv)
+        ls.set_values(lv)
+        return lv, ls
+
+
+class TwoConv(torch.nn.Module):  # mods:1221-1253
+    def __init__(self, in_channels, out_channels, dilations, biases, with_dropout, device="cuda"):
+        super().__init__()
+        self.conv1 = ConvAct(in_channels, out_channels, dilations[0], biases[0], with_dropout=False, device=device)
+        self.conv2 = ConvAct(in_channels, out_channels, dilations[1], biases[1], with_dropout=with_dropout, device=device)
+
+    def forward(self, lv, ls):
+        ls.set_values(lv)
+        lv, ls = self.conv1(lv, ls)
+        lv, ls = self.conv2(lv, ls)
+        ls.set_values(lv)
+        return lv, ls
+
+
+class ResnetBlock2(torch.nn.Module):  # mods:1291-1334: conv -> layer norm -> conv -> LeakyReLU, + identity
+    def __init__(self, in_channels, out_channels, dilations, biases, with_dropout, device="cuda"):
+        super().__init__()
+        self.conv1 = ConvLatticeIm2RowModule(in_channels=in_channels, out_channels=out_channels, neighbourhood_size=1, dilation=dilations[0],
+                                             bias=biases[0], device=device)
+        self.norm = torch.nn.GroupNorm(1, out_channels).to(device)
+        self.conv2 = ConvLatticeIm2RowModule(in_channels=out_channels, out_channels=out_channels, neighbourhood_size=1, dilation=dilations[1],
+                                             bias=biases[1], device=device)
+        self.act = torch.nn.LeakyReLU(0.2)
+
+    def forward(self, lv, ls):
+        identity = lv
+        ls.set_values(lv)
+        lv, ls = self.conv1(lv, ls)
+        lv = self.norm(lv)  # as the reference: GroupNorm(1, C) applied to the [M, C] matrix (statistics per vertex row)
+        ls.set_values(lv)
+        lv, ls = self.conv2(lv, ls)
+        lv = self.act(lv) + identity
+        ls.set_values(lv)
+        return lv, ls
+
+
+class DensenetBlock(torch.nn.Module):  # mods:1363-1395: every layer sees the concatenation of everything before it
+    def __init__(self, nr_filters, dilation_list, nr_layers, in_channels=None, device="cuda"):
+        super().__init__()
+        self.nr_filters = nr_filters
+        width = in_channels if in_channels is not None else nr_filters
+        self.layers = torch.nn.ModuleList([])
+        for i in range(nr_layers):
+            self.layers.append(GnReluConv(width, nr_filters, dilation_list[i], False, False, device=device))
+            width += nr_filters
+
+    def forward(self, lv, ls):
+        ls.set_values(lv)
+        stack, outputs = lv, []
+        for layer in self.layers:
+            lv_new, ls = layer(stack, ls)
+            stack = torch.cat((stack, lv_new), 1)
+            outputs.append(lv_new)
+        out = torch.cat(outputs, 1)
+        ls.set_values(out)
+        return out, ls
 
 
 # ---- classification head ---------------------------------------------------------------------------------------------

@@ -11,12 +11,12 @@ import torch
 
 from . import _lib
 from .lattice import Lattice
-from .lattice_funcs import (CoarsenLattice, ConvIm2RowLattice, DistributeLattice, FinefyLattice, GatherLattice, ScatterMaxLattice,
-                            SliceLattice, SplatLattice)
+from .lattice_funcs import (CoarsenLattice, ConvIm2RowLattice, DistributeLattice, ExpandLattice, FinefyLattice, GatherLattice,
+                            ScatterMaxLattice, SliceLattice, SplatLattice)
 
 __all__ = ["SplatLatticeModule", "DistributeLatticeModule", "PointNetModule", "ConvLatticeIm2RowModule", "CoarsenLatticeModule",
            "FinefyLatticeModule", "SliceLatticeModule", "GatherLatticeModule", "LinearWN", "ConvLatticeIm2RowWNModule",
-           "CoarsenLatticeWNModule", "FinefyLatticeWNModule"]
+           "CoarsenLatticeWNModule", "FinefyLatticeWNModule", "ExpandLatticeModule", "ConvLatticeModule"]
 
 
 def _kaiming_uniform_fan_out_(weight: torch.Tensor, fan_scale: float = 1.0, std_scale: float = 1.0):
@@ -187,6 +187,46 @@ class PointNetModule(torch.nn.Module):  # lattice_modules.py:618-733 (the step r
         reduced = self.act(reduced)
         lattice_py.set_values(reduced)
         return reduced, lattice_py
+
+
+class ExpandLatticeModule(torch.nn.Module):  # lattice_modules.py:98-118
+    """Adds vertices around jittered copies of the positions (Lattice.cu:292-348)."""
+
+    def __init__(self, point_multiplier, noise_stddev, expand_values):
+        super().__init__()
+        self.point_multiplier, self.noise_stddev, self.expand_values = point_multiplier, noise_stddev, expand_values
+
+    def forward(self, lattice_values, lattice_structure, positions):
+        lattice_structure.set_values(lattice_values)
+        lv, ls_wrap = ExpandLattice.apply(lattice_values, lattice_structure, positions, self.point_multiplier, self.noise_stddev,
+                                          self.expand_values)
+        ls = ls_wrap.lattice
+        ls.set_values(lv)
+        return lv, ls
+
+
+class ConvLatticeModule(torch.nn.Module):  # lattice_modules.py:120-172: the filter bank is sized from the first input
+    def __init__(self, nr_filters, neighbourhood_size, dilation=1, bias=True, device="cuda"):
+        super().__init__()
+        self.nr_filters, self.neighbourhood_size, self.dilation, self.use_bias, self.device = nr_filters, neighbourhood_size, dilation, bias, device
+        self.weight = None
+        self.bias = None
+
+    def forward(self, lattice_values, lattice_structure):
+        lattice_structure.set_values(lattice_values)
+        if self.weight is None:
+            rows = lattice_structure.get_filter_extent(self.neighbourhood_size) * lattice_structure.val_dim()
+            self.weight = torch.nn.Parameter(torch.empty(rows, self.nr_filters, device=self.device))
+            _kaiming_uniform_fan_out_(self.weight)
+            if self.use_bias:
+                self.bias = torch.nn.Parameter(torch.empty(self.nr_filters, device=self.device))
+                _bias_init_(self.bias, self.weight)
+        lv, ls_wrap = ConvIm2RowLattice.apply(lattice_values, lattice_structure, self.weight, self.dilation)
+        ls = ls_wrap.lattice
+        if self.use_bias:
+            lv = lv + self.bias
+        ls.set_values(lv)
+        return lv, ls
 
 
 class ConvLatticeIm2RowModule(torch.nn.Module):  # lattice_modules.py:174-250

@@ -158,3 +158,47 @@ def test_linear_leaky_relu_kernels_match_torch(rows, cin, cout, with_gx):
     torch.testing.assert_close(b.grad.cpu().double(), b64.grad, rtol=1e-4, atol=1e-4 * float(b64.grad.abs().max()))
     if with_gx:
         torch.testing.assert_close(x.grad.cpu().double(), x64.grad, rtol=1e-4, atol=1e-5)
+
+
+def test_remaining_reference_blocks_run_forward_and_backward():
+    """Blocks of lattice_modules.py that LNN does not use (Conv1x1WN(Act), TwoConv, ResnetBlock2, DensenetBlock, ConvAct,
+    GnGeluConv, BnReluConv, Gn*Coarsen / *Finefy variants, ConvLatticeModule, ExpandLatticeModule): shapes and gradients."""
+    from lattice_net_amd import Lattice
+    from lattice_net_amd import lattice_blocks as B
+    from lattice_net_amd.lattice_modules import ConvLatticeModule, ExpandLatticeModule
+    from lattice_net_amd.synthetic import cube_cloud
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    pos = torch.from_numpy(cube_cloud(3000, 3)).to(dev)
+    lat = Lattice(sigmas=[0.2] * 3, capacity=40000, device=dev)
+    lat.begin_splat()
+    lat.just_create_verts(pos, False)
+    lat.set_positions(pos)
+    m = lat.nr_lattice_vertices()
+    c = 16
+    for block in [B.Conv1x1WN(c, c, True), B.Conv1x1WNAct(c, c, False), B.TwoConv(c, c, [1, 1], [False, True], False),
+                  B.ResnetBlock2(c, c, [1, 2], [True, True], False), B.ConvAct(c, c, 1, True, False), B.GnGeluConv(c, c, 1, False, False),
+                  B.BnReluConv(c, c, 1, False), B.GnGelu1x1(c, c, True), B.Gn(c), ConvLatticeModule(c, 1)]:
+        lv = torch.randn((m, c), device=dev, requires_grad=True)
+        out, ls = block(lv, lat)
+        assert out.shape == (m, c) and torch.isfinite(out).all(), type(block).__name__
+        out.sum().backward()
+        assert lv.grad is not None and torch.isfinite(lv.grad).all(), type(block).__name__
+    dn = B.DensenetBlock(8, [1, 1, 1], 3, in_channels=c)
+    lv = torch.randn((m, c), device=dev, requires_grad=True)
+    out, _ = dn(lv, lat)
+    assert out.shape == (m, 24)
+    out.sum().backward()
+    # level-changing variants
+    for cls_c, cls_f in [(B.GnCoarsen, B.GnFinefy), (B.GnGeluCoarsen, B.GnGeluFinefy), (B.GnReluCoarsen, B.FinefyAct)]:
+        lv = torch.randn((m, c), device=dev, requires_grad=True)
+        cv, cs = cls_c(c, 2 * c)(lv, lat)
+        assert cs.lvl() == lat.lvl() + 1 and cv.shape == (cs.nr_lattice_vertices(), 2 * c)
+        fv, fs = cls_f(2 * c, c)(cv, cs, lat)
+        assert fv.shape == (m, c)
+        fv.sum().backward()
+        assert torch.isfinite(lv.grad).all() and lv.grad.abs().sum() > 0
+    ex = ExpandLatticeModule(2, 0.05, True)
+    lv = torch.randn((m, c), device=dev)
+    ev, es = ex(lv, lat, pos)
+    assert es.nr_lattice_vertices() >= m and ev.shape == (es.nr_lattice_vertices(), c)
