@@ -61,9 +61,10 @@ typedef struct LnTable {
     int* keys;                     /* [capacity,d] row  -> key            (m_keys)    */
     int* nr_filled;                /* [1]                                 (m_nr_filled) */
     int* status;                   /* [1] */
-    int* host_counters;            /* NULL, or 2 ints of pinned, device-visible host memory: every build writes
-                                      {nr_filled, status} there from its scan kernel, so the host reads the vertex
-                                      count by waiting for the build (an event) instead of enqueueing a copy */
+    int* host_counters;            /* NULL, or 4 ints of pinned, device-visible host memory: every build writes
+                                      {nr_filled, status, 1} there from its scan kernel (word 2 last, system-scope
+                                      release).  A host that cleared word 2 before the call can spin on it and read the
+                                      vertex count as soon as the scan has run, without a copy or an event */
 } LnTable;
 
 /* Adjacency "group -> the tokens that touch it" in CSR form, cut into segments of at most 16

@@ -139,8 +139,9 @@ __device__ __forceinline__ int ln_retrieve(const LnTable& t, const int* key) {
     for (int conflicts = 0; conflicts < limit; ++conflicts) {
         const int h = pr.slot(conflicts);
         const uint64_t cur = t.slot_keys[h];
+        const int row = t.entries[h];  // issued together with the key: a hit costs one memory round trip, not two
         if (cur == LN_EMPTY_KEY) return -1;
-        if (cur == pk) return t.entries[h];
+        if (cur == pk) return row;
     }
     return -1;
 }

@@ -707,9 +707,11 @@ __global__ void __launch_bounds__(1024) k_scan_blocks(const int* __restrict__ bl
     }
     if (tid == 0) {
         *nr_filled = base + s_running;
-        if (host_counters) {  // pinned host memory: visible to the host once this build's event has completed
+        if (host_counters) {  // pinned host memory: the host spins on word 2 (it cleared it before the launch)
             host_counters[0] = base + s_running;
             host_counters[1] = *status;  // every producer kernel ran before this one
+            __threadfence_system();
+            __hip_atomic_store(&host_counters[2], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }

@@ -138,7 +138,8 @@ class HashTable:
             self.clear()  # a deferred begin_splat must land before anybody looks at the table
         if getattr(self, "_pinned", None) is None:
             # builds write {nr_filled, status} straight into this pinned (device-visible) pair from their scan kernel
-            self._pinned = torch.empty((2,), dtype=torch.int32, pin_memory=True)
+            self._pinned = torch.zeros((4,), dtype=torch.int32, pin_memory=True)
+            self._pinned_np = self._pinned.numpy()  # same memory: the host polls word 2
             self._readback_event = torch.cuda.Event()
         key = (id(s), self._counters.data_ptr())
         if getattr(self, "_c_table_key", None) == key:
@@ -175,21 +176,33 @@ class HashTable:
         self.m_nr_filled_is_dirty = True
         self._readback_pending = False
 
+    def arm_count_readback(self):
+        """Call right before a build is issued: clears the "counters written" word the build's scan kernel sets."""
+        if getattr(self, "_pinned", None) is not None:
+            self._pinned_np[2] = 0
+
     def start_count_readback(self):
-        """Marks the end of a build on the stream: the build's scan kernel has written {nr_filled, status} into the pinned
-        pair, so nr_lattice_vertices() only waits for the build itself and not for kernels issued after it."""
+        """Marks the end of a build on the stream.  The build's scan kernel writes {nr_filled, status} into the pinned
+        triple and then sets its third word; nr_lattice_vertices() spins on that word, so it returns as soon as the scan
+        has run — before the rest of the build and anything queued behind it."""
         if self._counters is None or getattr(self, "_pinned", None) is None:
             return
         self._readback_event.record(torch.cuda.current_stream(self._counters.device))
         self._readback_pending = True
 
     def read_counters(self):
-        """[nr_filled, status]; one blocking wait (on the readback event if a build enqueued one)."""
+        """[nr_filled, status]; one wait (a spin on the pinned flag if a build armed one, else a device read)."""
         self.flush()
         if getattr(self, "_readback_pending", False):
-            self._readback_event.synchronize()
             self._readback_pending = False
-            return self._pinned.tolist()
+            arr = self._pinned_np
+            spins = 0
+            while arr[2] == 0:
+                spins += 1
+                if spins > 20000:  # ~ms: fall back to the event (a build that failed to launch, exotic memory settings)
+                    self._readback_event.synchronize()
+                    break
+            return [int(arr[0]), int(arr[1])]
         return self._counters.tolist()
 
     def take_pending_clear(self):
@@ -409,6 +422,7 @@ class Lattice:
             if force_atomic or _FORCE_ATOMIC_BUILD:
                 flags |= _lib.LN_BUILD_ATOMIC_PATH
             cv, cn = _lib.ptr(clear_vals), (0 if clear_vals is None else clear_vals.numel())
+            ht.arm_count_readback()
             if distributed is None:
                 rc = lib.ln_build_splat(C.byref(t), _lib.ptr(positions_raw), self._sigmas_host(), n, _lib.ptr(idx), _lib.ptr(w), flags,
                                         C.byref(csr), _lib.ptr(ws), ws.numel(), cv, cn, self._stream())
