@@ -62,9 +62,10 @@ typedef struct LnTable {
     int* nr_filled;                /* [1]                                 (m_nr_filled) */
     int* status;                   /* [1] */
     int* host_counters;            /* NULL, or 4 ints of pinned, device-visible host memory: every build writes
-                                      {nr_filled, status, 1} there from its scan kernel (word 2 last, system-scope
-                                      release).  A host that cleared word 2 before the call can spin on it and read the
-                                      vertex count as soon as the scan has run, without a copy or an event */
+                                      {nr_filled, status, host_seq} there from its scan kernel (word 2 last, system-
+                                      scope release).  A host that passes a fresh host_seq per build can spin on word 2
+                                      and read the vertex count as soon as the scan has run, without a copy or an event */
+    int host_seq;                  /* value the build stores in host_counters[2] */
 } LnTable;
 
 /* Adjacency "group -> the tokens that touch it" in CSR form, cut into segments of at most 16

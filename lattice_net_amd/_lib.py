@@ -38,6 +38,7 @@ class LnTable(C.Structure):
         ("nr_filled", C.c_void_p),
         ("status", C.c_void_p),
         ("host_counters", C.c_void_p),
+        ("host_seq", C.c_int),
     ]
 
 

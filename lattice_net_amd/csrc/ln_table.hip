@@ -663,7 +663,7 @@ __global__ void __launch_bounds__(256)
 // single workgroup: exclusive scan of the per-block first-occurrence counts (+ rows that existed before)
 __global__ void __launch_bounds__(1024) k_scan_blocks(const int* __restrict__ block_cnt, const unsigned long long* __restrict__ bitmap, int nb,
                                                       int* __restrict__ block_prefix, int* nr_filled, int* __restrict__ status,
-                                                      int* __restrict__ host_counters, int* __restrict__ cursor, int nbk) {
+                                                      int* __restrict__ host_counters, int host_seq, int* __restrict__ cursor, int nbk) {
     __shared__ int s_wave[16];
     __shared__ int s_running;
     const int tid = threadIdx.x;
@@ -711,7 +711,7 @@ __global__ void __launch_bounds__(1024) k_scan_blocks(const int* __restrict__ bl
             host_counters[0] = base + s_running;
             host_counters[1] = *status;  // every producer kernel ran before this one
             __threadfence_system();
-            __hip_atomic_store(&host_counters[2], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&host_counters[2], host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
@@ -844,7 +844,8 @@ static int ln_rank_rows(const LnTable& t, const int* tok_slot, int* idx_out, lon
     if (!marked)  // the bucketed build sets the first-occurrence bits itself
         LN_LAUNCH("k_mark_first", k_mark_first, dim3(ws.nb), dim3(256), 0, st, t, tok_slot, tokens, ws.bitmap, ws.block_cnt);
     LN_LAUNCH("k_scan_blocks", k_scan_blocks, dim3(1), dim3(1024), 0, st, marked ? (const int*)nullptr : ws.block_cnt, ws.bitmap, ws.nb,
-              ws.block_prefix, t.nr_filled, t.status, t.host_counters, marked ? t.slot_cnt : (int*)nullptr, ln_bucket_count(t.capacity));
+              ws.block_prefix, t.nr_filled, t.status, t.host_counters, t.host_seq, marked ? t.slot_cnt : (int*)nullptr,
+              ln_bucket_count(t.capacity));
     if (marked)  // bucketed build of a table cleared in the same call
         LN_LAUNCH("k_finalize", (k_finalize<D, true>), dim3(ws.nb), dim3(256), 0, st, t, tok_slot, idx_out, tokens, ws.bitmap, ws.block_prefix);
     else

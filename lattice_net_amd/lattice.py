@@ -150,7 +150,7 @@ class HashTable:
 
     def _make_c_table(self, s) -> _lib.LnTable:
         return _lib.LnTable(s.capacity, s.pos_dim, s.slot_keys.data_ptr(), s.slot_tok.data_ptr(), s.slot_cnt.data_ptr(), s.entries.data_ptr(),
-                            s.keys.data_ptr(), self._counters.data_ptr(), self._counters.data_ptr() + 4, self._pinned.data_ptr())
+                            s.keys.data_ptr(), self._counters.data_ptr(), self._counters.data_ptr() + 4, self._pinned.data_ptr(), 0)
 
     def clear(self, lazy: bool = False):  # HashTable.cu:49-57, one launch instead of four fill_ kernels
         """`lazy=True` only records that a clear is due: the next build issues it inside its own C call (no host
@@ -177,9 +177,10 @@ class HashTable:
         self._readback_pending = False
 
     def arm_count_readback(self):
-        """Call right before a build is issued: clears the "counters written" word the build's scan kernel sets."""
-        if getattr(self, "_pinned", None) is not None:
-            self._pinned_np[2] = 0
+        """Call right before a build is issued (after c_table()): gives the build a fresh sequence number, which its scan
+        kernel stores behind the counters; read_counters() spins until it sees that number."""
+        self._host_seq = (getattr(self, "_host_seq", 0) % 0x3FFFFFFF) + 1
+        self._c_table.host_seq = self._host_seq
 
     def start_count_readback(self):
         """Marks the end of a build on the stream.  The build's scan kernel writes {nr_filled, status} into the pinned
@@ -197,7 +198,8 @@ class HashTable:
             self._readback_pending = False
             arr = self._pinned_np
             spins = 0
-            while arr[2] == 0:
+            seq = self._host_seq
+            while arr[2] != seq:
                 spins += 1
                 if spins > 20000:  # ~ms: fall back to the event (a build that failed to launch, exotic memory settings)
                     self._readback_event.synchronize()
@@ -422,7 +424,7 @@ class Lattice:
             if force_atomic or _FORCE_ATOMIC_BUILD:
                 flags |= _lib.LN_BUILD_ATOMIC_PATH
             cv, cn = _lib.ptr(clear_vals), (0 if clear_vals is None else clear_vals.numel())
-            ht.arm_count_readback()
+            ht.arm_count_readback()  # t is ht's cached struct: the sequence number travels in it
             if distributed is None:
                 rc = lib.ln_build_splat(C.byref(t), _lib.ptr(positions_raw), self._sigmas_host(), n, _lib.ptr(idx), _lib.ptr(w), flags,
                                         C.byref(csr), _lib.ptr(ws), ws.numel(), cv, cn, self._stream())

@@ -159,3 +159,21 @@ def test_tiny_tables_and_empty_clouds(monkeypatch):
     lat.begin_splat()
     idx, w = lat.just_create_verts(T(np.zeros((0, 3), np.float32)), True)
     assert lat.nr_lattice_vertices() == 0 and idx.numel() == 0
+
+
+def test_back_to_back_builds_report_the_latest_vertex_count():
+    """Two builds into the same table without a read in between: the pinned {count, status, sequence} triple must not let
+    the first build's late write satisfy the wait for the second."""
+    from lattice_net_amd.synthetic import cube_cloud
+    a, b = cube_cloud(20000, 1), cube_cloud(300, 2)
+    lat = make_lattice(0.1, 400000)
+    counts = []
+    for _ in range(20):
+        lat.begin_splat()
+        lat.just_create_verts(T(a), False)
+        lat.begin_splat()
+        lat.just_create_verts(T(b), False)
+        counts.append(lat.nr_lattice_vertices())
+    t = O.OracleHashTable(400000, 3)
+    O.build_splat(t, O.scale_positions(b, np.full((3,), 0.1, np.float32)))
+    assert counts == [t.nr_filled] * 20
