@@ -142,6 +142,13 @@ int ln_csr_build(const int* idx, long long tokens, int groups_upper, const LnCsr
 int ln_csr_reduce_rows(const LnCsr* csr, const int* grp_row, long long max_segments, const float* src, const float* w, int val_dim,
                        int src_div, int src_stride, float* dst, void* stream);
 
+/* The two launches that follow a splat build and do not depend on each other, as ONE launch: ln_csr_reduce_rows(csr,
+ * grp_row, .., dst) (splatCacheNaive) in the first workgroups, ln_neighbours(table, query_rows_upper, table, same level,
+ * dilation 1, no flip, nbr) in the rest. */
+int ln_splat_accumulate_and_neighbours(const LnCsr* csr, const int* grp_row, long long max_segments, const float* src, const float* w,
+                                       int val_dim, int src_div, int src_stride, float* dst, const LnTable* table, int query_rows_upper,
+                                       int* nbr, void* stream);
+
 /* "Next" row: the vertex-wise aggregations PointNetModule runs on the distributed
  * rows — torch_scatter.scatter_max with argmax (lattice_modules.py:688) and scatter_add of ones
  * (lattice_modules.py:692) — on the same adjacency.

@@ -78,6 +78,7 @@ SIGNATURES = {
     "ln_csr_max_segments": (_ll, [_ll, _i]),
     "ln_csr_build": (_i, [_vp, _ll, _i, _CSR, _vp, _sz, _vp]),
     "ln_csr_reduce_rows": (_i, [_CSR, _vp, _ll, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "ln_splat_accumulate_and_neighbours": (_i, [_CSR, _vp, _ll, _vp, _vp, _i, _i, _i, _vp, _T, _i, _vp, _vp]),
     "ln_csr_segment_max": (_i, [_CSR, _vp, _ll, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "ln_csr_group_sizes": (_i, [_CSR, _vp, _i, _i, _vp, _vp]),
     "ln_distribute": (_i, [_T, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _CSR, _vp, _sz, _vp, _ll, _vp]),

@@ -13,6 +13,7 @@
 // A lane group reduces one segment in registers; rows that fit one segment are written with a plain
 // store, longer rows combine their segments with global atomicAdd (few, and only on hot rows).
 #include "ln_csr.h"
+#include "ln_neighbours.h"
 
 #define LN_SCAN_BLOCK 1024
 #define LN_SEG LN_CSR_SEG
@@ -183,14 +184,34 @@ extern "C" int ln_csr_build(const int* idx, long long tokens, int groups_upper, 
 // group have consecutive ids, so neighbouring lane groups of a wave often hold partial sums of the
 // same (hot) vertex: they are combined with a segmented shuffle reduction and only the head of each
 // run writes — a plain store when the run covers the whole group, one atomicAdd otherwise.
+struct LnReduceArgs {
+    const int* grp_start;
+    const int* csr_tok;
+    const int* seg_grp;
+    const int* seg_beg;
+    const int* seg_count;
+    const int* grp_row;
+    const float* src;
+    const float* w;
+    int chunks, lanes_per_seg, src_div, src_stride;
+    float* dst;
+};
+
+// body of the segment reduce for the workgroup `block_x` (of 256 threads)
 template <int VEC>
-__global__ void __launch_bounds__(256)
-    k_csr_reduce_segments(const int* __restrict__ grp_start, const int* __restrict__ csr_tok, const int* __restrict__ seg_grp,
-                          const int* __restrict__ seg_beg, const int* __restrict__ seg_count, const int* __restrict__ grp_row,
-                          const float* __restrict__ src, const float* __restrict__ w, int chunks, int lanes_per_seg, int src_div,
-                          int src_stride, float* __restrict__ dst) {
+__device__ __forceinline__ void ln_reduce_body(int block_x, const LnReduceArgs& a) {
+    const int* __restrict__ grp_start = a.grp_start;
+    const int* __restrict__ csr_tok = a.csr_tok;
+    const int* __restrict__ seg_grp = a.seg_grp;
+    const int* __restrict__ seg_beg = a.seg_beg;
+    const int* __restrict__ seg_count = a.seg_count;
+    const int* __restrict__ grp_row = a.grp_row;
+    const float* __restrict__ src = a.src;
+    const float* __restrict__ w = a.w;
+    float* __restrict__ dst = a.dst;
+    const int chunks = a.chunks, lanes_per_seg = a.lanes_per_seg, src_div = a.src_div, src_stride = a.src_stride;
     constexpr int U = 4;
-    const long long gt = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long gt = (long long)block_x * 256 + threadIdx.x;
     const long long sid = gt / lanes_per_seg;
     const int lc = int(gt - sid * lanes_per_seg);
     const int lane = threadIdx.x & 63;
@@ -276,27 +297,88 @@ __global__ void __launch_bounds__(256)
     }
 }
 
-extern "C" int ln_csr_reduce_rows(const LnCsr* csr, const int* grp_row, long long max_segments, const float* src, const float* w,
-                                  int val_dim, int src_div, int src_stride, float* dst, void* stream) {
-    LN_REQUIRE(max_segments >= 0 && val_dim >= 1 && src_div >= 1 && src_stride >= val_dim, LN_ERR_ARG, "ln_csr_reduce_rows: bad sizes");
+template <int VEC>
+__global__ void __launch_bounds__(256) k_csr_reduce_segments(LnReduceArgs a) { ln_reduce_body<VEC>(blockIdx.x, a); }
+
+// Horizontal fusion of the two launches that follow a splat build and do not depend on each other: workgroups
+// [0, reduce_blocks) accumulate the point features onto the vertices (segment reduce), the rest run the same-level
+// neighbour traversal.  One launch instead of two, and the traversal's short, latency-bound workgroups fill the CUs
+// the reduce's tail leaves idle.
+template <int VEC, int D>
+__global__ void __launch_bounds__(256)
+    k_reduce_and_neighbours(LnReduceArgs a, int reduce_blocks, LnTable t, int query_rows_upper, int* __restrict__ nbr) {
+    if ((int)blockIdx.x < reduce_blocks) {
+        ln_reduce_body<VEC>(blockIdx.x, a);
+    } else {
+        const long long g = (long long)(blockIdx.x - reduce_blocks) * 256 + threadIdx.x;
+        ln_neighbours_body<D>(g, t, query_rows_upper, t, 1.0f, 1, 0, nbr);
+    }
+}
+
+static int ln_reduce_args(const char* who, const LnCsr* csr, const int* grp_row, long long max_segments, const float* src, const float* w,
+                          int val_dim, int src_div, int src_stride, float* dst, LnReduceArgs& a, bool& vec4, long long& work) {
+    LN_REQUIRE(max_segments >= 0 && val_dim >= 1 && src_div >= 1 && src_stride >= val_dim, LN_ERR_ARG, "%s: bad sizes", who);
     LN_REQUIRE(max_segments == 0 || (csr && csr->grp_start && csr->csr_tok && csr->seg_grp && csr->seg_beg && csr->seg_count && src && w && dst),
-               LN_ERR_ARG, "ln_csr_reduce_rows: null buffer");
-    if (max_segments == 0) return LN_OK;
-    hipStream_t st = (hipStream_t)stream;
-    const bool vec4 = (val_dim % 4 == 0) && (src_stride % 4 == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0) &&
-                      ((reinterpret_cast<uintptr_t>(dst) & 15) == 0);
+               LN_ERR_ARG, "%s: null buffer", who);
+    vec4 = (val_dim % 4 == 0) && (src_stride % 4 == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0) &&
+           ((reinterpret_cast<uintptr_t>(dst) & 15) == 0);
     const int chunks = vec4 ? val_dim / 4 : val_dim;
     int lanes = 1;
     while (lanes < chunks && lanes < 64) lanes <<= 1;
-    const long long work = max_segments * lanes;
+    work = max_segments * lanes;
+    if (max_segments > 0) a = LnReduceArgs{csr->grp_start, csr->csr_tok, csr->seg_grp, csr->seg_beg, csr->seg_count, grp_row, src, w, chunks, lanes,
+                                           src_div, src_stride, dst};
+    return LN_OK;
+}
+
+extern "C" int ln_csr_reduce_rows(const LnCsr* csr, const int* grp_row, long long max_segments, const float* src, const float* w,
+                                  int val_dim, int src_div, int src_stride, float* dst, void* stream) {
+    LnReduceArgs a;
+    bool vec4;
+    long long work;
+    int rc = ln_reduce_args("ln_csr_reduce_rows", csr, grp_row, max_segments, src, w, val_dim, src_div, src_stride, dst, a, vec4, work);
+    if (rc) return rc;
+    if (max_segments == 0) return LN_OK;
+    hipStream_t st = (hipStream_t)stream;
     const dim3 grid(ln_div_up(work, 256)), block(256);
     if (vec4)
-        LN_LAUNCH("k_csr_reduce_segments", k_csr_reduce_segments<4>, grid, block, 0, st, csr->grp_start, csr->csr_tok, csr->seg_grp, csr->seg_beg,
-                  csr->seg_count, grp_row, src, w, chunks, lanes, src_div, src_stride, dst);
+        LN_LAUNCH("k_csr_reduce_segments", k_csr_reduce_segments<4>, grid, block, 0, st, a);
     else
-        LN_LAUNCH("k_csr_reduce_segments", k_csr_reduce_segments<1>, grid, block, 0, st, csr->grp_start, csr->csr_tok, csr->seg_grp, csr->seg_beg,
-                  csr->seg_count, grp_row, src, w, chunks, lanes, src_div, src_stride, dst);
+        LN_LAUNCH("k_csr_reduce_segments", k_csr_reduce_segments<1>, grid, block, 0, st, a);
     return ln_check_launch("ln_csr_reduce_rows");
+}
+
+// ln_csr_reduce_rows + ln_neighbours(table, rows_upper, table, same level, dilation 1, no flip) in ONE launch
+extern "C" int ln_splat_accumulate_and_neighbours(const LnCsr* csr, const int* grp_row, long long max_segments, const float* src,
+                                                  const float* w, int val_dim, int src_div, int src_stride, float* dst, const LnTable* table,
+                                                  int query_rows_upper, int* nbr, void* stream) {
+    LnReduceArgs a;
+    bool vec4;
+    long long work;
+    int rc = ln_reduce_args("ln_splat_accumulate_and_neighbours", csr, grp_row, max_segments, src, w, val_dim, src_div, src_stride, dst, a, vec4,
+                            work);
+    if (rc) return rc;
+    LN_REQUIRE(table && table->slot_keys && table->entries && table->keys && table->nr_filled && table->capacity > 0, LN_ERR_ARG,
+               "ln_splat_accumulate_and_neighbours: bad table");
+    LN_REQUIRE(max_segments > 0 && query_rows_upper > 0 && nbr, LN_ERR_ARG, "ln_splat_accumulate_and_neighbours: nothing to do / null output");
+    const int d = table->pos_dim;
+    LN_REQUIRE(d >= 1 && d <= LN_MAX_POS_DIM, LN_ERR_UNSUPPORTED, "ln_splat_accumulate_and_neighbours: pos_dim %d unsupported", d);
+    hipStream_t st = (hipStream_t)stream;
+    const int reduce_blocks = ln_div_up(work, 256);
+    const int nbr_blocks = ln_div_up((long long)query_rows_upper * (2 * (d + 1) + 1), 256);
+    const dim3 grid(reduce_blocks + nbr_blocks), block(256);
+#define LN_FUSED_CASE(DD)                                                                                                              \
+    case DD:                                                                                                                           \
+        if (vec4)                                                                                                                      \
+            LN_LAUNCH("k_reduce_and_neighbours", (k_reduce_and_neighbours<4, DD>), grid, block, 0, st, a, reduce_blocks, *table, query_rows_upper, \
+                      nbr);                                                                                                            \
+        else                                                                                                                           \
+            LN_LAUNCH("k_reduce_and_neighbours", (k_reduce_and_neighbours<1, DD>), grid, block, 0, st, a, reduce_blocks, *table, query_rows_upper, \
+                      nbr);                                                                                                            \
+        break;
+    switch (d) { LN_FUSED_CASE(1) LN_FUSED_CASE(2) LN_FUSED_CASE(3) LN_FUSED_CASE(4) LN_FUSED_CASE(5) LN_FUSED_CASE(6) }
+#undef LN_FUSED_CASE
+    return ln_check_launch("ln_splat_accumulate_and_neighbours");
 }
 
 // ------------------------------------------------------------------------------------------

@@ -16,6 +16,7 @@
 #include "ln_common.h"
 #include "ln_simplex.h"
 #include "ln_csr.h"
+#include "ln_neighbours.h"
 
 #include <stdarg.h>
 #include <stdio.h>
@@ -72,7 +73,7 @@ LnProfScope::~LnProfScope() {
     }
 }
 
-extern "C" const char* ln_kernel_names(void) { return "k_bucket_build,k_conv_generic,k_conv_generic_f16,k_conv_mfma,k_conv_mfma_f16,k_csr_count,k_csr_fill,k_csr_group_sizes,k_csr_reduce_segments,k_csr_scan_local,k_csr_segment_max,k_csr_segment_max_decode,k_finalize,k_gather_backward,k_gather_forward,k_gn_apply,k_gn_backward_apply,k_gn_stats,k_grad_filter_f16,k_grad_filter_generic,k_grad_filter_mfma,k_grad_filter_mfma_f16,k_im2row,k_im2rowindices,k_insert_coarse,k_insert_points,k_linear_act_backward_w,k_linear_act_backward_x,k_linear_act_forward,k_linear_reduce_slabs,k_mark_first,k_neighbours,k_point_keys,k_reduce_slabs,k_reduce_slabs_f32,k_retrieve_points,k_row2im,k_sc_reduce_slabs,k_sc_scatter_atomic,k_scan_blocks,k_scatter_point_rows,k_seg_min,k_slice_classify_backward,k_slice_classify_forward,k_slice_forward,k_table_clear"; }
+extern "C" const char* ln_kernel_names(void) { return "k_bucket_build,k_conv_generic,k_conv_generic_f16,k_conv_mfma,k_conv_mfma_f16,k_csr_count,k_csr_fill,k_csr_group_sizes,k_csr_reduce_segments,k_csr_scan_local,k_csr_segment_max,k_csr_segment_max_decode,k_finalize,k_gather_backward,k_gather_forward,k_gn_apply,k_gn_backward_apply,k_gn_stats,k_grad_filter_f16,k_grad_filter_generic,k_grad_filter_mfma,k_grad_filter_mfma_f16,k_im2row,k_im2rowindices,k_insert_coarse,k_insert_points,k_linear_act_backward_w,k_linear_act_backward_x,k_linear_act_forward,k_linear_reduce_slabs,k_mark_first,k_neighbours,k_point_keys,k_reduce_and_neighbours,k_reduce_slabs,k_reduce_slabs_f32,k_retrieve_points,k_row2im,k_sc_reduce_slabs,k_sc_scatter_atomic,k_scan_blocks,k_scatter_point_rows,k_seg_min,k_slice_classify_backward,k_slice_classify_forward,k_slice_forward,k_table_clear"; }
 
 extern "C" int ln_profile_begin(const char* kernel_name, int max_samples) {
     LN_REQUIRE(kernel_name && strlen(kernel_name) < sizeof(g_prof.name) && max_samples > 0, LN_ERR_ARG, "ln_profile_begin: bad args");
@@ -950,76 +951,10 @@ extern "C" int ln_coarsen(const LnTable* fine, int fine_rows_upper, const LnTabl
 // ------------------------------------------------------------------------------------------
 // neighbour traversal (LatticeGPU.cuh:1479-1684): one thread per (query vertex, filter slot)
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool ln_coord_is_integer(float v) {
-    float ip;
-    const float frac = fabsf(modff(v, &ip));
-    return !(frac > 0.0001f);  // LatticeGPU.cuh:467
-}
-
 template <int D>
 __global__ void __launch_bounds__(256)
     k_neighbours(LnTable tq, int query_rows_upper, LnTable tn, float scale, int dilation, int flip, int* __restrict__ nbr) {
-#pragma clang fp contract(off)
-    constexpr int E = 2 * (D + 1) + 1;
-    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int m = int(g / E);
-    const int e = int(g - (long long)m * E);
-    if (m >= query_rows_upper) return;
-    int mq = *tq.nr_filled;
-    if (m >= mq) {  // rows beyond the filled part: reference kernels return early (LatticeGPU.cuh:1471)
-        nbr[g] = LN_NOT_VISITED;
-        return;
-    }
-    float kf[D + 1];
-    float ksum = 0.0f;
-#pragma unroll
-    for (int i = 0; i < D; ++i) {
-        kf[i] = float(tq.keys[(size_t)m * D + i]);
-        ksum = ksum + kf[i];
-    }
-    kf[D] = -ksum;
-    bool all_int = true;
-#pragma unroll
-    for (int i = 0; i <= D; ++i) {
-        kf[i] = kf[i] * scale;
-        if (scale < 1.0f) all_int = all_int && ln_coord_is_integer(kf[i]);
-    }
-    int result = LN_NOT_VISITED;
-    if (e == E - 1) {  // centre, LatticeGPU.cuh:1534-1540
-        if (all_int) {
-            int key[D + 1];
-#pragma unroll
-            for (int i = 0; i <= D; ++i) key[i] = int(roundf(kf[i]));
-            result = ln_retrieve<D>(tn, key);
-        }
-    } else {
-        const bool check = (scale >= 1.0f) || !all_int;  // LatticeGPU.cuh:1547-1554
-        if (check) {
-            const int axis = e >> 1;
-            const bool is_np = ((e & 1) == (flip ? 1 : 0));
-            const float mm = (scale < 1.0f) ? scale : 1.0f;
-            const float step = mm * float(dilation);
-            const float big = mm * float(dilation) * float(D);
-            float nf[D + 1];
-            bool ok = true;
-#pragma unroll
-            for (int i = 0; i <= D; ++i) {
-                nf[i] = is_np ? (kf[i] + step) : (kf[i] - step);
-                if (i == axis) nf[i] = is_np ? (kf[i] - big) : (kf[i] + big);
-            }
-            if ((D + 1) % 2 != 0) {  // odd d+1: the neighbour itself must be all-integer (LatticeGPU.cuh:1581-1601)
-#pragma unroll
-                for (int i = 0; i <= D; ++i) ok = ok && ln_coord_is_integer(nf[i]);
-            }
-            if (ok) {
-                int key[D + 1];
-#pragma unroll
-                for (int i = 0; i <= D; ++i) key[i] = int(roundf(nf[i]));
-                result = ln_retrieve<D>(tn, key);
-            }
-        }
-    }
-    nbr[g] = result;
+    ln_neighbours_body<D>((long long)blockIdx.x * blockDim.x + threadIdx.x, tq, query_rows_upper, tn, scale, dilation, flip, nbr);
 }
 
 extern "C" int ln_neighbours(const LnTable* query, int query_rows_upper, const LnTable* neigh, int lvl_query, int lvl_neigh,

@@ -545,8 +545,7 @@ class Lattice:
         idx, w = self._build(positions_raw, True)
         tv = ht.m_values_tensor
         # splatCacheNaive (LatticeGPU.cuh:926-973) as a token-balanced reduce; begin_splat zeroed the table values
-        self._after_build(lambda: self._scatter_rows(values, idx, w, tv, v, d + 1, v))
-        self._after_build(lambda: self._prefetch_neighbours(n * (d + 1)))
+        self._after_build(lambda: self._accumulate_and_prefetch(values, idx, w, tv, v, d + 1, n * (d + 1)))
         return idx, w
 
     def just_create_verts(self, positions_raw: torch.Tensor, return_indices_and_weights: bool):  # Lattice.cu:244-290
@@ -607,6 +606,23 @@ class Lattice:
                 raise _lib.LatticeNetHipError("expand produced fewer vertices than the source lattice")
             new.set_values(torch.nn.functional.pad(self.values()[: self.nr_lattice_vertices()], (0, 0, 0, diff)))
         return new
+
+    def _accumulate_and_prefetch(self, values, idx, w, dst, val_dim, src_div, tokens):
+        """splatCacheNaive as a CSR segment reduce and the same-level neighbour prefetch in ONE launch (they only depend on
+        the build; see _prefetch_neighbours for why the list is computed this early)."""
+        ht = self.m_hash_table
+        st = ht._storage
+        rows_upper = min(ht.capacity(), tokens)
+        _, csr, max_seg, grp_row, _ = self._csr(idx)
+        if rows_upper <= 0 or max_seg <= 0:
+            return self._scatter_rows(values, idx, w, dst, val_dim, src_div, val_dim)
+        lib = _lib.load()
+        nbr = torch.empty((rows_upper, self.get_filter_extent(1)), dtype=torch.int32, device=self._dev())
+        t = ht.c_table()
+        _lib.check(lib.ln_splat_accumulate_and_neighbours(C.byref(csr), _lib.ptr(grp_row), max_seg, _lib.ptr(values), _lib.ptr(w), val_dim,
+                                                          src_div, val_dim, _lib.ptr(dst), C.byref(t), rows_upper, _lib.ptr(nbr),
+                                                          self._stream()), "ln_splat_accumulate_and_neighbours")
+        st.nbr_cache[("prefetch", id(st), st.version, self.m_lvl)] = (nbr, st)
 
     # ---------------------------------------------------------------- neighbour list (shared)
     def _prefetch_neighbours(self, tokens: int):
