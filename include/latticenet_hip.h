@@ -240,6 +240,15 @@ int ln_slice_classify_backward(const float* grad_logits, const float* values, co
                                float* g_values, float* g_delta_w, float* g_lin_w, float* g_lin_b, float* grad_sliced,
                                float* w_eff, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Both gradients of out = ln_conv_forward(nbr_q, values_neigh, filter[E*val_dim, nr_filters]) in one call:
+ * grad_filter as ln_conv_grad_filter(nbr_q, values_neigh, grad_out, mq, ..), grad_values[mn, val_dim] as
+ * ln_conv_forward(nbr_n, grad_out, filter, mn, E, nr_filters, val_dim, FLIP | TRANSPOSED_FILTER) where nbr_n is the
+ * neighbour list with the query / neighbour roles swapped.  For the small-filter shapes the slab sum of the filter
+ * gradient runs inside the value-gradient launch.  workspace: ln_conv_grad_filter_workspace_bytes(mq, ..). */
+int ln_conv_backward(const int* nbr_q, const int* nbr_n, const float* values_neigh, const float* grad_out, const float* filter, int mq, int mn,
+                     int filter_extent, int val_dim, int nr_filters, float* grad_values, float* grad_filter, void* workspace,
+                     size_t workspace_bytes, void* stream);
+
 /* Half-precision feature path of the convolution (BASELINE.json config 5 / SURVEY.md 8d C5: features fp16, accumulate
  * fp32).  Same arguments and flags as ln_conv_forward / ln_conv_grad_filter; values, filter bank, grad_out and out are
  * IEEE fp16 (`_Float16`), accumulation is fp32 (v_mfma_f32_16x16x16_f16 for val_dim in {16,32,64,96,128,256} and

@@ -96,6 +96,7 @@ SIGNATURES = {
     "ln_gather_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "ln_gather_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "ln_slice_classify_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "ln_conv_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "ln_conv_forward_f16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "ln_conv_grad_filter_f16_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "ln_conv_grad_filter_f16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),

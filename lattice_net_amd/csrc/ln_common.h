@@ -176,12 +176,12 @@ __device__ __forceinline__ int ln_block_excl_scan_256(int v, int* s_tmp, int* to
 // thread rows and combined through LDS (a single thread walking hundreds of slabs is latency-bound).  Launch with
 // grid = ceil(total / 16), block = 256.
 template <bool ACCUMULATE>
-__global__ void __launch_bounds__(256)
-    ln_k_sum_slabs(const float* __restrict__ partial, int nslabs, long long stride, int total, float* __restrict__ out) {
+__device__ __forceinline__ void ln_sum_slabs_body(int block_x, const float* __restrict__ partial, int nslabs, long long stride, int total,
+                                                  float* __restrict__ out) {
     __shared__ float s_part[16][17];
     const int o = threadIdx.x & 15;
     const int part = threadIdx.x >> 4;
-    const int g = blockIdx.x * 16 + o;
+    const int g = block_x * 16 + o;
     float acc = 0.0f;
     if (g < total)
         for (int s = part; s < nslabs; s += 16) acc += partial[(size_t)s * stride + g];
@@ -193,6 +193,12 @@ __global__ void __launch_bounds__(256)
         for (int k = 0; k < 16; ++k) r += s_part[k][o];
         out[g] = ACCUMULATE ? out[g] + r : r;
     }
+}
+
+template <bool ACCUMULATE>
+__global__ void __launch_bounds__(256)
+    ln_k_sum_slabs(const float* __restrict__ partial, int nslabs, long long stride, int total, float* __restrict__ out) {
+    ln_sum_slabs_body<ACCUMULATE>(blockIdx.x, partial, nslabs, stride, total, out);
 }
 #endif
 

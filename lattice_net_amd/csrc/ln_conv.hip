@@ -109,7 +109,14 @@ __global__ void __launch_bounds__(256)
 template <int V, int NT, int E, bool FLIP, bool WT>
 __global__ void __launch_bounds__(256)
     k_conv_mfma_full(const int* __restrict__ nbr, const float* __restrict__ values, const float* __restrict__ filter, int m,
-                     float* __restrict__ out) {
+                     float* __restrict__ out, int conv_blocks, const float* __restrict__ slab_partial, int nslabs, int slab_total,
+                     float* __restrict__ slab_out) {
+    // Horizontal fusion for the backward pass: workgroups past conv_blocks sum the filter-gradient slabs of the launch
+    // before this one (independent of the convolution; slab_out == nullptr: plain convolution).
+    if (slab_out != nullptr && (int)blockIdx.x >= conv_blocks) {
+        ln_sum_slabs_body<false>(blockIdx.x - conv_blocks, slab_partial, nslabs, slab_total, slab_total, slab_out);
+        return;
+    }
     constexpr int F = 16 * NT;
     constexpr int KQ = V / 4;
     static_assert(E * V * F * 4 <= 64 * 1024, "filter bank must fit 64 KiB of LDS");
@@ -259,7 +266,8 @@ static int ln_conv_dispatch(const int* nbr, const float* values_neigh, const flo
         const dim3 grid(ln_div_up(m, 64)), block(256);
 #define LN_CONV_FULL(VV, NN)                                                                                                        \
     if (!done && val_dim == VV && nr_filters == 16 * NN) {                                                                          \
-        LN_LAUNCH("k_conv_mfma", (k_conv_mfma_full<VV, NN, 9, FLIP, WT>), grid, block, 0, st, nbr, values_neigh, filter, m, out);  \
+        LN_LAUNCH("k_conv_mfma", (k_conv_mfma_full<VV, NN, 9, FLIP, WT>), grid, block, 0, st, nbr, values_neigh, filter, m, out,  \
+                  (int)grid.x, (const float*)nullptr, 0, 0, (float*)nullptr);                                                       \
         done = true;                                                                                                                \
     }
         LN_CONV_FULL(32, 2) LN_CONV_FULL(32, 1) LN_CONV_FULL(16, 1) LN_CONV_FULL(16, 2) LN_CONV_FULL(16, 4) LN_CONV_FULL(8, 1)
@@ -464,6 +472,31 @@ extern "C" size_t ln_conv_grad_filter_workspace_bytes(int m, int filter_extent, 
     return (size_t)ln_div_up(m, LN_GF_ROWS) * filter_extent * val_dim * nr_filters * sizeof(float) + 256;
 }
 
+// stage 1 of the MFMA filter gradient: per-row-chunk partial blocks -> slabs [chunk][E*V*F]; returns the chunk count
+static int ln_gf_launch_partials(const int* nbr, const float* values_neigh, const float* grad_out, int m, int filter_extent, int val_dim,
+                                 int nr_filters, float* partial, hipStream_t st) {
+    const int chunks = ln_div_up(m, LN_GF_ROWS);
+    const dim3 grid(chunks, filter_extent), block(256);
+    for (int v_off = 0; v_off < val_dim;) {
+        const int vleft = (val_dim - v_off) / 16;
+        const int vt = vleft >= 4 ? 4 : (vleft >= 2 ? 2 : 1);
+        for (int f_off = 0; f_off < nr_filters;) {
+            const int fleft = (nr_filters - f_off) / 16;
+            const int ft = fleft >= 4 ? 4 : (fleft >= 2 ? 2 : 1);
+#define LN_GF_CASE(A, B)                                                                                                          \
+    if (vt == A && ft == B)                                                                                                       \
+        LN_LAUNCH("k_grad_filter_mfma", (k_grad_filter_mfma<A, B>), grid, block, 0, st, nbr, values_neigh, grad_out, m, filter_extent, \
+                  partial, val_dim, v_off, nr_filters, f_off);
+            LN_GF_CASE(1, 1) LN_GF_CASE(1, 2) LN_GF_CASE(1, 4) LN_GF_CASE(2, 1) LN_GF_CASE(2, 2) LN_GF_CASE(2, 4) LN_GF_CASE(4, 1)
+            LN_GF_CASE(4, 2) LN_GF_CASE(4, 4)
+#undef LN_GF_CASE
+            f_off += ft * 16;
+        }
+        v_off += vt * 16;
+    }
+    return chunks;
+}
+
 extern "C" int ln_conv_grad_filter(const int* nbr, const float* values_neigh, const float* grad_out, int m, int filter_extent,
                                    int val_dim, int nr_filters, float* grad_filter, void* workspace, size_t workspace_bytes,
                                    void* stream) {
@@ -478,28 +511,10 @@ extern "C" int ln_conv_grad_filter(const int* nbr, const float* values_neigh, co
     if (ln_gf_mfma_supported(val_dim, nr_filters)) {
         LN_REQUIRE(workspace && workspace_bytes >= ln_conv_grad_filter_workspace_bytes(m, filter_extent, val_dim, nr_filters),
                    LN_ERR_WORKSPACE, "ln_conv_grad_filter: workspace too small");
-        float* partial = static_cast<float*>(workspace);
-        const int chunks = ln_div_up(m, LN_GF_ROWS);
-        const dim3 grid(chunks, filter_extent), block(256);
         LN_REQUIRE((reinterpret_cast<uintptr_t>(values_neigh) & 15) == 0 && (reinterpret_cast<uintptr_t>(grad_out) & 15) == 0, LN_ERR_ARG,
                    "ln_conv_grad_filter: values / grad_out must be 16-byte aligned");
-        for (int v_off = 0; v_off < val_dim;) {
-            const int vleft = (val_dim - v_off) / 16;
-            const int vt = vleft >= 4 ? 4 : (vleft >= 2 ? 2 : 1);
-            for (int f_off = 0; f_off < nr_filters;) {
-                const int fleft = (nr_filters - f_off) / 16;
-                const int ft = fleft >= 4 ? 4 : (fleft >= 2 ? 2 : 1);
-#define LN_GF_CASE(A, B)                                                                                                          \
-    if (vt == A && ft == B)                                                                                                       \
-        LN_LAUNCH("k_grad_filter_mfma", (k_grad_filter_mfma<A, B>), grid, block, 0, st, nbr, values_neigh, grad_out, m, filter_extent, \
-                  partial, val_dim, v_off, nr_filters, f_off);
-                LN_GF_CASE(1, 1) LN_GF_CASE(1, 2) LN_GF_CASE(1, 4) LN_GF_CASE(2, 1) LN_GF_CASE(2, 2) LN_GF_CASE(2, 4) LN_GF_CASE(4, 1)
-                LN_GF_CASE(4, 2) LN_GF_CASE(4, 4)
-#undef LN_GF_CASE
-                f_off += ft * 16;
-            }
-            v_off += vt * 16;
-        }
+        float* partial = static_cast<float*>(workspace);
+        const int chunks = ln_gf_launch_partials(nbr, values_neigh, grad_out, m, filter_extent, val_dim, nr_filters, partial, st);
         // slabs are laid out [chunk][e][V*F]; summing over chunks with stride E*V*F
         LN_LAUNCH("k_reduce_slabs", k_reduce_slabs, dim3(ln_div_up(total, 16)), dim3(256), 0, st, partial, chunks, total, grad_filter);
     } else {
@@ -507,4 +522,41 @@ extern "C" int ln_conv_grad_filter(const int* nbr, const float* values_neigh, co
                            filter_extent, val_dim, nr_filters, grad_filter);
     }
     return ln_check_launch("ln_conv_grad_filter");
+}
+
+// Both gradients of out = conv(values_neigh; nbr_q, filter[E*V, F]):
+//   grad_filter[E*V, F] = im2row(values_neigh; nbr_q)^T @ grad_out            (ln_conv_grad_filter)
+//   grad_values[mn, V]  = conv(grad_out; nbr_n, filter, FLIP | TRANSPOSED)     (ln_conv_forward)
+// For the small-filter shapes (whole bank in LDS) the slab sum of the filter gradient rides in the convolution launch.
+extern "C" int ln_conv_backward(const int* nbr_q, const int* nbr_n, const float* values_neigh, const float* grad_out, const float* filter, int mq,
+                                int mn, int filter_extent, int val_dim, int nr_filters, float* grad_values, float* grad_filter,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    bool fused = false;
+    const int V = nr_filters, F = val_dim;  // roles in the value-gradient convolution: V channels in, F channels out
+    if (filter_extent == 9 && mq > 0 && mn > 0 && ln_gf_mfma_supported(val_dim, nr_filters) && nbr_q && nbr_n && values_neigh && grad_out &&
+        filter && grad_values && grad_filter && workspace &&
+        workspace_bytes >= ln_conv_grad_filter_workspace_bytes(mq, filter_extent, val_dim, nr_filters) &&
+        ((reinterpret_cast<uintptr_t>(values_neigh) | reinterpret_cast<uintptr_t>(grad_out) | reinterpret_cast<uintptr_t>(filter)) & 15) == 0) {
+        float* partial = static_cast<float*>(workspace);
+        const int total = filter_extent * val_dim * nr_filters;
+        const int conv_blocks = ln_div_up(mn, 64);
+        const dim3 grid(conv_blocks + ln_div_up(total, 16)), block(256);
+#define LN_BWD_FULL(VV, NN)                                                                                                            \
+    if (!fused && V == VV && F == 16 * NN) {                                                                                           \
+        const int chunks = ln_gf_launch_partials(nbr_q, values_neigh, grad_out, mq, filter_extent, val_dim, nr_filters, partial, st);  \
+        LN_LAUNCH("k_conv_mfma", (k_conv_mfma_full<VV, NN, 9, true, true>), grid, block, 0, st, nbr_n, grad_out, filter, mn, grad_values, \
+                  conv_blocks, (const float*)partial, chunks, total, grad_filter);                                                      \
+        fused = true;                                                                                                                  \
+    }
+        LN_BWD_FULL(32, 2) LN_BWD_FULL(32, 1) LN_BWD_FULL(16, 1) LN_BWD_FULL(16, 2) LN_BWD_FULL(16, 4) LN_BWD_FULL(8, 1) LN_BWD_FULL(8, 2)
+        LN_BWD_FULL(8, 4) LN_BWD_FULL(8, 8)
+#undef LN_BWD_FULL
+    }
+    if (fused) return ln_check_launch("ln_conv_backward");
+    int rc = ln_conv_grad_filter(nbr_q, values_neigh, grad_out, mq, filter_extent, val_dim, nr_filters, grad_filter, workspace, workspace_bytes,
+                                 stream);
+    if (rc) return rc;
+    return ln_conv_forward(nbr_n, grad_out, filter, mn, filter_extent, nr_filters, val_dim, LN_CONV_FLIP_NEIGHBOURS | LN_CONV_TRANSPOSED_FILTER,
+                           grad_values, stream);
 }

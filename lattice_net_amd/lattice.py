@@ -761,12 +761,10 @@ class Lattice:
                                                main), "ln_conv_forward_f16")
             return gvals, gf.to(torch.float16)
         # (Measured on MI355X: running the filter gradient on a second stream made the step SLOWER, 0.254 -> 0.286 ms:
-        # both kernels already fill the chip and the event hand-offs cost more than the overlap.)
-        _lib.check(lib.ln_conv_grad_filter(_lib.ptr(nbr_q), _lib.ptr(nb.values()), _lib.ptr(grad_out), mq, E, v, f, _lib.ptr(gf), _lib.ptr(ws),
-                                           ws.numel(), main), "ln_conv_grad_filter")
-        flags = _lib.LN_CONV_FLIP_NEIGHBOURS | _lib.LN_CONV_TRANSPOSED_FILTER
-        _lib.check(lib.ln_conv_forward(_lib.ptr(nbr_n), _lib.ptr(grad_out), _lib.ptr(filter_bank), mn, E, f, v, flags, _lib.ptr(gvals), main),
-                   "ln_conv_forward")
+        # both kernels already fill the chip and the event hand-offs cost more than the overlap.  What does pay is
+        # putting the slab sum of the filter gradient into the value-gradient launch: ln_conv_backward.)
+        _lib.check(lib.ln_conv_backward(_lib.ptr(nbr_q), _lib.ptr(nbr_n), _lib.ptr(nb.values()), _lib.ptr(grad_out), _lib.ptr(filter_bank), mq,
+                                        mn, E, v, f, _lib.ptr(gvals), _lib.ptr(gf), _lib.ptr(ws), ws.numel(), main), "ln_conv_backward")
         return gvals, gf
 
     def convolve_im2row_grad_filter(self, grad_out: torch.Tensor, dilation: int, lattice_neighbours: Optional["Lattice"],
