@@ -209,6 +209,10 @@ int ln_conv_grad_filter(const int* nbr, const float* values_neigh, const float* 
 /* slice_with_precomputation (LatticeGPU.cuh:2552-2595). */
 int ln_slice_forward(const float* values, const int* idx, const float* w, int n, int pos_dim, int val_dim, float* out,
                      void* stream);
+/* ln_slice_forward that also zero-fills `grad_accumulator` (grad_accumulator_elems floats): the [rows, val_dim] buffer the
+ * backward pass of this slice scatters into (ln_csr_reduce_rows / ln_slice_backward need it zeroed), saving that fill launch. */
+int ln_slice_forward_prepare_backward(const float* values, const int* idx, const float* w, int n, int pos_dim, int val_dim, float* out,
+                                      float* grad_accumulator, long long grad_accumulator_elems, void* stream);
 /* slice_no_precomputation (LatticeGPU.cuh:2598-2750): also writes idx/w (-1 where absent). */
 int ln_slice_no_precomputation(const LnTable* t, const float* values, const float* positions_raw, const float* sigmas_host,
                                int n, int val_dim, float* out, int* idx, float* w, void* stream);

@@ -91,6 +91,7 @@ SIGNATURES = {
     "ln_conv_grad_filter_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "ln_conv_grad_filter": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "ln_slice_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "ln_slice_forward_prepare_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _ll, _vp]),
     "ln_slice_no_precomputation": (_i, [_T, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "ln_slice_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "ln_gather_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),

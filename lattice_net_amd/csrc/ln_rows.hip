@@ -103,9 +103,13 @@ extern "C" int ln_slice_backward(const float* grad_sliced, const int* idx, const
 template <int VEC>
 __global__ void __launch_bounds__(256)
     k_slice_forward(const float* __restrict__ values, const int* __restrict__ idx, const float* __restrict__ w, long long work,
-                    int dp1, int chunks, float* __restrict__ out) {
+                    int dp1, int chunks, float* __restrict__ out, float* __restrict__ zero_fill, long long zero_elems) {
     using T = typename VecT<VEC>::type;
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (zero_fill) {  // the accumulator the backward pass of this slice will scatter into, zeroed on the way
+        const long long threads = (long long)gridDim.x * blockDim.x;
+        for (long long i = g; i < zero_elems; i += threads) zero_fill[i] = 0.f;
+    }
     if (g >= work) return;
     const long long p = g / chunks;
     const int c = int(g - p * chunks);
@@ -120,19 +124,32 @@ __global__ void __launch_bounds__(256)
     reinterpret_cast<T*>(out)[g] = acc;
 }
 
-extern "C" int ln_slice_forward(const float* values, const int* idx, const float* w, int n, int pos_dim, int val_dim, float* out,
-                                void* stream) {
+static int ln_slice_forward_impl(const float* values, const int* idx, const float* w, int n, int pos_dim, int val_dim, float* out,
+                                 float* zero_fill, long long zero_elems, void* stream) {
     int rc = ln_check_rows("ln_slice_forward", values, idx, out, n, pos_dim, val_dim);
     if (rc) return rc;
     LN_REQUIRE(n == 0 || w, LN_ERR_ARG, "ln_slice_forward: null weights");
-    if (n == 0) return LN_OK;
+    if (n == 0) {
+        if (zero_fill && zero_elems > 0) (void)hipMemsetAsync(zero_fill, 0, sizeof(float) * zero_elems, (hipStream_t)stream);
+        return LN_OK;
+    }
     LN_DISPATCH_VEC(val_dim, {
         const int chunks = val_dim / VEC;
         const long long work = (long long)n * chunks;
         LN_LAUNCH("k_slice_forward", k_slice_forward<VEC>, dim3(ln_div_up(work, 256)), dim3(256), 0, (hipStream_t)stream, values, idx, w, work,
-                           pos_dim + 1, chunks, out);
+                           pos_dim + 1, chunks, out, zero_fill, zero_elems);
     });
     return ln_check_launch("ln_slice_forward");
+}
+
+extern "C" int ln_slice_forward(const float* values, const int* idx, const float* w, int n, int pos_dim, int val_dim, float* out,
+                                void* stream) {
+    return ln_slice_forward_impl(values, idx, w, n, pos_dim, val_dim, out, nullptr, 0, stream);
+}
+
+extern "C" int ln_slice_forward_prepare_backward(const float* values, const int* idx, const float* w, int n, int pos_dim, int val_dim,
+                                                 float* out, float* grad_accumulator, long long grad_accumulator_elems, void* stream) {
+    return ln_slice_forward_impl(values, idx, w, n, pos_dim, val_dim, out, grad_accumulator, grad_accumulator_elems, stream);
 }
 
 int ln_retrieve_points(const LnTable* t, const float* positions_raw, const float* sigmas_host, int n, int* idx, float* w,

@@ -877,14 +877,22 @@ class Lattice:
             raise ValueError(f"indices / weights must have {expect} elements")
         return n
 
-    def slice_standalone_with_precomputation(self, positions_raw, splatting_indices_tensor, splatting_weights_tensor):  # Lattice.cu:744-786
+    def slice_standalone_with_precomputation(self, positions_raw, splatting_indices_tensor, splatting_weights_tensor,
+                                             grad_accumulator: Optional[torch.Tensor] = None):  # Lattice.cu:744-786
+        """`grad_accumulator` (extension): a float buffer that the same launch zero-fills — the tensor the backward pass of
+        this slice will scatter into (SliceLattice hands it to slice_backwards_..._no_homogeneous)."""
         idx, w = splatting_indices_tensor.contiguous(), splatting_weights_tensor.contiguous()
         n = self._check_slice_inputs(positions_raw, idx, w)
         vals = self.values()
         out = torch.empty((n, self.val_dim()), dtype=torch.float32, device=self._dev())
         lib = _lib.load()
-        _lib.check(lib.ln_slice_forward(_lib.ptr(vals), _lib.ptr(idx), _lib.ptr(w), n, self.pos_dim(), self.val_dim(), _lib.ptr(out),
-                                        self._stream()), "ln_slice_forward")
+        if grad_accumulator is None:
+            _lib.check(lib.ln_slice_forward(_lib.ptr(vals), _lib.ptr(idx), _lib.ptr(w), n, self.pos_dim(), self.val_dim(), _lib.ptr(out),
+                                            self._stream()), "ln_slice_forward")
+        else:
+            _lib.check(lib.ln_slice_forward_prepare_backward(_lib.ptr(vals), _lib.ptr(idx), _lib.ptr(w), n, self.pos_dim(), self.val_dim(),
+                                                             _lib.ptr(out), _lib.ptr(grad_accumulator), grad_accumulator.numel(),
+                                                             self._stream()), "ln_slice_forward_prepare_backward")
         return out
 
     def slice_standalone_no_precomputation(self, positions_raw):  # Lattice.cu:789-832
@@ -935,14 +943,16 @@ class Lattice:
         return logits
 
     def slice_backwards_standalone_with_precomputation_no_homogeneous(self, positions_raw, grad_sliced_values, splatting_indices_tensor,
-                                                                      splatting_weights_tensor):  # Lattice.cu:1067-1088
+                                                                      splatting_weights_tensor, zeroed_accumulator=None):  # Lattice.cu:1067-1088
         idx, w = splatting_indices_tensor.contiguous(), splatting_weights_tensor.contiguous()
         n = self._check_slice_inputs(positions_raw, idx, w)
         if grad_sliced_values.dim() != 2 or not grad_sliced_values.is_contiguous():
             raise ValueError("grad_sliced_values should be contiguous nr_positions x val_dim")
         v = int(grad_sliced_values.shape[1])
         m = self.nr_lattice_vertices()
-        gv = torch.zeros((m, v), dtype=torch.float32, device=self._dev())
+        gv = zeroed_accumulator
+        if gv is None or tuple(gv.shape) != (m, v) or gv.dtype != torch.float32 or not gv.is_contiguous():
+            gv = torch.zeros((m, v), dtype=torch.float32, device=self._dev())
         self._scatter_rows(grad_sliced_values, idx, w, gv, v, self.pos_dim() + 1, v)
         self.m_hash_table.m_values_tensor = gv  # result is read back through values() (lattice_funcs.py:507)
 

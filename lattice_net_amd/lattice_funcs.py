@@ -231,7 +231,11 @@ class SliceLattice(Function):  # lattice_funcs.py:467-516
         if splatting_indices is None and splatting_weights is None:
             sliced_values, splatting_indices, splatting_weights = lattice_structure.slice_standalone_no_precomputation(positions)
         else:
-            sliced_values = lattice_structure.slice_standalone_with_precomputation(positions, splatting_indices, splatting_weights)
+            # the [M, V] accumulator of the backward scatter is zero-filled by the forward launch when a gradient will be asked for
+            ctx.grad_accumulator = torch.empty_like(lattice_values) if (ctx.needs_input_grad[0] and lattice_values.dtype == torch.float32 and
+                                                                        lattice_values.is_contiguous()) else None
+            sliced_values = lattice_structure.slice_standalone_with_precomputation(positions, splatting_indices, splatting_weights,
+                                                                                   grad_accumulator=ctx.grad_accumulator)
         ctx.save_for_backward(positions, splatting_indices, splatting_weights)
         ctx.lattice_structure = lattice_structure
         return sliced_values
@@ -243,8 +247,10 @@ class SliceLattice(Function):  # lattice_funcs.py:467-516
         if lattice_structure.val_dim() != grad_sliced_values.shape[1]:  # funcs:501-502
             raise RuntimeError("the values stored in the lattice do not have the dimension of the gradient")
         grad_sliced_values = grad_sliced_values.contiguous()
+        acc = getattr(ctx, "grad_accumulator", None)
+        ctx.grad_accumulator = None  # single use: a second backward through this node gets a freshly zeroed buffer
         lattice_structure.slice_backwards_standalone_with_precomputation_no_homogeneous(positions, grad_sliced_values, splatting_indices,
-                                                                                        splatting_weights)
+                                                                                        splatting_weights, zeroed_accumulator=acc)
         lattice_values = lattice_structure.values()
         ctx.lattice_structure = 0
         return lattice_values, None, None, None, None
