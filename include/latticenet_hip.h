@@ -265,9 +265,10 @@ int ln_conv_grad_filter_f16(const int* nbr, const void* values_neigh, const void
 
 /* "Next" row: the per-token MLP of PointNetModule (lattice_modules.py:636-676) on the distributed rows —
  * y[rows, cout] = act(x[rows, cin] @ w[cout, cin]^T + b), act = LeakyReLU(slope) (slope < 0: identity).  Streaming
- * kernels for rows ~ 10^5..10^6 and cin, cout <= 128 (cout % 4 == 0), where a BLAS GEMM with K = 4..32 is far off the
- * memory roofline.  backward: grad_x may be NULL (inputs that need no gradient; otherwise cin % 4 == 0), grad_b may be
- * NULL; `y` is the forward output (the activation mask is its sign); cin * cout <= 4096. */
+ * kernels for rows ~ 10^5..10^6 and cin, cout <= 128, where a BLAS GEMM with K = 4..32 is far off the memory roofline
+ * (float4 lanes when the channel count is a multiple of 4, scalar lanes otherwise).  backward: grad_x may be NULL (inputs
+ * that need no gradient), grad_b may be NULL; `y` is the forward output (the activation mask is its sign);
+ * cin * cout <= 10240. */
 int ln_linear_act_forward(const float* x, const float* w, const float* b, long long rows, int cin, int cout, float slope, float* y,
                           void* stream);
 size_t ln_linear_act_backward_workspace_bytes(int cin, int cout);

@@ -49,6 +49,53 @@ __global__ void __launch_bounds__(256)
     }
 }
 
+// any cout (e.g. the 9 -> 1 layer of the DeformSlice head): thread = (token, output channel)
+__global__ void __launch_bounds__(256)
+    k_linear_act_forward_scalar(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b, long long rows, int cin,
+                                int cout, float slope, float* __restrict__ y) {
+    extern __shared__ float s_w[];  // [cout, cin + 1]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < cout * cin; i += 256) {
+        const int o = i / cin;
+        s_w[o * (cin + 1) + (i - o * cin)] = w[i];
+    }
+    __syncthreads();
+    const long long total = rows * cout;
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long g = (long long)blockIdx.x * 256 + tid; g < total; g += stride) {
+        const long long t = g / cout;
+        const int o = int(g - t * cout);
+        const float* xr = x + t * cin;
+        const float* wr = s_w + o * (cin + 1);
+        float a = b ? b[o] : 0.f;
+        for (int i = 0; i < cin; ++i) a = fmaf(xr[i], wr[i], a);
+        y[g] = slope >= 0.f ? ln_lrelu(a, slope) : a;
+    }
+}
+
+// gx for any cin: thread = (token, input channel)
+__global__ void __launch_bounds__(256)
+    k_linear_act_backward_x_scalar(const float* __restrict__ w, const float* __restrict__ y, const float* __restrict__ gy, long long rows, int cin,
+                                   int cout, float slope, float* __restrict__ gx) {
+    extern __shared__ float s_w[];  // [cout, cin]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < cout * cin; i += 256) s_w[i] = w[i];
+    __syncthreads();
+    const long long total = rows * cin;
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long g = (long long)blockIdx.x * 256 + tid; g < total; g += stride) {
+        const long long t = g / cin;
+        const int i = int(g - t * cin);
+        float a = 0.f;
+        for (int o = 0; o < cout; ++o) {
+            float gv = gy[t * cout + o];
+            if (slope >= 0.f && !(y[t * cout + o] > 0.f)) gv *= slope;
+            a = fmaf(gv, s_w[o * cin + i], a);
+        }
+        gx[g] = a;
+    }
+}
+
 // gx[t, i] = sum_o g'[t, o] W[o, i],  g' = gy * act'(y)   (act' from the sign of the post-activation value)
 __global__ void __launch_bounds__(256)
     k_linear_act_backward_x(const float* __restrict__ w, const float* __restrict__ y, const float* __restrict__ gy, long long rows, int cin,
@@ -81,7 +128,7 @@ __global__ void __launch_bounds__(256)
 
 // slab[blockIdx.x][o*cin + i] = sum over the workgroup's tokens of g'[t, o] x[t, i];  slab[..][cout*cin + o] = sum g'[t, o]
 #define LN_MLP_TILE 64
-#define LN_MLP_MAXP 16  // (o, i) pairs per thread: cout * cin <= 4096
+#define LN_MLP_MAXP 40  // (o, i) pairs per thread: cout * cin <= 10240
 __global__ void __launch_bounds__(256)
     k_linear_act_backward_w(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ gy, long long rows, int cin,
                             int cout, float slope, float* __restrict__ slabs) {
@@ -136,9 +183,84 @@ __global__ void __launch_bounds__(256)
     if (tid < cout) slab[pairs + tid] = acc_b;
 }
 
+// Same slabs for wide layers (cin, cout multiples of 4, more than 1024 pairs): a thread owns up to LN_MLP_TILED_BLOCKS
+// 4x4 blocks of (o, i) pairs, so one row of a token tile costs two float4 LDS reads per 16 FMAs instead of two reads per FMA.
+#define LN_MLP_TILED_BLOCKS 3  // 256 threads x 3 blocks x 16 pairs = 12288 pairs
+__global__ void __launch_bounds__(256)
+    k_linear_act_backward_w_tiled(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ gy, long long rows, int cin,
+                                  int cout, float slope, float* __restrict__ slabs) {
+    extern __shared__ __attribute__((aligned(16))) float s_mem[];
+    float* s_x = s_mem;                        // [TILE, cin]
+    float* s_g = s_x + LN_MLP_TILE * cin;      // [TILE, cout]
+    const int tid = threadIdx.x;
+    const int pairs = cout * cin;
+    const int ib = cin >> 2, ob = cout >> 2;   // 4-wide blocks per dimension
+    const int nblocks = ib * ob;
+    float acc[LN_MLP_TILED_BLOCKS][16];
+#pragma unroll
+    for (int k = 0; k < LN_MLP_TILED_BLOCKS; ++k)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[k][j] = 0.f;
+    float acc_b = 0.f;
+    const long long tiles = (rows + LN_MLP_TILE - 1) / LN_MLP_TILE;
+    for (long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const long long t0 = tile * LN_MLP_TILE;
+        __syncthreads();
+        for (int i = tid; i < LN_MLP_TILE * cin; i += 256) {
+            const long long t = t0 + i / cin;
+            s_x[i] = t < rows ? x[t0 * cin + i] : 0.f;
+        }
+        for (int i = tid; i < LN_MLP_TILE * cout; i += 256) {
+            const long long t = t0 + i / cout;
+            float gv = 0.f;
+            if (t < rows) {
+                gv = gy[t0 * cout + i];
+                if (slope >= 0.f && !(y[t0 * cout + i] > 0.f)) gv *= slope;
+            }
+            s_g[i] = gv;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < LN_MLP_TILED_BLOCKS; ++k) {
+            const int blk = tid + k * 256;
+            if (blk < nblocks) {
+                const int o4 = blk / ib, i4 = blk - o4 * ib;
+                const float* pg = s_g + o4 * 4;
+                const float* px = s_x + i4 * 4;
+#pragma unroll 4
+                for (int lt = 0; lt < LN_MLP_TILE; ++lt) {
+                    const float4 g4 = *reinterpret_cast<const float4*>(pg + lt * cout);
+                    const float4 x4 = *reinterpret_cast<const float4*>(px + lt * cin);
+                    const float gg[4] = {g4.x, g4.y, g4.z, g4.w};
+                    const float xx[4] = {x4.x, x4.y, x4.z, x4.w};
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) acc[k][a * 4 + b] = fmaf(gg[a], xx[b], acc[k][a * 4 + b]);
+                }
+            }
+        }
+        if (tid < cout)
+            for (int lt = 0; lt < LN_MLP_TILE; ++lt) acc_b += s_g[lt * cout + tid];
+    }
+    float* slab = slabs + (size_t)blockIdx.x * (pairs + cout);
+#pragma unroll
+    for (int k = 0; k < LN_MLP_TILED_BLOCKS; ++k) {
+        const int blk = tid + k * 256;
+        if (blk < nblocks) {
+            const int o4 = blk / ib, i4 = blk - o4 * ib;
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) slab[(o4 * 4 + a) * cin + i4 * 4 + b] = acc[k][a * 4 + b];
+        }
+    }
+    if (tid < cout) slab[pairs + tid] = acc_b;
+}
+
 static int ln_mlp_check(const char* who, long long rows, int cin, int cout) {
-    LN_REQUIRE(rows >= 0 && cin >= 1 && cout >= 4 && cout % 4 == 0 && cin <= LN_MLP_MAX_C && cout <= LN_MLP_MAX_C, LN_ERR_UNSUPPORTED,
-               "%s: need cin <= %d, cout %% 4 == 0 and <= %d (got %d -> %d)", who, LN_MLP_MAX_C, LN_MLP_MAX_C, cin, cout);
+    LN_REQUIRE(rows >= 0 && cin >= 1 && cout >= 1 && cin <= LN_MLP_MAX_C && cout <= LN_MLP_MAX_C, LN_ERR_UNSUPPORTED,
+               "%s: need 1 <= cin, cout <= %d (got %d -> %d)", who, LN_MLP_MAX_C, cin, cout);
     return LN_OK;
 }
 
@@ -155,11 +277,14 @@ extern "C" int ln_linear_act_forward(const float* x, const float* w, const float
     int rc = ln_mlp_check("ln_linear_act_forward", rows, cin, cout);
     if (rc) return rc;
     LN_REQUIRE(rows == 0 || (x && w && y), LN_ERR_ARG, "ln_linear_act_forward: null buffer");
-    LN_REQUIRE((reinterpret_cast<uintptr_t>(y) & 15) == 0, LN_ERR_ARG, "ln_linear_act_forward: y must be 16-byte aligned");
     if (rows == 0) return LN_OK;
     const size_t lds = sizeof(float) * (size_t)cout * (cin + 1);
-    LN_LAUNCH("k_linear_act_forward", k_linear_act_forward, dim3(ln_mlp_grid(rows * (cout / 4))), dim3(256), lds, (hipStream_t)stream, x, w, b, rows,
-              cin, cout, slope, y);
+    if (cout % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0)
+        LN_LAUNCH("k_linear_act_forward", k_linear_act_forward, dim3(ln_mlp_grid(rows * (cout / 4))), dim3(256), lds, (hipStream_t)stream, x, w, b,
+                  rows, cin, cout, slope, y);
+    else
+        LN_LAUNCH("k_linear_act_forward", k_linear_act_forward_scalar, dim3(ln_mlp_grid(rows * cout)), dim3(256), lds, (hipStream_t)stream, x, w, b,
+                  rows, cin, cout, slope, y);
     return ln_check_launch("ln_linear_act_forward");
 }
 
@@ -185,16 +310,24 @@ extern "C" int ln_linear_act_backward(const float* x, const float* w, const floa
         return ln_check_launch("ln_linear_act_backward");
     }
     if (grad_x) {
-        LN_REQUIRE(cin % 4 == 0 && (reinterpret_cast<uintptr_t>(grad_x) & 15) == 0, LN_ERR_UNSUPPORTED,
-                   "ln_linear_act_backward: grad_x needs cin %% 4 == 0 and 16-byte alignment");
-        LN_LAUNCH("k_linear_act_backward_x", k_linear_act_backward_x, dim3(ln_mlp_grid(rows * (cin / 4))), dim3(256),
-                  sizeof(float) * (size_t)cout * cin, st, w, y, grad_y, rows, cin, cout, slope, grad_x);
+        if (cin % 4 == 0 && (reinterpret_cast<uintptr_t>(grad_x) & 15) == 0)
+            LN_LAUNCH("k_linear_act_backward_x", k_linear_act_backward_x, dim3(ln_mlp_grid(rows * (cin / 4))), dim3(256),
+                      sizeof(float) * (size_t)cout * cin, st, w, y, grad_y, rows, cin, cout, slope, grad_x);
+        else
+            LN_LAUNCH("k_linear_act_backward_x", k_linear_act_backward_x_scalar, dim3(ln_mlp_grid(rows * cin)), dim3(256),
+                      sizeof(float) * (size_t)cout * cin, st, w, y, grad_y, rows, cin, cout, slope, grad_x);
     }
     float* slabs = static_cast<float*>(workspace);
     long long tiles = (rows + LN_MLP_TILE - 1) / LN_MLP_TILE;
     const int grid = int(tiles < LN_MLP_W_GRID ? tiles : LN_MLP_W_GRID);
-    const size_t lds = sizeof(float) * LN_MLP_TILE * ((size_t)cin + cout + 1);
-    LN_LAUNCH("k_linear_act_backward_w", k_linear_act_backward_w, dim3(grid), dim3(256), lds, st, x, y, grad_y, rows, cin, cout, slope, slabs);
+    if (cin % 4 == 0 && cout % 4 == 0 && pairs > 1024 && pairs <= 256 * LN_MLP_TILED_BLOCKS * 16) {
+        const size_t lds = sizeof(float) * LN_MLP_TILE * ((size_t)cin + cout);
+        LN_LAUNCH("k_linear_act_backward_w", k_linear_act_backward_w_tiled, dim3(grid), dim3(256), lds, st, x, y, grad_y, rows, cin, cout, slope,
+                  slabs);
+    } else {
+        const size_t lds = sizeof(float) * LN_MLP_TILE * ((size_t)cin + cout + 1);
+        LN_LAUNCH("k_linear_act_backward_w", k_linear_act_backward_w, dim3(grid), dim3(256), lds, st, x, y, grad_y, rows, cin, cout, slope, slabs);
+    }
     LN_LAUNCH("k_linear_reduce_slabs", ln_k_sum_slabs<false>, dim3(ln_div_up(pairs, 16)), dim3(256), 0, st, slabs, grid, (long long)(pairs + cout),
               pairs, grad_w);
     if (grad_b)

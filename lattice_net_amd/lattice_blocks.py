@@ -15,7 +15,7 @@ import torch
 
 from . import _lib
 from .lattice_funcs import GatherLattice, SliceClassifyLattice
-from .lattice_modules import CoarsenLatticeModule, ConvLatticeIm2RowModule, FinefyLatticeModule, LinearWN
+from .lattice_modules import CoarsenLatticeModule, ConvLatticeIm2RowModule, FinefyLatticeModule, LinearWN, linear_leaky_relu
 
 __all__ = ["DropoutLattice", "BatchNormLatticeModule", "GroupNormLatticeModule", "Conv1x1", "GnRelu1x1", "GnGelu1x1", "Gn", "ConvAct",
            "GnReluConv", "GnGeluConv", "BnReluConv", "CoarsenAct", "GnCoarsen", "GnReluCoarsen", "GnGeluCoarsen", "FinefyAct", "GnFinefy",
@@ -182,7 +182,7 @@ class _Pre1x1(_PreActBlock):
 
     def forward(self, lv, ls):
         lv, ls = self._pre(lv, ls)
-        lv = self.linear(lv)
+        lv = linear_leaky_relu(lv, self.linear.weight, self.linear.bias, -1.0)  # plain per-vertex linear on the streaming kernels
         ls.set_values(lv)
         return lv, ls
 
@@ -486,7 +486,9 @@ class SliceFastCUDALatticeModule(torch.nn.Module):
         gathered = gathered.view(nr_positions, nr_vertices_per_simplex, per_vertex)
         max_vals = gathered.max(1, keepdim=True)[0]
         gathered = gathered - (self.gamma * max_vals + self.beta)
-        delta_weights = self.linear_deltaW(gathered).reshape(nr_positions, nr_vertices_per_simplex)
+        # [N(d+1), 9] -> 1: a BLAS GEMM with K = 9, N = 1 over 480 k rows; the streaming linear kernels instead
+        delta_weights = linear_leaky_relu(gathered.reshape(nr_positions * nr_vertices_per_simplex, per_vertex), self.linear_deltaW.weight,
+                                          self.linear_deltaW.bias, -1.0).reshape(nr_positions, nr_vertices_per_simplex)
         if self.experiment == "slice_no_deform":
             delta_weights = delta_weights * 0
         if self.dropout_prob > 0.0:

@@ -106,14 +106,14 @@ class LinearLeakyReluFunction(torch.autograd.Function):
 
 
 def linear_leaky_relu(x, weight, bias, slope: float):
-    """LeakyReLU(linear(x)); the fused kernels take float32 CUDA rows with <= 128 channels (cout % 4 == 0, cin % 4 == 0 when
-    x needs a gradient), everything else goes through torch."""
+    """LeakyReLU(linear(x)) (slope < 0: plain linear) for [rows, channels] inputs; the streaming kernels take float32 CUDA
+    rows with <= 128 channels, everything else goes through torch."""
     cin, cout = x.shape[1], weight.shape[0]
-    ok = (x.is_cuda and x.dtype == torch.float32 and cout % 4 == 0 and cin <= 128 and cout <= 128 and cin * cout <= 4096
-          and (not x.requires_grad or cin % 4 == 0))
+    ok = x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and cin <= 128 and cout <= 128 and cin * cout <= 10240
     if ok:
         return LinearLeakyReluFunction.apply(x, weight, bias, slope)
-    return torch.nn.functional.leaky_relu(torch.nn.functional.linear(x, weight, bias), slope)
+    y = torch.nn.functional.linear(x, weight, bias)
+    return torch.nn.functional.leaky_relu(y, slope) if slope >= 0 else y
 
 
 class SplatLatticeModule(torch.nn.Module):  # lattice_modules.py:46-51

@@ -135,9 +135,10 @@ def test_group_norm_kernels_match_torch(m, c, relu):
     torch.testing.assert_close(mod.gn.bias.grad.cpu().double(), b64.grad, rtol=2e-4, atol=2e-4 * float(b64.grad.abs().max()))
 
 
-@pytest.mark.parametrize("rows,cin,cout,with_gx", [(48000, 4, 16, False), (48000, 16, 32, True), (1000, 5, 8, False), (333, 32, 64, True),
-                                                   (7, 64, 64, True)])
-def test_linear_leaky_relu_kernels_match_torch(rows, cin, cout, with_gx):
+@pytest.mark.parametrize("rows,cin,cout,with_gx,slope", [(48000, 4, 16, False, 0.2), (48000, 16, 32, True, 0.2), (1000, 5, 8, False, 0.2),
+                                                         (333, 32, 64, True, 0.2), (7, 64, 64, True, 0.2), (48000, 9, 1, True, -1.0),
+                                                         (501, 7, 3, True, 0.1), (20000, 96, 96, True, -1.0), (5000, 96, 48, True, -1.0)])
+def test_linear_leaky_relu_kernels_match_torch(rows, cin, cout, with_gx, slope):
     """ln_linear_act_forward / _backward (the PointNet per-token MLP) against torch linear + leaky_relu in fp64."""
     from lattice_net_amd.lattice_modules import linear_leaky_relu
     torch.manual_seed(rows + cin)
@@ -146,12 +147,14 @@ def test_linear_leaky_relu_kernels_match_torch(rows, cin, cout, with_gx):
     w = (torch.randn((cout, cin), device=dev) / cin ** 0.5).requires_grad_(True)
     b = torch.randn((cout,), device=dev, requires_grad=True)
     gy = torch.randn((rows, cout), device=dev)
-    y = linear_leaky_relu(x, w, b, 0.2)
+    y = linear_leaky_relu(x, w, b, slope)
     y.backward(gy)
     x64 = x.detach().double().cpu().requires_grad_(with_gx)
     w64 = w.detach().double().cpu().requires_grad_(True)
     b64 = b.detach().double().cpu().requires_grad_(True)
-    ref = torch.nn.functional.leaky_relu(torch.nn.functional.linear(x64, w64, b64), 0.2)
+    ref = torch.nn.functional.linear(x64, w64, b64)
+    if slope >= 0:
+        ref = torch.nn.functional.leaky_relu(ref, slope)
     ref.backward(gy.double().cpu())
     torch.testing.assert_close(y.detach().cpu().double(), ref.detach(), rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(w.grad.cpu().double(), w64.grad, rtol=1e-4, atol=1e-4 * float(w64.grad.abs().max()))
