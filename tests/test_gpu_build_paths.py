@@ -177,3 +177,35 @@ def test_back_to_back_builds_report_the_latest_vertex_count():
     t = O.OracleHashTable(400000, 3)
     O.build_splat(t, O.scale_positions(b, np.full((3,), 0.1, np.float32)))
     assert counts == [t.nr_filled] * 20
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_random_configurations_against_the_oracle(seed, monkeypatch):
+    """Fuzz over dimension, cloud size, sigma and capacity (bucket counts from 1 to hundreds, ragged last buckets, loads up
+    to ~0.8): indices, weights, keys, vertex count, neighbour list and splat values against the CPU oracle."""
+    import lattice_net_amd.lattice as LM
+    monkeypatch.setattr(LM, "_FORCE_ATOMIC_BUILD", False)
+    rng = np.random.default_rng(1000 + seed)
+    d = int(rng.integers(1, 6))
+    n = int(rng.integers(1, 6000))
+    sigma = float(rng.choice([0.05, 0.1, 0.3, 1.0]))
+    pos_np = ((rng.random((n, d), dtype=np.float32) - 0.5) * float(rng.choice([0.5, 2.0, 8.0]))).astype(np.float32)
+    probe = O.OracleHashTable(n * (d + 1) + 8, d)
+    oidx, ow = O.build_splat(probe, O.scale_positions(pos_np, np.full((d,), sigma, np.float32)))
+    cap = int(probe.nr_filled / float(rng.choice([0.1, 0.3, 0.6, 0.8]))) + int(rng.integers(1, 700))
+    v = int(rng.choice([1, 3, 4, 8]))
+    vals_np = rng.standard_normal((n, v)).astype(np.float32)
+    lat = make_lattice(sigma, cap, d)
+    lat.begin_splat()
+    idx, w = lat.splat_standalone(T(pos_np), T(vals_np))
+    m = lat.nr_lattice_vertices()
+    t = O.OracleHashTable(cap, d)
+    oidx, ow = O.build_splat(t, O.scale_positions(pos_np, np.full((d,), sigma, np.float32)))
+    assert m == t.nr_filled, (d, n, sigma, cap)
+    np.testing.assert_array_equal(N(idx), oidx)
+    np.testing.assert_array_equal(N(w), ow)
+    np.testing.assert_array_equal(N(lat.hash_table().m_keys_tensor[:m]), t.keys[:m])
+    expect = np.zeros((m, v), np.float32)
+    O.splat_accumulate(expect, vals_np, oidx, ow)
+    np.testing.assert_allclose(N(lat.values()[:m]), expect, rtol=1e-5, atol=1e-5 * max(float(np.abs(expect).max()), 1e-30))
+    np.testing.assert_array_equal(N(lat.neighbours(None, 1, False)), O.neighbour_rows(t.keys[:m], t, 1, 1, 1, False))
