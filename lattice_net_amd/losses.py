@@ -11,7 +11,18 @@ from __future__ import annotations
 
 import torch
 
-__all__ = ["LovaszSoftmax", "Scores"]
+__all__ = ["LovaszSoftmax", "Scores", "nll_loss_gather"]
+
+
+def nll_loss_gather(log_probs: torch.Tensor, target: torch.Tensor, ignore_index=None) -> torch.Tensor:
+    """Mean negative log-likelihood, as torch.nn.NLLLoss(ignore_index=...) (ln_train.py:130), written as gather + masked mean:
+    torch's nll_loss kernels reduce a [120 k, C] input in a single workgroup (0.14 ms forward, 0.09 ms backward on MI355X)."""
+    target = target.reshape(-1)
+    picked = log_probs.gather(1, target.clamp(0, log_probs.shape[1] - 1).unsqueeze(1)).squeeze(1)
+    if ignore_index is None:
+        return -picked.mean()
+    keep = (target != ignore_index).to(picked.dtype)
+    return -(picked * keep).sum() / keep.sum().clamp(min=1)
 
 
 class LovaszSoftmax(torch.nn.Module):

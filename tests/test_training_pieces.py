@@ -8,7 +8,7 @@ import textwrap
 import numpy as np
 import torch
 
-from lattice_net_amd.losses import LovaszSoftmax, Scores
+from lattice_net_amd.losses import LovaszSoftmax, Scores, nll_loss_gather
 
 
 def lovasz_per_class_reference(logp: np.ndarray, target: np.ndarray, ignore: int) -> float:
@@ -98,3 +98,12 @@ def test_gradient_allreduce_two_ranks_gloo(tmp_path):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("-ok") == 2 and "rank0" in r.stdout and "rank1" in r.stdout
+
+
+def test_nll_loss_gather_matches_torch_nll_loss():
+    torch.manual_seed(0)
+    logp = torch.log_softmax(torch.randn(300, 7, dtype=torch.float64, requires_grad=True), 1)
+    target = torch.randint(0, 7, (300,))
+    for ignore in (None, 0, 3):
+        ref = torch.nn.functional.nll_loss(logp, target, ignore_index=-100 if ignore is None else ignore)
+        assert torch.allclose(nll_loss_gather(logp, target, ignore), ref, atol=1e-12)

@@ -13,6 +13,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lattice_net_amd import Lattice, ModelParams, synthetic  # noqa: E402
+from lattice_net_amd.losses import nll_loss_gather  # noqa: E402
 from lattice_net_amd.models import LNN  # noqa: E402
 
 CFG = """
@@ -64,7 +65,7 @@ def main():
     def step():
         nonlocal opt
         logsoftmax, _ = net(lattice, pos, vals)
-        loss = torch.nn.functional.nll_loss(logsoftmax, target)
+        loss = nll_loss_gather(logsoftmax, target)
         if opt is None:  # parameters of the PointNet MLP exist only after the first forward (ln_train.py:162-165)
             opt = torch.optim.AdamW(net.parameters(), lr=1e-3, weight_decay=1e-4, amsgrad=True, fused=True)
         opt.zero_grad()

@@ -18,7 +18,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lattice_net_amd import Lattice, ModelParams, sharding, synthetic  # noqa: E402
-from lattice_net_amd.losses import LovaszSoftmax, Scores  # noqa: E402
+from lattice_net_amd.losses import LovaszSoftmax, Scores, nll_loss_gather  # noqa: E402
 from lattice_net_amd.models import LNN  # noqa: E402
 
 CFG = """
@@ -74,7 +74,10 @@ def main():
     net = LNN(args.classes, mp)
     sharding.broadcast_parameters(dist, list(net.parameters()) + list(net.buffers()))
     opt = torch.optim.AdamW(net.parameters(), lr=args.lr, weight_decay=1e-4, amsgrad=True, fused=True)  # ln_train.py:165 (+ fused update)
-    lovasz, nll = LovaszSoftmax(ignore_index=0), torch.nn.NLLLoss(ignore_index=0)
+    lovasz = LovaszSoftmax(ignore_index=0)
+
+    def nll(logp, tgt):
+        return nll_loss_gather(logp, tgt, ignore_index=0)
     clouds = []
     for k in range(args.clouds):
         pos_np = synthetic.lidar_cloud(args.n, sharding.cloud_seed(rank, k))
