@@ -276,6 +276,7 @@ def main():
                                        "achieved_GBs": round((splat_bytes + slice_bytes) / ss_us / 1e3, 1),
                                        "frac_of_hbm_peak": round((splat_bytes + slice_bytes) / ss_us / 1e3 / HBM_PEAK_GBS, 4)}}
 
+    line = None
     if rank == 0:
         value = n * world * args.steps / max_elapsed / 1e6
         roofline = None
@@ -293,9 +294,14 @@ def main():
                        "sharding": f"{world} independent cloud(s), one per GPU", "checksum": round(checksum, 3)},
             "roofline": roofline, "roofline_others": others, "stages": stages, "cpu_baseline": cpu,
         }
-        print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0:
+        try:  # RCCL prints a version banner through C stdio, which a pipe buffers until exit: flush it first
+            C.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(json.dumps(line), flush=True)  # the last line on stdout
 
 
 if __name__ == "__main__":
