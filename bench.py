@@ -294,13 +294,14 @@ def main():
                        "sharding": f"{world} independent cloud(s), one per GPU", "checksum": round(checksum, 3)},
             "roofline": roofline, "roofline_others": others, "stages": stages, "cpu_baseline": cpu,
         }
+    try:  # RCCL prints a version banner through C stdio, which a pipe buffers until exit: every rank flushes it now
+        C.CDLL(None).fflush(None)
+    except OSError:
+        pass
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        try:  # RCCL prints a version banner through C stdio, which a pipe buffers until exit: flush it first
-            C.CDLL(None).fflush(None)
-        except OSError:
-            pass
         print(json.dumps(line), flush=True)  # the last line on stdout
 
 
