@@ -487,6 +487,132 @@ __global__ void __launch_bounds__(256)
     if (tid < C) slab[CV + tid] = acc_b;
 }
 
+// Same contract for V % 4 == 0 (the usual case), with the LDS-heavy loops register-blocked: the classifier-gradient
+// accumulation owns 4x4 blocks of (class, channel) pairs per thread (two float4 LDS reads per 16 FMAs instead of two
+// scalar reads per FMA), gh = g @ W and the delta-weight dots run on float4 lanes.  LDS: h[PB,V] | gh[PB,V] | g[PB,CP] | W[C,V]
+// with CP = C rounded up to 4 (zero padded).
+#define LN_SC_BLOCKS 2  // 4x4 blocks per thread: CP*V <= 256 * 2 * 16
+template <int PB>
+__global__ void __launch_bounds__(256)
+    k_slice_classify_backward_v4(const float* __restrict__ grad_logits, const float* __restrict__ values,
+                                 const float* __restrict__ delta_w, const float* __restrict__ lin_w, const int* __restrict__ idx,
+                                 const float* __restrict__ w, int n, int dp1, int V, int C, float* __restrict__ g_delta_w,
+                                 float* __restrict__ grad_sliced, float* __restrict__ w_eff, float* __restrict__ slabs) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int CP = (C + 3) & ~3;
+    float* s_h = smem;                  // [PB, V]
+    float* s_gh = s_h + PB * V;         // [PB, V]
+    float* s_g = s_gh + PB * V;         // [PB, CP]
+    float* s_w = s_g + PB * CP;         // [C, V]
+    const int tid = threadIdx.x;
+    const int CV = C * V;
+    const int V4 = V >> 2;
+    for (int i = tid; i < CV; i += 256) s_w[i] = lin_w[i];
+    const int cblocks = CP >> 2;
+    const int nblocks = cblocks * V4;   // 4x4 blocks of (class, channel)
+    float acc[LN_SC_BLOCKS][16];
+#pragma unroll
+    for (int k = 0; k < LN_SC_BLOCKS; ++k)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[k][j] = 0.0f;
+    float acc_b = 0.0f;
+    const int tiles = (n + PB - 1) / PB;
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const long long p0 = (long long)tile * PB;
+        __syncthreads();
+        for (int i = tid; i < PB * CP; i += 256) {
+            const int lp = i / CP, c = i - lp * CP;
+            const long long p = p0 + lp;
+            s_g[i] = (p < n && c < C) ? grad_logits[p * C + c] : 0.0f;
+        }
+        for (int i = tid; i < PB * V4; i += 256) {
+            const int lp = i / V4, v4 = i - lp * V4;
+            const long long p = p0 + lp;
+            float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p < n) {
+                for (int r = 0; r < dp1; ++r) {
+                    const int row = idx[p * dp1 + r];
+                    if (row >= 0) {
+                        const float wt = w[p * dp1 + r] + delta_w[p * dp1 + r];
+                        const float4 x = reinterpret_cast<const float4*>(values + (size_t)row * V)[v4];
+                        h.x = h.x + x.x * wt; h.y = h.y + x.y * wt; h.z = h.z + x.z * wt; h.w = h.w + x.w * wt;
+                    }
+                }
+            }
+            reinterpret_cast<float4*>(s_h)[i] = h;
+        }
+        for (int i = tid; i < PB * dp1; i += 256) {
+            const long long t = p0 * dp1 + i;
+            if (t < (long long)n * dp1) w_eff[t] = w[t] + delta_w[t];
+        }
+        __syncthreads();
+        for (int i = tid; i < PB * V4; i += 256) {  // gh = g @ W
+            const int lp = i / V4, v4 = i - lp * V4;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float* gr = s_g + lp * CP;
+            for (int c = 0; c < C; ++c) {
+                const float g = gr[c];
+                const float4 w4 = reinterpret_cast<const float4*>(s_w + c * V)[v4];
+                a.x = fmaf(g, w4.x, a.x); a.y = fmaf(g, w4.y, a.y); a.z = fmaf(g, w4.z, a.z); a.w = fmaf(g, w4.w, a.w);
+            }
+            reinterpret_cast<float4*>(s_gh)[i] = a;
+            if (p0 + lp < n) reinterpret_cast<float4*>(grad_sliced + (size_t)(p0 + lp) * V)[v4] = a;
+        }
+        __syncthreads();
+        for (int i = tid; i < PB * dp1; i += 256) {  // delta-weight gradients
+            const int lp = i / dp1, r = i - lp * dp1;
+            const long long p = p0 + lp;
+            if (p >= n) continue;
+            const int row = idx[p * dp1 + r];
+            if (row < 0) continue;
+            const float4* vr = reinterpret_cast<const float4*>(values + (size_t)row * V);
+            const float4* gh = reinterpret_cast<const float4*>(s_gh + lp * V);
+            float dot = 0.0f;
+            for (int v4 = 0; v4 < V4; ++v4) {
+                const float4 a = vr[v4], b = gh[v4];
+                dot = fmaf(a.x, b.x, dot); dot = fmaf(a.y, b.y, dot); dot = fmaf(a.z, b.z, dot); dot = fmaf(a.w, b.w, dot);
+            }
+            g_delta_w[p * dp1 + r] += dot;
+        }
+#pragma unroll
+        for (int k = 0; k < LN_SC_BLOCKS; ++k) {  // classifier weight gradient, 4 classes x 4 channels per block
+            const int blk = tid + k * 256;
+            if (blk < nblocks) {
+                const int cb = blk / V4, vb = blk - cb * V4;
+                const float* pg = s_g + cb * 4;
+                const float* ph = s_h + vb * 4;
+#pragma unroll 4
+                for (int lp = 0; lp < PB; ++lp) {
+                    const float4 g4 = *reinterpret_cast<const float4*>(pg + lp * CP);
+                    const float4 h4 = *reinterpret_cast<const float4*>(ph + lp * V);
+                    const float gg[4] = {g4.x, g4.y, g4.z, g4.w};
+                    const float hh[4] = {h4.x, h4.y, h4.z, h4.w};
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) acc[k][a * 4 + b] = fmaf(gg[a], hh[b], acc[k][a * 4 + b]);
+                }
+            }
+        }
+        if (tid < C)
+            for (int lp = 0; lp < PB; ++lp) acc_b = acc_b + s_g[lp * CP + tid];
+    }
+    float* slab = slabs + (size_t)blockIdx.x * (CV + C);
+#pragma unroll
+    for (int k = 0; k < LN_SC_BLOCKS; ++k) {
+        const int blk = tid + k * 256;
+        if (blk < nblocks) {
+            const int cb = blk / V4, vb = blk - cb * V4;
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+                if (cb * 4 + a < C)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) slab[(cb * 4 + a) * V + vb * 4 + b] = acc[k][a * 4 + b];
+        }
+    }
+    if (tid < C) slab[CV + tid] = acc_b;
+}
+
 // grad_sliced rows scattered with global atomics (callers without a CSR adjacency)
 __global__ void __launch_bounds__(256)
     k_sc_scatter_atomic(const float* __restrict__ grad_sliced, const float* __restrict__ w_eff, const int* __restrict__ idx, long long work,
@@ -522,17 +648,34 @@ extern "C" int ln_slice_classify_backward(const float* grad_logits, const float*
                "ln_slice_classify_backward: workspace too small");
     LN_REQUIRE((long long)nr_classes * val_dim <= 256 * LN_SC_MAX_ACC, LN_ERR_UNSUPPORTED,
                "ln_slice_classify_backward: nr_classes*val_dim = %d exceeds %d", nr_classes * val_dim, 256 * LN_SC_MAX_ACC);
-    const int pb = ln_sc_points_per_tile(val_dim, nr_classes, 2);
+    const int cp = (nr_classes + 3) & ~3;
+    const bool v4 = (val_dim % 4 == 0) && (cp * val_dim <= 256 * LN_SC_BLOCKS * 16) &&
+                    ((reinterpret_cast<uintptr_t>(values) | reinterpret_cast<uintptr_t>(grad_sliced)) & 15) == 0;
+    int pb = 0;
+    size_t lds = 0;
+    if (v4) {
+        for (int cand = 64; cand >= 8 && !pb; cand >>= 1) {
+            lds = sizeof(float) * ((size_t)cand * (2 * val_dim + cp) + (size_t)nr_classes * val_dim);
+            if (lds <= 64 * 1024) pb = cand;
+        }
+    } else {
+        pb = ln_sc_points_per_tile(val_dim, nr_classes, 2);
+        lds = sizeof(float) * ((size_t)nr_classes * (val_dim + 1) + (size_t)pb * (2 * val_dim + nr_classes));
+    }
     LN_REQUIRE(pb > 0, LN_ERR_UNSUPPORTED, "ln_slice_classify_backward: V=%d C=%d do not fit 64 KiB of LDS", val_dim, nr_classes);
-    const size_t lds = sizeof(float) * ((size_t)nr_classes * (val_dim + 1) + (size_t)pb * (2 * val_dim + nr_classes));
     const int grid = ln_sc_backward_grid(n, pb);
     float* slabs = static_cast<float*>(workspace);
     hipStream_t st = (hipStream_t)stream;
     const int dp1 = pos_dim + 1;
 #define LN_SC_BWD(P)                                                                                                               \
-    if (pb == P)                                                                                                                     \
-        LN_LAUNCH("k_slice_classify_backward", k_slice_classify_backward<P>, dim3(grid), dim3(256), lds, st, grad_logits, values, delta_w, lin_w, \
-                  idx, w, n, dp1, val_dim, nr_classes, g_delta_w, grad_sliced, w_eff, slabs);
+    if (pb == P) {                                                                                                                 \
+        if (v4)                                                                                                                    \
+            LN_LAUNCH("k_slice_classify_backward", k_slice_classify_backward_v4<P>, dim3(grid), dim3(256), lds, st, grad_logits, values, delta_w, \
+                      lin_w, idx, w, n, dp1, val_dim, nr_classes, g_delta_w, grad_sliced, w_eff, slabs);                           \
+        else                                                                                                                       \
+            LN_LAUNCH("k_slice_classify_backward", k_slice_classify_backward<P>, dim3(grid), dim3(256), lds, st, grad_logits, values, delta_w, \
+                      lin_w, idx, w, n, dp1, val_dim, nr_classes, g_delta_w, grad_sliced, w_eff, slabs);                           \
+    }
     LN_SC_BWD(64) LN_SC_BWD(32) LN_SC_BWD(16) LN_SC_BWD(8)
 #undef LN_SC_BWD
     // the gradient tensors are accumulated into (Lattice.cu:1091-1115)
