@@ -46,9 +46,14 @@ template <int V, int NT, bool FLIP, bool WT>
 __global__ void __launch_bounds__(256)
     k_conv_mfma(const int* __restrict__ nbr, const float* __restrict__ values, const float* __restrict__ filter, int m, int E,
                 float* __restrict__ out, int f_total, int f_off) {
-    // computes output columns [f_off, f_off + 16*NT) of an [.., f_total]-wide convolution
+    // computes output columns [f_off, f_off + 16*NT) of an [.., f_total]-wide convolution.
+    // Software pipeline over the filter slots: while the matrix cores work on slot e (operand A in registers, W_e in LDS),
+    // the gather of slot e+1's neighbour rows and the float4 loads of W_{e+1} are already in flight; W_{e+1} goes from
+    // registers to LDS between two barriers once every wave is done with W_e.
     constexpr int F = 16 * NT;
     constexpr int KQ = V / 4;
+    constexpr int W4 = (V * F / 4 + 255) / 256;  // float4 of a filter slice per thread
+    static_assert(V % 4 == 0, "V must be a multiple of 4");
     __shared__ __attribute__((aligned(16))) float s_b[V * F];  // W_e in fragment order [(kk*NT+nt)*64 + lane]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -62,34 +67,69 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-    for (int e = 0; e < E; ++e) {
-        // issue the gather first so its latency overlaps the filter staging
-        float a[KQ];
+    float a_cur[KQ], a_nxt[KQ];
+    float4 w_nxt[W4];
+    auto issue = [&](int e, float* a) {  // loads of slot e: this lane's quarter of the neighbour row + its share of W_e
         const int es = (FLIP && e < E - 1) ? (e ^ 1) : e;
         const int nb = (my_row < m) ? nbr[(size_t)my_row * E + es] : -1;
-        if (nb >= 0) {
-            ln_load_quarter<KQ>(values + (size_t)nb * V + q * KQ, a);
-        } else {
+        ln_load_quarter<KQ>(values + (size_t)(nb >= 0 ? nb : 0) * V + q * KQ, a);
+        if (nb < 0) {
 #pragma unroll
             for (int k = 0; k < KQ; ++k) a[k] = 0.f;
         }
-        __syncthreads();  // previous iteration's reads of s_b are done
-        for (int x = tid; x < V * F; x += 256) {
-            const int k = WT ? (x % V) : (x / F);
-            const int f = WT ? (x / V) : (x - k * F);
-            const int qq = k / KQ;
-            const int kk = k - qq * KQ;
-            const size_t src = WT ? ((size_t)e * f_total + f_off + f) * V + k : ((size_t)e * V + k) * f_total + f_off + f;
-            s_b[((kk * NT) + (f >> 4)) * 64 + qq * 16 + (f & 15)] = filter[src];
+#pragma unroll
+        for (int s = 0; s < W4; ++s) {
+            const int x = (tid + s * 256) * 4;
+            if (x < V * F) {
+                // !WT: x = k*F + f (4 consecutive f);  WT: x = f*V + k (4 consecutive k)
+                const int k = WT ? (x % V) : (x / F);
+                const int f = WT ? (x / V) : (x - k * F);
+                const size_t src = WT ? ((size_t)e * f_total + f_off + f) * V + k : ((size_t)e * V + k) * f_total + f_off + f;
+                w_nxt[s] = *reinterpret_cast<const float4*>(filter + src);
+            }
         }
-        __syncthreads();
+    };
+    auto stage = [&]() {  // W registers -> LDS in fragment order
+#pragma unroll
+        for (int s = 0; s < W4; ++s) {
+            const int x = (tid + s * 256) * 4;
+            if (x < V * F) {
+                if constexpr (!WT) {
+                    const int k = x / F, f = x - k * F;
+                    const int qq = k / KQ, kk = k - qq * KQ;
+                    *reinterpret_cast<float4*>(s_b + ((kk * NT) + (f >> 4)) * 64 + qq * 16 + (f & 15)) = w_nxt[s];
+                } else {
+                    const int f = x / V, k0 = x - f * V;
+                    const float v4[4] = {w_nxt[s].x, w_nxt[s].y, w_nxt[s].z, w_nxt[s].w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int k = k0 + j;
+                        const int qq = k / KQ, kk = k - qq * KQ;
+                        s_b[((kk * NT) + (f >> 4)) * 64 + qq * 16 + (f & 15)] = v4[j];
+                    }
+                }
+            }
+        }
+    };
+    issue(0, a_cur);
+    stage();
+    __syncthreads();
+    for (int e = 0; e < E; ++e) {
+        if (e + 1 < E) issue(e + 1, a_nxt);
 #pragma unroll
         for (int kk = 0; kk < KQ; ++kk) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const float b = s_b[(kk * NT + nt) * 64 + lane];
-                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], b, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[kk], b, acc[nt], 0, 0, 0);
             }
+        }
+        if (e + 1 < E) {
+            __syncthreads();  // every wave is done with W_e
+            stage();
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < KQ; ++k) a_cur[k] = a_nxt[k];
         }
     }
     // C/D layout: col = lane & 15, row = (lane >> 4) * 4 + reg
@@ -274,7 +314,7 @@ static int ln_conv_dispatch(const int* nbr, const float* values_neigh, const flo
         LN_CONV_FULL(8, 2) LN_CONV_FULL(8, 4) LN_CONV_FULL(8, 8)
 #undef LN_CONV_FULL
     }
-    if (!done && nr_filters % 16 == 0 && (reinterpret_cast<uintptr_t>(values_neigh) & 15) == 0) {
+    if (!done && nr_filters % 16 == 0 && ((reinterpret_cast<uintptr_t>(values_neigh) | reinterpret_cast<uintptr_t>(filter)) & 15) == 0) {
         const int nf = nr_filters;
         switch (val_dim) {
             case 8: done = ln_conv_launch_v<8, FLIP, WT>(nf, nbr, values_neigh, filter, m, filter_extent, out, st); break;
