@@ -121,6 +121,77 @@ def cpu_baseline(cfg, seconds: float):
                       f"pure-PyTorch CPU fallback oracle/torch_fallback.py, torch threads={threads}, os.cpu_count()={os.cpu_count()}"}
 
 
+UNET_CFG = """
+model: {
+    positions_mode: "xyz"
+    values_mode: "none"
+    pointnet_layers: [16,32]
+    pointnet_start_nr_channels: 32
+    nr_downsamples: 2
+    nr_blocks_down_stage: [1,1,1]
+    nr_blocks_bottleneck: 1
+    nr_blocks_up_stage: [1,1,1]
+    nr_levels_down_with_normal_resnet: 3
+    nr_levels_up_with_normal_resnet: 3
+    compression_factor: 1.0
+    dropout_last_layer: 0.0
+}
+lattice_gpu: {
+    hash_table_capacity: 100000
+    nr_sigmas: 1
+    sigma_0: "0.9 3"
+}
+"""
+
+
+def full_unet_step(dev, n: int, steps: int = 10, warmup: int = 3, classes: int = 20):
+    """Secondary number (BASELINE.json configs[2]: "SemanticKITTI single scan, full U-net with coarsen/finefy"): one training step
+    (forward + NLL + backward + AdamW) of the LNN assembled on this backend with the model shape of the reference's
+    lnn_train_semantic_kitti.cfg, on the same synthetic scan.  Not the headline metric."""
+    import gc
+    import tempfile
+    from lattice_net_amd import Lattice, ModelParams, synthetic
+    from lattice_net_amd.losses import nll_loss_gather
+    from lattice_net_amd.models import LNN
+    with tempfile.NamedTemporaryFile("w", suffix=".cfg", delete=False) as fcfg:
+        fcfg.write(UNET_CFG)
+        path = fcfg.name
+    torch.manual_seed(0)
+    mp = ModelParams.create(path)
+    lattice = Lattice.create(path, "lattice")
+    net = LNN(classes, mp, device=dev)
+    pos = torch.from_numpy(synthetic.lidar_cloud(n, 0)).to(dev)
+    vals = torch.zeros((n, 1), device=dev)
+    target = torch.from_numpy(np.random.default_rng(0).integers(0, classes, n)).to(dev)
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-3, weight_decay=1e-4, amsgrad=True)
+
+    def step():
+        logsoftmax, _ = net(lattice, pos, vals)
+        loss = nll_loss_gather(logsoftmax, target)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    gc_was_on = gc.isenabled()
+    gc.collect()
+    gc.disable()  # generation-2 passes over the live module / autograd objects cost milliseconds per step otherwise
+    try:
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+    finally:
+        if gc_was_on:
+            gc.enable()
+    return {"what": "LNN training step (forward + NLL + backward + AdamW), reference SemanticKITTI model shape, same 120k-point scan",
+            "ms_per_step": round(dt * 1e3, 3), "mpoints_per_s": round(n / dt / 1e6, 2), "parameters": sum(p.numel() for p in net.parameters()),
+            "steps": steps}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -133,6 +204,7 @@ def main():
     ap.add_argument("--extra-kernels", default="k_csr_reduce_segments,k_conv_mfma,k_grad_filter_mfma,k_bucket_build,k_point_keys,k_slice_forward",
                     help="kernels timed the same way in extra untimed steps AFTER the timed region (reported under roofline_others)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the CPU baseline leg (0 disables)")
+    ap.add_argument("--full-unet", type=int, default=1, help="0 = skip the secondary whole-network timing (rank 0, one GPU, workload C3)")
     ap.add_argument("--autograd-threads", type=int, default=0, help="1 = leave torch's per-device autograd worker thread on")
     args = ap.parse_args()
 
@@ -285,6 +357,12 @@ def main():
         cpu = None
         if world == 1 and args.cpu_seconds > 0:
             cpu = cpu_baseline(cfg, args.cpu_seconds)
+        unet = None
+        if world == 1 and args.full_unet and args.workload == "C3":
+            try:
+                unet = full_unet_step(dev, n)
+            except Exception as exc:  # secondary number: never take the headline line down with it
+                unet = {"error": f"{type(exc).__name__}: {exc}"}
         line = {
             "metric": "Mpoints/sec splat+conv+slice fwd+bwd on 120k-pt SemanticKITTI scan",
             "value": round(value, 3), "unit": "Mpoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -292,7 +370,7 @@ def main():
             "vs_baseline": None, "dtype": "f16 features / f32 accumulate" if half else "f32", "data": "synthetic",
             "config": {"workload": cfg["desc"], "points_per_gpu": n, "vertices": m, "val_dim": v, "nr_filters": f,
                        "sharding": f"{world} independent cloud(s), one per GPU", "checksum": round(checksum, 3)},
-            "roofline": roofline, "roofline_others": others, "stages": stages, "cpu_baseline": cpu,
+            "roofline": roofline, "roofline_others": others, "stages": stages, "full_unet": unet, "cpu_baseline": cpu,
         }
     try:  # RCCL prints a version banner through C stdio, which a pipe buffers until exit: every rank flushes it now
         C.CDLL(None).fflush(None)
