@@ -93,7 +93,7 @@ class HashTable:
         self.m_capacity = int(capacity)
         self._storage: Optional[_TableStorage] = None
         self.m_values_tensor: Optional[torch.Tensor] = None
-        self._counters: Optional[torch.Tensor] = None  # int32[2]: [nr_filled, status] -> ONE 8-byte readback
+        self._counters: Optional[torch.Tensor] = None  # int32[2]: [nr_filled, status] on the device (builds mirror them into pinned host memory)
         self.m_nr_filled_is_dirty = True
         self.m_nr_filled = -1
         self._pos_dim_hint = -1  # dimensions known before any CAP-sized buffer exists
@@ -1032,7 +1032,7 @@ class Lattice:
     def nr_lattice_vertices(self) -> int:  # Lattice.cu:1320-1352
         ht = self.m_hash_table
         if ht.m_nr_filled_is_dirty:
-            both = ht.read_counters()  # ONE blocking 8-byte readback: [nr_filled, status]
+            both = ht.read_counters()  # [nr_filled, status]: the path's one wait on the device
             nr, status = int(both[0]), int(both[1])
             if status & _lib.LN_STATUS_BUCKET_OVERFLOW:
                 # one LDS-staged bucket of the fast build filled up (table loaded beyond ~0.85): redo the build with
