@@ -123,25 +123,26 @@ class SplatLatticeModule(torch.nn.Module):  # lattice_modules.py:46-51
 
 
 class DistributeLatticeModule(torch.nn.Module):  # lattice_modules.py:52-96
-    """torch_scatter.scatter_mean is replaced by index_add_ (torch_scatter is not part of the ROCm image)."""
+    """The per-vertex mean of the token positions (torch_scatter.scatter_mean in the reference, mods:78) is a segment
+    reduce over the slot -> tokens adjacency the build emitted (no atomics, no extra host synchronisation); vertex 0 doubles
+    as the bucket of the tokens that could not be inserted, and its tokens are zeroed (mods:72-94)."""
 
     def forward(self, lattice, positions, values, reset_hashmap=True):
         wrap, distributed, splatting_indices, splatting_weights = DistributeLattice.apply(lattice, positions, values, reset_hashmap)
         distributed_lattice = wrap.lattice
         pos_dim = positions.shape[1]
-        distributed_positions = distributed[:, :pos_dim]
-        indices_long = splatting_indices.long()
-        indices_long = torch.where(indices_long < 0, torch.zeros_like(indices_long), indices_long)  # -1 -> bucket 0 (mods:72)
-        nr_rows = int(indices_long.max().item()) + 1
-        sums = torch.zeros((nr_rows, pos_dim), dtype=distributed.dtype, device=distributed.device).index_add_(0, indices_long, distributed_positions)
-        counts = torch.zeros((nr_rows,), dtype=distributed.dtype, device=distributed.device).index_add_(
-            0, indices_long, torch.ones_like(indices_long, dtype=distributed.dtype))
+        distributed_positions = distributed[:, :pos_dim].contiguous()
+        nr_rows = distributed_lattice.nr_lattice_vertices()
+        sums = torch.zeros((nr_rows, pos_dim), dtype=distributed.dtype, device=distributed.device)
+        ones = torch.ones((splatting_indices.numel(),), dtype=distributed.dtype, device=distributed.device)
+        distributed_lattice._scatter_rows(distributed_positions, splatting_indices, ones, sums, pos_dim, 1, pos_dim)
+        counts = distributed_lattice.vertex_point_counts(splatting_indices).to(distributed.dtype)
         mean_positions = sums / counts.clamp(min=1).unsqueeze(1)
         mean_positions[0, :] = 0  # vertex 0 doubles as the "invalid" bucket (mods:79-81)
+        indices_long = splatting_indices.long().clamp(min=0)  # -1 -> bucket 0 (mods:72)
         distributed_mean_positions = torch.index_select(mean_positions, 0, indices_long)
         distributed = torch.cat([distributed_positions - distributed_mean_positions, distributed[:, pos_dim:]], dim=1)
-        invalid = (indices_long == 0).unsqueeze(1)
-        distributed = distributed.masked_fill(invalid, 0)  # mods:88-94
+        distributed = distributed.masked_fill((indices_long == 0).unsqueeze(1), 0)  # mods:88-94
         return distributed_lattice, distributed, splatting_indices, splatting_weights
 
 
