@@ -491,7 +491,7 @@ __global__ void __launch_bounds__(256)
 // accumulation owns 4x4 blocks of (class, channel) pairs per thread (two float4 LDS reads per 16 FMAs instead of two
 // scalar reads per FMA), gh = g @ W and the delta-weight dots run on float4 lanes.  LDS: h[PB,V] | gh[PB,V] | g[PB,CP] | W[C,V]
 // with CP = C rounded up to 4 (zero padded).
-#define LN_SC_BLOCKS 2  // 4x4 blocks per thread: CP*V <= 256 * 2 * 16
+#define LN_SC_BLOCKS 3  // 4x4 blocks per thread: CP*V <= 256 * 3 * 16 = 12288
 template <int PB>
 __global__ void __launch_bounds__(256)
     k_slice_classify_backward_v4(const float* __restrict__ grad_logits, const float* __restrict__ values,
@@ -646,8 +646,6 @@ extern "C" int ln_slice_classify_backward(const float* grad_logits, const float*
     if (n == 0) return LN_OK;
     LN_REQUIRE(workspace && workspace_bytes >= ln_slice_classify_backward_workspace_bytes(n, pos_dim, val_dim, nr_classes), LN_ERR_WORKSPACE,
                "ln_slice_classify_backward: workspace too small");
-    LN_REQUIRE((long long)nr_classes * val_dim <= 256 * LN_SC_MAX_ACC, LN_ERR_UNSUPPORTED,
-               "ln_slice_classify_backward: nr_classes*val_dim = %d exceeds %d", nr_classes * val_dim, 256 * LN_SC_MAX_ACC);
     const int cp = (nr_classes + 3) & ~3;
     const bool v4 = (val_dim % 4 == 0) && (cp * val_dim <= 256 * LN_SC_BLOCKS * 16) &&
                     ((reinterpret_cast<uintptr_t>(values) | reinterpret_cast<uintptr_t>(grad_sliced)) & 15) == 0;
@@ -659,6 +657,9 @@ extern "C" int ln_slice_classify_backward(const float* grad_logits, const float*
             if (lds <= 64 * 1024) pb = cand;
         }
     } else {
+        LN_REQUIRE((long long)nr_classes * val_dim <= 256 * LN_SC_MAX_ACC, LN_ERR_UNSUPPORTED,
+                   "ln_slice_classify_backward: nr_classes*val_dim = %d exceeds %d (val_dim %% 4 != 0 path)", nr_classes * val_dim,
+                   256 * LN_SC_MAX_ACC);
         pb = ln_sc_points_per_tile(val_dim, nr_classes, 2);
         lds = sizeof(float) * ((size_t)nr_classes * (val_dim + 1) + (size_t)pb * (2 * val_dim + nr_classes));
     }

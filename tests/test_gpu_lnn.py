@@ -205,3 +205,52 @@ def test_remaining_reference_blocks_run_forward_and_backward():
     lv = torch.randn((m, c), device=dev)
     ev, es = ex(lv, lat, pos)
     assert es.nr_lattice_vertices() >= m and ev.shape == (es.nr_lattice_vertices(), c)
+
+
+SHAPENET_CFG = textwrap.dedent("""
+    model: {
+        positions_mode: "xyz"
+        values_mode: "none"
+        pointnet_channels_per_layer: [16,32,64]
+        pointnet_start_nr_channels: 32
+        nr_downsamples: 3
+        nr_blocks_down_stage: [4,4,4]
+        nr_blocks_bottleneck: 3
+        nr_blocks_up_stage: [2,2,2]
+        nr_levels_down_with_normal_resnet: 3
+        nr_levels_up_with_normal_resnet: 2
+        compression_factor: 1.0
+        dropout_last_layer: 0.0
+        experiment: "none"
+    }
+    lattice_gpu: {
+        hash_table_capacity: 60000
+        nr_sigmas: 1
+        sigma_0: "0.05 3"
+    }
+""")
+
+
+def test_lnn_with_the_shapenet_model_shape(tmp_path):
+    """BASELINE.json configs[1] (ln_train_shapenet_example.cfg:19-31,45-50): 3 downsamples, 4 blocks per level, bottleneck
+    blocks in the decoder, channel widths up to 256, a 2.5k-point surface cloud.  Forward + backward through all of it."""
+    from lattice_net_amd import Lattice, ModelParams
+    from lattice_net_amd.models import LNN
+    from lattice_net_amd.synthetic import box_surface_cloud
+    p = tmp_path / "shapenet.cfg"
+    p.write_text(SHAPENET_CFG)
+    torch.manual_seed(0)
+    mp = ModelParams.create(str(p))
+    lattice = Lattice.create(str(p), "lattice")
+    net = LNN(50, mp)  # ShapeNet part segmentation: 50 part labels
+    dev = torch.device("cuda", 0)
+    pos = torch.from_numpy(box_surface_cloud(2500, 0)).to(dev)
+    vals = torch.zeros((2500, 1), device=dev)
+    target = torch.randint(0, 50, (2500,), device=dev)
+    assert net.slice_fast_cuda.in_channels == 128
+    assert [c.coarse.weight.shape[1] for c in net.coarsens_list] == [64, 128, 256]
+    logsoftmax, logits = net(lattice, pos, vals)
+    assert logsoftmax.shape == (2500, 50) and torch.isfinite(logsoftmax).all()
+    torch.nn.functional.nll_loss(logsoftmax, target).backward()
+    bad = [n for n, q in net.named_parameters() if q.grad is None or not torch.isfinite(q.grad).all()]
+    assert not bad, bad

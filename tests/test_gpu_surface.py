@@ -77,7 +77,7 @@ def test_slice_and_gather_autograd_against_oracle():
     close(N(vals3.grad), O.gather_backwards(gg, oidx, ow, m, 3))
 
 
-@pytest.mark.parametrize("n,v,c", [(1500, 8, 20), (5000, 96, 20), (777, 128, 13), (300, 5, 3)])
+@pytest.mark.parametrize("n,v,c", [(1500, 8, 20), (5000, 96, 20), (777, 128, 13), (300, 5, 3), (2500, 128, 50)])
 def test_slice_classify_autograd_against_oracle(n, v, c):
     """(5000, 96, 20) is the head of the SemanticKITTI LNN: several tiles per workgroup; (777, 128, 13) takes the
     32-point tile; ragged last tiles everywhere."""
