@@ -254,3 +254,53 @@ def test_lnn_with_the_shapenet_model_shape(tmp_path):
     torch.nn.functional.nll_loss(logsoftmax, target).backward()
     bad = [n for n, q in net.named_parameters() if q.grad is None or not torch.isfinite(q.grad).all()]
     assert not bad, bad
+
+
+SCANNET_CFG = textwrap.dedent("""
+    model: {
+        positions_mode: "xyz"
+        values_mode: "rgb+height"
+        pointnet_layers: [16,32,64]
+        pointnet_start_nr_channels: 32
+        nr_downsamples: 3
+        nr_blocks_down_stage: [6,6,8]
+        nr_blocks_bottleneck: 8
+        nr_blocks_up_stage: [2,2,2]
+        nr_levels_down_with_normal_resnet: 3
+        nr_levels_up_with_normal_resnet: 3
+        compression_factor: 1.0
+        dropout_last_layer: 0.0
+        experiment: "none"
+    }
+    lattice_gpu: {
+        hash_table_capacity: 5000000
+        nr_sigmas: 1
+        sigma_0: "0.08 3" //default
+    }
+""")
+
+
+def test_lnn_with_the_scannet_model_shape(tmp_path):
+    """BASELINE.json configs[3] (lnn_train_scannet.cfg:22-48): rgb+height values (7 PointNet input channels), 5M-slot tables,
+    3 downsamples with 6/6/8 blocks and 8 bottleneck blocks, 21 classes; a 60k-point scene of planes."""
+    from lattice_net_amd import Lattice, ModelParams
+    from lattice_net_amd.models import LNN, prepare_cloud
+    from lattice_net_amd.synthetic import planes_cloud
+    p = tmp_path / "scannet.cfg"
+    p.write_text(SCANNET_CFG)
+    torch.manual_seed(0)
+    mp = ModelParams.create(str(p))
+    lattice = Lattice.create(str(p), "lattice")
+    net = LNN(21, mp)
+    cloud = Cloud()
+    cloud.V = planes_cloud(60000, 0)
+    rng = np.random.default_rng(0)
+    cloud.C = rng.random((60000, 3)).astype(np.float32)
+    cloud.L_gt = rng.integers(0, 21, (60000, 1))
+    positions, values, target = prepare_cloud(cloud, mp)
+    assert values.shape == (60000, 4) and net.point_net.layers[0].weight_v.shape == (16, 7)
+    logsoftmax, _ = net(lattice, positions, values)
+    assert logsoftmax.shape == (60000, 21) and torch.isfinite(logsoftmax).all()
+    torch.nn.functional.nll_loss(logsoftmax, target).backward()
+    bad = [n for n, q in net.named_parameters() if q.grad is None or not torch.isfinite(q.grad).all()]
+    assert not bad, bad
