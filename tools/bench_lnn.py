@@ -16,49 +16,53 @@ from lattice_net_amd import Lattice, ModelParams, synthetic  # noqa: E402
 from lattice_net_amd.losses import nll_loss_gather  # noqa: E402
 from lattice_net_amd.models import LNN  # noqa: E402
 
-CFG = """
-model: {
-    positions_mode: "xyz"
-    values_mode: "none"
-    pointnet_layers: [16,32]
-    pointnet_start_nr_channels: 32
-    nr_downsamples: 2
-    nr_blocks_down_stage: [1,1,1]
-    nr_blocks_bottleneck: 1
-    nr_blocks_up_stage: [1,1,1]
-    nr_levels_down_with_normal_resnet: 3
-    nr_levels_up_with_normal_resnet: 3
-    compression_factor: 1.0
-    dropout_last_layer: 0.0
+PRESETS = {
+    # the model / lattice blocks of the reference's configs (values only), with the synthetic cloud SURVEY.md 8d pairs with each
+    "kitti": dict(n=120000, classes=20, cloud="lidar", values=1, cfg="""
+model: { positions_mode: "xyz"  values_mode: "none"  pointnet_layers: [16,32]  pointnet_start_nr_channels: 32  nr_downsamples: 2
+    nr_blocks_down_stage: [1,1,1]  nr_blocks_bottleneck: 1  nr_blocks_up_stage: [1,1,1]  nr_levels_down_with_normal_resnet: 3
+    nr_levels_up_with_normal_resnet: 3  compression_factor: 1.0  dropout_last_layer: 0.0 }
+lattice_gpu: { hash_table_capacity: 100000  nr_sigmas: 1  sigma_0: "0.9 3" }
+"""),  # config/lnn_train_semantic_kitti.cfg:36-47,62-69
+    "shapenet": dict(n=2500, classes=50, cloud="box", values=1, cfg="""
+model: { positions_mode: "xyz"  values_mode: "none"  pointnet_channels_per_layer: [16,32,64]  pointnet_start_nr_channels: 32
+    nr_downsamples: 3  nr_blocks_down_stage: [4,4,4]  nr_blocks_bottleneck: 3  nr_blocks_up_stage: [2,2,2]
+    nr_levels_down_with_normal_resnet: 3  nr_levels_up_with_normal_resnet: 2  compression_factor: 1.0  dropout_last_layer: 0.0 }
+lattice_gpu: { hash_table_capacity: 60000  nr_sigmas: 1  sigma_0: "0.05 3" }
+"""),  # config/ln_train_shapenet_example.cfg:19-31,45-50
+    "scannet": dict(n=200000, classes=21, cloud="planes", values=4, cfg="""
+model: { positions_mode: "xyz"  values_mode: "rgb+height"  pointnet_layers: [16,32,64]  pointnet_start_nr_channels: 32
+    nr_downsamples: 3  nr_blocks_down_stage: [6,6,8]  nr_blocks_bottleneck: 8  nr_blocks_up_stage: [2,2,2]
+    nr_levels_down_with_normal_resnet: 3  nr_levels_up_with_normal_resnet: 3  compression_factor: 1.0  dropout_last_layer: 0.0 }
+lattice_gpu: { hash_table_capacity: 5000000  nr_sigmas: 1  sigma_0: "0.08 3" }
+"""),  # config/lnn_train_scannet.cfg:22-48
 }
-lattice_gpu: {
-    hash_table_capacity: 100000
-    nr_sigmas: 1
-    sigma_0: "0.9 3"
-}
-"""
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--n", type=int, default=120000)
+    ap.add_argument("--config", default="kitti", choices=sorted(PRESETS))
+    ap.add_argument("--n", type=int, default=0, help="points per cloud (0 = the preset's)")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--classes", type=int, default=20)
     ap.add_argument("--host-profile", action="store_true", help="cProfile of the host side of the timed steps")
     ap.add_argument("--gc", type=int, default=0, help="1 = leave Python's cyclic garbage collector on during the timed steps")
     args = ap.parse_args()
+    preset = PRESETS[args.config]
+    args.n = args.n or preset["n"]
+    args.classes = preset["classes"]
     dev = torch.device("cuda", 0)
     with tempfile.NamedTemporaryFile("w", suffix=".cfg", delete=False) as f:
-        f.write(CFG)
+        f.write(preset["cfg"])
         path = f.name
     torch.manual_seed(0)
     torch.autograd.set_multithreading_enabled(False)
     mp = ModelParams.create(path)
     lattice = Lattice.create(path, "lattice")
     net = LNN(args.classes, mp)
-    pos = torch.from_numpy(synthetic.lidar_cloud(args.n, 0)).to(dev)
-    vals = torch.zeros((args.n, 1), device=dev)
+    gen = {"lidar": synthetic.lidar_cloud, "box": synthetic.box_surface_cloud, "planes": synthetic.planes_cloud}[preset["cloud"]]
+    pos = torch.from_numpy(gen(args.n, 0)).to(dev)
+    vals = torch.zeros((args.n, 1), device=dev) if preset["values"] == 1 else torch.rand((args.n, preset["values"]), device=dev)
     target = torch.from_numpy(np.random.default_rng(0).integers(0, args.classes, args.n)).to(dev)
     opt = None
 
@@ -96,7 +100,7 @@ def main():
         pr.disable()
         pstats.Stats(pr).sort_stats("tottime").print_stats(35)
     nparams = sum(p.numel() for p in net.parameters())
-    print(f"LNN train step: {dt * 1e3:.2f} ms  ({args.n / dt / 1e6:.2f} Mpoints/s), {nparams} parameters, loss {loss.item():.4f}")
+    print(f"LNN[{args.config}] train step: {dt * 1e3:.2f} ms  ({args.n / dt / 1e6:.2f} Mpoints/s), {nparams} parameters, loss {loss.item():.4f}")
 
 
 if __name__ == "__main__":
