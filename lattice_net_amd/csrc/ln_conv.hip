@@ -62,6 +62,7 @@ __global__ void __launch_bounds__(256)
     const int q = lane >> 4;
     const int m0 = blockIdx.x * 64 + wave * 16;
     const int my_row = m0 + i;
+    f_off += blockIdx.y * F;  // gridDim.y consecutive column chunks of this width in one launch
 
     floatx4 acc[NT];
 #pragma unroll
@@ -276,25 +277,21 @@ __global__ void __launch_bounds__(256)
 template <int V, bool FLIP, bool WT>
 static bool ln_conv_launch_v(int nr_filters, const int* nbr, const float* values, const float* filter, int m, int E, float* out,
                              hipStream_t st) {
-    const dim3 grid(ln_div_up(m, 64)), block(256);
+    const dim3 block(256);
     constexpr int NT_MAX = (V * 16 * 8 * 4 <= 32 * 1024) ? 8 : ((V * 16 * 4 * 4 <= 48 * 1024) ? 4 : 2);
     int f_off = 0;
-    while (f_off < nr_filters) {
-        const int left = (nr_filters - f_off) / 16;
-        if (NT_MAX >= 8 && left >= 8) {
-            if constexpr (NT_MAX >= 8) LN_LAUNCH("k_conv_mfma", (k_conv_mfma<V, 8, FLIP, WT>), grid, block, 0, st, nbr, values, filter, m, E, out, nr_filters, f_off);
-            f_off += 128;
-        } else if (NT_MAX >= 4 && left >= 4) {
-            if constexpr (NT_MAX >= 4) LN_LAUNCH("k_conv_mfma", (k_conv_mfma<V, 4, FLIP, WT>), grid, block, 0, st, nbr, values, filter, m, E, out, nr_filters, f_off);
-            f_off += 64;
-        } else if (left >= 2) {
-            LN_LAUNCH("k_conv_mfma", (k_conv_mfma<V, 2, FLIP, WT>), grid, block, 0, st, nbr, values, filter, m, E, out, nr_filters, f_off);
-            f_off += 32;
-        } else {
-            LN_LAUNCH("k_conv_mfma", (k_conv_mfma<V, 1, FLIP, WT>), grid, block, 0, st, nbr, values, filter, m, E, out, nr_filters, f_off);
-            f_off += 16;
-        }
+    // all chunks of the widest size go out as ONE launch (gridDim.y = their count), then at most one launch per narrower size
+#define LN_CONV_CHUNKS(NTC)                                                                                                         \
+    if constexpr (NT_MAX >= NTC) {                                                                                                  \
+        const int cnt = (nr_filters - f_off) / (16 * NTC);                                                                          \
+        if (cnt > 0) {                                                                                                              \
+            LN_LAUNCH("k_conv_mfma", (k_conv_mfma<V, NTC, FLIP, WT>), dim3(ln_div_up(m, 64), cnt), block, 0, st, nbr, values, filter, m, E, out, \
+                      nr_filters, f_off);                                                                                           \
+            f_off += cnt * 16 * NTC;                                                                                                \
+        }                                                                                                                           \
     }
+    LN_CONV_CHUNKS(8) LN_CONV_CHUNKS(4) LN_CONV_CHUNKS(2) LN_CONV_CHUNKS(1)
+#undef LN_CONV_CHUNKS
     return true;
 }
 
@@ -370,7 +367,13 @@ template <int VT, int FT>
 __global__ void __launch_bounds__(256)
     k_grad_filter_mfma(const int* __restrict__ nbr, const float* __restrict__ values, const float* __restrict__ grad_out, int m,
                        int E, float* __restrict__ partial, int v_total, int v_off, int f_total, int f_off) {
-    // rows [v_off, v_off + 16*VT) x columns [f_off, f_off + 16*FT) of every slot's [v_total, f_total] block
+    // rows [v_off, v_off + 16*VT) x columns [f_off, f_off + 16*FT) of every slot's [v_total, f_total] block; with
+    // gridDim.z > 1 the launch covers a uniform tiling of the block: sub-block z = (row tile, column tile)
+    if (gridDim.z > 1) {
+        const int col_tiles = f_total / (16 * FT);
+        v_off = (blockIdx.z / col_tiles) * 16 * VT;
+        f_off = (blockIdx.z % col_tiles) * 16 * FT;
+    }
     constexpr int V = VT * 16;
     constexpr int F = FT * 16;
     constexpr int SA = V + 16;  // LDS row strides (floats), = 16 mod 32
@@ -516,25 +519,24 @@ extern "C" size_t ln_conv_grad_filter_workspace_bytes(int m, int filter_extent, 
 static int ln_gf_launch_partials(const int* nbr, const float* values_neigh, const float* grad_out, int m, int filter_extent, int val_dim,
                                  int nr_filters, float* partial, hipStream_t st) {
     const int chunks = ln_div_up(m, LN_GF_ROWS);
-    const dim3 grid(chunks, filter_extent), block(256);
-    for (int v_off = 0; v_off < val_dim;) {
-        const int vleft = (val_dim - v_off) / 16;
-        const int vt = vleft >= 4 ? 4 : (vleft >= 2 ? 2 : 1);
-        for (int f_off = 0; f_off < nr_filters;) {
-            const int fleft = (nr_filters - f_off) / 16;
-            const int ft = fleft >= 4 ? 4 : (fleft >= 2 ? 2 : 1);
-#define LN_GF_CASE(A, B)                                                                                                          \
-    if (vt == A && ft == B)                                                                                                       \
-        LN_LAUNCH("k_grad_filter_mfma", (k_grad_filter_mfma<A, B>), grid, block, 0, st, nbr, values_neigh, grad_out, m, filter_extent, \
-                  partial, val_dim, v_off, nr_filters, f_off);
-            LN_GF_CASE(1, 1) LN_GF_CASE(1, 2) LN_GF_CASE(1, 4) LN_GF_CASE(2, 1) LN_GF_CASE(2, 2) LN_GF_CASE(2, 4) LN_GF_CASE(4, 1)
-            LN_GF_CASE(4, 2) LN_GF_CASE(4, 4)
-#undef LN_GF_CASE
-            f_off += ft * 16;
+    const dim3 block(256);
+    // uniform tiling (both dimensions multiples of the widest tile that divides them): ONE launch, gridDim.z = sub-blocks
+    for (int t = 4; t >= 1; t >>= 1) {
+        if (val_dim % (16 * t) == 0 && nr_filters % (16 * t) == 0) {
+            const dim3 grid(chunks, filter_extent, (val_dim / (16 * t)) * (nr_filters / (16 * t)));
+            if (t == 4)
+                LN_LAUNCH("k_grad_filter_mfma", (k_grad_filter_mfma<4, 4>), grid, block, 0, st, nbr, values_neigh, grad_out, m, filter_extent, partial,
+                          val_dim, 0, nr_filters, 0);
+            else if (t == 2)
+                LN_LAUNCH("k_grad_filter_mfma", (k_grad_filter_mfma<2, 2>), grid, block, 0, st, nbr, values_neigh, grad_out, m, filter_extent, partial,
+                          val_dim, 0, nr_filters, 0);
+            else
+                LN_LAUNCH("k_grad_filter_mfma", (k_grad_filter_mfma<1, 1>), grid, block, 0, st, nbr, values_neigh, grad_out, m, filter_extent, partial,
+                          val_dim, 0, nr_filters, 0);
+            return chunks;
         }
-        v_off += vt * 16;
     }
-    return chunks;
+    return chunks;  // unreachable: both dimensions are multiples of 16 (ln_gf_mfma_supported)
 }
 
 extern "C" int ln_conv_grad_filter(const int* nbr, const float* values_neigh, const float* grad_out, int m, int filter_extent,
