@@ -281,13 +281,17 @@ int ln_linear_act_backward(const float* x, const float* w, const float* y, const
  * forward:  y = act(x * a[c] + b[c]),  a = gamma*rstd[g], b = beta - mean[g]*a;  also writes mean_rstd[2*groups]
  *           (means then rstds) and scale_shift[2*channels] (a then b) for the backward pass.
  * backward: grad_x (and grad_gamma / grad_beta when non-NULL) from x, grad_y and the two saved vectors.
- * channels % 4 == 0, channels <= 1024, 16-byte aligned tensors; workspace = ln_group_norm_workspace_bytes(channels). */
+ * channels % 4 == 0, channels <= 1024, 16-byte aligned tensors; workspace = ln_group_norm_workspace_bytes(channels).
+ * next_workspace (may be NULL): a caller that alternates two workspaces on one stream passes the other one here; the
+ * call then trusts `workspace` to be all-zero (no fill launch) and zero-fills next_workspace_bytes of `next_workspace` (what
+ * its last user dirtied) before it returns the GPU. */
 size_t ln_group_norm_workspace_bytes(int channels);
 int ln_group_norm_forward(const float* x, const float* gamma, const float* beta, int m, int channels, int groups, float eps, int relu,
-                          float* y, float* mean_rstd, float* scale_shift, void* workspace, size_t workspace_bytes, void* stream);
+                          float* y, float* mean_rstd, float* scale_shift, void* workspace, size_t workspace_bytes, void* next_workspace,
+                          size_t next_workspace_bytes, void* stream);
 int ln_group_norm_backward(const float* x, const float* grad_y, const float* gamma, const float* mean_rstd, const float* scale_shift, int m,
                            int channels, int groups, int relu, float* grad_x, float* grad_gamma, float* grad_beta, void* workspace,
-                           size_t workspace_bytes, void* stream);
+                           size_t workspace_bytes, void* next_workspace, size_t next_workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -133,8 +133,10 @@ __device__ __forceinline__ void ln_gn_channel_affine(const double* __restrict__ 
 __global__ void __launch_bounds__(256)
     k_gn_apply(const float* __restrict__ x, const double* __restrict__ acc, const float* __restrict__ gamma, const float* __restrict__ beta,
                int m, int c, int groups, float eps, int relu, float* __restrict__ y, float* __restrict__ mean_rstd,
-               float* __restrict__ scale_shift) {
+               float* __restrict__ scale_shift, double* __restrict__ zero_next, int zero_count) {
     __shared__ float s_a[LN_GN_MAX_C], s_b[LN_GN_MAX_C];
+    if (zero_next && blockIdx.x == 0)  // the accumulators of the NEXT call (nobody is using them now: stream order)
+        for (int i = threadIdx.x; i < zero_count; i += 256) zero_next[i] = 0.0;
     ln_gn_channel_affine(acc, gamma, beta, m, c, groups, eps, s_a, s_b, mean_rstd, scale_shift);
     __syncthreads();
     const long long total4 = (long long)m * c / 4;  // c % 4 == 0 checked by the host
@@ -160,7 +162,10 @@ __global__ void __launch_bounds__(256)
 __global__ void __launch_bounds__(256)
     k_gn_backward_apply(const float* __restrict__ x, const float* __restrict__ gy, const double* __restrict__ acc,
                         const float* __restrict__ gamma, const float* __restrict__ mean_rstd, const float* __restrict__ scale_shift, int m,
-                        int c, int groups, int relu, float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                        int c, int groups, int relu, float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                        double* __restrict__ zero_next, int zero_count) {
+    if (zero_next && blockIdx.x == 0)
+        for (int i = threadIdx.x; i < zero_count; i += 256) zero_next[i] = 0.0;
     __shared__ float s_gr[LN_GN_MAX_C], s_c2[LN_GN_MAX_C], s_c3[LN_GN_MAX_C], s_a[LN_GN_MAX_C], s_b[LN_GN_MAX_C];
     const int cg = c / groups;
     __shared__ double s_ds[LN_GN_MAX_C], s_db[LN_GN_MAX_C];
@@ -249,7 +254,7 @@ extern "C" size_t ln_group_norm_workspace_bytes(int channels) { return (size_t)L
 
 extern "C" int ln_group_norm_forward(const float* x, const float* gamma, const float* beta, int m, int channels, int groups, float eps,
                                      int relu, float* y, float* mean_rstd, float* scale_shift, void* workspace, size_t workspace_bytes,
-                                     void* stream) {
+                                     void* next_workspace, size_t next_workspace_bytes, void* stream) {
     int rc = ln_gn_check("ln_group_norm_forward", m, channels, groups);
     if (rc) return rc;
     LN_REQUIRE(x && y && mean_rstd && scale_shift && workspace && workspace_bytes >= ln_group_norm_workspace_bytes(channels), LN_ERR_ARG,
@@ -258,17 +263,20 @@ extern "C" int ln_group_norm_forward(const float* x, const float* gamma, const f
                LN_ERR_ARG, "ln_group_norm_forward: x / y must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     double* acc = static_cast<double*>(workspace);
-    if (hipMemsetAsync(acc, 0, ln_group_norm_workspace_bytes(channels), st) != hipSuccess) return ln_check_launch("ln_group_norm_forward(memset)");
+    // next_workspace != NULL: the caller alternates two workspaces and promises `workspace` is zero (it was `next_workspace` of
+    // the previous call on this stream, or freshly zeroed); this call zero-fills `next_workspace` on its way out.
+    if (!next_workspace && hipMemsetAsync(acc, 0, ln_group_norm_workspace_bytes(channels), st) != hipSuccess)
+        return ln_check_launch("ln_group_norm_forward(memset)");
     LN_LAUNCH("k_gn_stats", k_gn_stats, dim3(ln_gn_stats_grid(m, channels)), dim3(256), 0, st, x, (const float*)nullptr, (const float*)nullptr, 0, m,
               channels, acc);
     LN_LAUNCH("k_gn_apply", k_gn_apply, dim3(ln_gn_apply_grid(m, channels)), dim3(256), 0, st, x, acc, gamma, beta, m, channels, groups, eps, relu, y,
-              mean_rstd, scale_shift);
+              mean_rstd, scale_shift, static_cast<double*>(next_workspace), int(next_workspace_bytes / sizeof(double)));
     return ln_check_launch("ln_group_norm_forward");
 }
 
 extern "C" int ln_group_norm_backward(const float* x, const float* grad_y, const float* gamma, const float* mean_rstd,
                                       const float* scale_shift, int m, int channels, int groups, int relu, float* grad_x, float* grad_gamma,
-                                      float* grad_beta, void* workspace, size_t workspace_bytes, void* stream) {
+                                      float* grad_beta, void* workspace, size_t workspace_bytes, void* next_workspace, size_t next_workspace_bytes, void* stream) {
     int rc = ln_gn_check("ln_group_norm_backward", m, channels, groups);
     if (rc) return rc;
     LN_REQUIRE(x && grad_y && mean_rstd && scale_shift && grad_x && workspace && workspace_bytes >= ln_group_norm_workspace_bytes(channels),
@@ -277,9 +285,11 @@ extern "C" int ln_group_norm_backward(const float* x, const float* grad_y, const
                "ln_group_norm_backward: x / grad_y / grad_x must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     double* acc = static_cast<double*>(workspace);
-    if (hipMemsetAsync(acc, 0, ln_group_norm_workspace_bytes(channels), st) != hipSuccess) return ln_check_launch("ln_group_norm_backward(memset)");
+    if (!next_workspace && hipMemsetAsync(acc, 0, ln_group_norm_workspace_bytes(channels), st) != hipSuccess)
+        return ln_check_launch("ln_group_norm_backward(memset)");
     LN_LAUNCH("k_gn_stats", k_gn_stats, dim3(ln_gn_stats_grid(m, channels)), dim3(256), 0, st, x, grad_y, scale_shift, relu, m, channels, acc);
     LN_LAUNCH("k_gn_backward_apply", k_gn_backward_apply, dim3(ln_gn_apply_grid(m, channels)), dim3(256), 0, st, x, grad_y, acc, gamma, mean_rstd,
-              scale_shift, m, channels, groups, relu, grad_x, grad_gamma, grad_beta);
+              scale_shift, m, channels, groups, relu, grad_x, grad_gamma, grad_beta, static_cast<double*>(next_workspace),
+              int(next_workspace_bytes / sizeof(double)));
     return ln_check_launch("ln_group_norm_backward");
 }

@@ -50,6 +50,29 @@ class BatchNormLatticeModule(torch.nn.Module):  # mods:570-583
         return lattice_values, lattice_py
 
 
+_GN_WORKSPACES = {}
+
+
+def _gn_workspace_pair(device, stream: int, nbytes: int):
+    """(this call's accumulators, the next call's, bytes of the latter to zero) for GroupNorm launches on (device, stream): two
+    zero-initialised buffers used alternately — every call zeroes what the other buffer's last user dirtied, so no call needs
+    a fill launch of its own."""
+    key = (device, stream)
+    entry = _GN_WORKSPACES.get(key)
+    if entry is None or entry["bufs"][0].numel() * 8 < nbytes:
+        n = max(nbytes // 8, 1)
+        entry = {"bufs": [torch.zeros((n,), dtype=torch.float64, device=device), torch.zeros((n,), dtype=torch.float64, device=device)],
+                 "dirty": [0, 0], "cur": 0}
+        _GN_WORKSPACES[key] = entry
+    cur = entry["cur"]
+    nxt = cur ^ 1
+    entry["cur"] = nxt
+    to_zero = entry["dirty"][nxt]
+    entry["dirty"][nxt] = 0
+    entry["dirty"][cur] = nbytes
+    return entry["bufs"][cur], entry["bufs"][nxt], to_zero
+
+
 class GroupNormReluFunction(torch.autograd.Function):
     """GroupNorm (+ optional fused ReLU) over an [M, C] value matrix on the HIP kernels of csrc/ln_norm.hip
     (ln_group_norm_forward / _backward): statistics per group over all vertices x the group's channels."""
@@ -62,10 +85,11 @@ class GroupNormReluFunction(torch.autograd.Function):
         y = torch.empty_like(x)
         mean_rstd = torch.empty((2 * num_groups,), dtype=torch.float32, device=x.device)
         scale_shift = torch.empty((2 * c,), dtype=torch.float32, device=x.device)
-        ws = torch.empty((lib.ln_group_norm_workspace_bytes(c) // 8,), dtype=torch.float64, device=x.device)
+        stream = _lib.stream_ptr(x.device)
+        ws, ws_next, zero_bytes = _gn_workspace_pair(x.device, stream, lib.ln_group_norm_workspace_bytes(c))
         _lib.check(lib.ln_group_norm_forward(_lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), m, c, num_groups, float(eps), int(relu),
                                              _lib.ptr(y), _lib.ptr(mean_rstd), _lib.ptr(scale_shift), _lib.ptr(ws), ws.numel() * 8,
-                                             _lib.stream_ptr(x.device)), "ln_group_norm_forward")
+                                             _lib.ptr(ws_next), zero_bytes, stream), "ln_group_norm_forward")
         ctx.save_for_backward(x, weight, mean_rstd, scale_shift)
         ctx.args = (num_groups, bool(relu), bias is not None)
         return y
@@ -80,10 +104,11 @@ class GroupNormReluFunction(torch.autograd.Function):
         grad_x = torch.empty_like(x)
         grad_w = torch.empty((c,), dtype=torch.float32, device=x.device) if weight is not None else None
         grad_b = torch.empty((c,), dtype=torch.float32, device=x.device) if has_bias else None
-        ws = torch.empty((lib.ln_group_norm_workspace_bytes(c) // 8,), dtype=torch.float64, device=x.device)
+        stream = _lib.stream_ptr(x.device)
+        ws, ws_next, zero_bytes = _gn_workspace_pair(x.device, stream, lib.ln_group_norm_workspace_bytes(c))
         _lib.check(lib.ln_group_norm_backward(_lib.ptr(x), _lib.ptr(grad_y), _lib.ptr(weight), _lib.ptr(mean_rstd), _lib.ptr(scale_shift), m, c,
                                               num_groups, int(relu), _lib.ptr(grad_x), _lib.ptr(grad_w), _lib.ptr(grad_b), _lib.ptr(ws),
-                                              ws.numel() * 8, _lib.stream_ptr(x.device)), "ln_group_norm_backward")
+                                              ws.numel() * 8, _lib.ptr(ws_next), zero_bytes, stream), "ln_group_norm_backward")
         return grad_x, grad_w, grad_b, None, None, None
 
 
