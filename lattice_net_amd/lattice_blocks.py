@@ -73,6 +73,12 @@ def _gn_workspace_pair(device, stream: int, nbytes: int):
     return entry["bufs"][cur], entry["bufs"][nxt], to_zero
 
 
+def _gn_check(rc: int, what: str, device, stream: int):
+    if rc != 0:
+        _GN_WORKSPACES.pop((device, stream), None)  # the zero invariant of the pair may be broken: start over with fresh buffers
+    _lib.check(rc, what)
+
+
 class GroupNormReluFunction(torch.autograd.Function):
     """GroupNorm (+ optional fused ReLU) over an [M, C] value matrix on the HIP kernels of csrc/ln_norm.hip
     (ln_group_norm_forward / _backward): statistics per group over all vertices x the group's channels."""
@@ -87,9 +93,9 @@ class GroupNormReluFunction(torch.autograd.Function):
         scale_shift = torch.empty((2 * c,), dtype=torch.float32, device=x.device)
         stream = _lib.stream_ptr(x.device)
         ws, ws_next, zero_bytes = _gn_workspace_pair(x.device, stream, lib.ln_group_norm_workspace_bytes(c))
-        _lib.check(lib.ln_group_norm_forward(_lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), m, c, num_groups, float(eps), int(relu),
-                                             _lib.ptr(y), _lib.ptr(mean_rstd), _lib.ptr(scale_shift), _lib.ptr(ws), ws.numel() * 8,
-                                             _lib.ptr(ws_next), zero_bytes, stream), "ln_group_norm_forward")
+        _gn_check(lib.ln_group_norm_forward(_lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), m, c, num_groups, float(eps), int(relu),
+                                            _lib.ptr(y), _lib.ptr(mean_rstd), _lib.ptr(scale_shift), _lib.ptr(ws), ws.numel() * 8,
+                                            _lib.ptr(ws_next), zero_bytes, stream), "ln_group_norm_forward", x.device, stream)
         ctx.save_for_backward(x, weight, mean_rstd, scale_shift)
         ctx.args = (num_groups, bool(relu), bias is not None)
         return y
@@ -106,9 +112,9 @@ class GroupNormReluFunction(torch.autograd.Function):
         grad_b = torch.empty((c,), dtype=torch.float32, device=x.device) if has_bias else None
         stream = _lib.stream_ptr(x.device)
         ws, ws_next, zero_bytes = _gn_workspace_pair(x.device, stream, lib.ln_group_norm_workspace_bytes(c))
-        _lib.check(lib.ln_group_norm_backward(_lib.ptr(x), _lib.ptr(grad_y), _lib.ptr(weight), _lib.ptr(mean_rstd), _lib.ptr(scale_shift), m, c,
-                                              num_groups, int(relu), _lib.ptr(grad_x), _lib.ptr(grad_w), _lib.ptr(grad_b), _lib.ptr(ws),
-                                              ws.numel() * 8, _lib.ptr(ws_next), zero_bytes, stream), "ln_group_norm_backward")
+        _gn_check(lib.ln_group_norm_backward(_lib.ptr(x), _lib.ptr(grad_y), _lib.ptr(weight), _lib.ptr(mean_rstd), _lib.ptr(scale_shift), m, c,
+                                             num_groups, int(relu), _lib.ptr(grad_x), _lib.ptr(grad_w), _lib.ptr(grad_b), _lib.ptr(ws),
+                                             ws.numel() * 8, _lib.ptr(ws_next), zero_bytes, stream), "ln_group_norm_backward", x.device, stream)
         return grad_x, grad_w, grad_b, None, None, None
 
 
