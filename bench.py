@@ -234,6 +234,8 @@ def main():
     pos = torch.from_numpy(make_cloud(cfg["gen"], n, sharding.cloud_seed(rank))).to(dev)
     vals = torch.from_numpy(rng.standard_normal((n, v)).astype(np.float32)).to(dev)
     G = torch.from_numpy(rng.standard_normal((n, f)).astype(np.float32)).to(dev)
+    if cfg.get("half"):
+        vals, G = vals.half(), G.half()
     bound = float(np.sqrt(3.0) * np.sqrt(2.0) / np.sqrt(f))  # kaiming-uniform fan_out (lattice_modules.py:202-207)
     W = ((torch.rand((e * v, f), device=dev) * 2 - 1) * bound)
     sharding.broadcast_parameters(dist, [W], src=0)
@@ -246,9 +248,8 @@ def main():
         lv, wrap, idx, w = L.SplatLattice.apply(lat, pos, vals)       # clear + hash build + accumulate
         m = lat.nr_lattice_vertices()                                   # the path's one host readback
         lv = lv[:m].requires_grad_(True)
-        if half:  # fp16 feature path: fp16 operands on the matrix cores, fp32 accumulation
+        if half:  # fp16 feature path: fp16 point features, lattice values and filter bank; fp32 accumulation everywhere
             cv, cwrap = L.ConvIm2RowLattice.apply(lv.half(), lat, W.half(), 1)
-            cv = cv.float()
         else:
             cv, cwrap = L.ConvIm2RowLattice.apply(lv, lat, W, 1)       # neighbour list + gather-GEMM
         out = L.SliceLattice.apply(cv, cwrap.lattice, pos, idx, w)     # slice
@@ -326,7 +327,6 @@ def main():
             lv = lv[:mm].requires_grad_(True)
             if half:
                 cv, cwrap = L.ConvIm2RowLattice.apply(lv.half(), lat, W.half(), 1)
-                cv = cv.float()
             else:
                 cv, cwrap = L.ConvIm2RowLattice.apply(lv, lat, W, 1)
             ev[2].record()

@@ -253,6 +253,16 @@ int ln_conv_backward(const int* nbr_q, const int* nbr_n, const float* values_nei
                      int filter_extent, int val_dim, int nr_filters, float* grad_values, float* grad_filter, void* workspace,
                      size_t workspace_bytes, void* stream);
 
+/* Half-precision feature path of the scatters and the slice (C5: "features fp16, accumulate fp32"): the segment reduce with
+ * fp16 source rows (fp32 weights, fp32 accumulation into an fp32 dst) — plain and fused with the neighbour traversal — and the
+ * slice of fp16 lattice values into fp16 rows (fp32 arithmetic, val_dim % 4 == 0). */
+int ln_csr_reduce_rows_f16(const LnCsr* csr, const int* grp_row, long long max_segments, const void* src_f16, const float* w, int val_dim,
+                           int src_div, int src_stride, float* dst, void* stream);
+int ln_splat_accumulate_and_neighbours_f16(const LnCsr* csr, const int* grp_row, long long max_segments, const void* src_f16, const float* w,
+                                           int val_dim, int src_div, int src_stride, float* dst, const LnTable* table, int query_rows_upper,
+                                           int* nbr, void* stream);
+int ln_slice_forward_f16(const void* values_f16, const int* idx, const float* w, int n, int pos_dim, int val_dim, void* out_f16, void* stream);
+
 /* Half-precision feature path of the convolution (BASELINE.json config 5 / SURVEY.md 8d C5: features fp16, accumulate
  * fp32).  Same arguments and flags as ln_conv_forward / ln_conv_grad_filter; values, filter bank, grad_out and out are
  * IEEE fp16 (`_Float16`), accumulation is fp32 (v_mfma_f32_16x16x16_f16 for val_dim in {16,32,64,96,128,256} and

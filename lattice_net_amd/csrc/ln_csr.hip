@@ -191,14 +191,14 @@ struct LnReduceArgs {
     const int* seg_beg;
     const int* seg_count;
     const int* grp_row;
-    const float* src;
+    const void* src;  // float rows, or _Float16 rows for the HALF instantiations (accumulation and dst stay fp32)
     const float* w;
     int chunks, lanes_per_seg, src_div, src_stride;
     float* dst;
 };
 
 // body of the segment reduce for the workgroup `block_x` (of 256 threads)
-template <int VEC>
+template <int VEC, bool HALF>
 __device__ __forceinline__ void ln_reduce_body(int block_x, const LnReduceArgs& a) {
     const int* __restrict__ grp_start = a.grp_start;
     const int* __restrict__ csr_tok = a.csr_tok;
@@ -206,7 +206,8 @@ __device__ __forceinline__ void ln_reduce_body(int block_x, const LnReduceArgs& 
     const int* __restrict__ seg_beg = a.seg_beg;
     const int* __restrict__ seg_count = a.seg_count;
     const int* __restrict__ grp_row = a.grp_row;
-    const float* __restrict__ src = a.src;
+    const float* __restrict__ src = static_cast<const float*>(a.src);
+    const _Float16* __restrict__ src16 = static_cast<const _Float16*>(a.src);
     const float* __restrict__ w = a.w;
     float* __restrict__ dst = a.dst;
     const int chunks = a.chunks, lanes_per_seg = a.lanes_per_seg, src_div = a.src_div, src_stride = a.src_stride;
@@ -249,12 +250,20 @@ __device__ __forceinline__ void ln_reduce_body(int block_x, const LnReduceArgs& 
                     for (int k = 0; k < VEC; ++k) x[u][k] = 0.f;
                     if (tk[u] >= 0) {
                         wt[u] = w[tk[u]];
-                        const float* sp = src + (size_t)(tk[u] / src_div) * src_stride + c * VEC;
-                        if constexpr (VEC == 4) {
-                            const float4 v4 = *reinterpret_cast<const float4*>(sp);
+                        const size_t off = (size_t)(tk[u] / src_div) * src_stride + c * VEC;
+                        if constexpr (HALF) {
+                            if constexpr (VEC == 4) {
+                                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                                const h4 v4 = *reinterpret_cast<const h4*>(src16 + off);
+                                x[u][0] = (float)v4[0]; x[u][1] = (float)v4[1]; x[u][2] = (float)v4[2]; x[u][3] = (float)v4[3];
+                            } else {
+                                x[u][0] = (float)src16[off];
+                            }
+                        } else if constexpr (VEC == 4) {
+                            const float4 v4 = *reinterpret_cast<const float4*>(src + off);
                             x[u][0] = v4.x; x[u][1] = v4.y; x[u][2] = v4.z; x[u][3] = v4.w;
                         } else {
-                            x[u][0] = sp[0];
+                            x[u][0] = src[off];
                         }
                     }
                 }
@@ -297,30 +306,30 @@ __device__ __forceinline__ void ln_reduce_body(int block_x, const LnReduceArgs& 
     }
 }
 
-template <int VEC>
-__global__ void __launch_bounds__(256) k_csr_reduce_segments(LnReduceArgs a) { ln_reduce_body<VEC>(blockIdx.x, a); }
+template <int VEC, bool HALF>
+__global__ void __launch_bounds__(256) k_csr_reduce_segments(LnReduceArgs a) { ln_reduce_body<VEC, HALF>(blockIdx.x, a); }
 
 // Horizontal fusion of the two launches that follow a splat build and do not depend on each other: workgroups
 // [0, reduce_blocks) accumulate the point features onto the vertices (segment reduce), the rest run the same-level
 // neighbour traversal.  One launch instead of two, and the traversal's short, latency-bound workgroups fill the CUs
 // the reduce's tail leaves idle.
-template <int VEC, int D>
+template <int VEC, int D, bool HALF>
 __global__ void __launch_bounds__(256)
     k_reduce_and_neighbours(LnReduceArgs a, int reduce_blocks, LnTable t, int query_rows_upper, int* __restrict__ nbr) {
     if ((int)blockIdx.x < reduce_blocks) {
-        ln_reduce_body<VEC>(blockIdx.x, a);
+        ln_reduce_body<VEC, HALF>(blockIdx.x, a);
     } else {
         const long long g = (long long)(blockIdx.x - reduce_blocks) * 256 + threadIdx.x;
         ln_neighbours_body<D>(g, t, query_rows_upper, t, 1.0f, 1, 0, nbr);
     }
 }
 
-static int ln_reduce_args(const char* who, const LnCsr* csr, const int* grp_row, long long max_segments, const float* src, const float* w,
-                          int val_dim, int src_div, int src_stride, float* dst, LnReduceArgs& a, bool& vec4, long long& work) {
+static int ln_reduce_args(const char* who, const LnCsr* csr, const int* grp_row, long long max_segments, const void* src, bool half,
+                          const float* w, int val_dim, int src_div, int src_stride, float* dst, LnReduceArgs& a, bool& vec4, long long& work) {
     LN_REQUIRE(max_segments >= 0 && val_dim >= 1 && src_div >= 1 && src_stride >= val_dim, LN_ERR_ARG, "%s: bad sizes", who);
     LN_REQUIRE(max_segments == 0 || (csr && csr->grp_start && csr->csr_tok && csr->seg_grp && csr->seg_beg && csr->seg_count && src && w && dst),
                LN_ERR_ARG, "%s: null buffer", who);
-    vec4 = (val_dim % 4 == 0) && (src_stride % 4 == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0) &&
+    vec4 = (val_dim % 4 == 0) && (src_stride % 4 == 0) && ((reinterpret_cast<uintptr_t>(src) & (half ? 7 : 15)) == 0) &&
            ((reinterpret_cast<uintptr_t>(dst) & 15) == 0);
     const int chunks = vec4 ? val_dim / 4 : val_dim;
     int lanes = 1;
@@ -331,54 +340,91 @@ static int ln_reduce_args(const char* who, const LnCsr* csr, const int* grp_row,
     return LN_OK;
 }
 
-extern "C" int ln_csr_reduce_rows(const LnCsr* csr, const int* grp_row, long long max_segments, const float* src, const float* w,
-                                  int val_dim, int src_div, int src_stride, float* dst, void* stream) {
+static int ln_csr_reduce_rows_impl(const char* who, const LnCsr* csr, const int* grp_row, long long max_segments, const void* src, bool half,
+                                   const float* w, int val_dim, int src_div, int src_stride, float* dst, void* stream) {
     LnReduceArgs a;
     bool vec4;
     long long work;
-    int rc = ln_reduce_args("ln_csr_reduce_rows", csr, grp_row, max_segments, src, w, val_dim, src_div, src_stride, dst, a, vec4, work);
+    int rc = ln_reduce_args(who, csr, grp_row, max_segments, src, half, w, val_dim, src_div, src_stride, dst, a, vec4, work);
     if (rc) return rc;
     if (max_segments == 0) return LN_OK;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(ln_div_up(work, 256)), block(256);
-    if (vec4)
-        LN_LAUNCH("k_csr_reduce_segments", k_csr_reduce_segments<4>, grid, block, 0, st, a);
-    else
-        LN_LAUNCH("k_csr_reduce_segments", k_csr_reduce_segments<1>, grid, block, 0, st, a);
-    return ln_check_launch("ln_csr_reduce_rows");
+    if (half) {
+        if (vec4)
+            LN_LAUNCH("k_csr_reduce_segments", (k_csr_reduce_segments<4, true>), grid, block, 0, st, a);
+        else
+            LN_LAUNCH("k_csr_reduce_segments", (k_csr_reduce_segments<1, true>), grid, block, 0, st, a);
+    } else {
+        if (vec4)
+            LN_LAUNCH("k_csr_reduce_segments", (k_csr_reduce_segments<4, false>), grid, block, 0, st, a);
+        else
+            LN_LAUNCH("k_csr_reduce_segments", (k_csr_reduce_segments<1, false>), grid, block, 0, st, a);
+    }
+    return ln_check_launch(who);
+}
+
+extern "C" int ln_csr_reduce_rows(const LnCsr* csr, const int* grp_row, long long max_segments, const float* src, const float* w,
+                                  int val_dim, int src_div, int src_stride, float* dst, void* stream) {
+    return ln_csr_reduce_rows_impl("ln_csr_reduce_rows", csr, grp_row, max_segments, src, false, w, val_dim, src_div, src_stride, dst, stream);
+}
+
+extern "C" int ln_csr_reduce_rows_f16(const LnCsr* csr, const int* grp_row, long long max_segments, const void* src_f16, const float* w,
+                                      int val_dim, int src_div, int src_stride, float* dst, void* stream) {
+    return ln_csr_reduce_rows_impl("ln_csr_reduce_rows_f16", csr, grp_row, max_segments, src_f16, true, w, val_dim, src_div, src_stride, dst,
+                                   stream);
 }
 
 // ln_csr_reduce_rows + ln_neighbours(table, rows_upper, table, same level, dilation 1, no flip) in ONE launch
-extern "C" int ln_splat_accumulate_and_neighbours(const LnCsr* csr, const int* grp_row, long long max_segments, const float* src,
-                                                  const float* w, int val_dim, int src_div, int src_stride, float* dst, const LnTable* table,
-                                                  int query_rows_upper, int* nbr, void* stream) {
+static int ln_splat_tail_impl(const char* who, const LnCsr* csr, const int* grp_row, long long max_segments, const void* src, bool half,
+                              const float* w, int val_dim, int src_div, int src_stride, float* dst, const LnTable* table,
+                              int query_rows_upper, int* nbr, void* stream) {
     LnReduceArgs a;
     bool vec4;
     long long work;
-    int rc = ln_reduce_args("ln_splat_accumulate_and_neighbours", csr, grp_row, max_segments, src, w, val_dim, src_div, src_stride, dst, a, vec4,
-                            work);
+    int rc = ln_reduce_args(who, csr, grp_row, max_segments, src, half, w, val_dim, src_div, src_stride, dst, a, vec4, work);
     if (rc) return rc;
     LN_REQUIRE(table && table->slot_keys && table->entries && table->keys && table->nr_filled && table->capacity > 0, LN_ERR_ARG,
-               "ln_splat_accumulate_and_neighbours: bad table");
-    LN_REQUIRE(max_segments > 0 && query_rows_upper > 0 && nbr, LN_ERR_ARG, "ln_splat_accumulate_and_neighbours: nothing to do / null output");
+               "%s: bad table", who);
+    LN_REQUIRE(max_segments > 0 && query_rows_upper > 0 && nbr, LN_ERR_ARG, "%s: nothing to do / null output", who);
     const int d = table->pos_dim;
-    LN_REQUIRE(d >= 1 && d <= LN_MAX_POS_DIM, LN_ERR_UNSUPPORTED, "ln_splat_accumulate_and_neighbours: pos_dim %d unsupported", d);
+    LN_REQUIRE(d >= 1 && d <= LN_MAX_POS_DIM, LN_ERR_UNSUPPORTED, "%s: pos_dim %d unsupported", who, d);
     hipStream_t st = (hipStream_t)stream;
     const int reduce_blocks = ln_div_up(work, 256);
     const int nbr_blocks = ln_div_up((long long)query_rows_upper * (2 * (d + 1) + 1), 256);
     const dim3 grid(reduce_blocks + nbr_blocks), block(256);
 #define LN_FUSED_CASE(DD)                                                                                                              \
     case DD:                                                                                                                           \
-        if (vec4)                                                                                                                      \
-            LN_LAUNCH("k_reduce_and_neighbours", (k_reduce_and_neighbours<4, DD>), grid, block, 0, st, a, reduce_blocks, *table, query_rows_upper, \
-                      nbr);                                                                                                            \
+        if (half && vec4)                                                                                                              \
+            LN_LAUNCH("k_reduce_and_neighbours", (k_reduce_and_neighbours<4, DD, true>), grid, block, 0, st, a, reduce_blocks, *table,  \
+                      query_rows_upper, nbr);                                                                                          \
+        else if (half)                                                                                                                 \
+            LN_LAUNCH("k_reduce_and_neighbours", (k_reduce_and_neighbours<1, DD, true>), grid, block, 0, st, a, reduce_blocks, *table,  \
+                      query_rows_upper, nbr);                                                                                          \
+        else if (vec4)                                                                                                                 \
+            LN_LAUNCH("k_reduce_and_neighbours", (k_reduce_and_neighbours<4, DD, false>), grid, block, 0, st, a, reduce_blocks, *table, \
+                      query_rows_upper, nbr);                                                                                          \
         else                                                                                                                           \
-            LN_LAUNCH("k_reduce_and_neighbours", (k_reduce_and_neighbours<1, DD>), grid, block, 0, st, a, reduce_blocks, *table, query_rows_upper, \
-                      nbr);                                                                                                            \
+            LN_LAUNCH("k_reduce_and_neighbours", (k_reduce_and_neighbours<1, DD, false>), grid, block, 0, st, a, reduce_blocks, *table, \
+                      query_rows_upper, nbr);                                                                                          \
         break;
     switch (d) { LN_FUSED_CASE(1) LN_FUSED_CASE(2) LN_FUSED_CASE(3) LN_FUSED_CASE(4) LN_FUSED_CASE(5) LN_FUSED_CASE(6) }
 #undef LN_FUSED_CASE
-    return ln_check_launch("ln_splat_accumulate_and_neighbours");
+    return ln_check_launch(who);
+}
+
+extern "C" int ln_splat_accumulate_and_neighbours(const LnCsr* csr, const int* grp_row, long long max_segments, const float* src,
+                                                  const float* w, int val_dim, int src_div, int src_stride, float* dst, const LnTable* table,
+                                                  int query_rows_upper, int* nbr, void* stream) {
+    return ln_splat_tail_impl("ln_splat_accumulate_and_neighbours", csr, grp_row, max_segments, src, false, w, val_dim, src_div, src_stride, dst,
+                              table, query_rows_upper, nbr, stream);
+}
+
+extern "C" int ln_splat_accumulate_and_neighbours_f16(const LnCsr* csr, const int* grp_row, long long max_segments, const void* src_f16,
+                                                      const float* w, int val_dim, int src_div, int src_stride, float* dst,
+                                                      const LnTable* table, int query_rows_upper, int* nbr, void* stream) {
+    return ln_splat_tail_impl("ln_splat_accumulate_and_neighbours_f16", csr, grp_row, max_segments, src_f16, true, w, val_dim, src_div, src_stride,
+                              dst, table, query_rows_upper, nbr, stream);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -152,6 +152,44 @@ extern "C" int ln_slice_forward_prepare_backward(const float* values, const int*
     return ln_slice_forward_impl(values, idx, w, n, pos_dim, val_dim, out, grad_accumulator, grad_accumulator_elems, stream);
 }
 
+// fp16 lattice values -> fp16 sliced rows (fp32 arithmetic): thread = (point, 4 channels)
+__global__ void __launch_bounds__(256)
+    k_slice_forward_f16(const _Float16* __restrict__ values, const int* __restrict__ idx, const float* __restrict__ w, long long work, int dp1,
+                        int chunks, _Float16* __restrict__ out) {
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= work) return;
+    const long long p = g / chunks;
+    const int c = int(g - p * chunks);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int r = 0; r < dp1; ++r) {
+        const int row = idx[p * dp1 + r];
+        if (row >= 0) {
+            const h4 v = reinterpret_cast<const h4*>(values)[(size_t)row * chunks + c];
+            const float wt = w[p * dp1 + r];
+            a0 += (float)v[0] * wt; a1 += (float)v[1] * wt; a2 += (float)v[2] * wt; a3 += (float)v[3] * wt;
+        }
+    }
+    h4 o;
+    o[0] = (_Float16)a0; o[1] = (_Float16)a1; o[2] = (_Float16)a2; o[3] = (_Float16)a3;
+    reinterpret_cast<h4*>(out)[g] = o;
+}
+
+extern "C" int ln_slice_forward_f16(const void* values_f16, const int* idx, const float* w, int n, int pos_dim, int val_dim, void* out_f16,
+                                    void* stream) {
+    LN_REQUIRE(n >= 0 && pos_dim >= 1 && pos_dim <= LN_MAX_POS_DIM && val_dim >= 4 && val_dim % 4 == 0, LN_ERR_UNSUPPORTED,
+               "ln_slice_forward_f16: val_dim must be a multiple of 4 (got %d)", val_dim);
+    LN_REQUIRE(n == 0 || (values_f16 && idx && w && out_f16), LN_ERR_ARG, "ln_slice_forward_f16: null buffer");
+    LN_REQUIRE(((reinterpret_cast<uintptr_t>(values_f16) | reinterpret_cast<uintptr_t>(out_f16)) & 7) == 0, LN_ERR_ARG,
+               "ln_slice_forward_f16: buffers must be 8-byte aligned");
+    if (n == 0) return LN_OK;
+    const int chunks = val_dim / 4;
+    const long long work = (long long)n * chunks;
+    LN_LAUNCH("k_slice_forward_f16", k_slice_forward_f16, dim3(ln_div_up(work, 256)), dim3(256), 0, (hipStream_t)stream,
+              static_cast<const _Float16*>(values_f16), idx, w, work, pos_dim + 1, chunks, static_cast<_Float16*>(out_f16));
+    return ln_check_launch("ln_slice_forward_f16");
+}
+
 int ln_retrieve_points(const LnTable* t, const float* positions_raw, const float* sigmas_host, int n, int* idx, float* w,
                        void* stream);
 

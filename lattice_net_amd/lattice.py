@@ -365,8 +365,8 @@ class Lattice:
         _require_cuda(positions_raw, "positions")
 
     def _check_values(self, values: torch.Tensor):  # Lattice.cu:171-175
-        if values.dtype != torch.float32 or values.dim() != 2 or not values.is_contiguous():
-            raise ValueError("values should be a contiguous 2-D float tensor")
+        if values.dtype not in (torch.float32, torch.float16) or values.dim() != 2 or not values.is_contiguous():
+            raise ValueError("values should be a contiguous 2-D float tensor (float16 features are accumulated in float32)")
         _require_cuda(values, "values")
 
     def _check_positions_and_values(self, positions_raw, values):  # Lattice.cu:176-181
@@ -484,8 +484,10 @@ class Lattice:
         """dst[row] += sum of the row's contributions (segment-balanced reduce over the CSR adjacency); dst pre-zeroed."""
         _, csr, max_seg, grp_row, _ = self._csr(idx)
         lib = _lib.load()
-        _lib.check(lib.ln_csr_reduce_rows(C.byref(csr), _lib.ptr(grp_row), max_seg, _lib.ptr(src), _lib.ptr(w), val_dim, src_div,
-                                          src_stride, _lib.ptr(dst), self._stream()), "ln_csr_reduce_rows")
+        fn, what = (lib.ln_csr_reduce_rows_f16, "ln_csr_reduce_rows_f16") if src.dtype == torch.float16 else \
+            (lib.ln_csr_reduce_rows, "ln_csr_reduce_rows")
+        _lib.check(fn(C.byref(csr), _lib.ptr(grp_row), max_seg, _lib.ptr(src), _lib.ptr(w), val_dim, src_div, src_stride, _lib.ptr(dst),
+                      self._stream()), what)
 
     def scatter_max(self, src: torch.Tensor, idx: torch.Tensor):
         """Per-vertex maximum of per-token rows src[T, C] with its argmax token (torch_scatter.scatter_max over the
@@ -619,9 +621,10 @@ class Lattice:
         lib = _lib.load()
         nbr = torch.empty((rows_upper, self.get_filter_extent(1)), dtype=torch.int32, device=self._dev())
         t = ht.c_table()
-        _lib.check(lib.ln_splat_accumulate_and_neighbours(C.byref(csr), _lib.ptr(grp_row), max_seg, _lib.ptr(values), _lib.ptr(w), val_dim,
-                                                          src_div, val_dim, _lib.ptr(dst), C.byref(t), rows_upper, _lib.ptr(nbr),
-                                                          self._stream()), "ln_splat_accumulate_and_neighbours")
+        fn, what = (lib.ln_splat_accumulate_and_neighbours_f16, "ln_splat_accumulate_and_neighbours_f16") if values.dtype == torch.float16 \
+            else (lib.ln_splat_accumulate_and_neighbours, "ln_splat_accumulate_and_neighbours")
+        _lib.check(fn(C.byref(csr), _lib.ptr(grp_row), max_seg, _lib.ptr(values), _lib.ptr(w), val_dim, src_div, val_dim, _lib.ptr(dst),
+                      C.byref(t), rows_upper, _lib.ptr(nbr), self._stream()), what)
         st.nbr_cache[("prefetch", id(st), st.version, self.m_lvl)] = (nbr, st)
 
     # ---------------------------------------------------------------- neighbour list (shared)
@@ -884,8 +887,15 @@ class Lattice:
         idx, w = splatting_indices_tensor.contiguous(), splatting_weights_tensor.contiguous()
         n = self._check_slice_inputs(positions_raw, idx, w)
         vals = self.values()
-        out = torch.empty((n, self.val_dim()), dtype=torch.float32, device=self._dev())
         lib = _lib.load()
+        if vals.dtype == torch.float16:  # fp16 feature path: fp16 rows in, fp16 rows out, fp32 arithmetic
+            out = torch.empty((n, self.val_dim()), dtype=torch.float16, device=self._dev())
+            _lib.check(lib.ln_slice_forward_f16(_lib.ptr(vals), _lib.ptr(idx), _lib.ptr(w), n, self.pos_dim(), self.val_dim(), _lib.ptr(out),
+                                                self._stream()), "ln_slice_forward_f16")
+            if grad_accumulator is not None:
+                grad_accumulator.zero_()
+            return out
+        out = torch.empty((n, self.val_dim()), dtype=torch.float32, device=self._dev())
         if grad_accumulator is None:
             _lib.check(lib.ln_slice_forward(_lib.ptr(vals), _lib.ptr(idx), _lib.ptr(w), n, self.pos_dim(), self.val_dim(), _lib.ptr(out),
                                             self._stream()), "ln_slice_forward")
@@ -954,6 +964,8 @@ class Lattice:
         if gv is None or tuple(gv.shape) != (m, v) or gv.dtype != torch.float32 or not gv.is_contiguous():
             gv = torch.zeros((m, v), dtype=torch.float32, device=self._dev())
         self._scatter_rows(grad_sliced_values, idx, w, gv, v, self.pos_dim() + 1, v)
+        if grad_sliced_values.dtype == torch.float16:
+            gv = gv.half()  # fp16 feature path: accumulated in fp32, returned in the gradient's dtype
         self.m_hash_table.m_values_tensor = gv  # result is read back through values() (lattice_funcs.py:507)
 
     def slice_classify_backwards_with_precomputation(self, grad_class_logits, positions_raw, initial_values, delta_weights,

@@ -330,3 +330,45 @@ def test_conv_fp16_feature_path_matches_fp64_reference(v, f):
     close(N(out.float()), ref.detach().numpy(), scale=float(ref.abs().max()), rtol=2e-3)
     close(N(vals.grad.float()), v64.grad.numpy(), scale=float(v64.grad.abs().max()), rtol=2e-3)
     close(N(W.grad.float()), w64.grad.numpy(), scale=float(w64.grad.abs().max()), rtol=2e-3)
+
+
+def test_fp16_feature_path_splat_conv_slice_end_to_end():
+    """C5-style chain on half features: splat of fp16 point features (fp32 table), fp16 convolution, fp16 slice, and the
+    backward pass through all three, against an fp64 evaluation of the same fp16 inputs."""
+    from lattice_net_amd import ConvIm2RowLattice, SliceLattice, SplatLattice
+    from lattice_net_amd.synthetic import cube_cloud
+    n, v, f = 8000, 32, 32
+    pos_np = cube_cloud(n, 41)
+    rng = np.random.default_rng(3)
+    vals = torch.tensor(rng.standard_normal((n, v)), dtype=torch.float16, device=dev())
+    W = torch.tensor(rng.standard_normal((9 * v, f)) / np.sqrt(9 * v), dtype=torch.float16, device=dev(), requires_grad=True)
+    G = torch.tensor(rng.standard_normal((n, f)), dtype=torch.float16, device=dev())
+    lat = make_lattice(0.15, 120000)
+    pos = T(pos_np)
+    lv, wrap, idx, w = SplatLattice.apply(lat, pos, vals)
+    m = lat.nr_lattice_vertices()
+    assert lv.dtype == torch.float32  # accumulated in fp32
+    t, oidx, ow = oracle_table(pos_np, 0.15, 120000)
+    expect = np.zeros((m, v), np.float64)
+    np.add.at(expect, oidx, np.repeat(vals.cpu().double().numpy(), 4, axis=0) * ow[:, None])
+    close(N(lv[:m]), expect, rtol=1e-5)
+    lvh = lv[:m].half().requires_grad_(True)
+    cv, cwrap = ConvIm2RowLattice.apply(lvh, lat, W, 1)
+    out = SliceLattice.apply(cv, cwrap.lattice, pos, idx, w)
+    assert cv.dtype == torch.float16 and out.dtype == torch.float16 and out.shape == (n, f)
+    out.backward(G)
+    assert lvh.grad.dtype == torch.float16 and W.grad.dtype == torch.float16
+    # fp64 reference of conv + slice and their gradients on the same fp16 inputs
+    nbr = torch.from_numpy(O.neighbour_rows(t.keys[:m], t, 1, 1, 1, False).astype(np.int64))
+    v64 = lvh.detach().cpu().double().requires_grad_(True)
+    w64 = W.detach().cpu().double().requires_grad_(True)
+    padded = torch.cat([v64, torch.zeros((1, v), dtype=torch.float64)], 0)
+    rows = padded[torch.where(nbr >= 0, nbr, torch.full_like(nbr, m))].reshape(m, 9 * v)
+    conv_ref = rows @ w64
+    wi = torch.from_numpy(ow.astype(np.float64)).reshape(n, 4, 1)
+    ii = torch.from_numpy(oidx.astype(np.int64)).reshape(n, 4)
+    out_ref = (conv_ref[ii] * wi).sum(1)
+    (out_ref * G.cpu().double()).sum().backward()
+    close(N(out.float()), out_ref.detach().numpy(), scale=float(out_ref.abs().max()), rtol=4e-3)
+    close(N(lvh.grad.float()), v64.grad.numpy(), scale=float(v64.grad.abs().max()), rtol=4e-3)
+    close(N(W.grad.float()), w64.grad.numpy(), scale=float(w64.grad.abs().max()), rtol=4e-3)
