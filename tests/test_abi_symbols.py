@@ -74,3 +74,17 @@ def test_missing_library_fails_loudly(monkeypatch):
 def test_reference_module_alias():
     import latticenet
     assert latticenet.Lattice is lattice_net_amd.Lattice and latticenet.HashTable is lattice_net_amd.HashTable
+
+
+def test_kernel_name_list_matches_the_launch_sites():
+    """ln_kernel_names() is what ln_profile_begin accepts: it must list exactly the names the LN_LAUNCH sites use."""
+    import glob
+    import os
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lattice_net_amd", "csrc")
+    used = set()
+    for path in glob.glob(os.path.join(root, "*.hip")) + glob.glob(os.path.join(root, "*.h")):
+        with open(path) as f:
+            used |= set(re.findall(r'LN_LAUNCH\("([a-z0-9_]+)"', f.read()))
+    listed = set(_lib.load().ln_kernel_names().decode().split(","))
+    assert listed == used, (sorted(used - listed), sorted(listed - used))
