@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--n", type=int, default=0, help="points per cloud (0 = the preset's)")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--infer", action="store_true", help="forward only, under torch.no_grad()")
     ap.add_argument("--host-profile", action="store_true", help="cProfile of the host side of the timed steps")
     ap.add_argument("--gc", type=int, default=0, help="1 = leave Python's cyclic garbage collector on during the timed steps")
     args = ap.parse_args()
@@ -68,6 +69,10 @@ def main():
 
     def step():
         nonlocal opt
+        if args.infer:
+            with torch.no_grad():
+                logsoftmax, _ = net(lattice, pos, vals)
+            return logsoftmax[0, 0]
         logsoftmax, _ = net(lattice, pos, vals)
         loss = nll_loss_gather(logsoftmax, target)
         if opt is None:  # parameters of the PointNet MLP exist only after the first forward (ln_train.py:162-165)
@@ -100,7 +105,7 @@ def main():
         pr.disable()
         pstats.Stats(pr).sort_stats("tottime").print_stats(35)
     nparams = sum(p.numel() for p in net.parameters())
-    print(f"LNN[{args.config}] train step: {dt * 1e3:.2f} ms  ({args.n / dt / 1e6:.2f} Mpoints/s), {nparams} parameters, loss {loss.item():.4f}")
+    print(f"LNN[{args.config}] {'forward' if args.infer else 'train step'}: {dt * 1e3:.2f} ms  ({args.n / dt / 1e6:.2f} Mpoints/s), {nparams} parameters, loss {loss.item():.4f}")
 
 
 if __name__ == "__main__":
