@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""One-off soak: many random (dimension, size, sigma, capacity, value width) builds against the CPU oracle, then a long run of the
+bench step checking that the vertex count and the checksum never change.  Usage: python tools/fuzz_build.py [seeds] [steps]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import lattice_net_amd as L  # noqa: E402
+from lattice_net_amd import synthetic  # noqa: E402
+from oracle import lattice_oracle as O  # noqa: E402  (checker only)
+
+
+def main():
+    seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
+    dev = torch.device("cuda", 0)
+    bad = 0
+    skipped = 0
+    for seed in range(seeds):
+        rng = np.random.default_rng(5000 + seed)
+        d = int(rng.integers(1, 7))
+        n = int(rng.integers(1, 9000))
+        sigma = float(rng.choice([0.03, 0.1, 0.3, 1.0, 3.0]))
+        pos_np = ((rng.random((n, d), dtype=np.float32) - 0.5) * float(rng.choice([0.5, 2.0, 8.0, 40.0]))).astype(np.float32)
+        if rng.random() < 0.2:  # duplicated points / clusters
+            pos_np[n // 2:] = pos_np[: n - n // 2]
+        probe = O.OracleHashTable(n * (d + 1) + 8, d)
+        O.build_splat(probe, O.scale_positions(pos_np, np.full((d,), sigma, np.float32)))
+        cap = int(probe.nr_filled / float(rng.choice([0.05, 0.3, 0.6, 0.85, 0.97]))) + int(rng.integers(1, 900))
+        v = int(rng.choice([1, 2, 4, 8, 12]))
+        vals_np = rng.standard_normal((n, v)).astype(np.float32)
+        lat = L.Lattice(sigmas=[sigma] * d, capacity=cap, device=dev)
+        lat.begin_splat()
+        idx, w = lat.splat_standalone(torch.from_numpy(pos_np).to(dev), torch.from_numpy(vals_np).to(dev))
+        try:
+            m = lat.nr_lattice_vertices()
+        except L._lib.LatticeNetHipError as e:  # documented limit of the packed key format: reported, never silent
+            assert "packed" in str(e), e
+            skipped += 1
+            continue
+        t = O.OracleHashTable(cap, d)
+        oidx, ow = O.build_splat(t, O.scale_positions(pos_np, np.full((d,), sigma, np.float32)))
+        expect = np.zeros((t.nr_filled, v), np.float32)
+        O.splat_accumulate(expect, vals_np, oidx, ow)
+        ok = (m == t.nr_filled and np.array_equal(idx.cpu().numpy(), oidx) and np.array_equal(w.cpu().numpy(), ow)
+              and np.array_equal(lat.hash_table().m_keys_tensor[:m].cpu().numpy(), t.keys[:m])
+              and np.allclose(lat.values()[:m].cpu().numpy(), expect, rtol=1e-4, atol=1e-4 * max(float(np.abs(expect).max()), 1e-30)))
+        if not ok:
+            bad += 1
+            print(f"MISMATCH seed={seed} d={d} n={n} sigma={sigma} cap={cap} v={v} m={m} oracle_m={t.nr_filled}")
+    print(f"fuzz: {seeds} configurations, {skipped} outside the packed-key range (reported as errors), {bad} mismatches")
+
+    n, v, f = 120000, 32, 32
+    rng = np.random.default_rng(0)
+    pos = torch.from_numpy(synthetic.lidar_cloud(n, 0)).to(dev)
+    vals = torch.from_numpy(rng.standard_normal((n, v)).astype(np.float32)).to(dev)
+    G = torch.from_numpy(rng.standard_normal((n, f)).astype(np.float32)).to(dev)
+    W = (torch.rand((9 * v, f), device=dev) - 0.5).requires_grad_(True)
+    lat = L.Lattice(sigmas=[0.9] * 3, capacity=100000, device=dev)
+    torch.autograd.set_multithreading_enabled(False)
+    ref = None
+    drift = 0
+    for k in range(steps):
+        W.grad = None
+        lv, wrap, idx, w = L.SplatLattice.apply(lat, pos, vals)
+        m = lat.nr_lattice_vertices()
+        lv = lv[:m].requires_grad_(True)
+        cv, cwrap = L.ConvIm2RowLattice.apply(lv, lat, W, 1)
+        out = L.SliceLattice.apply(cv, cwrap.lattice, pos, idx, w)
+        out.backward(G)
+        if k % 250 == 0 or k == steps - 1:
+            sig = (m, int(idx.sum().item()), round(float(out.double().abs().sum().item()), 1), round(float(W.grad.double().abs().sum().item()), 1))
+            if ref is None:
+                ref = sig
+            elif sig[:2] != ref[:2] or abs(sig[2] - ref[2]) > 1e-4 * abs(ref[2]) or abs(sig[3] - ref[3]) > 1e-4 * abs(ref[3]):
+                drift += 1
+                print("DRIFT at step", k, sig, ref)
+    print(f"soak: {steps} steps, signature {ref}, {drift} drifts")
+    sys.exit(1 if (bad or drift) else 0)
+
+
+if __name__ == "__main__":
+    main()
