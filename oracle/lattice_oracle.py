@@ -14,6 +14,13 @@ golden vectors in ``tests/golden/*.npz`` that were produced by running the refer
 kernel source serially on the host (``oracle/ref_shim`` + ``tests/golden/make_goldens.py``).
 The reference ships no tests or known-answer vectors of its own.
 
+Strength of that pin, stated plainly: the reference itself (CUDA + jitify + EasyPBR) cannot be built
+or run here, so no output of an actual reference run exists.  The goldens come from the reference's two
+kernel headers compiled as serial host C++ behind a qualifier shim (SURVEY.md §8c's recipe); the shim
+restates no arithmetic but it IS a stand-in for the CUDA toolchain.  Read strictly, that makes this
+oracle "parity unpinned" against a real reference run; what is pinned is every arithmetic source line of
+the reference's kernels, executed in IEEE fp32, in serial thread order.
+
 Canonical vertex numbering: rows are numbered by first occurrence in (point, remainder)
 order — what a serial run of HG:425-484 produces (the CUDA run numbers by thread arrival
 order, HG:454, and is not reproducible).
