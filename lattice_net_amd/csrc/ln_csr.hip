@@ -16,6 +16,7 @@
 #include "ln_neighbours.h"
 
 #define LN_SCAN_BLOCK 1024
+#define LN_CSR_LDS_SCAN_BLOCKS 512  // up to this many row blocks (512k rows) the top-level scan is redone in LDS by every workgroup
 #define LN_SEG LN_CSR_SEG
 
 __global__ void __launch_bounds__(256)
@@ -90,29 +91,66 @@ __device__ __forceinline__ void ln_block_excl_scan_to_lds(const int* __restrict_
     __syncthreads();
 }
 
+// Tables beyond LN_CSR_LDS_SCAN_BLOCKS row blocks (8M+ slots): one workgroup turns the per-block totals into exclusive
+// offsets in place (block_tot[2b], block_tot[2b+1]; the grand totals go to block_tot[2nb], block_tot[2nb+1]) and
+// k_csr_fill<true> reads them from global memory instead of re-scanning them into LDS in every workgroup.
+__global__ void __launch_bounds__(256) k_csr_scan_top(int* __restrict__ block_tot, int nb) {
+    __shared__ int s_part[8];
+    const int tid = threadIdx.x;
+    const int per = (nb + 255) / 256;
+    const int b = tid * per;
+    for (int which = 0; which < 2; ++which) {
+        int sum = 0;
+        for (int k = 0; k < per; ++k)
+            if (b + k < nb) sum += block_tot[2 * (size_t)(b + k) + which];
+        int total;
+        int run = ln_block_excl_scan_256(sum, s_part, &total);
+        for (int k = 0; k < per; ++k)
+            if (b + k < nb) {
+                const int v = block_tot[2 * (size_t)(b + k) + which];
+                block_tot[2 * (size_t)(b + k) + which] = run;
+                run += v;
+            }
+        if (tid == 0) block_tot[2 * (size_t)nb + which] = total;
+        __syncthreads();
+    }
+}
+
+template <bool GLOBAL_OFFSETS>
 __global__ void __launch_bounds__(256)
     k_csr_fill(const int* __restrict__ idx, const int* __restrict__ pos, long long tokens, int rows_upper,
                const int* __restrict__ local_tok, const int* __restrict__ local_seg, const int* __restrict__ block_tot, int nb,
                int* __restrict__ row_start, int* __restrict__ csr_tok, int* __restrict__ seg_row, int* __restrict__ seg_beg,
                int* __restrict__ seg_count) {
     extern __shared__ int s_fill[];  // off_tok[nb+1] | off_seg[nb+1] | part[256]
-    int* off_tok = s_fill;
-    int* off_seg = s_fill + (nb + 1);
-    int* part = s_fill + 2 * (nb + 1);
-    ln_block_excl_scan_to_lds(block_tot, 2, nb, off_tok, part);
-    ln_block_excl_scan_to_lds(block_tot + 1, 2, nb, off_seg, part);
+    const int* off_tok;
+    const int* off_seg;
+    int seg_stride = 1;
+    if constexpr (GLOBAL_OFFSETS) {
+        off_tok = block_tot;
+        off_seg = block_tot + 1;
+        seg_stride = 2;
+    } else {
+        int* lt = s_fill;
+        int* ls = s_fill + (nb + 1);
+        int* part = s_fill + 2 * (nb + 1);
+        ln_block_excl_scan_to_lds(block_tot, 2, nb, lt, part);
+        ln_block_excl_scan_to_lds(block_tot + 1, 2, nb, ls, part);
+        off_tok = lt;
+        off_seg = ls;
+    }
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t == 0) *seg_count = off_seg[nb];
-    if (t <= rows_upper) row_start[t] = (t < rows_upper) ? local_tok[t] + off_tok[t / LN_SCAN_BLOCK] : off_tok[nb];
+    if (t == 0) *seg_count = off_seg[(size_t)nb * seg_stride];
+    if (t <= rows_upper) row_start[t] = (t < rows_upper) ? local_tok[t] + off_tok[(size_t)(t / LN_SCAN_BLOCK) * seg_stride] : off_tok[(size_t)nb * seg_stride];
     if (t < tokens) {
         const int p = pos[t];
         if (p >= 0) {
             const int row = idx[t];
             const int blk = row / LN_SCAN_BLOCK;
-            const int rbeg = local_tok[row] + off_tok[blk];
+            const int rbeg = local_tok[row] + off_tok[(size_t)blk * seg_stride];
             csr_tok[rbeg + p] = int(t);
             if (p % LN_SEG == 0) {  // this token opens a segment
-                const int sid = local_seg[row] + off_seg[blk] + p / LN_SEG;
+                const int sid = local_seg[row] + off_seg[(size_t)blk * seg_stride] + p / LN_SEG;
                 seg_row[sid] = row;
                 seg_beg[sid] = rbeg + p;
             }
@@ -131,7 +169,7 @@ extern "C" long long ln_csr_max_segments(long long tokens, int groups_upper) {
 size_t ln_csr_scan_workspace_bytes(int groups_upper) {
     if (groups_upper < 1) groups_upper = 1;
     const size_t nb = (size_t)ln_div_up(groups_upper, LN_SCAN_BLOCK);
-    return ln_align256c((size_t)groups_upper * 4) * 2 + ln_align256c(nb * 8);
+    return ln_align256c((size_t)groups_upper * 4) * 2 + ln_align256c((nb + 1) * 8);
 }
 
 int ln_csr_from_counts(const int* tok_grp, const int* tok_pos, long long tokens, const int* grp_cnt, int groups_upper,
@@ -144,12 +182,18 @@ int ln_csr_from_counts(const int* tok_grp, const int* tok_pos, long long tokens,
     int* local_seg = reinterpret_cast<int*>(p);
     p += ln_align256c((size_t)groups_upper * 4);
     int* block_tot = reinterpret_cast<int*>(p);
-    const size_t lds = (size_t)(2 * (nb + 1) + 256) * sizeof(int);
-    LN_REQUIRE(lds <= 64 * 1024, LN_ERR_UNSUPPORTED, "capacity %d too large for the in-LDS top-level scan", groups_upper);
     LN_LAUNCH("k_csr_scan_local", k_csr_scan_local, dim3(nb), dim3(LN_SCAN_BLOCK), 0, st, grp_cnt, groups_upper, local_tok, local_seg, block_tot);
     const long long work = (tokens > groups_upper + 1) ? tokens : (long long)groups_upper + 1;
-    LN_LAUNCH("k_csr_fill", k_csr_fill, dim3(ln_div_up(work, 256)), dim3(256), lds, st, tok_grp, tok_pos, tokens, groups_upper, local_tok, local_seg,
-              block_tot, nb, csr.grp_start, csr.csr_tok, csr.seg_grp, csr.seg_beg, csr.seg_count);
+    if (nb <= LN_CSR_LDS_SCAN_BLOCKS) {
+        // every workgroup re-scans the (few) block totals into LDS: cheaper than one more launch
+        const size_t lds = (size_t)(2 * (nb + 1) + 256) * sizeof(int);
+        LN_LAUNCH("k_csr_fill", k_csr_fill<false>, dim3(ln_div_up(work, 256)), dim3(256), lds, st, tok_grp, tok_pos, tokens, groups_upper, local_tok,
+                  local_seg, block_tot, nb, csr.grp_start, csr.csr_tok, csr.seg_grp, csr.seg_beg, csr.seg_count);
+    } else {
+        LN_LAUNCH("k_csr_scan_top", k_csr_scan_top, dim3(1), dim3(256), 0, st, block_tot, nb);
+        LN_LAUNCH("k_csr_fill", k_csr_fill<true>, dim3(ln_div_up(work, 256)), dim3(256), 0, st, tok_grp, tok_pos, tokens, groups_upper, local_tok,
+                  local_seg, block_tot, nb, csr.grp_start, csr.csr_tok, csr.seg_grp, csr.seg_beg, csr.seg_count);
+    }
     return ln_check_launch("ln_csr_from_counts");
 }
 

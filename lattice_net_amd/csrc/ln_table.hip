@@ -73,7 +73,7 @@ LnProfScope::~LnProfScope() {
     }
 }
 
-extern "C" const char* ln_kernel_names(void) { return "k_bucket_build,k_conv_generic,k_conv_generic_f16,k_conv_mfma,k_conv_mfma_f16,k_csr_count,k_csr_fill,k_csr_group_sizes,k_csr_reduce_segments,k_csr_scan_local,k_csr_segment_max,k_csr_segment_max_decode,k_finalize,k_gather_backward,k_gather_forward,k_gn_apply,k_gn_backward_apply,k_gn_stats,k_grad_filter_f16,k_grad_filter_generic,k_grad_filter_mfma,k_grad_filter_mfma_f16,k_im2row,k_im2rowindices,k_insert_coarse,k_insert_points,k_linear_act_backward_w,k_linear_act_backward_x,k_linear_act_forward,k_linear_reduce_slabs,k_mark_first,k_neighbours,k_point_keys,k_reduce_and_neighbours,k_reduce_slabs,k_reduce_slabs_f32,k_retrieve_points,k_row2im,k_sc_reduce_slabs,k_sc_scatter_atomic,k_scan_blocks,k_scatter_point_rows,k_seg_min,k_slice_classify_backward,k_slice_classify_forward,k_slice_forward,k_slice_forward_f16,k_table_clear"; }
+extern "C" const char* ln_kernel_names(void) { return "k_bucket_build,k_conv_generic,k_conv_generic_f16,k_conv_mfma,k_conv_mfma_f16,k_csr_count,k_csr_fill,k_csr_group_sizes,k_csr_reduce_segments,k_csr_scan_local,k_csr_scan_top,k_csr_segment_max,k_csr_segment_max_decode,k_finalize,k_gather_backward,k_gather_forward,k_gn_apply,k_gn_backward_apply,k_gn_stats,k_grad_filter_f16,k_grad_filter_generic,k_grad_filter_mfma,k_grad_filter_mfma_f16,k_im2row,k_im2rowindices,k_insert_coarse,k_insert_points,k_linear_act_backward_w,k_linear_act_backward_x,k_linear_act_forward,k_linear_reduce_slabs,k_mark_first,k_neighbours,k_point_keys,k_reduce_and_neighbours,k_reduce_slabs,k_reduce_slabs_f32,k_retrieve_points,k_row2im,k_sc_reduce_slabs,k_sc_scatter_atomic,k_scan_blocks,k_scatter_point_rows,k_seg_min,k_slice_classify_backward,k_slice_classify_forward,k_slice_forward,k_slice_forward_f16,k_table_clear"; }
 
 extern "C" int ln_profile_begin(const char* kernel_name, int max_samples) {
     LN_REQUIRE(kernel_name && strlen(kernel_name) < sizeof(g_prof.name) && max_samples > 0, LN_ERR_ARG, "ln_profile_begin: bad args");
@@ -373,6 +373,7 @@ __global__ void __launch_bounds__(256)
 
 // Pass 2: one workgroup per bucket.  LDS: keys[sb] | count[sb] | min token[sb] | token offset[sb] | segment offset[sb].
 #define LN_BKT_THREADS 1024
+#define LN_BKT_LDS_LIMIT (150 * 1024)  // dynamic LDS one k_bucket_build workgroup may ask for (160 KB per CU minus its static arrays)
 #define LN_BKT_REG_TOK 4  // tokens per thread whose (token, slot, position) stay in registers between the two sweeps
 template <int D>
 __global__ void __launch_bounds__(LN_BKT_THREADS)
@@ -878,8 +879,11 @@ static int ln_build_points(const LnTable* t, const float* positions_raw, const f
     }
     // The bucketed path needs a table it knows to be empty: it is taken when the clear rides in this call, and then does
     // the clearing itself (no k_table_clear launch).  Its cursors use the first nbk+1 words of slot_cnt.
+    // Beyond LN_BKT_MAX buckets the buckets grow instead; one bucket's staging area has to fit the 160 KB of LDS of a gfx950 CU
+    // (tables past ~14M slots take the atomic path).
+    const size_t bucket_lds = (size_t)ln_bucket_slots(t->capacity) * (sizeof(unsigned long long) + 4 * sizeof(int));
     const bool bucketed = n > 0 && (flags & LN_BUILD_CLEAR_FIRST) && !(flags & LN_BUILD_ATOMIC_PATH) &&
-                          t->capacity > ln_bucket_count(t->capacity);
+                          t->capacity > ln_bucket_count(t->capacity) && bucket_lds <= LN_BKT_LDS_LIMIT;
     LN_REQUIRE(clear_values == nullptr || (reinterpret_cast<uintptr_t>(clear_values) & 15) == 0, LN_ERR_ARG, "%s: clear_values must be 16-byte aligned", who);
     if ((flags & LN_BUILD_CLEAR_FIRST) && !bucketed) {
         rc = ln_table_clear(t, clear_values, clear_values_elems, stream);
@@ -893,7 +897,7 @@ static int ln_build_points(const LnTable* t, const float* positions_raw, const f
         if (bucketed) {
             const int sb = ln_bucket_slots(t->capacity);
             const int nbk = ln_bucket_count(t->capacity);
-            const size_t lds = (size_t)sb * (sizeof(unsigned long long) + 4 * sizeof(int));
+            const size_t lds = bucket_lds;
             LN_LAUNCH("k_point_keys", k_point_keys<D>, dim3(ln_div_up(n, LN_KEYS_PTS_PER_BLOCK)), dim3(256), 0, st, *t, positions_raw, sc, n, sb,
                       nbk, ws.capb, ws.part_tok, ws.part_pk, tok_slot, write_idx ? w : (float*)nullptr, vals, val_dim, distributed,
                       csr->seg_count, clear_values, clear_values_elems, ws.bitmap, (long long)ws.nb * 4);

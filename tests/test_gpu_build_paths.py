@@ -209,3 +209,21 @@ def test_random_configurations_against_the_oracle(seed, monkeypatch):
     O.splat_accumulate(expect, vals_np, oidx, ow)
     np.testing.assert_allclose(N(lat.values()[:m]), expect, rtol=1e-5, atol=1e-5 * max(float(np.abs(expect).max()), 1e-30))
     np.testing.assert_array_equal(N(lat.neighbours(None, 1, False)), O.neighbour_rows(t.keys[:m], t, 1, 1, 1, False))
+
+
+@pytest.mark.parametrize("cap,atomic", [(9_000_000, True), (9_000_000, False), (16_500_000, False)])
+def test_very_large_tables_number_rows_like_a_small_one(cap, atomic, monkeypatch):
+    """Row numbering (first occurrence in point order), weights and keys do not depend on the capacity, so a 9M / 16.5M-slot
+    table must reproduce the 200k-slot build bit for bit.  9M slots on the atomic path takes the CSR offsets from the
+    single-workgroup top-level scan (k_csr_scan_top); 16.5M slots is past what one bucket can stage in LDS, so the
+    library takes the atomic path by itself."""
+    rng = np.random.default_rng(77)
+    pos_np = ((rng.random((40000, 3), dtype=np.float32) - 0.5) * 6).astype(np.float32)
+    vals_np = rng.standard_normal((40000, 4)).astype(np.float32)
+    small, si, sw, sm, _ = build(pos_np, 0.2, 200000, False, monkeypatch, vals_np)
+    big, bi, bw, bm, _ = build(pos_np, 0.2, cap, atomic, monkeypatch, vals_np)
+    assert bm == sm and sm > 20000
+    assert torch.equal(bi, si) and torch.equal(bw, sw)
+    assert torch.equal(big.hash_table().m_keys_tensor[:bm], small.hash_table().m_keys_tensor[:sm])
+    np.testing.assert_allclose(N(big.values()[:bm]), N(small.values()[:sm]), rtol=1e-5, atol=1e-5)
+    assert torch.equal(big.neighbours(None, 1, False), small.neighbours(None, 1, False))
