@@ -1027,7 +1027,9 @@ class Lattice:
         return self.m_hash_table.val_dim()
 
     def pos_dim(self) -> int:
-        return self.m_hash_table.pos_dim()
+        d = self.m_hash_table.pos_dim()
+        # before the first build the table has no buffers yet; the sigmas already say how many dimensions it will have
+        return d if d >= 0 else len(self.m_sigmas)
 
     def capacity(self) -> int:
         return self.m_hash_table.capacity()

@@ -101,3 +101,11 @@ def test_synthetic_clouds_are_seeded_and_shaped():
     assert np.hypot(a[:, 0], a[:, 1]).max() <= 60.0 + 1e-3
     assert not np.array_equal(a, synthetic.lidar_cloud(1000, 4))
     assert synthetic.planes_cloud(500, 1).shape == (500, 3) and synthetic.box_surface_cloud(500, 1).shape == (500, 3)
+
+
+def test_filter_extent_is_known_before_the_first_build():
+    # models size their filter banks before any cloud has been splatted (lattice_modules.py:187 uses the static variant)
+    lat = Lattice(sigmas=[0.5] * 3, capacity=100)
+    assert lat.pos_dim() == 3 and lat.get_filter_extent(1) == 9
+    assert Lattice(sigmas=[0.1] * 5, capacity=100).get_filter_extent(1) == 13
+    assert Lattice.get_expected_filter_extent(1) == 13  # the static follows the last set_sigmas (Lattice.cu:44)
