@@ -212,9 +212,13 @@ def main():
     world, rank, local_rank = sharding.env_world()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the lattice backend has no CPU path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = sharding.init("nccl", dev)  # RCCL over xGMI; None for a single rank
+    # LATTICE_BENCH_SHARE_GPU=1 (testing aid for a one-GPU box): every rank runs on GPU 0 and the ranks talk over gloo,
+    # so the multi-rank control flow can be exercised with real kernels; never a measurement
+    share_gpu = bool(os.environ.get("LATTICE_BENCH_SHARE_GPU"))
+    dev_index = 0 if share_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    dist = sharding.init("gloo" if share_gpu else "nccl", dev)  # RCCL over xGMI; None for a single rank
     if args.gpus != world and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world} rank(s)", file=sys.stderr)
 
