@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--capacity", type=int, default=100000)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--scale", type=float, default=1.0, help="cube half-extent")
+    ap.add_argument("--scan-order", action="store_true",
+                    help="sort the points by azimuth, then range (a spinning sensor's order) instead of the i.i.d. order of the generator")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     lib = L.load_library()
@@ -32,6 +34,10 @@ def main():
         pos_np = synthetic.lidar_cloud(n, 0)
     else:
         pos_np = synthetic.cube_cloud(n, 0, -args.scale, args.scale)
+    if args.scan_order:
+        az = np.arctan2(pos_np[:, 1], pos_np[:, 0])
+        order = np.lexsort((np.hypot(pos_np[:, 0], pos_np[:, 1]), np.round(az / (2 * np.pi / 2048))))  # 2048 azimuth columns
+        pos_np = np.ascontiguousarray(pos_np[order])
     rng = np.random.default_rng(0)
     pos = torch.from_numpy(pos_np).to(dev)
     vals = torch.from_numpy(rng.standard_normal((n, v)).astype(np.float32)).to(dev)
