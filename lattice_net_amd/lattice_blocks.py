@@ -261,6 +261,16 @@ class GnReluConv(_PreConv):  # mods:935-960
         super().__init__(in_channels, out_channels, dilation, bias, with_dropout, "gn", "relu", False, device)
 
 
+class GnReluDepthwiseConv(torch.nn.Module):  # mods:880-905
+    """Present for name compatibility only: the reference's block builds on `DepthwiseConvLatticeModule`, which the
+    reference never defines (every use, mods:1233-1310, is commented out) — constructing it there raises NameError."""
+
+    def __init__(self, nr_filters, dilation, bias, with_dropout):
+        super().__init__()
+        raise NotImplementedError("GnReluDepthwiseConv needs DepthwiseConvLatticeModule, which the reference does not define "
+                                  "(lattice_modules.py:884); use GnReluConv")
+
+
 class GnGeluConv(_PreConv):  # mods:962-986
     def __init__(self, in_channels, out_channels, dilation, bias, with_dropout, device="cuda"):
         super().__init__(in_channels, out_channels, dilation, bias, with_dropout, "gn", "gelu", False, device)
