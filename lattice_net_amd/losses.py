@@ -11,7 +11,7 @@ from __future__ import annotations
 
 import torch
 
-__all__ = ["LovaszSoftmax", "Scores", "nll_loss_gather"]
+__all__ = ["GeneralizedSoftDiceLoss", "LovaszSoftmax", "Scores", "nll_loss_gather"]
 
 
 def nll_loss_gather(log_probs: torch.Tensor, target: torch.Tensor, ignore_index=None) -> torch.Tensor:
@@ -23,6 +23,33 @@ def nll_loss_gather(log_probs: torch.Tensor, target: torch.Tensor, ignore_index=
         return -picked.mean()
     keep = (target != ignore_index).to(picked.dtype)
     return -(picked * keep).sum() / keep.sum().clamp(min=1)
+
+
+class GeneralizedSoftDiceLoss(torch.nn.Module):
+    """The alternative to Lovasz-Softmax that ln_train.py:127 keeps at hand (reference latticenet_py/lattice/diceloss.py:172-209):
+    with p = exp(log_probs) [N, C] and labels [N], per class  dice_c = 2 sum_i p_ic [y_i = c] / (sum_i p_ic + #{y_i = c} + 1e-6);
+    loss = sum_c w_c (1 - dice_c) / C with w = 1 except w[ignore_index] = 0 (the division keeps all C classes, as there).
+    No one-hot matrix is built: the intersection is a gather + index_add over the labels."""
+
+    def __init__(self, p=1, smooth=1, reduction="mean", weight=1, ignore_index=None):
+        super().__init__()
+        self.p, self.smooth, self.reduction = p, smooth, reduction  # accepted and unused, as in the reference
+        self.ignore_index = ignore_index
+
+    def forward(self, output: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+        nr_classes = output.shape[1]
+        probs = output.exp()
+        target = target.reshape(-1)
+        picked = probs.gather(1, target.unsqueeze(1)).squeeze(1)
+        intersection = torch.zeros(nr_classes, dtype=probs.dtype, device=probs.device).index_add_(0, target, picked)
+        counts = torch.zeros(nr_classes, dtype=probs.dtype, device=probs.device).index_add_(0, target, torch.ones_like(picked))
+        union = probs.sum(0) + counts
+        loss_per_class = 1.0 - 2.0 * intersection / (union + 1e-6)
+        if self.ignore_index is not None:
+            weight = torch.ones(nr_classes, dtype=probs.dtype, device=probs.device)
+            weight[self.ignore_index] = 0
+            loss_per_class = loss_per_class * weight
+        return loss_per_class.sum() / nr_classes
 
 
 class LovaszSoftmax(torch.nn.Module):

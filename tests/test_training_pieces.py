@@ -107,3 +107,25 @@ def test_nll_loss_gather_matches_torch_nll_loss():
     for ignore in (None, 0, 3):
         ref = torch.nn.functional.nll_loss(logp, target, ignore_index=-100 if ignore is None else ignore)
         assert torch.allclose(nll_loss_gather(logp, target, ignore), ref, atol=1e-12)
+
+
+def test_generalized_soft_dice_loss_matches_the_one_hot_formula():
+    from lattice_net_amd.losses import GeneralizedSoftDiceLoss
+    rng = np.random.default_rng(5)
+    n, c = 400, 7
+    logp = torch.log_softmax(torch.from_numpy(rng.standard_normal((n, c))).double(), 1).requires_grad_(True)
+    target = torch.from_numpy(rng.integers(0, c, n))
+    loss = GeneralizedSoftDiceLoss(ignore_index=0)(logp, target)
+    # diceloss.py:172-209 spelled out with the one-hot matrix
+    p = logp.detach().exp()
+    onehot = torch.zeros((n, c), dtype=torch.float64)
+    onehot[torch.arange(n), target] = 1
+    dice = 2 * (p * onehot).sum(0) / ((p + onehot).sum(0) + 1e-6)
+    w = torch.ones(c, dtype=torch.float64)
+    w[0] = 0
+    expect = (w * (1 - dice)).sum() / c
+    assert abs(float(loss) - float(expect)) < 1e-12
+    loss.backward()
+    assert torch.isfinite(logp.grad).all() and float(logp.grad.abs().sum()) > 0
+    perfect = torch.log(onehot.clamp(min=1e-12))
+    assert float(GeneralizedSoftDiceLoss(ignore_index=0)(perfect, target)) < 1e-5
