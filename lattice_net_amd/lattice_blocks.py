@@ -20,7 +20,7 @@ from .lattice_modules import CoarsenLatticeModule, ConvLatticeIm2RowModule, Fine
 __all__ = ["DropoutLattice", "BatchNormLatticeModule", "GroupNormLatticeModule", "Conv1x1", "GnRelu1x1", "GnGelu1x1", "Gn", "ConvAct",
            "GnReluConv", "GnGeluConv", "BnReluConv", "CoarsenAct", "GnCoarsen", "GnReluCoarsen", "GnGeluCoarsen", "FinefyAct", "GnFinefy",
            "GnReluFinefy", "GnGeluFinefy", "ResnetBlock", "BottleneckBlock", "SliceFastCUDALatticeModule", "Conv1x1WN", "Conv1x1WNAct",
-           "TwoConv", "ResnetBlock2", "DensenetBlock"]
+           "TwoConv", "ResnetBlock2", "DensenetBlock", "GnReluDepthwiseConv"]
 
 
 def _require_2d(lv: torch.Tensor):

@@ -88,3 +88,25 @@ def test_kernel_name_list_matches_the_launch_sites():
             used |= set(re.findall(r'LN_LAUNCH\("([a-z0-9_]+)"', f.read()))
     listed = set(_lib.load().ln_kernel_names().decode().split(","))
     assert listed == used, (sorted(used - listed), sorted(listed - used))
+
+
+def test_reference_python_package_aliases():
+    """Code written against the reference's Python layout imports from latticenet_py.lattice.* / latticenet_py.callbacks.scores;
+    every class and Function named there must resolve to this backend."""
+    import importlib
+    mods = importlib.import_module("latticenet_py.lattice.lattice_modules")
+    for name in """DropoutLattice SplatLatticeModule DistributeLatticeModule ExpandLatticeModule ConvLatticeModule ConvLatticeIm2RowModule
+                   CoarsenLatticeModule FinefyLatticeModule SliceLatticeModule GatherLatticeModule SliceFastCUDALatticeModule
+                   BatchNormLatticeModule GroupNormLatticeModule PointNetModule Conv1x1WN Conv1x1WNAct Conv1x1 GnRelu1x1 GnGelu1x1 Gn
+                   GnReluDepthwiseConv ConvAct GnReluConv GnGeluConv BnReluConv CoarsenAct GnCoarsen GnReluCoarsen GnGeluCoarsen FinefyAct
+                   GnReluFinefy GnGeluFinefy GnFinefy TwoConv ResnetBlock ResnetBlock2 BottleneckBlock DensenetBlock""".split():
+        assert hasattr(mods, name), f"latticenet_py.lattice.lattice_modules.{name} missing"
+    funcs = importlib.import_module("latticenet_py.lattice.lattice_funcs")
+    for name in """SplatLattice DistributeLattice ExpandLattice Im2RowIndicesLattice Im2RowLattice ConvIm2RowLattice CoarsenLattice
+                   FinefyLattice SliceLattice SliceClassifyLattice GatherLattice""".split():
+        assert hasattr(funcs, name), f"latticenet_py.lattice.lattice_funcs.{name} missing"
+    from latticenet_py.callbacks.scores import Scores  # noqa: F401
+    from latticenet_py.lattice.diceloss import GeneralizedSoftDiceLoss  # noqa: F401
+    from latticenet_py.lattice.lattice_wrapper import LatticeWrapper  # noqa: F401
+    from latticenet_py.lattice.lovasz_loss import LovaszSoftmax  # noqa: F401
+    from latticenet_py.lattice.models import LNN, prepare_cloud  # noqa: F401
