@@ -1,5 +1,8 @@
+#!/usr/bin/env python3
+"""Large-size checks on the GPU box: multi-million-point clouds and tables up to 16M slots through both build paths (which
+must agree bit for bit), a centre-only identity convolution and the slice of a constant field.  Usage: python tools/big_sizes.py"""
 import os, sys, time
-import numpy as np, torch
+import torch
 sys.path.insert(0, os.getcwd())
 import lattice_net_amd as L
 from lattice_net_amd import lattice as LM
