@@ -46,6 +46,9 @@ struct LnProfScope {
 // A lattice key (first d coordinates, int32) is packed into one 64-bit word so that a slot can
 // be claimed and its key published by a single 64-bit CAS.  bits per coordinate = min(32, 63/d);
 // d*bits <= 63 for d >= 2 keeps bit 63 clear, so a packed key can never equal LN_EMPTY_KEY.
+// (Storing the remainder mod d+1 that the coordinates of a lattice point share, plus the quotients, would stretch the range
+// by d+1 — but `coarsen` halves fine keys (LatticeGPU.cuh:2376-2400), and half of a remainder-2 point such as (2,2,-2,-2)
+// is an integer tuple with mixed remainders that the reference does insert: the raw format is the one that holds them.)
 template <int D>
 struct KeyPack {
     static constexpr int BITS = (63 / D) > 32 ? 32 : (63 / D);
