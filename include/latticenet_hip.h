@@ -303,6 +303,20 @@ int ln_group_norm_backward(const float* x, const float* grad_y, const float* gam
                            int channels, int groups, int relu, float* grad_x, float* grad_gamma, float* grad_beta, void* workspace,
                            size_t workspace_bytes, void* next_workspace, size_t next_workspace_bytes, void* stream);
 
+/* ---- max-centring of the gathered simplex rows in the DeformSlice head ------------------------------------------
+ * Replaces the torch broadcasting at lattice_modules.py:525-529 (`rowified -= gamma * max_vals + beta`, max over the
+ * d+1 vertices of a simplex) and its autograd backward, whose two reductions over the N points dominate it.
+ * x, out, grad_out, grad_x: [n, k, c] (k = d+1 <= 8 vertex rows of c <= 64 values per point); gamma, beta: [c].
+ * Forward also emits max_vals [n, c] and arg_max [n, c] (u8, first maximum) for the backward pass.
+ * Backward: grad_x = grad_out - [k == arg_max] * gamma * sum_k grad_out;  grad_gamma_beta [2, c]: row 0 =
+ * -sum_n s*max, row 1 = -sum_n s with s = sum_k grad_out (summed in a fixed order: deterministic). */
+int ln_max_centre_forward(const float* x, const float* gamma, const float* beta, long long n, int k, int c, float* out,
+                          float* max_vals, unsigned char* arg_max, void* stream);
+size_t ln_max_centre_backward_workspace_bytes(long long n, int k, int c);
+int ln_max_centre_backward(const float* grad_out, const float* max_vals, const unsigned char* arg_max, const float* gamma,
+                           long long n, int k, int c, float* grad_x, float* grad_gamma_beta, void* workspace,
+                           size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -107,6 +107,9 @@ SIGNATURES = {
     "ln_linear_act_forward": (_i, [_vp, _vp, _vp, _ll, _i, _i, C.c_float, _vp, _vp]),
     "ln_linear_act_backward_workspace_bytes": (_sz, [_i, _i]),
     "ln_linear_act_backward": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _i, C.c_float, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ln_max_centre_forward": (_i, [_vp, _vp, _vp, _ll, _i, _i, _vp, _vp, _vp, _vp]),
+    "ln_max_centre_backward_workspace_bytes": (_sz, [_ll, _i, _i]),
+    "ln_max_centre_backward": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "ln_group_norm_workspace_bytes": (_sz, [_i]),
     "ln_group_norm_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, C.c_float, _i, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),
     "ln_group_norm_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 OUT = os.path.join(PKG, "liblatticenet_hip.so")
 OBJ_DIR = os.path.join(ROOT, "build", "obj")
-SOURCES = ["ln_table.hip", "ln_rows.hip", "ln_conv.hip", "ln_csr.hip", "ln_norm.hip", "ln_conv_f16.hip", "ln_mlp.hip"]
+SOURCES = ["ln_table.hip", "ln_rows.hip", "ln_conv.hip", "ln_csr.hip", "ln_norm.hip", "ln_conv_f16.hip", "ln_mlp.hip", "ln_centre.hip"]
 HEADERS = [os.path.join(CSRC, h) for h in ("ln_common.h", "ln_simplex.h", "ln_csr.h")] + [os.path.join(ROOT, "include", "latticenet_hip.h")]
 # -ffp-contract=off: lattice keys and barycentric weights must be bit-identical to the oracle
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"),

@@ -118,6 +118,46 @@ class GroupNormReluFunction(torch.autograd.Function):
         return grad_x, grad_w, grad_b, None, None, None
 
 
+class MaxCentreFunction(torch.autograd.Function):
+    """x [N, K, C] -> x - (gamma * max_k x + beta) on the kernels of csrc/ln_centre.hip: the max-centring of the gathered
+    simplex rows in the DeformSlice head (mods:525-529).  The gradients of gamma and beta are sums over all N points."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta):
+        lib = _lib.load()
+        x = x.contiguous()
+        n, k, c = x.shape
+        out = torch.empty_like(x)
+        max_vals = torch.empty((n, c), dtype=torch.float32, device=x.device)
+        arg_max = torch.empty((n, c), dtype=torch.uint8, device=x.device)
+        gamma, beta = gamma.contiguous(), beta.contiguous()
+        _lib.check(lib.ln_max_centre_forward(_lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta), n, k, c, _lib.ptr(out), _lib.ptr(max_vals),
+                                             _lib.ptr(arg_max), _lib.stream_ptr(x.device)), "ln_max_centre_forward")
+        ctx.save_for_backward(max_vals, arg_max, gamma)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        lib = _lib.load()
+        max_vals, arg_max, gamma = ctx.saved_tensors
+        grad_out = grad_out.contiguous()
+        n, k, c = grad_out.shape
+        grad_x = torch.empty_like(grad_out)
+        grad_gb = torch.empty((2, c), dtype=torch.float32, device=grad_out.device)
+        ws = torch.empty((lib.ln_max_centre_backward_workspace_bytes(n, k, c),), dtype=torch.uint8, device=grad_out.device)
+        _lib.check(lib.ln_max_centre_backward(_lib.ptr(grad_out), _lib.ptr(max_vals), _lib.ptr(arg_max), _lib.ptr(gamma), n, k, c,
+                                              _lib.ptr(grad_x), _lib.ptr(grad_gb), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(grad_out.device)),
+                   "ln_max_centre_backward")
+        return grad_x, grad_gb[0], grad_gb[1]
+
+
+def max_centre_rows(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor) -> torch.Tensor:
+    """[N, K, C] rows minus (gamma * their maximum over K + beta)."""
+    if x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and 1 <= x.shape[1] <= 8 and 1 <= x.shape[2] <= 64:
+        return MaxCentreFunction.apply(x, gamma, beta)
+    return x - (gamma * x.max(1, keepdim=True)[0] + beta)
+
+
 def group_norm_rows(x: torch.Tensor, gn: torch.nn.GroupNorm, relu: bool = False) -> torch.Tensor:
     """GroupNorm of an [M, C] matrix with the parameters of `gn` (statistics over rows x group channels)."""
     if x.is_cuda and x.dtype == torch.float32 and x.shape[1] % 4 == 0 and x.shape[1] <= 1024 and x.shape[0] > 0:
@@ -525,8 +565,7 @@ class SliceFastCUDALatticeModule(torch.nn.Module):
         nr_vertices_per_simplex = ls.pos_dim() + 1
         per_vertex = gathered.shape[1] // nr_vertices_per_simplex
         gathered = gathered.view(nr_positions, nr_vertices_per_simplex, per_vertex)
-        max_vals = gathered.max(1, keepdim=True)[0]
-        gathered = gathered - (self.gamma * max_vals + self.beta)
+        gathered = max_centre_rows(gathered, self.gamma, self.beta)  # mods:525-529: minus (gamma * max over the simplex + beta)
         # [N(d+1), 9] -> 1: a BLAS GEMM with K = 9, N = 1 over 480 k rows; the streaming linear kernels instead
         delta_weights = linear_leaky_relu(gathered.reshape(nr_positions * nr_vertices_per_simplex, per_vertex), self.linear_deltaW.weight,
                                           self.linear_deltaW.bias, -1.0).reshape(nr_positions, nr_vertices_per_simplex)

@@ -337,3 +337,33 @@ def test_alternating_clouds_through_one_lattice_leave_no_stale_state(tmp_path):
         for k in g0:
             err = float((g1[k] - g0[k]).norm() / (g0[k].norm() + 1e-30))
             assert err < 5e-2, f"{k}: relative L2 difference {err:.3e}"
+
+
+@pytest.mark.parametrize("n,k,c", [(120000, 4, 9), (1000, 4, 9), (777, 3, 5), (50, 7, 16), (1, 4, 9), (3000, 8, 64), (2049, 2, 1)])
+def test_max_centre_kernels_match_torch(n, k, c):
+    """ln_max_centre_forward / _backward (the max-centring of the DeformSlice head, mods:525-529) against the torch broadcasting
+    expression in fp64."""
+    from lattice_net_amd.lattice_blocks import MaxCentreFunction
+    torch.manual_seed(n + k + c)
+    dev = torch.device("cuda", 0)
+    x = torch.randn((n, k, c), device=dev, requires_grad=True)
+    gamma = (torch.rand((c,), device=dev) + 0.5).requires_grad_(True)
+    beta = torch.randn((c,), device=dev, requires_grad=True)
+    g = torch.randn((n, k, c), device=dev)
+    out = MaxCentreFunction.apply(x, gamma, beta)
+    out.backward(g)
+    x64, ga64, be64 = (t.detach().double().requires_grad_(True) for t in (x, gamma, beta))
+    ref = x64 - (ga64 * x64.max(1, keepdim=True)[0] + be64)
+    ref.backward(g.double())
+    torch.testing.assert_close(out.detach().double(), ref.detach(), rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(x.grad.double(), x64.grad, rtol=1e-5, atol=1e-5)
+    scale = max(float(ga64.grad.abs().max()), float(be64.grad.abs().max()), 1.0)
+    torch.testing.assert_close(gamma.grad.double(), ga64.grad, rtol=1e-4, atol=1e-5 * scale)
+    torch.testing.assert_close(beta.grad.double(), be64.grad, rtol=1e-4, atol=1e-5 * scale)
+    # fixed summation order: bit-identical on a second run
+    x.grad = gamma.grad = beta.grad = None
+    MaxCentreFunction.apply(x, gamma, beta).backward(g)
+    g1 = gamma.grad.clone()
+    x.grad = gamma.grad = beta.grad = None
+    MaxCentreFunction.apply(x, gamma, beta).backward(g)
+    assert torch.equal(g1, gamma.grad)

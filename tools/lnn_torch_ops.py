@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Which torch operators (not this library's kernels) still run in the LNN training step: torch.profiler table by GPU time,
+with input shapes.  Usage: python tools/lnn_torch_ops.py [kitti|shapenet|scannet]"""
+import os, sys, tempfile
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from bench_lnn import PRESETS  # noqa: E402
+from lattice_net_amd import Lattice, ModelParams, synthetic  # noqa: E402
+from lattice_net_amd.losses import nll_loss_gather  # noqa: E402
+from lattice_net_amd.models import LNN  # noqa: E402
+
+name = sys.argv[1] if len(sys.argv) > 1 else "kitti"
+preset = PRESETS[name]
+dev = torch.device("cuda", 0)
+with tempfile.NamedTemporaryFile("w", suffix=".cfg", delete=False) as f:
+    f.write(preset["cfg"])
+torch.manual_seed(0)
+mp = ModelParams.create(f.name)
+lattice = Lattice.create(f.name, "lattice")
+net = LNN(preset["classes"], mp)
+n = preset["n"]
+gen = {"lidar": synthetic.lidar_cloud, "box": synthetic.box_surface_cloud, "planes": synthetic.planes_cloud}[preset["cloud"]]
+pos = torch.from_numpy(gen(n, 0)).to(dev)
+vals = torch.zeros((n, 1), device=dev) if preset["values"] == 1 else torch.rand((n, preset["values"]), device=dev)
+target = torch.from_numpy(np.random.default_rng(0).integers(0, preset["classes"], n)).to(dev)
+opt = None
+def step():
+    global opt
+    ls, _ = net(lattice, pos, vals)
+    loss = nll_loss_gather(ls, target)
+    if opt is None:
+        opt = torch.optim.AdamW(net.parameters(), lr=1e-3, weight_decay=1e-4, amsgrad=True, fused=True)
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+for _ in range(3):
+    step()
+torch.cuda.synchronize()
+from torch.profiler import profile, ProfilerActivity
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+print(prof.key_averages(group_by_input_shape=True).table(sort_by="cuda_time_total", row_limit=28, max_name_column_width=40, max_shapes_column_width=60))
