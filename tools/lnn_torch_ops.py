@@ -42,4 +42,12 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_sh
     for _ in range(3):
         step()
     torch.cuda.synchronize()
-print(prof.key_averages(group_by_input_shape=True).table(sort_by="cuda_time_total", row_limit=28, max_name_column_width=40, max_shapes_column_width=60))
+steps = 3
+rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.key.startswith(("aten::", "Optimizer", "_fused"))]
+def gpu_us(e):
+    return getattr(e, "self_device_time_total", None) or getattr(e, "self_cuda_time_total", 0.0)
+rows.sort(key=gpu_us, reverse=True)
+total = sum(gpu_us(e) for e in rows)
+print(f"torch operators: {total / steps:.0f} us of GPU time per step")
+for e in rows[:30]:
+    print(f"{e.key[:34]:34s} {e.count / steps:6.1f}/step {gpu_us(e) / steps:8.1f} us/step   {str(e.input_shapes)[:110]}")
