@@ -194,7 +194,9 @@ int ln_row2im(const int* nbr, const float* rowified, int m, int filter_extent, i
  *   flags & LN_CONV_TRANSPOSED_FILTER : `filter` is the [E*F, V] bank of the convolution being
  *        differentiated and B_e is its per-slot transpose, i.e. the filter_bank_backwards of
  *        lattice_funcs.py:307-311 without building it; otherwise `filter` is [E*V, F] and
- *        B_e = filter[e*V:(e+1)*V, :]. */
+ *        B_e = filter[e*V:(e+1)*V, :].
+ * filter_extent = 1 with nbr = 0..m-1 is a per-vertex linear layer (the 1x1 blocks of lattice_modules.py:806-832):
+ * out = values @ W^T for W = `filter` [F, V] under LN_CONV_TRANSPOSED_FILTER. */
 #define LN_CONV_FLIP_NEIGHBOURS 1
 #define LN_CONV_TRANSPOSED_FILTER 2
 int ln_conv_forward(const int* nbr, const float* values_neigh, const float* filter, int m, int filter_extent, int val_dim,

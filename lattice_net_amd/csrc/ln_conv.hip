@@ -336,7 +336,7 @@ static int ln_conv_dispatch(const int* nbr, const float* values_neigh, const flo
 
 extern "C" int ln_conv_forward(const int* nbr, const float* values_neigh, const float* filter, int m, int filter_extent,
                                int val_dim, int nr_filters, int flags, float* out, void* stream) {
-    LN_REQUIRE(m >= 0 && filter_extent >= 3 && val_dim >= 1 && nr_filters >= 1, LN_ERR_ARG, "ln_conv_forward: bad sizes");
+    LN_REQUIRE(m >= 0 && filter_extent >= 1 && val_dim >= 1 && nr_filters >= 1, LN_ERR_ARG, "ln_conv_forward: bad sizes");
     LN_REQUIRE(m == 0 || (nbr && values_neigh && filter && out), LN_ERR_ARG, "ln_conv_forward: null buffer");
     LN_REQUIRE((flags & ~3) == 0, LN_ERR_ARG, "ln_conv_forward: unknown flags %d", flags);
     if (m == 0) return LN_OK;
@@ -542,7 +542,7 @@ static int ln_gf_launch_partials(const int* nbr, const float* values_neigh, cons
 extern "C" int ln_conv_grad_filter(const int* nbr, const float* values_neigh, const float* grad_out, int m, int filter_extent,
                                    int val_dim, int nr_filters, float* grad_filter, void* workspace, size_t workspace_bytes,
                                    void* stream) {
-    LN_REQUIRE(m >= 0 && filter_extent >= 3 && val_dim >= 1 && nr_filters >= 1, LN_ERR_ARG, "ln_conv_grad_filter: bad sizes");
+    LN_REQUIRE(m >= 0 && filter_extent >= 1 && val_dim >= 1 && nr_filters >= 1, LN_ERR_ARG, "ln_conv_grad_filter: bad sizes");
     LN_REQUIRE(grad_filter && (m == 0 || (nbr && values_neigh && grad_out)), LN_ERR_ARG, "ln_conv_grad_filter: null buffer");
     hipStream_t st = (hipStream_t)stream;
     const int total = filter_extent * val_dim * nr_filters;

@@ -105,11 +105,69 @@ class LinearLeakyReluFunction(torch.autograd.Function):
         return gx, gw, gb, None
 
 
+_IDENTITY_ROWS = {}
+_MFMA_LINEAR_WIDTHS = (16, 32, 48, 64, 96, 128, 192, 256)
+
+
+def _identity_rows(device, rows: int) -> torch.Tensor:
+    """int32 [rows, 1] = 0..rows-1: the neighbour list that turns a lattice convolution into a per-vertex linear layer."""
+    buf = _IDENTITY_ROWS.get(device)
+    if buf is None or buf.shape[0] < rows:
+        buf = torch.arange(max(rows, 65536), dtype=torch.int32, device=device).unsqueeze(1)
+        _IDENTITY_ROWS[device] = buf
+    return buf[:rows]
+
+
+class LinearMfmaFunction(torch.autograd.Function):
+    """y = x @ w^T for a per-vertex 1x1 layer (GnRelu1x1 and friends: no bias, no activation) on the MFMA kernels of the lattice
+    convolution (csrc/ln_conv.hip) — a convolution with a filter extent of 1 over the identity neighbour list; `w` [cout, cin]
+    is that convolution's bank in its transposed layout, so nothing is copied.  Both gradients come from the same kernels:
+    grad_x = conv(grad_y; w as a plain bank), grad_w = the filter gradient with the roles of x and grad_y swapped."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        lib = _lib.load()
+        x, w = x.contiguous(), w.contiguous()
+        rows, cin = x.shape
+        cout = w.shape[0]
+        ident = _identity_rows(x.device, rows)
+        y = torch.empty((rows, cout), dtype=torch.float32, device=x.device)
+        _lib.check(lib.ln_conv_forward(_lib.ptr(ident), _lib.ptr(x), _lib.ptr(w), rows, 1, cin, cout, 2, _lib.ptr(y), _lib.stream_ptr(x.device)),
+                   "ln_conv_forward(1x1)")  # 2 = LN_CONV_TRANSPOSED_FILTER
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        lib = _lib.load()
+        x, w = ctx.saved_tensors
+        grad_y = grad_y.contiguous()
+        rows, cin = x.shape
+        cout = w.shape[0]
+        dev = x.device
+        ident = _identity_rows(dev, rows)
+        stream = _lib.stream_ptr(dev)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            _lib.check(lib.ln_conv_forward(_lib.ptr(ident), _lib.ptr(grad_y), _lib.ptr(w), rows, 1, cout, cin, 0, _lib.ptr(gx), stream),
+                       "ln_conv_forward(1x1, grad_x)")
+        gw = torch.empty_like(w)
+        ws = torch.empty((lib.ln_conv_grad_filter_workspace_bytes(rows, 1, cout, cin),), dtype=torch.uint8, device=dev)
+        _lib.check(lib.ln_conv_grad_filter(_lib.ptr(ident), _lib.ptr(grad_y), _lib.ptr(x), rows, 1, cout, cin, _lib.ptr(gw), _lib.ptr(ws), ws.numel(),
+                                           stream), "ln_conv_grad_filter(1x1)")
+        return gx, gw
+
+
 def linear_leaky_relu(x, weight, bias, slope: float):
-    """LeakyReLU(linear(x)) (slope < 0: plain linear) for [rows, channels] inputs; the streaming kernels take float32 CUDA
-    rows with <= 128 channels, everything else goes through torch."""
+    """LeakyReLU(linear(x)) (slope < 0: plain linear) for [rows, channels] inputs.  Bias-free plain layers whose widths the
+    convolution's MFMA tiles cover run as a 1x1 lattice convolution; other float32 CUDA rows with <= 128 channels take the
+    streaming kernels; everything else goes through torch."""
     cin, cout = x.shape[1], weight.shape[0]
-    ok = x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and cin <= 128 and cout <= 128 and cin * cout <= 10240
+    gpu_rows = x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] > 0
+    if gpu_rows and bias is None and slope < 0 and cin in _MFMA_LINEAR_WIDTHS and cout in _MFMA_LINEAR_WIDTHS and x.shape[0] >= 64:
+        return LinearMfmaFunction.apply(x, weight)
+    ok = gpu_rows and cin <= 128 and cout <= 128 and cin * cout <= 10240
     if ok:
         return LinearLeakyReluFunction.apply(x, weight, bias, slope)
     y = torch.nn.functional.linear(x, weight, bias)

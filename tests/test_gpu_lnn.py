@@ -367,3 +367,24 @@ def test_max_centre_kernels_match_torch(n, k, c):
     x.grad = gamma.grad = beta.grad = None
     MaxCentreFunction.apply(x, gamma, beta).backward(g)
     assert torch.equal(g1, gamma.grad)
+
+
+@pytest.mark.parametrize("rows,cin,cout", [(46538, 96, 96), (46538, 96, 48), (11407, 128, 32), (11407, 32, 128), (500, 16, 64), (64, 64, 16),
+                                           (3001, 48, 192)])
+def test_per_vertex_linear_layers_on_the_convolution_kernels(rows, cin, cout):
+    """Bias-free 1x1 layers run as a lattice convolution with a filter extent of 1 over the identity neighbour list
+    (LinearMfmaFunction); forward and both gradients against torch in fp64, 1e-5 relative like the convolution itself."""
+    from lattice_net_amd.lattice_modules import LinearMfmaFunction, linear_leaky_relu
+    torch.manual_seed(rows + cin + cout)
+    dev = torch.device("cuda", 0)
+    x = torch.randn((rows, cin), device=dev, requires_grad=True)
+    w = (torch.randn((cout, cin), device=dev) / cin ** 0.5).requires_grad_(True)
+    g = torch.randn((rows, cout), device=dev)
+    y = linear_leaky_relu(x, w, None, -1.0)
+    assert y.grad_fn is not None and type(y.grad_fn).__name__.startswith("LinearMfmaFunction")
+    y.backward(g)
+    x64, w64 = x.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True)
+    ref = x64 @ w64.t()
+    ref.backward(g.double())
+    for got, want in ((y.detach(), ref.detach()), (x.grad, x64.grad), (w.grad, w64.grad)):
+        torch.testing.assert_close(got.double(), want, rtol=1e-5, atol=1e-5 * float(want.abs().max()))
