@@ -100,9 +100,9 @@ __global__ void __launch_bounds__(256)
 __global__ void __launch_bounds__(256)
     k_linear_act_backward_x(const float* __restrict__ w, const float* __restrict__ y, const float* __restrict__ gy, long long rows, int cin,
                             int cout, float slope, float* __restrict__ gx) {
-    extern __shared__ float s_w[];  // [cout, cin]  (lanes run over i: conflict-free)
+    extern __shared__ __attribute__((aligned(16))) float s_w4[];  // [cout, cin]  (lanes run over i: conflict-free)
     const int tid = threadIdx.x;
-    for (int i = tid; i < cout * cin; i += 256) s_w[i] = w[i];
+    for (int i = tid; i < cout * cin; i += 256) s_w4[i] = w[i];
     __syncthreads();
     const int q = cin >> 2;  // cin % 4 == 0 on this path
     const long long total = rows * q;
@@ -113,14 +113,26 @@ __global__ void __launch_bounds__(256)
         const float* gr = gy + t * cout;
         const float* yr = y + t * cout;
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        for (int o = 0; o < cout; ++o) {
-            float gv = gr[o];
-            if (slope >= 0.f && !(yr[o] > 0.f)) gv *= slope;
-            const float* wr = s_w + o * cin + i0;
-            a0 = fmaf(gv, wr[0], a0);
-            a1 = fmaf(gv, wr[1], a1);
-            a2 = fmaf(gv, wr[2], a2);
-            a3 = fmaf(gv, wr[3], a3);
+        auto step = [&](float gv, float yv, int o) {
+            if (slope >= 0.f && !(yv > 0.f)) gv *= slope;
+            const float4 wv = *reinterpret_cast<const float4*>(s_w4 + o * cin + i0);
+            a0 = fmaf(gv, wv.x, a0);
+            a1 = fmaf(gv, wv.y, a1);
+            a2 = fmaf(gv, wv.z, a2);
+            a3 = fmaf(gv, wv.w, a3);
+        };
+        if ((cout & 3) == 0) {  // rows of gy / y are 16-byte aligned: four output channels per load
+#pragma unroll 2
+            for (int o = 0; o < cout; o += 4) {
+                const float4 g4 = *reinterpret_cast<const float4*>(gr + o);
+                const float4 y4 = slope >= 0.f ? *reinterpret_cast<const float4*>(yr + o) : make_float4(1.f, 1.f, 1.f, 1.f);
+                step(g4.x, y4.x, o);
+                step(g4.y, y4.y, o + 1);
+                step(g4.z, y4.z, o + 2);
+                step(g4.w, y4.w, o + 3);
+            }
+        } else {
+            for (int o = 0; o < cout; ++o) step(gr[o], slope >= 0.f ? yr[o] : 1.f, o);
         }
         *reinterpret_cast<float4*>(gx + t * cin + i0) = make_float4(a0, a1, a2, a3);
     }
@@ -132,53 +144,97 @@ __global__ void __launch_bounds__(256)
 __global__ void __launch_bounds__(256)
     k_linear_act_backward_w(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ gy, long long rows, int cin,
                             int cout, float slope, float* __restrict__ slabs) {
-    extern __shared__ float s_mem[];
+    extern __shared__ __attribute__((aligned(16))) float s_mem[];
     float* s_x = s_mem;                        // [TILE, cin]
-    float* s_g = s_x + LN_MLP_TILE * cin;      // [TILE, cout + 1]
+    float* s_g = s_x + LN_MLP_TILE * cin;      // [TILE, cout]  (lanes that share an output channel read one address: broadcast)
+    __shared__ float s_red[256];
     const int tid = threadIdx.x;
     const int pairs = cout * cin;
+    // Layers with fewer than 256 (o, i) pairs: the tokens of a tile are split over 256 / pairs thread groups, folded at the end.
+    const int P = pairs < 256 ? pairs : 256;
+    const int G = 256 / P;
+    const int grp = tid / P;
+    const int j0 = tid - grp * P;
+    const bool active = grp < G;
     float acc[LN_MLP_MAXP];
 #pragma unroll
     for (int k = 0; k < LN_MLP_MAXP; ++k) acc[k] = 0.f;
     float acc_b = 0.f;
     const long long tiles = (rows + LN_MLP_TILE - 1) / LN_MLP_TILE;
+    const long long x_elems = rows * cin, g_elems = rows * cout;
     for (long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         const long long t0 = tile * LN_MLP_TILE;
         __syncthreads();
-        for (int i = tid; i < LN_MLP_TILE * cin; i += 256) {
-            const long long t = t0 + i / cin;
-            s_x[i] = t < rows ? x[t0 * cin + i] : 0.f;
-        }
-        for (int i = tid; i < LN_MLP_TILE * cout; i += 256) {
-            const int lt = i / cout, o = i - lt * cout;
-            const long long t = t0 + lt;
-            float gv = 0.f;
-            if (t < rows) {
-                gv = gy[t0 * cout + i];
-                if (slope >= 0.f && !(y[t0 * cout + i] > 0.f)) gv *= slope;
+        // contiguous copies of the tile's rows (16-byte aligned: a tile starts at a multiple of 64 rows), zero beyond the last row
+        {
+            const long long base = t0 * cin;
+            for (int v = tid; v < LN_MLP_TILE * cin / 4; v += 256) {
+                const long long e = base + (long long)v * 4;
+                float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e + 3 < x_elems) {
+                    xv = *reinterpret_cast<const float4*>(x + e);
+                } else {
+                    if (e < x_elems) xv.x = x[e];
+                    if (e + 1 < x_elems) xv.y = x[e + 1];
+                    if (e + 2 < x_elems) xv.z = x[e + 2];
+                }
+                *reinterpret_cast<float4*>(s_x + v * 4) = xv;
             }
-            s_g[lt * (cout + 1) + o] = gv;
+        }
+        {
+            const long long base = t0 * cout;
+            for (int v = tid; v < LN_MLP_TILE * cout / 4; v += 256) {
+                const long long e = base + (long long)v * 4;
+                float4 gv = make_float4(0.f, 0.f, 0.f, 0.f), yv = make_float4(1.f, 1.f, 1.f, 1.f);
+                if (e + 3 < g_elems) {
+                    gv = *reinterpret_cast<const float4*>(gy + e);
+                    if (slope >= 0.f) yv = *reinterpret_cast<const float4*>(y + e);
+                } else {
+                    if (e < g_elems) { gv.x = gy[e]; if (slope >= 0.f) yv.x = y[e]; }
+                    if (e + 1 < g_elems) { gv.y = gy[e + 1]; if (slope >= 0.f) yv.y = y[e + 1]; }
+                    if (e + 2 < g_elems) { gv.z = gy[e + 2]; if (slope >= 0.f) yv.z = y[e + 2]; }
+                }
+                if (slope >= 0.f) {
+                    if (!(yv.x > 0.f)) gv.x *= slope;
+                    if (!(yv.y > 0.f)) gv.y *= slope;
+                    if (!(yv.z > 0.f)) gv.z *= slope;
+                    if (!(yv.w > 0.f)) gv.w *= slope;
+                }
+                *reinterpret_cast<float4*>(s_g + v * 4) = gv;
+            }
         }
         __syncthreads();
+        if (active) {
 #pragma unroll
-        for (int k = 0; k < LN_MLP_MAXP; ++k) {
-            const int j = tid + k * 256;
-            if (j < pairs) {
-                const int o = j / cin, i = j - o * cin;
-                float a = acc[k];
+            for (int k = 0; k < LN_MLP_MAXP; ++k) {
+                const int j = j0 + k * 256;
+                if (j < pairs && (k == 0 || G == 1)) {
+                    const int o = j / cin, i = j - o * cin;
+                    float a = acc[k];
 #pragma unroll 8
-                for (int lt = 0; lt < LN_MLP_TILE; ++lt) a = fmaf(s_g[lt * (cout + 1) + o], s_x[lt * cin + i], a);
-                acc[k] = a;
+                    for (int lt = grp; lt < LN_MLP_TILE; lt += G) a = fmaf(s_g[lt * cout + o], s_x[lt * cin + i], a);
+                    acc[k] = a;
+                }
             }
         }
         if (tid < cout)
-            for (int lt = 0; lt < LN_MLP_TILE; ++lt) acc_b += s_g[lt * (cout + 1) + tid];
+            for (int lt = 0; lt < LN_MLP_TILE; ++lt) acc_b += s_g[lt * cout + tid];
     }
     float* slab = slabs + (size_t)blockIdx.x * (pairs + cout);
+    if (G == 1) {
 #pragma unroll
-    for (int k = 0; k < LN_MLP_MAXP; ++k) {
-        const int j = tid + k * 256;
-        if (j < pairs) slab[j] = acc[k];
+        for (int k = 0; k < LN_MLP_MAXP; ++k) {
+            const int j = tid + k * 256;
+            if (j < pairs) slab[j] = acc[k];
+        }
+    } else {  // fold the token groups of each pair in a fixed order
+        s_red[tid] = active ? acc[0] : 0.f;
+        __syncthreads();
+        if (tid < P) {
+            float a = 0.f;
+            for (int g = 0; g < G; ++g) a += s_red[g * P + tid];
+            slab[tid] = a;
+        }
     }
     if (tid < cout) slab[pairs + tid] = acc_b;
 }
@@ -319,7 +375,7 @@ extern "C" int ln_linear_act_backward(const float* x, const float* w, const floa
     }
     float* slabs = static_cast<float*>(workspace);
     long long tiles = (rows + LN_MLP_TILE - 1) / LN_MLP_TILE;
-    const int grid = int(tiles < LN_MLP_W_GRID ? tiles : LN_MLP_W_GRID);
+    const int grid = int(tiles < LN_MLP_W_GRID ? tiles : LN_MLP_W_GRID);  // measured: 256 and 2048 workgroups are both slower for the narrow layers
     if (cin % 4 == 0 && cout % 4 == 0 && pairs > 1024 && pairs <= 256 * LN_MLP_TILED_BLOCKS * 16) {
         const size_t lds = sizeof(float) * LN_MLP_TILE * ((size_t)cin + cout);
         LN_LAUNCH("k_linear_act_backward_w", k_linear_act_backward_w_tiled, dim3(grid), dim3(256), lds, st, x, y, grad_y, rows, cin, cout, slope,
