@@ -399,6 +399,81 @@ __global__ void __launch_bounds__(256)
     }
 }
 
+// Same result, bit for bit (each logit is still the serial sum over v of W[c,v] * h[p,v], multiply and add kept apart), for
+// V % 4 == 0: the d+1 row indices and effective weights of a tile are staged in LDS once (the scalar kernel re-reads them
+// for every channel — three quarters of its L1 traffic), rows are gathered as float4, and a thread owns one point and every
+// TPP-th class, so a channel of h is read from LDS once for all of the thread's classes.
+#define LN_SC_FWD_MAX_CPT 16  // classes per thread
+template <int PB>
+__global__ void __launch_bounds__(256)
+    k_slice_classify_forward_v4(const float* __restrict__ values, const float* __restrict__ delta_w, const float* __restrict__ lin_w,
+                                const float* __restrict__ lin_b, const int* __restrict__ idx, const float* __restrict__ w, int n,
+                                int dp1, int V, int C, float* __restrict__ logits) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int SH = V + 1;                // row stride of W and h: lanes that differ in class / point hit different banks
+    float* s_w = smem;                   // [C, V+1]
+    float* s_h = s_w + C * SH;           // [PB, V+1]
+    float* s_we = s_h + PB * SH;         // [PB, dp1]  w + delta_w
+    int* s_idx = reinterpret_cast<int*>(s_we + PB * dp1);  // [PB, dp1]
+    constexpr int TPP = 256 / PB;        // threads per point in the classifier phase
+    const int tid = threadIdx.x;
+    const int V4 = V >> 2;
+    for (int i = tid; i < C * V; i += 256) {
+        const int c = i / V;
+        s_w[c * SH + (i - c * V)] = lin_w[i];
+    }
+    const int tiles = (n + PB - 1) / PB;
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const long long p0 = (long long)tile * PB;
+        __syncthreads();  // s_w staged / previous tile consumed
+        for (int i = tid; i < PB * dp1; i += 256) {
+            const long long t = p0 * dp1 + i;
+            const bool ok = t < (long long)n * dp1;
+            s_idx[i] = ok ? idx[t] : -1;
+            s_we[i] = ok ? w[t] + delta_w[t] : 0.0f;
+        }
+        __syncthreads();
+        for (int i = tid; i < PB * V4; i += 256) {
+            const int lp = i / V4, v4 = i - lp * V4;
+            float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int r = 0; r < dp1; ++r) {
+                const int row = s_idx[lp * dp1 + r];
+                if (row >= 0) {
+                    const float wt = s_we[lp * dp1 + r];
+                    const float4 x = reinterpret_cast<const float4*>(values + (size_t)row * V)[v4];
+                    h.x = h.x + x.x * wt; h.y = h.y + x.y * wt; h.z = h.z + x.z * wt; h.w = h.w + x.w * wt;
+                }
+            }
+            float* d = s_h + lp * SH + v4 * 4;
+            d[0] = h.x; d[1] = h.y; d[2] = h.z; d[3] = h.w;
+        }
+        __syncthreads();
+        {
+            const int lp = tid / TPP, q = tid - lp * TPP;
+            const long long p = p0 + lp;
+            if (p < n) {
+                float acc[LN_SC_FWD_MAX_CPT];
+#pragma unroll
+                for (int k = 0; k < LN_SC_FWD_MAX_CPT; ++k) acc[k] = 0.0f;
+                const float* hw = s_h + lp * SH;
+                for (int v = 0; v < V; ++v) {
+                    const float hv = hw[v];
+#pragma unroll
+                    for (int k = 0; k < LN_SC_FWD_MAX_CPT; ++k) {
+                        const int c = q + k * TPP;
+                        if (c < C) acc[k] = acc[k] + s_w[c * SH + v] * hv;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < LN_SC_FWD_MAX_CPT; ++k) {
+                    const int c = q + k * TPP;
+                    if (c < C) logits[p * C + c] = acc[k] + lin_b[c];
+                }
+            }
+        }
+    }
+}
+
 static int ln_sc_points_per_tile(int V, int C, int arrays_of_v) {  // largest PB in {64,32,16,8} whose tiles fit 64 KiB of LDS
     for (int pb = 64; pb >= 8; pb >>= 1) {
         const size_t lds = sizeof(float) * ((size_t)C * (V + 1) + (size_t)pb * ((size_t)arrays_of_v * V + C));
@@ -414,12 +489,32 @@ extern "C" int ln_slice_classify_forward(const float* values, const float* delta
     if (rc) return rc;
     LN_REQUIRE(nr_classes >= 1 && (n == 0 || (delta_w && lin_w && lin_b && w)), LN_ERR_ARG, "ln_slice_classify_forward: bad args");
     if (n == 0) return LN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (val_dim % 4 == 0 && (reinterpret_cast<uintptr_t>(values) & 15) == 0) {
+        // float4 kernel: largest tile whose [C + PB, V+1] + 2 [PB, d+1] arrays fit 64 KiB and whose threads own <= 16 classes each
+        for (int pb = 64; pb >= 16; pb >>= 1) {
+            const size_t lds4 = sizeof(float) * ((size_t)(nr_classes + pb) * (val_dim + 1) + 2 * (size_t)pb * (pos_dim + 1));
+            const int cpt = ln_div_up(nr_classes, 256 / pb);
+            if (lds4 > 64 * 1024 || cpt > LN_SC_FWD_MAX_CPT) continue;
+            int grid4 = ln_div_up(n, pb);
+            if (grid4 > 2048) grid4 = 2048;
+            if (pb == 64)
+                LN_LAUNCH("k_slice_classify_forward", k_slice_classify_forward_v4<64>, dim3(grid4), dim3(256), lds4, st, values, delta_w, lin_w, lin_b,
+                          idx, w, n, pos_dim + 1, val_dim, nr_classes, logits);
+            else if (pb == 32)
+                LN_LAUNCH("k_slice_classify_forward", k_slice_classify_forward_v4<32>, dim3(grid4), dim3(256), lds4, st, values, delta_w, lin_w, lin_b,
+                          idx, w, n, pos_dim + 1, val_dim, nr_classes, logits);
+            else
+                LN_LAUNCH("k_slice_classify_forward", k_slice_classify_forward_v4<16>, dim3(grid4), dim3(256), lds4, st, values, delta_w, lin_w, lin_b,
+                          idx, w, n, pos_dim + 1, val_dim, nr_classes, logits);
+            return ln_check_launch("ln_slice_classify_forward");
+        }
+    }
     const int pb = ln_sc_points_per_tile(val_dim, nr_classes, 1);
     LN_REQUIRE(pb > 0, LN_ERR_UNSUPPORTED, "ln_slice_classify_forward: V=%d C=%d do not fit 64 KiB of LDS", val_dim, nr_classes);
     const size_t lds = sizeof(float) * ((size_t)nr_classes * (val_dim + 1) + (size_t)pb * val_dim);
     int grid = ln_div_up(n, pb);
     if (grid > 2048) grid = 2048;
-    hipStream_t st = (hipStream_t)stream;
 #define LN_SC_FWD(P)                                                                                                          \
     if (pb == P)                                                                                                                \
         LN_LAUNCH("k_slice_classify_forward", k_slice_classify_forward<P>, dim3(grid), dim3(256), lds, st, values, delta_w, lin_w, lin_b, idx, w, \
