@@ -637,6 +637,8 @@ __global__ void __launch_bounds__(256)
     float* s_gh = s_h + PB * V;         // [PB, V]
     float* s_g = s_gh + PB * V;         // [PB, CP]
     float* s_w = s_g + PB * CP;         // [C, V]
+    float* s_we = s_w + C * V;          // [PB, dp1]  w + delta_w
+    int* s_idx = reinterpret_cast<int*>(s_we + PB * dp1);  // [PB, dp1]
     const int tid = threadIdx.x;
     const int CV = C * V;
     const int V4 = V >> 2;
@@ -658,25 +660,27 @@ __global__ void __launch_bounds__(256)
             const long long p = p0 + lp;
             s_g[i] = (p < n && c < C) ? grad_logits[p * C + c] : 0.0f;
         }
+        for (int i = tid; i < PB * dp1; i += 256) {  // the tile's row indices and effective weights, once
+            const long long t = p0 * dp1 + i;
+            const bool ok = t < (long long)n * dp1;
+            const float we = ok ? w[t] + delta_w[t] : 0.0f;
+            s_idx[i] = ok ? idx[t] : -1;
+            s_we[i] = we;
+            if (ok) w_eff[t] = we;
+        }
+        __syncthreads();
         for (int i = tid; i < PB * V4; i += 256) {
             const int lp = i / V4, v4 = i - lp * V4;
-            const long long p = p0 + lp;
             float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p < n) {
-                for (int r = 0; r < dp1; ++r) {
-                    const int row = idx[p * dp1 + r];
-                    if (row >= 0) {
-                        const float wt = w[p * dp1 + r] + delta_w[p * dp1 + r];
-                        const float4 x = reinterpret_cast<const float4*>(values + (size_t)row * V)[v4];
-                        h.x = h.x + x.x * wt; h.y = h.y + x.y * wt; h.z = h.z + x.z * wt; h.w = h.w + x.w * wt;
-                    }
+            for (int r = 0; r < dp1; ++r) {
+                const int row = s_idx[lp * dp1 + r];
+                if (row >= 0) {
+                    const float wt = s_we[lp * dp1 + r];
+                    const float4 x = reinterpret_cast<const float4*>(values + (size_t)row * V)[v4];
+                    h.x = h.x + x.x * wt; h.y = h.y + x.y * wt; h.z = h.z + x.z * wt; h.w = h.w + x.w * wt;
                 }
             }
             reinterpret_cast<float4*>(s_h)[i] = h;
-        }
-        for (int i = tid; i < PB * dp1; i += 256) {
-            const long long t = p0 * dp1 + i;
-            if (t < (long long)n * dp1) w_eff[t] = w[t] + delta_w[t];
         }
         __syncthreads();
         for (int i = tid; i < PB * V4; i += 256) {  // gh = g @ W
@@ -696,7 +700,7 @@ __global__ void __launch_bounds__(256)
             const int lp = i / dp1, r = i - lp * dp1;
             const long long p = p0 + lp;
             if (p >= n) continue;
-            const int row = idx[p * dp1 + r];
+            const int row = s_idx[i];
             if (row < 0) continue;
             const float4* vr = reinterpret_cast<const float4*>(values + (size_t)row * V);
             const float4* gh = reinterpret_cast<const float4*>(s_gh + lp * V);
@@ -786,7 +790,7 @@ extern "C" int ln_slice_classify_backward(const float* grad_logits, const float*
     size_t lds = 0;
     if (v4) {
         for (int cand = 64; cand >= 8 && !pb; cand >>= 1) {
-            lds = sizeof(float) * ((size_t)cand * (2 * val_dim + cp) + (size_t)nr_classes * val_dim);
+            lds = sizeof(float) * ((size_t)cand * (2 * val_dim + cp + 2 * (pos_dim + 1)) + (size_t)nr_classes * val_dim);
             if (lds <= 64 * 1024) pb = cand;
         }
     } else {
