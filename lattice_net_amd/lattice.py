@@ -16,6 +16,7 @@ Differences that are deliberate:
 from __future__ import annotations
 
 import ctypes as C
+import itertools
 import os
 import re
 from typing import Optional, Sequence
@@ -51,7 +52,10 @@ def _require_cuda(t: torch.Tensor, name: str):
 class _TableStorage:
     """Structure buffers shared shallowly between lattice clones (Lattice.cu:88-92)."""
 
+    _uids = itertools.count(1)
+
     def __init__(self, capacity: int, pos_dim: int, device):
+        self.uid = next(_TableStorage._uids)  # never reused (unlike id()): cache keys may outlive the storage they name
         self.capacity = int(capacity)
         self.pos_dim = int(pos_dim)
         self.device = device
@@ -67,6 +71,7 @@ class _TableStorage:
 
     def clone(self) -> "_TableStorage":
         s = _TableStorage.__new__(_TableStorage)
+        s.uid = next(_TableStorage._uids)
         s.capacity, s.pos_dim, s.device = self.capacity, self.pos_dim, self.device
         s.keys = self.keys.clone()
         s.entries = self.entries.clone()
@@ -141,7 +146,7 @@ class HashTable:
             self._pinned = torch.zeros((4,), dtype=torch.int32, pin_memory=True)
             self._pinned_np = self._pinned.numpy()  # same memory: the host polls word 2
             self._readback_event = torch.cuda.Event()
-        key = (id(s), self._counters.data_ptr())
+        key = (s.uid, self._counters.data_ptr())
         if getattr(self, "_c_table_key", None) == key:
             return self._c_table
         self._c_table_key = key
@@ -625,7 +630,7 @@ class Lattice:
             else (lib.ln_splat_accumulate_and_neighbours, "ln_splat_accumulate_and_neighbours")
         _lib.check(fn(C.byref(csr), _lib.ptr(grp_row), max_seg, _lib.ptr(values), _lib.ptr(w), val_dim, src_div, val_dim, _lib.ptr(dst),
                       C.byref(t), rows_upper, _lib.ptr(nbr), self._stream()), what)
-        st.nbr_cache[("prefetch", id(st), st.version, self.m_lvl)] = (nbr, st)
+        st.nbr_cache[("prefetch", st.uid, st.version, self.m_lvl)] = (nbr,)
 
     # ---------------------------------------------------------------- neighbour list (shared)
     def _prefetch_neighbours(self, tokens: int):
@@ -643,7 +648,7 @@ class Lattice:
         t = ht.c_table()
         _lib.check(lib.ln_neighbours(C.byref(t), rows_upper, C.byref(t), self.m_lvl, self.m_lvl, 1, 0, _lib.ptr(nbr), self._stream()),
                    "ln_neighbours")
-        st.nbr_cache[("prefetch", id(st), st.version, self.m_lvl)] = (nbr, st)
+        st.nbr_cache[("prefetch", st.uid, st.version, self.m_lvl)] = (nbr,)
 
 
     def neighbours(self, lattice_neighbours: Optional["Lattice"], dilation: int, flip_neighbours: bool) -> torch.Tensor:
@@ -656,16 +661,16 @@ class Lattice:
         if m == 0:
             raise _lib.LatticeNetHipError("this lattice has zero vertices")
         sq, sn = self.m_hash_table._storage, nb.m_hash_table._storage
-        key = (id(sn), sn.version, self.m_lvl, nb.m_lvl, int(dilation), bool(flip_neighbours), m)
+        key = (sn.uid, sn.version, self.m_lvl, nb.m_lvl, int(dilation), bool(flip_neighbours), m)
         hit = sq.nbr_cache.get(key)
         if hit is not None:
             return hit[0]
         E = self.get_filter_extent(1)
-        pre = sq.nbr_cache.get(("prefetch", id(sn), sn.version, self.m_lvl)) if (sn is sq and not flip_neighbours and dilation == 1 and
+        pre = sq.nbr_cache.get(("prefetch", sn.uid, sn.version, self.m_lvl)) if (sn is sq and not flip_neighbours and dilation == 1 and
                                                                                   nb.m_lvl == self.m_lvl) else None
         if pre is not None and pre[0].shape[0] >= m:
             nbr = pre[0][:m]
-            sq.nbr_cache[key] = (nbr, sn)
+            sq.nbr_cache[key] = (nbr,)
             return nbr
         if flip_neighbours:
             base = self.neighbours(nb, dilation, False)
@@ -677,7 +682,7 @@ class Lattice:
             tq, tn = self.m_hash_table.c_table(), nb.m_hash_table.c_table()
             _lib.check(lib.ln_neighbours(C.byref(tq), m, C.byref(tn), self.m_lvl, nb.m_lvl, int(dilation), 0, _lib.ptr(nbr),
                                          self._stream()), "ln_neighbours")
-        sq.nbr_cache[key] = (nbr, sn)  # keep sn alive so id() stays unique
+        sq.nbr_cache[key] = (nbr,)  # keyed by the neighbour storage's uid: no reference to it (a storage in its own cache is a cycle)
         return nbr
 
     def _check_filter_extent(self, filter_extent: int):
