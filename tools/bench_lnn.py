@@ -47,7 +47,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--infer", action="store_true", help="forward only, under torch.no_grad()")
     ap.add_argument("--host-profile", action="store_true", help="cProfile of the host side of the timed steps")
-    ap.add_argument("--gc", type=int, default=0, help="1 = leave Python's cyclic garbage collector on during the timed steps")
+    ap.add_argument("--gc", type=int, default=0, help="1 = leave Python's cyclic garbage collector on during the timed steps; 2 = on, after gc.freeze()")
     args = ap.parse_args()
     preset = PRESETS[args.config]
     args.n = args.n or preset["n"]
@@ -85,6 +85,12 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    if args.gc == 2:
+        # collector left on, but everything alive after the warm-up (modules, torch internals) is moved out of its reach:
+        # full collections then only walk what the steps themselves allocate
+        import gc
+        gc.collect()
+        gc.freeze()
     if not args.gc:
         # the step allocates ~10k short-lived Python objects; generation-2 collections walking the live module / autograd
         # objects cost ~3 ms per step.  Nothing in the step relies on the cycle collector (reference counts free the graph).
