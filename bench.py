@@ -163,7 +163,7 @@ def full_unet_step(dev, n: int, steps: int = 10, warmup: int = 3, classes: int =
     pos = torch.from_numpy(synthetic.lidar_cloud(n, 0)).to(dev)
     vals = torch.zeros((n, 1), device=dev)
     target = torch.from_numpy(np.random.default_rng(0).integers(0, classes, n)).to(dev)
-    opt = torch.optim.AdamW(net.parameters(), lr=1e-3, weight_decay=1e-4, amsgrad=True)
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-3, weight_decay=1e-4, amsgrad=True, fused=True)  # ln_train.py:165, single-launch update
 
     def step():
         logsoftmax, _ = net(lattice, pos, vals)
