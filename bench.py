@@ -159,6 +159,7 @@ def full_unet_step(dev, n: int, steps: int = 10, warmup: int = 3, classes: int =
     torch.manual_seed(0)
     mp = ModelParams.create(path)
     lattice = Lattice.create(path, "lattice")
+    os.unlink(path)  # both readers are done with the temporary cfg
     net = LNN(classes, mp, device=dev)
     pos = torch.from_numpy(synthetic.lidar_cloud(n, 0)).to(dev)
     vals = torch.zeros((n, 1), device=dev)

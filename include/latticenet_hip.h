@@ -82,6 +82,9 @@ typedef struct LnCsr {
 
 const char* ln_last_error_string(void);
 const char* ln_version(void);
+/* short hash of THIS header as it was when the library was built (the binding compares it with the header it was written
+ * against and refuses a stale library) */
+const char* ln_abi_hash(void);
 
 /* Live per-kernel timing with HIP events recorded on the launch stream (used by bench.py for the
  * roofline line).  ln_profile_begin arms bracketing of every launch of the kernel called

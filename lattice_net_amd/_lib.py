@@ -67,6 +67,7 @@ _CSR = C.POINTER(LnCsr)
 SIGNATURES = {
     "ln_last_error_string": (C.c_char_p, []),
     "ln_version": (C.c_char_p, []),
+    "ln_abi_hash": (C.c_char_p, []),
     "ln_kernel_names": (C.c_char_p, []),
     "ln_profile_begin": (_i, [C.c_char_p, _i]),
     "ln_profile_end": (_i, [C.POINTER(C.c_double), C.POINTER(_i)]),
@@ -135,6 +136,16 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    # the .so is git-ignored: make sure it was built from the header these SIGNATURES were written against
+    from . import build_ext
+    try:
+        want = build_ext.abi_hash()
+    except OSError:
+        want = None  # header not shipped next to the package: nothing to compare with
+    have = lib.ln_abi_hash().decode()
+    if want is not None and have != want:
+        raise LatticeNetHipError(f"{LIB_PATH} was built from a different include/latticenet_hip.h (library {have}, header {want}): "
+                                 "rebuild it with `python lattice_net_amd/build_ext.py`")
     _lib = lib
     return lib
 
@@ -152,7 +163,13 @@ def ptr(t):
 
 def stream_ptr(device) -> int:
     """Raw hipStream_t of torch's current stream on `device` (fast path: no Stream object is built)."""
-    idx = device.index if device.index is not None else torch.cuda.current_device()
+    cur = torch.cuda.current_device()
+    idx = device.index if device.index is not None else cur
+    if idx != cur:
+        # the C ABI launches on the raw stream it is handed and never selects a device itself: a stream of another
+        # device than the current one would be used under the wrong device context
+        raise LatticeNetHipError(f"lattice tensors live on cuda:{idx} but the current device is cuda:{cur}; wrap the call in "
+                                 f"`with torch.cuda.device({idx}):` (or torch.cuda.set_device) — one process drives one GPU")
     return torch._C._cuda_getCurrentRawStream(idx)
 
 

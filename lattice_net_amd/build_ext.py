@@ -15,7 +15,19 @@ CSRC = os.path.join(PKG, "csrc")
 OUT = os.path.join(PKG, "liblatticenet_hip.so")
 OBJ_DIR = os.path.join(ROOT, "build", "obj")
 SOURCES = ["ln_table.hip", "ln_rows.hip", "ln_conv.hip", "ln_csr.hip", "ln_norm.hip", "ln_conv_f16.hip", "ln_mlp.hip", "ln_centre.hip"]
-HEADERS = [os.path.join(CSRC, h) for h in ("ln_common.h", "ln_simplex.h", "ln_csr.h")] + [os.path.join(ROOT, "include", "latticenet_hip.h")]
+import glob
+import hashlib
+
+ABI_HEADER = os.path.join(ROOT, "include", "latticenet_hip.h")
+# every header under csrc/ is a dependency of every object (editing ln_neighbours.h must rebuild ln_table.o and ln_csr.o)
+HEADERS = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [ABI_HEADER]
+
+
+def abi_hash() -> str:
+    """Short hash of the C-ABI header.  Compiled into the library (ln_abi_hash) and compared by _lib.load(): a stale
+    git-ignored .so whose argument lists no longer match the ctypes SIGNATURES raises instead of corrupting memory."""
+    with open(ABI_HEADER, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
 # -ffp-contract=off: lattice keys and barycentric weights must be bit-identical to the oracle
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"),
          "-I" + CSRC]
@@ -40,12 +52,13 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = _hipcc()
     jobs = []
     objs = []
+    flags = FLAGS + ['-DLN_ABI_HASH="%s"' % abi_hash()]
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(OBJ_DIR, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + HEADERS):
-            jobs.append([hipcc] + FLAGS + ["-c", src, "-o", obj])
+            jobs.append([hipcc] + flags + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:

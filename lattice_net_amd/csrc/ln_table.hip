@@ -118,7 +118,11 @@ extern "C" int ln_profile_end(double* total_ms, int* launches) {
     g_prof.name[0] = 0;
     return rc;
 }
-extern "C" const char* ln_version(void) { return "latticenet_hip 0.1 (gfx950)"; }
+extern "C" const char* ln_version(void) { return "latticenet_hip 0.2 (gfx950)"; }
+#ifndef LN_ABI_HASH
+#define LN_ABI_HASH "unknown"
+#endif
+extern "C" const char* ln_abi_hash(void) { return LN_ABI_HASH; }
 
 #define LN_DISPATCH_D(d, ...)                                                    \
     switch (d) {                                                                 \

@@ -1069,7 +1069,12 @@ class Lattice:
                 raise _lib.LatticeNetHipError(f"hash table overflow: capacity {ht.capacity()} is too small for this cloud "
                                               "(the reference would spin forever, HashTableGPU.cuh:443)")
             if status & _lib.LN_STATUS_KEY_RANGE:
-                raise _lib.LatticeNetHipError("a lattice key does not fit the packed 64-bit slot format (positions/sigma too large)")
+                d = self.pos_dim()
+                bits = min(32, 63 // max(d, 1))
+                raise _lib.LatticeNetHipError(
+                    f"a lattice key does not fit the packed 64-bit slot format: pos_dim {d} leaves {bits} bits per coordinate, i.e. "
+                    f"lattice coordinates within +-{2 ** (bits - 1)} (about +-{2 ** (bits - 1) / (d + 1) / 0.8165:.0f} sigmas from the "
+                    "origin per axis); centre the positions or use larger sigmas (README: 'Key range')")
             ht.m_nr_filled = nr
             ht.m_nr_filled_is_dirty = False
             if ht._storage is not None:

@@ -42,8 +42,10 @@ class ScatterMaxLattice(Function):
         (arg,) = ctx.saved_tensors
         valid = arg >= 0
         grad_src = torch.zeros((ctx.nr_tokens, grad_max.shape[1]), dtype=grad_max.dtype, device=grad_max.device)
-        # every (vertex, channel) picked exactly one token of that vertex: a conflict-free scatter
-        grad_src.scatter_(0, torch.where(valid, arg, torch.zeros_like(arg)).long(), torch.where(valid, grad_max, torch.zeros_like(grad_max)))
+        # every valid (vertex, channel) picked exactly one token of that vertex (conflict-free); vertices without a token
+        # (argmax -1) are routed to row 0 with a zero contribution, so the scatter has to ADD: a plain scatter_ of those
+        # zeros would race with the real gradient of whichever vertex holds token 0
+        grad_src.scatter_add_(0, torch.where(valid, arg, torch.zeros_like(arg)).long(), torch.where(valid, grad_max, torch.zeros_like(grad_max)))
         return grad_src, None, None
 
 

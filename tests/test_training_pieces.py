@@ -93,8 +93,12 @@ def test_gradient_allreduce_two_ranks_gloo(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     env = dict(os.environ, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), MASTER_ADDR="127.0.0.1")
+    import socket
+    with socket.socket() as sock:  # a free port: parallel CI jobs or a leftover worker must not collide on a fixed one
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port",
-           "29533", str(script)]
+           str(port), str(script)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("-ok") == 2 and "rank0" in r.stdout and "rank1" in r.stdout

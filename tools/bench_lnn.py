@@ -60,6 +60,7 @@ def main():
     torch.autograd.set_multithreading_enabled(False)
     mp = ModelParams.create(path)
     lattice = Lattice.create(path, "lattice")
+    os.unlink(path)  # both readers are done with the temporary cfg
     net = LNN(args.classes, mp)
     gen = {"lidar": synthetic.lidar_cloud, "box": synthetic.box_surface_cloud, "planes": synthetic.planes_cloud}[preset["cloud"]]
     pos = torch.from_numpy(gen(args.n, 0)).to(dev)

@@ -16,6 +16,7 @@ with tempfile.NamedTemporaryFile("w", suffix=".cfg", delete=False) as f:
     f.write(preset["cfg"])
 mp = ModelParams.create(f.name)
 lattice = L.Lattice.create(f.name, "lattice")
+os.unlink(f.name)  # the readers are done with the temporary cfg
 net = LNN(preset["classes"], mp)
 n = 120000
 pos = torch.from_numpy(synthetic.lidar_cloud(n, 0)).to(dev)

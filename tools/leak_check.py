@@ -45,6 +45,7 @@ with tempfile.NamedTemporaryFile("w", suffix=".cfg", delete=False) as f:
     f.write(preset["cfg"])
 mp = ModelParams.create(f.name)
 lattice = L.Lattice.create(f.name, "lattice")
+os.unlink(f.name)  # the readers are done with the temporary cfg
 net = LNN(preset["classes"], mp)
 targets = [torch.from_numpy(np.random.default_rng(k).integers(0, 20, c.shape[0])).to(dev) for k, c in enumerate(clouds)]
 opt = None

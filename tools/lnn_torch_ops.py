@@ -18,6 +18,7 @@ with tempfile.NamedTemporaryFile("w", suffix=".cfg", delete=False) as f:
 torch.manual_seed(0)
 mp = ModelParams.create(f.name)
 lattice = Lattice.create(f.name, "lattice")
+os.unlink(f.name)  # the readers are done with the temporary cfg
 net = LNN(preset["classes"], mp)
 n = preset["n"]
 gen = {"lidar": synthetic.lidar_cloud, "box": synthetic.box_surface_cloud, "planes": synthetic.planes_cloud}[preset["cloud"]]

@@ -71,6 +71,7 @@ def main():
     torch.autograd.set_multithreading_enabled(False)
     mp = ModelParams.create(path)
     lattice = Lattice.create(path, "lattice")
+    os.unlink(path)  # both readers are done with the temporary cfg
     net = LNN(args.classes, mp)
     sharding.broadcast_parameters(dist, list(net.parameters()) + list(net.buffers()))
     opt = torch.optim.AdamW(net.parameters(), lr=args.lr, weight_decay=1e-4, amsgrad=True, fused=True)  # ln_train.py:165 (+ fused update)
