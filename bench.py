@@ -207,6 +207,11 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the CPU baseline leg (0 disables)")
     ap.add_argument("--full-unet", type=int, default=1, help="0 = skip the secondary whole-network timing (rank 0, one GPU, workload C3)")
     ap.add_argument("--autograd-threads", type=int, default=0, help="1 = leave torch's per-device autograd worker thread on")
+    ap.add_argument("--mode", default="graph", choices=["graph", "eager"],
+                    help="graph (default): the whole step (forward + backward, ~10 launches) is captured ONCE into a hipGraph with the "
+                         "lattice in static-rows mode and every timed step is one graph replay; eager: one Python autograd pass per step")
+    ap.add_argument("--row-slack", type=float, default=0.06,
+                    help="graph mode: static row bound = vertex count of the calibration step x (1 + slack), rounded up to 256")
     args = ap.parse_args()
 
     from lattice_net_amd import sharding
@@ -265,21 +270,72 @@ def main():
         sharding.barrier(dist)
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # ---- calibration / eager warm-up: learns the vertex count (and is the reference result for the graph's output)
+    for _ in range(2 if args.mode == "graph" else args.warmup):
         step()
+    torch.cuda.synchronize()
+    m_real = state["m"]
+    graph = None
+    graph_err = None
+    if args.mode == "graph":
+        eager_out = state["out"].detach().clone()
+        eager_gw = W.grad.detach().clone()
+        bound = min(cap, ((int(m_real * (1.0 + args.row_slack)) + 255) // 256) * 256)
+        lat.set_static_rows(bound)  # no host readback inside the step any more: rows m_real..bound-1 are isolated zero vertices
+        # Drop every reference to the eager steps' autograd graphs first: W's AccumulateGrad node lives as long as one of
+        # them does and would run on the stream it was created on (the default stream), which a capture cannot include.
+        state.clear()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        state.clear()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step()
+        run_step = graph.replay
+    else:
+        run_step = step
+    for _ in range(args.warmup):
+        run_step()
     barrier()
+    if graph is not None:
+        nr, _status = lat.static_build_report()  # raises if the replayed build overflowed the bound / a bucket
+        assert nr == m_real, (nr, m_real)
+        scale = float(eager_out.abs().max())
+        graph_err = {"out_max_rel": float((state["out"].detach() - eager_out).abs().max()) / max(scale, 1e-30),
+                     "grad_filter_max_rel": float((W.grad - eager_gw).abs().max()) / max(float(eager_gw.abs().max()), 1e-30)}
+        if max(graph_err.values()) > 1e-5:
+            raise SystemExit(f"[bench] graph replay differs from the eager step: {graph_err}")
     prof_name = args.roofline_kernel.encode()
-    armed = lib.ln_profile_begin(prof_name, 8 * args.steps + 8) == 0
+    armed = graph is None and lib.ln_profile_begin(prof_name, 8 * args.steps + 8) == 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        run_step()
     barrier()
     elapsed = time.perf_counter() - t0
     total_ms, launches = C.c_double(0.0), C.c_int(0)
     if armed:
         lib.ln_profile_end(C.byref(total_ms), C.byref(launches))
+    if graph is not None:
+        lat.static_build_report()
+        # Per-kernel HIP-event timing needs host-side event records between the launches, which a graph replay has no
+        # room for: the roofline kernel is timed in eager steps of the same workload right after the timed region.
+        lat.set_static_rows(None)
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        if lib.ln_profile_begin(prof_name, 8 * args.steps + 8) == 0:
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            lib.ln_profile_end(C.byref(total_ms), C.byref(launches))
+            armed = True
 
-    m = state["m"]
+    m = m_real
     checksum = float(state["out"].double().abs().sum().item())
     max_elapsed = sharding.max_over_ranks(dist, elapsed, dev)
     checksum = sharding.gather_sum(dist, checksum, dev)
@@ -374,7 +430,10 @@ def main():
             "ms_per_step": round(max_elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16 features / f32 accumulate" if half else "f32", "data": "synthetic",
             "config": {"workload": cfg["desc"], "points_per_gpu": n, "vertices": m, "val_dim": v, "nr_filters": f,
-                       "sharding": f"{world} independent cloud(s), one per GPU", "checksum": round(checksum, 3)},
+                       "sharding": f"{world} independent cloud(s), one per GPU", "checksum": round(checksum, 3),
+                       "execution": ("one hipGraph replay per step (whole forward + backward captured once, static row bound)"
+                                     if graph is not None else "eager: Python autograd pass per step"),
+                       "graph_vs_eager": graph_err},
             "roofline": roofline, "roofline_others": others, "stages": stages, "full_unet": unet, "cpu_baseline": cpu,
         }
     try:  # RCCL prints a version banner through C stdio, which a pipe buffers until exit: every rank flushes it now

@@ -103,6 +103,7 @@ class HashTable:
         self.m_nr_filled = -1
         self._pos_dim_hint = -1  # dimensions known before any CAP-sized buffer exists
         self._val_dim_hint = 0
+        self._static_rows = None  # capture-safe mode (Lattice.set_static_rows): fixed row bound instead of the host readback
 
     def flush(self):
         """Issues a deferred begin_splat clear, if any (every reader of table state goes through this)."""
@@ -332,6 +333,7 @@ class Lattice:
         # so the counter is shared and the cached host count is kept.
         ht._counters = oh._counters
         ht._pos_dim_hint, ht._val_dim_hint = oh.pos_dim(), oh.val_dim()
+        ht._static_rows = oh._static_rows
         ht.m_nr_filled_is_dirty = oh.m_nr_filled_is_dirty
         ht.m_nr_filled = oh.m_nr_filled
         new.m_hash_table = ht
@@ -441,7 +443,7 @@ class Lattice:
                 _lib.check(rc, "ln_distribute")
             st.touch()
             ht.m_nr_filled_is_dirty = True
-            if n > 0:
+            if n > 0 and ht._static_rows is None:
                 ht.start_count_readback()
             else:
                 ht._readback_pending = False  # nothing was launched that writes the pinned pair: read the device counters
@@ -453,7 +455,9 @@ class Lattice:
         issue(False)
         # A bucketed build that reports LN_STATUS_BUCKET_OVERFLOW is replayed on the atomic path, together with the
         # work that was queued behind it (nr_lattice_vertices() is where the status is read).
-        st.replay = [lambda: issue(True)] if do_clear else None
+        # (static-rows mode: the launches may be inside a stream capture, where nothing can be replayed; an overflowing
+        # build is reported by static_build_report() instead)
+        st.replay = [lambda: issue(True)] if (do_clear and ht._static_rows is None) else None
         return idx, w
 
     def _after_build(self, fn):
@@ -1048,8 +1052,53 @@ class Lattice:
     def lvl(self) -> int:
         return self.m_lvl
 
+    def set_static_rows(self, rows_bound):
+        """Capture-safe mode for hipGraph / torch.cuda.graph capture of a whole step (extension; None switches it off).
+
+        The reference reads the vertex count back to the host after every build (Lattice.cu:1320-1352) and sizes the value
+        tensors with it; a stream capture cannot wait on the device.  With a static row bound B (>= the largest vertex
+        count of the clouds that will be replayed; <= capacity) nr_lattice_vertices() returns B without touching the
+        device, every [M, *] tensor of the path gets B rows, and rows M..B-1 behave as isolated vertices: zero values,
+        no neighbours (the traversal marks them LN_NOT_VISITED), no splat index refers to them — so every kernel of the
+        path computes exactly what it computes in eager mode on rows < M and zeros beyond.  The real count and the
+        status bits of each build still land in the pinned host pair: call static_build_report() after synchronising
+        to check them (M > B or a bucket overflow mean the replayed step is invalid and must be redone eagerly)."""
+        ht = self.m_hash_table
+        if rows_bound is None:
+            ht._static_rows = None
+            ht.m_nr_filled_is_dirty = True
+            return
+        rows_bound = int(rows_bound)
+        if rows_bound < 1 or rows_bound > ht.capacity():
+            raise ValueError(f"static row bound {rows_bound} must be in [1, capacity={ht.capacity()}]")
+        ht._static_rows = rows_bound
+
+    def static_build_report(self):
+        """(vertex count, status bits) of the last build as its scan kernel wrote them to pinned host memory.  Call after
+        the stream (or graph replay) that ran the build has been synchronised.  Raises if the build is unusable under
+        the static row bound."""
+        ht = self.m_hash_table
+        arr = getattr(ht, "_pinned_np", None)
+        if arr is None:
+            raise _lib.LatticeNetHipError("no build has run on this lattice yet")
+        nr, status = int(arr[0]), int(arr[1])
+        bound = ht._static_rows
+        if status & _lib.LN_STATUS_BUCKET_OVERFLOW:
+            raise _lib.LatticeNetHipError("the bucketed build overflowed inside a static-rows step: redo this cloud in eager mode "
+                                          "(set_static_rows(None)), which replays the build on the atomic path")
+        if status & _lib.LN_STATUS_TABLE_FULL:
+            raise _lib.LatticeNetHipError(f"hash table overflow: capacity {ht.capacity()} is too small for this cloud")
+        if status & _lib.LN_STATUS_KEY_RANGE:
+            raise _lib.LatticeNetHipError("a lattice key does not fit the packed 64-bit slot format (README: 'Key range')")
+        if bound is not None and nr > bound:
+            raise _lib.LatticeNetHipError(f"this cloud has {nr} lattice vertices but the static row bound is {bound}: rows beyond the "
+                                          "bound were dropped from the convolution; raise the bound and re-capture")
+        return nr, status
+
     def nr_lattice_vertices(self) -> int:  # Lattice.cu:1320-1352
         ht = self.m_hash_table
+        if ht._static_rows is not None:
+            return ht._static_rows
         if ht.m_nr_filled_is_dirty:
             both = ht.read_counters()  # [nr_filled, status]: the path's one wait on the device
             nr, status = int(both[0]), int(both[1])

@@ -1,0 +1,123 @@
+"""Static-rows mode and hipGraph replay of the whole hot-path step (run on a real MI355X: `pytest -m gpu`).
+
+The reference reads the vertex count back after every build (Lattice.cu:1320-1352); `Lattice.set_static_rows` replaces
+that readback by a fixed row bound so that splat -> conv -> slice, forward + backward, can be captured into ONE hipGraph.
+Checked here, through the C ABI, against the CPU oracle (oracle/lattice_oracle.py):
+  * a replayed graph reproduces the oracle's forward output and filter gradient (1e-5 relative, BASELINE.json);
+  * replaying after the positions / features were overwritten IN PLACE with another cloud gives that cloud's result
+    (the graph redoes the hash build, it does not cache a lattice);
+  * rows beyond the real vertex count stay zero; a bound that is too small is reported.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import lattice_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+
+
+def dev():
+    return torch.device("cuda", 0)
+
+
+def oracle_step(pos_np, vals_np, w_np, g_np, sigma, cap):
+    n, v = vals_np.shape
+    t = O.OracleHashTable(cap, 3)
+    idx, w = O.build_splat(t, O.scale_positions(pos_np, np.full((3,), sigma, np.float32)))
+    m = t.nr_filled
+    lv = np.zeros((m, v), np.float32)
+    O.splat_accumulate(lv, vals_np, idx, w)
+    nbr = O.neighbour_rows(t.keys[:m], t, 1, 1, 1, False)
+    cv = O.conv_forward(nbr, lv, w_np)
+    out = O.slice_with_precomputation(cv, idx, w, n)
+    g_c = O.slice_backwards(g_np, idx, w, m)
+    g_w = O.im2row(nbr, lv).astype(np.float64).T @ g_c.astype(np.float64)
+    return m, idx, out, g_w
+
+
+def rel(a, b):
+    return float(np.max(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)))) / max(float(np.max(np.abs(b))), 1e-30)
+
+
+def test_graph_replay_matches_oracle_and_follows_new_inputs():
+    import lattice_net_amd as L
+    from lattice_net_amd.synthetic import lidar_cloud
+
+    torch.autograd.set_multithreading_enabled(False)
+    n, v, f, sigma, cap = 6000, 32, 32, 0.9, 30000
+    rng = np.random.default_rng(3)
+    clouds = [lidar_cloud(n, 11), lidar_cloud(n, 12)]
+    feats = [rng.standard_normal((n, v)).astype(np.float32) for _ in range(2)]
+    w_np = (rng.standard_normal((9 * v, f)) / np.sqrt(9 * v)).astype(np.float32)
+    g_np = rng.standard_normal((n, f)).astype(np.float32)
+    refs = [oracle_step(clouds[k], feats[k], w_np, g_np, sigma, cap) for k in range(2)]
+
+    pos = torch.from_numpy(clouds[0]).to(dev())
+    vals = torch.from_numpy(feats[0]).to(dev())
+    G = torch.from_numpy(g_np).to(dev())
+    W = torch.from_numpy(w_np).to(dev()).requires_grad_(True)
+    lat = L.Lattice(sigmas=[sigma] * 3, capacity=cap, device=dev())
+    bound = ((max(r[0] for r in refs) + 300 + 255) // 256) * 256
+    lat.set_static_rows(bound)
+    st = {}
+
+    def step():
+        W.grad = None
+        lv, _, idx, w = L.SplatLattice.apply(lat, pos, vals)
+        m = lat.nr_lattice_vertices()
+        assert m == bound
+        lv = lv[:m].requires_grad_(True)
+        cv, cw = L.ConvIm2RowLattice.apply(lv, lat, W, 1)
+        out = L.SliceLattice.apply(cv, cw.lattice, pos, idx, w)
+        out.backward(G)
+        st.update(out=out, idx=idx, cv=cv, gv=lv.grad)
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()
+        step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    st.clear()  # no reference to the warm-up's autograd graph (and with it W's AccumulateGrad node) survives into the capture
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    for k in (0, 1, 0):
+        pos.copy_(torch.from_numpy(clouds[k]))
+        vals.copy_(torch.from_numpy(feats[k]))
+        graph.replay()
+        torch.cuda.synchronize()
+        m_ref, idx_ref, out_ref, gw_ref = refs[k]
+        nr, status = lat.static_build_report()
+        assert (nr, status) == (m_ref, 0)
+        assert np.array_equal(st["idx"].cpu().numpy(), idx_ref), "splat indices differ from the oracle"
+        assert rel(st["out"].detach().cpu().numpy(), out_ref) < RTOL
+        assert rel(W.grad.cpu().numpy(), gw_ref) < RTOL
+        cv = st["cv"].detach().cpu().numpy()
+        assert cv.shape[0] == bound and not cv[m_ref:].any(), "rows beyond the vertex count must stay zero"
+        assert not st["gv"].cpu().numpy()[m_ref:].any()
+
+
+def test_static_bound_too_small_is_reported():
+    import lattice_net_amd as L
+    from lattice_net_amd.synthetic import lidar_cloud
+
+    n, sigma, cap = 3000, 0.9, 20000
+    pos = torch.from_numpy(lidar_cloud(n, 5)).to(dev())
+    vals = torch.ones((n, 8), device=dev())
+    lat = L.Lattice(sigmas=[sigma] * 3, capacity=cap, device=dev())
+    L.SplatLattice.apply(lat, pos, vals)
+    m = lat.nr_lattice_vertices()
+    lat.set_static_rows(m // 2)
+    L.SplatLattice.apply(lat, pos, vals)
+    assert lat.nr_lattice_vertices() == m // 2
+    torch.cuda.synchronize()
+    with pytest.raises(L.LatticeNetHipError, match="static row bound"):
+        lat.static_build_report()
+    lat.set_static_rows(None)
+    L.SplatLattice.apply(lat, pos, vals)
+    assert lat.nr_lattice_vertices() == m
