@@ -10,7 +10,7 @@ import os
 import torch  # noqa: F401  (loads torch's libamdhip64 first so both share ONE HIP runtime by SONAME)
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "liblatticenet_hip.so")
+LIB_PATH = os.environ.get("LATTICE_NET_LIB") or os.path.join(_PKG, "liblatticenet_hip.so")  # override: experimental builds (tools)
 
 LN_STATUS_TABLE_FULL = 1
 LN_STATUS_KEY_RANGE = 2

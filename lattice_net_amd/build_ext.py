@@ -47,15 +47,19 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    os.makedirs(OBJ_DIR, exist_ok=True)
+def build(force: bool = False, verbose: bool = False, variant: str = "", extra_flags=()) -> str:
+    """`variant` / `extra_flags` (tools only): an experimental build liblatticenet_hip_<variant>.so with extra -D flags,
+    loaded instead of the product library when LATTICE_NET_LIB points at it."""
+    obj_dir = OBJ_DIR + ("_" + variant if variant else "")
+    out = OUT if not variant else OUT.replace(".so", "_" + variant + ".so")
+    os.makedirs(obj_dir, exist_ok=True)
     hipcc = _hipcc()
     jobs = []
     objs = []
-    flags = FLAGS + ['-DLN_ABI_HASH="%s"' % abi_hash()]
+    flags = FLAGS + ['-DLN_ABI_HASH="%s"' % abi_hash()] + list(extra_flags)
     for s in SOURCES:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(OBJ_DIR, s.replace(".hip", ".o"))
+        obj = os.path.join(obj_dir, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + HEADERS):
             jobs.append([hipcc] + flags + ["-c", src, "-o", obj])
@@ -69,10 +73,13 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
-    if force or jobs or _stale(OUT, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs)
-    return OUT
+    if force or jobs or _stale(out, objs):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+    return out
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    # python build_ext.py [--force] [--variant NAME -DX=1 -DY=2 ...]
+    argv = sys.argv[1:]
+    variant = argv[argv.index("--variant") + 1] if "--variant" in argv else ""
+    print(build(force="--force" in argv, verbose=True, variant=variant, extra_flags=[a for a in argv if a.startswith("-D")]))

@@ -170,16 +170,9 @@ __global__ void __launch_bounds__(256)
     const int m0 = blockIdx.x * 64 + wave * 16;
     const int my_row = m0 + i;
 
-    int nb[E];
-#pragma unroll
-    for (int e = 0; e < E; ++e) nb[e] = (my_row < m) ? nbr[(size_t)my_row * E + ((FLIP && e < E - 1) ? (e ^ 1) : e)] : -1;
-    // unconditional gathers (absent neighbours read row 0 and are zeroed afterwards): no branch, so all
-    // E gathers are in flight together
-    float a[E][KQ];
-#pragma unroll
-    for (int e = 0; e < E; ++e) ln_load_quarter<KQ>(values + (size_t)(nb[e] >= 0 ? nb[e] : 0) * V + q * KQ, a[e]);
-    // stage the filter bank: coalesced float4 reads of [E*V, F] rows, scattered into fragment order.
-    // All loads are issued before the first LDS write so the workgroup pays ONE memory latency.
+    // Load order = dependency order: the filter bank depends on nothing, so its loads go out first, then the neighbour
+    // indices, then the gathers that need them.  Loads return in order: staging the bank only waits for the bank (the gathers
+    // stay in flight behind it), and the MFMAs of slot e only wait for the gather of slot e.
     constexpr int N4 = E * V * F / 4;
     constexpr int NST = (N4 + 255) / 256;
     float4 wv[NST];
@@ -188,6 +181,14 @@ __global__ void __launch_bounds__(256)
         const int x4 = tid + s * 256;
         wv[s] = (x4 < N4) ? reinterpret_cast<const float4*>(filter)[x4] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    int nb[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) nb[e] = (my_row < m) ? nbr[(size_t)my_row * E + ((FLIP && e < E - 1) ? (e ^ 1) : e)] : -1;
+    // unconditional gathers (absent neighbours read row 0 and are zeroed afterwards): no branch, so all
+    // E gathers are in flight together
+    float a[E][KQ];
+#pragma unroll
+    for (int e = 0; e < E; ++e) ln_load_quarter<KQ>(values + (size_t)(nb[e] >= 0 ? nb[e] : 0) * V + q * KQ, a[e]);
 #pragma unroll
     for (int s = 0; s < NST; ++s) {
         const int x4 = tid + s * 256;
@@ -219,11 +220,6 @@ __global__ void __launch_bounds__(256)
         }
     }
     __syncthreads();
-#pragma unroll
-    for (int e = 0; e < E; ++e)
-#pragma unroll
-        for (int k = 0; k < KQ; ++k) a[e][k] = nb[e] >= 0 ? a[e][k] : 0.f;
-
     floatx4 acc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = floatx4{0.f, 0.f, 0.f, 0.f};
@@ -231,10 +227,11 @@ __global__ void __launch_bounds__(256)
     for (int e = 0; e < E; ++e) {
 #pragma unroll
         for (int kk = 0; kk < KQ; ++kk) {
+            const float av = nb[e] >= 0 ? a[e][kk] : 0.f;  // absent neighbour: a zero row
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const float b = s_b[((e * KQ + kk) * NT + nt) * 64 + lane];
-                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e][kk], b, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b, acc[nt], 0, 0, 0);
             }
         }
     }

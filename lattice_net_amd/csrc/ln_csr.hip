@@ -239,6 +239,8 @@ struct LnReduceArgs {
     const float* w;
     int chunks, lanes_per_seg, src_div, src_stride;
     float* dst;
+    int xcd_chunked;  // 1: workgroup b (dispatched to XCD b % 8) takes the (b / 8)-th block of the (b % 8)-th EIGHTH of the segment
+                      // list, so that each XCD walks one contiguous range of it (launch a multiple of 8 workgroups)
 };
 
 // body of the segment reduce for the workgroup `block_x` (of 256 threads)
@@ -256,6 +258,15 @@ __device__ __forceinline__ void ln_reduce_body(int block_x, const LnReduceArgs& 
     float* __restrict__ dst = a.dst;
     const int chunks = a.chunks, lanes_per_seg = a.lanes_per_seg, src_div = a.src_div, src_stride = a.src_stride;
     constexpr int U = 4;
+    if (a.xcd_chunked) {
+        // Segments are emitted bucket by bucket and a bucket holds whole cells of the lattice (LnProbe): a contiguous range of
+        // the list is a set of cells.  One XCD per range => the d+1 gathers of a point's row mostly hit the L2 that fetched it.
+        const int used = int(((long long)*seg_count * lanes_per_seg + 255) / 256);  // workgroups that have segments
+        const int per = (used + 7) >> 3;
+        const int j = block_x >> 3;
+        if (j >= per) return;
+        block_x = (block_x & 7) * per + j;
+    }
     const long long gt = (long long)block_x * 256 + threadIdx.x;
     const long long sid = gt / lanes_per_seg;
     const int lc = int(gt - sid * lanes_per_seg);
@@ -380,7 +391,7 @@ static int ln_reduce_args(const char* who, const LnCsr* csr, const int* grp_row,
     while (lanes < chunks && lanes < 64) lanes <<= 1;
     work = max_segments * lanes;
     if (max_segments > 0) a = LnReduceArgs{csr->grp_start, csr->csr_tok, csr->seg_grp, csr->seg_beg, csr->seg_count, grp_row, src, w, chunks, lanes,
-                                           src_div, src_stride, dst};
+                                           src_div, src_stride, dst, (ln_debug_mask() & 64) ? 1 : 0};
     return LN_OK;
 }
 
@@ -393,7 +404,7 @@ static int ln_csr_reduce_rows_impl(const char* who, const LnCsr* csr, const int*
     if (rc) return rc;
     if (max_segments == 0) return LN_OK;
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid(ln_div_up(work, 256)), block(256);
+    const dim3 grid(8 * ln_div_up(work, 8 * 256)), block(256);  // a multiple of 8: the XCD-chunked order needs whole rounds
     if (half) {
         if (vec4)
             LN_LAUNCH("k_csr_reduce_segments", (k_csr_reduce_segments<4, true>), grid, block, 0, st, a);
@@ -434,7 +445,7 @@ static int ln_splat_tail_impl(const char* who, const LnCsr* csr, const int* grp_
     const int d = table->pos_dim;
     LN_REQUIRE(d >= 1 && d <= LN_MAX_POS_DIM, LN_ERR_UNSUPPORTED, "%s: pos_dim %d unsupported", who, d);
     hipStream_t st = (hipStream_t)stream;
-    const int reduce_blocks = ln_div_up(work, 256);
+    const int reduce_blocks = 8 * ln_div_up(work, 8 * 256);  // a multiple of 8 (XCD-chunked order)
     const int nbr_blocks = ln_div_up((long long)query_rows_upper * (2 * (d + 1) + 1), 256);
     const dim3 grid(reduce_blocks + nbr_blocks), block(256);
 #define LN_FUSED_CASE(DD)                                                                                                              \

@@ -45,6 +45,16 @@ int ln_check_launch(const char* what) {
 
 extern "C" const char* ln_last_error_string(void) { return g_ln_error; }
 
+#include <stdlib.h>
+int ln_debug_mask() {
+    static int mask = -1;
+    if (mask < 0) {
+        const char* e = getenv("LN_DEBUG_MASK");
+        mask = e ? atoi(e) : 0;
+    }
+    return mask;
+}
+
 // ------------------------------------------------------------------------------------------
 // live per-kernel timing: HIP events recorded around each launch of ONE named kernel, on the
 // stream it is launched on (bench.py's roofline line is computed from these)
@@ -201,7 +211,7 @@ __device__ __forceinline__ int ln_insert(const LnTable& t, const int* key, int& 
         return -1;
     }
     const uint64_t pk = KeyPack<D>::pack(key);
-    const LnProbe pr(ln_hash<D>(key), t.capacity, ln_bucket_slots(t.capacity));
+    const LnProbe pr = LnProbe::of_key<D>(key, t.capacity, ln_bucket_slots(t.capacity));
     for (int probes = 0; probes < t.capacity; ++probes) {
         const int h = pr.slot(probes);
         // Plain (cacheable) pre-check: a slot only ever changes EMPTY -> key, so a stale read can only
@@ -278,7 +288,9 @@ __global__ void __launch_bounds__(256)
 // anyway: values and keys zeroed, nr_filled = status = 0, and this build's first-occurrence bitmap.  The bucket
 // cursors live in the first words of t.slot_cnt (zero between builds: the scan pass resets them), word nbk of
 // it collects "a key did not fit the packed format".
-#define LN_KEYS_PTS_PER_THREAD 2
+// points per thread: 2 keeps the (block, bucket) global atomics low; wide lattices take 1 so that the staging arrays fit
+// the 64 KB of static LDS
+#define LN_KEYS_PTS_PER_THREAD ((D) <= 3 ? 2 : 1)
 #define LN_KEYS_PTS_PER_BLOCK (256 * LN_KEYS_PTS_PER_THREAD)
 template <int D>
 __global__ void __launch_bounds__(256)
@@ -288,6 +300,11 @@ __global__ void __launch_bounds__(256)
                  int* __restrict__ seg_count, float* __restrict__ clear_values, long long clear_values_elems,
                  unsigned long long* __restrict__ bitmap, long long bitmap_words) {
     __shared__ int s_cnt[LN_BKT_MAX];
+    __shared__ int s_lbase[LN_BKT_MAX];
+    __shared__ int s_scan_tmp[8];
+    __shared__ unsigned long long s_stage_pk[LN_KEYS_PTS_PER_BLOCK * (D + 1)];
+    __shared__ int s_stage_tok[LN_KEYS_PTS_PER_BLOCK * (D + 1)];
+    __shared__ int s_stage_dst[LN_KEYS_PTS_PER_BLOCK * (D + 1)];
     int* cursor = t.slot_cnt;
     for (int b = threadIdx.x; b < nbk; b += 256) s_cnt[b] = 0;
     {  // clear duties (independent of everything below)
@@ -332,7 +349,7 @@ __global__ void __launch_bounds__(256)
             const bool ok = KeyPack<D>::in_range(key);
             if (ok) {
                 pk[it][r] = KeyPack<D>::pack(key);
-                bkt[it][r] = int(ln_hash<D>(key) % uint32_t(t.capacity)) / sb;
+                bkt[it][r] = LnProbe::of_key<D>(key, t.capacity, sb).lo / sb;
                 rank[it][r] = atomicAdd(&s_cnt[bkt[it][r]], 1);
             } else {
                 bad_key = true;
@@ -351,11 +368,24 @@ __global__ void __launch_bounds__(256)
     }
     if (bad_key) atomicOr(&t.slot_cnt[nbk], 1);
     __syncthreads();
-    for (int b = threadIdx.x; b < nbk; b += 256) {
-        const int c = s_cnt[b];
-        if (c) s_cnt[b] = atomicAdd(&cursor[b], c);
+    // Region cursors (one returning global atomic per (block, bucket), all of a thread row in flight together) and, for the
+    // staged write below, the exclusive prefix of this block's per-bucket counts (one 256-wide scan per row of buckets).
+    int block_tokens = 0;
+    for (int k0 = 0; k0 < nbk; k0 += 256) {  // block-uniform trip count
+        const int b = k0 + threadIdx.x;
+        const int c = b < nbk ? s_cnt[b] : 0;
+        int row_total;
+        const int ex = ln_block_excl_scan_256(c, s_scan_tmp, &row_total);  // (has its own barriers)
+        if (b < nbk) {
+            s_lbase[b] = block_tokens + ex;
+            if (c) s_cnt[b] = atomicAdd(&cursor[b], c);
+        }
+        block_tokens += row_total;
     }
     __syncthreads();
+    // Stage the block's tokens in LDS sorted by bucket, then write them out in that order: the lanes of a wave then cover a
+    // few runs of consecutive region entries instead of 64 different cache lines per store instruction (the scattered form
+    // of these two stores was a third of this kernel's time).
 #pragma unroll
     for (int it = 0; it < LN_KEYS_PTS_PER_THREAD; ++it) {
         const int p = blockIdx.x * LN_KEYS_PTS_PER_BLOCK + it * 256 + threadIdx.x;
@@ -364,13 +394,21 @@ __global__ void __launch_bounds__(256)
             if (bkt[it][r] < 0) continue;
             const int tk = p * (D + 1) + r;
             const int at = s_cnt[bkt[it][r]] + rank[it][r];
-            if (at < capb) {
-                const size_t dst = (size_t)bkt[it][r] * capb + at;
-                part_tok[dst] = tk;
-                part_pk[dst] = pk[it][r];
-            } else {
-                tok_slot[tk] = -1;  // region full (heavily skewed cloud): the bucket workgroup reports it, the build is replayed
-            }
+            const int j = s_lbase[bkt[it][r]] + rank[it][r];
+            s_stage_tok[j] = tk;
+            s_stage_pk[j] = pk[it][r];
+            s_stage_dst[j] = at < capb ? bkt[it][r] * capb + at : -1;  // (regions are < 2^31 entries in total: checked by the host)
+        }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < block_tokens; j += 256) {
+        const int dst = s_stage_dst[j];
+        const int tk = s_stage_tok[j];
+        if (dst >= 0) {
+            part_tok[dst] = tk;
+            part_pk[dst] = s_stage_pk[j];
+        } else {
+            tok_slot[tk] = -1;  // region full (heavily skewed cloud): the bucket workgroup reports it, the build is replayed
         }
     }
 }
@@ -440,7 +478,7 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
         if (valid) {
             int key[D];
             KeyPack<D>::unpack(pk, key);
-            int o = int(ln_hash<D>(key) % uint32_t(t.capacity)) - lo;
+            int o = LnProbe::of_key<D>(key, t.capacity, sb).off;
             for (int i = 0; i < size; ++i) {
                 unsigned long long cur = skeys[o];
                 if (cur == LN_EMPTY_KEY) {
@@ -887,7 +925,8 @@ static int ln_build_points(const LnTable* t, const float* positions_raw, const f
     // (tables past ~14M slots take the atomic path).
     const size_t bucket_lds = (size_t)ln_bucket_slots(t->capacity) * (sizeof(unsigned long long) + 4 * sizeof(int));
     const bool bucketed = n > 0 && (flags & LN_BUILD_CLEAR_FIRST) && !(flags & LN_BUILD_ATOMIC_PATH) &&
-                          t->capacity > ln_bucket_count(t->capacity) && bucket_lds <= LN_BKT_LDS_LIMIT;
+                          t->capacity > ln_bucket_count(t->capacity) && bucket_lds <= LN_BKT_LDS_LIMIT &&
+                          (long long)ln_bucket_count(t->capacity) * ln_bucket_region(tokens, t->capacity) < 0x7FFFFFFFll;  // int region offsets
     LN_REQUIRE(clear_values == nullptr || (reinterpret_cast<uintptr_t>(clear_values) & 15) == 0, LN_ERR_ARG, "%s: clear_values must be 16-byte aligned", who);
     if ((flags & LN_BUILD_CLEAR_FIRST) && !bucketed) {
         rc = ln_table_clear(t, clear_values, clear_values_elems, stream);
