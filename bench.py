@@ -210,6 +210,10 @@ def main():
     ap.add_argument("--mode", default="graph", choices=["graph", "eager"],
                     help="graph (default): the whole step (forward + backward, ~10 launches) is captured ONCE into a hipGraph with the "
                          "lattice in static-rows mode and every timed step is one graph replay; eager: one Python autograd pass per step")
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="graph mode: independent scans in flight per GPU (own cloud, lattice, hipGraph, stream each); the kernels of one "
+                         "scan are latency-bound chains at ~1 workgroup per CU, a second scan fills the idle slots.  1 = strictly one "
+                         "scan after the other")
     ap.add_argument("--row-slack", type=float, default=0.06,
                     help="graph mode: static row bound = vertex count of the calibration step x (1 + slack), rounded up to 256")
     args = ap.parse_args()
@@ -240,88 +244,134 @@ def main():
     d, e = 3, 9
     half = bool(cfg.get("half"))
     # independent clouds per rank (weak scaling); parameters broadcast from rank 0 over RCCL
-    rng = np.random.default_rng(rank)
-    pos = torch.from_numpy(make_cloud(cfg["gen"], n, sharding.cloud_seed(rank))).to(dev)
-    vals = torch.from_numpy(rng.standard_normal((n, v)).astype(np.float32)).to(dev)
-    G = torch.from_numpy(rng.standard_normal((n, f)).astype(np.float32)).to(dev)
-    if cfg.get("half"):
-        vals, G = vals.half(), G.half()
-    bound = float(np.sqrt(3.0) * np.sqrt(2.0) / np.sqrt(f))  # kaiming-uniform fan_out (lattice_modules.py:202-207)
-    W = ((torch.rand((e * v, f), device=dev) * 2 - 1) * bound)
+    bound_w = float(np.sqrt(3.0) * np.sqrt(2.0) / np.sqrt(f))  # kaiming-uniform fan_out (lattice_modules.py:202-207)
+    W = ((torch.rand((e * v, f), device=dev) * 2 - 1) * bound_w)
     sharding.broadcast_parameters(dist, [W], src=0)
     W.requires_grad_(True)
-    lat = L.Lattice(sigmas=[sigma] * d, capacity=cap, device=dev)
-    state = {}
+    in_flight = max(1, args.in_flight) if args.mode == "graph" else 1
 
-    def step():
-        W.grad = None
-        lv, wrap, idx, w = L.SplatLattice.apply(lat, pos, vals)       # clear + hash build + accumulate
-        m = lat.nr_lattice_vertices()                                   # the path's one host readback
-        lv = lv[:m].requires_grad_(True)
-        if half:  # fp16 feature path: fp16 point features, lattice values and filter bank; fp32 accumulation everywhere
-            cv, cwrap = L.ConvIm2RowLattice.apply(lv.half(), lat, W.half(), 1)
-        else:
-            cv, cwrap = L.ConvIm2RowLattice.apply(lv, lat, W, 1)       # neighbour list + gather-GEMM
-        out = L.SliceLattice.apply(cv, cwrap.lattice, pos, idx, w)     # slice
-        out.backward(G)                                                 # slice bwd, conv bwd (values + filter)
-        state.update(m=m, out=out, gv=lv.grad)
+    class CloudSet:
+        """One scan in flight: its own cloud, lattice, captured step and stream."""
+
+        def __init__(self, k):
+            rng = np.random.default_rng(rank + 1000 * k)
+            self.pos = torch.from_numpy(make_cloud(cfg["gen"], n, sharding.cloud_seed(rank, k))).to(dev)
+            self.vals = torch.from_numpy(rng.standard_normal((n, v)).astype(np.float32)).to(dev)
+            self.G = torch.from_numpy(rng.standard_normal((n, f)).astype(np.float32)).to(dev)
+            if half:
+                self.vals, self.G = self.vals.half(), self.G.half()
+            self.lat = L.Lattice(sigmas=[sigma] * d, capacity=cap, device=dev)
+            self.state = {}
+            self.graph = None
+            self.stream = torch.cuda.Stream() if k > 0 else None  # set 0 stays on the current stream
+
+        def step(self):
+            W.grad = None
+            lv, wrap, idx, w = L.SplatLattice.apply(self.lat, self.pos, self.vals)  # clear + hash build + accumulate
+            m = self.lat.nr_lattice_vertices()                                  # eager: the path's one host readback
+            lv = lv[:m].requires_grad_(True)
+            if half:  # fp16 feature path: fp16 point features, lattice values and filter bank; fp32 accumulation everywhere
+                cv, cwrap = L.ConvIm2RowLattice.apply(lv.half(), self.lat, W.half(), 1)
+            else:
+                cv, cwrap = L.ConvIm2RowLattice.apply(lv, self.lat, W, 1)      # neighbour list + gather-GEMM
+            out = L.SliceLattice.apply(cv, cwrap.lattice, self.pos, idx, w)    # slice
+            out.backward(self.G)                                                # slice bwd, conv bwd (values + filter)
+            self.state.update(m=m, out=out, gv=lv.grad, gw=W.grad)
+
+        def capture(self):
+            """Calibrates the static row bound with eager steps, then captures the whole step into one hipGraph."""
+            for _ in range(2):
+                self.step()
+            torch.cuda.synchronize()
+            self.m_real = self.state["m"]
+            self.eager_out = self.state["out"].detach().clone()
+            self.eager_gw = self.state["gw"].detach().clone()
+            rows = min(cap, ((int(self.m_real * (1.0 + args.row_slack)) + 255) // 256) * 256)
+            self.lat.set_static_rows(rows)  # no host readback inside the step: rows m_real..rows-1 are isolated zero vertices
+            # Drop every reference to the eager steps' autograd graphs first: W's AccumulateGrad node lives as long as one
+            # of them does and would run on the stream it was created on, which a capture of another stream cannot include.
+            self.state.clear()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    self.step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self.state.clear()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.step()
+
+        def launch(self):
+            if self.graph is None:
+                self.step()
+            elif self.stream is None:
+                self.graph.replay()
+            else:
+                with torch.cuda.stream(self.stream):
+                    self.graph.replay()
+
+        def check(self):
+            """Replayed build within its bounds, replayed results equal to the eager step's (1e-5 relative)."""
+            nr, _status = self.lat.static_build_report()
+            assert nr == self.m_real, (nr, self.m_real)
+            scale = float(self.eager_out.abs().max())
+            err = {"out_max_rel": float((self.state["out"].detach() - self.eager_out).abs().max()) / max(scale, 1e-30),
+                   "grad_filter_max_rel": float((self.state["gw"] - self.eager_gw).abs().max()) / max(float(self.eager_gw.abs().max()), 1e-30)}
+            if max(err.values()) > 1e-5:
+                raise SystemExit(f"[bench] graph replay differs from the eager step: {err}")
+            return err
 
     def barrier():
         sharding.barrier(dist)
         torch.cuda.synchronize()
 
-    # ---- calibration / eager warm-up: learns the vertex count (and is the reference result for the graph's output)
-    for _ in range(2 if args.mode == "graph" else args.warmup):
-        step()
-    torch.cuda.synchronize()
-    m_real = state["m"]
-    graph = None
+    sets = [CloudSet(k) for k in range(in_flight)]
     graph_err = None
     if args.mode == "graph":
-        eager_out = state["out"].detach().clone()
-        eager_gw = W.grad.detach().clone()
-        bound = min(cap, ((int(m_real * (1.0 + args.row_slack)) + 255) // 256) * 256)
-        lat.set_static_rows(bound)  # no host readback inside the step any more: rows m_real..bound-1 are isolated zero vertices
-        # Drop every reference to the eager steps' autograd graphs first: W's AccumulateGrad node lives as long as one of
-        # them does and would run on the stream it was created on (the default stream), which a capture cannot include.
-        state.clear()
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(2):
-                step()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        state.clear()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            step()
-        run_step = graph.replay
+        for cs in sets:
+            cs.capture()
     else:
-        run_step = step
-    for _ in range(args.warmup):
-        run_step()
+        sets[0].m_real = None
+    for i in range(max(args.warmup, in_flight)):
+        sets[i % in_flight].launch()
     barrier()
-    if graph is not None:
-        nr, _status = lat.static_build_report()  # raises if the replayed build overflowed the bound / a bucket
-        assert nr == m_real, (nr, m_real)
-        scale = float(eager_out.abs().max())
-        graph_err = {"out_max_rel": float((state["out"].detach() - eager_out).abs().max()) / max(scale, 1e-30),
-                     "grad_filter_max_rel": float((W.grad - eager_gw).abs().max()) / max(float(eager_gw.abs().max()), 1e-30)}
-        if max(graph_err.values()) > 1e-5:
-            raise SystemExit(f"[bench] graph replay differs from the eager step: {graph_err}")
+    if args.mode == "graph":
+        errs = [cs.check() for cs in sets]
+        graph_err = {k: max(e[k] for e in errs) for k in errs[0]}
+    else:
+        sets[0].m_real = sets[0].state["m"]
     prof_name = args.roofline_kernel.encode()
-    armed = graph is None and lib.ln_profile_begin(prof_name, 8 * args.steps + 8) == 0
+    armed = args.mode == "eager" and lib.ln_profile_begin(prof_name, 8 * args.steps + 8) == 0
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run_step()
+    for i in range(args.steps):  # K steps = K scans, issued round-robin over the scans in flight
+        sets[i % in_flight].launch()
     barrier()
     elapsed = time.perf_counter() - t0
     total_ms, launches = C.c_double(0.0), C.c_int(0)
     if armed:
         lib.ln_profile_end(C.byref(total_ms), C.byref(launches))
-    if graph is not None:
-        lat.static_build_report()
+    single = None
+    if args.mode == "graph":
+        for cs in sets:
+            cs.check()
+        if in_flight > 1:  # the same captured step, one scan at a time (latency of a scan = what a batch-1 training loop sees)
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                sets[0].launch()
+            torch.cuda.synchronize()
+            dt1 = (time.perf_counter() - t1) / args.steps
+            single = {"what": "one scan in flight (same hipGraph, one stream)", "us_per_step": round(dt1 * 1e6, 1),
+                      "mpoints_per_s": round(n / dt1 / 1e6, 1)}
+    checksum_local = sum(float(cs.state["out"].double().abs().sum().item()) for cs in sets)
+    m_all = [cs.m_real for cs in sets]
+
+    # everything below (per-kernel and per-stage timings) runs eager steps of scan 0
+    cs0 = sets[0]
+    lat, pos, vals, G, state, step = cs0.lat, cs0.pos, cs0.vals, cs0.G, cs0.state, cs0.step
+    m_real = cs0.m_real
+    if args.mode == "graph":
         # Per-kernel HIP-event timing needs host-side event records between the launches, which a graph replay has no
         # room for: the roofline kernel is timed in eager steps of the same workload right after the timed region.
         lat.set_static_rows(None)
@@ -336,7 +386,7 @@ def main():
             armed = True
 
     m = m_real
-    checksum = float(state["out"].double().abs().sum().item())
+    checksum = checksum_local
     max_elapsed = sharding.max_over_ranks(dist, elapsed, dev)
     checksum = sharding.gather_sum(dist, checksum, dev)
 
@@ -431,9 +481,11 @@ def main():
             "vs_baseline": None, "dtype": "f16 features / f32 accumulate" if half else "f32", "data": "synthetic",
             "config": {"workload": cfg["desc"], "points_per_gpu": n, "vertices": m, "val_dim": v, "nr_filters": f,
                        "sharding": f"{world} independent cloud(s), one per GPU", "checksum": round(checksum, 3),
-                       "execution": ("one hipGraph replay per step (whole forward + backward captured once, static row bound)"
-                                     if graph is not None else "eager: Python autograd pass per step"),
-                       "graph_vs_eager": graph_err},
+                       "execution": (f"one hipGraph replay per scan (whole forward + backward captured once, static row bound); "
+                                     f"{in_flight} independent scan(s) in flight per GPU, each with its own lattice, graph and stream; "
+                                     f"K steps = K scans" if args.mode == "graph" else "eager: Python autograd pass per step"),
+                       "scans_in_flight": in_flight, "vertices_per_scan": m_all, "graph_vs_eager": graph_err,
+                       "one_scan_in_flight": single},
             "roofline": roofline, "roofline_others": others, "stages": stages, "full_unet": unet, "cpu_baseline": cpu,
         }
     try:  # RCCL prints a version banner through C stdio, which a pipe buffers until exit: every rank flushes it now
