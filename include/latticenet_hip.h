@@ -72,12 +72,15 @@ typedef struct LnTable {
  * entries (the unit of work of ln_csr_reduce_rows).  A group is a hash slot for the CSR that
  * ln_build_splat / ln_distribute / ln_coarsen emit as a by-product (row of a group = entries[slot]),
  * or a row for ln_csr_build (row of a group = the group). */
+#define LN_XCD_GROUPS 8 /* segment / point / vertex lists are kept per XCD group (see csrc/ln_common.h, LnProbe) */
 typedef struct LnCsr {
     int* grp_start; /* [groups_upper + 1] */
     int* csr_tok;   /* [tokens]           tokens grouped by group */
-    int* seg_grp;   /* [max_segments]     group of each segment */
-    int* seg_beg;   /* [max_segments]     first CSR entry of each segment */
-    int* seg_count; /* [1]                device-side number of segments */
+    int* seg_grp;   /* [LN_XCD_GROUPS * seg_region]  group of each segment; region g holds the segments of XCD group g */
+    int* seg_beg;   /* [LN_XCD_GROUPS * seg_region]  first CSR entry of each segment */
+    int* seg_count; /* [LN_XCD_GROUPS + 1] device-side number of segments per region, then the number of regions in use
+                       (1: everything in region 0 — ln_csr_build, the atomic build path; LN_XCD_GROUPS: bucketed build) */
+    long long seg_region; /* entries per region (>= ln_csr_max_segments: one region may hold every segment) */
 } LnCsr;
 
 const char* ln_last_error_string(void);

@@ -22,6 +22,7 @@ LN_NOT_VISITED = -2
 LN_CONV_FLIP_NEIGHBOURS = 1
 LN_CONV_TRANSPOSED_FILTER = 2
 LN_MAX_POS_DIM = 6
+LN_XCD_GROUPS = 8
 
 
 class LnTable(C.Structure):
@@ -51,6 +52,7 @@ class LnCsr(C.Structure):
         ("seg_grp", C.c_void_p),
         ("seg_beg", C.c_void_p),
         ("seg_count", C.c_void_p),
+        ("seg_region", C.c_longlong),
     ]
 
 

@@ -101,6 +101,10 @@ LN_HD uint32_t ln_hash(const int* key) {
 #define LN_BKT_SLOTS 512
 #endif
 #define LN_BKT_MAX 2048
+#define LN_XCD_GROUPS 8
+#ifndef LN_CELL_SHIFT
+#define LN_CELL_SHIFT (-1)
+#endif
 // At least LN_BKT_MIN_COUNT buckets (one bucket = one workgroup of the build: fewer buckets than CUs leave CUs idle) as long
 // as they keep >= LN_BKT_MIN_SLOTS slots each.
 #ifndef LN_BKT_MIN_COUNT
@@ -115,20 +119,31 @@ LN_HD int ln_bucket_slots(int capacity) {
     }
     if (nb > LN_BKT_MAX) nb = LN_BKT_MAX;
     if (nb < 1) nb = 1;
+    if (nb >= 2 * LN_XCD_GROUPS) nb = (nb / LN_XCD_GROUPS) * LN_XCD_GROUPS;  // whole buckets per XCD group
     return (capacity + nb - 1) / nb;
 }
 LN_HD int ln_bucket_count(int capacity) {
     const int sb = ln_bucket_slots(capacity);
     return (capacity + sb - 1) / sb;
 }
-// Which bucket, and where in it.  Default (LN_CELL_SHIFT < 0): both from the reference's hash, h0 = hash % capacity.
-// Experimental spatial grouping (LN_CELL_SHIFT = s >= 0, tools only): the bucket comes from a hash of the CELL — the cube of
-// 2^s lattice units the key falls in — so that all vertices of a cell share a bucket and the slot-major CSR keeps the tokens
-// of a point together; measured on the C3 scan (s = 4): the segment reduce drops from 17.9 to 13.9 us, but dense cells (256
-// lattice points each) pile up in single buckets and overflow them, so it is off until buckets are balanced per XCD group.
-#ifndef LN_CELL_SHIFT
-#define LN_CELL_SHIFT (-1)
-#endif
+// Slots per XCD group (0 = this table is not grouped: too few buckets).  Group g owns the slots [g * gs, (g + 1) * gs).
+LN_HD int ln_group_slots(int capacity, int sb) {
+    const int nbk = (capacity + sb - 1) / sb;
+    if (LN_CELL_SHIFT < 0 || nbk < 2 * LN_XCD_GROUPS || nbk % LN_XCD_GROUPS != 0) return 0;
+    return (nbk / LN_XCD_GROUPS) * sb;
+}
+// Which slot a key starts probing at.  The table is cut into LN_XCD_GROUPS groups of whole buckets, one per XCD (a MI355X
+// dispatches workgroup b to XCD b % 8, each XCD has its own 4 MB L2).  The GROUP comes from a hash of the key's CELL — the
+// cube of 2^LN_CELL_SHIFT lattice units it falls in — the slot inside the group from the reference's hash of the key.  All
+// vertices of a cell land in one group, spread evenly over its buckets (so bucket loads stay as uniform as with plain
+// hashing); the d+1 vertices of a point's simplex span <= d units per coordinate and mostly share a cell.  The build emits
+// its segment, point and vertex lists per group, and every gather / scatter kernel lets XCD g walk group g's list: a
+// point row or vertex row is then fetched by ~1.4 XCD L2s instead of by every XCD that happens to touch it (d+1 for the
+// scatters, all 8 for the convolution).  The slot layout is internal (only row ids are reference-visible).
+// LN_CELL_SHIFT < 0 switches the grouping off (h0 = hash % capacity) — the DEFAULT: measured on the C3 LiDAR scan with
+// 16-unit cells, the token load of the 8 groups is too uneven (a handful of cells next to the sensor hold most tokens; an
+// XCD cannot borrow CUs): segment reduce 17.4 -> 19.1 us, bucket pass 19.2 -> 23.0 us.  The per-group segment regions
+// and the region walk (ln_csr.h) stay in place for a balanced (work-stealing) version.
 LN_HD uint32_t ln_stir(uint32_t k) {
     k ^= k >> 15;
     k *= 2246822519u;
@@ -154,19 +169,27 @@ struct LnProbe {
         size = (capacity - lo < sb) ? (capacity - lo) : sb;
         off = h0 - lo;
     }
-    // bucket_hash picks the bucket (proportionally to its size), slot_hash the starting slot inside it
-    LN_HD LnProbe(uint32_t bucket_hash, uint32_t slot_hash, int capacity, int sb) {
-        const int h0 = int(bucket_hash % uint32_t(capacity));
+    // grouped form: `group_hash` picks the XCD group, `slot_hash` the starting slot inside the group's slot range
+    LN_HD LnProbe(uint32_t group_hash, uint32_t slot_hash, int capacity, int sb, int gs) {
+        const int glo = int(group_hash % uint32_t(LN_XCD_GROUPS)) * gs;
+        const int gsz = (capacity - glo < gs) ? (capacity - glo) : gs;
+        const int h0 = glo + int(slot_hash % uint32_t(gsz));
         cap = capacity;
         lo = (h0 / sb) * sb;
         size = (capacity - lo < sb) ? (capacity - lo) : sb;
-        off = int(slot_hash % uint32_t(size));
+        off = h0 - lo;
     }
     template <int D>
     static LN_HD LnProbe of_key(const int* key, int capacity, int sb) {
-        if (LN_CELL_SHIFT < 0) return LnProbe(ln_hash<D>(key), capacity, sb);
-        // (the raw hash is a poor slot hash: 2531011 = 7 * 361573 and e.g. a 511-slot bucket is 7 * 73 slots wide)
-        return LnProbe(ln_cell_hash<D>(key), ln_stir(ln_hash<D>(key)), capacity, sb);
+        const int gs = ln_group_slots(capacity, sb);
+        if (gs == 0) return LnProbe(ln_hash<D>(key), capacity, sb);
+        // (the raw hash is a poor slot hash: 2531011 = 7 * 361573, and e.g. 511 = 7 * 73)
+        return LnProbe(ln_cell_hash<D>(key), ln_stir(ln_hash<D>(key)), capacity, sb, gs);
+    }
+    // XCD group of slot h (0 when the table is not grouped)
+    static LN_HD int group_of_slot(int h, int capacity, int sb) {
+        const int gs = ln_group_slots(capacity, sb);
+        return gs ? h / gs : 0;
     }
     LN_HD int slot(int i) const {
         if (i < size) {

@@ -140,7 +140,11 @@ __global__ void __launch_bounds__(256)
         off_seg = ls;
     }
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t == 0) *seg_count = off_seg[(size_t)nb * seg_stride];
+    if (t == 0) {  // one region holds everything
+        seg_count[0] = off_seg[(size_t)nb * seg_stride];
+        for (int g = 1; g < LN_XCD_GROUPS; ++g) seg_count[g] = 0;
+        seg_count[LN_XCD_GROUPS] = 1;
+    }
     if (t <= rows_upper) row_start[t] = (t < rows_upper) ? local_tok[t] + off_tok[(size_t)(t / LN_SCAN_BLOCK) * seg_stride] : off_tok[(size_t)nb * seg_stride];
     if (t < tokens) {
         const int p = pos[t];
@@ -239,13 +243,12 @@ struct LnReduceArgs {
     const float* w;
     int chunks, lanes_per_seg, src_div, src_stride;
     float* dst;
-    int xcd_chunked;  // 1: workgroup b (dispatched to XCD b % 8) takes the (b / 8)-th block of the (b % 8)-th EIGHTH of the segment
-                      // list, so that each XCD walks one contiguous range of it (launch a multiple of 8 workgroups)
+    long long seg_region;
 };
 
-// body of the segment reduce for the workgroup `block_x` (of 256 threads)
+// one block of segments (256 threads)
 template <int VEC, bool HALF>
-__device__ __forceinline__ void ln_reduce_body(int block_x, const LnReduceArgs& a) {
+__device__ __forceinline__ void ln_reduce_chunk(const LnSegOfThread& so, const LnReduceArgs& a) {
     const int* __restrict__ grp_start = a.grp_start;
     const int* __restrict__ csr_tok = a.csr_tok;
     const int* __restrict__ seg_grp = a.seg_grp;
@@ -258,22 +261,12 @@ __device__ __forceinline__ void ln_reduce_body(int block_x, const LnReduceArgs& 
     float* __restrict__ dst = a.dst;
     const int chunks = a.chunks, lanes_per_seg = a.lanes_per_seg, src_div = a.src_div, src_stride = a.src_stride;
     constexpr int U = 4;
-    if (a.xcd_chunked) {
-        // Segments are emitted bucket by bucket and a bucket holds whole cells of the lattice (LnProbe): a contiguous range of
-        // the list is a set of cells.  One XCD per range => the d+1 gathers of a point's row mostly hit the L2 that fetched it.
-        const int used = int(((long long)*seg_count * lanes_per_seg + 255) / 256);  // workgroups that have segments
-        const int per = (used + 7) >> 3;
-        const int j = block_x >> 3;
-        if (j >= per) return;
-        block_x = (block_x & 7) * per + j;
-    }
-    const long long gt = (long long)block_x * 256 + threadIdx.x;
-    const long long sid = gt / lanes_per_seg;
-    const int lc = int(gt - sid * lanes_per_seg);
+    const long long sid = so.sid;
+    const int lc = so.lane_in_seg;
     const int lane = threadIdx.x & 63;
     const int grp_in_wave = lane / lanes_per_seg;
     const int groups_per_wave = 64 / lanes_per_seg;
-    const bool active = sid < *seg_count;
+    const bool active = so.active;
     int grp = -1, beg = 0, rbeg = 0, rend = 0, end = 0, row = -1;
     if (active) {
         grp = seg_grp[sid];
@@ -361,8 +354,15 @@ __device__ __forceinline__ void ln_reduce_body(int block_x, const LnReduceArgs& 
     }
 }
 
+// body of the segment reduce for workgroup `block_x` of `nblocks`
 template <int VEC, bool HALF>
-__global__ void __launch_bounds__(256) k_csr_reduce_segments(LnReduceArgs a) { ln_reduce_body<VEC, HALF>(blockIdx.x, a); }
+__device__ __forceinline__ void ln_reduce_body(int block_x, int nblocks, const LnReduceArgs& a) {
+    for (LnSegWalk wk(block_x, nblocks, a.lanes_per_seg, a.seg_count, a.seg_region); wk.more(); wk.next())
+        ln_reduce_chunk<VEC, HALF>(wk.here(), a);
+}
+
+template <int VEC, bool HALF>
+__global__ void __launch_bounds__(256) k_csr_reduce_segments(LnReduceArgs a) { ln_reduce_body<VEC, HALF>(blockIdx.x, gridDim.x, a); }
 
 // Horizontal fusion of the two launches that follow a splat build and do not depend on each other: workgroups
 // [0, reduce_blocks) accumulate the point features onto the vertices (segment reduce), the rest run the same-level
@@ -372,7 +372,7 @@ template <int VEC, int D, bool HALF>
 __global__ void __launch_bounds__(256)
     k_reduce_and_neighbours(LnReduceArgs a, int reduce_blocks, LnTable t, int query_rows_upper, int* __restrict__ nbr) {
     if ((int)blockIdx.x < reduce_blocks) {
-        ln_reduce_body<VEC, HALF>(blockIdx.x, a);
+        ln_reduce_body<VEC, HALF>(blockIdx.x, reduce_blocks, a);
     } else {
         const long long g = (long long)(blockIdx.x - reduce_blocks) * 256 + threadIdx.x;
         ln_neighbours_body<D>(g, t, query_rows_upper, t, 1.0f, 1, 0, nbr);
@@ -391,7 +391,7 @@ static int ln_reduce_args(const char* who, const LnCsr* csr, const int* grp_row,
     while (lanes < chunks && lanes < 64) lanes <<= 1;
     work = max_segments * lanes;
     if (max_segments > 0) a = LnReduceArgs{csr->grp_start, csr->csr_tok, csr->seg_grp, csr->seg_beg, csr->seg_count, grp_row, src, w, chunks, lanes,
-                                           src_div, src_stride, dst, (ln_debug_mask() & 64) ? 1 : 0};
+                                           src_div, src_stride, dst, csr->seg_region};
     return LN_OK;
 }
 
@@ -404,7 +404,7 @@ static int ln_csr_reduce_rows_impl(const char* who, const LnCsr* csr, const int*
     if (rc) return rc;
     if (max_segments == 0) return LN_OK;
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid(8 * ln_div_up(work, 8 * 256)), block(256);  // a multiple of 8: the XCD-chunked order needs whole rounds
+    const dim3 grid(ln_seg_grid(max_segments, a.lanes_per_seg)), block(256);
     if (half) {
         if (vec4)
             LN_LAUNCH("k_csr_reduce_segments", (k_csr_reduce_segments<4, true>), grid, block, 0, st, a);
@@ -445,7 +445,7 @@ static int ln_splat_tail_impl(const char* who, const LnCsr* csr, const int* grp_
     const int d = table->pos_dim;
     LN_REQUIRE(d >= 1 && d <= LN_MAX_POS_DIM, LN_ERR_UNSUPPORTED, "%s: pos_dim %d unsupported", who, d);
     hipStream_t st = (hipStream_t)stream;
-    const int reduce_blocks = 8 * ln_div_up(work, 8 * 256);  // a multiple of 8 (XCD-chunked order)
+    const int reduce_blocks = ln_seg_grid(max_segments, a.lanes_per_seg);  // a multiple of LN_XCD_GROUPS
     const int nbr_blocks = ln_div_up((long long)query_rows_upper * (2 * (d + 1) + 1), 256);
     const dim3 grid(reduce_blocks + nbr_blocks), block(256);
 #define LN_FUSED_CASE(DD)                                                                                                              \
@@ -502,15 +502,17 @@ __device__ __forceinline__ float ln_ordered_to_float(unsigned int o) {
 // segments of a hot vertex combine with one 64-bit atomicMax.
 __global__ void __launch_bounds__(256)
     k_csr_segment_max(const int* __restrict__ grp_start, const int* __restrict__ csr_tok, const int* __restrict__ seg_grp,
-                      const int* __restrict__ seg_beg, const int* __restrict__ seg_count, const int* __restrict__ grp_row,
-                      const float* __restrict__ src, int channels, unsigned long long* __restrict__ packed) {
-    const long long gt = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long sid = gt / channels;
-    const int c = int(gt - sid * channels);
-    if (sid >= *seg_count) return;
+                      const int* __restrict__ seg_beg, const int* __restrict__ seg_count, long long seg_region,
+                      const int* __restrict__ grp_row, const float* __restrict__ src, int channels,
+                      unsigned long long* __restrict__ packed) {
+  for (LnSegWalk wk(blockIdx.x, gridDim.x, channels, seg_count, seg_region); wk.more(); wk.next()) {
+    const LnSegOfThread so = wk.here();
+    const long long sid = so.sid;
+    const int c = so.lane_in_seg;
+    if (!so.active) continue;
     const int grp = seg_grp[sid];
     const int row = grp_row ? grp_row[grp] : grp;
-    if (row < 0) return;
+    if (row < 0) continue;
     const int beg = seg_beg[sid];
     const int rbeg = grp_start[grp];
     const int rend = grp_start[grp + 1];
@@ -527,6 +529,7 @@ __global__ void __launch_bounds__(256)
         *d = best;
     else
         atomicMax(d, best);
+  }
 }
 
 __global__ void __launch_bounds__(256)
@@ -556,8 +559,9 @@ extern "C" int ln_csr_segment_max(const LnCsr* csr, const int* grp_row, long lon
     if (hipMemsetAsync(packed_ws, 0, (size_t)work * sizeof(unsigned long long), st) != hipSuccess)
         return ln_check_launch("ln_csr_segment_max(memset)");
     if (max_segments > 0)
-        LN_LAUNCH("k_csr_segment_max", k_csr_segment_max, dim3(ln_div_up(max_segments * channels, 256)), dim3(256), 0, st, csr->grp_start,
-                  csr->csr_tok, csr->seg_grp, csr->seg_beg, csr->seg_count, grp_row, src, channels, static_cast<unsigned long long*>(packed_ws));
+        LN_LAUNCH("k_csr_segment_max", k_csr_segment_max, dim3(ln_seg_grid(max_segments, channels)), dim3(256), 0, st, csr->grp_start,
+                  csr->csr_tok, csr->seg_grp, csr->seg_beg, csr->seg_count, csr->seg_region, grp_row, src, channels,
+                  static_cast<unsigned long long*>(packed_ws));
     LN_LAUNCH("k_csr_segment_max_decode", k_csr_segment_max_decode, dim3(ln_div_up(work, 256)), dim3(256), 0, st,
               static_cast<const unsigned long long*>(packed_ws), work, out_max, out_arg);
     return ln_check_launch("ln_csr_segment_max");

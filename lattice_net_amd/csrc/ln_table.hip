@@ -322,7 +322,8 @@ __global__ void __launch_bounds__(256)
         if (g == 0) {
             *t.nr_filled = 0;
             *t.status = 0;   // later passes (bucket build, scan) raise the error bits of this build
-            *seg_count = 0;  // the bucket workgroups of the next launch add to it
+            for (int gi = 0; gi < LN_XCD_GROUPS; ++gi) seg_count[gi] = 0;  // the bucket workgroups of the next launch add to them
+            seg_count[LN_XCD_GROUPS] = ln_group_slots(t.capacity, sb) ? LN_XCD_GROUPS : 1;
         }
     }
     __syncthreads();
@@ -569,7 +570,8 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
         }
         __syncthreads();
     }
-    if (tid == 0) s_seg_base = s_run_seg ? atomicAdd(csr.seg_count, s_run_seg) : 0;
+    const int xg = LnProbe::group_of_slot(lo, t.capacity, sb);  // this bucket's XCD group = its segment region
+    if (tid == 0) s_seg_base = s_run_seg ? atomicAdd(&csr.seg_count[xg], s_run_seg) : 0;
     __syncthreads();
     const int seg_base = s_seg_base;
     const int placed = s_run_tok;
@@ -583,7 +585,7 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
         t.slot_tok[h] = ft;
         const int c = scnt[i];
         if (c) atomicOr(&bitmap[ft >> 6], 1ull << (ft & 63));  // the slot's first occurrence (every slot is new)
-        int sid = seg_base + sseg[i];
+        long long sid = (long long)xg * csr.seg_region + seg_base + sseg[i];
         for (int e = 0; e < c; e += LN_CSR_SEG, ++sid) {
             csr.seg_grp[sid] = h;
             csr.seg_beg[sid] = beg + e;

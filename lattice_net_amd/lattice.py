@@ -397,16 +397,18 @@ class Lattice:
             self.m_hash_table.init(pos_dim, val_dim, self._dev(like))
 
     def _alloc_csr(self, tokens: int, groups_upper: int):
-        """One int32 allocation: grp_start[groups+1] | csr_tok[tokens] | seg_grp[S] | seg_beg[S] | seg_count[1]."""
+        """One int32 allocation: grp_start[groups+1] | csr_tok[tokens] | seg_grp[G*S] | seg_beg[G*S] | seg_count[G+1]
+        (G = LN_XCD_GROUPS segment regions of S = max_segments entries each)."""
         max_seg = _build_sizes(tokens, groups_upper)[2]
         tk = max(tokens, 1)
-        buf = torch.empty((groups_upper + 1 + tk + 2 * max_seg + 1,), dtype=torch.int32, device=self._dev())
+        G = _lib.LN_XCD_GROUPS
+        buf = torch.empty((groups_upper + 1 + tk + 2 * G * max_seg + G + 1,), dtype=torch.int32, device=self._dev())
         base = buf.data_ptr()
         o1 = groups_upper + 1
         o2 = o1 + tk
-        o3 = o2 + max_seg
-        o4 = o3 + max_seg
-        c = _lib.LnCsr(base, base + 4 * o1, base + 4 * o2, base + 4 * o3, base + 4 * o4)
+        o3 = o2 + G * max_seg
+        o4 = o3 + G * max_seg
+        c = _lib.LnCsr(base, base + 4 * o1, base + 4 * o2, base + 4 * o3, base + 4 * o4, max_seg)
         return buf, c, max_seg
 
     def _build(self, positions_raw, write: bool, vals=None, distributed=None):
