@@ -89,13 +89,17 @@ def algorithmic_work(kernel: str, n: int, m: int, d: int, v: int, f: int, e: int
 
 
 def pmc_traffic(kernel: str):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r1_pmc_traffic.json), or None."""
-    path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
-    try:
-        with open(path) as f:
-            return json.load(f).get(kernel, {}).get("traffic_bytes")
-    except OSError:
-        return None
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r<round>_pmc_traffic.json, newest round), or None."""
+    for rnd in (2, 1):
+        path = os.path.join(ROOT, "profiles", f"r{rnd}_pmc_traffic.json")
+        try:
+            with open(path) as f:
+                hit = json.load(f).get(kernel, {}).get("traffic_bytes")
+            if hit is not None:
+                return hit
+        except OSError:
+            continue
+    return None
 
 
 def cpu_baseline(cfg, seconds: float):
