@@ -218,6 +218,9 @@ def main():
                     help="graph mode: independent scans in flight per GPU (own cloud, lattice, hipGraph, stream each); the kernels of one "
                          "scan are latency-bound chains at ~1 workgroup per CU, a second scan fills the idle slots.  1 = strictly one "
                          "scan after the other")
+    ap.add_argument("--regions", type=int, default=int(os.environ.get("LN_BENCH_REGIONS", "0")),
+                    help="1: calibrate kd region planes on the first eager step of every scan (equal token load per region) so that "
+                         "the scatter kernels walk one compact region per XCD")
     ap.add_argument("--row-slack", type=float, default=0.06,
                     help="graph mode: static row bound = vertex count of the calibration step x (1 + slack), rounded up to 256")
     args = ap.parse_args()
@@ -280,12 +283,14 @@ def main():
                 cv, cwrap = L.ConvIm2RowLattice.apply(lv, self.lat, W, 1)      # neighbour list + gather-GEMM
             out = L.SliceLattice.apply(cv, cwrap.lattice, self.pos, idx, w)    # slice
             out.backward(self.G)                                                # slice bwd, conv bwd (values + filter)
-            self.state.update(m=m, out=out, gv=lv.grad, gw=W.grad)
+            self.state.update(m=m, out=out, gv=lv.grad, gw=W.grad, idx=idx)
 
         def capture(self):
             """Calibrates the static row bound with eager steps, then captures the whole step into one hipGraph."""
-            for _ in range(2):
-                self.step()
+            self.step()
+            if args.regions:
+                self.lat.set_region_planes(self.lat.balanced_region_planes(self.state["idx"]))
+            self.step()
             torch.cuda.synchronize()
             self.m_real = self.state["m"]
             self.eager_out = self.state["out"].detach().clone()

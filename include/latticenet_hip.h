@@ -76,11 +76,18 @@ typedef struct LnTable {
 typedef struct LnCsr {
     int* grp_start; /* [groups_upper + 1] */
     int* csr_tok;   /* [tokens]           tokens grouped by group */
-    int* seg_grp;   /* [LN_XCD_GROUPS * seg_region]  group of each segment; region g holds the segments of XCD group g */
-    int* seg_beg;   /* [LN_XCD_GROUPS * seg_region]  first CSR entry of each segment */
+    int* seg_desc;  /* [LN_XCD_GROUPS * seg_region * 4], 16-byte aligned: one descriptor {group, first CSR entry, entries from
+                       there to the end of the group, offset of the first entry inside the group} per segment — everything a
+                       reduce needs about a segment in ONE 16-byte load; region g holds the segments of XCD group g */
     int* seg_count; /* [LN_XCD_GROUPS + 1] device-side number of segments per region, then the number of regions in use
                        (1: everything in region 0 — ln_csr_build, the atomic build path; LN_XCD_GROUPS: bucketed build) */
     long long seg_region; /* entries per region (>= ln_csr_max_segments: one region may hold every segment) */
+    const int* planes;    /* NULL (everything in region 0), or 7 device ints: split planes of a 3-level kd partition of KEY space
+                             into LN_XCD_GROUPS compact regions — key[0] >= planes[0] picks the half, key[1] against
+                             planes[1 + half] the quarter, key[2] against planes[3 + quarter] the region.  A bucketed
+                             build then files every vertex's segments under its region, and the scatter kernels let
+                             XCD r walk region r: the d+1 gathers of a point row meet in ONE L2.  The planes only steer
+                             work placement (any values are correct); balanced ones come from ln_region_planes. */
 } LnCsr;
 
 const char* ln_last_error_string(void);

@@ -49,10 +49,10 @@ class LnCsr(C.Structure):
     _fields_ = [
         ("grp_start", C.c_void_p),
         ("csr_tok", C.c_void_p),
-        ("seg_grp", C.c_void_p),
-        ("seg_beg", C.c_void_p),
+        ("seg_desc", C.c_void_p),
         ("seg_count", C.c_void_p),
         ("seg_region", C.c_longlong),
+        ("planes", C.c_void_p),
     ]
 
 

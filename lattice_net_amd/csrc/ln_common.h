@@ -203,6 +203,16 @@ struct LnProbe {
     }
 };
 
+// Region of a lattice key under the 3-level kd split of key space described at LnCsr.planes (include/latticenet_hip.h).
+template <int D>
+LN_HD int ln_region_of_key(const int* key, const int* planes) {
+    const int k0 = key[0], k1 = key[1 % D], k2 = key[2 % D];
+    int r = (k0 >= planes[0]) ? 1 : 0;
+    r = 2 * r + ((k1 >= planes[1 + r]) ? 1 : 0);
+    r = 2 * r + ((k2 >= planes[3 + r]) ? 1 : 0);
+    return r;
+}
+
 #if defined(__HIPCC__)
 // HashTableGPU::retrieve (HashTableGPU.cuh:491-519) on packed slots: stop at an empty slot or
 // after 300 mismatching probes.

@@ -120,7 +120,7 @@ template <bool GLOBAL_OFFSETS>
 __global__ void __launch_bounds__(256)
     k_csr_fill(const int* __restrict__ idx, const int* __restrict__ pos, long long tokens, int rows_upper,
                const int* __restrict__ local_tok, const int* __restrict__ local_seg, const int* __restrict__ block_tot, int nb,
-               int* __restrict__ row_start, int* __restrict__ csr_tok, int* __restrict__ seg_row, int* __restrict__ seg_beg,
+               const int* __restrict__ grp_cnt, int* __restrict__ row_start, int* __restrict__ csr_tok, int4* __restrict__ seg_desc,
                int* __restrict__ seg_count) {
     extern __shared__ int s_fill[];  // off_tok[nb+1] | off_seg[nb+1] | part[256]
     const int* off_tok;
@@ -155,8 +155,7 @@ __global__ void __launch_bounds__(256)
             csr_tok[rbeg + p] = int(t);
             if (p % LN_SEG == 0) {  // this token opens a segment
                 const int sid = local_seg[row] + off_seg[(size_t)blk * seg_stride] + p / LN_SEG;
-                seg_row[sid] = row;
-                seg_beg[sid] = rbeg + p;
+                seg_desc[sid] = make_int4(row, rbeg + p, grp_cnt[row] - p, p);
             }
         }
     }
@@ -192,11 +191,11 @@ int ln_csr_from_counts(const int* tok_grp, const int* tok_pos, long long tokens,
         // every workgroup re-scans the (few) block totals into LDS: cheaper than one more launch
         const size_t lds = (size_t)(2 * (nb + 1) + 256) * sizeof(int);
         LN_LAUNCH("k_csr_fill", k_csr_fill<false>, dim3(ln_div_up(work, 256)), dim3(256), lds, st, tok_grp, tok_pos, tokens, groups_upper, local_tok,
-                  local_seg, block_tot, nb, csr.grp_start, csr.csr_tok, csr.seg_grp, csr.seg_beg, csr.seg_count);
+                  local_seg, block_tot, nb, grp_cnt, csr.grp_start, csr.csr_tok, reinterpret_cast<int4*>(csr.seg_desc), csr.seg_count);
     } else {
         LN_LAUNCH("k_csr_scan_top", k_csr_scan_top, dim3(1), dim3(256), 0, st, block_tot, nb);
         LN_LAUNCH("k_csr_fill", k_csr_fill<true>, dim3(ln_div_up(work, 256)), dim3(256), 0, st, tok_grp, tok_pos, tokens, groups_upper, local_tok,
-                  local_seg, block_tot, nb, csr.grp_start, csr.csr_tok, csr.seg_grp, csr.seg_beg, csr.seg_count);
+                  local_seg, block_tot, nb, grp_cnt, csr.grp_start, csr.csr_tok, reinterpret_cast<int4*>(csr.seg_desc), csr.seg_count);
     }
     return ln_check_launch("ln_csr_from_counts");
 }
@@ -210,7 +209,7 @@ extern "C" size_t ln_csr_workspace_bytes(long long tokens, int groups_upper) {
 extern "C" int ln_csr_build(const int* idx, long long tokens, int groups_upper, const LnCsr* csr, void* workspace,
                             size_t workspace_bytes, void* stream) {
     LN_REQUIRE(tokens >= 0 && groups_upper >= 1, LN_ERR_ARG, "ln_csr_build: bad sizes");
-    LN_REQUIRE(csr && csr->grp_start && csr->seg_count && (tokens == 0 || (idx && csr->csr_tok && csr->seg_grp && csr->seg_beg)), LN_ERR_ARG,
+    LN_REQUIRE(csr && csr->grp_start && csr->seg_count && (tokens == 0 || (idx && csr->csr_tok && csr->seg_desc)), LN_ERR_ARG,
                "ln_csr_build: null buffer");
     LN_REQUIRE(workspace && workspace_bytes >= ln_csr_workspace_bytes(tokens, groups_upper), LN_ERR_WORKSPACE,
                "ln_csr_build: workspace too small");
@@ -235,8 +234,7 @@ extern "C" int ln_csr_build(const int* idx, long long tokens, int groups_upper, 
 struct LnReduceArgs {
     const int* grp_start;
     const int* csr_tok;
-    const int* seg_grp;
-    const int* seg_beg;
+    const int4* seg_desc;
     const int* seg_count;
     const int* grp_row;
     const void* src;  // float rows, or _Float16 rows for the HALF instantiations (accumulation and dst stay fp32)
@@ -244,16 +242,18 @@ struct LnReduceArgs {
     int chunks, lanes_per_seg, src_div, src_stride;
     float* dst;
     long long seg_region;
+    int dbg_plain;  // experiment: plain stores instead of atomics (wrong sums, timing only)
 };
 
-// one block of segments (256 threads)
+// one block of segments (256 threads).  Per segment: descriptor -> row -> batches of 4 tokens {4 ids} -> {4 weights, 4 row chunks}.
+// Measured on MI355X (C3, 17.5 us): the kernel is insensitive to the length of this dependency chain — prefetching the next
+// batch's ids with the current gathers (6 trips instead of 10): 18.4 us; all 16 ids + 8 gathers in flight (4 trips, 128
+// VGPRs): 19.3 us; plain stores instead of the hot-vertex atomics: no change; 44 MB instead of 79 MB of L2 misses (kd
+// regions, LnCsr.planes): no change.
 template <int VEC, bool HALF>
 __device__ __forceinline__ void ln_reduce_chunk(const LnSegOfThread& so, const LnReduceArgs& a) {
-    const int* __restrict__ grp_start = a.grp_start;
     const int* __restrict__ csr_tok = a.csr_tok;
-    const int* __restrict__ seg_grp = a.seg_grp;
-    const int* __restrict__ seg_beg = a.seg_beg;
-    const int* __restrict__ seg_count = a.seg_count;
+    const int4* __restrict__ seg_desc = a.seg_desc;
     const int* __restrict__ grp_row = a.grp_row;
     const float* __restrict__ src = static_cast<const float*>(a.src);
     const _Float16* __restrict__ src16 = static_cast<const _Float16*>(a.src);
@@ -261,23 +261,26 @@ __device__ __forceinline__ void ln_reduce_chunk(const LnSegOfThread& so, const L
     float* __restrict__ dst = a.dst;
     const int chunks = a.chunks, lanes_per_seg = a.lanes_per_seg, src_div = a.src_div, src_stride = a.src_stride;
     constexpr int U = 4;
-    const long long sid = so.sid;
     const int lc = so.lane_in_seg;
     const int lane = threadIdx.x & 63;
     const int grp_in_wave = lane / lanes_per_seg;
     const int groups_per_wave = 64 / lanes_per_seg;
     const bool active = so.active;
-    int grp = -1, beg = 0, rbeg = 0, rend = 0, end = 0, row = -1;
+    int grp = -1, beg = 0, rbeg = 0, rend = 0, cnt = 0, row = -1;
     if (active) {
-        grp = seg_grp[sid];
-        beg = seg_beg[sid];
-        rbeg = grp_start[grp];
-        rend = grp_start[grp + 1];
-        end = min(beg + LN_SEG, rend);
-        row = grp_row ? grp_row[grp] : grp;  // groups are hash slots (row = entries[slot]) or rows themselves
+        const int4 d = seg_desc[so.sid];  // {group, first entry, entries to the end of the group, offset inside the group}
+        grp = d.x;
+        beg = d.y;
+        cnt = min(LN_SEG, d.z);
+        rbeg = beg - d.w;
+        rend = beg + d.z;
     }
+    const int end = beg + cnt;
+    if (active) row = grp_row ? grp_row[grp] : grp;  // groups are hash slots (row = entries[slot]) or rows themselves
     const int V = chunks * VEC;
     const int nchunk_iter = (chunks + lanes_per_seg - 1) / lanes_per_seg;  // wave-uniform trip count (shuffles inside)
+    const bool pow2 = (src_div & (src_div - 1)) == 0;
+    const int shift = __ffs(src_div) - 1;
     for (int it = 0; it < nchunk_iter; ++it) {
         const int c = lc + it * lanes_per_seg;
         const bool cok = active && row >= 0 && c < chunks;
@@ -287,18 +290,20 @@ __device__ __forceinline__ void ln_reduce_chunk(const LnSegOfThread& so, const L
         if (cok) {
             for (int e0 = beg; e0 < end; e0 += U) {
                 int tk[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) tk[u] = (e0 + u < end) ? csr_tok[e0 + u] : -1;
                 float wt[U];
                 float x[U][VEC];
 #pragma unroll
-                for (int u = 0; u < U; ++u) tk[u] = (e0 + u < end) ? csr_tok[e0 + u] : -1;
-#pragma unroll
                 for (int u = 0; u < U; ++u) {
+                    const int t = tk[u];
                     wt[u] = 0.f;
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) x[u][k] = 0.f;
-                    if (tk[u] >= 0) {
-                        wt[u] = w[tk[u]];
-                        const size_t off = (size_t)(tk[u] / src_div) * src_stride + c * VEC;
+                    if (t >= 0) {
+                        wt[u] = w[t];
+                        const int srow = pow2 ? (t >> shift) : (t / src_div);
+                        const size_t off = (size_t)srow * src_stride + c * VEC;
                         if constexpr (HALF) {
                             if constexpr (VEC == 4) {
                                 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -340,7 +345,7 @@ __device__ __forceinline__ void ln_reduce_chunk(const LnSegOfThread& so, const L
         const bool head = (grp_in_wave == 0) || (prev_grp != grp);
         if (cok && head) {
             float* d = dst + (size_t)row * V + c * VEC;
-            if (beg == rbeg && run_end == rend) {  // this run is the whole group: no other writer
+            if ((beg == rbeg && run_end == rend) || a.dbg_plain) {  // this run is the whole group: no other writer
                 if constexpr (VEC == 4) {
                     *reinterpret_cast<float4*>(d) = make_float4(acc[0], acc[1], acc[2], acc[3]);
                 } else {
@@ -382,7 +387,7 @@ __global__ void __launch_bounds__(256)
 static int ln_reduce_args(const char* who, const LnCsr* csr, const int* grp_row, long long max_segments, const void* src, bool half,
                           const float* w, int val_dim, int src_div, int src_stride, float* dst, LnReduceArgs& a, bool& vec4, long long& work) {
     LN_REQUIRE(max_segments >= 0 && val_dim >= 1 && src_div >= 1 && src_stride >= val_dim, LN_ERR_ARG, "%s: bad sizes", who);
-    LN_REQUIRE(max_segments == 0 || (csr && csr->grp_start && csr->csr_tok && csr->seg_grp && csr->seg_beg && csr->seg_count && src && w && dst),
+    LN_REQUIRE(max_segments == 0 || (csr && csr->grp_start && csr->csr_tok && csr->seg_desc && csr->seg_count && src && w && dst),
                LN_ERR_ARG, "%s: null buffer", who);
     vec4 = (val_dim % 4 == 0) && (src_stride % 4 == 0) && ((reinterpret_cast<uintptr_t>(src) & (half ? 7 : 15)) == 0) &&
            ((reinterpret_cast<uintptr_t>(dst) & 15) == 0);
@@ -390,8 +395,8 @@ static int ln_reduce_args(const char* who, const LnCsr* csr, const int* grp_row,
     int lanes = 1;
     while (lanes < chunks && lanes < 64) lanes <<= 1;
     work = max_segments * lanes;
-    if (max_segments > 0) a = LnReduceArgs{csr->grp_start, csr->csr_tok, csr->seg_grp, csr->seg_beg, csr->seg_count, grp_row, src, w, chunks, lanes,
-                                           src_div, src_stride, dst, csr->seg_region};
+    if (max_segments > 0) a = LnReduceArgs{csr->grp_start, csr->csr_tok, reinterpret_cast<const int4*>(csr->seg_desc), csr->seg_count, grp_row, src, w, chunks, lanes,
+                                           src_div, src_stride, dst, csr->seg_region, (ln_debug_mask() & 128) ? 1 : 0};
     return LN_OK;
 }
 
@@ -501,8 +506,7 @@ __device__ __forceinline__ float ln_ordered_to_float(unsigned int o) {
 // (ordered value in the high word, ~token in the low word -> ties go to the smallest token) so that the
 // segments of a hot vertex combine with one 64-bit atomicMax.
 __global__ void __launch_bounds__(256)
-    k_csr_segment_max(const int* __restrict__ grp_start, const int* __restrict__ csr_tok, const int* __restrict__ seg_grp,
-                      const int* __restrict__ seg_beg, const int* __restrict__ seg_count, long long seg_region,
+    k_csr_segment_max(const int* __restrict__ csr_tok, const int4* __restrict__ seg_desc, const int* __restrict__ seg_count, long long seg_region,
                       const int* __restrict__ grp_row, const float* __restrict__ src, int channels,
                       unsigned long long* __restrict__ packed) {
   for (LnSegWalk wk(blockIdx.x, gridDim.x, channels, seg_count, seg_region); wk.more(); wk.next()) {
@@ -510,13 +514,13 @@ __global__ void __launch_bounds__(256)
     const long long sid = so.sid;
     const int c = so.lane_in_seg;
     if (!so.active) continue;
-    const int grp = seg_grp[sid];
+    const int4 sd = seg_desc[sid];
+    const int grp = sd.x;
     const int row = grp_row ? grp_row[grp] : grp;
     if (row < 0) continue;
-    const int beg = seg_beg[sid];
-    const int rbeg = grp_start[grp];
-    const int rend = grp_start[grp + 1];
-    const int end = min(beg + LN_SEG, rend);
+    const int beg = sd.y;
+    const int end = beg + min(LN_SEG, sd.z);
+    const bool only_segment = sd.w == 0 && sd.z <= LN_SEG;
     unsigned long long best = 0ull;
     for (int e = beg; e < end; ++e) {
         const int t = csr_tok[e];
@@ -525,7 +529,7 @@ __global__ void __launch_bounds__(256)
         best = p > best ? p : best;
     }
     unsigned long long* d = packed + (size_t)row * channels + c;
-    if (rend - rbeg <= LN_SEG)
+    if (only_segment)
         *d = best;
     else
         atomicMax(d, best);
@@ -550,7 +554,7 @@ __global__ void __launch_bounds__(256)
 extern "C" int ln_csr_segment_max(const LnCsr* csr, const int* grp_row, long long max_segments, const float* src, int channels,
                                   int rows, void* packed_ws, float* out_max, int* out_arg, void* stream) {
     LN_REQUIRE(max_segments >= 0 && channels >= 1 && rows >= 0, LN_ERR_ARG, "ln_csr_segment_max: bad sizes");
-    LN_REQUIRE(rows == 0 || (csr && csr->grp_start && csr->csr_tok && csr->seg_grp && csr->seg_beg && csr->seg_count && src && packed_ws &&
+    LN_REQUIRE(rows == 0 || (csr && csr->grp_start && csr->csr_tok && csr->seg_desc && csr->seg_count && src && packed_ws &&
                              out_max && out_arg),
                LN_ERR_ARG, "ln_csr_segment_max: null buffer");
     if (rows == 0) return LN_OK;
@@ -559,8 +563,8 @@ extern "C" int ln_csr_segment_max(const LnCsr* csr, const int* grp_row, long lon
     if (hipMemsetAsync(packed_ws, 0, (size_t)work * sizeof(unsigned long long), st) != hipSuccess)
         return ln_check_launch("ln_csr_segment_max(memset)");
     if (max_segments > 0)
-        LN_LAUNCH("k_csr_segment_max", k_csr_segment_max, dim3(ln_seg_grid(max_segments, channels)), dim3(256), 0, st, csr->grp_start,
-                  csr->csr_tok, csr->seg_grp, csr->seg_beg, csr->seg_count, csr->seg_region, grp_row, src, channels,
+        LN_LAUNCH("k_csr_segment_max", k_csr_segment_max, dim3(ln_seg_grid(max_segments, channels)), dim3(256), 0, st, csr->csr_tok,
+                  reinterpret_cast<const int4*>(csr->seg_desc), csr->seg_count, csr->seg_region, grp_row, src, channels,
                   static_cast<unsigned long long*>(packed_ws));
     LN_LAUNCH("k_csr_segment_max_decode", k_csr_segment_max_decode, dim3(ln_div_up(work, 256)), dim3(256), 0, st,
               static_cast<const unsigned long long*>(packed_ws), work, out_max, out_arg);

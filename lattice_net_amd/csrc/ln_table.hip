@@ -297,7 +297,7 @@ __global__ void __launch_bounds__(256)
     k_point_keys(LnTable t, const float* __restrict__ pos_raw, LnScale<D> sc, int n, int sb, int nbk, int capb,
                  int* __restrict__ part_tok, unsigned long long* __restrict__ part_pk, int* __restrict__ tok_slot,
                  float* __restrict__ w, const float* __restrict__ vals, int val_dim, float* __restrict__ distributed,
-                 int* __restrict__ seg_count, float* __restrict__ clear_values, long long clear_values_elems,
+                 int* __restrict__ seg_count, int seg_regions, float* __restrict__ clear_values, long long clear_values_elems,
                  unsigned long long* __restrict__ bitmap, long long bitmap_words) {
     __shared__ int s_cnt[LN_BKT_MAX];
     __shared__ int s_lbase[LN_BKT_MAX];
@@ -323,7 +323,7 @@ __global__ void __launch_bounds__(256)
             *t.nr_filled = 0;
             *t.status = 0;   // later passes (bucket build, scan) raise the error bits of this build
             for (int gi = 0; gi < LN_XCD_GROUPS; ++gi) seg_count[gi] = 0;  // the bucket workgroups of the next launch add to them
-            seg_count[LN_XCD_GROUPS] = ln_group_slots(t.capacity, sb) ? LN_XCD_GROUPS : 1;
+            seg_count[LN_XCD_GROUPS] = seg_regions;
         }
     }
     __syncthreads();
@@ -431,6 +431,7 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
     int* sseg = soff + sb;
     __shared__ int s_wave_tok[16], s_wave_seg[16];
     __shared__ int s_run_tok, s_run_seg, s_seg_base;
+    __shared__ int s_rcnt[LN_XCD_GROUPS], s_rbase[LN_XCD_GROUPS];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -452,6 +453,7 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
         s_run_tok = 0;
         s_run_seg = 0;
     }
+    if (tid < LN_XCD_GROUPS) s_rcnt[tid] = 0;
     const int ntok = min(cursor[b], capb);
     if (tid == 0 && cursor[b] > capb) atomicOr(t.status, LN_STATUS_BUCKET_OVERFLOW);  // region overflow: tokens were dropped
     const size_t in0 = (size_t)b * capb;
@@ -570,10 +572,26 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
         }
         __syncthreads();
     }
-    const int xg = LnProbe::group_of_slot(lo, t.capacity, sb);  // this bucket's XCD group = its segment region
-    if (tid == 0) s_seg_base = s_run_seg ? atomicAdd(&csr.seg_count[xg], s_run_seg) : 0;
+    // Segment ids.  Without region planes: one contiguous run of region 0 per bucket.  With planes: every slot files its
+    // segments under the kd region of its key (sseg[i] becomes region << 28 | position among this bucket's segments of that
+    // region; one returning global atomic per (bucket, region)).
+    const int* planes = csr.planes;
+    if (planes) {
+        for (int i = tid; i < size; i += LN_BKT_THREADS) {
+            const int c = scnt[i];
+            if (c) {
+                int key[D];
+                KeyPack<D>::unpack(skeys[i], key);
+                const int r = ln_region_of_key<D>(key, planes);
+                sseg[i] = (r << 28) | atomicAdd(&s_rcnt[r], (c + LN_CSR_SEG - 1) / LN_CSR_SEG);
+            }
+        }
+        __syncthreads();
+        if (tid < LN_XCD_GROUPS) s_rbase[tid] = s_rcnt[tid] ? atomicAdd(&csr.seg_count[tid], s_rcnt[tid]) : 0;
+    } else if (tid == 0) {
+        s_rbase[0] = s_run_seg ? atomicAdd(&csr.seg_count[0], s_run_seg) : 0;
+    }
     __syncthreads();
-    const int seg_base = s_seg_base;
     const int placed = s_run_tok;
     for (int i = tid; i < size; i += LN_BKT_THREADS) {
         const int h = lo + i;
@@ -585,11 +603,10 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
         t.slot_tok[h] = ft;
         const int c = scnt[i];
         if (c) atomicOr(&bitmap[ft >> 6], 1ull << (ft & 63));  // the slot's first occurrence (every slot is new)
-        long long sid = (long long)xg * csr.seg_region + seg_base + sseg[i];
-        for (int e = 0; e < c; e += LN_CSR_SEG, ++sid) {
-            csr.seg_grp[sid] = h;
-            csr.seg_beg[sid] = beg + e;
-        }
+        const int sr = planes ? (sseg[i] >> 28) : 0;
+        long long sid = (long long)sr * csr.seg_region + s_rbase[sr] + (planes ? (sseg[i] & 0x0FFFFFFF) : sseg[i]);
+        for (int e = 0; e < c; e += LN_CSR_SEG, ++sid)
+            reinterpret_cast<int4*>(csr.seg_desc)[sid] = make_int4(h, beg + e, c - e, e);
     }
     if (b == nbk - 1 && tid == 0) csr.grp_start[t.capacity] = base + ntok;
 #pragma unroll
@@ -665,19 +682,17 @@ __global__ void __launch_bounds__(256)
 // segment minimum -> smallest token per slot (defines the canonical row order)
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-    k_seg_min(LnTable t, const int* __restrict__ slot_start, const int* __restrict__ csr_tok, const int* __restrict__ seg_slot,
-              const int* __restrict__ seg_beg, const int* __restrict__ seg_count) {
+    k_seg_min(LnTable t, const int* __restrict__ csr_tok, const int4* __restrict__ seg_desc, const int* __restrict__ seg_count) {
     const int sid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (sid >= *seg_count) return;
-    const int h = seg_slot[sid];
-    const int beg = seg_beg[sid];
-    const int sbeg = slot_start[h];
-    const int send = slot_start[h + 1];
-    const int end = min(beg + LN_CSR_SEG, send);
+    if (sid >= *seg_count) return;  // (the atomic build path files every segment under region 0)
+    const int4 d = seg_desc[sid];  // {slot, first entry, entries to the end of the slot, offset inside the slot}
+    const int h = d.x;
+    const int beg = d.y;
+    const int end = beg + min(LN_CSR_SEG, d.z);
     unsigned int mn = LN_EMPTY_TOK;
     for (int e = beg; e < end; ++e) mn = min(mn, (unsigned int)csr_tok[e]);
     t.slot_cnt[h] = 0;  // the counts were consumed by the scan: keep the invariant "all zero between builds"
-    if (send - sbeg <= LN_CSR_SEG)
+    if (d.w == 0 && d.z <= LN_CSR_SEG)
         t.slot_tok[h] = mn;  // the slot's only segment
     else
         atomicMin(&t.slot_tok[h], mn);
@@ -879,8 +894,8 @@ static int ln_rank_and_finalize(const LnTable& t, const int* tok_slot, const int
     int rc = ln_csr_from_counts(tok_slot, tok_pos, tokens, t.slot_cnt, t.capacity, csr, ws.csr_ws, ws.csr_ws_bytes, st);
     if (rc) return rc;
     const long long max_seg = ln_csr_max_segments(tokens, t.capacity);
-    LN_LAUNCH("k_seg_min", k_seg_min, dim3(ln_div_up(max_seg, 256)), dim3(256), 0, st, t, csr.grp_start, csr.csr_tok, csr.seg_grp,
-              csr.seg_beg, csr.seg_count);
+    LN_LAUNCH("k_seg_min", k_seg_min, dim3(ln_div_up(max_seg, 256)), dim3(256), 0, st, t, csr.csr_tok,
+              reinterpret_cast<const int4*>(csr.seg_desc), csr.seg_count);
     return ln_rank_rows<D>(t, tok_slot, idx_out, tokens, ws, false, st);
 }
 
@@ -900,7 +915,7 @@ static int ln_rank_rows(const LnTable& t, const int* tok_slot, int* idx_out, lon
 }
 
 static int ln_check_csr(const LnCsr* c, const char* who) {
-    LN_REQUIRE(c && c->grp_start && c->csr_tok && c->seg_grp && c->seg_beg && c->seg_count, LN_ERR_ARG, "%s: CSR output has a null buffer", who);
+    LN_REQUIRE(c && c->grp_start && c->csr_tok && c->seg_desc && (reinterpret_cast<uintptr_t>(c->seg_desc) & 15) == 0 && c->seg_count, LN_ERR_ARG, "%s: CSR output has a null buffer", who);
     return LN_OK;
 }
 
@@ -945,7 +960,7 @@ static int ln_build_points(const LnTable* t, const float* positions_raw, const f
             const size_t lds = bucket_lds;
             LN_LAUNCH("k_point_keys", k_point_keys<D>, dim3(ln_div_up(n, LN_KEYS_PTS_PER_BLOCK)), dim3(256), 0, st, *t, positions_raw, sc, n, sb,
                       nbk, ws.capb, ws.part_tok, ws.part_pk, tok_slot, write_idx ? w : (float*)nullptr, vals, val_dim, distributed,
-                      csr->seg_count, clear_values, clear_values_elems, ws.bitmap, (long long)ws.nb * 4);
+                      csr->seg_count, csr->planes ? LN_XCD_GROUPS : 1, clear_values, clear_values_elems, ws.bitmap, (long long)ws.nb * 4);
             LN_LAUNCH("k_bucket_build", k_bucket_build<D>, dim3(nbk), dim3(LN_BKT_THREADS), lds, st, *t, sb, nbk, ws.capb, t->slot_cnt,
                       ws.part_tok, ws.part_pk, ws.part_slot, ws.part_pos, tok_slot, *csr, ws.bitmap);
             rc = ln_rank_rows<D>(*t, tok_slot, write_idx ? idx : (int*)nullptr, tokens, ws, true, st);

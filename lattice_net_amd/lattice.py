@@ -68,6 +68,7 @@ class _TableStorage:
         self.nbr_cache = {}
         self.csr_cache = {}
         self.replay = None  # [rebuild on the atomic path, then the work queued behind the build], see Lattice._build
+        self.planes = None  # int32[8] device tensor: kd split planes of key space (LnCsr.planes), None = no regions
 
     def clone(self) -> "_TableStorage":
         s = _TableStorage.__new__(_TableStorage)
@@ -82,6 +83,7 @@ class _TableStorage:
         s.nbr_cache = {}
         s.csr_cache = {}
         s.replay = None
+        s.planes = self.planes
         return s
 
     def touch(self):
@@ -396,19 +398,18 @@ class Lattice:
         if not self.m_hash_table.is_initialized():
             self.m_hash_table.init(pos_dim, val_dim, self._dev(like))
 
-    def _alloc_csr(self, tokens: int, groups_upper: int):
-        """One int32 allocation: grp_start[groups+1] | csr_tok[tokens] | seg_grp[G*S] | seg_beg[G*S] | seg_count[G+1]
-        (G = LN_XCD_GROUPS segment regions of S = max_segments entries each)."""
+    def _alloc_csr(self, tokens: int, groups_upper: int, planes=None):
+        """One int32 allocation: seg_desc[G*S*4] (16-byte aligned) | grp_start[groups+1] | csr_tok[tokens] | seg_count[G+1]
+        (G = LN_XCD_GROUPS segment regions of S = max_segments descriptors each)."""
         max_seg = _build_sizes(tokens, groups_upper)[2]
         tk = max(tokens, 1)
         G = _lib.LN_XCD_GROUPS
-        buf = torch.empty((groups_upper + 1 + tk + 2 * G * max_seg + G + 1,), dtype=torch.int32, device=self._dev())
-        base = buf.data_ptr()
-        o1 = groups_upper + 1
-        o2 = o1 + tk
-        o3 = o2 + G * max_seg
-        o4 = o3 + G * max_seg
-        c = _lib.LnCsr(base, base + 4 * o1, base + 4 * o2, base + 4 * o3, base + 4 * o4, max_seg)
+        buf = torch.empty((4 * G * max_seg + groups_upper + 1 + tk + G + 1,), dtype=torch.int32, device=self._dev())
+        base = buf.data_ptr()  # torch allocations are at least 256-byte aligned
+        o1 = 4 * G * max_seg
+        o2 = o1 + groups_upper + 1
+        o3 = o2 + tk
+        c = _lib.LnCsr(base + 4 * o1, base + 4 * o2, base, base + 4 * o3, max_seg, _lib.ptr(planes))
         return buf, c, max_seg
 
     def _build(self, positions_raw, write: bool, vals=None, distributed=None):
@@ -421,9 +422,9 @@ class Lattice:
             w = torch.empty((n * (d + 1),), dtype=torch.float32, device=dev)
         tokens = n * (d + 1)
         cap = ht.capacity()
-        csr_buf, csr, max_seg = self._alloc_csr(tokens, cap)
-        clear_vals, do_clear = ht.take_pending_clear()  # begin_splat's clear rides in the same C call
         st = ht._storage
+        csr_buf, csr, max_seg = self._alloc_csr(tokens, cap, st.planes)
+        clear_vals, do_clear = ht.take_pending_clear()  # begin_splat's clear rides in the same C call
 
         def issue(force_atomic: bool):
             lib = _lib.load()
@@ -1074,6 +1075,48 @@ class Lattice:
         if rows_bound < 1 or rows_bound > ht.capacity():
             raise ValueError(f"static row bound {rows_bound} must be in [1, capacity={ht.capacity()}]")
         ht._static_rows = rows_bound
+
+    def set_region_planes(self, planes):
+        """kd split planes of key space (7 ints, see LnCsr.planes) or None.  With planes, the builds of this lattice file the
+        CSR segments of every vertex under one of 8 compact regions and the scatter kernels let XCD r walk region r."""
+        st = self.m_hash_table._storage
+        if st is None:
+            raise _lib.LatticeNetHipError("build the lattice once before setting region planes")
+        if planes is None:
+            st.planes = None
+            return
+        p = torch.as_tensor(planes, dtype=torch.int32).reshape(-1)
+        if p.numel() != 7:
+            raise ValueError("region planes: 7 ints (1 + 2 + 4 thresholds)")
+        st.planes = torch.cat([p, torch.zeros(1, dtype=torch.int32)]).to(self._dev())
+
+    def balanced_region_planes(self, idx: torch.Tensor):
+        """Planes that split the vertices of the CURRENT build into 8 regions of equal token load: weighted medians of
+        key[0], then key[1] inside each half, then key[2] inside each quarter (host-side calibration helper)."""
+        m = self.nr_lattice_vertices()
+        keys = self.m_hash_table._storage.keys[:m].cpu().numpy().astype("int64")
+        wts = self.vertex_point_counts(idx).cpu().numpy().astype("float64")
+        import numpy as np
+        d = keys.shape[1]
+
+        def wmedian(vals, w):
+            if len(vals) == 0:
+                return 0
+            order = np.argsort(vals, kind="stable")
+            cs = np.cumsum(w[order])
+            return int(vals[order][min(np.searchsorted(cs, cs[-1] / 2.0), len(vals) - 1)])  # region test is key >= plane
+
+        planes = [0] * 7
+        planes[0] = wmedian(keys[:, 0], wts)
+        half = (keys[:, 0] >= planes[0]).astype(int)
+        for h in range(2):
+            sel = half == h
+            planes[1 + h] = wmedian(keys[sel, 1 % d], wts[sel])
+        quarter = 2 * half + (keys[:, 1 % d] >= np.where(half == 1, planes[2], planes[1])).astype(int)
+        for q in range(4):
+            sel = quarter == q
+            planes[3 + q] = wmedian(keys[sel, 2 % d], wts[sel])
+        return planes
 
     def static_build_report(self):
         """(vertex count, status bits) of the last build as its scan kernel wrote them to pinned host memory.  Call after
