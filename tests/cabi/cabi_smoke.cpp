@@ -84,8 +84,11 @@ int main() {
     HIPCHECK(hipMemcpy(d_vals, ones.data(), ones.size() * sizeof(float), hipMemcpyHostToDevice));
 
     const long long S = ln_csr_max_segments(tokens, cap);
-    int* csr_buf = dmalloc<int>((size_t)cap + 1 + tokens + 2 * S + 1);
-    LnCsr csr{csr_buf, csr_buf + cap + 1, csr_buf + cap + 1 + tokens, csr_buf + cap + 1 + tokens + S, csr_buf + cap + 1 + tokens + 2 * S};
+    // seg_desc[G*S*4] first (16-byte aligned: hipMalloc is) | grp_start[cap+1] | csr_tok[tokens] | seg_count[G+1]
+    const size_t G = LN_XCD_GROUPS;
+    int* csr_buf = dmalloc<int>(4 * G * S + (size_t)cap + 1 + tokens + G + 1);
+    int* c0 = csr_buf + 4 * G * S;
+    LnCsr csr{c0, c0 + cap + 1, csr_buf, c0 + cap + 1 + tokens, S, nullptr};
     const size_t ws_bytes = ln_build_workspace_bytes(tokens, cap);
     void* ws = nullptr;
     HIPCHECK(hipMalloc(&ws, ws_bytes));
