@@ -249,7 +249,7 @@ struct LnReduceArgs {
 // Measured on MI355X (C3, 17.5 us): the kernel is insensitive to the length of this dependency chain — prefetching the next
 // batch's ids with the current gathers (6 trips instead of 10): 18.4 us; all 16 ids + 8 gathers in flight (4 trips, 128
 // VGPRs): 19.3 us; plain stores instead of the hot-vertex atomics: no change; 44 MB instead of 79 MB of L2 misses (kd
-// regions, LnCsr.planes): no change.
+// regions, LnCsr.planes): no change; 71 instead of 104 SGPRs (8 instead of 6 workgroups per CU admitted): no change.
 template <int VEC, bool HALF>
 __device__ __forceinline__ void ln_reduce_chunk(const LnSegOfThread& so, const LnReduceArgs& a) {
     const int* __restrict__ csr_tok = a.csr_tok;
