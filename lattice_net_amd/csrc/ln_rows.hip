@@ -100,10 +100,12 @@ extern "C" int ln_slice_backward(const float* grad_sliced, const int* idx, const
 // ------------------------------------------------------------------------------------------
 // slice forward (LatticeGPU.cuh:2567-2591): out[p,:] = sum_r values[idx_r,:] * w_r, r ascending
 // ------------------------------------------------------------------------------------------
-template <int VEC>
+// DP1 = d + 1 at compile time: the d+1 (index, weight) pairs of a point are fetched in one round trip and its d+1 row gathers
+// in a second one (with a runtime trip count the compiler kept the loop rolled: d+1 dependent {index -> row} pairs).
+template <int VEC, int DP1>
 __global__ void __launch_bounds__(256)
     k_slice_forward(const float* __restrict__ values, const int* __restrict__ idx, const float* __restrict__ w, long long work,
-                    int dp1, int chunks, float* __restrict__ out, float* __restrict__ zero_fill, long long zero_elems) {
+                    int chunks, float* __restrict__ out, float* __restrict__ zero_fill, long long zero_elems) {
     using T = typename VecT<VEC>::type;
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (zero_fill) {  // the accumulator the backward pass of this slice will scatter into, zeroed on the way
@@ -113,17 +115,28 @@ __global__ void __launch_bounds__(256)
     if (g >= work) return;
     const long long p = g / chunks;
     const int c = int(g - p * chunks);
-    T acc = ln_zero(T());
-    for (int r = 0; r < dp1; ++r) {
-        const int row = idx[p * dp1 + r];
-        if (row >= 0) {
-            const T v = reinterpret_cast<const T*>(values)[(size_t)row * chunks + c];
-            acc = ln_add(acc, ln_mul(v, w[p * dp1 + r]));
-        }
+    int rows[DP1];
+    float wt[DP1];
+#pragma unroll
+    for (int r = 0; r < DP1; ++r) {
+        rows[r] = idx[p * DP1 + r];
+        wt[r] = w[p * DP1 + r];
     }
+    T v[DP1];
+#pragma unroll
+    for (int r = 0; r < DP1; ++r) v[r] = reinterpret_cast<const T*>(values)[(size_t)(rows[r] >= 0 ? rows[r] : 0) * chunks + c];
+    T acc = ln_zero(T());
+#pragma unroll
+    for (int r = 0; r < DP1; ++r)
+        if (rows[r] >= 0) acc = ln_add(acc, ln_mul(v[r], wt[r]));  // same order and the same skips as LatticeGPU.cuh:2567-2591
     reinterpret_cast<T*>(out)[g] = acc;
 }
 
+#define LN_SLICE_CASE(DD)                                                                                                             \
+    case DD:                                                                                                                          \
+        LN_LAUNCH("k_slice_forward", (k_slice_forward<VEC, DD + 1>), dim3(ln_div_up(work, 256)), dim3(256), 0, (hipStream_t)stream, values, \
+                  idx, w, work, chunks, out, zero_fill, zero_elems);                                                                  \
+        break;
 static int ln_slice_forward_impl(const float* values, const int* idx, const float* w, int n, int pos_dim, int val_dim, float* out,
                                  float* zero_fill, long long zero_elems, void* stream) {
     int rc = ln_check_rows("ln_slice_forward", values, idx, out, n, pos_dim, val_dim);
@@ -136,8 +149,8 @@ static int ln_slice_forward_impl(const float* values, const int* idx, const floa
     LN_DISPATCH_VEC(val_dim, {
         const int chunks = val_dim / VEC;
         const long long work = (long long)n * chunks;
-        LN_LAUNCH("k_slice_forward", k_slice_forward<VEC>, dim3(ln_div_up(work, 256)), dim3(256), 0, (hipStream_t)stream, values, idx, w, work,
-                           pos_dim + 1, chunks, out, zero_fill, zero_elems);
+        switch (pos_dim) { LN_SLICE_CASE(1) LN_SLICE_CASE(2) LN_SLICE_CASE(3) LN_SLICE_CASE(4) LN_SLICE_CASE(5) LN_SLICE_CASE(6) }
+
     });
     return ln_check_launch("ln_slice_forward");
 }

@@ -793,12 +793,21 @@ __global__ void __launch_bounds__(256)
     int row = e;
     const unsigned int ft = t.slot_tok[h];
     if (e < 0) {
+        // rank of token ft among the first occurrences: prefix of its 256-token block + the set bits below it inside the
+        // block.  The block's four bitmap words are fetched together with the prefix (one round trip, not up to five).
         const unsigned int blk = ft >> 8;
         const unsigned int wd = (ft >> 6) & 3;
         int r = block_prefix[blk];
-        for (unsigned int k = 0; k < wd; ++k) r += __popcll(bitmap[(size_t)blk * 4 + k]);
-        const unsigned long long below = (ft & 63) ? (bitmap[ft >> 6] & ((1ull << (ft & 63)) - 1ull)) : 0ull;
-        r += __popcll(below);
+        const ulonglong2 w01 = *reinterpret_cast<const ulonglong2*>(bitmap + (size_t)blk * 4);
+        const ulonglong2 w23 = *reinterpret_cast<const ulonglong2*>(bitmap + (size_t)blk * 4 + 2);
+        const unsigned long long words[4] = {w01.x, w01.y, w23.x, w23.y};
+        unsigned long long mine = 0ull;
+#pragma unroll
+        for (unsigned int k = 0; k < 4; ++k) {
+            if (k < wd) r += __popcll(words[k]);
+            if (k == wd) mine = words[k];
+        }
+        r += __popcll(mine & ((1ull << (ft & 63)) - 1ull));
         row = r;
         if (ft == (unsigned int)tk) {  // first occurrence publishes the vertex
             t.entries[h] = row;
