@@ -328,7 +328,9 @@ def main():
             scale = float(self.eager_out.abs().max())
             err = {"out_max_rel": float((self.state["out"].detach() - self.eager_out).abs().max()) / max(scale, 1e-30),
                    "grad_filter_max_rel": float((self.state["gw"] - self.eager_gw).abs().max()) / max(float(self.eager_gw.abs().max()), 1e-30)}
-            if max(err.values()) > 1e-5:
+            # fp32 path: 1e-5 (BASELINE.json); fp16 feature path (C5): outputs are rounded to fp16 and the order of the
+            # hot-vertex atomics differs from run to run, 2e-3 as in tests/test_gpu_surface.py
+            if max(err.values()) > (2e-3 if half else 1e-5):
                 raise SystemExit(f"[bench] graph replay differs from the eager step: {err}")
             return err
 
