@@ -449,12 +449,24 @@ __global__ void __launch_bounds__(256)
         for (int i = tid; i < PB * V4; i += 256) {
             const int lp = i / V4, v4 = i - lp * V4;
             float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int r = 0; r < dp1; ++r) {
-                const int row = s_idx[lp * dp1 + r];
-                if (row >= 0) {
+            // all d+1 row gathers in flight before the first use (a rolled loop with the load inside its branch waits for
+            // each row in turn); summation order and skips unchanged
+            int rows[LN_MAX_POS_DIM + 1];
+            float4 x[LN_MAX_POS_DIM + 1];
+#pragma unroll
+            for (int r = 0; r <= LN_MAX_POS_DIM; ++r) {
+                rows[r] = -1;
+                x[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (r < dp1) {  // wave-uniform
+                    rows[r] = s_idx[lp * dp1 + r];
+                    x[r] = reinterpret_cast<const float4*>(values + (size_t)(rows[r] >= 0 ? rows[r] : 0) * V)[v4];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r <= LN_MAX_POS_DIM; ++r) {
+                if (rows[r] >= 0) {
                     const float wt = s_we[lp * dp1 + r];
-                    const float4 x = reinterpret_cast<const float4*>(values + (size_t)row * V)[v4];
-                    h.x = h.x + x.x * wt; h.y = h.y + x.y * wt; h.z = h.z + x.z * wt; h.w = h.w + x.w * wt;
+                    h.x = h.x + x[r].x * wt; h.y = h.y + x[r].y * wt; h.z = h.z + x[r].z * wt; h.w = h.w + x[r].w * wt;
                 }
             }
             float* d = s_h + lp * SH + v4 * 4;
@@ -685,12 +697,24 @@ __global__ void __launch_bounds__(256)
         for (int i = tid; i < PB * V4; i += 256) {
             const int lp = i / V4, v4 = i - lp * V4;
             float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int r = 0; r < dp1; ++r) {
-                const int row = s_idx[lp * dp1 + r];
-                if (row >= 0) {
+            // all d+1 row gathers in flight before the first use (a rolled loop with the load inside its branch waits for
+            // each row in turn); summation order and skips unchanged
+            int rows[LN_MAX_POS_DIM + 1];
+            float4 x[LN_MAX_POS_DIM + 1];
+#pragma unroll
+            for (int r = 0; r <= LN_MAX_POS_DIM; ++r) {
+                rows[r] = -1;
+                x[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (r < dp1) {  // wave-uniform
+                    rows[r] = s_idx[lp * dp1 + r];
+                    x[r] = reinterpret_cast<const float4*>(values + (size_t)(rows[r] >= 0 ? rows[r] : 0) * V)[v4];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r <= LN_MAX_POS_DIM; ++r) {
+                if (rows[r] >= 0) {
                     const float wt = s_we[lp * dp1 + r];
-                    const float4 x = reinterpret_cast<const float4*>(values + (size_t)row * V)[v4];
-                    h.x = h.x + x.x * wt; h.y = h.y + x.y * wt; h.z = h.z + x.z * wt; h.w = h.w + x.w * wt;
+                    h.x = h.x + x[r].x * wt; h.y = h.y + x[r].y * wt; h.z = h.z + x[r].z * wt; h.w = h.w + x[r].w * wt;
                 }
             }
             reinterpret_cast<float4*>(s_h)[i] = h;
