@@ -134,6 +134,22 @@ extern "C" const char* ln_version(void) { return "latticenet_hip 0.2 (gfx950)"; 
 #endif
 extern "C" const char* ln_abi_hash(void) { return LN_ABI_HASH; }
 
+// Phase stamps (tools/kernel_timeline.py; compiled in with -DLN_STAMPS only): thread 0 of every workgroup stores the
+// 100 MHz wall clock at the marked points of k_point_keys / k_bucket_build.
+#ifdef LN_STAMPS
+__device__ unsigned long long* g_ln_stamps = nullptr;
+extern "C" int ln_debug_set_stamps(void* buffer) {
+    unsigned long long* p = static_cast<unsigned long long*>(buffer);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_ln_stamps), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+#define LN_STAMP(slot)                                                                                         \
+    do {                                                                                                       \
+        if (g_ln_stamps && threadIdx.x == 0) g_ln_stamps[(size_t)blockIdx.x * 16 + (slot)] = wall_clock64(); \
+    } while (0)
+#else
+#define LN_STAMP(slot) do { } while (0)
+#endif
+
 #define LN_DISPATCH_D(d, ...)                                                    \
     switch (d) {                                                                 \
         case 1: { constexpr int D = 1; __VA_ARGS__; } break;                     \
@@ -306,6 +322,7 @@ __global__ void __launch_bounds__(256)
     __shared__ int s_stage_tok[LN_KEYS_PTS_PER_BLOCK * (D + 1)];
     __shared__ int s_stage_dst[LN_KEYS_PTS_PER_BLOCK * (D + 1)];
     int* cursor = t.slot_cnt;
+    LN_STAMP(0);
     for (int b = threadIdx.x; b < nbk; b += 256) s_cnt[b] = 0;
     {  // clear duties (independent of everything below)
         const long long stride = (long long)gridDim.x * 256;
@@ -327,6 +344,7 @@ __global__ void __launch_bounds__(256)
         }
     }
     __syncthreads();
+    LN_STAMP(1);
     unsigned long long pk[LN_KEYS_PTS_PER_THREAD][D + 1];
     int bkt[LN_KEYS_PTS_PER_THREAD][D + 1];
     int rank[LN_KEYS_PTS_PER_THREAD][D + 1];
@@ -368,7 +386,9 @@ __global__ void __launch_bounds__(256)
         }
     }
     if (bad_key) atomicOr(&t.slot_cnt[nbk], 1);
+    LN_STAMP(2);
     __syncthreads();
+    LN_STAMP(3);
     // Region cursors (one returning global atomic per (block, bucket), all of a thread row in flight together) and, for the
     // staged write below, the exclusive prefix of this block's per-bucket counts (one 256-wide scan per row of buckets).
     int block_tokens = 0;
@@ -383,7 +403,9 @@ __global__ void __launch_bounds__(256)
         }
         block_tokens += row_total;
     }
+    LN_STAMP(4);
     __syncthreads();
+    LN_STAMP(5);
     // Stage the block's tokens in LDS sorted by bucket, then write them out in that order: the lanes of a wave then cover a
     // few runs of consecutive region entries instead of 64 different cache lines per store instruction (the scattered form
     // of these two stores was a third of this kernel's time).
@@ -402,6 +424,7 @@ __global__ void __launch_bounds__(256)
         }
     }
     __syncthreads();
+    LN_STAMP(6);
     for (int j = threadIdx.x; j < block_tokens; j += 256) {
         const int dst = s_stage_dst[j];
         const int tk = s_stage_tok[j];
@@ -412,6 +435,7 @@ __global__ void __launch_bounds__(256)
             tok_slot[tk] = -1;  // region full (heavily skewed cloud): the bucket workgroup reports it, the build is replayed
         }
     }
+    LN_STAMP(7);
 }
 
 // Pass 2: one workgroup per bucket.  LDS: keys[sb] | count[sb] | min token[sb] | token offset[sb] | segment offset[sb].
@@ -438,6 +462,7 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
     const int b = blockIdx.x;
     const int lo = b * sb;
     const int size = min(sb, t.capacity - lo);
+    LN_STAMP(8);
     for (int i = tid; i < size; i += LN_BKT_THREADS) {
         skeys[i] = LN_EMPTY_KEY;  // the table was cleared by this build call
         scnt[i] = 0;
@@ -473,6 +498,7 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
 #pragma unroll
     for (int k = 0; k < 16; ++k) base += s_wave_tok[k];
     __syncthreads();  // s_wave_tok is reused by the scans below
+    LN_STAMP(9);
 
     // Called by every lane of the wave (invalid lanes carry no token): the wave-level grouping below uses shuffles.
     auto place = [&](bool valid, int tk, unsigned long long pk, int& ls, int& pos) {
@@ -535,6 +561,7 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
         }
     }
     __syncthreads();
+    LN_STAMP(10);
     // exclusive scans of the per-slot token and segment counts
     for (int start = 0; start < size; start += LN_BKT_THREADS) {
         const int i = start + tid;
@@ -572,6 +599,7 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
         }
         __syncthreads();
     }
+    LN_STAMP(11);
     // Segment ids.  Without region planes: one contiguous run of region 0 per bucket.  With planes: every slot files its
     // segments under the kd region of its key (sseg[i] becomes region << 28 | position among this bucket's segments of that
     // region; one returning global atomic per (bucket, region)).
@@ -593,6 +621,7 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
     }
     __syncthreads();
     const int placed = s_run_tok;
+    LN_STAMP(12);
     for (int i = tid; i < size; i += LN_BKT_THREADS) {
         const int h = lo + i;
         const int beg = base + soff[i];
@@ -602,13 +631,17 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
         const unsigned int ft = smin[i];
         t.slot_tok[h] = ft;
         const int c = scnt[i];
-        if (c) atomicOr(&bitmap[ft >> 6], 1ull << (ft & 63));  // the slot's first occurrence (every slot is new)
+        // the slot's first occurrence (every slot is new).  These 46 k memory-side atomics cost 4.4 us of back pressure on
+        // this loop at C3; a byte flag per token instead (plain stores) brings this kernel to 14.5 us, but packing 480 KB of
+        // flags into the bitmap inside the single-workgroup scan costs 17 us, and as a separate launch about what it saves.
+        if (c) atomicOr(&bitmap[ft >> 6], 1ull << (ft & 63));
         const int sr = planes ? (sseg[i] >> 28) : 0;
         long long sid = (long long)sr * csr.seg_region + s_rbase[sr] + (planes ? (sseg[i] & 0x0FFFFFFF) : sseg[i]);
         for (int e = 0; e < c; e += LN_CSR_SEG, ++sid)
             reinterpret_cast<int4*>(csr.seg_desc)[sid] = make_int4(h, beg + e, c - e, e);
     }
     if (b == nbk - 1 && tid == 0) csr.grp_start[t.capacity] = base + ntok;
+    LN_STAMP(13);
 #pragma unroll
     for (int k = 0; k < LN_BKT_REG_TOK; ++k)
         if (r_ls[k] >= 0) csr.csr_tok[base + soff[r_ls[k]] + r_pos[k]] = r_tk[k];
@@ -618,6 +651,7 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
     }
     for (int j = placed + tid; j < ntok; j += LN_BKT_THREADS)
         csr.csr_tok[base + j] = -1;  // only after an overflow: keeps readers in bounds until the rebuild
+    LN_STAMP(14);
 }
 
 // Token producer 2: coarsen kernel (LatticeGPU.cuh:2348-2511): per fine vertex with all-even key,

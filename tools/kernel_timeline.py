@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Phase timeline of k_point_keys / k_bucket_build from per-workgroup wall-clock stamps (needs the -DLN_STAMPS build:
+LATTICE_NET_LIB=lattice_net_amd/liblatticenet_hip_stamps.so python tools/kernel_timeline.py)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import lattice_net_amd as L  # noqa: E402
+from lattice_net_amd import synthetic  # noqa: E402
+
+lib = C.CDLL(L.LIB_PATH)
+dev = torch.device("cuda", 0)
+n, v, sigma, cap = 120000, 32, 0.9, 100000
+pos = torch.from_numpy(synthetic.lidar_cloud(n, 0)).to(dev)
+vals = torch.randn((n, v), device=dev)
+lat = L.Lattice(sigmas=[sigma] * 3, capacity=cap, device=dev)
+stamps = torch.zeros((4096, 16), dtype=torch.int64, device=dev)
+for _ in range(5):
+    L.SplatLattice.apply(lat, pos, vals)
+    lat.nr_lattice_vertices()
+torch.cuda.synchronize()
+lib.ln_debug_set_stamps.argtypes = [C.c_void_p]
+assert lib.ln_debug_set_stamps(stamps.data_ptr()) == 0
+acc = {}
+reps = 10
+for _ in range(reps):
+    stamps.zero_()
+    L.SplatLattice.apply(lat, pos, vals)
+    lat.nr_lattice_vertices()
+    torch.cuda.synchronize()
+    s = stamps.cpu().numpy().astype(np.float64) / 100.0  # 100 MHz -> microseconds
+    for name, first, last, nwg in (("k_point_keys", 0, 7, None), ("k_bucket_build", 8, 14, None)):
+        rows = s[(s[:, first] > 0)]
+        t0 = rows[:, first].min()
+        rel = rows[:, first:last + 1] - t0
+        acc.setdefault(name, []).append(rel)
+lib.ln_debug_set_stamps(None)
+labels = {"k_point_keys": ["start", "clear issued+sync", "keys+LDS rank done", "sync", "scan+global atomics", "sync", "LDS staging+sync", "stores issued (end)"],
+          "k_bucket_build": ["start", "init+loads+sync", "place (LDS CAS/add/min)", "scans", "segment ids", "emit slots", "csr_tok stores (end)"]}
+for name, runs in acc.items():
+    m = np.mean([r.mean(0) for r in runs], 0)
+    mx = np.mean([r.max(0) for r in runs], 0)
+    mn = np.mean([r.min(0) for r in runs], 0)
+    print(f"{name}: {runs[0].shape[0]} workgroups; microseconds since the first workgroup started")
+    prev = 0.0
+    for k, lab in enumerate(labels[name]):
+        print(f"  {lab:28s} mean {m[k]:7.2f}  (+{m[k] - prev:5.2f})   earliest {mn[k]:7.2f}  latest {mx[k]:7.2f}")
+        prev = m[k]

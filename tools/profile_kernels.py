@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--capacity", type=int, default=100000)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--scale", type=float, default=1.0, help="cube half-extent")
+    ap.add_argument("--regions", action="store_true", help="calibrate kd region planes (XCD-affine segment walk)")
     ap.add_argument("--scan-order", action="store_true",
                     help="sort the points by azimuth, then range (a spinning sensor's order) instead of the i.i.d. order of the generator")
     args = ap.parse_args()
@@ -55,9 +56,14 @@ def main():
         out = L.SliceLattice.apply(cv, cwrap.lattice, pos, idx, w)
         out.backward(G)
         st["m"] = m
+        st["idx"] = idx
 
     for _ in range(3):
         step()
+    if args.regions:
+        lat.set_region_planes(lat.balanced_region_planes(st["idx"]))
+        for _ in range(2):
+            step()
     torch.cuda.synchronize()
     names = lib.ln_kernel_names().decode().split(",")
     rows = []
