@@ -15,6 +15,21 @@
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
+// Phase stamps of the small-filter convolution (tools/kernel_timeline.py --conv; -DLN_STAMPS builds only)
+#ifdef LN_STAMPS
+__device__ unsigned long long* g_ln_stamps_conv = nullptr;
+extern "C" int ln_debug_set_stamps_conv(void* buffer) {
+    unsigned long long* p = static_cast<unsigned long long*>(buffer);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_ln_stamps_conv), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+#define LN_CSTAMP(slot)                                                                                                  \
+    do {                                                                                                                 \
+        if (g_ln_stamps_conv && threadIdx.x == 0) g_ln_stamps_conv[(size_t)blockIdx.x * 8 + (slot)] = wall_clock64(); \
+    } while (0)
+#else
+#define LN_CSTAMP(slot) do { } while (0)
+#endif
+
 template <int KQ>
 __device__ __forceinline__ void ln_load_quarter(const float* __restrict__ src, float* a) {
     if constexpr (KQ % 4 == 0) {
@@ -170,6 +185,7 @@ __global__ void __launch_bounds__(256)
     const int m0 = blockIdx.x * 64 + wave * 16;
     const int my_row = m0 + i;
 
+    LN_CSTAMP(0);
     // Load order = dependency order: the filter bank depends on nothing, so its loads go out first, then the neighbour
     // indices, then the gathers that need them.  Loads return in order: staging the bank only waits for the bank (the gathers
     // stay in flight behind it), and the MFMAs of slot e only wait for the gather of slot e.
@@ -220,6 +236,7 @@ __global__ void __launch_bounds__(256)
         }
     }
     __syncthreads();
+    LN_CSTAMP(1);
     floatx4 acc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = floatx4{0.f, 0.f, 0.f, 0.f};
@@ -235,6 +252,7 @@ __global__ void __launch_bounds__(256)
             }
         }
     }
+    LN_CSTAMP(2);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
@@ -243,6 +261,7 @@ __global__ void __launch_bounds__(256)
             if (row < m) out[(size_t)row * F + nt * 16 + i] = acc[nt][r];
         }
     }
+    LN_CSTAMP(3);
 }
 
 // Any (V, F): one thread per output element.

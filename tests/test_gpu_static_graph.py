@@ -121,3 +121,42 @@ def test_static_bound_too_small_is_reported():
     lat.set_static_rows(None)
     L.SplatLattice.apply(lat, pos, vals)
     assert lat.nr_lattice_vertices() == m
+
+
+def test_region_planes_change_placement_not_results():
+    """kd region planes (LnCsr.planes) only steer which XCD walks which segments: indices stay bit-exact with the oracle,
+    splatted values / slice backward within 1e-5, for balanced planes and for deliberately lopsided ones."""
+    import lattice_net_amd as L
+    from lattice_net_amd.synthetic import lidar_cloud
+
+    n, v, sigma, cap = 20000, 32, 0.9, 40000
+    rng = np.random.default_rng(7)
+    pos_np = lidar_cloud(n, 21)
+    vals_np = rng.standard_normal((n, v)).astype(np.float32)
+    g_np = rng.standard_normal((n, v)).astype(np.float32)
+    t = O.OracleHashTable(cap, 3)
+    idx_ref, w_ref = O.build_splat(t, O.scale_positions(pos_np, np.full((3,), sigma, np.float32)))
+    m = t.nr_filled
+    lv_ref = np.zeros((m, v), np.float32)
+    O.splat_accumulate(lv_ref, vals_np, idx_ref, w_ref)
+    gb_ref = O.slice_backwards(g_np, idx_ref, w_ref, m)
+
+    pos = torch.from_numpy(pos_np).to(dev())
+    vals = torch.from_numpy(vals_np).to(dev())
+    G = torch.from_numpy(g_np).to(dev())
+    lat = L.Lattice(sigmas=[sigma] * 3, capacity=cap, device=dev())
+    _, _, idx, _ = L.SplatLattice.apply(lat, pos, vals)
+    balanced = lat.balanced_region_planes(idx)
+    for planes in (balanced, [10 ** 6] * 7, [-10 ** 6] * 7, [0, -50, 50, 3, -3, 7, -7]):
+        lat.set_region_planes(planes)
+        lv, _, idx, w = L.SplatLattice.apply(lat, pos, vals)
+        assert lat.nr_lattice_vertices() == m
+        assert np.array_equal(idx.cpu().numpy(), idx_ref)
+        assert rel(lv[:m].cpu().numpy(), lv_ref) < RTOL
+        lvm = lv[:m].clone().requires_grad_(True)
+        out = L.SliceLattice.apply(lvm, lat, pos, idx, w)
+        out.backward(G)
+        assert rel(lvm.grad.cpu().numpy(), gb_ref) < RTOL
+    lat.set_region_planes(None)
+    lv, _, idx, w = L.SplatLattice.apply(lat, pos, vals)
+    assert rel(lv[:m].cpu().numpy(), lv_ref) < RTOL

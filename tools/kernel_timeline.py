@@ -50,3 +50,29 @@ for name, runs in acc.items():
     for k, lab in enumerate(labels[name]):
         print(f"  {lab:28s} mean {m[k]:7.2f}  (+{m[k] - prev:5.2f})   earliest {mn[k]:7.2f}  latest {mx[k]:7.2f}")
         prev = m[k]
+
+# ---- small-filter convolution (forward): one launch, stamps per workgroup
+if hasattr(lib, "ln_debug_set_stamps_conv"):
+    W = (torch.rand((9 * v, v), device=dev) - 0.5)
+    lv, _, idx, w = L.SplatLattice.apply(lat, pos, vals)
+    m = lat.nr_lattice_vertices()
+    lvm = lv[:m].contiguous()
+    cst = torch.zeros((4096, 8), dtype=torch.int64, device=dev)
+    lib.ln_debug_set_stamps_conv.argtypes = [C.c_void_p]
+    runs = []
+    for _ in range(reps + 2):
+        cst.zero_()
+        lib.ln_debug_set_stamps_conv(cst.data_ptr())
+        L.ConvIm2RowLattice.apply(lvm, lat, W, 1)
+        torch.cuda.synchronize()
+        lib.ln_debug_set_stamps_conv(None)
+        s = cst.cpu().numpy().astype(np.float64) / 100.0
+        rows = s[s[:, 0] > 0]
+        runs.append(rows[:, :4] - rows[:, 0].min())
+    runs = runs[2:]
+    m_ = np.mean([r.mean(0) for r in runs], 0); mx = np.mean([r.max(0) for r in runs], 0); mn = np.mean([r.min(0) for r in runs], 0)
+    print(f"k_conv_mfma_full: {runs[0].shape[0]} workgroups")
+    prev = 0.0
+    for k, lab in enumerate(["start", "ids + gathers issued, bank staged, sync", "MFMA loop done", "stores issued (end)"]):
+        print(f"  {lab:44s} mean {m_[k]:7.2f}  (+{m_[k] - prev:5.2f})   earliest {mn[k]:7.2f}  latest {mx[k]:7.2f}")
+        prev = m_[k]
