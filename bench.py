@@ -218,9 +218,10 @@ def main():
                     help="graph mode: independent scans in flight per GPU (own cloud, lattice, hipGraph, stream each); the kernels of one "
                          "scan are latency-bound chains at ~1 workgroup per CU, a second scan fills the idle slots.  1 = strictly one "
                          "scan after the other")
-    ap.add_argument("--regions", type=int, default=int(os.environ.get("LN_BENCH_REGIONS", "0")),
-                    help="1: calibrate kd region planes on the first eager step of every scan (equal token load per region) so that "
-                         "the scatter kernels walk one compact region per XCD")
+    ap.add_argument("--regions", type=int, default=int(os.environ.get("LN_BENCH_REGIONS", "1")),
+                    help="1 (default, graph mode): calibrate kd region planes on the first eager step of every scan (equal token load per "
+                         "region) so that the scatter kernels walk one compact region of the lattice per XCD: -40 %% L2-miss traffic "
+                         "on the two segment reduces, +5 %% throughput with two scans in flight")
     ap.add_argument("--row-slack", type=float, default=0.06,
                     help="graph mode: static row bound = vertex count of the calibration step x (1 + slack), rounded up to 256")
     args = ap.parse_args()
@@ -495,7 +496,8 @@ def main():
                        "execution": (f"one hipGraph replay per scan (whole forward + backward captured once, static row bound); "
                                      f"{in_flight} independent scan(s) in flight per GPU, each with its own lattice, graph and stream; "
                                      f"K steps = K scans" if args.mode == "graph" else "eager: Python autograd pass per step"),
-                       "scans_in_flight": in_flight, "vertices_per_scan": m_all, "graph_vs_eager": graph_err,
+                       "scans_in_flight": in_flight, "kd_regions": bool(args.regions and args.mode == "graph"),
+                       "vertices_per_scan": m_all, "graph_vs_eager": graph_err,
                        "one_scan_in_flight": single},
             "roofline": roofline, "roofline_others": others, "stages": stages, "full_unet": unet, "cpu_baseline": cpu,
         }
