@@ -214,6 +214,13 @@ int ln_row2im(const int* nbr, const float* rowified, int m, int filter_extent, i
 #define LN_CONV_TRANSPOSED_FILTER 2
 int ln_conv_forward(const int* nbr, const float* values_neigh, const float* filter, int m, int filter_extent, int val_dim,
                     int nr_filters, int flags, float* out, void* stream);
+/* ln_conv_forward with scratch.  When the lattice has few vertices (coarse levels of a U-Net: fewer vertex tiles than CUs) the
+ * contraction is split over the filter slots and the partial sums are added by a second launch; that needs
+ * ln_conv_forward_workspace_bytes(m, filter_extent, val_dim, nr_filters) bytes of 16-byte aligned scratch (256 when no
+ * split applies).  Without enough scratch it runs unsplit, exactly as ln_conv_forward. */
+size_t ln_conv_forward_workspace_bytes(int m, int filter_extent, int val_dim, int nr_filters);
+int ln_conv_forward_ws(const int* nbr, const float* values_neigh, const float* filter, int m, int filter_extent, int val_dim,
+                       int nr_filters, int flags, float* out, void* workspace, size_t workspace_bytes, void* stream);
 /* grad_filter = rowified^T @ grad_out (lattice_funcs.py:302) without the rowified tensor.
  * workspace: ln_conv_grad_filter_workspace_bytes(). */
 size_t ln_conv_grad_filter_workspace_bytes(int m, int filter_extent, int val_dim, int nr_filters);

@@ -91,6 +91,8 @@ SIGNATURES = {
     "ln_im2rowindices": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "ln_row2im": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "ln_conv_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "ln_conv_forward_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "ln_conv_forward_ws": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "ln_conv_grad_filter_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "ln_conv_grad_filter": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "ln_slice_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),

@@ -12,6 +12,7 @@
 //     so every ds_read is lane-linear and conflict-free.
 // fp32 in, fp32 accumulate: results are exact-fp32 fmaf chains (1e-5 parity bar).
 #include "ln_common.h"
+#include <stdlib.h>
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
@@ -57,10 +58,21 @@ __device__ __forceinline__ void ln_load_quarter(const float* __restrict__ src, f
 // FLIP: read slot e^1 of an un-flipped neighbour list (the flipped traversal only swaps the np/nm slots
 // of every axis, LatticeGPU.cuh:1622-1626).  WT: `filter` is the bank of the op being differentiated,
 // [E*F, V]; the contraction uses its per-slot transpose (lattice_funcs.py:307-311) without materialising it.
+// Compiled for 2 waves per SIMD: left to itself the compiler aims at 3-4 (it has LDS for that) and spills the prefetched
+// neighbour row — 36 dwords of scratch per lane at V = 128.
+#ifndef LN_CONV_WAVES_ATTR
+#define LN_CONV_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
+#endif
 template <int V, int NT, bool FLIP, bool WT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) LN_CONV_WAVES_ATTR
     k_conv_mfma(const int* __restrict__ nbr, const float* __restrict__ values, const float* __restrict__ filter, int m, int E,
-                float* __restrict__ out, int f_total, int f_off) {
+                float* __restrict__ out, int f_total, int f_off, int e_per) {
+    // gridDim.z > 1 (few vertices: the coarse levels of a U-Net leave most CUs without a tile): split over the filter slots —
+    // workgroup z contracts slots [z * e_per, (z + 1) * e_per) only and writes its partial sums to slab z of `out`
+    // ([gridDim.z, m, f_total]); ln_k_sum_partials adds the slabs.
+    const int e_begin = blockIdx.z * e_per;
+    const int e_end = min(E, e_begin + e_per);
+    out += (size_t)blockIdx.z * m * f_total;
     // computes output columns [f_off, f_off + 16*NT) of an [.., f_total]-wide convolution.
     // Software pipeline over the filter slots: while the matrix cores work on slot e (operand A in registers, W_e in LDS),
     // the gather of slot e+1's neighbour rows and the float4 loads of W_{e+1} are already in flight; W_{e+1} goes from
@@ -85,7 +97,7 @@ __global__ void __launch_bounds__(256)
 
     float a_cur[KQ], a_nxt[KQ];
     float4 w_nxt[W4];
-    auto issue = [&](int e, float* a) {  // loads of slot e: this lane's quarter of the neighbour row + its share of W_e
+    auto issue = [&](int e, float (&a)[KQ]) {  // loads of slot e: this lane's quarter of the neighbour row + its share of W_e
         const int es = (FLIP && e < E - 1) ? (e ^ 1) : e;
         const int nb = (my_row < m) ? nbr[(size_t)my_row * E + es] : -1;
         ln_load_quarter<KQ>(values + (size_t)(nb >= 0 ? nb : 0) * V + q * KQ, a);
@@ -127,11 +139,11 @@ __global__ void __launch_bounds__(256)
             }
         }
     };
-    issue(0, a_cur);
+    issue(e_begin, a_cur);
     stage();
     __syncthreads();
-    for (int e = 0; e < E; ++e) {
-        if (e + 1 < E) issue(e + 1, a_nxt);
+    for (int e = e_begin; e < e_end; ++e) {
+        if (e + 1 < e_end) issue(e + 1, a_nxt);
 #pragma unroll
         for (int kk = 0; kk < KQ; ++kk) {
 #pragma unroll
@@ -140,7 +152,7 @@ __global__ void __launch_bounds__(256)
                 acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[kk], b, acc[nt], 0, 0, 0);
             }
         }
-        if (e + 1 < E) {
+        if (e + 1 < e_end) {
             __syncthreads();  // every wave is done with W_e
             stage();
             __syncthreads();
@@ -159,6 +171,11 @@ __global__ void __launch_bounds__(256)
     }
 }
 
+// (Measured dead end, round 2: the same kernel on v_mfma_f32_16x16x32_bf16 with 3-way split operands — a = a1 + a2 + a3 in
+// bf16, six products of total order <= 4, fp32 accumulation; accurate to the same 1e-5 bar — with the filter bank pre-split
+// once per call.  2.5x less matrix time on paper, but the per-slot kernel is not bound by the matrix pipe even at 46 k
+// vertices x 128 channels (50 % of the fp32 MFMA peak): 91 vs 87 us there, whole LNN step 6.0 vs 5.5 ms.  What bounds it is the
+// slot loop itself: gather + 32-48 KB of bank staging + two workgroup barriers per slot.)
 // Small-filter fast path (E*V*F*4 <= 64 KiB, e.g. V = F = 32 with E = 9): the WHOLE filter bank is
 // staged into LDS once per workgroup (one barrier), and every lane issues the gathers of all E
 // neighbour rows up front, so the kernel pays one memory latency instead of E.
@@ -290,30 +307,87 @@ __global__ void __launch_bounds__(256)
 
 // Output columns are produced in chunks of 16*NT (NT in {8, 4, 2, 1}; the per-slot filter slice V x 16NT must fit LDS),
 // so any nr_filters that is a multiple of 16 runs on the matrix cores.
+// out[i] = sum over s of partial[s * total + i], float4 per thread (total % 4 == 0)
+__global__ void __launch_bounds__(256) ln_k_sum_partials(const float* __restrict__ partial, int nslabs, long long total4, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    float4 acc = reinterpret_cast<const float4*>(partial)[i];
+    for (int sl = 1; sl < nslabs; ++sl) {
+        const float4 v = reinterpret_cast<const float4*>(partial)[(long long)sl * total4 + i];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    reinterpret_cast<float4*>(out)[i] = acc;
+}
+
+// Split of the per-slot convolution over the filter slots: 1 (no split) while the vertex tiles alone fill the chip.
+#define LN_CONV_SPLIT_TILES 512  // workgroups aimed at (two per CU)
+template <int V>
+static int ln_conv_slots_per_split(int m, int E, int nr_filters) {
+    constexpr int NT_MAX = (V * 16 * 8 * 4 <= 32 * 1024) ? 8 : ((V * 16 * 4 * 4 <= 48 * 1024) ? 4 : 2);
+    const long long tiles = (long long)ln_div_up(m, 64) * ln_div_up(nr_filters, 16 * NT_MAX);
+    if (tiles * 2 > LN_CONV_SPLIT_TILES || E < 2) return E;
+    int nsplit = int((LN_CONV_SPLIT_TILES + tiles - 1) / tiles);
+    if (nsplit > E) nsplit = E;
+    return (E + nsplit - 1) / nsplit;  // slots per workgroup
+}
+static int ln_conv_slots_per_split_rt(int m, int E, int val_dim, int nr_filters) {
+    switch (val_dim) {
+        case 8: return ln_conv_slots_per_split<8>(m, E, nr_filters);
+        case 16: return ln_conv_slots_per_split<16>(m, E, nr_filters);
+        case 32: return ln_conv_slots_per_split<32>(m, E, nr_filters);
+        case 48: return ln_conv_slots_per_split<48>(m, E, nr_filters);
+        case 64: return ln_conv_slots_per_split<64>(m, E, nr_filters);
+        case 96: return ln_conv_slots_per_split<96>(m, E, nr_filters);
+        case 128: return ln_conv_slots_per_split<128>(m, E, nr_filters);
+        case 192: return ln_conv_slots_per_split<192>(m, E, nr_filters);
+        case 256: return ln_conv_slots_per_split<256>(m, E, nr_filters);
+        default: return E;
+    }
+}
+
+extern "C" size_t ln_conv_forward_workspace_bytes(int m, int filter_extent, int val_dim, int nr_filters) {
+    if (m <= 0 || nr_filters % 16 != 0) return 256;
+    const int e_per = ln_conv_slots_per_split_rt(m, filter_extent, val_dim, nr_filters);
+    const int nsplit = (filter_extent + e_per - 1) / e_per;
+    return (nsplit > 1 ? (size_t)nsplit * m * nr_filters * sizeof(float) : 0) + 256;
+}
+
 template <int V, bool FLIP, bool WT>
 static bool ln_conv_launch_v(int nr_filters, const int* nbr, const float* values, const float* filter, int m, int E, float* out,
-                             hipStream_t st) {
+                             void* workspace, size_t workspace_bytes, hipStream_t st) {
     const dim3 block(256);
     constexpr int NT_MAX = (V * 16 * 8 * 4 <= 32 * 1024) ? 8 : ((V * 16 * 4 * 4 <= 48 * 1024) ? 4 : 2);
+    int e_per = ln_conv_slots_per_split<V>(m, E, nr_filters);
+    int nsplit = (E + e_per - 1) / e_per;
+    if (nsplit > 1 && (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 15) != 0 ||
+                       workspace_bytes < (size_t)nsplit * m * nr_filters * sizeof(float))) {
+        e_per = E;  // no room for the partial slabs: one workgroup walks all slots
+        nsplit = 1;
+    }
+    float* dst = nsplit > 1 ? static_cast<float*>(workspace) : out;
     int f_off = 0;
     // all chunks of the widest size go out as ONE launch (gridDim.y = their count), then at most one launch per narrower size
 #define LN_CONV_CHUNKS(NTC)                                                                                                         \
     if constexpr (NT_MAX >= NTC) {                                                                                                  \
         const int cnt = (nr_filters - f_off) / (16 * NTC);                                                                          \
         if (cnt > 0) {                                                                                                              \
-            LN_LAUNCH("k_conv_mfma", (k_conv_mfma<V, NTC, FLIP, WT>), dim3(ln_div_up(m, 64), cnt), block, 0, st, nbr, values, filter, m, E, out, \
-                      nr_filters, f_off);                                                                                           \
+            LN_LAUNCH("k_conv_mfma", (k_conv_mfma<V, NTC, FLIP, WT>), dim3(ln_div_up(m, 64), cnt, nsplit), block, 0, st, nbr, values, filter, m, E, \
+                      dst, nr_filters, f_off, e_per);                                                                               \
             f_off += cnt * 16 * NTC;                                                                                                \
         }                                                                                                                           \
     }
     LN_CONV_CHUNKS(8) LN_CONV_CHUNKS(4) LN_CONV_CHUNKS(2) LN_CONV_CHUNKS(1)
 #undef LN_CONV_CHUNKS
+    if (nsplit > 1) {
+        const long long total4 = (long long)m * nr_filters / 4;
+        LN_LAUNCH("k_conv_sum_partials", ln_k_sum_partials, dim3(ln_div_up(total4, 256)), block, 0, st, (const float*)dst, nsplit, total4, out);
+    }
     return true;
 }
 
 template <bool FLIP, bool WT>
 static int ln_conv_dispatch(const int* nbr, const float* values_neigh, const float* filter, int m, int filter_extent, int val_dim,
-                            int nr_filters, float* out, hipStream_t st) {
+                            int nr_filters, float* out, void* ws, size_t ws_bytes, hipStream_t st) {
     bool done = false;
     if (filter_extent == 9 && (reinterpret_cast<uintptr_t>(filter) & 15) == 0) {  // d = 3 small-filter fast path
         const dim3 grid(ln_div_up(m, 64)), block(256);
@@ -330,15 +404,15 @@ static int ln_conv_dispatch(const int* nbr, const float* values_neigh, const flo
     if (!done && nr_filters % 16 == 0 && ((reinterpret_cast<uintptr_t>(values_neigh) | reinterpret_cast<uintptr_t>(filter)) & 15) == 0) {
         const int nf = nr_filters;
         switch (val_dim) {
-            case 8: done = ln_conv_launch_v<8, FLIP, WT>(nf, nbr, values_neigh, filter, m, filter_extent, out, st); break;
-            case 16: done = ln_conv_launch_v<16, FLIP, WT>(nf, nbr, values_neigh, filter, m, filter_extent, out, st); break;
-            case 32: done = ln_conv_launch_v<32, FLIP, WT>(nf, nbr, values_neigh, filter, m, filter_extent, out, st); break;
-            case 48: done = ln_conv_launch_v<48, FLIP, WT>(nf, nbr, values_neigh, filter, m, filter_extent, out, st); break;
-            case 64: done = ln_conv_launch_v<64, FLIP, WT>(nf, nbr, values_neigh, filter, m, filter_extent, out, st); break;
-            case 96: done = ln_conv_launch_v<96, FLIP, WT>(nf, nbr, values_neigh, filter, m, filter_extent, out, st); break;
-            case 128: done = ln_conv_launch_v<128, FLIP, WT>(nf, nbr, values_neigh, filter, m, filter_extent, out, st); break;
-            case 192: done = ln_conv_launch_v<192, FLIP, WT>(nf, nbr, values_neigh, filter, m, filter_extent, out, st); break;
-            case 256: done = ln_conv_launch_v<256, FLIP, WT>(nf, nbr, values_neigh, filter, m, filter_extent, out, st); break;
+            case 8: done = ln_conv_launch_v<8, FLIP, WT>(nf, nbr, values_neigh, filter, m, filter_extent, out, ws, ws_bytes, st); break;
+            case 16: done = ln_conv_launch_v<16, FLIP, WT>(nf, nbr, values_neigh, filter, m, filter_extent, out, ws, ws_bytes, st); break;
+            case 32: done = ln_conv_launch_v<32, FLIP, WT>(nf, nbr, values_neigh, filter, m, filter_extent, out, ws, ws_bytes, st); break;
+            case 48: done = ln_conv_launch_v<48, FLIP, WT>(nf, nbr, values_neigh, filter, m, filter_extent, out, ws, ws_bytes, st); break;
+            case 64: done = ln_conv_launch_v<64, FLIP, WT>(nf, nbr, values_neigh, filter, m, filter_extent, out, ws, ws_bytes, st); break;
+            case 96: done = ln_conv_launch_v<96, FLIP, WT>(nf, nbr, values_neigh, filter, m, filter_extent, out, ws, ws_bytes, st); break;
+            case 128: done = ln_conv_launch_v<128, FLIP, WT>(nf, nbr, values_neigh, filter, m, filter_extent, out, ws, ws_bytes, st); break;
+            case 192: done = ln_conv_launch_v<192, FLIP, WT>(nf, nbr, values_neigh, filter, m, filter_extent, out, ws, ws_bytes, st); break;
+            case 256: done = ln_conv_launch_v<256, FLIP, WT>(nf, nbr, values_neigh, filter, m, filter_extent, out, ws, ws_bytes, st); break;
             default: break;
         }
     }
@@ -350,19 +424,26 @@ static int ln_conv_dispatch(const int* nbr, const float* values_neigh, const flo
     return ln_check_launch("ln_conv_forward");
 }
 
-extern "C" int ln_conv_forward(const int* nbr, const float* values_neigh, const float* filter, int m, int filter_extent,
-                               int val_dim, int nr_filters, int flags, float* out, void* stream) {
+extern "C" int ln_conv_forward_ws(const int* nbr, const float* values_neigh, const float* filter, int m, int filter_extent, int val_dim,
+                                  int nr_filters, int flags, float* out, void* workspace, size_t workspace_bytes, void* stream) {
     LN_REQUIRE(m >= 0 && filter_extent >= 1 && val_dim >= 1 && nr_filters >= 1, LN_ERR_ARG, "ln_conv_forward: bad sizes");
     LN_REQUIRE(m == 0 || (nbr && values_neigh && filter && out), LN_ERR_ARG, "ln_conv_forward: null buffer");
     LN_REQUIRE((flags & ~3) == 0, LN_ERR_ARG, "ln_conv_forward: unknown flags %d", flags);
     if (m == 0) return LN_OK;
     hipStream_t st = (hipStream_t)stream;
+    void* ws = workspace;
+    const size_t wb = workspace_bytes;
     switch (flags) {
-        case 0: return ln_conv_dispatch<false, false>(nbr, values_neigh, filter, m, filter_extent, val_dim, nr_filters, out, st);
-        case LN_CONV_FLIP_NEIGHBOURS: return ln_conv_dispatch<true, false>(nbr, values_neigh, filter, m, filter_extent, val_dim, nr_filters, out, st);
-        case LN_CONV_TRANSPOSED_FILTER: return ln_conv_dispatch<false, true>(nbr, values_neigh, filter, m, filter_extent, val_dim, nr_filters, out, st);
-        default: return ln_conv_dispatch<true, true>(nbr, values_neigh, filter, m, filter_extent, val_dim, nr_filters, out, st);
+        case 0: return ln_conv_dispatch<false, false>(nbr, values_neigh, filter, m, filter_extent, val_dim, nr_filters, out, ws, wb, st);
+        case LN_CONV_FLIP_NEIGHBOURS: return ln_conv_dispatch<true, false>(nbr, values_neigh, filter, m, filter_extent, val_dim, nr_filters, out, ws, wb, st);
+        case LN_CONV_TRANSPOSED_FILTER: return ln_conv_dispatch<false, true>(nbr, values_neigh, filter, m, filter_extent, val_dim, nr_filters, out, ws, wb, st);
+        default: return ln_conv_dispatch<true, true>(nbr, values_neigh, filter, m, filter_extent, val_dim, nr_filters, out, ws, wb, st);
     }
+}
+
+extern "C" int ln_conv_forward(const int* nbr, const float* values_neigh, const float* filter, int m, int filter_extent,
+                               int val_dim, int nr_filters, int flags, float* out, void* stream) {
+    return ln_conv_forward_ws(nbr, values_neigh, filter, m, filter_extent, val_dim, nr_filters, flags, out, nullptr, 0, stream);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -615,6 +696,9 @@ extern "C" int ln_conv_backward(const int* nbr_q, const int* nbr_n, const float*
     int rc = ln_conv_grad_filter(nbr_q, values_neigh, grad_out, mq, filter_extent, val_dim, nr_filters, grad_filter, workspace, workspace_bytes,
                                  stream);
     if (rc) return rc;
-    return ln_conv_forward(nbr_n, grad_out, filter, mn, filter_extent, nr_filters, val_dim, LN_CONV_FLIP_NEIGHBOURS | LN_CONV_TRANSPOSED_FILTER,
-                           grad_values, stream);
+    // the value-gradient convolution may split over the filter slots: its partial slabs go behind the filter gradient's
+    size_t gf_bytes = (ln_conv_grad_filter_workspace_bytes(mq, filter_extent, val_dim, nr_filters) + 255) & ~size_t(255);
+    char* conv_ws = (workspace && workspace_bytes > gf_bytes) ? static_cast<char*>(workspace) + gf_bytes : nullptr;
+    return ln_conv_forward_ws(nbr_n, grad_out, filter, mn, filter_extent, nr_filters, val_dim, LN_CONV_FLIP_NEIGHBOURS | LN_CONV_TRANSPOSED_FILTER,
+                              grad_values, conv_ws, conv_ws ? workspace_bytes - gf_bytes : 0, stream);
 }

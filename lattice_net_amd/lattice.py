@@ -728,9 +728,16 @@ class Lattice:
         out = torch.empty((m, nr_filters), dtype=vals.dtype, device=self._dev())
         flags = (_lib.LN_CONV_FLIP_NEIGHBOURS if flip_neighbours else 0) | (_lib.LN_CONV_TRANSPOSED_FILTER if filter_is_transposed else 0)
         lib = _lib.load()
-        fn, what = (lib.ln_conv_forward_f16, "ln_conv_forward_f16") if half else (lib.ln_conv_forward, "ln_conv_forward")
-        _lib.check(fn(_lib.ptr(nbr), _lib.ptr(vals), _lib.ptr(filter_bank), m, filter_extent, v, nr_filters, flags, _lib.ptr(out),
-                      self._stream()), what)
+        if half:
+            _lib.check(lib.ln_conv_forward_f16(_lib.ptr(nbr), _lib.ptr(vals), _lib.ptr(filter_bank), m, filter_extent, v, nr_filters, flags,
+                                               _lib.ptr(out), self._stream()), "ln_conv_forward_f16")
+        else:
+            # few vertices (coarse levels): the kernel splits the contraction over the filter slots and needs room for the partials
+            wsb = int(lib.ln_conv_forward_workspace_bytes(m, filter_extent, v, nr_filters))
+            ws = torch.empty((wsb,), dtype=torch.uint8, device=self._dev()) if wsb > 256 else None
+            _lib.check(lib.ln_conv_forward_ws(_lib.ptr(nbr), _lib.ptr(vals), _lib.ptr(filter_bank), m, filter_extent, v, nr_filters, flags,
+                                              _lib.ptr(out), _lib.ptr(ws), 0 if ws is None else ws.numel(), self._stream()),
+                       "ln_conv_forward")
         conv = Lattice._clone_of(self)
         conv.m_name = "convolved_lattice"
         conv.m_hash_table.set_values(out)
@@ -763,7 +770,12 @@ class Lattice:
             raise ValueError("grad_out, filter bank and lattice values must share one dtype (float32 or float16)")
         gf = torch.empty((E * v, f), dtype=torch.float32, device=dev)
         ws_bytes = lib.ln_conv_grad_filter_f16_workspace_bytes(mq, E, v, f) if half else lib.ln_conv_grad_filter_workspace_bytes(mq, E, v, f)
-        ws = torch.empty((max(int(ws_bytes), 256),), dtype=torch.uint8, device=dev)
+        ws_bytes = int(ws_bytes)
+        if not half:  # + the slot-split partials of the value-gradient convolution (behind the filter gradient's slabs)
+            conv_ws = int(lib.ln_conv_forward_workspace_bytes(int(nb.nr_lattice_vertices()), E, f, v))
+            if conv_ws > 256:
+                ws_bytes = ((ws_bytes + 255) // 256) * 256 + conv_ws
+        ws = torch.empty((max(ws_bytes, 256),), dtype=torch.uint8, device=dev)
         # ---- value gradient on the main stream: the query and neighbour roles swap (funcs:307-313, 380-387)
         nbr_n = nb.neighbours(q, dilation, False)
         mn = nbr_n.shape[0]

@@ -8,7 +8,7 @@ OUT=$ROOT/gpurun_out/prof_lnn
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python3 $ROOT/tools/bench_lnn.py --config $CONFIG --steps 10 --warmup 3 > $OUT/stats.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python3 $ROOT/tools/bench_lnn.py --config $CONFIG --steps 10 --warmup 3 > $OUT/stats.log 2>&1
 cd $ROOT
 tail -2 $OUT/stats.log
 S=$(find $OUT/stats -name "*kernel_stats.csv" | head -1)
