@@ -491,7 +491,8 @@ def main():
             "value": round(value, 3), "unit": "Mpoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(max_elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16 features / f32 accumulate" if half else "f32", "data": "synthetic",
-            "config": {"workload": cfg["desc"], "points_per_gpu": n, "vertices": m, "val_dim": v, "nr_filters": f,
+            "config": {"workload": cfg["desc"] + (f"; {in_flight} independent scans in flight per GPU, K steps = K scans" if in_flight > 1 else ""),
+                       "points_per_gpu": n, "vertices": m, "val_dim": v, "nr_filters": f,
                        "sharding": f"{world} independent cloud(s), one per GPU", "checksum": round(checksum, 3),
                        "execution": (f"one hipGraph replay per scan (whole forward + backward captured once, static row bound); "
                                      f"{in_flight} independent scan(s) in flight per GPU, each with its own lattice, graph and stream; "
