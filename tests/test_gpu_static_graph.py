@@ -160,3 +160,30 @@ def test_region_planes_change_placement_not_results():
     lat.set_region_planes(None)
     lv, _, idx, w = L.SplatLattice.apply(lat, pos, vals)
     assert rel(lv[:m].cpu().numpy(), lv_ref) < RTOL
+
+
+@pytest.mark.parametrize("d", [1, 2, 4, 5])
+def test_region_planes_other_dimensions(d):
+    """The kd region function uses key[0], key[1 % d], key[2 % d]: any d builds the same lattice with or without planes."""
+    import lattice_net_amd as L
+
+    n, v, cap = 6000, 8, 40000
+    rng = np.random.default_rng(100 + d)
+    pos_np = (rng.standard_normal((n, d)) * 2.0).astype(np.float32)
+    vals_np = rng.standard_normal((n, v)).astype(np.float32)
+    sigma = 0.6
+    t = O.OracleHashTable(cap, d)
+    idx_ref, w_ref = O.build_splat(t, O.scale_positions(pos_np, np.full((d,), sigma, np.float32)))
+    m = t.nr_filled
+    lv_ref = np.zeros((m, v), np.float32)
+    O.splat_accumulate(lv_ref, vals_np, idx_ref, w_ref)
+    pos = torch.from_numpy(pos_np).to(dev())
+    vals = torch.from_numpy(vals_np).to(dev())
+    lat = L.Lattice(sigmas=[sigma] * d, capacity=cap, device=dev())
+    _, _, idx, _ = L.SplatLattice.apply(lat, pos, vals)
+    assert lat.nr_lattice_vertices() == m
+    lat.set_region_planes(lat.balanced_region_planes(idx))
+    lv, _, idx, w = L.SplatLattice.apply(lat, pos, vals)
+    assert lat.nr_lattice_vertices() == m
+    assert np.array_equal(idx.cpu().numpy(), idx_ref)
+    assert rel(lv[:m].cpu().numpy(), lv_ref) < RTOL
