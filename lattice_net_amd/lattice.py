@@ -1077,7 +1077,12 @@ class Lattice:
         no neighbours (the traversal marks them LN_NOT_VISITED), no splat index refers to them — so every kernel of the
         path computes exactly what it computes in eager mode on rows < M and zeros beyond.  The real count and the
         status bits of each build still land in the pinned host pair: call static_build_report() after synchronising
-        to check them (M > B or a bucket overflow mean the replayed step is invalid and must be redone eagerly)."""
+        to check them (M > B or a bucket overflow mean the replayed step is invalid and must be redone eagerly).
+
+        Capture notes: run the step once or twice on a side stream first (it creates the table buffers, the pinned counter
+        pair and the build workspace, none of which may be allocated during a capture), keep this object alive as long as
+        the graph, and do not use it eagerly with LARGER clouds while the graph exists (the workspace the captured kernels
+        point at would be re-allocated)."""
         ht = self.m_hash_table
         if rows_bound is None:
             ht._static_rows = None
