@@ -287,44 +287,28 @@ def main():
             self.state.update(m=m, out=out, gv=lv.grad, gw=W.grad, idx=idx)
 
         def capture(self):
-            """Calibrates the static row bound with eager steps, then captures the whole step into one hipGraph."""
-            self.step()
-            if args.regions:
-                self.lat.set_region_planes(self.lat.balanced_region_planes(self.state["idx"]))
+            """Eager reference result, then lattice_net_amd.capture.CapturedStep: static row bound + kd region planes calibrated
+            on this scan, warm-up on a side stream, the whole step captured into one hipGraph."""
+            from lattice_net_amd.capture import CapturedStep
             self.step()
             torch.cuda.synchronize()
             self.m_real = self.state["m"]
             self.eager_out = self.state["out"].detach().clone()
             self.eager_gw = self.state["gw"].detach().clone()
-            rows = min(cap, ((int(self.m_real * (1.0 + args.row_slack)) + 255) // 256) * 256)
-            self.lat.set_static_rows(rows)  # no host readback inside the step: rows m_real..rows-1 are isolated zero vertices
-            # Drop every reference to the eager steps' autograd graphs first: W's AccumulateGrad node lives as long as one
-            # of them does and would run on the stream it was created on, which a capture of another stream cannot include.
-            self.state.clear()
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(2):
-                    self.step()
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            self.state.clear()
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                self.step()
+            self.cap = CapturedStep(self.step, [self.lat], row_slack=args.row_slack, regions=bool(args.regions),
+                                    region_indices=lambda: self.state["idx"], stream=self.stream, before_capture=self.state.clear)
+            assert self.cap.vertices[0] == self.m_real
+            self.graph = self.cap.graph
 
         def launch(self):
             if self.graph is None:
                 self.step()
-            elif self.stream is None:
-                self.graph.replay()
             else:
-                with torch.cuda.stream(self.stream):
-                    self.graph.replay()
+                self.cap.launch()
 
         def check(self):
             """Replayed build within its bounds, replayed results equal to the eager step's (1e-5 relative)."""
-            nr, _status = self.lat.static_build_report()
+            nr = self.cap.check()[0]  # raises if the replayed build overflowed its row bound or a bucket
             assert nr == self.m_real, (nr, self.m_real)
             scale = float(self.eager_out.abs().max())
             err = {"out_max_rel": float((self.state["out"].detach() - self.eager_out).abs().max()) / max(scale, 1e-30),

@@ -1,0 +1,85 @@
+"""Whole-step capture: run a splat -> conv -> slice style step (forward + backward) as ONE hipGraph replay.
+
+The reference reads the vertex count back to the host after every lattice build (src/Lattice.cu:1320-1352), which no stream
+capture can contain.  `CapturedStep` packages the recipe that removes that wait:
+
+  1. calibrate: run the step eagerly once; for every lattice it builds, read the vertex count, set a static row bound
+     (count x (1 + row_slack), rounded up to 256) and, optionally, kd region planes balanced on this cloud;
+  2. warm up the static-rows step on a side stream (allocates the table buffers, pinned counters and build workspaces
+     outside the capture);
+  3. capture the step with torch.cuda.graph;
+  4. `launch()` replays it (on `stream`, so that several captured steps — independent scans — can be in flight at once),
+     `check()` verifies after a synchronise that every replayed build stayed inside its bounds.
+
+The step function must be self-contained: it reads its inputs from tensors that stay alive (overwrite them IN PLACE to feed
+new data of the same shape), uses `lattice.nr_lattice_vertices()` wherever it needs a row count, and must not synchronise.
+Only the splat -> conv -> slice family is capture-safe today: modules whose statistics run over the vertex rows (GroupNorm)
+would see the padded rows.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Sequence
+
+import torch
+
+from .lattice import Lattice
+
+__all__ = ["CapturedStep"]
+
+
+class CapturedStep:
+    def __init__(self, step: Callable[[], object], lattices: Sequence[Lattice], *, row_slack: float = 0.06, regions: bool = True,
+                 region_indices: Optional[Callable[[], torch.Tensor]] = None, stream: Optional[torch.cuda.Stream] = None,
+                 before_capture: Optional[Callable[[], None]] = None):
+        """`step`: the function to capture.  `lattices`: the Lattice objects it builds (each gets a static row bound).
+        `region_indices`: returns the splat-index tensor of the calibration step when kd region planes are wanted (they are
+        balanced on the token counts of that build); None: no regions.  `before_capture`: called right before the warm-up and
+        the capture to drop references to earlier autograd graphs (a parameter's AccumulateGrad node lives as long as one of
+        them does and would run on the stream it was created on, which a capture of another stream cannot include)."""
+        self.step = step
+        self.lattices = list(lattices)
+        self.stream = stream
+        self.vertices = []
+        self.result = step()  # calibration (eager: reads the vertex counts back)
+        for lat in self.lattices:
+            m = lat.nr_lattice_vertices()
+            self.vertices.append(m)
+            if regions and region_indices is not None:
+                lat.set_region_planes(lat.balanced_region_planes(region_indices()))
+        if regions and region_indices is not None:
+            self.result = step()  # the eager reference result with the regions in place
+        torch.cuda.synchronize()
+        for lat, m in zip(self.lattices, self.vertices):
+            rows = min(lat.capacity(), ((int(m * (1.0 + row_slack)) + 255) // 256) * 256)
+            lat.set_static_rows(rows)
+        if before_capture is not None:
+            before_capture()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        if before_capture is not None:
+            before_capture()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.captured = step()
+
+    def launch(self):
+        """One replay, on `stream` if one was given (asynchronous)."""
+        if self.stream is None:
+            self.graph.replay()
+        else:
+            with torch.cuda.stream(self.stream):
+                self.graph.replay()
+
+    def check(self):
+        """After a synchronise: every replayed build inside its row bound, no bucket overflow.  Returns the vertex counts."""
+        return [lat.static_build_report()[0] for lat in self.lattices]
+
+    def release(self):
+        """Back to eager mode (the lattices read their vertex counts again)."""
+        for lat in self.lattices:
+            lat.set_static_rows(None)

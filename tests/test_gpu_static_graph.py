@@ -187,3 +187,48 @@ def test_region_planes_other_dimensions(d):
     assert lat.nr_lattice_vertices() == m
     assert np.array_equal(idx.cpu().numpy(), idx_ref)
     assert rel(lv[:m].cpu().numpy(), lv_ref) < RTOL
+
+
+def test_captured_step_helper_two_scans_in_flight():
+    """lattice_net_amd.CapturedStep: calibration + capture in one call; two captured scans replayed concurrently on their own
+    streams give each scan's oracle result."""
+    import lattice_net_amd as L
+    from lattice_net_amd.synthetic import lidar_cloud
+
+    torch.autograd.set_multithreading_enabled(False)
+    n, v, f, sigma, cap = 5000, 32, 32, 0.9, 30000
+    rng = np.random.default_rng(9)
+    w_np = (rng.standard_normal((9 * v, f)) / np.sqrt(9 * v)).astype(np.float32)
+    W = torch.from_numpy(w_np).to(dev()).requires_grad_(True)
+    scans = []
+    for k in range(2):
+        pos_np = lidar_cloud(n, 40 + k)
+        vals_np = rng.standard_normal((n, v)).astype(np.float32)
+        g_np = rng.standard_normal((n, f)).astype(np.float32)
+        sc = {"ref": oracle_step(pos_np, vals_np, w_np, g_np, sigma, cap), "st": {},
+              "pos": torch.from_numpy(pos_np).to(dev()), "vals": torch.from_numpy(vals_np).to(dev()), "G": torch.from_numpy(g_np).to(dev()),
+              "lat": L.Lattice(sigmas=[sigma] * 3, capacity=cap, device=dev())}
+
+        def step(sc=sc):
+            W.grad = None
+            lv, _, idx, w = L.SplatLattice.apply(sc["lat"], sc["pos"], sc["vals"])
+            lv = lv[:sc["lat"].nr_lattice_vertices()].requires_grad_(True)
+            cv, cw = L.ConvIm2RowLattice.apply(lv, sc["lat"], W, 1)
+            out = L.SliceLattice.apply(cv, cw.lattice, sc["pos"], idx, w)
+            out.backward(sc["G"])
+            sc["st"].update(out=out, idx=idx, gw=W.grad)
+
+        sc["cap"] = L.CapturedStep(step, [sc["lat"]], region_indices=lambda sc=sc: sc["st"]["idx"], stream=torch.cuda.Stream(),
+                                   before_capture=sc["st"].clear)
+        scans.append(sc)
+    torch.cuda.synchronize()
+    for _ in range(3):
+        for sc in scans:
+            sc["cap"].launch()
+    torch.cuda.synchronize()
+    for sc in scans:
+        m_ref, idx_ref, out_ref, gw_ref = sc["ref"]
+        assert sc["cap"].check() == [m_ref]
+        assert np.array_equal(sc["st"]["idx"].cpu().numpy(), idx_ref)
+        assert rel(sc["st"]["out"].detach().cpu().numpy(), out_ref) < RTOL
+        assert rel(sc["st"]["gw"].cpu().numpy(), gw_ref) < RTOL
