@@ -109,3 +109,25 @@ def test_filter_extent_is_known_before_the_first_build():
     assert lat.pos_dim() == 3 and lat.get_filter_extent(1) == 9
     assert Lattice(sigmas=[0.1] * 5, capacity=100).get_filter_extent(1) == 13
     assert Lattice.get_expected_filter_extent(1) == 13  # the static follows the last set_sigmas (Lattice.cu:44)
+
+
+def test_static_rows_and_region_planes_argument_checks():
+    """Capture-mode switches (extensions of the reference API): bounds are validated on the host, a static lattice answers
+    nr_lattice_vertices() without touching the device, and the ctypes mirror of LnCsr matches the header's field order."""
+    from lattice_net_amd import _lib, LatticeNetHipError
+
+    lat = Lattice(sigmas=[0.5] * 3, capacity=1000)
+    with pytest.raises(ValueError):
+        lat.set_static_rows(0)
+    with pytest.raises(ValueError):
+        lat.set_static_rows(1001)
+    lat.set_static_rows(512)
+    assert lat.nr_lattice_vertices() == 512          # no table exists yet: nothing was read from a device
+    assert lat.clone_lattice().nr_lattice_vertices() == 512  # clones (e.g. the convolved lattice) inherit the bound
+    lat.set_static_rows(None)
+    with pytest.raises(LatticeNetHipError):
+        lat.set_region_planes([0] * 7)               # needs a built table
+    with pytest.raises(LatticeNetHipError):
+        lat.static_build_report()                    # no build has run
+    assert [f[0] for f in _lib.LnCsr._fields_] == ["grp_start", "csr_tok", "seg_desc", "seg_count", "seg_region", "planes"]
+    assert _lib.LN_XCD_GROUPS == 8
