@@ -40,6 +40,8 @@ extern "C" {
                                        re-run it with LN_BUILD_ATOMIC_PATH (whose inserts spill past a full bucket) */
 
 #define LN_MAX_POS_DIM 6
+#define LN_KEYS_RAW 0     /* LnTable.key_format */
+#define LN_KEYS_LATTICE 1
 #define LN_NOT_VISITED (-2)          /* neighbour-list code: traversal never looks at this slot */
 
 /* Device-side open-addressing table.  Replaces HashTableGPU (HashTableGPU.cuh:12-30) and its
@@ -66,6 +68,10 @@ typedef struct LnTable {
                                       scope release).  A host that passes a fresh host_seq per build can spin on word 2
                                       and read the vertex count as soon as the scan has run, without a copy or an event */
     int host_seq;                  /* value the build stores in host_counters[2] */
+    int key_format;                /* how slot_keys packs a key (fixed for the life of the table's contents): 0 = raw, any integer
+                                      tuple (needed by ln_coarsen's target, which receives halved fine keys); 1 = lattice points
+                                      only — remainder + quotients, 6-7x the coordinate range for pos_dim 5-6 (every table
+                                      built from positions).  See KeyPack in csrc/ln_common.h */
 } LnTable;
 
 /* Adjacency "group -> the tokens that touch it" in CSR form, cut into segments of at most 16

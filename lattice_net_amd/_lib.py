@@ -22,6 +22,8 @@ LN_NOT_VISITED = -2
 LN_CONV_FLIP_NEIGHBOURS = 1
 LN_CONV_TRANSPOSED_FILTER = 2
 LN_MAX_POS_DIM = 6
+LN_KEYS_RAW = 0
+LN_KEYS_LATTICE = 1
 LN_XCD_GROUPS = 8
 
 
@@ -40,6 +42,7 @@ class LnTable(C.Structure):
         ("status", C.c_void_p),
         ("host_counters", C.c_void_p),
         ("host_seq", C.c_int),
+        ("key_format", C.c_int),
     ]
 
 

@@ -43,32 +43,69 @@ struct LnProfScope {
     } while (0)
 
 // ---- key packing -----------------------------------------------------------------------
-// A lattice key (first d coordinates, int32) is packed into one 64-bit word so that a slot can
-// be claimed and its key published by a single 64-bit CAS.  bits per coordinate = min(32, 63/d);
-// d*bits <= 63 for d >= 2 keeps bit 63 clear, so a packed key can never equal LN_EMPTY_KEY.
-// (Storing the remainder mod d+1 that the coordinates of a lattice point share, plus the quotients, would stretch the range
-// by d+1 — but `coarsen` halves fine keys (LatticeGPU.cuh:2376-2400), and half of a remainder-2 point such as (2,2,-2,-2)
-// is an integer tuple with mixed remainders that the reference does insert: the raw format is the one that holds them.)
+// A lattice key (first d coordinates, int32) is packed into one 64-bit word so that a slot can be claimed and its key
+// published by a single 64-bit CAS.  Bit 63 stays clear in both formats, so a packed key never equals LN_EMPTY_KEY.
+//   LN_KEYS_RAW     : min(32, 63/d) bits per coordinate — any integer tuple (the key-based coarsening inserts halved fine keys,
+//                     which are not lattice points: LatticeGPU.cuh:2376-2400), d = 5: +-2048, d = 6: +-512 lattice units.
+//   LN_KEYS_LATTICE : for tables that only ever hold points of the permutohedral lattice (everything built from positions):
+//                     all d+1 coordinates of such a point share one remainder r mod d+1, key[i] = (d+1) q[i] + r, and the
+//                     word holds r (3 bits) and the d quotients with min(32, 60/d) bits each — d = 5: +-12288, d = 6: +-3584
+//                     lattice units, 6-7x the raw range (d <= 3: 2^20 quotients, i.e. more than int32 positions can need).
+//                     A key that is not a lattice point cannot be packed — and cannot be in such a table: lookups return -1.
 template <int D>
 struct KeyPack {
     static constexpr int BITS = (63 / D) > 32 ? 32 : (63 / D);
     static constexpr int64_t LO = -(int64_t(1) << (BITS - 1));
     static constexpr int64_t HI = (int64_t(1) << (BITS - 1)) - 1;
     static constexpr uint64_t MASK = (BITS == 64) ? ~0ull : ((uint64_t(1) << BITS) - 1);
+    static constexpr int QBITS = (60 / D) > 32 ? 32 : (60 / D);
+    static constexpr int64_t QLO = -(int64_t(1) << (QBITS - 1));
+    static constexpr int64_t QHI = (int64_t(1) << (QBITS - 1)) - 1;
+    static constexpr uint64_t QMASK = (uint64_t(1) << QBITS) - 1;
 
-    static LN_HD bool in_range(const int* key) {
+    static LN_HD int rem(int k) {  // k mod (D+1) in [0, D]
+        const int r = k % (D + 1);
+        return r < 0 ? r + (D + 1) : r;
+    }
+    static LN_HD bool in_range(const int* key, int fmt) {
         bool ok = true;
+        if (fmt == LN_KEYS_LATTICE) {
+            const int r = rem(key[0]);
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                const int64_t qi = (int64_t(key[i]) - r) / (D + 1);
+                ok = ok && rem(key[i]) == r && qi >= QLO && qi <= QHI;
+            }
+            return ok;
+        }
 #pragma unroll
         for (int i = 0; i < D; ++i) ok = ok && (int64_t(key[i]) >= LO) && (int64_t(key[i]) <= HI);
         return ok;
     }
-    static LN_HD uint64_t pack(const int* key) {
+    static LN_HD uint64_t pack(const int* key, int fmt) {
         uint64_t p = 0;
+        if (fmt == LN_KEYS_LATTICE) {
+            const int r = rem(key[0]);
+            p = uint64_t(r);
+#pragma unroll
+            for (int i = 0; i < D; ++i) p |= (uint64_t((int64_t(key[i]) - r) / (D + 1)) & QMASK) << (3 + i * QBITS);
+            return p;
+        }
 #pragma unroll
         for (int i = 0; i < D; ++i) p |= (uint64_t(int64_t(key[i])) & MASK) << (i * BITS);
         return p;
     }
-    static LN_HD void unpack(uint64_t p, int* key) {
+    static LN_HD void unpack(uint64_t p, int* key, int fmt) {
+        if (fmt == LN_KEYS_LATTICE) {
+            const int r = int(p & 7);
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                const uint64_t f = (p >> (3 + i * QBITS)) & QMASK;
+                const int64_t qi = int64_t(f << (64 - QBITS)) >> (64 - QBITS);  // sign extend
+                key[i] = int(qi * (D + 1) + r);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < D; ++i) {
             uint64_t f = (p >> (i * BITS)) & MASK;
@@ -218,8 +255,8 @@ LN_HD int ln_region_of_key(const int* key, const int* planes) {
 // after 300 mismatching probes.
 template <int D>
 __device__ __forceinline__ int ln_retrieve(const LnTable& t, const int* key) {
-    if (!KeyPack<D>::in_range(key)) return -1;  // cannot have been inserted
-    const uint64_t pk = KeyPack<D>::pack(key);
+    if (!KeyPack<D>::in_range(key, t.key_format)) return -1;  // cannot have been inserted
+    const uint64_t pk = KeyPack<D>::pack(key, t.key_format);
     const LnProbe pr = LnProbe::of_key<D>(key, t.capacity, ln_bucket_slots(t.capacity));
     const int limit = t.capacity < LN_MAX_RETRIEVE_CONFLICTS ? t.capacity : LN_MAX_RETRIEVE_CONFLICTS;
     for (int conflicts = 0; conflicts < limit; ++conflicts) {

@@ -222,11 +222,11 @@ extern "C" int ln_table_clear(const LnTable* t, float* values, long long values_
 template <int D>
 __device__ __forceinline__ int ln_insert(const LnTable& t, const int* key, int& pos) {
     pos = -1;
-    if (!KeyPack<D>::in_range(key)) {
+    if (!KeyPack<D>::in_range(key, t.key_format)) {
         atomicOr(t.status, LN_STATUS_KEY_RANGE);
         return -1;
     }
-    const uint64_t pk = KeyPack<D>::pack(key);
+    const uint64_t pk = KeyPack<D>::pack(key, t.key_format);
     const LnProbe pr = LnProbe::of_key<D>(key, t.capacity, ln_bucket_slots(t.capacity));
     for (int probes = 0; probes < t.capacity; ++probes) {
         const int h = pr.slot(probes);
@@ -346,9 +346,9 @@ __global__ void __launch_bounds__(256)
             int key[D];
             ln_vertex_key<D>(s, r, key);
             const size_t tk = (size_t)p * (D + 1) + r;
-            const bool ok = KeyPack<D>::in_range(key);
+            const bool ok = KeyPack<D>::in_range(key, t.key_format);
             if (ok) {
-                pk[it][r] = KeyPack<D>::pack(key);
+                pk[it][r] = KeyPack<D>::pack(key, t.key_format);
                 bkt[it][r] = LnProbe::of_key<D>(key, t.capacity, sb).lo / sb;
                 rank[it][r] = atomicAdd(&s_cnt[bkt[it][r]], 1);
             } else {
@@ -507,7 +507,7 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
         pos = -1;
         if (valid) {
             int key[D];
-            KeyPack<D>::unpack(pk, key);
+            KeyPack<D>::unpack(pk, key, t.key_format);
             int o = LnProbe::of_key<D>(key, t.capacity, sb).off;
             for (int i = 0; i < size; ++i) {
                 unsigned long long cur = skeys[o];
@@ -610,7 +610,7 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
             const int c = scnt[i];
             if (c) {
                 int key[D];
-                KeyPack<D>::unpack(skeys[i], key);
+                KeyPack<D>::unpack(skeys[i], key, t.key_format);
                 const int r = ln_region_of_key<D>(key, planes);
                 sseg[i] = (r << 28) | atomicAdd(&s_rcnt[r], (c + LN_CSR_SEG - 1) / LN_CSR_SEG);
             }
@@ -847,7 +847,7 @@ __global__ void __launch_bounds__(256)
         if (ft == (unsigned int)tk) {  // first occurrence publishes the vertex
             t.entries[h] = row;
             int key[D];
-            KeyPack<D>::unpack(t.slot_keys[h], key);
+            KeyPack<D>::unpack(t.slot_keys[h], key, t.key_format);
 #pragma unroll
             for (int i = 0; i < D; ++i) t.keys[(size_t)row * D + i] = key[i];
         }

@@ -64,6 +64,9 @@ class _TableStorage:
         self.slot_keys = torch.empty((capacity,), dtype=torch.int64, device=device)
         self.slot_tok = torch.empty((capacity,), dtype=torch.int32, device=device)
         self.slot_cnt = torch.zeros((capacity,), dtype=torch.int32, device=device)  # scratch that is all-zero between builds
+        # every table built from positions holds lattice points only: the wide packed-key format (LnTable.key_format); the target
+        # of the key-based coarsening (create_coarse_verts) receives halved fine keys and switches to the raw format
+        self.key_format = _lib.LN_KEYS_LATTICE
         self.version = 0
         self.nbr_cache = {}
         self.csr_cache = {}
@@ -74,6 +77,7 @@ class _TableStorage:
         s = _TableStorage.__new__(_TableStorage)
         s.uid = next(_TableStorage._uids)
         s.capacity, s.pos_dim, s.device = self.capacity, self.pos_dim, self.device
+        s.key_format = self.key_format
         s.keys = self.keys.clone()
         s.entries = self.entries.clone()
         s.slot_keys = self.slot_keys.clone()
@@ -158,7 +162,8 @@ class HashTable:
 
     def _make_c_table(self, s) -> _lib.LnTable:
         return _lib.LnTable(s.capacity, s.pos_dim, s.slot_keys.data_ptr(), s.slot_tok.data_ptr(), s.slot_cnt.data_ptr(), s.entries.data_ptr(),
-                            s.keys.data_ptr(), self._counters.data_ptr(), self._counters.data_ptr() + 4, self._pinned.data_ptr(), 0)
+                            s.keys.data_ptr(), self._counters.data_ptr(), self._counters.data_ptr() + 4, self._pinned.data_ptr(), 0,
+                            s.key_format)
 
     def clear(self, lazy: bool = False):  # HashTable.cu:49-57, one launch instead of four fill_ kernels
         """`lazy=True` only records that a clear is due: the next build issues it inside its own C call (no host
@@ -871,6 +876,7 @@ class Lattice:
 
     def create_coarse_verts(self) -> "Lattice":  # Lattice.cu:670-703
         coarse = self._new_coarse()
+        coarse.m_hash_table._storage.key_format = _lib.LN_KEYS_RAW  # halved fine keys are not all lattice points
         lib = _lib.load()
         m = self.nr_lattice_vertices()
         tokens = m * (2 * (self.pos_dim() + 1) + 1)
@@ -1181,10 +1187,16 @@ class Lattice:
                                               "(the reference would spin forever, HashTableGPU.cuh:443)")
             if status & _lib.LN_STATUS_KEY_RANGE:
                 d = self.pos_dim()
-                bits = min(32, 63 // max(d, 1))
+                fmt = getattr(ht._storage, "key_format", _lib.LN_KEYS_LATTICE)
+                if fmt == _lib.LN_KEYS_LATTICE:
+                    bits = min(32, 60 // max(d, 1))
+                    reach = 2 ** (bits - 1) * (d + 1)
+                else:
+                    bits = min(32, 63 // max(d, 1))
+                    reach = 2 ** (bits - 1)
                 raise _lib.LatticeNetHipError(
                     f"a lattice key does not fit the packed 64-bit slot format: pos_dim {d} leaves {bits} bits per coordinate, i.e. "
-                    f"lattice coordinates within +-{2 ** (bits - 1)} (about +-{2 ** (bits - 1) / (d + 1) / 0.8165:.0f} sigmas from the "
+                    f"lattice coordinates within +-{reach} (about +-{reach / (d + 1) / 0.8165:.0f} sigmas from the "
                     "origin per axis); centre the positions or use larger sigmas (README: 'Key range')")
             ht.m_nr_filled = nr
             ht.m_nr_filled_is_dirty = False

@@ -227,3 +227,41 @@ def test_very_large_tables_number_rows_like_a_small_one(cap, atomic, monkeypatch
     assert torch.equal(big.hash_table().m_keys_tensor[:bm], small.hash_table().m_keys_tensor[:sm])
     np.testing.assert_allclose(N(big.values()[:bm]), N(small.values()[:sm]), rtol=1e-5, atol=1e-5)
     assert torch.equal(big.neighbours(None, 1, False), small.neighbours(None, 1, False))
+
+
+@pytest.mark.parametrize("d,reach", [(5, 9000), (6, 3000)])
+def test_lattice_key_format_covers_wide_clouds(d, reach):
+    """pos_dim 5 / 6 (e.g. xyz+rgb positions): the packed key of a table built from positions stores the shared remainder and
+    the quotients, so lattice coordinates of several thousand units fit (the raw format stops at +-2048 / +-512).  Indices,
+    weights and keys must still match the oracle bit for bit; beyond the range the build reports it."""
+    import lattice_net_amd as L
+
+    rng = np.random.default_rng(50 + d)
+    n, cap = 3000, 40000
+    # keys scale linearly with the positions: measure them at one scale, then stretch the cloud so that the largest lattice
+    # coordinate lands at `reach` units — beyond the raw format, inside the lattice format
+    unit = rng.uniform(-1.0, 1.0, (n, d)).astype(np.float32)
+    t0 = O.OracleHashTable(cap, d)
+    O.build_splat(t0, O.scale_positions(unit * 100.0, np.ones((d,), np.float32)), False)
+    spread = 100.0 * reach / float(np.abs(t0.keys[: t0.nr_filled]).max())
+    pos_np = (unit * spread).astype(np.float32)
+    t = O.OracleHashTable(cap, d)
+    idx_ref, w_ref = O.build_splat(t, O.scale_positions(pos_np, np.ones((d,), np.float32)))
+    kmax = int(np.abs(t.keys[: t.nr_filled]).max())
+    assert (2048 if d == 5 else 512) < kmax < (12288 if d == 5 else 3584), kmax
+    lat = L.Lattice(sigmas=[1.0] * d, capacity=cap, device=dev())
+    lat.begin_splat()
+    idx, w = lat.just_create_verts(T(pos_np), True)
+    assert lat.nr_lattice_vertices() == t.nr_filled
+    assert np.array_equal(N(idx), idx_ref)
+    assert np.array_equal(N(w), w_ref)
+    assert np.array_equal(N(lat.m_hash_table.m_keys_tensor)[: t.nr_filled], t.keys[: t.nr_filled])
+    # neighbour lookups go through the same format
+    nbr_ref = O.neighbour_rows(t.keys[: t.nr_filled], t, 1, 1, 1, False)
+    assert np.array_equal(N(lat.neighbours(lat, 1, False)), nbr_ref)
+    # far beyond the range: reported, not silently wrong
+    far = L.Lattice(sigmas=[1.0] * d, capacity=cap, device=dev())
+    far.begin_splat()
+    far.just_create_verts(T(pos_np * 50.0), True)
+    with pytest.raises(L.LatticeNetHipError, match="packed 64-bit"):
+        far.nr_lattice_vertices()
