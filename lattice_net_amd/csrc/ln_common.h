@@ -95,6 +95,23 @@ struct KeyPack {
         for (int i = 0; i < D; ++i) p |= (uint64_t(int64_t(key[i])) & MASK) << (i * BITS);
         return p;
     }
+    // Lattice format when the caller KNOWS the shared remainder r (the simplex code does: vertex `r` of a simplex has remainder r):
+    // no modulo per coordinate, and the division by d+1 is exact.
+    static LN_HD bool lattice_in_range(const int* key, int r) {
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            const int64_t qi = (int64_t(key[i]) - r) / (D + 1);
+            ok = ok && qi >= QLO && qi <= QHI;
+        }
+        return ok;
+    }
+    static LN_HD uint64_t lattice_pack(const int* key, int r) {
+        uint64_t p = uint64_t(r);
+#pragma unroll
+        for (int i = 0; i < D; ++i) p |= (uint64_t((int64_t(key[i]) - r) / (D + 1)) & QMASK) << (3 + i * QBITS);
+        return p;
+    }
     static LN_HD void unpack(uint64_t p, int* key, int fmt) {
         if (fmt == LN_KEYS_LATTICE) {
             const int r = int(p & 7);

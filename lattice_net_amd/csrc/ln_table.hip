@@ -346,9 +346,10 @@ __global__ void __launch_bounds__(256)
             int key[D];
             ln_vertex_key<D>(s, r, key);
             const size_t tk = (size_t)p * (D + 1) + r;
-            const bool ok = KeyPack<D>::in_range(key, t.key_format);
+            const bool lat_fmt = t.key_format == LN_KEYS_LATTICE;  // (vertex r of a simplex has remainder r: no modulo needed)
+            const bool ok = lat_fmt ? KeyPack<D>::lattice_in_range(key, r) : KeyPack<D>::in_range(key, t.key_format);
             if (ok) {
-                pk[it][r] = KeyPack<D>::pack(key, t.key_format);
+                pk[it][r] = lat_fmt ? KeyPack<D>::lattice_pack(key, r) : KeyPack<D>::pack(key, t.key_format);
                 bkt[it][r] = LnProbe::of_key<D>(key, t.capacity, sb).lo / sb;
                 rank[it][r] = atomicAdd(&s_cnt[bkt[it][r]], 1);
             } else {
