@@ -452,7 +452,9 @@ extern "C" int ln_conv_forward(const int* nbr, const float* values_neigh, const 
 //          the 4 waves are combined through LDS and the workgroup writes one partial [V,F] slab.
 // Stage 2: deterministic sum of the slabs.
 // ------------------------------------------------------------------------------------------
+#ifndef LN_GF_ROWS
 #define LN_GF_ROWS 320   // lattice vertices per workgroup (one slab each)
+#endif
 #define LN_GF_SUB 64     // vertices staged in LDS at a time (25 KiB of LDS -> 6 workgroups per CU)
 
 // Stage 1.  grid = (row chunks, E).  A workgroup walks its chunk in sub-tiles of LN_GF_SUB vertices: the
