@@ -72,6 +72,10 @@ typedef struct LnTable {
                                       tuple (needed by ln_coarsen's target, which receives halved fine keys); 1 = lattice points
                                       only — remainder + quotients, 6-7x the coordinate range for pos_dim 5-6 (every table
                                       built from positions).  See KeyPack in csrc/ln_common.h */
+    int row_limit;                 /* 0 = none.  > 0 (static-rows mode of the host, whose [rows, *] tensors are this tall): a build
+                                      leaves vertices that would get a row >= row_limit un-inserted — idx = -1, no entries[] /
+                                      keys[] row — so that no consumer can index past the host's tensors; nr_filled still
+                                      counts them, which is how the host notices (nr_filled > row_limit) */
 } LnTable;
 
 /* Adjacency "group -> the tokens that touch it" in CSR form, cut into segments of at most 16

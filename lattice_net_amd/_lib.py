@@ -43,6 +43,7 @@ class LnTable(C.Structure):
         ("host_counters", C.c_void_p),
         ("host_seq", C.c_int),
         ("key_format", C.c_int),
+        ("row_limit", C.c_int),
     ]
 
 

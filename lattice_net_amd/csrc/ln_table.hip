@@ -845,7 +845,8 @@ __global__ void __launch_bounds__(256)
         }
         r += __popcll(mine & ((1ull << (ft & 63)) - 1ull));
         row = r;
-        if (ft == (unsigned int)tk) {  // first occurrence publishes the vertex
+        if (t.row_limit > 0 && row >= t.row_limit) row = -1;  // beyond the host's static row bound: stays un-inserted
+        if (ft == (unsigned int)tk && row >= 0) {  // first occurrence publishes the vertex
             t.entries[h] = row;
             int key[D];
             KeyPack<D>::unpack(t.slot_keys[h], key, t.key_format);

@@ -153,7 +153,7 @@ class HashTable:
             self._pinned = torch.zeros((4,), dtype=torch.int32, pin_memory=True)
             self._pinned_np = self._pinned.numpy()  # same memory: the host polls word 2
             self._readback_event = torch.cuda.Event()
-        key = (s.uid, self._counters.data_ptr())
+        key = (s.uid, self._counters.data_ptr(), self._static_rows)
         if getattr(self, "_c_table_key", None) == key:
             return self._c_table
         self._c_table_key = key
@@ -163,7 +163,7 @@ class HashTable:
     def _make_c_table(self, s) -> _lib.LnTable:
         return _lib.LnTable(s.capacity, s.pos_dim, s.slot_keys.data_ptr(), s.slot_tok.data_ptr(), s.slot_cnt.data_ptr(), s.entries.data_ptr(),
                             s.keys.data_ptr(), self._counters.data_ptr(), self._counters.data_ptr() + 4, self._pinned.data_ptr(), 0,
-                            s.key_format)
+                            s.key_format, self._static_rows or 0)
 
     def clear(self, lazy: bool = False):  # HashTable.cu:49-57, one launch instead of four fill_ kernels
         """`lazy=True` only records that a clear is due: the next build issues it inside its own C call (no host
@@ -551,7 +551,9 @@ class Lattice:
         if not ht.is_initialized():
             ht.init(d, v, self._dev(positions_raw))
         tv = ht.m_values_tensor
-        cap = ht.capacity()
+        # the accumulator is capacity rows tall (HashTable.cu:32) — except in static-rows mode, where no row beyond the bound can
+        # be a vertex: the bound is enough (a ScanNet-sized table, 5 M slots x 32 channels, is 640 MB to zero per build otherwise)
+        cap = ht._static_rows if ht._static_rows is not None else ht.capacity()
         if tv is None or tuple(tv.shape) != (cap, v) or tv.requires_grad or tv._base is not None or not tv.is_contiguous():
             # The table must own a plain [capacity, V] accumulator (HashTable.cu:32).  Python code re-points the
             # values of this object between ops (set_values in every Function); the reference would then splat into

@@ -30,10 +30,10 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 
 def test_struct_layout_matches_header():
-    # int, int, 8 pointers, int, int -> 80 bytes on LP64
-    assert C.sizeof(_lib.LnTable) == 80
+    # int, int, 8 pointers, int, int, int (+4 padding) -> 88 bytes on LP64
+    assert C.sizeof(_lib.LnTable) == 88
     assert [f[0] for f in _lib.LnTable._fields_] == ["capacity", "pos_dim", "slot_keys", "slot_tok", "slot_cnt", "entries", "keys",
-                                                     "nr_filled", "status", "host_counters", "host_seq", "key_format"]
+                                                     "nr_filled", "status", "host_counters", "host_seq", "key_format", "row_limit"]
     assert C.sizeof(_lib.LnCsr) == 48  # 4 pointers + seg_region + planes
 
 

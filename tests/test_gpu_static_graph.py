@@ -113,9 +113,17 @@ def test_static_bound_too_small_is_reported():
     L.SplatLattice.apply(lat, pos, vals)
     m = lat.nr_lattice_vertices()
     lat.set_static_rows(m // 2)
-    L.SplatLattice.apply(lat, pos, vals)
-    assert lat.nr_lattice_vertices() == m // 2
+    # the whole chain must stay inside its (too short) tensors: vertices beyond the bound are left un-inserted (LnTable.row_limit)
+    W = torch.randn((9 * 8, 16), device=dev(), requires_grad=True)
+    lv, _, idx, w = L.SplatLattice.apply(lat, pos, vals)
+    assert lat.nr_lattice_vertices() == m // 2 and lv.shape[0] == m // 2
+    lvb = lv.clone().requires_grad_(True)
+    cv, cw = L.ConvIm2RowLattice.apply(lvb, lat, W, 1)
+    out = L.SliceLattice.apply(cv, cw.lattice, pos, idx, w)
+    out.sum().backward()
     torch.cuda.synchronize()
+    assert int(idx.max()) < m // 2 and int((idx < 0).sum()) > 0
+    assert torch.isfinite(out).all() and torch.isfinite(lvb.grad).all() and torch.isfinite(W.grad).all()
     with pytest.raises(L.LatticeNetHipError, match="static row bound"):
         lat.static_build_report()
     lat.set_static_rows(None)
