@@ -171,7 +171,160 @@ __global__ void __launch_bounds__(256) LN_CONV_WAVES_ATTR
     }
 }
 
-// (Measured dead end, round 2: the same kernel on v_mfma_f32_16x16x32_bf16 with 3-way split operands — a = a1 + a2 + a3 in
+// ------------------------------------------------------------------------------------------
+// The per-slot gather-GEMM on the bf16 matrix cores with exactly-split operands ("bf16x3"), for large lattices.
+// fp32-input MFMA runs at the fp32 VECTOR rate on gfx950 (32 cycles per 16x16x4): at ScanNet / SemanticKITTI shapes the kernel
+// above sits at 50-80 % of that peak.  Here a = a1 + a2 + a3 EXACTLY, each part the top 16 bits of what is left (bf16 has fp32's
+// exponent range, so no scaling; 3 x 8 significant bits = fp32's 24), the same for the filter, and a*b is accumulated in fp32 as
+// the six products of total order <= 4: a1b1 + a1b2 + a2b1 + a1b3 + a2b2 + a3b1 (what is dropped is < 2^-23 |ab|).  One
+// v_mfma_f32_16x16x32_bf16 contracts 32 channels in ~17 cycles, so a slot costs 6 V/32 NT of those instead of V/4 NT of 32
+// cycles: 2.5x less matrix time, for ~8 bit operations per gathered value.  The filter bank is split once per call
+// (k_conv_split_bank) into fragment order, so staging a slot is a straight 16-byte copy.
+// Lane (i, q) holds its quarter of the gathered row, V/4 contiguous channels: MFMA step s takes channels [8s, 8s + 8) of the
+// quarter as the A fragment of k-group q, i.e. the contraction order inside a slot is permuted; the bank uses the same order.
+// ------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// x = hi + mid + lo exactly, each the top 16 bits of the remainder; returned as raw bf16 bit patterns in the HIGH half-words
+__device__ __forceinline__ void ln_split3_bits(float x, unsigned int& hi, unsigned int& mid, unsigned int& lo) {
+    hi = __float_as_uint(x) & 0xFFFF0000u;
+    const float r1 = x - __uint_as_float(hi);
+    mid = __float_as_uint(r1) & 0xFFFF0000u;
+    const float r2 = r1 - __uint_as_float(mid);
+    lo = __float_as_uint(r2) & 0xFFFF0000u;
+}
+
+// Filter slice of (slot e, column chunk y), split and in fragment order: [e][y][((s * NT + nt) * 3 + part) * 64 + lane][8 bf16]
+template <int V, int NT, bool WT>
+__global__ void __launch_bounds__(256)
+    k_conv_split_bank(const float* __restrict__ filter, int f_total, int f_off, unsigned short* __restrict__ bank) {
+    constexpr int F = 16 * NT;
+    constexpr int KQ = V / 4;
+    constexpr int S = KQ / 8;
+    constexpr int SLICE = S * NT * 3 * 64 * 8;  // bf16 elements per (slot, chunk)
+    const int e = blockIdx.y;
+    const int y = blockIdx.z;
+    unsigned short* dst = bank + ((size_t)e * gridDim.z + y) * SLICE;
+    const int fo = f_off + y * F;
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= V * F) return;
+    // !WT: x = k*F + f;  WT: x = f*V + k  (coalesced reads either way)
+    const int k = WT ? (x % V) : (x / F);
+    const int f = WT ? (x / V) : (x - k * F);
+    const size_t src = WT ? ((size_t)e * f_total + fo + f) * V + k : ((size_t)e * V + k) * f_total + fo + f;
+    unsigned int h, md, l;
+    ln_split3_bits(filter[src], h, md, l);
+    const int qq = k / KQ, kk = k - qq * KQ;
+    const int st = kk >> 3, j = kk & 7;
+    const int base = ((st * NT + (f >> 4)) * 3 * 64 + qq * 16 + (f & 15)) * 8 + j;
+    dst[base] = (unsigned short)(h >> 16);
+    dst[base + 64 * 8] = (unsigned short)(md >> 16);
+    dst[base + 2 * 64 * 8] = (unsigned short)(l >> 16);
+}
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+template <int V, int NT, bool FLIP>
+__global__ void __launch_bounds__(256) LN_CONV_WAVES_ATTR
+    k_conv_mfma_b3(const int* __restrict__ nbr, const float* __restrict__ values, const u32x4* __restrict__ bank, int m, int E,
+                   float* __restrict__ out, int f_total, int f_off, int e_per) {
+    const int e_begin = blockIdx.z * e_per;  // slot split, as in k_conv_mfma
+    const int e_end = min(E, e_begin + e_per);
+    out += (size_t)blockIdx.z * m * f_total;
+    constexpr int F = 16 * NT;
+    constexpr int KQ = V / 4;
+    constexpr int S = KQ / 8;                 // MFMA steps per slot
+    constexpr int BANK16 = S * NT * 3 * 64;   // 16-byte fragments of one (slot, chunk) slice
+    constexpr int W16 = (BANK16 + 255) / 256;
+    static_assert(V % 32 == 0, "bf16x3 path: V must be a multiple of 32");
+    __shared__ u32x4 s_b[BANK16];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int i = lane & 15;
+    const int q = lane >> 4;
+    const int m0 = blockIdx.x * 64 + wave * 16;
+    const int my_row = m0 + i;
+    f_off += blockIdx.y * F;
+
+    floatx4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    float a_cur[KQ], a_nxt[KQ];
+    u32x4 w_nxt[W16];
+    auto issue = [&](int e, float (&a)[KQ]) {
+        const int es = (FLIP && e < E - 1) ? (e ^ 1) : e;
+        const int nb = (my_row < m) ? nbr[(size_t)my_row * E + es] : -1;
+        ln_load_quarter<KQ>(values + (size_t)(nb >= 0 ? nb : 0) * V + q * KQ, a);
+        if (nb < 0) {
+#pragma unroll
+            for (int k = 0; k < KQ; ++k) a[k] = 0.f;
+        }
+        const u32x4* src = bank + ((size_t)e * gridDim.y + blockIdx.y) * BANK16;
+#pragma unroll
+        for (int s = 0; s < W16; ++s) {
+            const int x = tid + s * 256;
+            if (BANK16 % 256 == 0 || x < BANK16) w_nxt[s] = src[x];
+        }
+    };
+    auto stage = [&]() {  // straight copy: the bank is already in fragment order
+#pragma unroll
+        for (int s = 0; s < W16; ++s) {
+            const int x = tid + s * 256;
+            if (BANK16 % 256 == 0 || x < BANK16) s_b[x] = w_nxt[s];
+        }
+    };
+    issue(e_begin, a_cur);
+    stage();
+    __syncthreads();
+    for (int e = e_begin; e < e_end; ++e) {
+        if (e + 1 < e_end) issue(e + 1, a_nxt);
+#pragma unroll
+        for (int st = 0; st < S; ++st) {
+            // three bf16x8 fragments of this lane's 8 channels: two bf16 per dword, the LOWER channel in the low half-word
+            u32x4 p1, p2, p3;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                unsigned int h0, m0_, l0, h1, m1_, l1;
+                ln_split3_bits(a_cur[st * 8 + 2 * j], h0, m0_, l0);
+                ln_split3_bits(a_cur[st * 8 + 2 * j + 1], h1, m1_, l1);
+                p1[j] = (h0 >> 16) | h1;
+                p2[j] = (m0_ >> 16) | m1_;
+                p3[j] = (l0 >> 16) | l1;
+            }
+            const bf16x8 a1 = __builtin_bit_cast(bf16x8, p1), a2 = __builtin_bit_cast(bf16x8, p2), a3 = __builtin_bit_cast(bf16x8, p3);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const u32x4* pb = s_b + ((st * NT + nt) * 3) * 64 + lane;
+                const bf16x8 b1 = __builtin_bit_cast(bf16x8, pb[0]), b2 = __builtin_bit_cast(bf16x8, pb[64]), b3 = __builtin_bit_cast(bf16x8, pb[128]);
+                // small terms first, the dominant product last
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, b1, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b3, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b2, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b1, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b2, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, acc[nt], 0, 0, 0);
+            }
+        }
+        if (e + 1 < e_end) {
+            __syncthreads();  // every wave is done with W_e
+            stage();
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < KQ; ++k) a_cur[k] = a_nxt[k];
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + q * 4 + r;
+            if (row < m) out[(size_t)row * f_total + f_off + nt * 16 + i] = acc[nt][r];
+        }
+    }
+}
+
+// (Round-2 first attempt, kept for the record: the same kernel on v_mfma_f32_16x16x32_bf16 with 3-way split operands — a = a1 + a2 + a3 in
 // bf16, six products of total order <= 4, fp32 accumulation; accurate to the same 1e-5 bar — with the filter bank pre-split
 // once per call.  2.5x less matrix time on paper, but the per-slot kernel is not bound by the matrix pipe even at 46 k
 // vertices x 128 channels (50 % of the fp32 MFMA peak): 91 vs 87 us there, whole LNN step 6.0 vs 5.5 ms.  What bounds it is the
@@ -345,11 +498,30 @@ static int ln_conv_slots_per_split_rt(int m, int E, int val_dim, int nr_filters)
     }
 }
 
+// bf16x3 path: channel counts that are multiples of 32, lattices large enough to be matrix-bound, LN_CONV_EXACT_F32=1 switches
+// it off (A/B; read once)
+#define LN_CONV_B3_MIN_ROWS 16384
+static bool ln_conv_b3_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("LN_CONV_EXACT_F32");
+        v = (e && e[0] == '1') ? 0 : 1;
+    }
+    return v == 1;
+}
+static size_t ln_conv_bank_bytes(int m, int E, int val_dim, int nr_filters) {
+    if (val_dim % 32 != 0 || nr_filters % 16 != 0 || m < LN_CONV_B3_MIN_ROWS || !ln_conv_b3_enabled()) return 0;
+    return (((size_t)E * val_dim * nr_filters * 3 * sizeof(unsigned short)) + 255) & ~size_t(255);
+}
+
 extern "C" size_t ln_conv_forward_workspace_bytes(int m, int filter_extent, int val_dim, int nr_filters) {
     if (m <= 0 || nr_filters % 16 != 0) return 256;
     const int e_per = ln_conv_slots_per_split_rt(m, filter_extent, val_dim, nr_filters);
     const int nsplit = (filter_extent + e_per - 1) / e_per;
-    return (nsplit > 1 ? (size_t)nsplit * m * nr_filters * sizeof(float) : 0) + 256;
+    // + the filter bank split into three bf16 parts (bf16x3 path of the per-slot kernel; not the small-filter fast path)
+    const bool small_filter = filter_extent == 9 && (size_t)filter_extent * val_dim * nr_filters * 4 <= 64 * 1024 && val_dim <= 32;
+    const size_t bank = small_filter ? 0 : ln_conv_bank_bytes(m, filter_extent, val_dim, nr_filters);
+    return bank + (nsplit > 1 ? (size_t)nsplit * m * nr_filters * sizeof(float) : 0) + 256;
 }
 
 template <int V, bool FLIP, bool WT>
@@ -357,22 +529,41 @@ static bool ln_conv_launch_v(int nr_filters, const int* nbr, const float* values
                              void* workspace, size_t workspace_bytes, hipStream_t st) {
     const dim3 block(256);
     constexpr int NT_MAX = (V * 16 * 8 * 4 <= 32 * 1024) ? 8 : ((V * 16 * 4 * 4 <= 48 * 1024) ? 4 : 2);
+    // workspace: [filter bank split into three bf16 parts (bf16x3 path)] [partial slabs of the slot split]
+    const bool ws_ok = workspace && (reinterpret_cast<uintptr_t>(workspace) & 255) == 0;
+    const size_t bank_bytes = ln_conv_bank_bytes(m, E, V, nr_filters);
+    const bool b3 = bank_bytes > 0 && ws_ok && workspace_bytes >= bank_bytes;
+    unsigned short* bank = b3 ? static_cast<unsigned short*>(workspace) : nullptr;
+    char* slab_ws = ws_ok ? static_cast<char*>(workspace) + (b3 ? bank_bytes : 0) : nullptr;
+    const size_t slab_bytes = ws_ok ? workspace_bytes - (b3 ? bank_bytes : 0) : 0;
     int e_per = ln_conv_slots_per_split<V>(m, E, nr_filters);
     int nsplit = (E + e_per - 1) / e_per;
-    if (nsplit > 1 && (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 15) != 0 ||
-                       workspace_bytes < (size_t)nsplit * m * nr_filters * sizeof(float))) {
+    if (nsplit > 1 && (!slab_ws || slab_bytes < (size_t)nsplit * m * nr_filters * sizeof(float))) {
         e_per = E;  // no room for the partial slabs: one workgroup walks all slots
         nsplit = 1;
     }
-    float* dst = nsplit > 1 ? static_cast<float*>(workspace) : out;
+    float* dst = nsplit > 1 ? reinterpret_cast<float*>(slab_ws) : out;
     int f_off = 0;
+    size_t bank_off = 0;  // bf16 elements
     // all chunks of the widest size go out as ONE launch (gridDim.y = their count), then at most one launch per narrower size
 #define LN_CONV_CHUNKS(NTC)                                                                                                         \
     if constexpr (NT_MAX >= NTC) {                                                                                                  \
         const int cnt = (nr_filters - f_off) / (16 * NTC);                                                                          \
         if (cnt > 0) {                                                                                                              \
-            LN_LAUNCH("k_conv_mfma", (k_conv_mfma<V, NTC, FLIP, WT>), dim3(ln_div_up(m, 64), cnt, nsplit), block, 0, st, nbr, values, filter, m, E, \
-                      dst, nr_filters, f_off, e_per);                                                                               \
+            bool done_b3 = false;                                                                                                   \
+            if constexpr (V % 32 == 0 && V * 16 * NTC * 6 <= 64 * 1024) {                                                           \
+                if (b3) {                                                                                                           \
+                    LN_LAUNCH("k_conv_split_bank", (k_conv_split_bank<V, NTC, WT>), dim3(ln_div_up(V * 16 * NTC, 256), E, cnt), block, 0, st, filter, \
+                              nr_filters, f_off, bank + bank_off);                                                                  \
+                    LN_LAUNCH("k_conv_mfma", (k_conv_mfma_b3<V, NTC, FLIP>), dim3(ln_div_up(m, 64), cnt, nsplit), block, 0, st, nbr, values, \
+                              reinterpret_cast<const u32x4*>(bank + bank_off), m, E, dst, nr_filters, f_off, e_per);                \
+                    bank_off += (size_t)E * cnt * V * 16 * NTC * 3;                                                                 \
+                    done_b3 = true;                                                                                                 \
+                }                                                                                                                   \
+            }                                                                                                                       \
+            if (!done_b3)                                                                                                           \
+                LN_LAUNCH("k_conv_mfma", (k_conv_mfma<V, NTC, FLIP, WT>), dim3(ln_div_up(m, 64), cnt, nsplit), block, 0, st, nbr, values, filter, \
+                          m, E, dst, nr_filters, f_off, e_per);                                                                     \
             f_off += cnt * 16 * NTC;                                                                                                \
         }                                                                                                                           \
     }

@@ -311,6 +311,49 @@ def test_conv_forward_and_filter_gradient(v, f):
     close(N(gf), ref, scale=scale)
 
 
+@pytest.mark.parametrize("v,f", [(32, 32), (64, 32), (96, 96), (128, 64), (128, 128), (32, 80)])
+def test_conv_large_lattice_split_bf16_path(v, f):
+    """Lattices of >= 16384 vertices with a channel count that is a multiple of 32 take the per-slot kernel on the bf16 matrix
+    cores with exactly 3-way split operands (ln_conv.hip: k_conv_mfma_b3); same 1e-5 bar against fp64 as the fp32-MFMA kernel,
+    forward (both neighbour orders) and value gradient (the flipped, transposed bank)."""
+    from lattice_net_amd import ConvIm2RowLattice
+    from lattice_net_amd.synthetic import cube_cloud
+    pos = cube_cloud(30000, 11)
+    lat = make_lattice(0.05, 200000)
+    lat.begin_splat()
+    lat.just_create_verts(T(pos), False)
+    m = lat.nr_lattice_vertices()
+    assert m >= 16384
+    rng = np.random.default_rng(v + f)
+    # values with a wide dynamic range: the split has to be exact for every exponent, not just for N(0, 1)
+    vals_np = (rng.standard_normal((m, v)) * np.exp(rng.uniform(-6, 6, (m, 1)))).astype(np.float32)
+    W_np = (rng.standard_normal((9 * v, f)) / np.sqrt(9 * v)).astype(np.float32)
+    G_np = rng.standard_normal((m, f)).astype(np.float32)
+    vals = T(vals_np).requires_grad_(True)
+    W = T(W_np).requires_grad_(True)
+    lat.set_values(vals.detach())
+    rows = N(lat.im2row(lat, 9, 1, False)).astype(np.float64)       # a pure copy by the neighbour list (bit-exact, tested above)
+    for flip in (False, True):
+        conv = lat.convolve_im2row_standalone(T(W_np), 1, lat, flip)
+        r = N(lat.im2row(lat, 9, 1, flip)).astype(np.float64)
+        ref = r @ W_np.astype(np.float64)
+        scale = np.abs(r) @ np.abs(W_np.astype(np.float64))         # per-element bound of the terms summed
+        err = np.abs(N(conv.values()).astype(np.float64) - ref)
+        assert np.all(err <= RTOL * np.maximum(scale, 1e-30)), float(np.max(err / np.maximum(scale, 1e-30)))
+    out, _ = ConvIm2RowLattice.apply(vals, lat, W, 1)
+    (out * T(G_np)).sum().backward()
+    ref_gw = rows.T @ G_np.astype(np.float64)
+    close(N(W.grad), ref_gw, scale=float(np.max(np.abs(rows).T @ np.abs(G_np.astype(np.float64)))))
+    # value gradient = row2im of G W^T: check through the adjoint identity <conv(x), G> = <x, grad_x> for a second x
+    x2 = rng.standard_normal((m, v)).astype(np.float32)
+    lat.set_values(T(x2))
+    r2 = N(lat.im2row(lat, 9, 1, False)).astype(np.float64)
+    lhs = float(np.sum((r2 @ W_np.astype(np.float64)) * G_np))
+    rhs = float(np.sum(x2.astype(np.float64) * N(vals.grad).astype(np.float64)))
+    bound = float(np.sum(np.abs(r2) @ np.abs(W_np.astype(np.float64)) * np.abs(G_np)))
+    assert abs(lhs - rhs) <= RTOL * bound
+
+
 @pytest.mark.parametrize("v,f", [(32, 32), (96, 64), (128, 128), (48, 96)])
 def test_conv_autograd_matches_dense_reference(v, f):
     """ConvIm2RowLattice fwd+bwd against autograd through the explicit im2row matrix (fp64)."""
