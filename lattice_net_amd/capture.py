@@ -4,7 +4,7 @@ The reference reads the vertex count back to the host after every lattice build 
 capture can contain.  `CapturedStep` packages the recipe that removes that wait:
 
   1. calibrate: run the step eagerly once; for every lattice it builds, read the vertex count, set a static row bound
-     (count x (1 + row_slack), rounded up to 256) and, optionally, kd region planes balanced on this cloud;
+     (count x (1 + row_slack), rounded up to 256, snapped down to a multiple of 16384 when half the slack survives) and, optionally, kd region planes balanced on this cloud;
   2. warm up the static-rows step on a side stream (allocates the table buffers, pinned counters and build workspaces
      outside the capture);
   3. capture the step with torch.cuda.graph;
@@ -25,6 +25,8 @@ import torch
 from .lattice import Lattice
 
 __all__ = ["CapturedStep"]
+
+_ROUND_ROWS = 256 * 64  # one 64-vertex tile on every CU of an MI355X
 
 
 class CapturedStep:
@@ -51,6 +53,11 @@ class CapturedStep:
         torch.cuda.synchronize()
         for lat, m in zip(self.lattices, self.vertices):
             rows = min(lat.capacity(), ((int(m * (1.0 + row_slack)) + 255) // 256) * 256)
+            # The vertex-tiled kernels work in rounds of 256 CUs x 64 rows: a bound a little above a multiple of that costs the
+            # fused convolution backward a whole extra sub-tile per CU.  Snap down to the multiple if at least half the slack survives.
+            snapped = rows // _ROUND_ROWS * _ROUND_ROWS
+            if snapped >= m * (1.0 + 0.5 * row_slack):
+                rows = snapped
             lat.set_static_rows(rows)
         if before_capture is not None:
             before_capture()

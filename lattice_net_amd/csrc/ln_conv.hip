@@ -16,6 +16,20 @@
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
+// fused backward of a same-lattice small-filter convolution (k_conv_backward_fused): vertices per workgroup, shapes it covers
+#define LN_BWD_MAX_SUBTILES 4
+#define LN_BWD_CUS 256
+static bool ln_bwd_fused_shape(int filter_extent, int val_dim, int nr_filters) {
+    return filter_extent == 9 && val_dim == 32 && nr_filters == 32;
+}
+// 64-vertex sub-tiles per workgroup: the fewest that keep the launch to one workgroup per CU (a 257th workgroup would run after
+// the others: twice the time); 0 = too many vertices for one round, the two-launch backward takes over
+static int ln_bwd_subtiles(int m) {
+    const int s = (m + 63) / 64;
+    const int t = (s + LN_BWD_CUS - 1) / LN_BWD_CUS;
+    return t <= LN_BWD_MAX_SUBTILES ? (t < 1 ? 1 : t) : 0;
+}
+
 // Phase stamps of the small-filter convolution (tools/kernel_timeline.py --conv; -DLN_STAMPS builds only)
 #ifdef LN_STAMPS
 __device__ unsigned long long* g_ln_stamps_conv = nullptr;
@@ -797,12 +811,49 @@ __global__ void __launch_bounds__(256) k_reduce_slabs(const float* __restrict__ 
     }
 }
 
+// total % 64 == 0: 64 outputs per workgroup as 16 float4 columns x 16 slab groups (every thread has its <= ceil(nslabs / 16)
+// float4 loads in flight at once), combined through LDS in a fixed order
+__global__ void __launch_bounds__(256) k_reduce_slabs4(const float* __restrict__ partial, int nslabs, int total, float* __restrict__ out) {
+    __shared__ float4 s_part[16][16];
+    const int c = threadIdx.x & 15;
+    const int g = threadIdx.x >> 4;
+    const size_t col = (size_t)blockIdx.x * 16 + c;  // float4 column
+    const size_t stride4 = (size_t)total / 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s0 = g; s0 < nslabs; s0 += 16 * 8) {
+        float4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int sl = s0 + 16 * k;
+            v[k] = sl < nslabs ? reinterpret_cast<const float4*>(partial)[(size_t)sl * stride4 + col] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            acc.x += v[k].x; acc.y += v[k].y; acc.z += v[k].z; acc.w += v[k].w;
+        }
+    }
+    s_part[g][c] = acc;
+    __syncthreads();
+    if (g == 0) {
+        float4 r = s_part[0][c];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) {
+            const float4 t = s_part[k][c];
+            r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
+        }
+        reinterpret_cast<float4*>(out)[col] = r;
+    }
+}
+
 // Any multiple of 16 in both dimensions: the [V, F] block of a slot is covered by sub-blocks of {64, 32, 16} x {64, 32, 16}.
 static bool ln_gf_mfma_supported(int val_dim, int nr_filters) { return val_dim % 16 == 0 && nr_filters % 16 == 0; }
 
 extern "C" size_t ln_conv_grad_filter_workspace_bytes(int m, int filter_extent, int val_dim, int nr_filters) {
     if (!ln_gf_mfma_supported(val_dim, nr_filters) || m <= 0) return 256;
-    return (size_t)ln_div_up(m, LN_GF_ROWS) * filter_extent * val_dim * nr_filters * sizeof(float) + 256;
+    // one [E, V, F] slab per row chunk; the fused backward of a same-lattice convolution (ln_conv_backward) has its own chunking
+    const int chunks = ln_bwd_fused_shape(filter_extent, val_dim, nr_filters) ? max(ln_div_up(m, LN_GF_ROWS), min(ln_div_up(m, 64), LN_BWD_CUS))
+                                                                              : ln_div_up(m, LN_GF_ROWS);
+    return (size_t)chunks * filter_extent * val_dim * nr_filters * sizeof(float) + 256;
 }
 
 // stage 1 of the MFMA filter gradient: per-row-chunk partial blocks -> slabs [chunk][E*V*F]; returns the chunk count
@@ -856,6 +907,171 @@ extern "C" int ln_conv_grad_filter(const int* nbr, const float* values_neigh, co
     return ln_check_launch("ln_conv_grad_filter");
 }
 
+// ------------------------------------------------------------------------------------------
+// Both gradients of a same-lattice small-filter convolution from ONE gather per (vertex, slot).
+//   grad_values[n, :] = sum_e G_e[n, :] W_e^T            with G_e[n, :] = grad_out[nbr(n, e^1), :]   (centre: nbr(n, 8) = n)
+//   grad_filter[e]    = sum_m values[nbr(m, e), :]^T grad_out[m, :]
+//                     = sum_n values[n, :]^T G_e[n, :]   (substitute n = nbr(m, e); neighbour lists of one lattice are symmetric:
+//                                                          nbr(m, e) = n  <=>  nbr(n, e^1) = m, both or neither present)
+// so the rows the value gradient gathers are exactly the rows the filter gradient needs, against the vertex's OWN value row.
+// The separate launches gathered 9 rows per vertex twice (grad_out rows for one, value rows for the other: 37 + 73 MB of
+// L2 misses at C3) and staged the bank / the gradient rows twice.
+// Workgroup = T 64-vertex sub-tiles of 4 waves each (T = 3 at C3: 192 vertices, one workgroup per CU, 3 waves per SIMD); a
+// sub-tile's wave w owns the vertices 16w..16w+15 for the value gradient (A = its gathered quarter rows in registers, B =
+// W_e^T fragments in LDS, as k_conv_mfma_full) and the 16x16 tile (w / FT, w % FT) of every slot's filter gradient over the
+// sub-tile's 64 vertices (A = its own value rows, transposed, in registers for all slots; B = G_e staged row-major in LDS,
+// double-buffered: one barrier per slot).  The sub-tiles' filter-gradient accumulators are added through LDS and
+// the workgroup writes one [E, V, F] slab; k_reduce_slabs4 adds the slabs (deterministic order).
+// ------------------------------------------------------------------------------------------
+template <int V, int F, int E, int T>
+__global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(T, T)))
+    k_conv_backward_fused(const int* __restrict__ nbr, const float* __restrict__ values, const float* __restrict__ grad_out,
+                          const float* __restrict__ filter, int m, float* __restrict__ grad_values, float* __restrict__ slabs) {
+    constexpr int KQ = F / 4;    // contraction channels (forward outputs) per lane quarter
+    constexpr int NT = V / 16;   // value-gradient column tiles
+    constexpr int VT = V / 16, FT = F / 16;
+    static_assert(VT * FT == 4, "one filter-gradient tile per wave of a sub-tile");
+    static_assert(E * V * F * 4 <= 64 * 1024, "filter bank must fit 64 KiB of LDS");
+    constexpr int SG = F + 16;   // LDS row stride of the staged gradient rows (floats, = 16 mod 32: conflict-free k-strided reads)
+    constexpr int THREADS = 256 * T;
+    constexpr int BANK = E * V * F;
+    constexpr int STAGE = 2 * 64 * SG;  // floats per sub-tile: G_e double-buffered
+    // one array: [W_e^T fragments ((e*KQ + kk)*NT + nt)*64 + lane][G_e of each sub-tile]; reused at the end to add up the
+    // sub-tiles' filter gradients (T - 1 parked copies)
+    constexpr int LDS_FLOATS = (BANK + T * STAGE) > (T - 1) * BANK ? (BANK + T * STAGE) : (T - 1) * BANK;
+    __shared__ __attribute__((aligned(16))) float s_all[LDS_FLOATS];
+    float* s_b = s_all;
+    const int tid = threadIdx.x;
+    const int sub = tid >> 8;
+    const int t256 = tid & 255;
+    const int lane = tid & 63;
+    const int wave = t256 >> 6;
+    const int i = lane & 15;
+    const int q = lane >> 4;
+    const int sub0 = blockIdx.x * (64 * T) + sub * 64;  // first vertex of this sub-tile
+    const int m0 = sub0 + wave * 16;
+    const int my_row = m0 + i;
+
+    LN_CSTAMP(0);
+    // loads in dependency order: bank (depends on nothing), neighbour ids, own value rows, the E gathers
+    constexpr int N4 = E * V * F / 4;
+    constexpr int NST = (N4 + THREADS - 1) / THREADS;
+    float4 wv[NST];
+#pragma unroll
+    for (int s = 0; s < NST; ++s) {
+        const int x4 = tid + s * THREADS;
+        wv[s] = (x4 < N4) ? reinterpret_cast<const float4*>(filter)[x4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    int nb[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) nb[e] = (my_row < m) ? nbr[(size_t)my_row * E + (e < E - 1 ? (e ^ 1) : e)] : -1;
+    // A operand of the filter gradient: values[sub0 + 4*step + q][vt*16 + i] for the 16 steps over the sub-tile's rows
+    const int vt = wave / FT, ft = wave % FT;
+    float vT[16];
+#pragma unroll
+    for (int st = 0; st < 16; ++st) {
+        const int row = sub0 + 4 * st + q;
+        vT[st] = (row < m) ? values[(size_t)row * V + vt * 16 + i] : 0.f;
+    }
+    // The gathers run DEPTH slots ahead of the matrix cores (loads return in order: issuing all E up front, as k_conv_mfma_full
+    // does, makes slot 0 wait behind the whole 53 MB burst of every wave on the chip — with one workgroup per CU nothing else
+    // would cover that wait)
+    constexpr int DEPTH = 3;
+    float a[DEPTH + 1][KQ];
+#pragma unroll
+    for (int e = 0; e < DEPTH && e < E; ++e) ln_load_quarter<KQ>(grad_out + (size_t)(nb[e] >= 0 ? nb[e] : 0) * F + q * KQ, a[e % (DEPTH + 1)]);
+    // bank -> LDS as W_e^T fragments (the bank is [e][v][f]: contraction index f, output index v)
+#pragma unroll
+    for (int s = 0; s < NST; ++s) {
+        const int x4 = tid + s * THREADS;
+        if (x4 < N4) {
+            const int x = x4 * 4;
+            const int ev = x / F;       // e*V + v
+            const int k0 = x - ev * F;  // f, multiple of 4
+            const int e = ev / V;
+            const int v = ev - e * V;
+            const float vals4[4] = {wv[s].x, wv[s].y, wv[s].z, wv[s].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = k0 + j;
+                const int qq = k / KQ;
+                const int kk = k - qq * KQ;
+                s_b[((e * KQ + kk) * NT + (v >> 4)) * 64 + qq * 16 + (v & 15)] = vals4[j];
+            }
+        }
+    }
+    floatx4 acc_v[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc_v[nt] = floatx4{0.f, 0.f, 0.f, 0.f};
+    floatx4 acc_w[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc_w[e] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        float* sg = s_all + BANK + sub * STAGE + (e & 1) * (64 * SG);
+        float (&ae)[KQ] = a[e % (DEPTH + 1)];
+        if (e + DEPTH < E)
+            ln_load_quarter<KQ>(grad_out + (size_t)(nb[e + DEPTH] >= 0 ? nb[e + DEPTH] : 0) * F + q * KQ, a[(e + DEPTH) % (DEPTH + 1)]);
+        // this lane's quarter of G_e[row i of its wave] -> LDS (zeros for absent neighbours)
+        {
+            float* dst = sg + (wave * 16 + i) * SG + q * KQ;
+#pragma unroll
+            for (int k = 0; k < KQ; k += 4)
+                *reinterpret_cast<float4*>(dst + k) = nb[e] >= 0 ? make_float4(ae[k], ae[k + 1], ae[k + 2], ae[k + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();  // G_e staged (and, for e = 0, the bank); buffer (e+1)&1 was last read before the previous barrier
+        if (e == 0) LN_CSTAMP(1);
+        if (e == 1) LN_CSTAMP(4);
+        if (e == 8) LN_CSTAMP(5);
+#pragma unroll
+        for (int kk = 0; kk < KQ; ++kk) {
+            const float av = nb[e] >= 0 ? ae[kk] : 0.f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc_v[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, s_b[((e * KQ + kk) * NT + nt) * 64 + lane], acc_v[nt], 0, 0, 0);
+        }
+        const float* pg = sg + q * SG + ft * 16 + i;
+#pragma unroll
+        for (int st = 0; st < 16; ++st) acc_w[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(vT[st], pg[(4 * st) * SG], acc_w[e], 0, 0, 0);
+    }
+    LN_CSTAMP(2);
+    // value gradient: C/D layout col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + q * 4 + r;
+            if (row < m) grad_values[(size_t)row * V + nt * 16 + i] = acc_v[nt][r];
+        }
+    }
+    // filter gradient: sub-tiles 1.. park their tiles in LDS, sub-tile 0 adds them (fixed order) and writes the workgroup's slab
+    __syncthreads();
+    if (sub > 0) {
+        float* park = s_all + (size_t)(sub - 1) * BANK;
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) park[(e * V + vt * 16 + q * 4 + r) * F + ft * 16 + i] = acc_w[e][r];
+    }
+    if constexpr (T > 1) __syncthreads();
+    if (sub == 0) {
+        float* dst = slabs + (size_t)blockIdx.x * BANK;
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = (e * V + vt * 16 + q * 4 + r) * F + ft * 16 + i;
+                float sum = acc_w[e][r];
+#pragma unroll
+                for (int k = 1; k < T; ++k) sum += s_all[(size_t)(k - 1) * BANK + o];
+                dst[o] = sum;
+            }
+    }
+    LN_CSTAMP(3);
+}
+
+static bool ln_bwd_fused_enabled() { return !(ln_debug_mask() & 2048); }  // LN_DEBUG_MASK & 2048: the two-launch backward (A/B)
+
 // Both gradients of out = conv(values_neigh; nbr_q, filter[E*V, F]):
 //   grad_filter[E*V, F] = im2row(values_neigh; nbr_q)^T @ grad_out            (ln_conv_grad_filter)
 //   grad_values[mn, V]  = conv(grad_out; nbr_n, filter, FLIP | TRANSPOSED)     (ln_conv_forward)
@@ -872,6 +1088,20 @@ extern "C" int ln_conv_backward(const int* nbr_q, const int* nbr_n, const float*
         ((reinterpret_cast<uintptr_t>(values_neigh) | reinterpret_cast<uintptr_t>(grad_out) | reinterpret_cast<uintptr_t>(filter)) & 15) == 0) {
         float* partial = static_cast<float*>(workspace);
         const int total = filter_extent * val_dim * nr_filters;
+        const int bwd_t = ln_bwd_subtiles(mn);
+        if (nbr_q == nbr_n && mq == mn && ln_bwd_fused_shape(filter_extent, val_dim, nr_filters) && bwd_t > 0 && ln_bwd_fused_enabled()) {
+            // same lattice on both sides: one gather per (vertex, slot) serves both gradients
+            const int wgs = ln_div_up(mn, 64 * bwd_t);
+#define LN_BWD_FUSED(TT)                                                                                                               \
+    case TT:                                                                                                                           \
+        LN_LAUNCH("k_conv_backward_fused", (k_conv_backward_fused<32, 32, 9, TT>), dim3(wgs), dim3(256 * TT), 0, st, nbr_n, values_neigh, grad_out,  \
+                  filter, mn, grad_values, partial);                                                                                   \
+        break;
+            switch (bwd_t) { LN_BWD_FUSED(1) LN_BWD_FUSED(2) LN_BWD_FUSED(3) LN_BWD_FUSED(4) }
+#undef LN_BWD_FUSED
+            LN_LAUNCH("k_reduce_slabs", k_reduce_slabs4, dim3(total / 64), dim3(256), 0, st, (const float*)partial, wgs, total, grad_filter);
+            return ln_check_launch("ln_conv_backward");
+        }
         const int conv_blocks = ln_div_up(mn, 64);
         const dim3 grid(conv_blocks + ln_div_up(total, 16)), block(256);
 #define LN_BWD_FULL(VV, NN)                                                                                                            \

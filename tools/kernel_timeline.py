@@ -76,3 +76,25 @@ if hasattr(lib, "ln_debug_set_stamps_conv"):
     for k, lab in enumerate(["start", "ids + gathers issued, bank staged, sync", "MFMA loop done", "stores issued (end)"]):
         print(f"  {lab:44s} mean {m_[k]:7.2f}  (+{m_[k] - prev:5.2f})   earliest {mn[k]:7.2f}  latest {mx[k]:7.2f}")
         prev = m_[k]
+
+    # ---- fused backward of the same convolution (k_conv_backward_fused)
+    lvm.requires_grad_(True)
+    Wg = W.clone().requires_grad_(True)
+    Gc = torch.randn((m, v), device=dev)
+    runs = []
+    for _ in range(reps + 2):
+        out, _ = L.ConvIm2RowLattice.apply(lvm, lat, Wg, 1)
+        torch.cuda.synchronize()
+        cst.zero_()
+        lib.ln_debug_set_stamps_conv(cst.data_ptr())
+        out.backward(Gc)
+        torch.cuda.synchronize()
+        lib.ln_debug_set_stamps_conv(None)
+        s = cst.cpu().numpy().astype(np.float64) / 100.0
+        rows = s[s[:, 0] > 0]
+        runs.append(rows[:, :6] - rows[:, 0].min())
+    runs = runs[2:]
+    m_ = np.mean([r.mean(0) for r in runs], 0); mx = np.mean([r.max(0) for r in runs], 0); mn = np.mean([r.min(0) for r in runs], 0)
+    print(f"backward (k_conv_backward_fused when enabled): {runs[0].shape[0]} workgroups")
+    for k, lab in ((0, "start"), (1, "bank + G_0 staged, first barrier"), (4, "slot 0 MFMAs done, barrier 1"), (5, "barrier 8"), (2, "slot loop done"), (3, "end")):
+        print(f"  {lab:44s} mean {m_[k]:7.2f}   earliest {mn[k]:7.2f}  latest {mx[k]:7.2f}")

@@ -10,7 +10,7 @@ cd /tmp
 i=0
 for group in "$@"; do
     i=$((i + 1))
-    rocprofv3 --pmc $group --kernel-trace --output-format csv -d $OUT/p$i -o p -- python3 $ROOT/bench.py --steps 4 --warmup 2 --cpu-seconds 0 --full-unet 0 > $OUT/p$i.log 2>&1
+    timeout ${PMC_TIMEOUT:-150} rocprofv3 --pmc $group --kernel-trace --output-format csv -d $OUT/p$i -o p -- python3 $ROOT/bench.py --steps 4 --warmup 2 --cpu-seconds 0 --full-unet 0 > $OUT/p$i.log 2>&1
 done
 cd $ROOT
 python3 - $OUT <<'PY'
