@@ -71,6 +71,8 @@ def algorithmic_work(kernel: str, n: int, m: int, d: int, v: int, f: int, e: int
         return "mfma_f16", "TFLOP/s", 2.0 * m * e * v * f
     if kernel == "k_grad_filter_mfma":
         return "mfma", "TFLOP/s", 2.0 * m * e * v * f
+    if kernel == "k_conv_backward_fused":  # value gradient + filter gradient of the convolution in one launch (fp32 matrix cores)
+        return "mfma", "TFLOP/s", 4.0 * m * e * v * f
     if kernel in ("k_scatter_point_rows", "k_csr_reduce_segments"):  # splat accumulate / slice backward: read rows+idx+w, write vertex rows
         return "hbm", "GB/s", n * (4.0 * v + 8.0 * (d + 1)) + m * 4.0 * v
     if kernel == "k_reduce_and_neighbours":  # splat accumulate + same-level neighbour list in one launch
@@ -203,10 +205,10 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
-    ap.add_argument("--roofline-kernel", default="k_reduce_and_neighbours",
-                    help="dominant kernel (largest share of GPU time in profiles/r1_kernel_stats.csv): its launches are timed live "
+    ap.add_argument("--roofline-kernel", default="k_conv_backward_fused",
+                    help="dominant kernel (largest share of GPU time in profiles/r2_kernel_stats.csv): its launches are timed live "
                          "with HIP events during the timed region")
-    ap.add_argument("--extra-kernels", default="k_csr_reduce_segments,k_conv_mfma,k_grad_filter_mfma,k_bucket_build,k_point_keys,k_slice_forward",
+    ap.add_argument("--extra-kernels", default="k_reduce_and_neighbours,k_csr_reduce_segments,k_conv_mfma,k_bucket_build,k_point_keys,k_slice_forward",
                     help="kernels timed the same way in extra untimed steps AFTER the timed region (reported under roofline_others)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the CPU baseline leg (0 disables)")
     ap.add_argument("--full-unet", type=int, default=1, help="0 = skip the secondary whole-network timing (rank 0, one GPU, workload C3)")
