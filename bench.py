@@ -216,7 +216,7 @@ def main():
     ap.add_argument("--mode", default="graph", choices=["graph", "eager"],
                     help="graph (default): the whole step (forward + backward, ~10 launches) is captured ONCE into a hipGraph with the "
                          "lattice in static-rows mode and every timed step is one graph replay; eager: one Python autograd pass per step")
-    ap.add_argument("--in-flight", type=int, default=2,
+    ap.add_argument("--in-flight", type=int, default=3,
                     help="graph mode: independent scans in flight per GPU (own cloud, lattice, hipGraph, stream each); the kernels of one "
                          "scan are latency-bound chains at ~1 workgroup per CU, a second scan fills the idle slots.  1 = strictly one "
                          "scan after the other")

@@ -20,6 +20,7 @@ dev = torch.device("cuda", 0)
 n, v, f, sigma, cap = 120000, 32, 32, 0.9, 100000
 K = int(os.environ.get("PROBE_K", 4))
 ROWS = 49152
+R = int(os.environ.get("PROBE_R", 8))
 
 
 class Scan:
@@ -80,7 +81,8 @@ for ph in PHASES:
         g = torch.cuda.CUDAGraph()
         with torch.cuda.stream(s.stream):
             with torch.cuda.graph(g, stream=s.stream):
-                getattr(s, ph)()
+                for _ in range(R):  # R copies per replay: the host's ~10 us per replay stays off the measurement
+                    getattr(s, ph)()
         torch.cuda.synchronize()
         with torch.cuda.stream(s.stream):
             g.replay()  # a capture executes nothing: the next phase's warm-up needs this phase's outputs to be real
@@ -96,19 +98,19 @@ def replay(ph, which, reps):
             with torch.cuda.stream(s.stream):
                 graphs[(ph, id(s))].replay()
     torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / reps / len(which) * 1e6
+    return (time.perf_counter() - t0) / reps / len(which) / R * 1e6
 
 
 print(f"{'phase':14s} {'solo us':>9s} " + " ".join(f"{'x%d us/scan' % k:>12s} {'ratio':>6s}" for k in (2, K)))
 tot = {1: 0.0, 2: 0.0, K: 0.0}
 tot_add = lambda k, t: tot.__setitem__(k, tot[k] + t)
 for ph in PHASES:
-    replay(ph, scans, 20)
-    solo = replay(ph, scans[:1], 200)
+    replay(ph, scans, 5)
+    solo = replay(ph, scans[:1], 40)
     row = f"{ph:14s} {solo:9.1f} "
     tot[1] += solo
     for k in (2, K):
-        t = replay(ph, scans[:k], 200)
+        t = replay(ph, scans[:k], 40)
         if not (k == 2 and K == 2 and False):
             tot[k] += t
         row += f"{t:12.1f} {t / solo:6.2f} "
