@@ -22,13 +22,23 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 static bool ln_bwd_fused_shape(int filter_extent, int val_dim, int nr_filters) {
     return filter_extent == 9 && val_dim == 32 && nr_filters == 32;
 }
-// 64-vertex sub-tiles per workgroup: the fewest that keep the launch to one workgroup per CU (a 257th workgroup would run after
-// the others: twice the time); 0 = too many vertices for one round, the two-launch backward takes over
+// 64-vertex sub-tiles per workgroup (1..4).  A workgroup takes a whole CU, so the launch runs in rounds of 256 workgroups and a
+// round costs about T: the T with the cheapest rounds(T) * T wins, larger T on ties (fewer slabs) — one round at C3 (T = 3; a
+// 257th workgroup would run after all the others: twice the time), 2 rounds of T = 4 at 129 k vertices.
 static int ln_bwd_subtiles(int m) {
     const int s = (m + 63) / 64;
-    const int t = (s + LN_BWD_CUS - 1) / LN_BWD_CUS;
-    return t <= LN_BWD_MAX_SUBTILES ? (t < 1 ? 1 : t) : 0;
+    int best = 1, best_cost = 1 << 30;
+    for (int t = 1; t <= LN_BWD_MAX_SUBTILES; ++t) {
+        const int wgs = (s + t - 1) / t;
+        const int cost = ((wgs + LN_BWD_CUS - 1) / LN_BWD_CUS) * t;
+        if (cost <= best_cost) {
+            best = t;
+            best_cost = cost;
+        }
+    }
+    return best;
 }
+static int ln_bwd_workgroups(int m) { return (m + 64 * ln_bwd_subtiles(m) - 1) / (64 * ln_bwd_subtiles(m)); }
 
 // Phase stamps of the small-filter convolution (tools/kernel_timeline.py --conv; -DLN_STAMPS builds only)
 #ifdef LN_STAMPS
@@ -851,7 +861,7 @@ static bool ln_gf_mfma_supported(int val_dim, int nr_filters) { return val_dim %
 extern "C" size_t ln_conv_grad_filter_workspace_bytes(int m, int filter_extent, int val_dim, int nr_filters) {
     if (!ln_gf_mfma_supported(val_dim, nr_filters) || m <= 0) return 256;
     // one [E, V, F] slab per row chunk; the fused backward of a same-lattice convolution (ln_conv_backward) has its own chunking
-    const int chunks = ln_bwd_fused_shape(filter_extent, val_dim, nr_filters) ? max(ln_div_up(m, LN_GF_ROWS), min(ln_div_up(m, 64), LN_BWD_CUS))
+    const int chunks = ln_bwd_fused_shape(filter_extent, val_dim, nr_filters) ? max(ln_div_up(m, LN_GF_ROWS), ln_bwd_workgroups(m))
                                                                               : ln_div_up(m, LN_GF_ROWS);
     return (size_t)chunks * filter_extent * val_dim * nr_filters * sizeof(float) + 256;
 }
@@ -899,7 +909,10 @@ extern "C" int ln_conv_grad_filter(const int* nbr, const float* values_neigh, co
         float* partial = static_cast<float*>(workspace);
         const int chunks = ln_gf_launch_partials(nbr, values_neigh, grad_out, m, filter_extent, val_dim, nr_filters, partial, st);
         // slabs are laid out [chunk][e][V*F]; summing over chunks with stride E*V*F
-        LN_LAUNCH("k_reduce_slabs", k_reduce_slabs, dim3(ln_div_up(total, 16)), dim3(256), 0, st, partial, chunks, total, grad_filter);
+        if (total % 64 == 0 && (reinterpret_cast<uintptr_t>(grad_filter) & 15) == 0)  // (always, for multiples of 16 in both dimensions)
+            LN_LAUNCH("k_reduce_slabs", k_reduce_slabs4, dim3(total / 64), dim3(256), 0, st, (const float*)partial, chunks, total, grad_filter);
+        else
+            LN_LAUNCH("k_reduce_slabs", k_reduce_slabs, dim3(ln_div_up(total, 16)), dim3(256), 0, st, partial, chunks, total, grad_filter);
     } else {
         LN_LAUNCH("k_grad_filter_generic", k_grad_filter_generic, dim3(ln_div_up(total, 256)), dim3(256), 0, st, nbr, values_neigh, grad_out, m,
                            filter_extent, val_dim, nr_filters, grad_filter);
@@ -1089,7 +1102,7 @@ extern "C" int ln_conv_backward(const int* nbr_q, const int* nbr_n, const float*
         float* partial = static_cast<float*>(workspace);
         const int total = filter_extent * val_dim * nr_filters;
         const int bwd_t = ln_bwd_subtiles(mn);
-        if (nbr_q == nbr_n && mq == mn && ln_bwd_fused_shape(filter_extent, val_dim, nr_filters) && bwd_t > 0 && ln_bwd_fused_enabled()) {
+        if (nbr_q == nbr_n && mq == mn && ln_bwd_fused_shape(filter_extent, val_dim, nr_filters) && ln_bwd_fused_enabled()) {
             // same lattice on both sides: one gather per (vertex, slot) serves both gradients
             const int wgs = ln_div_up(mn, 64 * bwd_t);
 #define LN_BWD_FUSED(TT)                                                                                                               \

@@ -357,8 +357,7 @@ def test_conv_large_lattice_split_bf16_path(v, f):
 @pytest.mark.parametrize("n_points,subtiles", [(1500, 1), (5000, 2), (12000, 3), (30000, 4), (45000, 5)])
 def test_conv_backward_fused_same_lattice(n_points, subtiles):
     """Backward of a same-lattice V = F = 32 convolution: one launch computes both gradients from one gather per (vertex, slot)
-    (ln_conv.hip: k_conv_backward_fused, 1..4 sub-tiles of 64 vertices per workgroup; beyond 4 x 256 sub-tiles the two-launch
-    backward).  Checked against fp64 through the explicit im2row matrix, 1e-5 of the per-element sum of magnitudes."""
+    (ln_conv.hip: k_conv_backward_fused, 1..4 sub-tiles of 64 vertices per workgroup, one or more rounds of 256 workgroups).  Checked against fp64 through the explicit im2row matrix, 1e-5 of the per-element sum of magnitudes."""
     from lattice_net_amd import ConvIm2RowLattice
     from lattice_net_amd.synthetic import cube_cloud
     v = f = 32
