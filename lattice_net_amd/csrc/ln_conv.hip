@@ -989,10 +989,15 @@ __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(T,
     // The gathers run DEPTH slots ahead of the matrix cores (loads return in order: issuing all E up front, as k_conv_mfma_full
     // does, makes slot 0 wait behind the whole 53 MB burst of every wave on the chip — with one workgroup per CU nothing else
     // would cover that wait)
+    // The centre slot goes FIRST: its row is the vertex's own (no neighbour id to wait for), so its gather leaves with the
+    // id loads and the first barrier is one round trip away instead of two; the id only masks it (rows beyond the build).
     constexpr int DEPTH = 3;
+    auto slot_of = [](int k) { return k == 0 ? E - 1 : k - 1; };  // processing order -> filter slot
     float a[DEPTH + 1][KQ];
+    ln_load_quarter<KQ>(grad_out + (size_t)(my_row < m ? my_row : 0) * F + q * KQ, a[0]);
 #pragma unroll
-    for (int e = 0; e < DEPTH && e < E; ++e) ln_load_quarter<KQ>(grad_out + (size_t)(nb[e] >= 0 ? nb[e] : 0) * F + q * KQ, a[e % (DEPTH + 1)]);
+    for (int k = 1; k < DEPTH && k < E; ++k)
+        ln_load_quarter<KQ>(grad_out + (size_t)(nb[slot_of(k)] >= 0 ? nb[slot_of(k)] : 0) * F + q * KQ, a[k % (DEPTH + 1)]);
     // bank -> LDS as W_e^T fragments (the bank is [e][v][f]: contraction index f, output index v)
 #pragma unroll
     for (int s = 0; s < NST; ++s) {
@@ -1020,22 +1025,23 @@ __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(T,
 #pragma unroll
     for (int e = 0; e < E; ++e) acc_w[e] = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-        float* sg = s_all + BANK + sub * STAGE + (e & 1) * (64 * SG);
-        float (&ae)[KQ] = a[e % (DEPTH + 1)];
-        if (e + DEPTH < E)
-            ln_load_quarter<KQ>(grad_out + (size_t)(nb[e + DEPTH] >= 0 ? nb[e + DEPTH] : 0) * F + q * KQ, a[(e + DEPTH) % (DEPTH + 1)]);
+    for (int k = 0; k < E; ++k) {
+        const int e = slot_of(k);
+        float* sg = s_all + BANK + sub * STAGE + (k & 1) * (64 * SG);
+        float (&ae)[KQ] = a[k % (DEPTH + 1)];
+        if (k + DEPTH < E)
+            ln_load_quarter<KQ>(grad_out + (size_t)(nb[slot_of(k + DEPTH)] >= 0 ? nb[slot_of(k + DEPTH)] : 0) * F + q * KQ, a[(k + DEPTH) % (DEPTH + 1)]);
         // this lane's quarter of G_e[row i of its wave] -> LDS (zeros for absent neighbours)
         {
             float* dst = sg + (wave * 16 + i) * SG + q * KQ;
 #pragma unroll
-            for (int k = 0; k < KQ; k += 4)
-                *reinterpret_cast<float4*>(dst + k) = nb[e] >= 0 ? make_float4(ae[k], ae[k + 1], ae[k + 2], ae[k + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int c = 0; c < KQ; c += 4)
+                *reinterpret_cast<float4*>(dst + c) = nb[e] >= 0 ? make_float4(ae[c], ae[c + 1], ae[c + 2], ae[c + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        __syncthreads();  // G_e staged (and, for e = 0, the bank); buffer (e+1)&1 was last read before the previous barrier
-        if (e == 0) LN_CSTAMP(1);
-        if (e == 1) LN_CSTAMP(4);
-        if (e == 8) LN_CSTAMP(5);
+        __syncthreads();  // G_e staged (and, the first time, the bank); buffer (k+1)&1 was last read before the previous barrier
+        if (k == 0) LN_CSTAMP(1);
+        if (k == 1) LN_CSTAMP(4);
+        if (k == 8) LN_CSTAMP(5);
 #pragma unroll
         for (int kk = 0; kk < KQ; ++kk) {
             const float av = nb[e] >= 0 ? ae[kk] : 0.f;
@@ -1044,8 +1050,13 @@ __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(T,
                 acc_v[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, s_b[((e * KQ + kk) * NT + nt) * 64 + lane], acc_v[nt], 0, 0, 0);
         }
         const float* pg = sg + q * SG + ft * 16 + i;
+        floatx4 w0 = floatx4{0.f, 0.f, 0.f, 0.f}, w1 = floatx4{0.f, 0.f, 0.f, 0.f};  // two chains: no back-to-back dependent MFMAs
 #pragma unroll
-        for (int st = 0; st < 16; ++st) acc_w[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(vT[st], pg[(4 * st) * SG], acc_w[e], 0, 0, 0);
+        for (int st = 0; st < 16; st += 2) {
+            w0 = __builtin_amdgcn_mfma_f32_16x16x4f32(vT[st], pg[(4 * st) * SG], w0, 0, 0, 0);
+            w1 = __builtin_amdgcn_mfma_f32_16x16x4f32(vT[st + 1], pg[(4 * st + 4) * SG], w1, 0, 0, 0);
+        }
+        acc_w[e] = w0 + w1;
     }
     LN_CSTAMP(2);
     // value gradient: C/D layout col = lane & 15, row = (lane >> 4) * 4 + reg
