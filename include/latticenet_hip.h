@@ -334,6 +334,15 @@ int ln_group_norm_forward(const float* x, const float* gamma, const float* beta,
 int ln_group_norm_backward(const float* x, const float* grad_y, const float* gamma, const float* mean_rstd, const float* scale_shift, int m,
                            int channels, int groups, int relu, float* grad_x, float* grad_gamma, float* grad_beta, void* workspace,
                            size_t workspace_bytes, void* next_workspace, size_t next_workspace_bytes, void* stream);
+/* The same with a device-side row count (static-rows mode: the [m, channels] tensors are taller than the lattice they hold):
+ * rows_device == NULL, or one device int — the statistics run over min(m, *rows_device) rows, rows beyond are written as zeros
+ * (y, grad_x) and contribute to nothing.  Pass LnTable.nr_filled of the lattice the values belong to. */
+int ln_group_norm_forward_rows(const float* x, const float* gamma, const float* beta, int m, int channels, int groups, float eps, int relu,
+                               float* y, float* mean_rstd, float* scale_shift, void* workspace, size_t workspace_bytes, void* next_workspace,
+                               size_t next_workspace_bytes, const int* rows_device, void* stream);
+int ln_group_norm_backward_rows(const float* x, const float* grad_y, const float* gamma, const float* mean_rstd, const float* scale_shift, int m,
+                                int channels, int groups, int relu, float* grad_x, float* grad_gamma, float* grad_beta, void* workspace,
+                                size_t workspace_bytes, void* next_workspace, size_t next_workspace_bytes, const int* rows_device, void* stream);
 
 /* ---- max-centring of the gathered simplex rows in the DeformSlice head ------------------------------------------
  * Replaces the torch broadcasting at lattice_modules.py:525-529 (`rowified -= gamma * max_vals + beta`, max over the

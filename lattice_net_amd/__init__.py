@@ -9,6 +9,6 @@ from .lattice import HashTable, Lattice  # noqa: F401
 from .lattice_wrapper import LatticeWrapper  # noqa: F401
 from .lattice_funcs import *  # noqa: F401,F403
 from .model_params import ModelParams  # noqa: F401
-from .capture import CapturedStep  # noqa: F401
+from .capture import CapturedNetworkStep, CapturedStep  # noqa: F401
 
 __version__ = "0.1.0"

@@ -122,6 +122,8 @@ SIGNATURES = {
     "ln_group_norm_workspace_bytes": (_sz, [_i]),
     "ln_group_norm_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, C.c_float, _i, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),
     "ln_group_norm_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),
+    "ln_group_norm_forward_rows": (_i, [_vp, _vp, _vp, _i, _i, _i, C.c_float, _i, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp, _vp]),
+    "ln_group_norm_backward_rows": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp, _vp]),
     "ln_slice_classify_backward_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "ln_slice_classify_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
 }

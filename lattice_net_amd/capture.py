@@ -24,7 +24,7 @@ import torch
 
 from .lattice import Lattice
 
-__all__ = ["CapturedStep"]
+__all__ = ["CapturedStep", "CapturedNetworkStep"]
 
 _ROUND_ROWS = 256 * 64  # one 64-vertex tile on every CU of an MI355X
 
@@ -90,3 +90,63 @@ class CapturedStep:
         """Back to eager mode (the lattices read their vertex counts again)."""
         for lat in self.lattices:
             lat.set_static_rows(None)
+
+
+class CapturedNetworkStep:
+    """A whole-network training step (forward + loss + backward of an LNN-style model: several lattice levels, GroupNorm between the
+    lattice operators) as ONE hipGraph replay.
+
+      1. calibrate: one eager `step()` under Lattice.start_level_trace() -> vertex count of every lattice level the network builds;
+      2. `lattice.set_static_rows(bound(level 1), coarse_bounds=[bound(level 2), ...])`: every `[M, C]` tensor of the network gets
+         its level's bound as height, the GroupNorm kernels read the real count from the lattice's device counter
+         (Lattice.rows_device()), rows beyond it stay isolated (no neighbour, no splat index, zero gradient);
+      3. warm-up on a side stream, capture, `launch()` = one replay.  Parameter gradients live in the graph's memory pool:
+         after a replay `p.grad` holds that step's gradients, the optimizer runs outside the graph.
+
+    `step` must read its inputs (positions, values, targets) from tensors that stay alive — overwrite them in place to feed another
+    cloud of the same size — set `p.grad = None` itself is NOT needed (done here), and must not synchronise."""
+
+    def __init__(self, step: Callable[[], torch.Tensor], lattice: Lattice, parameters, *, row_slack: float = 0.07,
+                 stream: Optional[torch.cuda.Stream] = None):
+        from .lattice_blocks import reset_gn_workspaces
+        self.step, self.lattice, self.stream = step, lattice, stream
+        self.parameters = list(parameters)
+        Lattice.start_level_trace()
+        try:
+            self.eager_loss = step()
+            torch.cuda.synchronize()
+        finally:
+            self.levels = Lattice.stop_level_trace()
+        lv = sorted(self.levels)
+        bounds = [min(lattice.capacity(), ((int(self.levels[k] * (1.0 + row_slack)) + 255) // 256) * 256) for k in lv]
+        self.bounds = dict(zip(lv, bounds))
+        lattice.set_static_rows(bounds[0], coarse_bounds=bounds[1:])
+
+        def guarded():
+            reset_gn_workspaces()
+            return step()
+
+        side = stream if stream is not None else torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                for p in self.parameters:
+                    p.grad = None
+                guarded()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        for p in self.parameters:
+            p.grad = None
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(self.graph, stream=side):
+                self.loss = guarded()
+        torch.cuda.synchronize()
+
+    def launch(self):
+        if self.stream is None:
+            self.graph.replay()
+        else:
+            with torch.cuda.stream(self.stream):
+                self.graph.replay()
+        return self.loss

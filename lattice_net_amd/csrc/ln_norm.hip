@@ -20,7 +20,8 @@
 // passes are in flight per thread.
 __global__ void __launch_bounds__(256)
     k_gn_stats(const float* __restrict__ x, const float* __restrict__ gy, const float* __restrict__ scale_shift, int relu, int m, int c,
-               double* __restrict__ acc) {
+               double* __restrict__ acc, const int* __restrict__ rows_dev) {
+    if (rows_dev) m = min(m, *rows_dev);  // static-rows mode: the tensors are taller than the lattice, only its rows count
     __shared__ float4 s_p[256], s_q[256];
     const int tid = threadIdx.x;
     const int quads = c >> 2;                 // c % 4 == 0, c <= 1024  ->  quads <= 256
@@ -84,6 +85,7 @@ __global__ void __launch_bounds__(256)
 __device__ __forceinline__ void ln_gn_channel_affine(const double* __restrict__ acc, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, int m, int c, int groups, float eps, float* s_a,
                                                      float* s_b, float* __restrict__ mean_rstd, float* __restrict__ scale_shift) {
+    if (m < 1) m = 1;  // (an empty lattice under a static row bound: all sums are zero)
     const int cg = c / groups;
     __shared__ double s_sum[LN_GN_MAX_C], s_sq[LN_GN_MAX_C];
     for (int col = threadIdx.x; col < c; col += 256) {  // channel sums over the accumulator replicas
@@ -133,14 +135,19 @@ __device__ __forceinline__ void ln_gn_channel_affine(const double* __restrict__ 
 __global__ void __launch_bounds__(256)
     k_gn_apply(const float* __restrict__ x, const double* __restrict__ acc, const float* __restrict__ gamma, const float* __restrict__ beta,
                int m, int c, int groups, float eps, int relu, float* __restrict__ y, float* __restrict__ mean_rstd,
-               float* __restrict__ scale_shift, double* __restrict__ zero_next, int zero_count) {
+               float* __restrict__ scale_shift, double* __restrict__ zero_next, int zero_count, const int* __restrict__ rows_dev) {
     __shared__ float s_a[LN_GN_MAX_C], s_b[LN_GN_MAX_C];
+    const int m_tensor = m;
+    if (rows_dev) m = min(m, *rows_dev);  // rows beyond the lattice: excluded from the statistics, written as zeros
     if (zero_next && blockIdx.x == 0)  // the accumulators of the NEXT call (nobody is using them now: stream order)
         for (int i = threadIdx.x; i < zero_count; i += 256) zero_next[i] = 0.0;
     ln_gn_channel_affine(acc, gamma, beta, m, c, groups, eps, s_a, s_b, mean_rstd, scale_shift);
     __syncthreads();
     const long long total4 = (long long)m * c / 4;  // c % 4 == 0 checked by the host
+    const long long tensor4 = (long long)m_tensor * c / 4;
     const long long stride = (long long)gridDim.x * 256;
+    for (long long i = total4 + (long long)blockIdx.x * 256 + threadIdx.x; i < tensor4; i += stride)
+        reinterpret_cast<float4*>(y)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += stride) {
         const int col = int((i * 4) % c);
         float4 v = reinterpret_cast<const float4*>(x)[i];
@@ -163,7 +170,10 @@ __global__ void __launch_bounds__(256)
     k_gn_backward_apply(const float* __restrict__ x, const float* __restrict__ gy, const double* __restrict__ acc,
                         const float* __restrict__ gamma, const float* __restrict__ mean_rstd, const float* __restrict__ scale_shift, int m,
                         int c, int groups, int relu, float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                        double* __restrict__ zero_next, int zero_count) {
+                        double* __restrict__ zero_next, int zero_count, const int* __restrict__ rows_dev) {
+    const int m_tensor = m;
+    if (rows_dev) m = min(m, *rows_dev);
+    if (m < 1) m = 1;
     if (zero_next && blockIdx.x == 0)
         for (int i = threadIdx.x; i < zero_count; i += 256) zero_next[i] = 0.0;
     __shared__ float s_gr[LN_GN_MAX_C], s_c2[LN_GN_MAX_C], s_c3[LN_GN_MAX_C], s_a[LN_GN_MAX_C], s_b[LN_GN_MAX_C];
@@ -210,8 +220,11 @@ __global__ void __launch_bounds__(256)
         }
     }
     __syncthreads();
-    const long long total4 = (long long)m * c / 4;
+    const long long total4 = (rows_dev ? (long long)min(m_tensor, *rows_dev) : (long long)m) * c / 4;
+    const long long tensor4 = (long long)m_tensor * c / 4;
     const long long stride = (long long)gridDim.x * 256;
+    for (long long i = total4 + (long long)blockIdx.x * 256 + threadIdx.x; i < tensor4; i += stride)
+        reinterpret_cast<float4*>(dx)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += stride) {
         const int col = int((i * 4) % c);
         const float4 xv = reinterpret_cast<const float4*>(x)[i];
@@ -252,9 +265,18 @@ static int ln_gn_apply_grid(int m, int c) {
 
 extern "C" size_t ln_group_norm_workspace_bytes(int channels) { return (size_t)LN_GN_REPLICAS * 2 * channels * sizeof(double); }
 
+extern "C" int ln_group_norm_forward_rows(const float* x, const float* gamma, const float* beta, int m, int channels, int groups, float eps,
+                                          int relu, float* y, float* mean_rstd, float* scale_shift, void* workspace, size_t workspace_bytes,
+                                          void* next_workspace, size_t next_workspace_bytes, const int* rows_device, void* stream);
 extern "C" int ln_group_norm_forward(const float* x, const float* gamma, const float* beta, int m, int channels, int groups, float eps,
                                      int relu, float* y, float* mean_rstd, float* scale_shift, void* workspace, size_t workspace_bytes,
                                      void* next_workspace, size_t next_workspace_bytes, void* stream) {
+    return ln_group_norm_forward_rows(x, gamma, beta, m, channels, groups, eps, relu, y, mean_rstd, scale_shift, workspace, workspace_bytes,
+                                      next_workspace, next_workspace_bytes, nullptr, stream);
+}
+extern "C" int ln_group_norm_forward_rows(const float* x, const float* gamma, const float* beta, int m, int channels, int groups, float eps,
+                                          int relu, float* y, float* mean_rstd, float* scale_shift, void* workspace, size_t workspace_bytes,
+                                          void* next_workspace, size_t next_workspace_bytes, const int* rows_device, void* stream) {
     int rc = ln_gn_check("ln_group_norm_forward", m, channels, groups);
     if (rc) return rc;
     LN_REQUIRE(x && y && mean_rstd && scale_shift && workspace && workspace_bytes >= ln_group_norm_workspace_bytes(channels), LN_ERR_ARG,
@@ -268,15 +290,26 @@ extern "C" int ln_group_norm_forward(const float* x, const float* gamma, const f
     if (!next_workspace && hipMemsetAsync(acc, 0, ln_group_norm_workspace_bytes(channels), st) != hipSuccess)
         return ln_check_launch("ln_group_norm_forward(memset)");
     LN_LAUNCH("k_gn_stats", k_gn_stats, dim3(ln_gn_stats_grid(m, channels)), dim3(256), 0, st, x, (const float*)nullptr, (const float*)nullptr, 0, m,
-              channels, acc);
+              channels, acc, rows_device);
     LN_LAUNCH("k_gn_apply", k_gn_apply, dim3(ln_gn_apply_grid(m, channels)), dim3(256), 0, st, x, acc, gamma, beta, m, channels, groups, eps, relu, y,
-              mean_rstd, scale_shift, static_cast<double*>(next_workspace), int(next_workspace_bytes / sizeof(double)));
+              mean_rstd, scale_shift, static_cast<double*>(next_workspace), int(next_workspace_bytes / sizeof(double)), rows_device);
     return ln_check_launch("ln_group_norm_forward");
 }
 
+extern "C" int ln_group_norm_backward_rows(const float* x, const float* grad_y, const float* gamma, const float* mean_rstd,
+                                           const float* scale_shift, int m, int channels, int groups, int relu, float* grad_x, float* grad_gamma,
+                                           float* grad_beta, void* workspace, size_t workspace_bytes, void* next_workspace,
+                                           size_t next_workspace_bytes, const int* rows_device, void* stream);
 extern "C" int ln_group_norm_backward(const float* x, const float* grad_y, const float* gamma, const float* mean_rstd,
                                       const float* scale_shift, int m, int channels, int groups, int relu, float* grad_x, float* grad_gamma,
                                       float* grad_beta, void* workspace, size_t workspace_bytes, void* next_workspace, size_t next_workspace_bytes, void* stream) {
+    return ln_group_norm_backward_rows(x, grad_y, gamma, mean_rstd, scale_shift, m, channels, groups, relu, grad_x, grad_gamma, grad_beta, workspace,
+                                       workspace_bytes, next_workspace, next_workspace_bytes, nullptr, stream);
+}
+extern "C" int ln_group_norm_backward_rows(const float* x, const float* grad_y, const float* gamma, const float* mean_rstd,
+                                           const float* scale_shift, int m, int channels, int groups, int relu, float* grad_x, float* grad_gamma,
+                                           float* grad_beta, void* workspace, size_t workspace_bytes, void* next_workspace,
+                                           size_t next_workspace_bytes, const int* rows_device, void* stream) {
     int rc = ln_gn_check("ln_group_norm_backward", m, channels, groups);
     if (rc) return rc;
     LN_REQUIRE(x && grad_y && mean_rstd && scale_shift && grad_x && workspace && workspace_bytes >= ln_group_norm_workspace_bytes(channels),
@@ -287,9 +320,9 @@ extern "C" int ln_group_norm_backward(const float* x, const float* grad_y, const
     double* acc = static_cast<double*>(workspace);
     if (!next_workspace && hipMemsetAsync(acc, 0, ln_group_norm_workspace_bytes(channels), st) != hipSuccess)
         return ln_check_launch("ln_group_norm_backward(memset)");
-    LN_LAUNCH("k_gn_stats", k_gn_stats, dim3(ln_gn_stats_grid(m, channels)), dim3(256), 0, st, x, grad_y, scale_shift, relu, m, channels, acc);
+    LN_LAUNCH("k_gn_stats", k_gn_stats, dim3(ln_gn_stats_grid(m, channels)), dim3(256), 0, st, x, grad_y, scale_shift, relu, m, channels, acc, rows_device);
     LN_LAUNCH("k_gn_backward_apply", k_gn_backward_apply, dim3(ln_gn_apply_grid(m, channels)), dim3(256), 0, st, x, grad_y, acc, gamma, mean_rstd,
               scale_shift, m, channels, groups, relu, grad_x, grad_gamma, grad_beta, static_cast<double*>(next_workspace),
-              int(next_workspace_bytes / sizeof(double)));
+              int(next_workspace_bytes / sizeof(double)), rows_device);
     return ln_check_launch("ln_group_norm_backward");
 }

@@ -341,6 +341,7 @@ class Lattice:
         ht._counters = oh._counters
         ht._pos_dim_hint, ht._val_dim_hint = oh.pos_dim(), oh.val_dim()
         ht._static_rows = oh._static_rows
+        ht._static_levels = getattr(oh, "_static_levels", None)
         ht.m_nr_filled_is_dirty = oh.m_nr_filled_is_dirty
         ht.m_nr_filled = oh.m_nr_filled
         new.m_hash_table = ht
@@ -606,6 +607,7 @@ class Lattice:
             nh._counters = oh._counters.clone()
         idx, w = new._build(positions_raw, True, vals=values, distributed=distributed)
         new._after_build(lambda: new._prefetch_neighbours(n * (d + 1)))
+        new._trace_level()
         return new, distributed, idx, w
 
     def expand(self, positions_raw: torch.Tensor, point_multiplier: int, noise_stddev: float, expand_values: bool):  # Lattice.cu:292-348
@@ -872,6 +874,13 @@ class Lattice:
         ht._storage = _TableStorage(capacity, d, dev)
         ht.m_values_tensor = torch.zeros((1, self.val_dim()), dtype=torch.float32, device=dev)
         ht._counters = torch.zeros((2,), dtype=torch.int32, device=dev)
+        levels = getattr(self.m_hash_table, "_static_levels", None)
+        if self.m_hash_table._static_rows is not None:  # static-rows mode: every level needs its own bound
+            if not levels or coarse.m_lvl not in levels:
+                raise _lib.LatticeNetHipError(f"static-rows mode: no row bound for lattice level {coarse.m_lvl} "
+                                              "(set_static_rows(bound, coarse_bounds=[...]))")
+            ht._static_rows = min(int(levels[coarse.m_lvl]), capacity)
+        ht._static_levels = levels
         coarse.m_hash_table = ht
         ht.clear(lazy=True)  # rides in the build call of create_coarse_verts_naive; c_table() flushes it for ln_coarsen
         return coarse
@@ -891,12 +900,14 @@ class Lattice:
         coarse.m_hash_table.m_nr_filled_is_dirty = True
         nr = coarse.nr_lattice_vertices()
         coarse.m_hash_table.m_values_tensor = torch.zeros((nr, self.val_dim()), dtype=torch.float32, device=self._dev())
+        coarse._trace_level()
         return coarse
 
     def create_coarse_verts_naive(self, positions_raw: torch.Tensor) -> "Lattice":  # Lattice.cu:706-740
         self._check_positions(positions_raw)
         coarse = self._new_coarse()
         coarse.just_create_verts(positions_raw, False)
+        coarse._trace_level()
         return coarse
 
     # ---------------------------------------------------------------- slice family
@@ -1075,7 +1086,33 @@ class Lattice:
     def lvl(self) -> int:
         return self.m_lvl
 
-    def set_static_rows(self, rows_bound):
+    def rows_device(self):
+        """Device int32[1] holding this lattice's vertex count when the static-rows mode is on (its [rows, *] tensors are then
+        taller than the lattice: row-mixing consumers such as GroupNorm need the real count), else None."""
+        ht = self.m_hash_table
+        return ht._counters[0:1] if (ht._static_rows is not None and ht._counters is not None) else None
+
+    # calibration of the static-rows mode for a whole network: every build made while a trace is open records (level, vertices)
+    _level_trace = None
+
+    @staticmethod
+    def start_level_trace():
+        Lattice._level_trace = []
+
+    @staticmethod
+    def stop_level_trace():
+        """{level: largest vertex count seen} of the builds since start_level_trace() (host reads: eager mode only)."""
+        trace, Lattice._level_trace = Lattice._level_trace or [], None
+        out = {}
+        for lvl, nr in trace:
+            out[lvl] = max(out.get(lvl, 0), nr)
+        return out
+
+    def _trace_level(self):
+        if Lattice._level_trace is not None:
+            Lattice._level_trace.append((self.m_lvl, self.nr_lattice_vertices()))
+
+    def set_static_rows(self, rows_bound, coarse_bounds=None):
         """Capture-safe mode for hipGraph / torch.cuda.graph capture of a whole step (extension; None switches it off).
 
         The reference reads the vertex count back to the host after every build (Lattice.cu:1320-1352) and sizes the value
@@ -1094,12 +1131,15 @@ class Lattice:
         ht = self.m_hash_table
         if rows_bound is None:
             ht._static_rows = None
+            ht._static_levels = None
             ht.m_nr_filled_is_dirty = True
             return
         rows_bound = int(rows_bound)
         if rows_bound < 1 or rows_bound > ht.capacity():
             raise ValueError(f"static row bound {rows_bound} must be in [1, capacity={ht.capacity()}]")
         ht._static_rows = rows_bound
+        # coarse_bounds[k]: bound of the lattice k + 1 levels coarser than this one (create_coarse_verts hands them down)
+        ht._static_levels = None if coarse_bounds is None else {self.m_lvl + 1 + k: int(b) for k, b in enumerate(coarse_bounds)}
 
     def set_region_planes(self, planes):
         """kd split planes of key space (7 ints, see LnCsr.planes) or None.  With planes, the builds of this lattice file the

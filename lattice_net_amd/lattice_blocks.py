@@ -73,6 +73,18 @@ def _gn_workspace_pair(device, stream: int, nbytes: int):
     return entry["bufs"][cur], entry["bufs"][nxt], to_zero
 
 
+def reset_gn_workspaces(device=None):
+    """Zero-fills the GroupNorm accumulator pairs of the CURRENT stream and restarts their alternation.  A captured step calls this
+    first, so that every replay starts from the state the capture started from whatever ran on the stream in between (and whether
+    the step holds an even or an odd number of GroupNorm launches)."""
+    for (dev, stream), entry in _GN_WORKSPACES.items():
+        if (device is None or dev == device) and stream == _lib.stream_ptr(dev):
+            entry["bufs"][0].zero_()
+            entry["bufs"][1].zero_()
+            entry["dirty"] = [0, 0]
+            entry["cur"] = 0
+
+
 def _gn_check(rc: int, what: str, device, stream: int):
     if rc != 0:
         _GN_WORKSPACES.pop((device, stream), None)  # the zero invariant of the pair may be broken: start over with fresh buffers
@@ -84,7 +96,7 @@ class GroupNormReluFunction(torch.autograd.Function):
     (ln_group_norm_forward / _backward): statistics per group over all vertices x the group's channels."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, num_groups, eps, relu):
+    def forward(ctx, x, weight, bias, num_groups, eps, relu, rows_dev=None):
         lib = _lib.load()
         x = x.contiguous()
         m, c = x.shape
@@ -93,9 +105,10 @@ class GroupNormReluFunction(torch.autograd.Function):
         scale_shift = torch.empty((2 * c,), dtype=torch.float32, device=x.device)
         stream = _lib.stream_ptr(x.device)
         ws, ws_next, zero_bytes = _gn_workspace_pair(x.device, stream, lib.ln_group_norm_workspace_bytes(c))
-        _gn_check(lib.ln_group_norm_forward(_lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), m, c, num_groups, float(eps), int(relu),
-                                            _lib.ptr(y), _lib.ptr(mean_rstd), _lib.ptr(scale_shift), _lib.ptr(ws), ws.numel() * 8,
-                                            _lib.ptr(ws_next), zero_bytes, stream), "ln_group_norm_forward", x.device, stream)
+        _gn_check(lib.ln_group_norm_forward_rows(_lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), m, c, num_groups, float(eps), int(relu),
+                                                 _lib.ptr(y), _lib.ptr(mean_rstd), _lib.ptr(scale_shift), _lib.ptr(ws), ws.numel() * 8,
+                                                 _lib.ptr(ws_next), zero_bytes, _lib.ptr(rows_dev), stream), "ln_group_norm_forward", x.device, stream)
+        ctx.rows_dev = rows_dev  # device-side row count of the lattice (static-rows mode), None otherwise
         ctx.save_for_backward(x, weight, mean_rstd, scale_shift)
         ctx.args = (num_groups, bool(relu), bias is not None)
         return y
@@ -112,10 +125,11 @@ class GroupNormReluFunction(torch.autograd.Function):
         grad_b = torch.empty((c,), dtype=torch.float32, device=x.device) if has_bias else None
         stream = _lib.stream_ptr(x.device)
         ws, ws_next, zero_bytes = _gn_workspace_pair(x.device, stream, lib.ln_group_norm_workspace_bytes(c))
-        _gn_check(lib.ln_group_norm_backward(_lib.ptr(x), _lib.ptr(grad_y), _lib.ptr(weight), _lib.ptr(mean_rstd), _lib.ptr(scale_shift), m, c,
-                                             num_groups, int(relu), _lib.ptr(grad_x), _lib.ptr(grad_w), _lib.ptr(grad_b), _lib.ptr(ws),
-                                             ws.numel() * 8, _lib.ptr(ws_next), zero_bytes, stream), "ln_group_norm_backward", x.device, stream)
-        return grad_x, grad_w, grad_b, None, None, None
+        _gn_check(lib.ln_group_norm_backward_rows(_lib.ptr(x), _lib.ptr(grad_y), _lib.ptr(weight), _lib.ptr(mean_rstd), _lib.ptr(scale_shift), m, c,
+                                                  num_groups, int(relu), _lib.ptr(grad_x), _lib.ptr(grad_w), _lib.ptr(grad_b), _lib.ptr(ws),
+                                                  ws.numel() * 8, _lib.ptr(ws_next), zero_bytes, _lib.ptr(ctx.rows_dev), stream),
+                  "ln_group_norm_backward", x.device, stream)
+        return grad_x, grad_w, grad_b, None, None, None, None
 
 
 class MaxCentreFunction(torch.autograd.Function):
@@ -158,10 +172,13 @@ def max_centre_rows(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor) ->
     return x - (gamma * x.max(1, keepdim=True)[0] + beta)
 
 
-def group_norm_rows(x: torch.Tensor, gn: torch.nn.GroupNorm, relu: bool = False) -> torch.Tensor:
-    """GroupNorm of an [M, C] matrix with the parameters of `gn` (statistics over rows x group channels)."""
+def group_norm_rows(x: torch.Tensor, gn: torch.nn.GroupNorm, relu: bool = False, rows_dev=None) -> torch.Tensor:
+    """GroupNorm of an [M, C] matrix with the parameters of `gn` (statistics over rows x group channels).  `rows_dev`: device int
+    holding the number of rows that count (Lattice.rows_device(): static-rows mode, where x is taller than its lattice)."""
     if x.is_cuda and x.dtype == torch.float32 and x.shape[1] % 4 == 0 and x.shape[1] <= 1024 and x.shape[0] > 0:
-        return GroupNormReluFunction.apply(x, gn.weight, gn.bias, gn.num_groups, gn.eps, relu)
+        return GroupNormReluFunction.apply(x, gn.weight, gn.bias, gn.num_groups, gn.eps, relu, rows_dev)
+    if rows_dev is not None:
+        raise ValueError("static-rows mode needs the HIP GroupNorm (float32 CUDA rows, channels % 4 == 0, <= 1024 channels)")
     y = gn(x.t().unsqueeze(0)).squeeze(0).t()  # torch's layout: [1, C, M]
     return torch.relu(y) if relu else y
 
@@ -174,7 +191,7 @@ class GroupNormLatticeModule(torch.nn.Module):  # mods:585-616: 32 groups, or C/
 
     def forward(self, lattice_values, lattice_py, do_set_values: bool = True, fuse_relu: bool = False):
         _require_2d(lattice_values)
-        lattice_values = group_norm_rows(lattice_values, self.gn, fuse_relu)
+        lattice_values = group_norm_rows(lattice_values, self.gn, fuse_relu, lattice_py.rows_device() if lattice_py is not None else None)
         if do_set_values:
             lattice_py.set_values(lattice_values)
         return lattice_values, lattice_py
