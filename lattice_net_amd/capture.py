@@ -142,6 +142,7 @@ class CapturedNetworkStep:
             with torch.cuda.graph(self.graph, stream=side):
                 self.loss = guarded()
         torch.cuda.synchronize()
+        self.grads = [p.grad for p in self.parameters]  # this graph's gradient tensors (another capture rebinds p.grad)
 
     def launch(self):
         if self.stream is None:

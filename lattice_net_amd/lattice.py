@@ -44,6 +44,20 @@ def _build_sizes(tokens: int, capacity: int):
     return hit
 
 
+_STATIC_PINNED = [None, 0]  # [pinned int32[256, 4], next row]
+
+
+def _static_pinned() -> torch.Tensor:
+    """One row of a pinned int32[256, 4] block, handed out round-robin; the block is allocated once (outside any stream capture:
+    the first static-rows build of a process has to run eagerly) and never freed (see HashTable.c_table)."""
+    if _STATIC_PINNED[0] is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise _lib.LatticeNetHipError("static-rows mode: run the step eagerly once before capturing it (pinned counter block)")
+        _STATIC_PINNED[0] = torch.zeros((256, 4), dtype=torch.int32, pin_memory=True)
+    _STATIC_PINNED[1] = (_STATIC_PINNED[1] + 1) % 256
+    return _STATIC_PINNED[0][_STATIC_PINNED[1]]
+
+
 def _require_cuda(t: torch.Tensor, name: str):
     if not t.is_cuda:
         raise ValueError(f"{name} must live on a ROCm/HIP device (got {t.device}); the lattice backend has no CPU path")
@@ -150,7 +164,12 @@ class HashTable:
             self.clear()  # a deferred begin_splat must land before anybody looks at the table
         if getattr(self, "_pinned", None) is None:
             # builds write {nr_filled, status} straight into this pinned (device-visible) pair from their scan kernel
-            self._pinned = torch.zeros((4,), dtype=torch.int32, pin_memory=True)
+            if self._static_rows is not None:
+                # static-rows mode: a captured graph keeps writing to this address for as long as it is replayed, long after
+                # this (per-forward) table object is gone — the buffer comes from a pool that is never freed
+                self._pinned = _static_pinned()
+            else:
+                self._pinned = torch.zeros((4,), dtype=torch.int32, pin_memory=True)
             self._pinned_np = self._pinned.numpy()  # same memory: the host polls word 2
             self._readback_event = torch.cuda.Event()
         key = (s.uid, self._counters.data_ptr(), self._static_rows)

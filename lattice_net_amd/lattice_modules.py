@@ -111,11 +111,16 @@ _MFMA_LINEAR_WIDTHS = (16, 32, 48, 64, 96, 128, 192, 256)
 
 def _identity_rows(device, rows: int) -> torch.Tensor:
     """int32 [rows, 1] = 0..rows-1: the neighbour list that turns a lattice convolution into a per-vertex linear layer."""
-    buf = _IDENTITY_ROWS.get(device)
-    if buf is None or buf.shape[0] < rows:
-        buf = torch.arange(max(rows, 65536), dtype=torch.int32, device=device).unsqueeze(1)
-        _IDENTITY_ROWS[device] = buf
-    return buf[:rows]
+    bufs = _IDENTITY_ROWS.setdefault(device, [])
+    if not bufs or bufs[-1].shape[0] < rows:
+        # grown, never freed: a captured hipGraph may point at an earlier (shorter) buffer
+        size = 65536
+        while size < rows:
+            size *= 2
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("the identity neighbour list would be allocated inside a stream capture: run the step eagerly once first")
+        bufs.append(torch.arange(size, dtype=torch.int32, device=device).unsqueeze(1))
+    return bufs[-1][:rows]
 
 
 class LinearMfmaFunction(torch.autograd.Function):

@@ -39,6 +39,80 @@ lattice_gpu: { hash_table_capacity: 5000000  nr_sigmas: 1  sigma_0: "0.08 3" }
 }
 
 
+def make_graph_step(args, preset, cfg_text, net, opt, gen, dev, nll_loss_gather):
+    """K scans per optimizer step, each captured once (forward + NLL + backward = one hipGraph) on its own stream."""
+    from lattice_net_amd import CapturedNetworkStep
+    K = max(1, args.in_flight)
+    params = list(net.parameters())
+    scans = []
+    for k in range(K):
+        with tempfile.NamedTemporaryFile("w", suffix=".cfg", delete=False) as f:
+            f.write(cfg_text)
+        lat = Lattice.create(f.name, "lattice")
+        os.unlink(f.name)
+        pos = torch.from_numpy(gen(args.n, k)).to(dev)
+        vals = torch.zeros((args.n, 1), device=dev) if preset["values"] == 1 else torch.rand((args.n, preset["values"]), device=dev)
+        target = torch.from_numpy(np.random.default_rng(k).integers(0, args.classes, args.n)).to(dev)
+
+        def one(lat=lat, pos=pos, vals=vals, target=target):
+            logsoftmax, _ = net(lat, pos, vals)
+            loss = nll_loss_gather(logsoftmax, target)
+            loss.backward()
+            return loss.detach()
+
+        for p in params:
+            p.grad = None
+        cap = CapturedNetworkStep(one, lat, params, stream=torch.cuda.Stream() if K > 1 else None)
+        scans.append(cap)
+        if os.environ.get("LNN_DEBUG"):
+            torch.cuda.synchronize()
+            print("captured scan", k, cap.bounds, flush=True)
+            for it in range(2):
+                cap.launch()
+                torch.cuda.synchronize()
+                print("  replay", it, float(cap.loss), flush=True)
+    main_stream = torch.cuda.current_stream()
+    if os.environ.get("LNN_DEBUG"):
+        for it in range(2):
+            for k, cap in enumerate(scans):
+                cap.launch()
+                torch.cuda.synchronize()
+                print("serial replay", it, k, float(cap.loss), flush=True)
+        for it in range(2):
+            for cap in scans:
+                cap.launch()
+            torch.cuda.synchronize()
+            print("concurrent replay", it, [float(c.loss) for c in scans], flush=True)
+
+    pending = []  # the host stays at most two optimizer steps ahead of the GPU: thousands of graph nodes per replay otherwise pile
+                  # up in the queues (the ScanNet-shaped step, ~2500 nodes per replay, aborted with a queue exception without this)
+
+    def step():
+        if len(pending) >= 2:
+            pending.pop(0).synchronize()
+        if K == 1:
+            loss = scans[0].launch()
+            for p, g in zip(params, scans[0].grads):
+                p.grad = g
+        else:
+            for cap in scans:
+                cap.stream.wait_stream(main_stream)  # the parameters of the previous optimizer step
+                loss = cap.launch()
+            for cap in scans:
+                main_stream.wait_stream(cap.stream)
+            for cap in scans[1:]:
+                torch._foreach_add_(scans[0].grads, cap.grads)
+            for p, g in zip(params, scans[0].grads):
+                p.grad = g
+        opt.step()
+        ev = torch.cuda.Event()
+        ev.record(main_stream)
+        pending.append(ev)
+        return loss
+
+    return step
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="kitti", choices=sorted(PRESETS))
@@ -46,6 +120,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--infer", action="store_true", help="forward only, under torch.no_grad()")
+    ap.add_argument("--graph", action="store_true", help="forward + loss + backward of a scan as ONE hipGraph replay (CapturedNetworkStep); "
+                                                         "the optimizer step stays outside the graph")
+    ap.add_argument("--in-flight", type=int, default=1, help="with --graph: scans per optimizer step, each with its own lattice, graph and "
+                                                             "stream, replayed concurrently; their gradients are summed (batch of K scans)")
     ap.add_argument("--host-profile", action="store_true", help="cProfile of the host side of the timed steps")
     ap.add_argument("--gc", type=int, default=0, help="1 = leave Python's cyclic garbage collector on during the timed steps; 2 = on, after gc.freeze()")
     args = ap.parse_args()
@@ -61,6 +139,7 @@ def main():
     mp = ModelParams.create(path)
     lattice = Lattice.create(path, "lattice")
     os.unlink(path)  # both readers are done with the temporary cfg
+    path_cfg = preset["cfg"]
     net = LNN(args.classes, mp)
     gen = {"lidar": synthetic.lidar_cloud, "box": synthetic.box_surface_cloud, "planes": synthetic.planes_cloud}[preset["cloud"]]
     pos = torch.from_numpy(gen(args.n, 0)).to(dev)
@@ -86,6 +165,11 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    if args.graph:
+        step = make_graph_step(args, preset, path_cfg, net, opt, gen, dev, nll_loss_gather)
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
     if args.gc == 2:
         # collector left on, but everything alive after the warm-up (modules, torch internals) is moved out of its reach:
         # full collections then only walk what the steps themselves allocate
@@ -112,7 +196,9 @@ def main():
         pr.disable()
         pstats.Stats(pr).sort_stats("tottime").print_stats(35)
     nparams = sum(p.numel() for p in net.parameters())
-    print(f"LNN[{args.config}] {'forward' if args.infer else 'train step'}: {dt * 1e3:.2f} ms  ({args.n / dt / 1e6:.2f} Mpoints/s), {nparams} parameters, loss {loss.item():.4f}")
+    scans = max(1, args.in_flight) if args.graph else 1
+    mode = (f"train step, graph x{scans} in flight" if args.graph else "train step") if not args.infer else "forward"
+    print(f"LNN[{args.config}] {mode}: {dt * 1e3 / scans:.2f} ms per scan  ({args.n * scans / dt / 1e6:.2f} Mpoints/s), {nparams} parameters, loss {loss.item():.4f}")
 
 
 if __name__ == "__main__":
