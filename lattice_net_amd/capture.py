@@ -13,8 +13,8 @@ capture can contain.  `CapturedStep` packages the recipe that removes that wait 
 
 The step function must be self-contained: it reads its inputs from tensors that stay alive (overwrite them IN PLACE to feed
 new data of the same shape), uses `lattice.nr_lattice_vertices()` wherever it needs a row count, and must not synchronise.
-Only the splat -> conv -> slice family is capture-safe today: modules whose statistics run over the vertex rows (GroupNorm)
-would see the padded rows.
+`CapturedStep` covers the splat -> conv -> slice family on one lattice; `CapturedNetworkStep` (below) covers a whole LNN-style
+network: one row bound per lattice level and GroupNorm statistics over the device-side vertex count.
 """
 from __future__ import annotations
 
