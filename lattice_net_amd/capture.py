@@ -145,9 +145,38 @@ class CapturedNetworkStep:
         self.grads = [p.grad for p in self.parameters]  # this graph's gradient tensors (another capture rebinds p.grad)
 
     def launch(self):
-        if self.stream is None:
+        """One replay (asynchronous).  Two guards against a host that runs ahead: at most two replays of this graph are queued
+        behind the running one (event wait), and every 8th launch waits for the launch stream itself — a whole-network replay is
+        hundreds to thousands of graph nodes, and on this stack (ROCm 7.2) the runtime only recycles the per-node launch resources
+        of a stream when the host synchronises with it: without any stream-level wait the process aborted with an HSA queue
+        exception after ~10^5 nodes (a ScanNet-shaped step after ~25 replays, the SemanticKITTI one after ~250), whatever the
+        event waits in between."""
+        pending = self.__dict__.setdefault("_pending", [])
+        if len(pending) >= 2:
+            pending.pop(0).synchronize()
+        self._launches = getattr(self, "_launches", 0) + 1
+        stream = self.stream if self.stream is not None else torch.cuda.current_stream()
+        if self._launches % 8 == 0:
+            stream.synchronize()
+        with torch.cuda.stream(stream):
             self.graph.replay()
-        else:
-            with torch.cuda.stream(self.stream):
-                self.graph.replay()
+            ev = torch.cuda.Event()
+            ev.record()
+        pending.append(ev)
         return self.loss
+
+    @staticmethod
+    def publish_gradients(captures, buffers=None):
+        """Sums the gradients of `captures` (CapturedNetworkStep objects of one parameter list, all replayed and joined on the
+        current stream) into persistent buffers and binds them as `p.grad`.  Returns the buffers (pass them back in the next
+        step).  The graphs' own gradient tensors stay untouched (the next replay overwrites them anyway)."""
+        first = captures[0]
+        if buffers is None:
+            buffers = [torch.empty_like(g) if g is not None else None for g in first.grads]
+        live = [(b, g) for b, g in zip(buffers, first.grads) if g is not None]
+        torch._foreach_copy_([b for b, _ in live], [g for _, g in live])
+        for cap in captures[1:]:
+            torch._foreach_add_([b for b, g in zip(buffers, cap.grads) if g is not None], [g for g in cap.grads if g is not None])
+        for p, b in zip(first.parameters, buffers):
+            p.grad = b
+        return buffers

@@ -46,8 +46,7 @@ class GeneralizedSoftDiceLoss(torch.nn.Module):
         union = probs.sum(0) + counts
         loss_per_class = 1.0 - 2.0 * intersection / (union + 1e-6)
         if self.ignore_index is not None:
-            weight = torch.ones(nr_classes, dtype=probs.dtype, device=probs.device)
-            weight[self.ignore_index] = 0
+            weight = (torch.arange(nr_classes, device=probs.device) != int(self.ignore_index)).to(probs.dtype)
             loss_per_class = loss_per_class * weight
         return loss_per_class.sum() / nr_classes
 
@@ -70,7 +69,14 @@ class LovaszSoftmax(torch.nn.Module):
         # column-wise ones on an [N, C] matrix
         onehot = onehot.t().contiguous()
         errors = (onehot - probs.t()).abs()
-        errors_sorted, order = torch.sort(errors, dim=1, descending=True)
+        if errors.is_cuda and torch.cuda.is_current_stream_capturing():
+            # torch.sort of a [C, N] matrix (or of one long vector) is not replay-safe on this stack beyond ~10^5 elements per
+            # call (PyTorch 2.10 / ROCm 7: the second replay of the captured sort faults); one sort per class row is
+            parts = [torch.sort(errors[k], descending=True) for k in range(c)]
+            errors_sorted = torch.stack([p[0] for p in parts])
+            order = torch.stack([p[1] for p in parts])
+        else:
+            errors_sorted, order = torch.sort(errors, dim=1, descending=True)
         fg_sorted = torch.gather(onehot, 1, order)
         # gradient of the Jaccard loss along the sorted order: J_k = 1 - (G - cumsum fg) / (G + cumsum (1 - fg))
         gts = fg_sorted.sum(1, keepdim=True)
@@ -81,8 +87,7 @@ class LovaszSoftmax(torch.nn.Module):
         per_class = (errors_sorted * grad).sum(1)
         present = gts.squeeze(1) > 0
         if self.ignore_index is not None and 0 <= int(self.ignore_index) < c:
-            keep = torch.ones(c, dtype=torch.bool, device=probs.device)
-            keep[int(self.ignore_index)] = False
+            keep = torch.arange(c, device=probs.device) != int(self.ignore_index)  # (no host scalar: safe inside a stream capture)
             present = present & keep
         if self.reduction == "none":
             return per_class[present]

@@ -43,6 +43,9 @@ def make_graph_step(args, preset, cfg_text, net, opt, gen, dev, nll_loss_gather)
     """K scans per optimizer step, each captured once (forward + NLL + backward = one hipGraph) on its own stream."""
     from lattice_net_amd import CapturedNetworkStep
     K = max(1, args.in_flight)
+    if K > 1 and args.steps > 100:
+        print("[bench_lnn] note: long runs of SEVERAL whole-network graphs replaying concurrently abort the HSA queue on this stack "
+              "(ROCm 7.2, a few hundred steps in); one graph at a time (--in-flight 1) runs clean for as long as tried", flush=True)
     params = list(net.parameters())
     scans = []
     for k in range(K):
@@ -84,26 +87,25 @@ def make_graph_step(args, preset, cfg_text, net, opt, gen, dev, nll_loss_gather)
             torch.cuda.synchronize()
             print("concurrent replay", it, [float(c.loss) for c in scans], flush=True)
 
+    state = {"buffers": None}
     pending = []  # the host stays at most two optimizer steps ahead of the GPU: thousands of graph nodes per replay otherwise pile
                   # up in the queues (the ScanNet-shaped step, ~2500 nodes per replay, aborted with a queue exception without this)
 
     def step():
         if len(pending) >= 2:
             pending.pop(0).synchronize()
+        state["n"] = state.get("n", 0) + 1
+        if K > 1 and state["n"] % int(os.environ.get("LNN_SYNC_EVERY", "8")) == 0:
+            torch.cuda.synchronize()  # several streams of replays: a device-level wait every few steps (CapturedNetworkStep.launch)
         if K == 1:
             loss = scans[0].launch()
-            for p, g in zip(params, scans[0].grads):
-                p.grad = g
         else:
             for cap in scans:
                 cap.stream.wait_stream(main_stream)  # the parameters of the previous optimizer step
                 loss = cap.launch()
             for cap in scans:
                 main_stream.wait_stream(cap.stream)
-            for cap in scans[1:]:
-                torch._foreach_add_(scans[0].grads, cap.grads)
-            for p, g in zip(params, scans[0].grads):
-                p.grad = g
+        state["buffers"] = CapturedNetworkStep.publish_gradients(scans, state["buffers"])
         opt.step()
         ev = torch.cuda.Event()
         ev.record(main_stream)
@@ -188,8 +190,10 @@ def main():
         pr = cProfile.Profile()
         pr.enable()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for it in range(args.steps):
         loss = step()
+        if os.environ.get("LNN_TRACE") and it % 20 == 0:
+            print("step", it, float(loss), flush=True)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
     if args.host_profile:
