@@ -1123,7 +1123,10 @@ extern "C" int ln_conv_backward(const int* nbr_q, const int* nbr_n, const float*
         break;
             switch (bwd_t) { LN_BWD_FUSED(1) LN_BWD_FUSED(2) LN_BWD_FUSED(3) LN_BWD_FUSED(4) }
 #undef LN_BWD_FUSED
-            LN_LAUNCH("k_reduce_slabs", k_reduce_slabs4, dim3(total / 64), dim3(256), 0, st, (const float*)partial, wgs, total, grad_filter);
+            if ((reinterpret_cast<uintptr_t>(grad_filter) & 15) == 0)
+                LN_LAUNCH("k_reduce_slabs", k_reduce_slabs4, dim3(total / 64), dim3(256), 0, st, (const float*)partial, wgs, total, grad_filter);
+            else
+                LN_LAUNCH("k_reduce_slabs", k_reduce_slabs, dim3(ln_div_up(total, 16)), dim3(256), 0, st, (const float*)partial, wgs, total, grad_filter);
             return ln_check_launch("ln_conv_backward");
         }
         const int conv_blocks = ln_div_up(mn, 64);
