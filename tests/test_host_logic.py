@@ -124,7 +124,16 @@ def test_static_rows_and_region_planes_argument_checks():
     lat.set_static_rows(512)
     assert lat.nr_lattice_vertices() == 512          # no table exists yet: nothing was read from a device
     assert lat.clone_lattice().nr_lattice_vertices() == 512  # clones (e.g. the convolved lattice) inherit the bound
+    # whole-network mode: one bound per lattice level, handed down to clones; the device-side row count is only offered in
+    # static mode (and only once a table exists)
+    lat.set_static_rows(512, coarse_bounds=[128, 64])
+    assert lat.m_hash_table._static_levels == {lat.m_lvl + 1: 128, lat.m_lvl + 2: 64}
+    assert lat.clone_lattice().m_hash_table._static_levels == lat.m_hash_table._static_levels
+    assert lat.rows_device() is None                 # no counters yet
     lat.set_static_rows(None)
+    assert lat.m_hash_table._static_levels is None and lat.rows_device() is None
+    Lattice.start_level_trace()
+    assert Lattice.stop_level_trace() == {}
     with pytest.raises(LatticeNetHipError):
         lat.set_region_planes([0] * 7)               # needs a built table
     with pytest.raises(LatticeNetHipError):
