@@ -197,70 +197,22 @@ def full_unet_step(dev, n: int, steps: int = 10, warmup: int = 3, classes: int =
     out = {"what": "LNN training step (forward + NLL + backward + AdamW), reference SemanticKITTI model shape, same 120k-point scan",
            "ms_per_step": round(dt * 1e3, 3), "mpoints_per_s": round(n / dt / 1e6, 2), "parameters": sum(p.numel() for p in net.parameters()),
            "steps": steps}
-    # The same step with forward + loss + backward captured as ONE hipGraph per scan (lattice_net_amd.CapturedNetworkStep: static
-    # row bounds on every lattice level, GroupNorm over the device-side vertex count) and `scans` scans in flight per optimizer
-    # step (own lattice, graph and stream each; their gradients are summed — a batch of `scans` clouds).
+    # The same step with forward + loss + backward captured as ONE hipGraph (lattice_net_amd.CapturedNetworkStep: static row bounds
+    # on every lattice level, GroupNorm over the device-side vertex count), timed by tools/bench_lnn.py in a CHILD
+    # process: a secondary number must not be able to take the headline down with it.
     try:
-        from lattice_net_amd import CapturedNetworkStep
-        scans, params = 1, list(net.parameters())  # (several captured scans in flight: faster — tools/bench_lnn.py --in-flight — but long runs
-        # of concurrent whole-network replays abort the HSA queue on this stack; the bench keeps to one)
-        caps = []
-        for k in range(scans):
-            with tempfile.NamedTemporaryFile("w", suffix=".cfg", delete=False) as fcfg:
-                fcfg.write(UNET_CFG)
-            lat_k = Lattice.create(fcfg.name, "lattice")
-            os.unlink(fcfg.name)
-            pos_k = torch.from_numpy(synthetic.lidar_cloud(n, k)).to(dev)
-            tgt_k = torch.from_numpy(np.random.default_rng(k).integers(0, classes, n)).to(dev)
-
-            def one(lat_k=lat_k, pos_k=pos_k, tgt_k=tgt_k):
-                logsoftmax, _ = net(lat_k, pos_k, vals)
-                loss = nll_loss_gather(logsoftmax, tgt_k)
-                loss.backward()
-                return loss.detach()
-
-            for p in params:
-                p.grad = None
-            caps.append(CapturedNetworkStep(one, lat_k, params, stream=torch.cuda.Stream() if scans > 1 else None))
-        main_stream = torch.cuda.current_stream()
-        pending, state = [], {"buffers": None}
-
-        def graph_step():
-            if len(pending) >= 2:
-                pending.pop(0).synchronize()
-            state["n"] = state.get("n", 0) + 1
-            if state["n"] % 8 == 0:
-                torch.cuda.synchronize()  # several streams of replays: a device-level wait every few steps (CapturedNetworkStep.launch)
-            for cap in caps:
-                if cap.stream is not None:
-                    cap.stream.wait_stream(main_stream)
-                cap.launch()
-            for cap in caps:
-                if cap.stream is not None:
-                    main_stream.wait_stream(cap.stream)
-            state["buffers"] = CapturedNetworkStep.publish_gradients(caps, state["buffers"])
-            opt.step()
-            ev = torch.cuda.Event()
-            ev.record(main_stream)
-            pending.append(ev)
-
-        for _ in range(3):
-            graph_step()
-        torch.cuda.synchronize()
-        gc.collect()
-        gc.disable()
-        try:
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                graph_step()
-            torch.cuda.synchronize()
-            dtg = (time.perf_counter() - t0) / steps / scans
-        finally:
-            if gc_was_on:
-                gc.enable()
-        out["graph"] = {"what": f"forward + NLL + backward as one hipGraph per scan, {scans} scan(s) per AdamW step",
-                        "ms_per_scan": round(dtg * 1e3, 3), "mpoints_per_s": round(n / dtg / 1e6, 2), "scans_in_flight": scans}
-    except Exception as e:  # the secondary number must never take the headline down
+        import subprocess
+        import sys
+        tool = os.path.join(ROOT, "tools", "bench_lnn.py")
+        r = subprocess.run([sys.executable, tool, "--config", "kitti", "--n", str(n), "--graph", "--steps", str(2 * steps), "--warmup", str(warmup)],
+                           capture_output=True, text=True, timeout=300)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("LNN[")]
+        if r.returncode != 0 or not line:
+            raise RuntimeError((r.stderr or r.stdout)[-300:])
+        ms = float(line[-1].split(":")[1].split("ms")[0])
+        out["graph"] = {"what": "forward + NLL + backward as one hipGraph replay, AdamW outside (tools/bench_lnn.py --graph, child process)",
+                        "ms_per_step": round(ms, 3), "mpoints_per_s": round(n / ms / 1e3, 2)}
+    except Exception as e:
         out["graph"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     return out
 
