@@ -26,6 +26,14 @@ static bool ln_bwd_fused_shape(int filter_extent, int val_dim, int nr_filters) {
 // round costs about T: the T with the cheapest rounds(T) * T wins, larger T on ties (fewer slabs) — one round at C3 (T = 3; a
 // 257th workgroup would run after all the others: twice the time), 2 rounds of T = 4 at 129 k vertices.
 static int ln_bwd_subtiles(int m) {
+    {
+        static int forced = -1;  // experiment knob: LN_BWD_T=1..4 forces the sub-tile count
+        if (forced < 0) {
+            const char* e = getenv("LN_BWD_T");
+            forced = e ? atoi(e) : 0;
+        }
+        if (forced >= 1 && forced <= LN_BWD_MAX_SUBTILES) return forced;
+    }
     const int s = (m + 63) / 64;
     int best = 1, best_cost = 1 << 30;
     for (int t = 1; t <= LN_BWD_MAX_SUBTILES; ++t) {
