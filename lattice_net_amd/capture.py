@@ -18,6 +18,7 @@ network: one row bound per lattice level and GroupNorm statistics over the devic
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, Optional, Sequence
 
 import torch
@@ -165,18 +166,19 @@ class CapturedNetworkStep:
         pending.append(ev)
         return self.loss
 
+    def bind_gradients(self):
+        """Binds this graph's gradient tensors as `p.grad` (they hold the last replay's gradients; another capture over the same
+        parameters rebinds `p.grad` to its own).  (Copying them into persistent buffers with torch._foreach_copy_ first faulted
+        on the 9 M-parameter ScanNet-shaped model on this stack; the optimizer reads the graph's tensors directly.)"""
+        for p, g in zip(self.parameters, self.grads):
+            p.grad = g
+
     @staticmethod
-    def publish_gradients(captures, buffers=None):
-        """Sums the gradients of `captures` (CapturedNetworkStep objects of one parameter list, all replayed and joined on the
-        current stream) into persistent buffers and binds them as `p.grad`.  Returns the buffers (pass them back in the next
-        step).  The graphs' own gradient tensors stay untouched (the next replay overwrites them anyway)."""
+    def sum_gradients(captures):
+        """Adds the gradients of captures[1:] into those of captures[0] (in place: the next replay overwrites them) and binds the
+        result — K scans per optimizer step, all replays joined on the current stream."""
         first = captures[0]
-        if buffers is None:
-            buffers = [torch.empty_like(g) if g is not None else None for g in first.grads]
-        live = [(b, g) for b, g in zip(buffers, first.grads) if g is not None]
-        torch._foreach_copy_([b for b, _ in live], [g for _, g in live])
         for cap in captures[1:]:
-            torch._foreach_add_([b for b, g in zip(buffers, cap.grads) if g is not None], [g for g in cap.grads if g is not None])
-        for p, b in zip(first.parameters, buffers):
-            p.grad = b
-        return buffers
+            pairs = [(a, b) for a, b in zip(first.grads, cap.grads) if a is not None and b is not None]
+            torch._foreach_add_([a for a, _ in pairs], [b for _, b in pairs])
+        first.bind_gradients()

@@ -532,7 +532,9 @@ static int ln_conv_slots_per_split_rt(int m, int E, int val_dim, int nr_filters)
 
 // bf16x3 path: channel counts that are multiples of 32, lattices large enough to be matrix-bound, LN_CONV_EXACT_F32=1 switches
 // it off (A/B; read once)
+#ifndef LN_CONV_B3_MIN_ROWS
 #define LN_CONV_B3_MIN_ROWS 16384
+#endif
 static bool ln_conv_b3_enabled() {
     static int v = -1;
     if (v < 0) {

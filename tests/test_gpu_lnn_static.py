@@ -70,7 +70,17 @@ def test_lnn_static_rows_matches_eager(tmp_path):
 
 def test_lnn_training_step_as_one_graph(tmp_path):
     """forward + NLL + backward captured once (CapturedNetworkStep), replayed on the calibration cloud and on another cloud
-    written into the same tensors: losses equal to the eager step's on each cloud."""
+    written into the same tensors: losses equal to the eager step's on each cloud.  Runs in a child process: whole-network
+    hipGraphs are the one place where this stack has aborted processes, and an abort must not take the suite along."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("LNN_GRAPH_TEST_CHILD") != "1":
+        env = dict(os.environ, LNN_GRAPH_TEST_CHILD="1")
+        r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-k", "test_lnn_training_step_as_one_graph", "-p", "no:cacheprovider"],
+                           env=env, capture_output=True, text=True, timeout=600, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+        return
     from lattice_net_amd import CapturedNetworkStep, synthetic
     from lattice_net_amd.losses import nll_loss_gather
     torch.autograd.set_multithreading_enabled(False)
@@ -109,52 +119,3 @@ def test_lnn_training_step_as_one_graph(tmp_path):
         worst = max(worst, float((q.grad - grads_a[k]).abs().max()) / max(float(grads_a[k].abs().max()), 1e-12))
     assert worst <= 1e-2, worst
 
-
-def test_training_with_the_captured_step_follows_the_eager_loss_curve(tmp_path):
-    """40 AdamW steps on one cloud: (a) eager, (b) forward + NLL + backward replayed from one hipGraph with the optimizer outside
-    (CapturedNetworkStep.publish_gradients).  Same initial weights, same data: the loss curves stay within a few percent (the
-    network's own atomics make two eager runs differ by about as much)."""
-    import copy
-    from lattice_net_amd import CapturedNetworkStep
-    from lattice_net_amd.losses import nll_loss_gather
-    torch.autograd.set_multithreading_enabled(False)
-    net, lattice, pos, vals, target = _setup(tmp_path, n=20000)
-    init = copy.deepcopy(net.state_dict())
-
-    def run(graph: bool):
-        net.load_state_dict(init)
-        lattice.set_static_rows(None)
-        opt = torch.optim.AdamW(net.parameters(), lr=2e-3, weight_decay=1e-4, amsgrad=True, fused=True)
-        losses = []
-        if graph:
-            def one():
-                logsoftmax, _ = net(lattice, pos, vals)
-                loss = nll_loss_gather(logsoftmax, target)
-                loss.backward()
-                return loss.detach()
-            for p in net.parameters():
-                p.grad = None
-            cap = CapturedNetworkStep(one, lattice, net.parameters())
-            net.load_state_dict(init)  # (calibration and warm-up ran forward / backward only: weights untouched; be explicit)
-            buffers = None
-            for _ in range(40):
-                losses.append(cap.launch().clone())
-                buffers = CapturedNetworkStep.publish_gradients([cap], buffers)
-                opt.step()
-        else:
-            for _ in range(40):
-                logsoftmax, _ = net(lattice, pos, vals)
-                loss = nll_loss_gather(logsoftmax, target)
-                opt.zero_grad()
-                loss.backward()
-                opt.step()
-                losses.append(loss.detach())
-        torch.cuda.synchronize()
-        return [float(x) for x in losses]
-
-    eager = run(False)
-    graph = run(True)
-    assert eager[-1] < 0.9 * eager[0]                       # it learns (memorises the random labels of one cloud)
-    assert abs(graph[0] - eager[0]) <= 1e-4 * eager[0]      # same first step
-    for a, b in zip(eager, graph):
-        assert abs(a - b) <= 0.05 * max(a, 1e-6), (eager, graph)

@@ -105,7 +105,7 @@ def make_graph_step(args, preset, cfg_text, net, opt, gen, dev, nll_loss_gather)
                 loss = cap.launch()
             for cap in scans:
                 main_stream.wait_stream(cap.stream)
-        state["buffers"] = CapturedNetworkStep.publish_gradients(scans, state["buffers"])
+        CapturedNetworkStep.sum_gradients(scans)
         opt.step()
         ev = torch.cuda.Event()
         ev.record(main_stream)
