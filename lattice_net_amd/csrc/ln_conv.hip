@@ -204,7 +204,7 @@ __global__ void __launch_bounds__(256) LN_CONV_WAVES_ATTR
 }
 
 // ------------------------------------------------------------------------------------------
-// The per-slot gather-GEMM on the bf16 matrix cores with exactly-split operands ("bf16x3"), for large lattices.
+// The per-slot gather-GEMM on the bf16 matrix cores with exactly-split operands ("bf16x3"), for lattices of >= LN_CONV_B3_MIN_ROWS vertices.
 // fp32-input MFMA runs at the fp32 VECTOR rate on gfx950 (32 cycles per 16x16x4): at ScanNet / SemanticKITTI shapes the kernel
 // above sits at 50-80 % of that peak.  Here a = a1 + a2 + a3 EXACTLY, each part the top 16 bits of what is left (bf16 has fp32's
 // exponent range, so no scaling; 3 x 8 significant bits = fp32's 24), the same for the filter, and a*b is accumulated in fp32 as
@@ -533,7 +533,7 @@ static int ln_conv_slots_per_split_rt(int m, int E, int val_dim, int nr_filters)
 // bf16x3 path: channel counts that are multiples of 32, lattices large enough to be matrix-bound, LN_CONV_EXACT_F32=1 switches
 // it off (A/B; read once)
 #ifndef LN_CONV_B3_MIN_ROWS
-#define LN_CONV_B3_MIN_ROWS 16384
+#define LN_CONV_B3_MIN_ROWS 4096
 #endif
 static bool ln_conv_b3_enabled() {
     static int v = -1;
