@@ -127,7 +127,13 @@ class CapturedNetworkStep:
             reset_gn_workspaces()
             return step()
 
+        # The graph is ALWAYS replayed on the stream it was captured on (launch() joins it with the caller's stream): replaying on
+        # another stream — legal, and what CapturedStep does for its ten-node graphs — aborted 4 of 10 forty-step training runs of
+        # tools/probes/graph_training_flake.py when eager optimizer steps ran between the replays; on the capture stream 0 of 30.
+        # (Training loops over replays remain experimental on this stack: DESIGN.md 4.7, "State of the mode".)
         side = stream if stream is not None else torch.cuda.Stream()
+        self.own_stream = stream is None
+        self.stream = side
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(2):
@@ -146,7 +152,9 @@ class CapturedNetworkStep:
         self.grads = [p.grad for p in self.parameters]  # this graph's gradient tensors (another capture rebinds p.grad)
 
     def launch(self):
-        """One replay (asynchronous).  Two guards against a host that runs ahead: at most two replays of this graph are queued
+        """One replay (asynchronous), on the capture stream.  Without a `stream` argument at construction the object owns that
+        stream and joins it with the caller's current stream before and after the replay (drop-in for an eager step); with one,
+        the caller orders the streams itself (several scans in flight).  Two guards against a host that runs ahead: at most two replays of this graph are queued
         behind the running one (event wait), and every 8th launch waits for the launch stream itself — a whole-network replay is
         hundreds to thousands of graph nodes, and on this stack (ROCm 7.2) the runtime only recycles the per-node launch resources
         of a stream when the host synchronises with it: without any stream-level wait the process aborted with an HSA queue
@@ -156,13 +164,18 @@ class CapturedNetworkStep:
         if len(pending) >= 2:
             pending.pop(0).synchronize()
         self._launches = getattr(self, "_launches", 0) + 1
-        stream = self.stream if self.stream is not None else torch.cuda.current_stream()
+        stream = self.stream
         if self._launches % 8 == 0:
             stream.synchronize()
+        caller = torch.cuda.current_stream()
+        if self.own_stream:
+            stream.wait_stream(caller)  # inputs written / parameters updated on the caller's stream
         with torch.cuda.stream(stream):
             self.graph.replay()
             ev = torch.cuda.Event()
             ev.record()
+        if self.own_stream:
+            caller.wait_stream(stream)  # the caller's next operations see the loss and the gradients
         pending.append(ev)
         return self.loss
 

@@ -39,7 +39,7 @@ lattice_gpu: { hash_table_capacity: 5000000  nr_sigmas: 1  sigma_0: "0.08 3" }
 }
 
 
-def make_graph_step(args, preset, cfg_text, net, opt, gen, dev, nll_loss_gather):
+def make_graph_step(args, preset, cfg_text, net, opt, gen, dev, nll_loss_gather, first=None):
     """K scans per optimizer step, each captured once (forward + NLL + backward = one hipGraph) on its own stream."""
     from lattice_net_amd import CapturedNetworkStep
     K = max(1, args.in_flight)
@@ -92,8 +92,6 @@ def make_graph_step(args, preset, cfg_text, net, opt, gen, dev, nll_loss_gather)
                   # up in the queues (the ScanNet-shaped step, ~2500 nodes per replay, aborted with a queue exception without this)
 
     def step():
-        if len(pending) >= 2:
-            pending.pop(0).synchronize()
         state["n"] = state.get("n", 0) + 1
         if K > 1 and state["n"] % int(os.environ.get("LNN_SYNC_EVERY", "8")) == 0:
             torch.cuda.synchronize()  # several streams of replays: a device-level wait every few steps (CapturedNetworkStep.launch)
@@ -107,9 +105,6 @@ def make_graph_step(args, preset, cfg_text, net, opt, gen, dev, nll_loss_gather)
                 main_stream.wait_stream(cap.stream)
         CapturedNetworkStep.sum_gradients(scans)
         opt.step()
-        ev = torch.cuda.Event()
-        ev.record(main_stream)
-        pending.append(ev)
         return loss
 
     return step
@@ -168,7 +163,7 @@ def main():
         step()
     torch.cuda.synchronize()
     if args.graph:
-        step = make_graph_step(args, preset, path_cfg, net, opt, gen, dev, nll_loss_gather)
+        step = make_graph_step(args, preset, path_cfg, net, opt, gen, dev, nll_loss_gather, first=(lattice, pos, vals, target))
         for _ in range(3):
             step()
         torch.cuda.synchronize()

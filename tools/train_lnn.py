@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--classes", type=int, default=20)
     ap.add_argument("--clouds", type=int, default=4, help="distinct clouds per rank, cycled")
     ap.add_argument("--lr", type=float, default=1e-3)
+    ap.add_argument("--graph", action="store_true", help="forward + loss + backward captured once as a hipGraph (lattice_net_amd."
+                                                         "CapturedNetworkStep) and fed in place; all-reduce and AdamW stay outside")
     args = ap.parse_args()
     world, rank, local_rank = sharding.env_world()
     torch.cuda.set_device(local_rank)
@@ -87,6 +89,21 @@ def main():
     scores = Scores()
     losses, t_start = [], None
     import gc
+    cap = None
+    if args.graph:
+        # ONE captured step; every cloud of the rotation is copied into the tensors the graph reads
+        from lattice_net_amd import CapturedNetworkStep
+        pos_s, vals_s, target_s = (t.clone() for t in clouds[0])
+        held = {}
+
+        def one():
+            logsoftmax, _ = net(lattice, pos_s, vals_s)
+            loss = 0.5 * lovasz(logsoftmax, target_s) + 0.5 * nll(logsoftmax, target_s)
+            loss.backward()
+            held["logsoftmax"] = logsoftmax.detach()
+            return loss.detach()
+
+        cap = CapturedNetworkStep(one, lattice, list(net.parameters()), row_slack=0.10)
     for step in range(args.steps):
         if step == 2:
             # Python's cycle collector costs ~4 ms per step here: its full passes walk every live module / torch object.  The
@@ -99,10 +116,18 @@ def main():
             sharding.barrier(dist)
             t_start, timed_from = time.perf_counter(), step
         pos, vals, target = clouds[step % len(clouds)]
-        logsoftmax, _ = net(lattice, pos, vals)
-        loss = 0.5 * lovasz(logsoftmax, target) + 0.5 * nll(logsoftmax, target)
-        opt.zero_grad()
-        loss.backward()
+        if cap is not None:
+            pos_s.copy_(pos)
+            vals_s.copy_(vals)
+            target_s.copy_(target)
+            loss = cap.launch().clone()
+            logsoftmax = held["logsoftmax"]
+            cap.bind_gradients()
+        else:
+            logsoftmax, _ = net(lattice, pos, vals)
+            loss = 0.5 * lovasz(logsoftmax, target) + 0.5 * nll(logsoftmax, target)
+            opt.zero_grad()
+            loss.backward()
         sharding.allreduce_gradients(dist, net.parameters())
         opt.step()
         losses.append(loss.detach())
