@@ -87,11 +87,12 @@ def make_graph_step(args, preset, cfg_text, net, opt, gen, dev, nll_loss_gather,
             torch.cuda.synchronize()
             print("concurrent replay", it, [float(c.loss) for c in scans], flush=True)
 
-    state = {"buffers": None}
-    pending = []  # the host stays at most two optimizer steps ahead of the GPU: thousands of graph nodes per replay otherwise pile
-                  # up in the queues (the ScanNet-shaped step, ~2500 nodes per replay, aborted with a queue exception without this)
+    state = {}
+    pending = []  # the host stays at most two optimizer steps ahead of the GPU (fewer aborts than without: DESIGN.md 4.7)
 
     def step():
+        if len(pending) >= 2:
+            pending.pop(0).synchronize()
         state["n"] = state.get("n", 0) + 1
         if K > 1 and state["n"] % int(os.environ.get("LNN_SYNC_EVERY", "8")) == 0:
             torch.cuda.synchronize()  # several streams of replays: a device-level wait every few steps (CapturedNetworkStep.launch)
@@ -105,6 +106,9 @@ def make_graph_step(args, preset, cfg_text, net, opt, gen, dev, nll_loss_gather,
                 main_stream.wait_stream(cap.stream)
         CapturedNetworkStep.sum_gradients(scans)
         opt.step()
+        ev = torch.cuda.Event()
+        ev.record(main_stream)
+        pending.append(ev)
         return loss
 
     return step
