@@ -1104,6 +1104,216 @@ __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(T,
     LN_CSTAMP(3);
 }
 
+// ------------------------------------------------------------------------------------------
+// The fused backward on the bf16 matrix cores with exactly 3-way split operands (see k_conv_mfma_b3 for the arithmetic).
+// V = F = 32 only: one v_mfma_f32_16x16x32_bf16 step contracts all 32 channels (value gradient) or 32 vertices (filter gradient).
+//   value gradient : A = this lane's gathered quarter row (channels 8q..8q+7 = its k-group), split in registers; B = W_e^T split
+//                    while the bank is staged — LDS holds one 16-byte fragment per (slot, column tile, part, lane), 54 KB
+//   filter gradient: D[v][f] += sum_rows values[row][v] G_e[row][f].  A = own value rows, transposed (lane (v, q): rows 8q..8q+7 of
+//                    each 32-row step), loaded and split once per sub-tile; B = G_e, whose three parts every lane stages row-major
+//                    as bf16 — the SAME parts it feeds the value gradient with — and the column access the MFMA needs (lane (f, q):
+//                    rows 8q..8q+7 of column f) comes from ds_read_b64_tr_b16, the LDS transpose read (tools/probes/tr_read_probe.cpp)
+// Per slot and wave 12 + 12 MFMAs of 16 cycles instead of 16 + 16 of 32: backward 31.0 -> 24.5 us at C3.
+// Launched with T = 3 only.  Four sub-tiles of staging do not fit LDS; and with T = 1 or 2 (86 / 117 KB of LDS: workgroups of OTHER
+// kernels fit next to one on a CU) about 1 % of the replays of two concurrent captured scans came back with wrong filter-gradient
+// columns (f = 2 mod 4 of every slot: one lane class of the transposed operand; tools/probes/fused_b3_stress.py: 4 of 300, the
+// fp32 kernel 0 of 300), which is not understood yet — with T = 3 a workgroup owns its CU (147 KB, 12 waves x 153 VGPRs): 0 of 450
+// replays at three scans in flight, and every eager / single-stream comparison at any T is clean.
+// ------------------------------------------------------------------------------------------
+typedef short short4v __attribute__((ext_vector_type(4)));
+template <int T>
+__global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(T, T)))
+    k_conv_backward_fused_b3(const int* __restrict__ nbr, const float* __restrict__ values, const float* __restrict__ grad_out,
+                             const float* __restrict__ filter, int m, float* __restrict__ grad_values, float* __restrict__ slabs) {
+    constexpr int V = 32, F = 32, E = 9, KQ = 8, NT = 2, FT = 2;
+    constexpr int THREADS = 256 * T;
+    constexpr int BANK = E * V * F;                      // floats of one slab (the parking area at the end)
+    constexpr int FRAG16 = E * NT * 3 * 64;              // 16-byte fragments of the split bank
+    constexpr int RS = 40;                               // bf16 elements per staged G_e row: 32 + 8 of padding (80 bytes)
+    constexpr int PART = 64 * RS;                        // one part of one sub-tile's G_e
+    constexpr int STAGE = 2 * 3 * PART;                  // double-buffered, three parts (bf16 elements)
+    constexpr int LDS_BYTES_A = FRAG16 * 16 + T * STAGE * 2;
+    constexpr int LDS_BYTES_B = (T - 1) * BANK * 4;
+    constexpr int LDS_BYTES = LDS_BYTES_A > LDS_BYTES_B ? LDS_BYTES_A : LDS_BYTES_B;
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[LDS_BYTES];
+    u32x4* s_frag = reinterpret_cast<u32x4*>(s_raw);
+    unsigned short* s_fh = reinterpret_cast<unsigned short*>(s_raw);
+    unsigned short* s_stage = reinterpret_cast<unsigned short*>(s_raw + FRAG16 * 16);
+    const int tid = threadIdx.x;
+    const int sub = tid >> 8;
+    const int t256 = tid & 255;
+    const int lane = tid & 63;
+    const int wave = t256 >> 6;
+    const int i = lane & 15;
+    const int q = lane >> 4;
+    const int sub0 = blockIdx.x * (64 * T) + sub * 64;
+    const int m0 = sub0 + wave * 16;
+    const int my_row = m0 + i;
+
+    constexpr int N4 = E * V * F / 4;
+    constexpr int NST = (N4 + THREADS - 1) / THREADS;
+    float4 wv[NST];
+#pragma unroll
+    for (int s = 0; s < NST; ++s) {
+        const int x4 = tid + s * THREADS;
+        wv[s] = (x4 < N4) ? reinterpret_cast<const float4*>(filter)[x4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    int nb[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) nb[e] = (my_row < m) ? nbr[(size_t)my_row * E + (e < E - 1 ? (e ^ 1) : e)] : -1;
+    const int vt = wave / FT, ft = wave % FT;
+    // A operand of the filter gradient, split: step s (32 rows), part p -> 8 bf16 = rows 32s + 8q + j of column vt*16 + i
+    u32x4 va[2][3];
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = sub0 + 32 * st + 8 * q + j;
+            x[j] = (row < m) ? values[(size_t)row * V + vt * 16 + i] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned int h0, m0_, l0, h1, m1_, l1;
+            ln_split3_bits(x[2 * j], h0, m0_, l0);
+            ln_split3_bits(x[2 * j + 1], h1, m1_, l1);
+            va[st][0][j] = (h0 >> 16) | h1;
+            va[st][1][j] = (m0_ >> 16) | m1_;
+            va[st][2][j] = (l0 >> 16) | l1;
+        }
+    }
+    constexpr int DEPTH = 3;
+    auto slot_of = [](int k) { return k == 0 ? E - 1 : k - 1; };
+    float a[DEPTH + 1][KQ];
+    ln_load_quarter<KQ>(grad_out + (size_t)(my_row < m ? my_row : 0) * F + q * KQ, a[0]);
+#pragma unroll
+    for (int k = 1; k < DEPTH && k < E; ++k)
+        ln_load_quarter<KQ>(grad_out + (size_t)(nb[slot_of(k)] >= 0 ? nb[slot_of(k)] : 0) * F + q * KQ, a[k % (DEPTH + 1)]);
+    // bank -> split -> LDS fragments of W_e^T: x = (e*V + v)*F + f, four consecutive f = elements j..j+3 of ONE fragment
+#pragma unroll
+    for (int s = 0; s < NST; ++s) {
+        const int x4 = tid + s * THREADS;
+        if (x4 < N4) {
+            const int x = x4 * 4;
+            const int ev = x / F;
+            const int f0 = x - ev * F;
+            const int e = ev / V;
+            const int v = ev - e * V;
+            const float v4[4] = {wv[s].x, wv[s].y, wv[s].z, wv[s].w};
+            unsigned int h[4], md[4], lo[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ln_split3_bits(v4[j], h[j], md[j], lo[j]);
+            const int fr = (((e * NT + (v >> 4)) * 3) * 64 + (f0 >> 3) * 16 + (v & 15)) * 8 + (f0 & 7);
+            *reinterpret_cast<uint2*>(s_fh + fr) = make_uint2((h[0] >> 16) | h[1], (h[2] >> 16) | h[3]);
+            *reinterpret_cast<uint2*>(s_fh + fr + 64 * 8) = make_uint2((md[0] >> 16) | md[1], (md[2] >> 16) | md[3]);
+            *reinterpret_cast<uint2*>(s_fh + fr + 2 * 64 * 8) = make_uint2((lo[0] >> 16) | lo[1], (lo[2] >> 16) | lo[3]);
+        }
+    }
+    floatx4 acc_v[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc_v[nt] = floatx4{0.f, 0.f, 0.f, 0.f};
+    floatx4 acc_w[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc_w[e] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        const int e = slot_of(k);
+        unsigned short* sg = s_stage + (size_t)sub * STAGE + (k & 1) * (3 * PART);
+        float (&ae)[KQ] = a[k % (DEPTH + 1)];
+        if (k + DEPTH < E)
+            ln_load_quarter<KQ>(grad_out + (size_t)(nb[slot_of(k + DEPTH)] >= 0 ? nb[slot_of(k + DEPTH)] : 0) * F + q * KQ, a[(k + DEPTH) % (DEPTH + 1)]);
+        // this lane's quarter of G_e[row], split once: the A fragments of the value gradient AND what is staged for the filter gradient
+        u32x4 p1, p2, p3;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned int h0, m0_, l0, h1, m1_, l1;
+            ln_split3_bits(nb[e] >= 0 ? ae[2 * j] : 0.f, h0, m0_, l0);
+            ln_split3_bits(nb[e] >= 0 ? ae[2 * j + 1] : 0.f, h1, m1_, l1);
+            p1[j] = (h0 >> 16) | h1;
+            p2[j] = (m0_ >> 16) | m1_;
+            p3[j] = (l0 >> 16) | l1;
+        }
+        {
+            unsigned short* dst = sg + (wave * 16 + i) * RS + q * KQ;
+            *reinterpret_cast<u32x4*>(dst) = p1;
+            *reinterpret_cast<u32x4*>(dst + PART) = p2;
+            *reinterpret_cast<u32x4*>(dst + 2 * PART) = p3;
+        }
+        __syncthreads();
+        const bf16x8 a1 = __builtin_bit_cast(bf16x8, p1), a2 = __builtin_bit_cast(bf16x8, p2), a3 = __builtin_bit_cast(bf16x8, p3);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const u32x4* pb = s_frag + ((e * NT + nt) * 3) * 64 + lane;
+            const bf16x8 b1 = __builtin_bit_cast(bf16x8, pb[0]), b2 = __builtin_bit_cast(bf16x8, pb[64]), b3 = __builtin_bit_cast(bf16x8, pb[128]);
+            acc_v[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, b1, acc_v[nt], 0, 0, 0);
+            acc_v[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b3, acc_v[nt], 0, 0, 0);
+            acc_v[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b2, acc_v[nt], 0, 0, 0);
+            acc_v[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b1, acc_v[nt], 0, 0, 0);
+            acc_v[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b2, acc_v[nt], 0, 0, 0);
+            acc_v[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, acc_v[nt], 0, 0, 0);
+        }
+        // filter gradient: two 32-row steps; B fragments through the LDS transpose read (lane: 4 contiguous bf16 of row
+        // row0 + (i >> 2), columns ft*16 + 4 (i & 3) ..; it receives rows row0..row0+3 of column ft*16 + i)
+        floatx4 w0 = floatx4{0.f, 0.f, 0.f, 0.f}, w1 = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            bf16x8 b[3];
+#pragma unroll
+            for (int part = 0; part < 3; ++part) {
+                const unsigned short* base = sg + part * PART + (32 * st + 8 * q + (i >> 2)) * RS + ft * 16 + (i & 3) * 4;
+                const short4v lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4v __attribute__((address_space(3)))*)(base));
+                const short4v hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4v __attribute__((address_space(3)))*)(base + 4 * RS));
+                u32x4 packed;
+                packed[0] = (unsigned int)(unsigned short)lo4[0] | ((unsigned int)(unsigned short)lo4[1] << 16);
+                packed[1] = (unsigned int)(unsigned short)lo4[2] | ((unsigned int)(unsigned short)lo4[3] << 16);
+                packed[2] = (unsigned int)(unsigned short)hi4[0] | ((unsigned int)(unsigned short)hi4[1] << 16);
+                packed[3] = (unsigned int)(unsigned short)hi4[2] | ((unsigned int)(unsigned short)hi4[3] << 16);
+                b[part] = __builtin_bit_cast(bf16x8, packed);
+            }
+            const bf16x8 v1 = __builtin_bit_cast(bf16x8, va[st][0]), v2 = __builtin_bit_cast(bf16x8, va[st][1]), v3 = __builtin_bit_cast(bf16x8, va[st][2]);
+            floatx4& acc = st ? w1 : w0;
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v3, b[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, b[2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v2, b[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v2, b[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, b[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, b[0], acc, 0, 0, 0);
+        }
+        acc_w[e] = w0 + w1;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + q * 4 + r;
+            if (row < m) grad_values[(size_t)row * V + nt * 16 + i] = acc_v[nt][r];
+        }
+    }
+    __syncthreads();
+    float* park_all = reinterpret_cast<float*>(s_raw);
+    if (sub > 0) {
+        float* park = park_all + (size_t)(sub - 1) * BANK;
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) park[(e * V + vt * 16 + q * 4 + r) * F + ft * 16 + i] = acc_w[e][r];
+    }
+    if constexpr (T > 1) __syncthreads();
+    if (sub == 0) {
+        float* dst = slabs + (size_t)blockIdx.x * BANK;
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = (e * V + vt * 16 + q * 4 + r) * F + ft * 16 + i;
+                float sum = acc_w[e][r];
+#pragma unroll
+                for (int k2 = 1; k2 < T; ++k2) sum += park_all[(size_t)(k2 - 1) * BANK + o];
+                dst[o] = sum;
+            }
+    }
+}
+
 static bool ln_bwd_fused_enabled() { return !(ln_debug_mask() & 2048); }  // LN_DEBUG_MASK & 2048: the two-launch backward (A/B)
 
 // Both gradients of out = conv(values_neigh; nbr_q, filter[E*V, F]):
@@ -1128,8 +1338,16 @@ extern "C" int ln_conv_backward(const int* nbr_q, const int* nbr_n, const float*
             const int wgs = ln_div_up(mn, 64 * bwd_t);
 #define LN_BWD_FUSED(TT)                                                                                                               \
     case TT:                                                                                                                           \
-        LN_LAUNCH("k_conv_backward_fused", (k_conv_backward_fused<32, 32, 9, TT>), dim3(wgs), dim3(256 * TT), 0, st, nbr_n, values_neigh, grad_out,  \
-                  filter, mn, grad_values, partial);                                                                                   \
+        if constexpr (TT == 3) { /* bf16 matrix cores, exactly split operands: the three-sub-tile form only (see below) */             \
+            if (ln_conv_b3_enabled() && !(ln_debug_mask() & 65536)) {                                                                  \
+                LN_LAUNCH("k_conv_backward_fused", (k_conv_backward_fused_b3<TT>), dim3(wgs), dim3(256 * TT), 0, st, nbr_n, values_neigh, grad_out, \
+                          filter, mn, grad_values, partial);                                                                           \
+                break;                                                                                                                 \
+            }                                                                                                                          \
+        }                                                                                                                              \
+        if (true)                                                                                                                         \
+            LN_LAUNCH("k_conv_backward_fused", (k_conv_backward_fused<32, 32, 9, TT>), dim3(wgs), dim3(256 * TT), 0, st, nbr_n, values_neigh, grad_out, \
+                      filter, mn, grad_values, partial);                                                                               \
         break;
             switch (bwd_t) { LN_BWD_FUSED(1) LN_BWD_FUSED(2) LN_BWD_FUSED(3) LN_BWD_FUSED(4) }
 #undef LN_BWD_FUSED
