@@ -1117,8 +1117,11 @@ __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(T,
 // Launched with T = 3 only.  Four sub-tiles of staging do not fit LDS; and with T = 1 or 2 (86 / 117 KB of LDS: workgroups of OTHER
 // kernels fit next to one on a CU) about 1 % of the replays of two concurrent captured scans came back with wrong filter-gradient
 // columns (f = 2 mod 4 of every slot: one lane class of the transposed operand; tools/probes/fused_b3_stress.py: 4 of 300, the
-// fp32 kernel 0 of 300), which is not understood yet — with T = 3 a workgroup owns its CU (147 KB, 12 waves x 153 VGPRs): 0 of 450
-// replays at three scans in flight, and every eager / single-stream comparison at any T is clean.
+// fp32 kernel 0 of 300), which is not understood yet — with T = 3 a workgroup owns its CU (147 KB, 12 waves x 153 VGPRs): 0 of 600
+// replays at three scans in flight, and every eager / single-stream comparison at any T is clean.  Ruled out so far: LDS isolation
+// of > 64 KB workgroups and the transpose read itself beside foreign LDS traffic (tools/probes/lds_coresidency_probe.cpp,
+// tr_read_stress.cpp: 0 errors), a missing wait after the transpose reads (a full lgkmcnt(0) made it worse: 146 instead of 60 of
+// 600).  LN_DEBUG_MASK & 131072 launches the T = 1 / 2 forms for further investigation.
 // ------------------------------------------------------------------------------------------
 typedef short short4v __attribute__((ext_vector_type(4)));
 template <int T>
@@ -1338,8 +1341,8 @@ extern "C" int ln_conv_backward(const int* nbr_q, const int* nbr_n, const float*
             const int wgs = ln_div_up(mn, 64 * bwd_t);
 #define LN_BWD_FUSED(TT)                                                                                                               \
     case TT:                                                                                                                           \
-        if constexpr (TT == 3) { /* bf16 matrix cores, exactly split operands: the three-sub-tile form only (see below) */             \
-            if (ln_conv_b3_enabled() && !(ln_debug_mask() & 65536)) {                                                                  \
+        if constexpr (TT <= 3) { /* bf16 matrix cores, exactly split operands: the three-sub-tile form only (see below) */             \
+            if (ln_conv_b3_enabled() && !(ln_debug_mask() & 65536) && (TT == 3 || (ln_debug_mask() & 131072))) {                                                                \
                 LN_LAUNCH("k_conv_backward_fused", (k_conv_backward_fused_b3<TT>), dim3(wgs), dim3(256 * TT), 0, st, nbr_n, values_neigh, grad_out, \
                           filter, mn, grad_values, partial);                                                                           \
                 break;                                                                                                                 \
