@@ -1114,16 +1114,31 @@ __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(T,
 //                    as bf16 — the SAME parts it feeds the value gradient with — and the column access the MFMA needs (lane (f, q):
 //                    rows 8q..8q+7 of column f) comes from ds_read_b64_tr_b16, the LDS transpose read (tools/probes/tr_read_probe.cpp)
 // Per slot and wave 12 + 12 MFMAs of 16 cycles instead of 16 + 16 of 32: backward 31.0 -> 24.5 us at C3.
-// Launched with T = 3 only.  Four sub-tiles of staging do not fit LDS; and with T = 1 or 2 (86 / 117 KB of LDS: workgroups of OTHER
-// kernels fit next to one on a CU) about 1 % of the replays of two concurrent captured scans came back with wrong filter-gradient
-// columns (f = 2 mod 4 of every slot: one lane class of the transposed operand; tools/probes/fused_b3_stress.py: 4 of 300, the
-// fp32 kernel 0 of 300), which is not understood yet — with T = 3 a workgroup owns its CU (147 KB, 12 waves x 153 VGPRs): 0 of 600
-// replays at three scans in flight, and every eager / single-stream comparison at any T is clean.  Ruled out so far: LDS isolation
-// of > 64 KB workgroups and the transpose read itself beside foreign LDS traffic (tools/probes/lds_coresidency_probe.cpp,
-// tr_read_stress.cpp: 0 errors), a missing wait after the transpose reads (a full lgkmcnt(0) made it worse: 146 instead of 60 of
-// 600).  LN_DEBUG_MASK & 131072 launches the T = 1 / 2 forms for further investigation.
+// Launched with T = 3 only.  Four sub-tiles of staging do not fit LDS.  The T = 1 / 2 forms (86 / 117 KB of LDS, 1 / 2 waves per
+// SIMD) leave room on their CUs for waves of OTHER kernels, and a segment reduce (k_csr_reduce_segments: bpermute suffix sums +
+// fp32 atomics) running in that room on another stream returns wrong rows — one component of each float4 of heavy vertices:
+//   tools/probes/pair_probe.py (stream 1 loops this kernel, stream 2 loops the reduce on fixed inputs): T = 1: 288 of 300 reduces
+//   wrong, T = 2: 2 of 200; the fp32 kernel with T = 1, 2, 4 (same LDS sizes, same 264 / 176 VGPR allocations): 0; T = 3: 0; a
+//   convolution forward or a torch elementwise kernel as the victim: 0.
+// That is what the wrong filter gradients of two concurrently replayed scans were (tools/probes/fused_b3_stress.py): THIS kernel's
+// results followed its input exactly (transposed fragments re-read element by element in a -DLN_TR_CHECK build: no mismatch) — the
+// gradient rows the OTHER scan's slice backward had just reduced were off.  The mechanism is not known: synthetic pairs (transpose
+// reads + 16-byte LDS writes + bf16 MFMAs beside six in-flight ds_bpermute_b32, tools/probes/tr_vs_bpermute_probe.cpp; LDS
+// isolation of > 64 KB workgroups, lds_coresidency_probe.cpp; the transpose read beside foreign LDS traffic, tr_read_stress.cpp)
+// all come back clean.  So the rule is empirical: this kernel must own its CU.  T = 3 fills LDS to 147 KB and, through the
+// register claim below, the VGPR file to 504 of 512 per SIMD, so no other wave can be placed there;
+// tests/test_gpu_parity.py::test_other_streams_unharmed_beside_fused_backward guards it.  LN_DEBUG_MASK & 131072 launches the
+// T = 1 / 2 forms for further investigation.
 // ------------------------------------------------------------------------------------------
 typedef short short4v __attribute__((ext_vector_type(4)));
+#ifdef LN_TR_CHECK  // investigation build (tools/probes/fused_b3_stress.py): transposed fragments re-read element by element
+__device__ int ln_dbg[4 + 16 * 8];
+extern "C" int ln_debug_dump(int* host, int n) {
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(ln_dbg), n * sizeof(int)) != hipSuccess) return 1;
+    static int zeros[4 + 16 * 8];
+    return hipMemcpyToSymbol(HIP_SYMBOL(ln_dbg), zeros, sizeof zeros) != hipSuccess;
+}
+#endif
 template <int T>
 __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(T, T)))
     k_conv_backward_fused_b3(const int* __restrict__ nbr, const float* __restrict__ values, const float* __restrict__ grad_out,
@@ -1153,6 +1168,9 @@ __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(T,
     const int m0 = sub0 + wave * 16;
     const int my_row = m0 + i;
 
+    // T = 3: claim the whole register file of the CU (3 waves x 168 of 512 VGPRs per SIMD; the kernel itself needs 153 -> 160), so
+    // that no wave of another kernel can be placed beside this workgroup — see the note on co-residency above the kernel
+    if constexpr (T == 3) asm volatile("" ::: "v167");
     constexpr int N4 = E * V * F / 4;
     constexpr int NST = (N4 + THREADS - 1) / THREADS;
     float4 wv[NST];
@@ -1243,6 +1261,12 @@ __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(T,
             *reinterpret_cast<u32x4*>(dst + 2 * PART) = p3;
         }
         __syncthreads();
+#ifdef LN_TR_CHECK
+        {
+            const u32x4 rb = *reinterpret_cast<volatile u32x4*>(sg + (wave * 16 + i) * RS + q * KQ);
+            if (rb[0] != p1[0] || rb[1] != p1[1] || rb[2] != p1[2] || rb[3] != p1[3]) atomicAdd(&ln_dbg[1], 1);
+        }
+#endif
         const bf16x8 a1 = __builtin_bit_cast(bf16x8, p1), a2 = __builtin_bit_cast(bf16x8, p2), a3 = __builtin_bit_cast(bf16x8, p3);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -1272,6 +1296,31 @@ __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(T,
                 packed[2] = (unsigned int)(unsigned short)hi4[0] | ((unsigned int)(unsigned short)hi4[1] << 16);
                 packed[3] = (unsigned int)(unsigned short)hi4[2] | ((unsigned int)(unsigned short)hi4[3] << 16);
                 b[part] = __builtin_bit_cast(bf16x8, packed);
+#ifdef LN_TR_CHECK
+                {
+                    unsigned int badm = 0, ex2 = 0, got2 = 0;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const unsigned int ex = *(volatile unsigned short*)(sg + part * PART + (32 * st + 8 * q + j) * RS + ft * 16 + i);
+                        const unsigned int got = (packed[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+                        if (ex != got) { badm |= 1u << j; ex2 = ex; got2 = got; }
+                    }
+                    if (badm) {
+                        const int slot = atomicAdd(&ln_dbg[0], 1);
+                        if (slot < 16) {
+                            int* r = ln_dbg + 4 + slot * 8;
+                            r[0] = blockIdx.x;
+                            r[1] = lane | wave << 8 | k << 16 | part << 24 | st << 28;
+                            r[2] = (int)badm;
+                            r[3] = (int)__builtin_amdgcn_s_getreg((31 << 11) | 6);   // HW_REG_LDS_ALLOC
+                            r[4] = (int)__builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_REG_HW_ID
+                            r[5] = (int)__builtin_amdgcn_s_getreg((3 << 11) | 20);   // XCC id
+                            r[6] = (int)(ex2 | got2 << 16);
+                            r[7] = (int)(size_t)(sg - reinterpret_cast<unsigned short*>(s_raw));
+                        }
+                    }
+                }
+#endif
             }
             const bf16x8 v1 = __builtin_bit_cast(bf16x8, va[st][0]), v2 = __builtin_bit_cast(bf16x8, va[st][1]), v3 = __builtin_bit_cast(bf16x8, va[st][2]);
             floatx4& acc = st ? w1 : w0;

@@ -387,6 +387,46 @@ def test_conv_backward_fused_same_lattice(n_points, subtiles):
     assert np.all(np.abs(N(vals.grad) - ref_gv) <= 4 * RTOL * np.maximum(bound_gv, 1e-30))
 
 
+@pytest.mark.parametrize("n_points", [5000, 12000, 45000])
+def test_other_streams_unharmed_beside_fused_backward(n_points):
+    """Two streams: one loops the fused convolution backward, the other the segment reduce of a slice backward on fixed inputs.
+    Every result of the reduce must equal its first one.  (The one- / two-sub-tile bf16x3 forms of the fused backward left room
+    on their CUs for waves of other kernels, and a segment reduce running there came back with wrong rows in 96 % of the
+    iterations — tools/probes/pair_probe.py; the launched forms must not do that at any lattice size.)"""
+    from lattice_net_amd import SplatLattice
+    from lattice_net_amd.synthetic import cube_cloud
+    v = 32
+    rng = np.random.default_rng(n_points)
+    W = T((rng.standard_normal((9 * v, v)) / 17).astype(np.float32))
+    scans = []
+    for seed in (1, 2):
+        lat = make_lattice(0.05, 400000)
+        pos = T(cube_cloud(n_points, seed))
+        _, _, idx, w = SplatLattice.apply(lat, pos, torch.randn((n_points, v), device=dev()))
+        m = lat.nr_lattice_vertices()
+        lat.neighbours(lat, 1, False)
+        scans.append(dict(lat=lat, idx=idx, w=w, m=m, G=torch.randn((m, v), device=dev()), P=torch.randn((n_points, v), device=dev())))
+    A, B = scans
+
+    def reduce():
+        gv = torch.zeros((B["m"], v), device=dev())
+        B["lat"]._scatter_rows(B["P"], B["idx"], B["w"], gv, v, 4, v)
+        return gv
+
+    ref = reduce().clone()
+    scale = float(ref.abs().max())
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    bad = torch.zeros((), device=dev(), dtype=torch.int64)
+    for _ in range(150):
+        with torch.cuda.stream(sa):
+            A["lat"].convolve_im2row_backward(A["G"], W, 1, None, None)
+        with torch.cuda.stream(sb):
+            bad += ((reduce() - ref).abs().max() / scale > 1e-4).long()
+    torch.cuda.synchronize()
+    assert int(bad) == 0
+
+
 @pytest.mark.parametrize("v,f", [(32, 32), (96, 64), (128, 128), (48, 96)])
 def test_conv_autograd_matches_dense_reference(v, f):
     """ConvIm2RowLattice fwd+bwd against autograd through the explicit im2row matrix (fp64)."""
