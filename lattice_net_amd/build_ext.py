@@ -29,8 +29,14 @@ def abi_hash() -> str:
     with open(ABI_HEADER, "rb") as f:
         return hashlib.sha256(f.read()).hexdigest()[:16]
 # -ffp-contract=off: lattice keys and barycentric weights must be bit-identical to the oracle
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"),
-         "-I" + CSRC]
+# -target-feature -packed-fp32-ops: no v_pk_{fma,mul,add}_f32 / v_pk_mov_b32 in the device code.  Measured on MI355X
+# (tools/probes/pk_fma_vs_mfma_probe.cpp): a packed fp32 instruction whose LOW result takes a source from the HIGH
+# half of a register pair (op_sel:[0,1,0], what the compiler emits to broadcast a weight) returns a wrong low result while a wave of
+# ANOTHER kernel on the same SIMD executes v_mfma_f32_16x16x32_{bf16,f16} — e.g. a segment reduce on one stream beside a bf16x3
+# convolution on another.  The kernels here are bound by memory and latency, not by the fp32 vector rate, so nothing is lost.
+# (The host half of the compilation prints "not a recognized feature for this target (ignoring feature)".)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Xclang", "-target-feature", "-Xclang",
+         "-packed-fp32-ops", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
 
 def _hipcc() -> str:
@@ -57,6 +63,9 @@ def build(force: bool = False, verbose: bool = False, variant: str = "", extra_f
     jobs = []
     objs = []
     flags = FLAGS + ['-DLN_ABI_HASH="%s"' % abi_hash()] + list(extra_flags)
+    stamp = os.path.join(obj_dir, "flags.txt")  # objects compiled with other flags are stale whatever their age
+    if not os.path.exists(stamp) or open(stamp).read() != " ".join(flags):
+        force = True
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(obj_dir, s.replace(".hip", ".o"))
@@ -73,6 +82,8 @@ def build(force: bool = False, verbose: bool = False, variant: str = "", extra_f
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
+    with open(stamp, "w") as f:
+        f.write(" ".join(flags))
     if force or jobs or _stale(out, objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
     return out

@@ -387,12 +387,13 @@ def test_conv_backward_fused_same_lattice(n_points, subtiles):
     assert np.all(np.abs(N(vals.grad) - ref_gv) <= 4 * RTOL * np.maximum(bound_gv, 1e-30))
 
 
-@pytest.mark.parametrize("n_points", [5000, 12000, 45000])
-def test_other_streams_unharmed_beside_fused_backward(n_points):
+@pytest.mark.parametrize("n_points,aggressor", [(5000, "fused"), (12000, "fused"), (45000, "fused"), (12000, "per-slot bf16x3")])
+def test_other_streams_unharmed_beside_fused_backward(n_points, aggressor):
     """Two streams: one loops the fused convolution backward, the other the segment reduce of a slice backward on fixed inputs.
     Every result of the reduce must equal its first one.  (The one- / two-sub-tile bf16x3 forms of the fused backward left room
     on their CUs for waves of other kernels, and a segment reduce running there came back with wrong rows in 96 % of the
-    iterations — tools/probes/pair_probe.py; the launched forms must not do that at any lattice size.)"""
+    iterations, as it did beside the per-slot bf16x3 convolution — tools/probes/pair_probe.py, DESIGN.md §4.4: packed fp32
+    instructions of the reduce beside K = 32 matrix instructions; the library is compiled without them now.)"""
     from lattice_net_amd import SplatLattice
     from lattice_net_amd.synthetic import cube_cloud
     v = 32
@@ -407,6 +408,10 @@ def test_other_streams_unharmed_beside_fused_backward(n_points):
         lat.neighbours(lat, 1, False)
         scans.append(dict(lat=lat, idx=idx, w=w, m=m, G=torch.randn((m, v), device=dev()), P=torch.randn((n_points, v), device=dev())))
     A, B = scans
+    if aggressor != "fused":
+        W64 = T((rng.standard_normal((9 * 64, 64)) / 24).astype(np.float32))
+        A["lat"].set_values(torch.randn((A["m"], 64), device=dev()))
+        assert A["m"] >= 4096  # the bf16x3 gate of the per-slot kernel
 
     def reduce():
         gv = torch.zeros((B["m"], v), device=dev())
@@ -420,7 +425,10 @@ def test_other_streams_unharmed_beside_fused_backward(n_points):
     bad = torch.zeros((), device=dev(), dtype=torch.int64)
     for _ in range(150):
         with torch.cuda.stream(sa):
-            A["lat"].convolve_im2row_backward(A["G"], W, 1, None, None)
+            if aggressor == "fused":
+                A["lat"].convolve_im2row_backward(A["G"], W, 1, None, None)
+            else:
+                A["lat"].convolve_im2row_standalone(W64, 1, A["lat"], False)
         with torch.cuda.stream(sb):
             bad += ((reduce() - ref).abs().max() / scale > 1e-4).long()
     torch.cuda.synchronize()

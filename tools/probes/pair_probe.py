@@ -32,8 +32,18 @@ sA, sB = torch.cuda.Stream(), torch.cuda.Stream()
 torch.cuda.synchronize()
 
 
+import os
+KIND = os.environ.get("PAIR_AGGRESSOR", "fused")  # fused: the fused backward; perslot: the per-slot bf16x3 convolution (V = F = 64)
+if KIND == "perslot":
+    W64 = torch.from_numpy((rng.standard_normal((9 * 64, 64)) / 24).astype(np.float32)).to(dev)
+    A["lat"].set_values(torch.randn((A["m"], 64), device=dev))
+
+
 def aggressor():
-    A["lat"].convolve_im2row_backward(A["G"], W, 1, None, None)
+    if KIND == "perslot":
+        A["lat"].convolve_im2row_standalone(W64, 1, A["lat"], False)
+    else:
+        A["lat"].convolve_im2row_backward(A["G"], W, 1, None, None)
 
 
 def victim_reduce():
