@@ -119,3 +119,64 @@ def test_lnn_training_step_as_one_graph(tmp_path):
         worst = max(worst, float((q.grad - grads_a[k]).abs().max()) / max(float(grads_a[k].abs().max()), 1e-12))
     assert worst <= 1e-2, worst
 
+
+
+def test_lnn_training_loop_of_replays_with_captured_optimizer(tmp_path):
+    """The AdamW step captured behind the backward pass (CapturedNetworkStep(optimizer=...), capturable=True): 30 replays = 30
+    training steps, loss trajectory equal to 30 eager steps from the same initial parameters.  (Loops that alternate replays with
+    EAGER optimizer kernels aborted 25-75 % of 65-step runs on this stack; loops of replays only: 0 of 10 runs of 200 steps —
+    DESIGN.md 4.7.)  Child process, as above."""
+    import copy
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("LNN_GRAPH_TEST_CHILD") != "1":
+        env = dict(os.environ, LNN_GRAPH_TEST_CHILD="1")
+        r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-k", "test_lnn_training_loop_of_replays_with_captured_optimizer",
+                            "-p", "no:cacheprovider"],
+                           env=env, capture_output=True, text=True, timeout=600, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+        return
+    from lattice_net_amd import CapturedNetworkStep
+    from lattice_net_amd.losses import nll_loss_gather
+    torch.autograd.set_multithreading_enabled(False)
+    net, lattice, pos, vals, target = _setup(tmp_path)
+
+    def step():
+        logsoftmax, _ = net(lattice, pos, vals)
+        loss = nll_loss_gather(logsoftmax, target)
+        loss.backward()
+        return loss.detach()
+
+    for q in net.parameters():
+        q.grad = None
+    step()  # the PointNet parameters exist after the first forward
+    start = copy.deepcopy(net.state_dict())
+    steps = 30
+    # eager trajectory
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-3, weight_decay=1e-4)
+    eager = []
+    for _ in range(steps):
+        opt.zero_grad(set_to_none=True)
+        eager.append(float(step()))
+        opt.step()
+    # captured trajectory from the same start (the capture's three warm-up iterations move the parameters: reset after it)
+    net.load_state_dict(start)
+    opt_g = torch.optim.AdamW(net.parameters(), lr=1e-3, weight_decay=1e-4, capturable=True)
+    cap = CapturedNetworkStep(step, lattice, net.parameters(), optimizer=opt_g)
+    with torch.no_grad():
+        net.load_state_dict(start)
+        for group in opt_g.param_groups:
+            for q in group["params"]:
+                st = opt_g.state[q]
+                st["step"].zero_()
+                st["exp_avg"].zero_()
+                st["exp_avg_sq"].zero_()
+    captured = []
+    for _ in range(steps):
+        captured.append(cap.launch().clone())
+    torch.cuda.synchronize()
+    captured = [float(c) for c in captured]
+    assert eager[-1] < eager[0]  # it trains
+    for a, b in zip(eager, captured):
+        assert abs(a - b) <= 2e-3 * abs(a), (eager, captured)

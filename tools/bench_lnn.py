@@ -65,7 +65,12 @@ def make_graph_step(args, preset, cfg_text, net, opt, gen, dev, nll_loss_gather,
 
         for p in params:
             p.grad = None
-        cap = CapturedNetworkStep(one, lat, params, stream=torch.cuda.Stream() if K > 1 else None)
+        graph_opt = None
+        if args.graph_optimizer:  # optimizer step inside the graph: the training loop is nothing but replays
+            if K > 1:
+                raise SystemExit("--graph-optimizer captures one scan per optimizer step (--in-flight 1)")
+            graph_opt = torch.optim.AdamW(params, lr=1e-3, weight_decay=1e-4, amsgrad=True, fused=True, capturable=True)
+        cap = CapturedNetworkStep(one, lat, params, stream=torch.cuda.Stream() if K > 1 else None, optimizer=graph_opt)
         scans.append(cap)
         if os.environ.get("LNN_DEBUG"):
             torch.cuda.synchronize()
@@ -90,12 +95,24 @@ def make_graph_step(args, preset, cfg_text, net, opt, gen, dev, nll_loss_gather,
     state = {}
     pending = []  # the host stays at most two optimizer steps ahead of the GPU (fewer aborts than without: DESIGN.md 4.7)
 
+    if args.graph_optimizer:
+        return lambda: scans[0].launch()
+
     def step():
         if len(pending) >= 2:
             pending.pop(0).synchronize()
         state["n"] = state.get("n", 0) + 1
         if K > 1 and state["n"] % int(os.environ.get("LNN_SYNC_EVERY", "8")) == 0:
             torch.cuda.synchronize()  # several streams of replays: a device-level wait every few steps (CapturedNetworkStep.launch)
+        if K == 1 and not os.environ.get("LNN_CROSS_STREAM"):  # the eager optimizer kernels on the capture stream itself: no event joins
+            with torch.cuda.stream(scans[0].stream):
+                loss = scans[0].launch()
+                scans[0].bind_gradients()
+                opt.step()
+                ev = torch.cuda.Event()
+                ev.record()
+            pending.append(ev)
+            return loss
         if K == 1:
             loss = scans[0].launch()
         else:
@@ -123,6 +140,7 @@ def main():
     ap.add_argument("--infer", action="store_true", help="forward only, under torch.no_grad()")
     ap.add_argument("--graph", action="store_true", help="forward + loss + backward of a scan as ONE hipGraph replay (CapturedNetworkStep); "
                                                          "the optimizer step stays outside the graph")
+    ap.add_argument("--graph-optimizer", action="store_true", help="with --graph: capture the AdamW step (capturable=True) behind the backward pass")
     ap.add_argument("--in-flight", type=int, default=1, help="with --graph: scans per optimizer step, each with its own lattice, graph and "
                                                              "stream, replayed concurrently; their gradients are summed (batch of K scans)")
     ap.add_argument("--host-profile", action="store_true", help="cProfile of the host side of the timed steps")
@@ -200,7 +218,7 @@ def main():
         pstats.Stats(pr).sort_stats("tottime").print_stats(35)
     nparams = sum(p.numel() for p in net.parameters())
     scans = max(1, args.in_flight) if args.graph else 1
-    mode = (f"train step, graph x{scans} in flight" if args.graph else "train step") if not args.infer else "forward"
+    mode = (f"train step, graph x{scans} in flight" + (" incl. AdamW" if args.graph_optimizer else "") if args.graph else "train step") if not args.infer else "forward"
     print(f"LNN[{args.config}] {mode}: {dt * 1e3 / scans:.2f} ms per scan  ({args.n * scans / dt / 1e6:.2f} Mpoints/s), {nparams} parameters, loss {loss.item():.4f}")
 
 

@@ -104,6 +104,13 @@ def main():
             return loss.detach()
 
         cap = CapturedNetworkStep(one, lattice, list(net.parameters()), row_slack=0.10)
+    import contextlib
+    loop_stream = contextlib.ExitStack()
+    if cap is not None:
+        # the whole loop on the capture stream: eager kernels (input copies, all-reduce hand-off, AdamW) queue behind the replay
+        # without cross-stream event joins (CapturedNetworkStep.launch)
+        torch.cuda.synchronize()
+        loop_stream.enter_context(torch.cuda.stream(cap.stream))
     for step in range(args.steps):
         if step == 2:
             # Python's cycle collector costs ~4 ms per step here: its full passes walk every live module / torch object.  The
