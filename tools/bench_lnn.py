@@ -113,6 +113,14 @@ def make_graph_step(args, preset, cfg_text, net, opt, gen, dev, nll_loss_gather,
                 ev.record()
             pending.append(ev)
             return loss
+        if K > 1 and os.environ.get("LNN_HOST_JOIN"):  # experiment: host-side joins only (no events between the streams)
+            torch.cuda.synchronize()
+            for cap in scans:
+                loss = cap.launch()
+            torch.cuda.synchronize()
+            CapturedNetworkStep.sum_gradients(scans)
+            opt.step()
+            return loss
         if K == 1:
             loss = scans[0].launch()
         else:
