@@ -9,6 +9,8 @@ scalar per class back to the host.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 __all__ = ["GeneralizedSoftDiceLoss", "LovaszSoftmax", "Scores", "nll_loss_gather"]
@@ -69,9 +71,9 @@ class LovaszSoftmax(torch.nn.Module):
         # column-wise ones on an [N, C] matrix
         onehot = onehot.t().contiguous()
         errors = (onehot - probs.t()).abs()
-        if errors.is_cuda and torch.cuda.is_current_stream_capturing():
-            # torch.sort of a [C, N] matrix (or of one long vector) is not replay-safe on this stack beyond ~10^5 elements per
-            # call (PyTorch 2.10 / ROCm 7: the second replay of the captured sort faults); one sort per class row is
+        if errors.is_cuda and torch.cuda.is_current_stream_capturing() and os.environ.get("LN_LOVASZ_ROW_SORT"):
+            # (kept as a switch: for a while the captured [C, N] sort looked unsafe to replay — the faults were those of training loops
+            # that joined replays and eager kernels across streams; on the capture stream the matrix sort replays fine)
             parts = [torch.sort(errors[k], descending=True) for k in range(c)]
             errors_sorted = torch.stack([p[0] for p in parts])
             order = torch.stack([p[1] for p in parts])
