@@ -483,6 +483,49 @@ def main():
                   "splat_plus_slice": {"us": round(ss_us, 1), "algorithmic_bytes": int(splat_bytes + slice_bytes),
                                        "achieved_GBs": round((splat_bytes + slice_bytes) / ss_us / 1e3, 1),
                                        "frac_of_hbm_peak": round((splat_bytes + slice_bytes) / ss_us / 1e3 / HBM_PEAK_GBS, 4)}}
+        if args.mode == "graph" and not half:
+            # the same two stages in the benchmark's execution mode: splat -> slice (forward) captured per scan, scans in flight
+            try:
+                from lattice_net_amd.capture import CapturedStep
+                chains = []
+                for k in range(in_flight):
+                    c = {"lat": L.Lattice(sigmas=[sigma] * d, capacity=cap, device=dev), "st": {}, "pos": sets[k].pos, "vals": sets[k].vals}
+
+                    def chain(c=c):
+                        with torch.no_grad():
+                            lv2, _, idx2, w2 = L.SplatLattice.apply(c["lat"], c["pos"], c["vals"])
+                            m2 = c["lat"].nr_lattice_vertices()
+                            c["st"].update(idx=idx2, out=L.SliceLattice.apply(lv2[:m2], c["lat"], c["pos"], idx2, w2))
+
+                    chain()
+                    torch.cuda.synchronize()
+                    ref2 = c["st"]["out"].detach().clone()
+                    c["cap"] = CapturedStep(chain, [c["lat"]], row_slack=args.row_slack, regions=bool(args.regions),
+                                            region_indices=lambda c=c: c["st"]["idx"], stream=torch.cuda.Stream(), before_capture=c["st"].clear)
+                    c["cap"].launch()
+                    torch.cuda.synchronize()
+                    err2 = float((c["st"]["out"] - ref2).abs().max()) / max(float(ref2.abs().max()), 1e-30)
+                    if err2 > 1e-5:
+                        raise RuntimeError(f"replayed splat -> slice differs from the eager one: {err2}")
+                    chains.append(c)
+                reps2 = 600
+                for i in range(30):
+                    chains[i % in_flight]["cap"].launch()
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                for i in range(reps2):
+                    chains[i % in_flight]["cap"].launch()
+                torch.cuda.synchronize()
+                us2 = (time.perf_counter() - t2) / reps2 * 1e6
+                for c in chains:
+                    c["cap"].check()
+                stages["splat_plus_slice_in_flight"] = {
+                    "what": f"splat -> slice (forward) as one hipGraph per scan, {in_flight} scans in flight, {reps2} scans timed",
+                    "us_per_scan": round(us2, 1), "algorithmic_bytes": int(splat_bytes + slice_bytes),
+                    "achieved_GBs": round((splat_bytes + slice_bytes) / us2 / 1e3, 1),
+                    "frac_of_hbm_peak": round((splat_bytes + slice_bytes) / us2 / 1e3 / HBM_PEAK_GBS, 4)}
+            except Exception as ex:  # secondary figure: never endangers the bench line
+                stages["splat_plus_slice_in_flight"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
 
     line = None
     if rank == 0:
