@@ -311,7 +311,7 @@ def test_conv_forward_and_filter_gradient(v, f):
     close(N(gf), ref, scale=scale)
 
 
-@pytest.mark.parametrize("v,f", [(32, 32), (64, 32), (96, 96), (128, 64), (128, 128), (32, 80)])
+@pytest.mark.parametrize("v,f", [(32, 32), (64, 32), (96, 96), (128, 64), (128, 128), (32, 80), (64, 64), (64, 192)])
 def test_conv_large_lattice_split_bf16_path(v, f):
     """Lattices of >= 16384 vertices with a channel count that is a multiple of 32 take the per-slot kernel on the bf16 matrix
     cores with exactly 3-way split operands (ln_conv.hip: k_conv_mfma_b3); same 1e-5 bar against fp64 as the fp32-MFMA kernel,
@@ -343,7 +343,10 @@ def test_conv_large_lattice_split_bf16_path(v, f):
     out, _ = ConvIm2RowLattice.apply(vals, lat, W, 1)
     (out * T(G_np)).sum().backward()
     ref_gw = rows.T @ G_np.astype(np.float64)
-    close(N(W.grad), ref_gw, scale=float(np.max(np.abs(rows).T @ np.abs(G_np.astype(np.float64)))))
+    bound_gw = np.abs(rows).T @ np.abs(G_np.astype(np.float64))
+    close(N(W.grad), ref_gw, scale=float(np.max(bound_gw)))
+    # per element as well: both dimensions multiples of 64 take the bf16x3 filter-gradient kernel (k_grad_filter_mfma_b3)
+    assert np.all(np.abs(N(W.grad).astype(np.float64) - ref_gw) <= RTOL * np.maximum(bound_gw, 1e-30))
     # value gradient = row2im of G W^T: check through the adjoint identity <conv(x), G> = <x, grad_x> for a second x
     x2 = rng.standard_normal((m, v)).astype(np.float32)
     lat.set_values(T(x2))
