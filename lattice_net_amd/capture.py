@@ -102,7 +102,8 @@ class CapturedNetworkStep:
          its level's bound as height, the GroupNorm kernels read the real count from the lattice's device counter
          (Lattice.rows_device()), rows beyond it stay isolated (no neighbour, no splat index, zero gradient);
       3. warm-up on a side stream, capture, `launch()` = one replay.  Parameter gradients live in the graph's memory pool:
-         after a replay `p.grad` holds that step's gradients, the optimizer runs outside the graph.
+         after a replay `p.grad` holds that step's gradients; the optimizer runs outside the graph, or inside with `optimizer=`.
+         Training loop: `with torch.cuda.stream(cap.stream): for ...: cap.launch(); optimizer.step()` (see launch()).
 
     `step` must read its inputs (positions, values, targets) from tensors that stay alive — overwrite them in place to feed another
     cloud of the same size — set `p.grad = None` itself is NOT needed (done here), and must not synchronise."""
@@ -138,7 +139,7 @@ class CapturedNetworkStep:
         # The graph is ALWAYS replayed on the stream it was captured on (launch() joins it with the caller's stream): replaying on
         # another stream — legal, and what CapturedStep does for its ten-node graphs — aborted 4 of 10 forty-step training runs of
         # tools/probes/graph_training_flake.py when eager optimizer steps ran between the replays; on the capture stream 0 of 30.
-        # (Training loops over replays remain experimental on this stack: DESIGN.md 4.7, "State of the mode".)
+        # What makes training loops solid is to run the WHOLE loop on that stream (see launch()): DESIGN.md 4.7, "State of the mode".
         side = stream if stream is not None else torch.cuda.Stream()
         self.own_stream = stream is None
         self.stream = side
