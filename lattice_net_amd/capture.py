@@ -166,12 +166,11 @@ class CapturedNetworkStep:
         the caller orders the streams itself (several scans in flight).  RUN TRAINING LOOPS ON THE CAPTURE STREAM
         (`with torch.cuda.stream(cap.stream): ...`): then the eager kernels between two replays (optimizer, input copies) are
         simply queued behind the graph and no cross-stream event joins exist — loops with such joins aborted 25-75 % of 65-step
-        runs on this stack (HSA queue exception), loops on one stream 0 of 18 runs of 100-300 steps, and a step is 0.4 ms shorter.  Two guards against a host that runs ahead: at most two replays of this graph are queued
-        behind the running one (event wait), and every 8th launch waits for the launch stream itself — a whole-network replay is
-        hundreds to thousands of graph nodes, and on this stack (ROCm 7.2) the runtime only recycles the per-node launch resources
-        of a stream when the host synchronises with it: without any stream-level wait the process aborted with an HSA queue
-        exception after ~10^5 nodes (a ScanNet-shaped step after ~25 replays, the SemanticKITTI one after ~250), whatever the
-        event waits in between."""
+        runs on this stack (HSA queue exception), loops on one stream 0 of 18 runs of 100-300 steps, and a step is 0.4 ms shorter.  Two bounds on a host that runs ahead: at most two replays of this graph are queued
+        behind the running one (event wait), and every 8th launch waits for the launch stream (`LN_GRAPH_SYNC_EVERY`).  (The second
+        one dates from the cross-stream loops, whose aborts after ~10^5 graph nodes looked like launch resources that are only
+        recycled by a stream-level wait; on the capture stream 4000 SemanticKITTI-shaped and 600 ScanNet-shaped steps — 2 M and 1.5 M
+        nodes — run without any such wait.  It costs nothing measurable and stays.)"""
         pending = self.__dict__.setdefault("_pending", [])
         if len(pending) >= 2:
             pending.pop(0).synchronize()
