@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Do several LARGE hipGraphs replaying concurrently on their own streams survive hundreds of rounds on this stack?  Pure PyTorch
 (an MLP with many small layers, forward + backward = ~600 graph nodes), no lattice kernels.  (GPU box.)"""
+import os
 import sys
 import torch
+HOST_JOIN = bool(os.environ.get("PROBE_HOST_JOIN"))  # device-level waits instead of event joins between the streams
 
 torch.autograd.set_multithreading_enabled(False)
 dev = torch.device("cuda", 0)
@@ -38,12 +40,18 @@ for k in range(K):
 main = torch.cuda.current_stream()
 bufs = [torch.empty_like(p) for p in params]
 for it in range(ROUNDS):
+    if HOST_JOIN:
+        torch.cuda.synchronize()
     for g, s, _, _ in caps:
-        s.wait_stream(main)
+        if not HOST_JOIN:
+            s.wait_stream(main)
         with torch.cuda.stream(s):
             g.replay()
-    for g, s, _, _ in caps:
-        main.wait_stream(s)
+    if HOST_JOIN:
+        torch.cuda.synchronize()
+    else:
+        for g, s, _, _ in caps:
+            main.wait_stream(s)
     torch._foreach_copy_(bufs, caps[0][3])
     for c in caps[1:]:
         torch._foreach_add_(bufs, c[3])
