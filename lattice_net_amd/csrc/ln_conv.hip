@@ -610,11 +610,126 @@ static bool ln_conv_launch_v(int nr_filters, const int* nbr, const float* values
     return true;
 }
 
+// ------------------------------------------------------------------------------------------
+// Forward of the V = F = 32, E = 9 convolution on the bf16 matrix cores with exactly 3-way split operands, in the workgroup shape of
+// the fused backward (T sub-tiles of 64 vertices per workgroup, one workgroup per CU and round: the bank is split and staged once per
+// 64 * T vertices instead of once per 64).  out[row][f] = sum_e sum_v values[nbr[row][e]][v] * W[e][v][f]:
+//   A = this lane's gathered quarter row (channels 8q..8q+7 = its k-group), split in registers;
+//   B = W_e split while the bank is staged: one 16-byte fragment per (slot, column tile, part, lane (f, q)) = W[e][8q..8q+7][f].
+// After the one barrier behind the staging the slot loop is gathers, register splits and 12 matrix instructions per slot and wave.
+// ------------------------------------------------------------------------------------------
+template <int T>
+__global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(T, T)))
+    k_conv_forward_b3(const int* __restrict__ nbr, const float* __restrict__ values, const float* __restrict__ filter, int m,
+                      float* __restrict__ out) {
+    constexpr int V = 32, F = 32, E = 9, KQ = 8, NT = 2;
+    constexpr int THREADS = 256 * T;
+    constexpr int FRAG16 = E * NT * 3 * 64;  // 16-byte fragments of the split bank (54 KB)
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[FRAG16 * 16];
+    const u32x4* s_frag = reinterpret_cast<const u32x4*>(s_raw);
+    unsigned short* s_fh = reinterpret_cast<unsigned short*>(s_raw);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int i = lane & 15;
+    const int q = lane >> 4;
+    const int m0 = blockIdx.x * (64 * T) + (tid >> 6) * 16;
+    const int my_row = m0 + i;
+    constexpr int N4 = E * V * F / 4;
+    constexpr int NST = (N4 + THREADS - 1) / THREADS;
+    float4 wv[NST];
+#pragma unroll
+    for (int s = 0; s < NST; ++s) {
+        const int x4 = tid + s * THREADS;
+        wv[s] = (x4 < N4) ? reinterpret_cast<const float4*>(filter)[x4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    int nb[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) nb[e] = (my_row < m) ? nbr[(size_t)my_row * E + e] : -1;
+    constexpr int DEPTH = 4;
+    float a[DEPTH][KQ];
+#pragma unroll
+    for (int k = 0; k < DEPTH - 1; ++k) ln_load_quarter<KQ>(values + (size_t)(nb[k] >= 0 ? nb[k] : 0) * V + q * KQ, a[k]);
+    // bank -> split -> LDS fragments: x = (e*V + v)*F + f; the four consecutive f of one float4 belong to four lanes' fragments
+#pragma unroll
+    for (int s = 0; s < NST; ++s) {
+        const int x4 = tid + s * THREADS;
+        if (x4 < N4) {
+            const int x = x4 * 4;
+            const int ev = x / F;
+            const int f0 = x - ev * F;
+            const int e = ev / V;
+            const int v = ev - e * V;
+            const float v4[4] = {wv[s].x, wv[s].y, wv[s].z, wv[s].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                unsigned int h, md, lo;
+                ln_split3_bits(v4[j], h, md, lo);
+                const int f = f0 + j;
+                const int fr = (((e * NT + (f >> 4)) * 3) * 64 + (v >> 3) * 16 + (f & 15)) * 8 + (v & 7);
+                s_fh[fr] = (unsigned short)(h >> 16);
+                s_fh[fr + 64 * 8] = (unsigned short)(md >> 16);
+                s_fh[fr + 2 * 64 * 8] = (unsigned short)(lo >> 16);
+            }
+        }
+    }
+    floatx4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = floatx4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        float (&ae)[KQ] = a[e % DEPTH];
+        if (e + DEPTH - 1 < E)
+            ln_load_quarter<KQ>(values + (size_t)(nb[e + DEPTH - 1] >= 0 ? nb[e + DEPTH - 1] : 0) * V + q * KQ, a[(e + DEPTH - 1) % DEPTH]);
+        u32x4 p1, p2, p3;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned int h0, m0_, l0, h1, m1_, l1;
+            ln_split3_bits(nb[e] >= 0 ? ae[2 * j] : 0.f, h0, m0_, l0);
+            ln_split3_bits(nb[e] >= 0 ? ae[2 * j + 1] : 0.f, h1, m1_, l1);
+            p1[j] = (h0 >> 16) | h1;
+            p2[j] = (m0_ >> 16) | m1_;
+            p3[j] = (l0 >> 16) | l1;
+        }
+        const bf16x8 a1 = __builtin_bit_cast(bf16x8, p1), a2 = __builtin_bit_cast(bf16x8, p2), a3 = __builtin_bit_cast(bf16x8, p3);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const u32x4* pb = s_frag + ((e * NT + nt) * 3) * 64 + lane;
+            const bf16x8 b1 = __builtin_bit_cast(bf16x8, pb[0]), b2 = __builtin_bit_cast(bf16x8, pb[64]), b3 = __builtin_bit_cast(bf16x8, pb[128]);
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, b1, acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b3, acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b2, acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b1, acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b2, acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, acc[nt], 0, 0, 0);
+        }
+    }
+    // C/D layout: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + q * 4 + r;
+            if (row < m) out[(size_t)row * F + nt * 16 + i] = acc[nt][r];
+        }
+}
+
 template <bool FLIP, bool WT>
 static int ln_conv_dispatch(const int* nbr, const float* values_neigh, const float* filter, int m, int filter_extent, int val_dim,
                             int nr_filters, float* out, void* ws, size_t ws_bytes, hipStream_t st) {
     bool done = false;
     if (filter_extent == 9 && (reinterpret_cast<uintptr_t>(filter) & 15) == 0) {  // d = 3 small-filter fast path
+        if constexpr (!FLIP && !WT) {  // V = F = 32 forward on the bf16 matrix cores (LN_DEBUG_MASK & 524288: fp32 form, A/B)
+            if (val_dim == 32 && nr_filters == 32 && m >= LN_CONV_B3_MIN_ROWS && ln_conv_b3_enabled() && !(ln_debug_mask() & 524288) &&
+                (reinterpret_cast<uintptr_t>(values_neigh) & 15) == 0) {
+                const int t = min(ln_bwd_subtiles(m), 3);
+                const dim3 grid_t(ln_div_up(m, 64 * t)), block_t(256 * t);
+                if (t == 1) LN_LAUNCH("k_conv_mfma", (k_conv_forward_b3<1>), grid_t, block_t, 0, st, nbr, values_neigh, filter, m, out);
+                else if (t == 2) LN_LAUNCH("k_conv_mfma", (k_conv_forward_b3<2>), grid_t, block_t, 0, st, nbr, values_neigh, filter, m, out);
+                else LN_LAUNCH("k_conv_mfma", (k_conv_forward_b3<3>), grid_t, block_t, 0, st, nbr, values_neigh, filter, m, out);
+                return ln_check_launch("ln_conv_forward");
+            }
+        }
         const dim3 grid(ln_div_up(m, 64)), block(256);
 #define LN_CONV_FULL(VV, NN)                                                                                                        \
     if (!done && val_dim == VV && nr_filters == 16 * NN) {                                                                          \
