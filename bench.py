@@ -98,7 +98,8 @@ def pmc_traffic(kernel: str):
             with open(path) as f:
                 table = json.load(f)
                 # (the launch name of the ABI's timers covers both forms of the fused backward; the profile lists the kernel symbol)
-                hit = (table.get(kernel) or table.get(kernel + "_b3") or {}).get("traffic_bytes")
+                alias = {"k_conv_mfma": "k_conv_forward_b3"}.get(kernel, kernel + "_b3")  # launch name -> kernel symbol of the C3 step
+                hit = (table.get(kernel) or table.get(alias) or {}).get("traffic_bytes")
             if hit is not None:
                 return hit
         except OSError:
