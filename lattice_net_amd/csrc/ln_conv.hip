@@ -645,10 +645,13 @@ __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(T,
     int nb[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) nb[e] = (my_row < m) ? nbr[(size_t)my_row * E + e] : -1;
-    constexpr int DEPTH = 4;
+#ifndef LN_FWD_DEPTH
+#define LN_FWD_DEPTH 4
+#endif
+    constexpr int DEPTH = LN_FWD_DEPTH;  // ring of gathered quarter rows: DEPTH - 1 gathers in flight (4: 14.9 us, 7: 15.7, 10 = all nine up front: 17.1)
     float a[DEPTH][KQ];
 #pragma unroll
-    for (int k = 0; k < DEPTH - 1; ++k) ln_load_quarter<KQ>(values + (size_t)(nb[k] >= 0 ? nb[k] : 0) * V + q * KQ, a[k]);
+    for (int k = 0; k < DEPTH - 1 && k < E; ++k) ln_load_quarter<KQ>(values + (size_t)(nb[k] >= 0 ? nb[k] : 0) * V + q * KQ, a[k]);
     // bank -> split -> LDS fragments: x = (e*V + v)*F + f; the four consecutive f of one float4 belong to four lanes' fragments
 #pragma unroll
     for (int s = 0; s < NST; ++s) {
