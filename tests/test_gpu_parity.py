@@ -313,9 +313,10 @@ def test_conv_forward_and_filter_gradient(v, f):
 
 @pytest.mark.parametrize("v,f", [(32, 32), (64, 32), (96, 96), (128, 64), (128, 128), (32, 80), (64, 64), (64, 192)])
 def test_conv_large_lattice_split_bf16_path(v, f):
-    """Lattices of >= 16384 vertices with a channel count that is a multiple of 32 take the per-slot kernel on the bf16 matrix
-    cores with exactly 3-way split operands (ln_conv.hip: k_conv_mfma_b3); same 1e-5 bar against fp64 as the fp32-MFMA kernel,
-    forward (both neighbour orders) and value gradient (the flipped, transposed bank)."""
+    """Lattices of >= 4096 vertices with a channel count that is a multiple of 32 take the kernels on the bf16 matrix cores with
+    exactly 3-way split operands (ln_conv.hip: k_conv_mfma_b3 per slot; k_conv_forward_b3 / k_conv_backward_fused_b3 at V = F = 32);
+    same 1e-5 bar against fp64 as the fp32-MFMA kernels, forward (both neighbour orders), filter gradient (per element) and value
+    gradient (the flipped, transposed bank)."""
     from lattice_net_amd import ConvIm2RowLattice
     from lattice_net_amd.synthetic import cube_cloud
     pos = cube_cloud(30000, 11)
