@@ -140,3 +140,15 @@ def test_static_rows_and_region_planes_argument_checks():
         lat.static_build_report()                    # no build has run
     assert [f[0] for f in _lib.LnCsr._fields_] == ["grp_start", "csr_tok", "seg_desc", "seg_count", "seg_region", "planes"]
     assert _lib.LN_XCD_GROUPS == 8
+
+
+def test_captured_network_step_rejects_a_non_capturable_optimizer():
+    """An optimizer whose step() is to be captured behind the backward pass must keep its step count on the device
+    (capturable=True); the constructor says so before anything touches the GPU."""
+    import pytest
+    import torch
+    from lattice_net_amd import CapturedNetworkStep
+    p = torch.nn.Parameter(torch.zeros(3))
+    opt = torch.optim.AdamW([p], lr=1e-3)
+    with pytest.raises(ValueError, match="capturable"):
+        CapturedNetworkStep(lambda: None, None, [p], optimizer=opt)
