@@ -14,8 +14,10 @@
  *   - asynchronous device-side conditions (table full, key out of packable range) are
  *     recorded in LnTable.status and must be read back by the caller (ln_status_string).
  *
- * Vertex numbering is canonical: rows are numbered by first occurrence in
- * (point, remainder) order, i.e. what a serial run of HashTableGPU::insert
+ * Vertex numbering: deterministic.  Builds that start from a cleared table number the vertices in hash-slot
+ * order (the reference's own numbering is thread-arrival order and not reproducible); with
+ * LN_BUILD_CANONICAL_ROWS / ln_canonicalize, and on every incremental build, rows are numbered by first
+ * occurrence in (point, remainder) order, i.e. what a serial run of HashTableGPU::insert
  * (HashTableGPU.cuh:425-484) produces.
  */
 #ifndef LATTICENET_HIP_H
@@ -141,9 +143,20 @@ size_t ln_build_workspace_bytes(long long tokens, int capacity);
 #define LN_BUILD_WRITE_IDX 1
 #define LN_BUILD_CLEAR_FIRST 2
 #define LN_BUILD_ATOMIC_PATH 4
+#define LN_BUILD_CANONICAL_ROWS 8 /* bucketed path: run ln_canonicalize behind the build (the atomic path numbers canonically anyway) */
 int ln_build_splat(const LnTable* t, const float* positions_raw, const float* sigmas_host, int n, int* idx, float* w,
                    int flags, const LnCsr* csr, void* workspace, size_t workspace_bytes, float* clear_values,
                    long long clear_values_elems, void* stream);
+
+/* Vertex numbering.  The reference numbers vertices in thread-arrival order (atomicAdd(m_nr_filled), HashTableGPU.cuh:454) — it
+ * differs from run to run and nothing downstream depends on it.  The bucketed build numbers them in SLOT order (bucket by
+ * bucket, occupied slots in ascending order: deterministic, and the whole build is two launches).  ln_canonicalize relabels
+ * the rows of a table that ONE bucketed build has just produced — entries[], keys[] and, when given, the idx[tokens] that
+ * build wrote — into first-occurrence order over (point, remainder), i.e. the numbering a serial run of
+ * HashTableGPU::insert (HashTableGPU.cuh:425-484) produces and the golden vectors hold.  It must run before anything that
+ * stores row ids elsewhere (accumulated values, neighbour lists).  workspace: ln_build_workspace_bytes(tokens, capacity).
+ * LN_BUILD_CANONICAL_ROWS makes ln_build_splat / ln_distribute do this themselves. */
+int ln_canonicalize(const LnTable* t, int* idx, long long tokens, void* workspace, size_t workspace_bytes, void* stream);
 
 /* splatCacheNaive (LatticeGPU.cuh:926-973): table_values[idx] += vals * w. */
 int ln_splat_accumulate(float* table_values, const float* vals, const int* idx, const float* w, int n, int pos_dim,

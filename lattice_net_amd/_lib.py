@@ -18,6 +18,7 @@ LN_STATUS_BUCKET_OVERFLOW = 4
 LN_BUILD_WRITE_IDX = 1
 LN_BUILD_CLEAR_FIRST = 2
 LN_BUILD_ATOMIC_PATH = 4
+LN_BUILD_CANONICAL_ROWS = 8
 LN_NOT_VISITED = -2
 LN_CONV_FLIP_NEIGHBOURS = 1
 LN_CONV_TRANSPOSED_FILTER = 2
@@ -80,6 +81,7 @@ SIGNATURES = {
     "ln_table_clear": (_i, [_T, _vp, _ll, _vp]),
     "ln_build_workspace_bytes": (_sz, [_ll, _i]),
     "ln_build_splat": (_i, [_T, _vp, _vp, _i, _vp, _vp, _i, _CSR, _vp, _sz, _vp, _ll, _vp]),
+    "ln_canonicalize": (_i, [_T, _vp, _ll, _vp, _sz, _vp]),
     "ln_splat_accumulate": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "ln_csr_workspace_bytes": (_sz, [_ll, _i]),
     "ln_csr_max_segments": (_ll, [_ll, _i]),

@@ -83,7 +83,7 @@ LnProfScope::~LnProfScope() {
     }
 }
 
-extern "C" const char* ln_kernel_names(void) { return "k_bucket_build,k_conv_backward_fused,k_conv_generic,k_conv_generic_f16,k_conv_mfma,k_conv_mfma_f16,k_conv_split_bank,k_conv_sum_partials,k_csr_count,k_csr_fill,k_csr_group_sizes,k_csr_reduce_segments,k_csr_scan_local,k_csr_scan_top,k_csr_segment_max,k_csr_segment_max_decode,k_finalize,k_gather_backward,k_gather_forward,k_gn_apply,k_gn_backward_apply,k_gn_stats,k_grad_filter_f16,k_grad_filter_generic,k_grad_filter_mfma,k_grad_filter_mfma_f16,k_im2row,k_im2rowindices,k_insert_coarse,k_insert_points,k_linear_act_backward_w,k_linear_act_backward_x,k_linear_act_forward,k_linear_reduce_slabs,k_mark_first,k_max_centre_backward,k_max_centre_forward,k_max_centre_sum,k_neighbours,k_point_keys,k_reduce_and_neighbours,k_reduce_slabs,k_reduce_slabs_f32,k_retrieve_points,k_row2im,k_sc_reduce_slabs,k_sc_scatter_atomic,k_scan_blocks,k_scatter_point_rows,k_seg_min,k_slice_classify_backward,k_slice_classify_forward,k_slice_forward,k_slice_forward_f16,k_table_clear"; }
+extern "C" const char* ln_kernel_names(void) { return "k_bucket_rows,k_canon_idx,k_canon_mark,k_canon_slots,k_conv_backward_fused,k_conv_generic,k_conv_generic_f16,k_conv_mfma,k_conv_mfma_f16,k_conv_split_bank,k_conv_sum_partials,k_csr_count,k_csr_fill,k_csr_group_sizes,k_csr_reduce_segments,k_csr_scan_local,k_csr_scan_top,k_csr_segment_max,k_csr_segment_max_decode,k_finalize,k_gather_backward,k_gather_forward,k_gn_apply,k_gn_backward_apply,k_gn_stats,k_grad_filter_f16,k_grad_filter_generic,k_grad_filter_mfma,k_grad_filter_mfma_f16,k_im2row,k_im2rowindices,k_insert_coarse,k_insert_points,k_linear_act_backward_w,k_linear_act_backward_x,k_linear_act_forward,k_linear_reduce_slabs,k_mark_first,k_max_centre_backward,k_max_centre_forward,k_max_centre_sum,k_neighbours,k_point_keys,k_reduce_and_neighbours,k_reduce_slabs,k_reduce_slabs_f32,k_retrieve_points,k_row2im,k_sc_reduce_slabs,k_sc_scatter_atomic,k_scan_blocks,k_scatter_point_rows,k_seg_min,k_slice_classify_backward,k_slice_classify_forward,k_slice_forward,k_slice_forward_f16,k_table_clear"; }
 
 extern "C" int ln_profile_begin(const char* kernel_name, int max_samples) {
     LN_REQUIRE(kernel_name && strlen(kernel_name) < sizeof(g_prof.name) && max_samples > 0, LN_ERR_ARG, "ln_profile_begin: bad args");
@@ -314,7 +314,7 @@ __global__ void __launch_bounds__(256)
                  int* __restrict__ part_tok, unsigned long long* __restrict__ part_pk, int* __restrict__ tok_slot,
                  float* __restrict__ w, const float* __restrict__ vals, int val_dim, float* __restrict__ distributed,
                  int* __restrict__ seg_count, int seg_regions, float* __restrict__ clear_values, long long clear_values_elems,
-                 unsigned long long* __restrict__ bitmap, long long bitmap_words) {
+                 unsigned int* __restrict__ pub) {
     __shared__ int s_cnt[LN_BKT_MAX];
     __shared__ int s_lbase[LN_BKT_MAX];
     __shared__ int s_scan_tmp[8];
@@ -354,7 +354,7 @@ __global__ void __launch_bounds__(256)
                 rank[it][r] = atomicAdd(&s_cnt[bkt[it][r]], 1);
             } else {
                 bad_key = true;
-                tok_slot[tk] = -1;
+                if (tok_slot) tok_slot[tk] = -1;
             }
             if (w) w[tk] = ok ? s.bary[r] : -1.0f;
             if (distributed) {  // LatticeGPU.cuh:626-637: [pos_scaled(d) | val(V) | bary[r]] per simplex vertex
@@ -413,7 +413,7 @@ __global__ void __launch_bounds__(256)
         if (dst >= 0) {
             part_tok[dst] = tk;
             part_pk[dst] = s_stage_pk[j];
-        } else {
+        } else if (tok_slot) {
             tok_slot[tk] = -1;  // region full (heavily skewed cloud): the bucket workgroup reports it, the build is replayed
         }
     }
@@ -429,7 +429,7 @@ __global__ void __launch_bounds__(256)
         }
         const long long nk = (long long)t.capacity * D;
         for (long long i = g; i < nk; i += stride) t.keys[i] = 0;
-        for (long long i = g; i < bitmap_words; i += stride) bitmap[i] = 0ull;
+        for (long long i = g; i < nbk; i += stride) pub[i] = 0u;  // the bucket workgroups' look-back words (k_bucket_rows)
         if (g == 0) {
             *t.nr_filled = 0;
             *t.status = 0;   // later passes (bucket build, scan) raise the error bits of this build
@@ -440,23 +440,37 @@ __global__ void __launch_bounds__(256)
     LN_STAMP(7);
 }
 
-// Pass 2: one workgroup per bucket.  LDS: keys[sb] | count[sb] | min token[sb] | token offset[sb] | segment offset[sb].
+// Pass 2: one workgroup per bucket.  LDS: keys[sb] | count[sb] | min token[sb] | token offset[sb] | segment offset[sb] | row[sb].
+// This is the LAST kernel of a bucketed build.  Rows are numbered in SLOT order: row of a new vertex = (new vertices of all
+// buckets before this one) + (occupied slots before it inside the bucket).  The only cross-workgroup quantity is that per-
+// bucket count, handed on through `pub` (one word per bucket: ready bit | error bit | count) with relaxed agent-scope
+// atomics — no fence (the word IS the payload), published right after the bucket's scans and read just before the emit
+// phase (decoupled look-back over all earlier buckets; workgroups are dispatched in index order, so a workgroup only ever
+// waits for workgroups that are resident or done).  The last bucket closes the build: nr_filled, status, the pinned host
+// pair, and the bucket cursors back to zero (every workgroup read them before it published).
+// The reference numbers vertices by thread-arrival order (atomicAdd(m_nr_filled), HashTableGPU.cuh:454: not reproducible);
+// ln_canonicalize relabels a table built here into first-occurrence order (= a serial run of the reference) on request.
 #define LN_BKT_THREADS 1024
-#define LN_BKT_LDS_LIMIT (150 * 1024)  // dynamic LDS one k_bucket_build workgroup may ask for (160 KB per CU minus its static arrays)
+#define LN_BKT_LDS_LIMIT (150 * 1024)  // dynamic LDS one k_bucket_rows workgroup may ask for (160 KB per CU minus its static arrays)
+#define LN_BKT_LDS_PER_SLOT (sizeof(unsigned long long) + 5 * sizeof(int))
 #define LN_BKT_REG_TOK 4  // tokens per thread whose (token, slot, position) stay in registers between the two sweeps
+#define LN_PUB_READY 0x80000000u
+#define LN_PUB_ERR 0x40000000u
+#define LN_PUB_CNT 0x3FFFFFFFu
 template <int D>
 __global__ void __launch_bounds__(LN_BKT_THREADS)
-    k_bucket_build(LnTable t, int sb, int nbk, int capb, const int* __restrict__ cursor, const int* __restrict__ part_tok,
-                   const unsigned long long* __restrict__ part_pk, int* __restrict__ part_slot, int* __restrict__ part_pos,
-                   int* __restrict__ tok_slot, LnCsr csr, unsigned long long* __restrict__ bitmap) {
+    k_bucket_rows(LnTable t, int sb, int nbk, int capb, int* __restrict__ cursor, const int* __restrict__ part_tok,
+                  const unsigned long long* __restrict__ part_pk, int* __restrict__ part_slot, int* __restrict__ part_pos,
+                  int* __restrict__ idx_out, LnCsr csr, unsigned int* __restrict__ pub) {
     extern __shared__ unsigned long long s_mem[];
     unsigned long long* skeys = s_mem;
     int* scnt = reinterpret_cast<int*>(skeys + sb);
     unsigned int* smin = reinterpret_cast<unsigned int*>(scnt + sb);
     int* soff = reinterpret_cast<int*>(smin + sb);
     int* sseg = soff + sb;
-    __shared__ int s_wave_tok[16], s_wave_seg[16];
-    __shared__ int s_run_tok, s_run_seg, s_seg_base;
+    int* srow = sseg + sb;
+    __shared__ int s_wave_tok[16], s_wave_seg[16], s_wave_new[16];
+    __shared__ int s_run_tok, s_run_seg, s_run_new, s_err;
     __shared__ int s_rcnt[LN_XCD_GROUPS], s_rbase[LN_XCD_GROUPS];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -476,13 +490,15 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) before += __shfl_xor(before, off, 64);
     if (lane == 0) s_wave_tok[wave] = before;
+    const int my_cursor = cursor[b];
+    const int ntok = min(my_cursor, capb);
     if (tid == 0) {
         s_run_tok = 0;
         s_run_seg = 0;
+        s_run_new = 0;
+        s_err = my_cursor > capb ? 1 : 0;  // region overflow: tokens were dropped by pass 1
     }
     if (tid < LN_XCD_GROUPS) s_rcnt[tid] = 0;
-    const int ntok = min(cursor[b], capb);
-    if (tid == 0 && cursor[b] > capb) atomicOr(t.status, LN_STATUS_BUCKET_OVERFLOW);  // region overflow: tokens were dropped
     const size_t in0 = (size_t)b * capb;
     // issue the loads of the register-resident tokens before the barrier
     int r_tk[LN_BKT_REG_TOK], r_ls[LN_BKT_REG_TOK], r_pos[LN_BKT_REG_TOK];
@@ -495,7 +511,7 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
         r_tk[k] = j < ntok ? part_tok[in0 + j] : -1;
         r_pk[k] = j < ntok ? part_pk[in0 + j] : LN_EMPTY_KEY;
     }
-    __syncthreads();
+    __syncthreads();  // (every cursor[] load of this workgroup has returned by now: the last bucket relies on it)
     int base = 0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) base += s_wave_tok[k];
@@ -522,7 +538,7 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
                 }
                 if (++o >= size) o = 0;
             }
-            if (ls < 0) atomicOr(t.status, LN_STATUS_BUCKET_OVERFLOW);
+            if (ls < 0) s_err = 1;  // every slot of the bucket is taken (benign race: all writers store 1)
         }
         // Hot vertices (coarse lattices: thousands of tokens on one slot) would serialise on one LDS address.  When a
         // large part of the wave landed on the slot of its first placed lane, that group takes its positions with ONE
@@ -548,7 +564,6 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
             pos = atomicAdd(&scnt[ls], 1);
             atomicMin(&smin[ls], (unsigned int)tk);
         }
-        if (valid) tok_slot[tk] = ls >= 0 ? lo + ls : -1;
     };
 #pragma unroll
     for (int k = 0; k < LN_BKT_REG_TOK; ++k) place(r_tk[k] >= 0, r_tk[k], r_pk[k], r_ls[k], r_pos[k]);
@@ -564,11 +579,12 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
     }
     __syncthreads();
     LN_STAMP(10);
-    // exclusive scans of the per-slot token and segment counts
+    // exclusive scans of the per-slot token counts, segment counts and occupancy (-> row of the slot inside the bucket)
     for (int start = 0; start < size; start += LN_BKT_THREADS) {
         const int i = start + tid;
         const int c = (i < size) ? scnt[i] : 0;
         const int g = (c + LN_CSR_SEG - 1) / LN_CSR_SEG;
+        const int nw = c ? 1 : 0;
         int ic = c, ig = g;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -579,28 +595,38 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
                 ig += og;
             }
         }
+        const unsigned long long occ = __ballot(nw);
+        const int in_wave_new = __popcll(occ & ((1ull << lane) - 1ull));
         if (lane == 63) {
             s_wave_tok[wave] = ic;
             s_wave_seg[wave] = ig;
+            s_wave_new[wave] = __popcll(occ);
         }
         __syncthreads();
-        int wt = 0, wg = 0;
+        int wt = 0, wg = 0, wn = 0;
         for (int k = 0; k < wave; ++k) {
             wt += s_wave_tok[k];
             wg += s_wave_seg[k];
+            wn += s_wave_new[k];
         }
-        const int rt = s_run_tok, rg = s_run_seg;
+        const int rt = s_run_tok, rg = s_run_seg, rn = s_run_new;
         if (i < size) {
             soff[i] = rt + wt + ic - c;
             sseg[i] = rg + wg + ig - g;
+            srow[i] = rn + wn + in_wave_new;
         }
         __syncthreads();
         if (tid == LN_BKT_THREADS - 1) {
             s_run_tok = rt + wt + ic;
             s_run_seg = rg + wg + ig;
+            s_run_new = rn + wn + __popcll(occ);
         }
         __syncthreads();
     }
+    // hand the count on as early as it is known
+    if (tid == 0)
+        __hip_atomic_store(&pub[b], LN_PUB_READY | (s_err ? LN_PUB_ERR : 0u) | (unsigned int)s_run_new, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
     LN_STAMP(11);
     // Segment ids.  Without region planes: one contiguous run of region 0 per bucket.  With planes: every slot files its
     // segments under the kd region of its key (sseg[i] becomes region << 28 | position among this bucket's segments of that
@@ -621,35 +647,94 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
     } else if (tid == 0) {
         s_rbase[0] = s_run_seg ? atomicAdd(&csr.seg_count[0], s_run_seg) : 0;
     }
+    // look-back: new vertices (and error flags) of every earlier bucket
+    int rows_before = 0;
+    unsigned int err_before = 0u;
+    for (int i = tid; i < b; i += LN_BKT_THREADS) {
+        unsigned int v = __hip_atomic_load(&pub[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (!(v & LN_PUB_READY)) {
+            __builtin_amdgcn_s_sleep(2);
+            v = __hip_atomic_load(&pub[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        rows_before += int(v & LN_PUB_CNT);
+        err_before |= v & LN_PUB_ERR;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        rows_before += __shfl_xor(rows_before, off, 64);
+        err_before |= (unsigned int)__shfl_xor((int)err_before, off, 64);
+    }
+    if (lane == 0) {
+        s_wave_tok[wave] = rows_before;
+        s_wave_seg[wave] = int(err_before);
+    }
     __syncthreads();
+    int base_row = 0;
+    unsigned int err_all = s_err ? LN_PUB_ERR : 0u;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        base_row += s_wave_tok[k];
+        err_all |= (unsigned int)s_wave_seg[k];
+    }
     const int placed = s_run_tok;
+    const int new_here = s_run_new;
     LN_STAMP(12);
     for (int i = tid; i < size; i += LN_BKT_THREADS) {
         const int h = lo + i;
         const int beg = base + soff[i];
-        csr.grp_start[h] = beg;
-        t.slot_keys[h] = skeys[i];
-        t.entries[h] = -1;  // the clear's share of this slot range; finalize publishes the rows of the new vertices
-        const unsigned int ft = smin[i];
-        t.slot_tok[h] = ft;
         const int c = scnt[i];
-        // the slot's first occurrence (every slot is new).  These 46 k memory-side atomics cost 4.4 us of back pressure on
-        // this loop at C3; a byte flag per token instead (plain stores) brings this kernel to 14.5 us, but packing 480 KB of
-        // flags into the bitmap inside the single-workgroup scan costs 17 us, and as a separate launch about what it saves.
-        if (c) atomicOr(&bitmap[ft >> 6], 1ull << (ft & 63));
+        int row = -1;
+        if (c) {
+            row = base_row + srow[i];
+            if (t.row_limit > 0 && row >= t.row_limit) row = -1;  // beyond the host's static row bound: stays un-inserted
+        }
+        srow[i] = row;
+        csr.grp_start[h] = beg;
+        const unsigned long long pk = skeys[i];
+        t.slot_keys[h] = pk;
+        t.entries[h] = row;
+        t.slot_tok[h] = smin[i];  // smallest token of the slot: what ln_canonicalize orders the rows by
+        if (row >= 0) {
+            int key[D];
+            KeyPack<D>::unpack(pk, key, t.key_format);
+#pragma unroll
+            for (int k = 0; k < D; ++k) t.keys[(size_t)row * D + k] = key[k];
+        }
         const int sr = planes ? (sseg[i] >> 28) : 0;
         long long sid = (long long)sr * csr.seg_region + s_rbase[sr] + (planes ? (sseg[i] & 0x0FFFFFFF) : sseg[i]);
         for (int e = 0; e < c; e += LN_CSR_SEG, ++sid)
             reinterpret_cast<int4*>(csr.seg_desc)[sid] = make_int4(h, beg + e, c - e, e);
     }
-    if (b == nbk - 1 && tid == 0) csr.grp_start[t.capacity] = base + ntok;
+    if (b == nbk - 1) {  // close the build
+        if (tid == 0) {
+            csr.grp_start[t.capacity] = base + ntok;
+            const int total = base_row + new_here;
+            int bits = (err_all ? LN_STATUS_BUCKET_OVERFLOW : 0) | (cursor[nbk] ? LN_STATUS_KEY_RANGE : 0);
+            *t.nr_filled = total;
+            if (bits) atomicOr(t.status, bits);
+            if (t.host_counters) {  // pinned host memory: the host spins on word 2 (it cleared it before the launch)
+                t.host_counters[0] = total;
+                t.host_counters[1] = bits;
+                __threadfence_system();
+                __hip_atomic_store(&t.host_counters[2], t.host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        __syncthreads();  // (tid 0 has read cursor[nbk])
+        for (int i = tid; i <= nbk; i += LN_BKT_THREADS) cursor[i] = 0;  // all-zero between builds; every reader has published
+    }
+    __syncthreads();  // srow[] now holds the final row of every slot
     LN_STAMP(13);
 #pragma unroll
-    for (int k = 0; k < LN_BKT_REG_TOK; ++k)
+    for (int k = 0; k < LN_BKT_REG_TOK; ++k) {
+        if (r_tk[k] < 0) continue;
         if (r_ls[k] >= 0) csr.csr_tok[base + soff[r_ls[k]] + r_pos[k]] = r_tk[k];
+        if (idx_out) idx_out[r_tk[k]] = r_ls[k] >= 0 ? srow[r_ls[k]] : -1;
+    }
     for (int j = tid + LN_BKT_REG_TOK * LN_BKT_THREADS; j < ntok; j += LN_BKT_THREADS) {
         const int ls = part_slot[in0 + j];
-        if (ls >= 0) csr.csr_tok[base + soff[ls] + part_pos[in0 + j]] = part_tok[in0 + j];
+        const int tk = part_tok[in0 + j];
+        if (ls >= 0) csr.csr_tok[base + soff[ls] + part_pos[in0 + j]] = tk;
+        if (idx_out) idx_out[tk] = ls >= 0 ? srow[ls] : -1;
     }
     for (int j = placed + tid; j < ntok; j += LN_BKT_THREADS)
         csr.csr_tok[base + j] = -1;  // only after an overflow: keeps readers in bounds until the rebuild
@@ -760,19 +845,14 @@ __global__ void __launch_bounds__(256)
 // single workgroup: exclusive scan of the per-block first-occurrence counts (+ rows that existed before)
 __global__ void __launch_bounds__(1024) k_scan_blocks(const int* __restrict__ block_cnt, const unsigned long long* __restrict__ bitmap, int nb,
                                                       int* __restrict__ block_prefix, int* nr_filled, int* __restrict__ status,
-                                                      int* __restrict__ host_counters, int host_seq, int* __restrict__ cursor, int nbk) {
+                                                      int* __restrict__ host_counters, int host_seq, int relabel) {
     __shared__ int s_wave[16];
     __shared__ int s_running;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int base = *nr_filled;
+    const int base = relabel ? 0 : *nr_filled;  // relabel (ln_canonicalize): ranks among the rows that exist, counters untouched
     if (tid == 0) s_running = 0;
-    if (cursor) {  // bucketed build: its bucket cursors (+ the key-range word behind them) go back to zero for the next build
-        if (tid == 0 && cursor[nbk]) atomicOr(status, LN_STATUS_KEY_RANGE);
-        __syncthreads();
-        for (int i = tid; i <= nbk; i += 1024) cursor[i] = 0;
-    }
     __syncthreads();
     for (int start = 0; start < nb; start += 1024) {
         const int i = start + tid;
@@ -780,7 +860,7 @@ __global__ void __launch_bounds__(1024) k_scan_blocks(const int* __restrict__ bl
         if (i < nb) {
             if (block_cnt) {
                 v = block_cnt[i];
-            } else {  // bucketed build: the first-occurrence bits were set directly, count them here
+            } else {  // ln_canonicalize: the first-occurrence bits were set directly, count them here
                 const ulonglong2 a = *reinterpret_cast<const ulonglong2*>(bitmap + (size_t)i * 4);
                 const ulonglong2 c = *reinterpret_cast<const ulonglong2*>(bitmap + (size_t)i * 4 + 2);
                 v = __popcll(a.x) + __popcll(a.y) + __popcll(c.x) + __popcll(c.y);
@@ -802,7 +882,7 @@ __global__ void __launch_bounds__(1024) k_scan_blocks(const int* __restrict__ bl
         if (tid == 1023) s_running = running + wave_off + incl;
         __syncthreads();
     }
-    if (tid == 0) {
+    if (tid == 0 && !relabel) {
         *nr_filled = base + s_running;
         if (host_counters) {  // pinned host memory: the host spins on word 2 (it cleared it before the launch)
             host_counters[0] = base + s_running;
@@ -813,8 +893,26 @@ __global__ void __launch_bounds__(1024) k_scan_blocks(const int* __restrict__ bl
     }
 }
 
-// FRESH: the table was cleared by this build call, so every slot is new (no entries[] gather per token)
-template <int D, bool FRESH>
+// rank of token `ft` among the marked tokens: prefix of its 256-token block + the set bits below it inside the block (the
+// block's four bitmap words are fetched together with the prefix: one round trip)
+__device__ __forceinline__ int ln_rank_of_token(unsigned int ft, const unsigned long long* __restrict__ bitmap,
+                                                const int* __restrict__ block_prefix) {
+    const unsigned int blk = ft >> 8;
+    const unsigned int wd = (ft >> 6) & 3;
+    int r = block_prefix[blk];
+    const ulonglong2 w01 = *reinterpret_cast<const ulonglong2*>(bitmap + (size_t)blk * 4);
+    const ulonglong2 w23 = *reinterpret_cast<const ulonglong2*>(bitmap + (size_t)blk * 4 + 2);
+    const unsigned long long words[4] = {w01.x, w01.y, w23.x, w23.y};
+    unsigned long long mine = 0ull;
+#pragma unroll
+    for (unsigned int k = 0; k < 4; ++k) {
+        if (k < wd) r += __popcll(words[k]);
+        if (k == wd) mine = words[k];
+    }
+    return r + __popcll(mine & ((1ull << (ft & 63)) - 1ull));
+}
+
+template <int D>
 __global__ void __launch_bounds__(256)
     k_finalize(LnTable t, const int* tok_slot, int* idx_out, long long tokens, const unsigned long long* __restrict__ bitmap,
                const int* __restrict__ block_prefix) {
@@ -825,25 +923,11 @@ __global__ void __launch_bounds__(256)
         if (idx_out) idx_out[tk] = -1;
         return;
     }
-    const int e = FRESH ? -1 : t.entries[h];  // >=0: existed before this build (or already finalized — same value)
+    const int e = t.entries[h];  // >=0: existed before this build (or already finalized — same value)
     int row = e;
     const unsigned int ft = t.slot_tok[h];
     if (e < 0) {
-        // rank of token ft among the first occurrences: prefix of its 256-token block + the set bits below it inside the
-        // block.  The block's four bitmap words are fetched together with the prefix (one round trip, not up to five).
-        const unsigned int blk = ft >> 8;
-        const unsigned int wd = (ft >> 6) & 3;
-        int r = block_prefix[blk];
-        const ulonglong2 w01 = *reinterpret_cast<const ulonglong2*>(bitmap + (size_t)blk * 4);
-        const ulonglong2 w23 = *reinterpret_cast<const ulonglong2*>(bitmap + (size_t)blk * 4 + 2);
-        const unsigned long long words[4] = {w01.x, w01.y, w23.x, w23.y};
-        unsigned long long mine = 0ull;
-#pragma unroll
-        for (unsigned int k = 0; k < 4; ++k) {
-            if (k < wd) r += __popcll(words[k]);
-            if (k == wd) mine = words[k];
-        }
-        r += __popcll(mine & ((1ull << (ft & 63)) - 1ull));
+        const int r = ln_rank_of_token(ft, bitmap, block_prefix);  // rank of the slot's smallest token among the first occurrences
         row = r;
         if (t.row_limit > 0 && row >= t.row_limit) row = -1;  // beyond the host's static row bound: stays un-inserted
         if (ft == (unsigned int)tk && row >= 0) {  // first occurrence publishes the vertex
@@ -874,6 +958,7 @@ struct BuildWs {
     int* part_tok;
     int* part_slot;
     int* part_pos;
+    unsigned int* pub;  // [buckets] look-back words of k_bucket_rows
 };
 
 static size_t ln_align256(size_t x) { return (x + 255) & ~size_t(255); }
@@ -895,7 +980,8 @@ extern "C" size_t ln_build_workspace_bytes(long long tokens, int capacity) {
     const size_t region = (size_t)ln_bucket_count(capacity) * ln_bucket_region(tokens, capacity);
     return ln_align256(nb * 4 * sizeof(unsigned long long)) + 2 * ln_align256(nb * sizeof(int)) +
            2 * ln_align256((size_t)tokens * sizeof(int)) + ln_align256(ln_csr_scan_workspace_bytes(capacity)) +
-           ln_align256(region * sizeof(unsigned long long)) + 3 * ln_align256(region * sizeof(int));
+           ln_align256(region * sizeof(unsigned long long)) + 3 * ln_align256(region * sizeof(int)) +
+           ln_align256((size_t)ln_bucket_count(capacity) * sizeof(unsigned int));
 }
 
 static int ln_carve_ws(long long tokens, int capacity, void* workspace, size_t bytes, BuildWs& ws) {
@@ -927,11 +1013,13 @@ static int ln_carve_ws(long long tokens, int capacity, void* workspace, size_t b
     ws.part_slot = reinterpret_cast<int*>(p);
     p += ln_align256(region * sizeof(int));
     ws.part_pos = reinterpret_cast<int*>(p);
+    p += ln_align256(region * sizeof(int));
+    ws.pub = reinterpret_cast<unsigned int*>(p);
     return LN_OK;
 }
 
 template <int D>
-static int ln_rank_rows(const LnTable& t, const int* tok_slot, int* idx_out, long long tokens, const BuildWs& ws, bool marked, hipStream_t st);
+static int ln_rank_rows(const LnTable& t, const int* tok_slot, int* idx_out, long long tokens, const BuildWs& ws, hipStream_t st);
 
 // After the producer: slot CSR (scan of slot_cnt + fill) -> per-slot smallest token -> canonical rank.
 template <int D>
@@ -942,22 +1030,62 @@ static int ln_rank_and_finalize(const LnTable& t, const int* tok_slot, const int
     const long long max_seg = ln_csr_max_segments(tokens, t.capacity);
     LN_LAUNCH("k_seg_min", k_seg_min, dim3(ln_div_up(max_seg, 256)), dim3(256), 0, st, t, csr.csr_tok,
               reinterpret_cast<const int4*>(csr.seg_desc), csr.seg_count);
-    return ln_rank_rows<D>(t, tok_slot, idx_out, tokens, ws, false, st);
+    return ln_rank_rows<D>(t, tok_slot, idx_out, tokens, ws, st);
 }
 
-// slot_tok (smallest token per slot) -> canonical row numbers
+// slot_tok (smallest token per slot) -> canonical row numbers (atomic build path: works on tables that already hold rows)
 template <int D>
-static int ln_rank_rows(const LnTable& t, const int* tok_slot, int* idx_out, long long tokens, const BuildWs& ws, bool marked, hipStream_t st) {
-    if (!marked)  // the bucketed build sets the first-occurrence bits itself
-        LN_LAUNCH("k_mark_first", k_mark_first, dim3(ws.nb), dim3(256), 0, st, t, tok_slot, tokens, ws.bitmap, ws.block_cnt);
-    LN_LAUNCH("k_scan_blocks", k_scan_blocks, dim3(1), dim3(1024), 0, st, marked ? (const int*)nullptr : ws.block_cnt, ws.bitmap, ws.nb,
-              ws.block_prefix, t.nr_filled, t.status, t.host_counters, t.host_seq, marked ? t.slot_cnt : (int*)nullptr,
-              ln_bucket_count(t.capacity));
-    if (marked)  // bucketed build of a table cleared in the same call
-        LN_LAUNCH("k_finalize", (k_finalize<D, true>), dim3(ws.nb), dim3(256), 0, st, t, tok_slot, idx_out, tokens, ws.bitmap, ws.block_prefix);
-    else
-        LN_LAUNCH("k_finalize", (k_finalize<D, false>), dim3(ws.nb), dim3(256), 0, st, t, tok_slot, idx_out, tokens, ws.bitmap, ws.block_prefix);
+static int ln_rank_rows(const LnTable& t, const int* tok_slot, int* idx_out, long long tokens, const BuildWs& ws, hipStream_t st) {
+    LN_LAUNCH("k_mark_first", k_mark_first, dim3(ws.nb), dim3(256), 0, st, t, tok_slot, tokens, ws.bitmap, ws.block_cnt);
+    LN_LAUNCH("k_scan_blocks", k_scan_blocks, dim3(1), dim3(1024), 0, st, (const int*)ws.block_cnt, ws.bitmap, ws.nb, ws.block_prefix, t.nr_filled,
+              t.status, t.host_counters, t.host_seq, 0);
+    LN_LAUNCH("k_finalize", (k_finalize<D>), dim3(ws.nb), dim3(256), 0, st, t, tok_slot, idx_out, tokens, ws.bitmap, ws.block_prefix);
     return ln_check_launch("ln build (mark/scan/finalize)");
+}
+
+// ------------------------------------------------------------------------------------------
+// ln_canonicalize: slot-order rows of ONE fresh bucketed build -> first-occurrence order
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_canon_mark(LnTable t, unsigned long long* __restrict__ bitmap) {
+    const int h = blockIdx.x * 256 + threadIdx.x;
+    if (h >= t.capacity || t.entries[h] < 0) return;
+    const unsigned int ft = t.slot_tok[h];
+    atomicOr(&bitmap[ft >> 6], 1ull << (ft & 63));
+}
+
+template <int D>
+__global__ void __launch_bounds__(256)
+    k_canon_slots(LnTable t, const unsigned long long* __restrict__ bitmap, const int* __restrict__ block_prefix, int* __restrict__ perm) {
+    const int h = blockIdx.x * 256 + threadIdx.x;
+    if (h >= t.capacity) return;
+    const int old_row = t.entries[h];
+    if (old_row < 0) return;
+    const int row = ln_rank_of_token(t.slot_tok[h], bitmap, block_prefix);
+    perm[old_row] = row;
+    t.entries[h] = row;
+    int key[D];
+    KeyPack<D>::unpack(t.slot_keys[h], key, t.key_format);  // (from the slot, not from keys[old_row]: the permutation runs in place)
+#pragma unroll
+    for (int i = 0; i < D; ++i) t.keys[(size_t)row * D + i] = key[i];
+}
+
+__global__ void __launch_bounds__(256) k_canon_idx(int* __restrict__ idx, long long tokens, const int* __restrict__ perm) {
+    const long long tk = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (tk >= tokens) return;
+    const int r = idx[tk];
+    if (r >= 0) idx[tk] = perm[r];
+}
+
+template <int D>
+static int ln_canonicalize_impl(const LnTable& t, int* idx, long long tokens, const BuildWs& ws, hipStream_t st) {
+    if (hipMemsetAsync(ws.bitmap, 0, (size_t)ws.nb * 4 * sizeof(unsigned long long), st) != hipSuccess) return ln_check_launch("ln_canonicalize(memset)");
+    const int slot_blocks = ln_div_up(t.capacity, 256);
+    LN_LAUNCH("k_canon_mark", k_canon_mark, dim3(slot_blocks), dim3(256), 0, st, t, ws.bitmap);
+    LN_LAUNCH("k_scan_blocks", k_scan_blocks, dim3(1), dim3(1024), 0, st, (const int*)nullptr, ws.bitmap, ws.nb, ws.block_prefix, t.nr_filled, t.status,
+              (int*)nullptr, 0, 1);
+    LN_LAUNCH("k_canon_slots", k_canon_slots<D>, dim3(slot_blocks), dim3(256), 0, st, t, ws.bitmap, ws.block_prefix, ws.tok_pos);
+    if (idx) LN_LAUNCH("k_canon_idx", k_canon_idx, dim3(ws.nb), dim3(256), 0, st, idx, tokens, ws.tok_pos);
+    return ln_check_launch("ln_canonicalize");
 }
 
 static int ln_check_csr(const LnCsr* c, const char* who) {
@@ -986,7 +1114,7 @@ static int ln_build_points(const LnTable* t, const float* positions_raw, const f
     // the clearing itself (no k_table_clear launch).  Its cursors use the first nbk+1 words of slot_cnt.
     // Beyond LN_BKT_MAX buckets the buckets grow instead; one bucket's staging area has to fit the 160 KB of LDS of a gfx950 CU
     // (tables past ~14M slots take the atomic path).
-    const size_t bucket_lds = (size_t)ln_bucket_slots(t->capacity) * (sizeof(unsigned long long) + 4 * sizeof(int));
+    const size_t bucket_lds = (size_t)ln_bucket_slots(t->capacity) * LN_BKT_LDS_PER_SLOT;
     const bool bucketed = n > 0 && (flags & LN_BUILD_CLEAR_FIRST) && !(flags & LN_BUILD_ATOMIC_PATH) &&
                           t->capacity > ln_bucket_count(t->capacity) && bucket_lds <= LN_BKT_LDS_LIMIT &&
                           (long long)ln_bucket_count(t->capacity) * ln_bucket_region(tokens, t->capacity) < 0x7FFFFFFFll;  // int region offsets
@@ -997,19 +1125,21 @@ static int ln_build_points(const LnTable* t, const float* positions_raw, const f
     }
     if (n == 0) return LN_OK;
     hipStream_t st = (hipStream_t)stream;
-    int* tok_slot = write_idx ? idx : ws.tok_slot;  // idx doubles as the token->slot scratch
+    int* tok_slot = write_idx ? idx : ws.tok_slot;  // atomic path: idx doubles as the token->slot scratch
     LN_DISPATCH_D(t->pos_dim, {
         LnScale<D> sc = ln_make_scale<D>(sigmas_host);
         if (bucketed) {
             const int sb = ln_bucket_slots(t->capacity);
             const int nbk = ln_bucket_count(t->capacity);
             const size_t lds = bucket_lds;
+            int* dropped_idx = write_idx ? idx : (int*)nullptr;  // tokens that never reach a bucket get idx = -1 in pass 1
             LN_LAUNCH("k_point_keys", k_point_keys<D>, dim3(ln_div_up(n, LN_KEYS_PTS_PER_BLOCK)), dim3(256), 0, st, *t, positions_raw, sc, n, sb,
-                      nbk, ws.capb, ws.part_tok, ws.part_pk, tok_slot, write_idx ? w : (float*)nullptr, vals, val_dim, distributed,
-                      csr->seg_count, csr->planes ? LN_XCD_GROUPS : 1, clear_values, clear_values_elems, ws.bitmap, (long long)ws.nb * 4);
-            LN_LAUNCH("k_bucket_build", k_bucket_build<D>, dim3(nbk), dim3(LN_BKT_THREADS), lds, st, *t, sb, nbk, ws.capb, t->slot_cnt,
-                      ws.part_tok, ws.part_pk, ws.part_slot, ws.part_pos, tok_slot, *csr, ws.bitmap);
-            rc = ln_rank_rows<D>(*t, tok_slot, write_idx ? idx : (int*)nullptr, tokens, ws, true, st);
+                      nbk, ws.capb, ws.part_tok, ws.part_pk, dropped_idx, write_idx ? w : (float*)nullptr, vals, val_dim, distributed,
+                      csr->seg_count, csr->planes ? LN_XCD_GROUPS : 1, clear_values, clear_values_elems, ws.pub);
+            LN_LAUNCH("k_bucket_rows", k_bucket_rows<D>, dim3(nbk), dim3(LN_BKT_THREADS), lds, st, *t, sb, nbk, ws.capb, t->slot_cnt,
+                      ws.part_tok, ws.part_pk, ws.part_slot, ws.part_pos, dropped_idx, *csr, ws.pub);
+            rc = ln_check_launch(who);
+            if (rc == LN_OK && (flags & LN_BUILD_CANONICAL_ROWS)) rc = ln_canonicalize_impl<D>(*t, dropped_idx, tokens, ws, st);
         } else {
             LN_LAUNCH("k_insert_points", k_insert_points<D>, dim3(ln_div_up(tokens, 256)), dim3(256), 0, st, *t, positions_raw, sc, n, tok_slot,
                       ws.tok_pos, write_idx ? w : (float*)nullptr, vals, val_dim, distributed);
@@ -1033,6 +1163,18 @@ extern "C" int ln_distribute(const LnTable* t, const float* positions_raw, const
     LN_REQUIRE(val_dim >= 1, LN_ERR_ARG, "ln_distribute: val_dim=%d", val_dim);
     return ln_build_points(t, positions_raw, sigmas_host, n, idx, w, flags | LN_BUILD_WRITE_IDX, vals, val_dim, distributed, csr, workspace,
                            workspace_bytes, clear_values, clear_values_elems, stream, "ln_distribute");
+}
+
+extern "C" int ln_canonicalize(const LnTable* t, int* idx, long long tokens, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = ln_check_table(t, "ln_canonicalize");
+    if (rc) return rc;
+    LN_REQUIRE(tokens >= 0, LN_ERR_ARG, "ln_canonicalize: tokens=%lld", tokens);
+    if (tokens == 0) return LN_OK;
+    BuildWs ws;
+    rc = ln_carve_ws(tokens, t->capacity, workspace, workspace_bytes, ws);
+    if (rc) return rc;
+    LN_DISPATCH_D(t->pos_dim, { rc = ln_canonicalize_impl<D>(*t, idx, tokens, ws, (hipStream_t)stream); });
+    return rc;
 }
 
 extern "C" int ln_coarsen(const LnTable* fine, int fine_rows_upper, const LnTable* coarse, const LnCsr* csr, void* workspace,

@@ -7,7 +7,8 @@ are plain torch tensors on a ROCm device, kernels run on torch's current HIP str
 
 Differences that are deliberate:
   * errors raise Python exceptions instead of glog CHECK aborts;
-  * vertex numbering is canonical (first occurrence in (point, remainder) order);
+  * vertex numbering is deterministic: hash-slot order by default, first occurrence in (point, remainder) order under
+    set_row_order("canonical") (the reference's is thread-arrival order);
   * the 9-probe neighbour traversal is done ONCE per (query, neighbour, dilation, flip) and the
     [M, E] neighbour list is cached with the table structure, then shared by im2row,
     im2rowindices, row2im, the fused convolution and its backward;
@@ -25,11 +26,30 @@ import torch
 
 from . import _lib
 
-__all__ = ["Lattice", "HashTable"]
+__all__ = ["Lattice", "HashTable", "set_row_order", "get_row_order"]
 
 
 _SIZE_CACHE = {}
 _FORCE_ATOMIC_BUILD = os.environ.get("LATTICE_BUILD_PATH", "") == "atomic"  # A/B switch: skip the bucketed build
+
+# Vertex numbering of builds that start from a cleared table (begin_splat + splat / distribute / just_create_verts):
+#   "slot"      (default) rows in hash-slot order — deterministic, and the build is two launches.  The reference numbers its
+#               vertices in thread-arrival order (HashTableGPU.cuh:454), so nothing it computes depends on the numbering;
+#   "canonical" rows by first occurrence in (point, remainder) order — what a serial run of the reference produces and
+#               what the golden vectors hold; costs a relabelling pass behind the build (ln_canonicalize).
+_ROW_ORDER = [os.environ.get("LATTICE_ROW_ORDER", "slot")]
+
+
+def set_row_order(order: str) -> str:
+    """Selects the vertex numbering of subsequent builds ("slot" or "canonical"); returns the previous setting."""
+    if order not in ("slot", "canonical"):
+        raise ValueError(f"row order must be 'slot' or 'canonical', got {order!r}")
+    prev, _ROW_ORDER[0] = _ROW_ORDER[0], order
+    return prev
+
+
+def get_row_order() -> str:
+    return _ROW_ORDER[0]
 
 
 def _build_sizes(tokens: int, capacity: int):
@@ -458,6 +478,8 @@ class Lattice:
             flags = (_lib.LN_BUILD_WRITE_IDX if write else 0) | (_lib.LN_BUILD_CLEAR_FIRST if do_clear else 0)
             if force_atomic or _FORCE_ATOMIC_BUILD:
                 flags |= _lib.LN_BUILD_ATOMIC_PATH
+            if _ROW_ORDER[0] == "canonical":
+                flags |= _lib.LN_BUILD_CANONICAL_ROWS
             cv, cn = _lib.ptr(clear_vals), (0 if clear_vals is None else clear_vals.numel())
             ht.arm_count_readback()  # t is ht's cached struct: the sequence number travels in it
             if distributed is None:

@@ -1,0 +1,160 @@
+"""Default vertex numbering of the bucketed build (hash-slot order) against the oracle (`pytest -m gpu`).
+
+The reference numbers vertices in thread-arrival order (HashTableGPU.cuh:454), so its results are defined up to a
+permutation of the rows.  Here: the slot-order build must produce exactly the oracle's vertex SET (keys), and its splat
+indices must be the oracle's under the row permutation that matches the keys; everything that does not mention rows
+(barycentric weights, sliced outputs, filter gradients) must agree directly; and ln_canonicalize must turn the table
+into the oracle's numbering bit for bit."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import lattice_oracle as O
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-5
+
+
+def dev():
+    return torch.device("cuda", 0)
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(autouse=True)
+def slot_order(canonical_row_order):
+    from lattice_net_amd import lattice as lat
+    prev = lat.set_row_order("slot")
+    yield
+    lat.set_row_order(prev)
+
+
+def row_permutation(keys_gpu, keys_oracle):
+    """perm[gpu row] = oracle row; asserts that both hold the same set of keys."""
+    assert keys_gpu.shape == keys_oracle.shape
+    og = np.lexsort(keys_gpu.T[::-1])
+    oo = np.lexsort(keys_oracle.T[::-1])
+    assert np.array_equal(keys_gpu[og], keys_oracle[oo]), "vertex sets differ"
+    perm = np.empty(len(og), np.int64)
+    perm[og] = oo
+    return perm
+
+
+def clouds():
+    from lattice_net_amd import synthetic
+    rng = np.random.default_rng(5)
+    yield "cube1k", rng.uniform(-1, 1, (1000, 3)).astype(np.float32), 0.2, 60000
+    yield "lidar20k", synthetic.lidar_cloud(20000, 3), 0.9, 30000
+    dup = np.repeat(rng.uniform(-2, 2, (50, 3)).astype(np.float32), 40, axis=0)  # 40 copies of 50 points: hot vertices
+    yield "duplicates", dup, 0.5, 5000
+    yield "lidar120k", synthetic.lidar_cloud(120000, 0), 0.9, 100000
+
+
+@pytest.mark.parametrize("case", list(clouds()), ids=lambda c: c[0])
+def test_slot_order_build_equals_oracle_up_to_row_permutation(case):
+    from lattice_net_amd import Lattice
+    _, pos_np, sigma, cap = case
+    lat = Lattice(sigmas=[sigma] * 3, capacity=cap, device=dev())
+    lat.begin_splat()
+    idx, w = lat.just_create_verts(T(pos_np), True)
+    m = lat.nr_lattice_vertices()
+    t = O.OracleHashTable(cap, 3)
+    oidx, ow = O.build_splat(t, O.scale_positions(pos_np, np.full((3,), sigma, np.float32)))
+    assert m == t.nr_filled
+    ht = lat.m_hash_table
+    keys = N(ht.m_keys_tensor)
+    assert not keys[m:].any(), "key rows beyond the vertex count must stay zero (HashTable::clear)"
+    perm = row_permutation(keys[:m], t.keys[:m])
+    gi = N(idx).astype(np.int64)
+    assert gi.min() >= 0 and gi.max() == m - 1
+    assert np.array_equal(perm[gi], oidx)
+    assert np.array_equal(N(w), ow)  # weights do not depend on the numbering: bit-exact
+    ent = N(ht.m_entries_tensor)
+    assert np.array_equal(np.sort(ent[ent >= 0]), np.arange(m)), "entries must hold every row exactly once"
+    # rows follow the slots
+    assert np.all(np.diff(ent[ent >= 0]) > 0), "slot-order numbering: rows ascend with the slot index"
+
+
+@pytest.mark.parametrize("case", list(clouds())[:3], ids=lambda c: c[0])
+def test_canonicalize_after_slot_order_build_is_bit_exact(case):
+    """ln_canonicalize called through the C ABI on a slot-order table: keys, entries and idx become the oracle's."""
+    import lattice_net_amd as L
+    from lattice_net_amd import _lib, lattice as LT
+    _, pos_np, sigma, cap = case
+    lat = L.Lattice(sigmas=[sigma] * 3, capacity=cap, device=dev())
+    lat.begin_splat()
+    idx, w = lat.just_create_verts(T(pos_np), True)
+    m = lat.nr_lattice_vertices()
+    lib = L.load_library()
+    tokens = idx.numel()
+    ws = torch.empty((LT._build_sizes(tokens, cap)[0],), dtype=torch.uint8, device=dev())
+    t = lat.m_hash_table.c_table()
+    _lib.check(lib.ln_canonicalize(C.byref(t), _lib.ptr(idx), tokens, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev())), "ln_canonicalize")
+    torch.cuda.synchronize()
+    to = O.OracleHashTable(cap, 3)
+    oidx, ow = O.build_splat(to, O.scale_positions(pos_np, np.full((3,), sigma, np.float32)))
+    assert m == to.nr_filled
+    assert np.array_equal(N(idx), oidx)
+    assert np.array_equal(N(lat.m_hash_table.m_keys_tensor)[:m], to.keys[:m])
+    ent = N(lat.m_hash_table.m_entries_tensor)
+    assert np.array_equal(np.sort(ent[ent >= 0]), np.arange(m))
+
+
+def test_slot_order_chain_matches_oracle():
+    """splat -> conv -> slice forward + backward under the default numbering: the sliced output and the filter gradient do
+    not mention rows and must equal the oracle's; lattice values and their gradient are compared through the permutation."""
+    import lattice_net_amd as L
+    from lattice_net_amd import synthetic
+    n, v, f, sigma, cap = 6000, 32, 32, 0.9, 20000
+    pos_np = synthetic.lidar_cloud(n, 1)
+    rng = np.random.default_rng(1)
+    vals_np = rng.standard_normal((n, v)).astype(np.float32)
+    w_np = (rng.standard_normal((9 * v, f)) / np.sqrt(9 * v)).astype(np.float32)
+    g_np = rng.standard_normal((n, f)).astype(np.float32)
+    pos, vals = T(pos_np), T(vals_np)
+    W = T(w_np).requires_grad_(True)
+    lat = L.Lattice(sigmas=[sigma] * 3, capacity=cap, device=dev())
+    lv, wrap, idx, w = L.SplatLattice.apply(lat, pos, vals)
+    m = lat.nr_lattice_vertices()
+    lv = lv[:m].contiguous().requires_grad_(True)
+    cv, cwrap = L.ConvIm2RowLattice.apply(lv, lat, W, 1)
+    out = L.SliceLattice.apply(cv, cwrap.lattice, pos, idx, w)
+    out.backward(T(g_np))
+    torch.cuda.synchronize()
+
+    t = O.OracleHashTable(cap, 3)
+    oidx, ow = O.build_splat(t, O.scale_positions(pos_np, np.full((3,), sigma, np.float32)))
+    assert t.nr_filled == m
+    perm = row_permutation(N(lat.m_hash_table.m_keys_tensor)[:m], t.keys[:m])
+    ov = np.zeros((m, v), np.float32)
+    O.splat_accumulate(ov, vals_np, oidx, ow)
+    nbr = O.neighbour_rows(t.keys[:m], t, 1, 1, 1, False)
+    oc = O.conv_forward(nbr, ov, w_np)
+    oo = O.slice_with_precomputation(oc, oidx, ow, n)
+
+    def close(a, b):
+        np.testing.assert_allclose(np.asarray(a, np.float64), np.asarray(b, np.float64), rtol=RTOL, atol=RTOL * float(np.max(np.abs(b))))
+
+    close(N(lv)[np.argsort(perm)], ov)  # gpu row r is oracle row perm[r]
+    # the neighbour list, relabelled, is the oracle's (bit-exact)
+    gn = N(lat.neighbours(lat, 1, False)).astype(np.int64)
+    gn_as_oracle = np.where(gn >= 0, perm[np.maximum(gn, 0)], gn)[np.argsort(perm)]
+    assert np.array_equal(gn_as_oracle, nbr)
+    close(N(out), oo)
+    g_c = O.slice_backwards(g_np, oidx, ow, m)
+    rows = O.im2row(nbr, ov).astype(np.float64)
+    close(N(W.grad), rows.T @ g_c.astype(np.float64))
+    wb = w_np.reshape(9, v, f)
+    gv = np.zeros((m, v), np.float64)  # adjoint of the gather-GEMM, fp64
+    for e in range(9):
+        ok = nbr[:, e] >= 0
+        np.add.at(gv, nbr[ok, e], g_c[ok].astype(np.float64) @ wb[e].T.astype(np.float64))
+    close(N(lv.grad)[np.argsort(perm)], gv)
