@@ -158,6 +158,20 @@ int ln_build_splat(const LnTable* t, const float* positions_raw, const float* si
  * LN_BUILD_CANONICAL_ROWS makes ln_build_splat / ln_distribute do this themselves. */
 int ln_canonicalize(const LnTable* t, int* idx, long long tokens, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Lattice::splat_standalone (src/Lattice.cu:196-241) in one call: kernel_splat (LatticeGPU.cuh:707-842) + splatCacheNaive
+ * (LatticeGPU.cuh:926-973).  ln_build_splat (idx / w always written) followed by
+ *     table_values[row(t), j] += values[p, j] * w[t]    for every token t = p*(d+1)+r that was inserted, j < val_dim.
+ * `values` is [n, val_dim] fp32, or IEEE fp16 when values_f16 != 0 (accumulation and table_values are fp32 either way).
+ * table_values is [table_values_elems / val_dim, val_dim]: with LN_BUILD_CLEAR_FIRST it is zero-filled by this call
+ * (begin_splat), otherwise it must hold what is to be added to.  On the bucketed build path with val_dim % 4 == 0 the
+ * accumulation happens inside the bucket pass (the workgroup that resolves a bucket holds its tokens in LDS: no second
+ * pass over the CSR); on the atomic path, under LN_BUILD_CANONICAL_ROWS, or for other widths it is the segment reduce
+ * ln_csr_reduce_rows over the CSR the build emitted.  After a LN_STATUS_BUCKET_OVERFLOW the whole call must be repeated
+ * with LN_BUILD_ATOMIC_PATH (and LN_BUILD_CLEAR_FIRST). */
+int ln_splat(const LnTable* t, const float* positions_raw, const float* sigmas_host, const void* values, int val_dim, int values_f16,
+             int n, int* idx, float* w, int flags, const LnCsr* csr, void* workspace, size_t workspace_bytes, float* table_values,
+             long long table_values_elems, void* stream);
+
 /* splatCacheNaive (LatticeGPU.cuh:926-973): table_values[idx] += vals * w. */
 int ln_splat_accumulate(float* table_values, const float* vals, const int* idx, const float* w, int n, int pos_dim,
                         int val_dim, void* stream);

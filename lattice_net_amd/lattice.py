@@ -307,6 +307,10 @@ class Lattice:
     """Drop-in for `latticenet.Lattice` (src/PyBridge.cxx:41-113)."""
 
     m_expected_position_dimensions = -1  # static, Lattice.cu:44
+    # splat_standalone also launches the same-level neighbour traversal (fused into the accumulate launch): every lattice
+    # convolution starts with that list.  A caller that only splats and slices (no convolution on this lattice) sets the
+    # attribute to False on its lattice and saves the traversal.
+    prefetch_neighbours = True
 
     # ---------------------------------------------------------------- construction
     def __init__(self, config_file: Optional[str] = None, name: str = "", *, sigmas: Optional[Sequence[float]] = None,
@@ -457,7 +461,9 @@ class Lattice:
         c = _lib.LnCsr(base + 4 * o1, base + 4 * o2, base, base + 4 * o3, max_seg, _lib.ptr(planes))
         return buf, c, max_seg
 
-    def _build(self, positions_raw, write: bool, vals=None, distributed=None):
+    def _build(self, positions_raw, write: bool, vals=None, distributed=None, splat_values=None):
+        """One build call.  `splat_values` (splat_standalone): point features to accumulate onto the vertices in the same C call
+        (ln_splat: build + splatCacheNaive), into the table's value tensor."""
         n, d = positions_raw.shape
         dev = self._dev(positions_raw)
         ht = self.m_hash_table
@@ -482,7 +488,13 @@ class Lattice:
                 flags |= _lib.LN_BUILD_CANONICAL_ROWS
             cv, cn = _lib.ptr(clear_vals), (0 if clear_vals is None else clear_vals.numel())
             ht.arm_count_readback()  # t is ht's cached struct: the sequence number travels in it
-            if distributed is None:
+            if splat_values is not None:
+                tv = ht.m_values_tensor  # zero-filled by this call when the deferred clear rides in it (cv is tv then), else already zero
+                rc = lib.ln_splat(C.byref(t), _lib.ptr(positions_raw), self._sigmas_host(), _lib.ptr(splat_values), splat_values.shape[1],
+                                  1 if splat_values.dtype == torch.float16 else 0, n, _lib.ptr(idx), _lib.ptr(w), flags, C.byref(csr), _lib.ptr(ws),
+                                  ws.numel(), _lib.ptr(tv), tv.numel(), self._stream())
+                _lib.check(rc, "ln_splat")
+            elif distributed is None:
                 rc = lib.ln_build_splat(C.byref(t), _lib.ptr(positions_raw), self._sigmas_host(), n, _lib.ptr(idx), _lib.ptr(w), flags,
                                         C.byref(csr), _lib.ptr(ws), ws.numel(), cv, cn, self._stream())
                 _lib.check(rc, "ln_build_splat")
@@ -605,10 +617,10 @@ class Lattice:
             ht.m_values_tensor = torch.empty((cap, v), dtype=torch.float32, device=self._dev(positions_raw)) if pending else \
                 torch.zeros((cap, v), dtype=torch.float32, device=self._dev(positions_raw))
             ht._clear_pending = pending  # a deferred begin_splat clear zeroes the new accumulator inside the build call
-        idx, w = self._build(positions_raw, True)
-        tv = ht.m_values_tensor
-        # splatCacheNaive (LatticeGPU.cuh:926-973) as a token-balanced reduce; begin_splat zeroed the table values
-        self._after_build(lambda: self._accumulate_and_prefetch(values, idx, w, tv, v, d + 1, n * (d + 1)))
+        # kernel_splat + splatCacheNaive (LatticeGPU.cuh:707-842, 926-973) in one C call; begin_splat zeroed the table values
+        idx, w = self._build(positions_raw, True, splat_values=values)
+        if self.prefetch_neighbours:
+            self._after_build(lambda: self._prefetch_neighbours(n * (d + 1)))
         return idx, w
 
     def just_create_verts(self, positions_raw: torch.Tensor, return_indices_and_weights: bool):  # Lattice.cu:244-290
@@ -678,7 +690,7 @@ class Lattice:
         st = ht._storage
         rows_upper = min(ht.capacity(), tokens)
         _, csr, max_seg, grp_row, _ = self._csr(idx)
-        if rows_upper <= 0 or max_seg <= 0:
+        if rows_upper <= 0 or max_seg <= 0 or not self.prefetch_neighbours:
             return self._scatter_rows(values, idx, w, dst, val_dim, src_div, val_dim)
         lib = _lib.load()
         nbr = torch.empty((rows_upper, self.get_filter_extent(1)), dtype=torch.int32, device=self._dev())

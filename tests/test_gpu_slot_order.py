@@ -158,3 +158,70 @@ def test_slot_order_chain_matches_oracle():
         ok = nbr[:, e] >= 0
         np.add.at(gv, nbr[ok, e], g_c[ok].astype(np.float64) @ wb[e].T.astype(np.float64))
     close(N(lv.grad)[np.argsort(perm)], gv)
+
+
+def _splat_values_case(pos_np, vals_np, sigma, cap, half=False):
+    import lattice_net_amd as L
+    n, v = vals_np.shape
+    lat = L.Lattice(sigmas=[sigma] * 3, capacity=cap, device=dev())
+    vals = T(vals_np)
+    if half:
+        vals = vals.half()
+        vals_np = N(vals).astype(np.float32)
+    lv, wrap, idx, w = L.SplatLattice.apply(lat, T(pos_np), vals)
+    m = lat.nr_lattice_vertices()
+    t = O.OracleHashTable(cap, 3)
+    oidx, ow = O.build_splat(t, O.scale_positions(pos_np, np.full((3,), sigma, np.float32)))
+    assert m == t.nr_filled
+    perm = row_permutation(N(lat.m_hash_table.m_keys_tensor)[:m], t.keys[:m])
+    ov = np.zeros((m, v), np.float64)
+    np.add.at(ov, oidx[oidx >= 0], (vals_np.astype(np.float64)[:, None, :] * ow.reshape(n, 4, 1).astype(np.float64)).reshape(n * 4, v)[oidx >= 0])
+    got = N(lv).astype(np.float64)
+    assert not got[m:].any(), "rows beyond the vertex count must stay zero"
+    np.testing.assert_allclose(got[:m][np.argsort(perm)], ov, rtol=RTOL, atol=RTOL * float(np.abs(ov).max()))
+    return lat
+
+
+@pytest.mark.parametrize("v", [4, 32, 64, 6, 20])
+def test_fused_splat_accumulate_matches_oracle(v, golden):
+    """ln_splat: the accumulate runs inside the bucket pass for val_dim % 4 == 0 (float4 lanes) and as the segment reduce
+    otherwise; both against an fp64 evaluation of splatCacheNaive (LatticeGPU.cuh:937-971) on the oracle's indices."""
+    g = golden("F9_lidar")
+    pos_np = g["pos_raw"]
+    rng = np.random.default_rng(v)
+    _splat_values_case(pos_np, rng.standard_normal((pos_np.shape[0], v)).astype(np.float32), float(g["sigma"]), int(g["capacity"]))
+
+
+def test_fused_splat_accumulate_golden_values(golden):
+    g = golden("F1_config1")
+    lat = _splat_values_case(g["pos_raw"], g["vals"], float(g["sigma"]), int(g["capacity"]))
+    m = int(g["nr_filled"])
+    perm = row_permutation(N(lat.m_hash_table.m_keys_tensor)[:m], g["keys"])
+    got = N(lat.values())[:m][np.argsort(perm)]  # the reference kernel's own accumulate (serial run), rows matched through the keys
+    np.testing.assert_allclose(got, g["values"], rtol=RTOL, atol=RTOL * float(np.abs(g["values"]).max()))
+
+
+def test_fused_splat_accumulate_fp16_rows():
+    from lattice_net_amd import synthetic
+    rng = np.random.default_rng(2)
+    pos_np = synthetic.lidar_cloud(30000, 2)
+    _splat_values_case(pos_np, rng.standard_normal((30000, 32)).astype(np.float32), 0.9, 60000, half=True)
+
+
+@pytest.mark.parametrize("n_same", [500, 6000])
+def test_fused_splat_accumulate_hot_vertices(n_same):
+    """Thousands of tokens on four vertices: multi-segment runs (shuffle combine + atomics) and, at 6000 identical points,
+    buckets with more tokens than the LDS list holds (tokens beyond it are added one by one)."""
+    rng = np.random.default_rng(3)
+    pos_np = np.concatenate([np.tile(np.array([[0.31, -0.17, 0.05]], np.float32), (n_same, 1)),
+                             rng.uniform(-3, 3, (800, 3)).astype(np.float32)], 0)
+    vals_np = rng.uniform(0.5, 1.5, (pos_np.shape[0], 8)).astype(np.float32)  # same sign: no cancellation in the hot sums
+    _splat_values_case(pos_np, vals_np, 0.5, 5000)
+
+
+def test_fused_splat_full_size_c3():
+    from lattice_net_amd import synthetic
+    rng = np.random.default_rng(4)
+    pos_np = synthetic.lidar_cloud(120000, 0)
+    lat = _splat_values_case(pos_np, rng.standard_normal((120000, 32)).astype(np.float32), 0.9, 100000)
+    assert lat.nr_lattice_vertices() == 46538

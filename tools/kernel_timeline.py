@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Phase timeline of k_point_keys / k_bucket_build from per-workgroup wall-clock stamps (needs the -DLN_STAMPS build:
+"""Phase timeline of k_point_keys / k_bucket_rows from per-workgroup wall-clock stamps (needs the -DLN_STAMPS build:
 LATTICE_NET_LIB=lattice_net_amd/liblatticenet_hip_stamps.so python tools/kernel_timeline.py)."""
 import ctypes as C
 import os
@@ -17,8 +17,10 @@ dev = torch.device("cuda", 0)
 n, v, sigma, cap = 120000, 32, 0.9, 100000
 pos = torch.from_numpy(synthetic.lidar_cloud(n, 0)).to(dev)
 vals = torch.randn((n, v), device=dev)
+L.set_row_order("slot")
 lat = L.Lattice(sigmas=[sigma] * 3, capacity=cap, device=dev)
-stamps = torch.zeros((4096, 16), dtype=torch.int64, device=dev)
+lat.prefetch_neighbours = False
+stamps = torch.zeros((4096, 24), dtype=torch.int64, device=dev)
 for _ in range(5):
     L.SplatLattice.apply(lat, pos, vals)
     lat.nr_lattice_vertices()
@@ -33,14 +35,14 @@ for _ in range(reps):
     lat.nr_lattice_vertices()
     torch.cuda.synchronize()
     s = stamps.cpu().numpy().astype(np.float64) / 100.0  # 100 MHz -> microseconds
-    for name, first, last, nwg in (("k_point_keys", 0, 7, None), ("k_bucket_build", 8, 14, None)):
+    for name, first, last, nwg in (("k_point_keys", 0, 7, None), ("k_bucket_rows", 8, 18, None)):
         rows = s[(s[:, first] > 0)]
         t0 = rows[:, first].min()
         rel = rows[:, first:last + 1] - t0
         acc.setdefault(name, []).append(rel)
 lib.ln_debug_set_stamps(None)
 labels = {"k_point_keys": ["start", "clear issued+sync", "keys+LDS rank done", "sync", "scan+global atomics", "sync", "LDS staging+sync", "stores issued (end)"],
-          "k_bucket_build": ["start", "init+loads+sync", "place (LDS CAS/add/min)", "scans", "segment ids", "emit slots", "csr_tok stores (end)"]}
+          "k_bucket_rows": ["start", "init+loads+sync", "place (LDS CAS/add/min)", "scans + publish", "look-back done", "emit slots", "token stores", "(segment ids done, before look-back)", "accumulate: start", "accumulate: gathers consumed", "accumulate: carries done (end)"]}
 for name, runs in acc.items():
     m = np.mean([r.mean(0) for r in runs], 0)
     mx = np.mean([r.max(0) for r in runs], 0)
@@ -52,7 +54,7 @@ for name, runs in acc.items():
         prev = m[k]
 
 # ---- small-filter convolution (forward): one launch, stamps per workgroup
-if hasattr(lib, "ln_debug_set_stamps_conv"):
+if hasattr(lib, "ln_debug_set_stamps_conv") and os.environ.get("LN_TIMELINE_CONV"):
     W = (torch.rand((9 * v, v), device=dev) - 0.5)
     lv, _, idx, w = L.SplatLattice.apply(lat, pos, vals)
     m = lat.nr_lattice_vertices()
