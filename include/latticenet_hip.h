@@ -65,11 +65,11 @@ typedef struct LnTable {
     int* keys;                     /* [capacity,d] row  -> key            (m_keys)    */
     int* nr_filled;                /* [1]                                 (m_nr_filled) */
     int* status;                   /* [1] */
-    int* host_counters;            /* NULL, or 4 ints of pinned, device-visible host memory: every build writes
-                                      {nr_filled, status, host_seq} there from its scan kernel (word 2 last, system-
-                                      scope release).  A host that passes a fresh host_seq per build can spin on word 2
-                                      and read the vertex count as soon as the scan has run, without a copy or an event */
-    int host_seq;                  /* value the build stores in host_counters[2] */
+    int* host_counters;            /* NULL, or 8-byte aligned pinned, device-visible host memory: every build ends with ONE 64-bit store
+                                      there: nr_filled | status << 32 | (host_seq & 0xFFFFFF) << 40.  A host that passes a fresh
+                                      host_seq per build can spin on that word and read the vertex count as soon as the build's last
+                                      kernel has got there, without a copy or an event */
+    int host_seq;                  /* sequence number of this build (24 bits are reported) */
     int key_format;                /* how slot_keys packs a key (fixed for the life of the table's contents): 0 = raw, any integer
                                       tuple (needed by ln_coarsen's target, which receives halved fine keys); 1 = lattice points
                                       only — remainder + quotients, 6-7x the coordinate range for pos_dim 5-6 (every table
@@ -91,8 +91,10 @@ typedef struct LnCsr {
     int* seg_desc;  /* [LN_XCD_GROUPS * seg_region * 4], 16-byte aligned: one descriptor {group, first CSR entry, entries from
                        there to the end of the group, offset of the first entry inside the group} per segment — everything a
                        reduce needs about a segment in ONE 16-byte load; region g holds the segments of XCD group g */
-    int* seg_count; /* [LN_XCD_GROUPS + 1] device-side number of segments per region, then the number of regions in use
-                       (1: everything in region 0 — ln_csr_build, the atomic build path; LN_XCD_GROUPS: bucketed build) */
+    int* seg_count; /* [LN_XCD_GROUPS + 2] device-side number of segments per region, then the number of regions in use
+                       (1: everything in region 0 — ln_csr_build, the atomic build path; LN_XCD_GROUPS: bucketed build with
+                       planes), then the descriptor format: 0 = the first descriptor word is the group; 1 (bucketed build) = it is the
+                       ROW of the group, so a reduce needs no group -> row lookup */
     long long seg_region; /* entries per region (>= ln_csr_max_segments: one region may hold every segment) */
     const int* planes;    /* NULL (everything in region 0), or 7 device ints: split planes of a 3-level kd partition of KEY space
                              into LN_XCD_GROUPS compact regions — key[0] >= planes[0] picks the half, key[1] against
@@ -152,25 +154,11 @@ int ln_build_splat(const LnTable* t, const float* positions_raw, const float* si
  * differs from run to run and nothing downstream depends on it.  The bucketed build numbers them in SLOT order (bucket by
  * bucket, occupied slots in ascending order: deterministic, and the whole build is two launches).  ln_canonicalize relabels
  * the rows of a table that ONE bucketed build has just produced — entries[], keys[] and, when given, the idx[tokens] that
- * build wrote — into first-occurrence order over (point, remainder), i.e. the numbering a serial run of
- * HashTableGPU::insert (HashTableGPU.cuh:425-484) produces and the golden vectors hold.  It must run before anything that
+ * build wrote and the row ids in the segment descriptors of `csr` (may be NULL) — into first-occurrence order over
+ * (point, remainder), i.e. the numbering a serial run of HashTableGPU::insert (HashTableGPU.cuh:425-484) produces and the golden vectors hold.  It must run before anything that
  * stores row ids elsewhere (accumulated values, neighbour lists).  workspace: ln_build_workspace_bytes(tokens, capacity).
  * LN_BUILD_CANONICAL_ROWS makes ln_build_splat / ln_distribute do this themselves. */
-int ln_canonicalize(const LnTable* t, int* idx, long long tokens, void* workspace, size_t workspace_bytes, void* stream);
-
-/* Lattice::splat_standalone (src/Lattice.cu:196-241) in one call: kernel_splat (LatticeGPU.cuh:707-842) + splatCacheNaive
- * (LatticeGPU.cuh:926-973).  ln_build_splat (idx / w always written) followed by
- *     table_values[row(t), j] += values[p, j] * w[t]    for every token t = p*(d+1)+r that was inserted, j < val_dim.
- * `values` is [n, val_dim] fp32, or IEEE fp16 when values_f16 != 0 (accumulation and table_values are fp32 either way).
- * table_values is [table_values_elems / val_dim, val_dim]: with LN_BUILD_CLEAR_FIRST it is zero-filled by this call
- * (begin_splat), otherwise it must hold what is to be added to.  On the bucketed build path with val_dim % 4 == 0 the
- * accumulation happens inside the bucket pass (the workgroup that resolves a bucket holds its tokens in LDS: no second
- * pass over the CSR); on the atomic path, under LN_BUILD_CANONICAL_ROWS, or for other widths it is the segment reduce
- * ln_csr_reduce_rows over the CSR the build emitted.  After a LN_STATUS_BUCKET_OVERFLOW the whole call must be repeated
- * with LN_BUILD_ATOMIC_PATH (and LN_BUILD_CLEAR_FIRST). */
-int ln_splat(const LnTable* t, const float* positions_raw, const float* sigmas_host, const void* values, int val_dim, int values_f16,
-             int n, int* idx, float* w, int flags, const LnCsr* csr, void* workspace, size_t workspace_bytes, float* table_values,
-             long long table_values_elems, void* stream);
+int ln_canonicalize(const LnTable* t, int* idx, long long tokens, const LnCsr* csr, void* workspace, size_t workspace_bytes, void* stream);
 
 /* splatCacheNaive (LatticeGPU.cuh:926-973): table_values[idx] += vals * w. */
 int ln_splat_accumulate(float* table_values, const float* vals, const int* idx, const float* w, int n, int pos_dim,

@@ -144,6 +144,7 @@ __global__ void __launch_bounds__(256)
         seg_count[0] = off_seg[(size_t)nb * seg_stride];
         for (int g = 1; g < LN_XCD_GROUPS; ++g) seg_count[g] = 0;
         seg_count[LN_XCD_GROUPS] = 1;
+        seg_count[LN_XCD_GROUPS + 1] = 0;  // descriptors name groups, weights are read per token
     }
     if (t <= rows_upper) row_start[t] = (t < rows_upper) ? local_tok[t] + off_tok[(size_t)(t / LN_SCAN_BLOCK) * seg_stride] : off_tok[(size_t)nb * seg_stride];
     if (t < tokens) {
@@ -266,6 +267,7 @@ __device__ __forceinline__ void ln_reduce_chunk(const LnSegOfThread& so, const L
     const int grp_in_wave = lane / lanes_per_seg;
     const int groups_per_wave = 64 / lanes_per_seg;
     const bool active = so.active;
+    const bool rows_in_desc = a.seg_count[LN_XCD_GROUPS + 1] & 1;  // (uniform: a scalar load)
     int grp = -1, beg = 0, rbeg = 0, rend = 0, cnt = 0, row = -1;
     if (active) {
         const int4 d = seg_desc[so.sid];  // {group, first entry, entries to the end of the group, offset inside the group}
@@ -276,7 +278,8 @@ __device__ __forceinline__ void ln_reduce_chunk(const LnSegOfThread& so, const L
         rend = beg + d.z;
     }
     const int end = beg + cnt;
-    if (active) row = grp_row ? grp_row[grp] : grp;  // groups are hash slots (row = entries[slot]) or rows themselves
+    // the descriptor names the row itself (bucketed build), a hash slot (row = entries[slot]) or a row-group (ln_csr_build)
+    if (active) row = (rows_in_desc || !grp_row) ? grp : grp_row[grp];
     const int V = chunks * VEC;
     const int nchunk_iter = (chunks + lanes_per_seg - 1) / lanes_per_seg;  // wave-uniform trip count (shuffles inside)
     const bool pow2 = (src_div & (src_div - 1)) == 0;
@@ -486,7 +489,6 @@ extern "C" int ln_splat_accumulate_and_neighbours_f16(const LnCsr* csr, const in
     return ln_splat_tail_impl("ln_splat_accumulate_and_neighbours_f16", csr, grp_row, max_segments, src_f16, true, w, val_dim, src_div, src_stride,
                               dst, table, query_rows_upper, nbr, stream);
 }
-
 // ------------------------------------------------------------------------------------------
 // segment max with argmax (the PointNet aggregation of the reference's first stage:
 // torch_scatter.scatter_max over splat indices, lattice_modules.py:688) and vertex degrees
@@ -516,7 +518,7 @@ __global__ void __launch_bounds__(256)
     if (!so.active) continue;
     const int4 sd = seg_desc[sid];
     const int grp = sd.x;
-    const int row = grp_row ? grp_row[grp] : grp;
+    const int row = ((seg_count[LN_XCD_GROUPS + 1] & 1) || !grp_row) ? grp : grp_row[grp];
     if (row < 0) continue;
     const int beg = sd.y;
     const int end = beg + min(LN_SEG, sd.z);

@@ -83,7 +83,7 @@ LnProfScope::~LnProfScope() {
     }
 }
 
-extern "C" const char* ln_kernel_names(void) { return "k_bucket_rows,k_canon_idx,k_canon_mark,k_canon_slots,k_conv_backward_fused,k_conv_generic,k_conv_generic_f16,k_conv_mfma,k_conv_mfma_f16,k_conv_split_bank,k_conv_sum_partials,k_csr_count,k_csr_fill,k_csr_group_sizes,k_csr_reduce_segments,k_csr_scan_local,k_csr_scan_top,k_csr_segment_max,k_csr_segment_max_decode,k_finalize,k_gather_backward,k_gather_forward,k_gn_apply,k_gn_backward_apply,k_gn_stats,k_grad_filter_f16,k_grad_filter_generic,k_grad_filter_mfma,k_grad_filter_mfma_f16,k_im2row,k_im2rowindices,k_insert_coarse,k_insert_points,k_linear_act_backward_w,k_linear_act_backward_x,k_linear_act_forward,k_linear_reduce_slabs,k_mark_first,k_max_centre_backward,k_max_centre_forward,k_max_centre_sum,k_neighbours,k_point_keys,k_reduce_and_neighbours,k_reduce_slabs,k_reduce_slabs_f32,k_retrieve_points,k_row2im,k_sc_reduce_slabs,k_sc_scatter_atomic,k_scan_blocks,k_scatter_point_rows,k_seg_min,k_slice_classify_backward,k_slice_classify_forward,k_slice_forward,k_slice_forward_f16,k_table_clear"; }
+extern "C" const char* ln_kernel_names(void) { return "k_bucket_rows,k_canon_idx,k_canon_mark,k_canon_segs,k_canon_slots,k_conv_backward_fused,k_conv_generic,k_conv_generic_f16,k_conv_mfma,k_conv_mfma_f16,k_conv_split_bank,k_conv_sum_partials,k_csr_count,k_csr_fill,k_csr_group_sizes,k_csr_reduce_segments,k_csr_scan_local,k_csr_scan_top,k_csr_segment_max,k_csr_segment_max_decode,k_finalize,k_gather_backward,k_gather_forward,k_gn_apply,k_gn_backward_apply,k_gn_stats,k_grad_filter_f16,k_grad_filter_generic,k_grad_filter_mfma,k_grad_filter_mfma_f16,k_im2row,k_im2rowindices,k_insert_coarse,k_insert_points,k_linear_act_backward_w,k_linear_act_backward_x,k_linear_act_forward,k_linear_reduce_slabs,k_mark_first,k_max_centre_backward,k_max_centre_forward,k_max_centre_sum,k_neighbours,k_point_keys,k_reduce_and_neighbours,k_reduce_slabs,k_reduce_slabs_f32,k_retrieve_points,k_row2im,k_sc_reduce_slabs,k_sc_scatter_atomic,k_scan_blocks,k_scatter_point_rows,k_seg_min,k_slice_classify_backward,k_slice_classify_forward,k_slice_forward,k_slice_forward_f16,k_table_clear"; }
 
 extern "C" int ln_profile_begin(const char* kernel_name, int max_samples) {
     LN_REQUIRE(kernel_name && strlen(kernel_name) < sizeof(g_prof.name) && max_samples > 0, LN_ERR_ARG, "ln_profile_begin: bad args");
@@ -171,6 +171,16 @@ static int ln_check_table(const LnTable* t, const char* who) {
     LN_REQUIRE(t->slot_keys && t->slot_tok && t->slot_cnt && t->entries && t->keys && t->nr_filled && t->status, LN_ERR_ARG,
                "%s: table has a null buffer", who);
     return LN_OK;
+}
+
+// {vertex count, status bits, the build's sequence number} as ONE 64-bit word into pinned host memory (LnTable.host_counters):
+// count | status << 32 | seq << 40.  A single aligned 8-byte store needs no release fence in front of it — the fence of the
+// three-word form made the last workgroup of a build write back its whole L2 (buffer_wbl2) twice.
+__device__ __forceinline__ void ln_report_to_host(int* host_counters, int count, int status, int seq) {
+    if (!host_counters) return;
+    const unsigned long long word = (unsigned long long)(unsigned int)count | ((unsigned long long)(status & 0xFF) << 32) |
+                                    ((unsigned long long)(seq & 0xFFFFFF) << 40);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(host_counters), word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -311,8 +321,8 @@ __global__ void __launch_bounds__(256)
 template <int D>
 __global__ void __launch_bounds__(256)
     k_point_keys(LnTable t, const float* __restrict__ pos_raw, LnScale<D> sc, int n, int sb, int nbk, int capb,
-                 int* __restrict__ part_tok, unsigned long long* __restrict__ part_pk, float* __restrict__ part_w,
-                 int* __restrict__ tok_slot, float* __restrict__ w, const float* __restrict__ vals, int val_dim, float* __restrict__ distributed,
+                 int* __restrict__ part_tok, unsigned long long* __restrict__ part_pk, int* __restrict__ tok_slot,
+                 float* __restrict__ w, const float* __restrict__ vals, int val_dim, float* __restrict__ distributed,
                  int* __restrict__ seg_count, int seg_regions, float* __restrict__ clear_values, long long clear_values_elems,
                  unsigned int* __restrict__ pub) {
     __shared__ int s_cnt[LN_BKT_MAX];
@@ -321,14 +331,12 @@ __global__ void __launch_bounds__(256)
     __shared__ unsigned long long s_stage_pk[LN_KEYS_PTS_PER_BLOCK * (D + 1)];
     __shared__ int s_stage_tok[LN_KEYS_PTS_PER_BLOCK * (D + 1)];
     __shared__ int s_stage_dst[LN_KEYS_PTS_PER_BLOCK * (D + 1)];
-    __shared__ float s_stage_w[LN_KEYS_PTS_PER_BLOCK * (D + 1)];  // only used when part_w is asked for (fused accumulate)
     int* cursor = t.slot_cnt;
     LN_STAMP(0);
     for (int b = threadIdx.x; b < nbk; b += 256) s_cnt[b] = 0;
     __syncthreads();
     LN_STAMP(1);
     unsigned long long pk[LN_KEYS_PTS_PER_THREAD][D + 1];
-    float bw[LN_KEYS_PTS_PER_THREAD][D + 1];
     int bkt[LN_KEYS_PTS_PER_THREAD][D + 1];
     int rank[LN_KEYS_PTS_PER_THREAD][D + 1];
     bool bad_key = false;
@@ -358,7 +366,6 @@ __global__ void __launch_bounds__(256)
                 bad_key = true;
                 if (tok_slot) tok_slot[tk] = -1;
             }
-            bw[it][r] = s.bary[r];
             if (w) w[tk] = ok ? s.bary[r] : -1.0f;
             if (distributed) {  // LatticeGPU.cuh:626-637: [pos_scaled(d) | val(V) | bary[r]] per simplex vertex
                 const int row_len = D + val_dim + 1;
@@ -406,7 +413,6 @@ __global__ void __launch_bounds__(256)
             const int j = s_lbase[bkt[it][r]] + rank[it][r];
             s_stage_tok[j] = tk;
             s_stage_pk[j] = pk[it][r];
-            if (part_w) s_stage_w[j] = bw[it][r];
             s_stage_dst[j] = at < capb ? bkt[it][r] * capb + at : -1;  // (regions are < 2^31 entries in total: checked by the host)
         }
     }
@@ -418,7 +424,6 @@ __global__ void __launch_bounds__(256)
         if (dst >= 0) {
             part_tok[dst] = tk;
             part_pk[dst] = s_stage_pk[j];
-            if (part_w) part_w[dst] = s_stage_w[j];
         } else if (tok_slot) {
             tok_slot[tk] = -1;  // region full (heavily skewed cloud): the bucket workgroup reports it, the build is replayed
         }
@@ -435,12 +440,13 @@ __global__ void __launch_bounds__(256)
         }
         const long long nk = (long long)t.capacity * D;
         for (long long i = g; i < nk; i += stride) t.keys[i] = 0;
-        for (long long i = g; i < nbk; i += stride) pub[i] = 0u;  // the bucket workgroups' look-back words (k_bucket_rows)
+        for (long long i = g; i <= nbk; i += stride) pub[i] = 0u;  // the bucket workgroups' look-back words + their ticket counter (k_bucket_rows)
         if (g == 0) {
             *t.nr_filled = 0;
             *t.status = 0;   // later passes (bucket build, scan) raise the error bits of this build
             for (int gi = 0; gi < LN_XCD_GROUPS; ++gi) seg_count[gi] = 0;  // the bucket workgroups of the next launch add to them
             seg_count[LN_XCD_GROUPS] = seg_regions;
+            seg_count[LN_XCD_GROUPS + 1] = 1;  // the segment descriptors of this build carry rows (k_bucket_rows)
         }
     }
     LN_STAMP(7);
@@ -451,8 +457,8 @@ __global__ void __launch_bounds__(256)
 // buckets before this one) + (occupied slots before it inside the bucket).  The only cross-workgroup quantity is that per-
 // bucket count, handed on through `pub` (one word per bucket: ready bit | error bit | count) with relaxed agent-scope
 // atomics — no fence (the word IS the payload), published right after the bucket's scans and read just before the emit
-// phase (decoupled look-back over all earlier buckets; workgroups are dispatched in index order, so a workgroup only ever
-// waits for workgroups that are resident or done).  The last bucket closes the build: nr_filled, status, the pinned host
+// phase (decoupled look-back over all earlier buckets; buckets are handed out as tickets, so a workgroup only ever waits for
+// workgroups that are resident or done).  The last bucket closes the build: nr_filled, status, the pinned host
 // pair, and the bucket cursors back to zero (every workgroup read them before it published).
 // The reference numbers vertices by thread-arrival order (atomicAdd(m_nr_filled), HashTableGPU.cuh:454: not reproducible);
 // ln_canonicalize relabels a table built here into first-occurrence order (= a serial run of the reference) on request.
@@ -463,27 +469,11 @@ __global__ void __launch_bounds__(256)
 #define LN_PUB_READY 0x80000000u
 #define LN_PUB_ERR 0x40000000u
 #define LN_PUB_CNT 0x3FFFFFFFu
-// Fused splat accumulate (ACC = 1: fp32 point rows, 2: fp16 point rows; 0: none).  splatCacheNaive (LatticeGPU.cuh:937-971)
-// done by the workgroup that already holds the bucket's tokens: they are filed slot-sorted in LDS (token, weight), cut into
-// the same <= 16-entry segments as the CSR, and a lane group (val_dim / 4 lanes, float4 each) gathers and sums one segment
-// with LN_ACC_INFLIGHT rows in flight; segments of one vertex that sit side by side in a wave are combined with shuffles,
-// a vertex covered by one run is written with a plain store, longer ones add their runs with global atomics (hot vertices
-// only; the accumulator was zeroed by pass 1).  Tokens filed beyond the LDS list (a bucket with > LN_ACC_LIST tokens) are
-// added one by one with atomics.
-#define LN_ACC_LIST (LN_BKT_REG_TOK * LN_BKT_THREADS)
-#define LN_ACC_INFLIGHT 16
-struct LnAccArgs {
-    int dbg;              // experiments (LN_DEBUG_MASK): 8 = plain stores instead of atomics (wrong sums, timing only)
-    const void* src;      // [n, val_dim] point features (fp32 or fp16)
-    const float* part_w;  // barycentric weight of every partition entry (written by pass 1)
-    float* dst;           // [rows, val_dim] accumulator, zeroed
-    int val_dim;
-};
-template <int D, int ACC>
+template <int D>
 __global__ void __launch_bounds__(LN_BKT_THREADS)
     k_bucket_rows(LnTable t, int sb, int nbk, int capb, int* __restrict__ cursor, const int* __restrict__ part_tok,
                   const unsigned long long* __restrict__ part_pk, int* __restrict__ part_slot, int* __restrict__ part_pos,
-                  int* __restrict__ idx_out, LnCsr csr, unsigned int* __restrict__ pub, LnAccArgs acc) {
+                  int* __restrict__ idx_out, LnCsr csr, unsigned int* __restrict__ pub) {
     extern __shared__ unsigned long long s_mem[];
     unsigned long long* skeys = s_mem;
     int* scnt = reinterpret_cast<int*>(skeys + sb);
@@ -491,24 +481,28 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
     int* soff = reinterpret_cast<int*>(smin + sb);
     int* sseg = soff + sb;
     int* srow = sseg + sb;
-    int* l_tok = srow + sb;                                                              // [LN_ACC_LIST]   (ACC only)
-    float* l_w = reinterpret_cast<float*>(l_tok + LN_ACC_LIST);                          // [LN_ACC_LIST]
-    unsigned short* l_slot = reinterpret_cast<unsigned short*>(l_w + LN_ACC_LIST);       // [LN_ACC_LIST]
     __shared__ int s_wave_tok[16], s_wave_seg[16], s_wave_new[16];
     __shared__ int s_run_tok, s_run_seg, s_run_new, s_err;
     __shared__ int s_rcnt[LN_XCD_GROUPS], s_rbase[LN_XCD_GROUPS];
+    __shared__ int s_ticket;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int b = blockIdx.x;
-    const int lo = b * sb;
-    const int size = min(sb, t.capacity - lo);
+    // The bucket is NOT blockIdx.x: it is a ticket taken when the workgroup starts running.  Whoever holds ticket b knows that
+    // the holders of all smaller tickets are resident (or done), whatever order workgroups are dispatched in and however other
+    // kernels share the CUs — with blockIdx.x as the bucket, three of these kernels running side by side on different queues
+    // can fill one XCD each with workgroups that wait for a bucket whose workgroup has nowhere to go (measured: a 0.6 s stall).
+    if (tid == 0) s_ticket = atomicAdd(reinterpret_cast<int*>(&pub[nbk]), 1);
     LN_STAMP(8);
-    for (int i = tid; i < size; i += LN_BKT_THREADS) {
+    for (int i = tid; i < sb; i += LN_BKT_THREADS) {  // (while the ticket is in flight)
         skeys[i] = LN_EMPTY_KEY;  // the table was cleared by this build call
         scnt[i] = 0;
         smin[i] = LN_EMPTY_TOK;
     }
+    __syncthreads();
+    const int b = s_ticket;
+    const int lo = b * sb;
+    const int size = min(sb, t.capacity - lo);
     // CSR offset of this bucket = tokens of all buckets before it
     int before = 0;
     for (int i = tid; i < b; i += LN_BKT_THREADS) before += min(cursor[i], capb);
@@ -528,7 +522,6 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
     // issue the loads of the register-resident tokens before the barrier
     int r_tk[LN_BKT_REG_TOK], r_ls[LN_BKT_REG_TOK], r_pos[LN_BKT_REG_TOK];
     unsigned long long r_pk[LN_BKT_REG_TOK];
-    float r_w[LN_BKT_REG_TOK];
 #pragma unroll
     for (int k = 0; k < LN_BKT_REG_TOK; ++k) {
         const int j = tid + k * LN_BKT_THREADS;
@@ -536,8 +529,6 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
         r_pos[k] = -1;
         r_tk[k] = j < ntok ? part_tok[in0 + j] : -1;
         r_pk[k] = j < ntok ? part_pk[in0 + j] : LN_EMPTY_KEY;
-        r_w[k] = 0.f;
-        if constexpr (ACC != 0) r_w[k] = j < ntok ? acc.part_w[in0 + j] : 0.f;
     }
     __syncthreads();  // (every cursor[] load of this workgroup has returned by now: the last bucket relies on it)
     int base = 0;
@@ -659,29 +650,6 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
     if (tid == 0)
         __hip_atomic_store(&pub[b], LN_PUB_READY | (s_err ? LN_PUB_ERR : 0u) | (unsigned int)s_run_new, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
-    if constexpr (ACC != 0) {
-        // slot-sorted (token, weight, slot) list
-#pragma unroll
-        for (int k = 0; k < LN_BKT_REG_TOK; ++k) {
-            if (r_ls[k] < 0) continue;
-            const int q = soff[r_ls[k]] + r_pos[k];
-            if (q < LN_ACC_LIST) {
-                l_tok[q] = r_tk[k];
-                l_w[q] = r_w[k];
-                l_slot[q] = (unsigned short)r_ls[k];
-            }
-        }
-        for (int j = tid + LN_BKT_REG_TOK * LN_BKT_THREADS; j < ntok; j += LN_BKT_THREADS) {  // (this thread wrote part_slot / part_pos [j])
-            const int ls = part_slot[in0 + j];
-            if (ls < 0) continue;
-            const int q = soff[ls] + part_pos[in0 + j];
-            if (q < LN_ACC_LIST) {
-                l_tok[q] = part_tok[in0 + j];
-                l_w[q] = acc.part_w[in0 + j];
-                l_slot[q] = (unsigned short)ls;
-            }
-        }
-    }
     LN_STAMP(11);
     // Segment ids.  Without region planes: one contiguous run of region 0 per bucket.  With planes: every slot files its
     // segments under the kd region of its key (sseg[i] becomes region << 28 | position among this bucket's segments of that
@@ -764,7 +732,7 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
         const int sr = planes ? (sseg[i] >> 28) : 0;
         long long sid = (long long)sr * csr.seg_region + s_rbase[sr] + (planes ? (sseg[i] & 0x0FFFFFFF) : sseg[i]);
         for (int e = 0; e < c; e += LN_CSR_SEG, ++sid)
-            reinterpret_cast<int4*>(csr.seg_desc)[sid] = make_int4(h, beg + e, c - e, e);
+            reinterpret_cast<int4*>(csr.seg_desc)[sid] = make_int4(row, beg + e, c - e, e);  // {ROW, first entry, entries to the end, offset}
     }
     if (b == nbk - 1) {  // close the build
         if (tid == 0) {
@@ -773,12 +741,7 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
             int bits = (err_all ? LN_STATUS_BUCKET_OVERFLOW : 0) | (cursor[nbk] ? LN_STATUS_KEY_RANGE : 0);
             *t.nr_filled = total;
             if (bits) atomicOr(t.status, bits);
-            if (t.host_counters) {  // pinned host memory: the host spins on word 2 (it cleared it before the launch)
-                t.host_counters[0] = total;
-                t.host_counters[1] = bits;
-                __threadfence_system();
-                __hip_atomic_store(&t.host_counters[2], t.host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
+            ln_report_to_host(t.host_counters, total, bits, t.host_seq);
         }
         __syncthreads();  // (tid 0 has read cursor[nbk])
         for (int i = tid; i <= nbk; i += LN_BKT_THREADS) cursor[i] = 0;  // all-zero between builds; every reader has published
@@ -797,136 +760,6 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
         if (ls >= 0) csr.csr_tok[base + soff[ls] + part_pos[in0 + j]] = tk;
         if (idx_out) idx_out[tk] = ls >= 0 ? srow[ls] : -1;
     }
-    if constexpr (ACC != 0) {
-        constexpr bool HALF = ACC == 2;
-        const float* __restrict__ src = static_cast<const float*>(acc.src);
-        const _Float16* __restrict__ src16 = static_cast<const _Float16*>(acc.src);
-        const int V = acc.val_dim;
-        // tokens filed beyond the LDS list: one by one (first: the register-resident tokens die here)
-        auto add_token = [&](int tk, int ls, int pos, float wt) {
-            if (ls < 0 || soff[ls] + pos < LN_ACC_LIST || srow[ls] < 0) return;
-            float* d = acc.dst + (size_t)srow[ls] * V;
-            const size_t off = (size_t)(tk / (D + 1)) * V;
-            for (int ch = 0; ch < V; ++ch) {
-                const float xv = HALF ? (float)src16[off + ch] : src[off + ch];
-                __hip_atomic_fetch_add(d + ch, xv * wt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        };
-        if (ntok > LN_ACC_LIST) {
-#pragma unroll
-            for (int k = 0; k < LN_BKT_REG_TOK; ++k)
-                if (r_tk[k] >= 0) add_token(r_tk[k], r_ls[k], r_pos[k], r_w[k]);
-            for (int j = tid + LN_BKT_REG_TOK * LN_BKT_THREADS; j < ntok; j += LN_BKT_THREADS)
-                add_token(part_tok[in0 + j], part_slot[in0 + j], part_pos[in0 + j], acc.part_w[in0 + j]);
-        }
-        const int chunks = V >> 2;
-        int lps = 1;
-        while (lps < chunks) lps <<= 1;  // lanes per lane group (<= 64: val_dim <= 256, checked by the host)
-        const int gpw = 64 / lps;        // lane groups per wave
-        const int gpb = LN_BKT_THREADS / lps;
-        const int lc = tid & (lps - 1);
-        const int gw = lane / lps;
-        const bool lane_ok = lc < chunks;
-        LN_STAMP(16);
-        // Token-parallel: the list is cut into gpb equal runs of T consecutive entries, one per lane group, whatever the slot
-        // boundaries — every lane has the same number of row gathers and issues them all before it consumes the first.
-        const int nlist = min(placed, LN_ACC_LIST);
-        const int T = (nlist + gpb - 1) / gpb;
-        const int qb = min((tid / lps) * T, nlist), qe = min(qb + T, nlist);
-        // A run of entries of one slot that ends is written out: plain store when it holds every token of the slot, atomics
-        // otherwise (the slot continues in another wave, or beyond the list).
-        auto flush = [&](int slot, int start, int end, float f0, float f1, float f2, float f3) {
-            const int row = srow[slot];
-            if (row < 0 || !lane_ok) return;
-            float* d = acc.dst + (size_t)row * V + lc * 4;
-            const int so = soff[slot];
-            if ((start == so && end == so + scnt[slot]) || acc.dbg) {
-                *reinterpret_cast<float4*>(d) = make_float4(f0, f1, f2, f3);
-            } else {
-                __hip_atomic_fetch_add(d + 0, f0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_fetch_add(d + 1, f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_fetch_add(d + 2, f2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_fetch_add(d + 3, f3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        };
-        // leading run of this lane group's entries when its slot began before them (waits for the carry of the group in front)
-        bool have_l = false;
-        int l_s = -1, l_end = 0;
-        float l0 = 0.f, l1 = 0.f, l2 = 0.f, l3 = 0.f;
-        // current (finally: trailing) run
-        int cur = -1, cstart = qb;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        for (int q = qb; q < qe; q += LN_ACC_INFLIGHT) {
-            float x[LN_ACC_INFLIGHT][4];
-#pragma unroll
-            for (int u = 0; u < LN_ACC_INFLIGHT; ++u) {
-                const bool ok = q + u < qe && lane_ok;
-                const int tk = ok ? l_tok[q + u] : 0;
-                const size_t off = (size_t)(tk / (D + 1)) * V + lc * 4;
-                if constexpr (HALF) {
-                    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-                    const h4 v4 = ok ? *reinterpret_cast<const h4*>(src16 + off) : h4{0, 0, 0, 0};
-                    x[u][0] = (float)v4[0]; x[u][1] = (float)v4[1]; x[u][2] = (float)v4[2]; x[u][3] = (float)v4[3];
-                } else {
-                    const float4 v4 = ok ? *reinterpret_cast<const float4*>(src + off) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    x[u][0] = v4.x; x[u][1] = v4.y; x[u][2] = v4.z; x[u][3] = v4.w;
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < LN_ACC_INFLIGHT; ++u) {
-                if (q + u >= qe) continue;
-                const int sl = l_slot[q + u];  // (weights and slots are re-read from LDS here rather than held in registers across the gathers)
-                const float wt = l_w[q + u];
-                if (sl != cur) {
-                    if (cur >= 0) {  // the run of `cur` ended inside this lane group's entries
-                        if (cstart == qb && soff[cur] < qb) {
-                            have_l = true; l_s = cur; l_end = q + u; l0 = a0; l1 = a1; l2 = a2; l3 = a3;
-                        } else {
-                            flush(cur, cstart, q + u, a0, a1, a2, a3);
-                        }
-                    }
-                    cur = sl;
-                    cstart = q + u;
-                    a0 = a1 = a2 = a3 = 0.f;
-                }
-                a0 = fmaf(x[u][0], wt, a0);
-                a1 = fmaf(x[u][1], wt, a1);
-                a2 = fmaf(x[u][2], wt, a2);
-                a3 = fmaf(x[u][3], wt, a3);
-            }
-        }
-        LN_STAMP(17);
-        // Hand the open runs along the wave, lane group by lane group: the trailing run of one group continues as the leading
-        // run of the next when both belong to one slot (69 % of the C3 scan's tokens sit on vertices with more than 16 of them).
-        const bool pass_through = cur >= 0 && cstart == qb && soff[cur] < qb;  // all my entries are one slot that began before them
-        int c_s = -1, c_start = 0, c_end = 0;  // incoming carry
-        float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
-        for (int step = 0; step < gpw; ++step) {  // wave-uniform
-            int o_s = -1, o_start = 0, o_end = 0;
-            float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
-            if (gw == step) {
-                if (have_l) {
-                    int st = qb;
-                    if (c_s == l_s) { l0 += c0; l1 += c1; l2 += c2; l3 += c3; st = c_start; }
-                    else if (c_s >= 0) flush(c_s, c_start, c_end, c0, c1, c2, c3);
-                    flush(l_s, st, l_end, l0, l1, l2, l3);
-                } else if (pass_through && c_s == cur) {
-                    a0 += c0; a1 += c1; a2 += c2; a3 += c3;
-                    cstart = c_start;
-                } else if (c_s >= 0) {
-                    flush(c_s, c_start, c_end, c0, c1, c2, c3);
-                }
-                if (cur >= 0) { o_s = cur; o_start = cstart; o_end = qe; o0 = a0; o1 = a1; o2 = a2; o3 = a3; }
-                if (step == gpw - 1 && o_s >= 0) flush(o_s, o_start, o_end, o0, o1, o2, o3);  // last group of the wave: nobody to hand it to
-            }
-            if (step + 1 < gpw) {
-                const int n_s = __shfl_up(o_s, lps, 64), n_start = __shfl_up(o_start, lps, 64), n_end = __shfl_up(o_end, lps, 64);
-                const float n0 = __shfl_up(o0, lps, 64), n1 = __shfl_up(o1, lps, 64), n2 = __shfl_up(o2, lps, 64), n3 = __shfl_up(o3, lps, 64);
-                if (gw == step + 1) { c_s = n_s; c_start = n_start; c_end = n_end; c0 = n0; c1 = n1; c2 = n2; c3 = n3; }
-            }
-        }
-    }
-    LN_STAMP(18);
     for (int j = placed + tid; j < ntok; j += LN_BKT_THREADS)
         csr.csr_tok[base + j] = -1;  // only after an overflow: keeps readers in bounds until the rebuild
     LN_STAMP(14);
@@ -1075,12 +908,7 @@ __global__ void __launch_bounds__(1024) k_scan_blocks(const int* __restrict__ bl
     }
     if (tid == 0 && !relabel) {
         *nr_filled = base + s_running;
-        if (host_counters) {  // pinned host memory: the host spins on word 2 (it cleared it before the launch)
-            host_counters[0] = base + s_running;
-            host_counters[1] = *status;  // every producer kernel ran before this one
-            __threadfence_system();
-            __hip_atomic_store(&host_counters[2], host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
+        ln_report_to_host(host_counters, base + s_running, *status, host_seq);  // (every producer kernel ran before this one)
     }
 }
 
@@ -1149,8 +977,7 @@ struct BuildWs {
     int* part_tok;
     int* part_slot;
     int* part_pos;
-    float* part_w;      // barycentric weight per entry (fused accumulate only)
-    unsigned int* pub;  // [buckets] look-back words of k_bucket_rows
+    unsigned int* pub;  // [buckets + 1] look-back words of k_bucket_rows, then its ticket counter
 };
 
 static size_t ln_align256(size_t x) { return (x + 255) & ~size_t(255); }
@@ -1172,8 +999,8 @@ extern "C" size_t ln_build_workspace_bytes(long long tokens, int capacity) {
     const size_t region = (size_t)ln_bucket_count(capacity) * ln_bucket_region(tokens, capacity);
     return ln_align256(nb * 4 * sizeof(unsigned long long)) + 2 * ln_align256(nb * sizeof(int)) +
            2 * ln_align256((size_t)tokens * sizeof(int)) + ln_align256(ln_csr_scan_workspace_bytes(capacity)) +
-           ln_align256(region * sizeof(unsigned long long)) + 4 * ln_align256(region * sizeof(int)) +
-           ln_align256((size_t)ln_bucket_count(capacity) * sizeof(unsigned int));
+           ln_align256(region * sizeof(unsigned long long)) + 3 * ln_align256(region * sizeof(int)) +
+           ln_align256(((size_t)ln_bucket_count(capacity) + 1) * sizeof(unsigned int));
 }
 
 static int ln_carve_ws(long long tokens, int capacity, void* workspace, size_t bytes, BuildWs& ws) {
@@ -1206,8 +1033,6 @@ static int ln_carve_ws(long long tokens, int capacity, void* workspace, size_t b
     p += ln_align256(region * sizeof(int));
     ws.part_pos = reinterpret_cast<int*>(p);
     p += ln_align256(region * sizeof(int));
-    ws.part_w = reinterpret_cast<float*>(p);
-    p += ln_align256(region * sizeof(float));
     ws.pub = reinterpret_cast<unsigned int*>(p);
     return LN_OK;
 }
@@ -1263,6 +1088,17 @@ __global__ void __launch_bounds__(256)
     for (int i = 0; i < D; ++i) t.keys[(size_t)row * D + i] = key[i];
 }
 
+// the bucketed build's segment descriptors carry rows (LnCsr.seg_count): relabel them as well
+__global__ void __launch_bounds__(256) k_canon_segs(int4* __restrict__ seg_desc, const int* __restrict__ seg_count, long long seg_region,
+                                                    const int* __restrict__ perm) {
+    const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int region = int(g / seg_region);
+    const long long s = g - (long long)region * seg_region;
+    if (region >= seg_count[LN_XCD_GROUPS] || s >= seg_count[region] || !(seg_count[LN_XCD_GROUPS + 1] & 1)) return;
+    const int r = seg_desc[g].x;
+    if (r >= 0) seg_desc[g].x = perm[r];
+}
+
 __global__ void __launch_bounds__(256) k_canon_idx(int* __restrict__ idx, long long tokens, const int* __restrict__ perm) {
     const long long tk = (long long)blockIdx.x * 256 + threadIdx.x;
     if (tk >= tokens) return;
@@ -1271,7 +1107,7 @@ __global__ void __launch_bounds__(256) k_canon_idx(int* __restrict__ idx, long l
 }
 
 template <int D>
-static int ln_canonicalize_impl(const LnTable& t, int* idx, long long tokens, const BuildWs& ws, hipStream_t st) {
+static int ln_canonicalize_impl(const LnTable& t, int* idx, long long tokens, const LnCsr* csr, const BuildWs& ws, hipStream_t st) {
     if (hipMemsetAsync(ws.bitmap, 0, (size_t)ws.nb * 4 * sizeof(unsigned long long), st) != hipSuccess) return ln_check_launch("ln_canonicalize(memset)");
     const int slot_blocks = ln_div_up(t.capacity, 256);
     LN_LAUNCH("k_canon_mark", k_canon_mark, dim3(slot_blocks), dim3(256), 0, st, t, ws.bitmap);
@@ -1279,6 +1115,9 @@ static int ln_canonicalize_impl(const LnTable& t, int* idx, long long tokens, co
               (int*)nullptr, 0, 1);
     LN_LAUNCH("k_canon_slots", k_canon_slots<D>, dim3(slot_blocks), dim3(256), 0, st, t, ws.bitmap, ws.block_prefix, ws.tok_pos);
     if (idx) LN_LAUNCH("k_canon_idx", k_canon_idx, dim3(ws.nb), dim3(256), 0, st, idx, tokens, ws.tok_pos);
+    if (csr && csr->seg_desc && csr->seg_count)
+        LN_LAUNCH("k_canon_segs", k_canon_segs, dim3(ln_div_up((long long)LN_XCD_GROUPS * csr->seg_region, 256)), dim3(256), 0, st,
+                  reinterpret_cast<int4*>(csr->seg_desc), csr->seg_count, csr->seg_region, ws.tok_pos);
     return ln_check_launch("ln_canonicalize");
 }
 
@@ -1287,14 +1126,9 @@ static int ln_check_csr(const LnCsr* c, const char* who) {
     return LN_OK;
 }
 
-// `acc_src` != NULL (ln_splat): also accumulate the point features onto the vertices, acc_dst[row] += feature * weight —
-// inside the bucket pass when the build is bucketed (*accumulated = 1), otherwise left to the caller (*accumulated = 0).
 static int ln_build_points(const LnTable* t, const float* positions_raw, const float* sigmas_host, int n, int* idx, float* w,
                            int flags, const float* vals, int val_dim, float* distributed, const LnCsr* csr, void* workspace,
-                           size_t workspace_bytes, float* clear_values, long long clear_values_elems, void* stream, const char* who,
-                           const void* acc_src = nullptr, int acc_half = 0, int acc_val_dim = 0, float* acc_dst = nullptr,
-                           int* accumulated = nullptr) {
-    if (accumulated) *accumulated = 0;
+                           size_t workspace_bytes, float* clear_values, long long clear_values_elems, void* stream, const char* who) {
     int rc = ln_check_table(t, who);
     if (rc) return rc;
     rc = ln_check_csr(csr, who);
@@ -1332,27 +1166,13 @@ static int ln_build_points(const LnTable* t, const float* positions_raw, const f
             const int nbk = ln_bucket_count(t->capacity);
             const size_t lds = bucket_lds;
             int* dropped_idx = write_idx ? idx : (int*)nullptr;  // tokens that never reach a bucket get idx = -1 in pass 1
-            // fused accumulate: float4 lanes along a feature row, slot-order rows (a relabelling pass would move the rows afterwards)
-            const bool fuse = acc_src && acc_dst && acc_val_dim % 4 == 0 && acc_val_dim <= 256 && !(flags & LN_BUILD_CANONICAL_ROWS) &&
-                              (reinterpret_cast<uintptr_t>(acc_src) & (acc_half ? 7 : 15)) == 0 && (reinterpret_cast<uintptr_t>(acc_dst) & 15) == 0 &&
-                              !(ln_debug_mask() & 4);
-            const size_t lds_acc = fuse ? (size_t)LN_ACC_LIST * (4 + 4 + 2) : 0;
             LN_LAUNCH("k_point_keys", k_point_keys<D>, dim3(ln_div_up(n, LN_KEYS_PTS_PER_BLOCK)), dim3(256), 0, st, *t, positions_raw, sc, n, sb,
-                      nbk, ws.capb, ws.part_tok, ws.part_pk, fuse ? ws.part_w : (float*)nullptr, dropped_idx, write_idx ? w : (float*)nullptr, vals,
-                      val_dim, distributed, csr->seg_count, csr->planes ? LN_XCD_GROUPS : 1, clear_values, clear_values_elems, ws.pub);
-            const LnAccArgs aa{ln_debug_mask() & 8, acc_src, ws.part_w, acc_dst, acc_val_dim};
-            if (fuse && acc_half)
-                LN_LAUNCH("k_bucket_rows", (k_bucket_rows<D, 2>), dim3(nbk), dim3(LN_BKT_THREADS), lds + lds_acc, st, *t, sb, nbk, ws.capb, t->slot_cnt,
-                          ws.part_tok, ws.part_pk, ws.part_slot, ws.part_pos, dropped_idx, *csr, ws.pub, aa);
-            else if (fuse)
-                LN_LAUNCH("k_bucket_rows", (k_bucket_rows<D, 1>), dim3(nbk), dim3(LN_BKT_THREADS), lds + lds_acc, st, *t, sb, nbk, ws.capb, t->slot_cnt,
-                          ws.part_tok, ws.part_pk, ws.part_slot, ws.part_pos, dropped_idx, *csr, ws.pub, aa);
-            else
-                LN_LAUNCH("k_bucket_rows", (k_bucket_rows<D, 0>), dim3(nbk), dim3(LN_BKT_THREADS), lds, st, *t, sb, nbk, ws.capb, t->slot_cnt,
-                          ws.part_tok, ws.part_pk, ws.part_slot, ws.part_pos, dropped_idx, *csr, ws.pub, aa);
-            if (fuse && accumulated) *accumulated = 1;
+                      nbk, ws.capb, ws.part_tok, ws.part_pk, dropped_idx, write_idx ? w : (float*)nullptr, vals, val_dim, distributed,
+                      csr->seg_count, csr->planes ? LN_XCD_GROUPS : 1, clear_values, clear_values_elems, ws.pub);
+            LN_LAUNCH("k_bucket_rows", k_bucket_rows<D>, dim3(nbk), dim3(LN_BKT_THREADS), lds, st, *t, sb, nbk, ws.capb, t->slot_cnt,
+                      ws.part_tok, ws.part_pk, ws.part_slot, ws.part_pos, dropped_idx, *csr, ws.pub);
             rc = ln_check_launch(who);
-            if (rc == LN_OK && (flags & LN_BUILD_CANONICAL_ROWS)) rc = ln_canonicalize_impl<D>(*t, dropped_idx, tokens, ws, st);
+            if (rc == LN_OK && (flags & LN_BUILD_CANONICAL_ROWS)) rc = ln_canonicalize_impl<D>(*t, dropped_idx, tokens, csr, ws, st);
         } else {
             LN_LAUNCH("k_insert_points", k_insert_points<D>, dim3(ln_div_up(tokens, 256)), dim3(256), 0, st, *t, positions_raw, sc, n, tok_slot,
                       ws.tok_pos, write_idx ? w : (float*)nullptr, vals, val_dim, distributed);
@@ -1369,25 +1189,6 @@ extern "C" int ln_build_splat(const LnTable* t, const float* positions_raw, cons
                            clear_values, clear_values_elems, stream, "ln_build_splat");
 }
 
-extern "C" int ln_splat(const LnTable* t, const float* positions_raw, const float* sigmas_host, const void* values, int val_dim,
-                        int values_f16, int n, int* idx, float* w, int flags, const LnCsr* csr, void* workspace, size_t workspace_bytes,
-                        float* table_values, long long table_values_elems, void* stream) {
-    LN_REQUIRE(n == 0 || (values && table_values && idx && w), LN_ERR_ARG, "ln_splat: null buffer");
-    LN_REQUIRE(val_dim >= 1, LN_ERR_ARG, "ln_splat: val_dim=%d", val_dim);
-    LN_REQUIRE(t && table_values_elems >= 0 && (table_values_elems % val_dim) == 0, LN_ERR_ARG, "ln_splat: table_values_elems is not a whole number of rows");
-    int accumulated = 0;
-    const bool clear = (flags & LN_BUILD_CLEAR_FIRST) != 0;
-    int rc = ln_build_points(t, positions_raw, sigmas_host, n, idx, w, flags | LN_BUILD_WRITE_IDX, nullptr, 0, nullptr, csr, workspace, workspace_bytes,
-                             clear ? table_values : (float*)nullptr, clear ? table_values_elems : 0, stream, "ln_splat", values, values_f16, val_dim,
-                             table_values, &accumulated);
-    if (rc || accumulated || n == 0) return rc;
-    // atomic build path / relabelled rows / odd feature widths: the segment reduce over the CSR this build emitted (groups = slots)
-    const long long max_seg = ln_csr_max_segments((long long)n * (t->pos_dim + 1), t->capacity);
-    if (values_f16)
-        return ln_csr_reduce_rows_f16(csr, t->entries, max_seg, values, w, val_dim, t->pos_dim + 1, val_dim, table_values, stream);
-    return ln_csr_reduce_rows(csr, t->entries, max_seg, static_cast<const float*>(values), w, val_dim, t->pos_dim + 1, val_dim, table_values, stream);
-}
-
 extern "C" int ln_distribute(const LnTable* t, const float* positions_raw, const float* sigmas_host, const float* vals, int n,
                              int val_dim, int* idx, float* w, float* distributed, int flags, const LnCsr* csr, void* workspace,
                              size_t workspace_bytes, float* clear_values, long long clear_values_elems, void* stream) {
@@ -1397,7 +1198,8 @@ extern "C" int ln_distribute(const LnTable* t, const float* positions_raw, const
                            workspace_bytes, clear_values, clear_values_elems, stream, "ln_distribute");
 }
 
-extern "C" int ln_canonicalize(const LnTable* t, int* idx, long long tokens, void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int ln_canonicalize(const LnTable* t, int* idx, long long tokens, const LnCsr* csr, void* workspace, size_t workspace_bytes,
+                               void* stream) {
     int rc = ln_check_table(t, "ln_canonicalize");
     if (rc) return rc;
     LN_REQUIRE(tokens >= 0, LN_ERR_ARG, "ln_canonicalize: tokens=%lld", tokens);
@@ -1405,7 +1207,7 @@ extern "C" int ln_canonicalize(const LnTable* t, int* idx, long long tokens, voi
     BuildWs ws;
     rc = ln_carve_ws(tokens, t->capacity, workspace, workspace_bytes, ws);
     if (rc) return rc;
-    LN_DISPATCH_D(t->pos_dim, { rc = ln_canonicalize_impl<D>(*t, idx, tokens, ws, (hipStream_t)stream); });
+    LN_DISPATCH_D(t->pos_dim, { rc = ln_canonicalize_impl<D>(*t, idx, tokens, csr, ws, (hipStream_t)stream); });
     return rc;
 }
 

@@ -190,7 +190,7 @@ class HashTable:
                 self._pinned = _static_pinned()
             else:
                 self._pinned = torch.zeros((4,), dtype=torch.int32, pin_memory=True)
-            self._pinned_np = self._pinned.numpy()  # same memory: the host polls word 2
+            self._pinned_np = self._pinned.numpy().view("int64")  # same memory: the host polls the build's 64-bit report word
             self._readback_event = torch.cuda.Event()
         key = (s.uid, self._counters.data_ptr(), self._static_rows)
         if getattr(self, "_c_table_key", None) == key:
@@ -231,7 +231,7 @@ class HashTable:
     def arm_count_readback(self):
         """Call right before a build is issued (after c_table()): gives the build a fresh sequence number, which its scan
         kernel stores behind the counters; read_counters() spins until it sees that number."""
-        self._host_seq = (getattr(self, "_host_seq", 0) % 0x3FFFFFFF) + 1
+        self._host_seq = (getattr(self, "_host_seq", 0) % 0xFFFFFF) + 1  # (24 bits travel back in the report word)
         self._c_table.host_seq = self._host_seq
 
     def start_count_readback(self):
@@ -248,15 +248,18 @@ class HashTable:
         self.flush()
         if getattr(self, "_readback_pending", False):
             self._readback_pending = False
-            arr = self._pinned_np
+            arr = self._pinned_np  # int64 view: nr_filled | status << 32 | seq << 40, ONE device store per build
             spins = 0
             seq = self._host_seq
-            while arr[2] != seq:
+            word = int(arr[0])
+            while ((word >> 40) & 0xFFFFFF) != seq:
                 spins += 1
                 if spins > 20000:  # ~ms: fall back to the event (a build that failed to launch, exotic memory settings)
                     self._readback_event.synchronize()
+                    word = int(arr[0])
                     break
-            return [int(arr[0]), int(arr[1])]
+                word = int(arr[0])
+            return [word & 0xFFFFFFFF, (word >> 32) & 0xFF]
         return self._counters.tolist()
 
     def take_pending_clear(self):
@@ -448,12 +451,12 @@ class Lattice:
             self.m_hash_table.init(pos_dim, val_dim, self._dev(like))
 
     def _alloc_csr(self, tokens: int, groups_upper: int, planes=None):
-        """One int32 allocation: seg_desc[G*S*4] (16-byte aligned) | grp_start[groups+1] | csr_tok[tokens] | seg_count[G+1]
+        """One int32 allocation: seg_desc[G*S*4] (16-byte aligned) | grp_start[groups+1] | csr_tok[tokens] | seg_count[G+2]
         (G = LN_XCD_GROUPS segment regions of S = max_segments descriptors each)."""
         max_seg = _build_sizes(tokens, groups_upper)[2]
         tk = max(tokens, 1)
         G = _lib.LN_XCD_GROUPS
-        buf = torch.empty((4 * G * max_seg + groups_upper + 1 + tk + G + 1,), dtype=torch.int32, device=self._dev())
+        buf = torch.empty((4 * G * max_seg + groups_upper + 1 + tk + G + 2,), dtype=torch.int32, device=self._dev())
         base = buf.data_ptr()  # torch allocations are at least 256-byte aligned
         o1 = 4 * G * max_seg
         o2 = o1 + groups_upper + 1
@@ -461,9 +464,7 @@ class Lattice:
         c = _lib.LnCsr(base + 4 * o1, base + 4 * o2, base, base + 4 * o3, max_seg, _lib.ptr(planes))
         return buf, c, max_seg
 
-    def _build(self, positions_raw, write: bool, vals=None, distributed=None, splat_values=None):
-        """One build call.  `splat_values` (splat_standalone): point features to accumulate onto the vertices in the same C call
-        (ln_splat: build + splatCacheNaive), into the table's value tensor."""
+    def _build(self, positions_raw, write: bool, vals=None, distributed=None):
         n, d = positions_raw.shape
         dev = self._dev(positions_raw)
         ht = self.m_hash_table
@@ -488,13 +489,7 @@ class Lattice:
                 flags |= _lib.LN_BUILD_CANONICAL_ROWS
             cv, cn = _lib.ptr(clear_vals), (0 if clear_vals is None else clear_vals.numel())
             ht.arm_count_readback()  # t is ht's cached struct: the sequence number travels in it
-            if splat_values is not None:
-                tv = ht.m_values_tensor  # zero-filled by this call when the deferred clear rides in it (cv is tv then), else already zero
-                rc = lib.ln_splat(C.byref(t), _lib.ptr(positions_raw), self._sigmas_host(), _lib.ptr(splat_values), splat_values.shape[1],
-                                  1 if splat_values.dtype == torch.float16 else 0, n, _lib.ptr(idx), _lib.ptr(w), flags, C.byref(csr), _lib.ptr(ws),
-                                  ws.numel(), _lib.ptr(tv), tv.numel(), self._stream())
-                _lib.check(rc, "ln_splat")
-            elif distributed is None:
+            if distributed is None:
                 rc = lib.ln_build_splat(C.byref(t), _lib.ptr(positions_raw), self._sigmas_host(), n, _lib.ptr(idx), _lib.ptr(w), flags,
                                         C.byref(csr), _lib.ptr(ws), ws.numel(), cv, cn, self._stream())
                 _lib.check(rc, "ln_build_splat")
@@ -617,10 +612,10 @@ class Lattice:
             ht.m_values_tensor = torch.empty((cap, v), dtype=torch.float32, device=self._dev(positions_raw)) if pending else \
                 torch.zeros((cap, v), dtype=torch.float32, device=self._dev(positions_raw))
             ht._clear_pending = pending  # a deferred begin_splat clear zeroes the new accumulator inside the build call
-        # kernel_splat + splatCacheNaive (LatticeGPU.cuh:707-842, 926-973) in one C call; begin_splat zeroed the table values
-        idx, w = self._build(positions_raw, True, splat_values=values)
-        if self.prefetch_neighbours:
-            self._after_build(lambda: self._prefetch_neighbours(n * (d + 1)))
+        idx, w = self._build(positions_raw, True)
+        tv = ht.m_values_tensor
+        # splatCacheNaive (LatticeGPU.cuh:926-973) as a token-balanced reduce; begin_splat zeroed the table values
+        self._after_build(lambda: self._accumulate_and_prefetch(values, idx, w, tv, v, d + 1, n * (d + 1)))
         return idx, w
 
     def just_create_verts(self, positions_raw: torch.Tensor, return_indices_and_weights: bool):  # Lattice.cu:244-290
@@ -1244,7 +1239,8 @@ class Lattice:
         arr = getattr(ht, "_pinned_np", None)
         if arr is None:
             raise _lib.LatticeNetHipError("no build has run on this lattice yet")
-        nr, status = int(arr[0]), int(arr[1])
+        word = int(arr[0])
+        nr, status = word & 0xFFFFFFFF, (word >> 32) & 0xFF
         bound = ht._static_rows
         if status & _lib.LN_STATUS_BUCKET_OVERFLOW:
             raise _lib.LatticeNetHipError("the bucketed build overflowed inside a static-rows step: redo this cloud in eager mode "

@@ -84,9 +84,9 @@ int main() {
     HIPCHECK(hipMemcpy(d_vals, ones.data(), ones.size() * sizeof(float), hipMemcpyHostToDevice));
 
     const long long S = ln_csr_max_segments(tokens, cap);
-    // seg_desc[G*S*4] first (16-byte aligned: hipMalloc is) | grp_start[cap+1] | csr_tok[tokens] | seg_count[G+1]
+    // seg_desc[G*S*4] first (16-byte aligned: hipMalloc is) | grp_start[cap+1] | csr_tok[tokens] | seg_count[G+2]
     const size_t G = LN_XCD_GROUPS;
-    int* csr_buf = dmalloc<int>(4 * G * S + (size_t)cap + 1 + tokens + G + 1);
+    int* csr_buf = dmalloc<int>(4 * G * S + (size_t)cap + 1 + tokens + G + 2);
     int* c0 = csr_buf + 4 * G * S;
     LnCsr csr{c0, c0 + cap + 1, csr_buf, c0 + cap + 1 + tokens, S, nullptr};
     const size_t ws_bytes = ln_build_workspace_bytes(tokens, cap);

@@ -97,7 +97,7 @@ def test_canonicalize_after_slot_order_build_is_bit_exact(case):
     tokens = idx.numel()
     ws = torch.empty((LT._build_sizes(tokens, cap)[0],), dtype=torch.uint8, device=dev())
     t = lat.m_hash_table.c_table()
-    _lib.check(lib.ln_canonicalize(C.byref(t), _lib.ptr(idx), tokens, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev())), "ln_canonicalize")
+    _lib.check(lib.ln_canonicalize(C.byref(t), _lib.ptr(idx), tokens, None, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev())), "ln_canonicalize")
     torch.cuda.synchronize()
     to = O.OracleHashTable(cap, 3)
     oidx, ow = O.build_splat(to, O.scale_positions(pos_np, np.full((3,), sigma, np.float32)))
@@ -183,16 +183,16 @@ def _splat_values_case(pos_np, vals_np, sigma, cap, half=False):
 
 
 @pytest.mark.parametrize("v", [4, 32, 64, 6, 20])
-def test_fused_splat_accumulate_matches_oracle(v, golden):
-    """ln_splat: the accumulate runs inside the bucket pass for val_dim % 4 == 0 (float4 lanes) and as the segment reduce
-    otherwise; both against an fp64 evaluation of splatCacheNaive (LatticeGPU.cuh:937-971) on the oracle's indices."""
+def test_splat_values_match_oracle(v, golden):
+    """Splat values under the slot-order numbering (float4 and scalar lanes of the segment reduce) against an fp64 evaluation
+    of splatCacheNaive (LatticeGPU.cuh:937-971) on the oracle's indices, rows matched through the keys."""
     g = golden("F9_lidar")
     pos_np = g["pos_raw"]
     rng = np.random.default_rng(v)
     _splat_values_case(pos_np, rng.standard_normal((pos_np.shape[0], v)).astype(np.float32), float(g["sigma"]), int(g["capacity"]))
 
 
-def test_fused_splat_accumulate_golden_values(golden):
+def test_splat_values_match_golden(golden):
     g = golden("F1_config1")
     lat = _splat_values_case(g["pos_raw"], g["vals"], float(g["sigma"]), int(g["capacity"]))
     m = int(g["nr_filled"])
@@ -201,7 +201,7 @@ def test_fused_splat_accumulate_golden_values(golden):
     np.testing.assert_allclose(got, g["values"], rtol=RTOL, atol=RTOL * float(np.abs(g["values"]).max()))
 
 
-def test_fused_splat_accumulate_fp16_rows():
+def test_splat_values_fp16_rows():
     from lattice_net_amd import synthetic
     rng = np.random.default_rng(2)
     pos_np = synthetic.lidar_cloud(30000, 2)
@@ -209,9 +209,9 @@ def test_fused_splat_accumulate_fp16_rows():
 
 
 @pytest.mark.parametrize("n_same", [500, 6000])
-def test_fused_splat_accumulate_hot_vertices(n_same):
-    """Thousands of tokens on four vertices: multi-segment runs (shuffle combine + atomics) and, at 6000 identical points,
-    buckets with more tokens than the LDS list holds (tokens beyond it are added one by one)."""
+def test_splat_values_hot_vertices(n_same):
+    """Thousands of tokens on four vertices: multi-segment runs (shuffle combine + atomics), and at 6000 identical points
+    buckets that hold more tokens than the bucket pass keeps in registers."""
     rng = np.random.default_rng(3)
     pos_np = np.concatenate([np.tile(np.array([[0.31, -0.17, 0.05]], np.float32), (n_same, 1)),
                              rng.uniform(-3, 3, (800, 3)).astype(np.float32)], 0)
@@ -219,7 +219,7 @@ def test_fused_splat_accumulate_hot_vertices(n_same):
     _splat_values_case(pos_np, vals_np, 0.5, 5000)
 
 
-def test_fused_splat_full_size_c3():
+def test_splat_values_full_size_c3():
     from lattice_net_amd import synthetic
     rng = np.random.default_rng(4)
     pos_np = synthetic.lidar_cloud(120000, 0)
