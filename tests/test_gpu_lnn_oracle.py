@@ -1,0 +1,126 @@
+"""Whole-network parity (`pytest -m gpu`): the LNN definition (reference latticenet_py/lattice/models.py:196-266) evaluated on the
+GPU through the C ABI against the SAME definition evaluated in float64 on the CPU over tests/oracle_lattice.OracleLattice
+(NumPy oracle for every integer decision, reference formulas for the arithmetic; its own gradients are pinned against central
+differences by tests/test_oracle_network.py).  Identical state_dict and cloud; compared: logits, loss, every parameter gradient.
+Plus the two pieces of Python post-processing around the distribute kernel that have row-level rules of their own:
+lattice_modules.py:66-94 (mean subtraction, index -1 -> bucket 0, masked_fill) and :705-712 (< 4 points per vertex -> zero)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.test_oracle_network import CFG, make_oracle_case
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def dev():
+    return torch.device("cuda", 0)
+
+
+def gpu_twin(net64, tmp_path, nr_classes=6):
+    """The same network on the GPU in float32 with the oracle network's parameters."""
+    from lattice_net_amd import Lattice, ModelParams
+    from lattice_net_amd.models import LNN
+    p = tmp_path / "net.cfg"
+    p.write_text(CFG)
+    mp = ModelParams.create(str(p))
+    lattice = Lattice.create(str(p), "lattice")
+    net = LNN(nr_classes, mp)
+    missing = net.load_state_dict({k: v.float() for k, v in net64.state_dict().items()}, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return net, lattice
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max()) / max(float(np.abs(b).max()), 1e-30)
+
+
+def test_whole_network_logits_and_gradients_match_the_oracle_network(tmp_path):
+    net64, olat, pos, vals, target = make_oracle_case(n=1500)
+    ls64, logits64 = net64(olat, pos, vals)
+    loss64 = torch.nn.functional.nll_loss(ls64, target)
+    loss64.backward()
+
+    net, lattice = gpu_twin(net64, tmp_path)
+    ls, logits = net(lattice, pos.to(dev()), vals.float().to(dev()))
+    loss = torch.nn.functional.nll_loss(ls, target.to(dev()))
+    loss.backward()
+    torch.cuda.synchronize()
+
+    assert rel(logits.detach().cpu().numpy(), logits64.detach().numpy()) < TOL
+    assert abs(float(loss) - float(loss64)) < TOL * abs(float(loss64))
+    g64 = {k: p.grad for k, p in net64.named_parameters()}
+    worst = {}
+    # tolerance relative to the largest gradient entry of the tensor, with a floor at 1e-3 of the largest gradient of the whole network
+    # (tensors whose gradient vanishes analytically — biases in front of a normalisation — hold rounding noise only)
+    gmax = max(float(g.abs().max()) for g in g64.values())
+    for k, p in net.named_parameters():
+        ref = g64[k].numpy()
+        scale = max(float(np.abs(ref).max()), 1e-3 * gmax)
+        worst[k] = float(np.abs(p.grad.detach().cpu().numpy().astype(np.float64) - ref).max()) / scale
+    bad = {k: v for k, v in worst.items() if v > TOL}
+    assert not bad, f"parameter gradients off: {sorted(bad.items(), key=lambda kv: -kv[1])[:8]}"
+
+
+def test_distribute_module_post_processing_matches_oracle():
+    """lattice_modules.py:66-94 on the GPU (segment reduce + index arithmetic) against torch on the oracle lattice."""
+    from lattice_net_amd import Lattice
+    from lattice_net_amd.lattice_modules import DistributeLatticeModule
+    from lattice_net_amd.synthetic import box_surface_cloud
+    from tests.oracle_lattice import OracleLattice
+    n = 3000
+    pos = torch.from_numpy(box_surface_cloud(n, 4))
+    vals = torch.from_numpy(np.random.default_rng(4).standard_normal((n, 2)).astype(np.float32))
+    mod = DistributeLatticeModule()
+    olat = OracleLattice([0.08] * 3, 60000)
+    with torch.no_grad():
+        ls64, d64, i64, w64 = mod(olat, pos, vals.double())
+        lat = Lattice(sigmas=[0.08] * 3, capacity=60000, device=dev())
+        ls, d, i, w = mod(lat, pos.to(dev()), vals.to(dev()))
+    assert ls.nr_lattice_vertices() == ls64.nr_lattice_vertices()
+    assert np.array_equal(i.cpu().numpy(), i64.numpy())
+    assert np.array_equal(w.cpu().numpy(), w64.numpy().astype(np.float32))
+    d_np, d64_np = d.cpu().numpy(), d64.numpy()
+    # rows of the tokens on vertex 0 (the "invalid" bucket) are zero on both sides, exactly
+    bucket0 = i64.numpy() == 0
+    assert bucket0.any() and not d_np[bucket0].any() and not d64_np[bucket0].any()
+    np.testing.assert_allclose(d_np, d64_np, rtol=0, atol=1e-5 * float(np.abs(d64_np).max()))
+    # the mean of the centred positions over every vertex (other than vertex 0) vanishes
+    sums = np.zeros((ls64.nr_lattice_vertices(), 3))
+    np.add.at(sums, i64.numpy(), d_np[:, :3].astype(np.float64))
+    assert np.abs(sums[1:]).max() < 1e-4
+
+
+def test_pointnet_rule_fewer_than_four_points_matches_oracle(tmp_path):
+    """lattice_modules.py:705-712: vertices with fewer than 4 points and vertex 0 are zeroed before the PointNet convolution;
+    the module's output on the GPU against the same module (same parameters) on the oracle lattice."""
+    net64, olat, pos, vals, _ = make_oracle_case(n=1500, seed=2)
+    net, lattice = gpu_twin(net64, tmp_path)
+    seen = {}
+
+    def grab(tag):
+        def hook(mod, args):
+            seen[tag] = args[0].detach().cpu().double()
+        return hook
+
+    h1 = net64.point_net.last_conv.register_forward_pre_hook(grab("cpu"))
+    h2 = net.point_net.last_conv.register_forward_pre_hook(grab("gpu"))
+    with torch.no_grad():
+        o_ls, o_d, o_i, o_w = net64.distribute(olat, pos, vals)
+        o_lv, _ = net64.point_net(o_ls, o_d, o_i)
+        g_ls, g_d, g_i, g_w = net.distribute(lattice, pos.to(dev()), vals.float().to(dev()))
+        g_lv, _ = net.point_net(g_ls, g_d, g_i)
+    h1.remove()
+    h2.remove()
+    counts = np.bincount(o_i.numpy()[o_i.numpy() >= 0], minlength=o_ls.nr_lattice_vertices())
+    must_be_zero = counts < 4
+    must_be_zero[0] = True
+    assert must_be_zero.sum() > 10 and (~must_be_zero).sum() > 10  # both kinds of vertices occur in this cloud
+    for tag in ("cpu", "gpu"):
+        rows = seen[tag].numpy()
+        assert not rows[must_be_zero].any(), tag
+        assert np.abs(rows[~must_be_zero]).sum(1).min() > 0, tag
+    assert rel(seen["gpu"].numpy(), seen["cpu"].numpy()) < 1e-5
+    assert rel(g_lv.cpu().numpy(), o_lv.numpy()) < 1e-5

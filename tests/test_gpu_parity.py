@@ -367,7 +367,8 @@ def test_conv_backward_fused_same_lattice(n_points, subtiles):
     v = f = 32
     lat = make_lattice(0.05, 400000)
     lat.begin_splat()
-    lat.just_create_verts(T(cube_cloud(n_points, 11)), False)
+    pos_np = cube_cloud(n_points, 11)
+    lat.just_create_verts(T(pos_np), False)
     m = lat.nr_lattice_vertices()
     assert -(-(-(-m // 64)) // 256) == subtiles, m
     rng = np.random.default_rng(n_points)
@@ -379,16 +380,25 @@ def test_conv_backward_fused_same_lattice(n_points, subtiles):
     W = T(W_np).requires_grad_(True)
     out, _ = ConvIm2RowLattice.apply(vals, lat, W, 1)
     out.backward(T(G_np))
-    lat.set_values(vals.detach())
-    rows = N(lat.im2row(lat, 9, 1, False)).astype(np.float64)
+    # reference: the ORACLE's table and neighbour list (same canonical numbering), fp64 arithmetic, both gradients per element
+    t, _, _, _ = oracle_build(pos_np, 0.05, 400000, write=False)
+    assert t.nr_filled == m
+    nbr = O.neighbour_rows(t.keys[:m], t, 1, 1, 1, False)
+    ok = nbr >= 0
     G64, W64 = G_np.astype(np.float64), W_np.astype(np.float64)
-    ref_gw = rows.T @ G64
+    rows = np.zeros((m, 9, v))
+    rows[ok] = vals_np.astype(np.float64)[nbr[ok]]
+    rows = rows.reshape(m, 9 * v)
+    ref_gw = rows.T @ G64  # lattice_funcs.py:302
     bound_gw = np.abs(rows).T @ np.abs(G64)
     assert np.all(np.abs(N(W.grad) - ref_gw) <= RTOL * np.maximum(bound_gw, 1e-30))
-    # grad_values = row2im(G W^T): reference through the reference-shaped API (row2im of the rowified gradient)
-    ref_gv = N(lat.row2im(T((G64 @ W64.T).astype(np.float32)), 1, 9, f, lat)).astype(np.float64)
-    bound_gv = N(lat.row2im(T((np.abs(G64) @ np.abs(W64).T).astype(np.float32)), 1, 9, f, lat)).astype(np.float64)
-    assert np.all(np.abs(N(vals.grad) - ref_gv) <= 4 * RTOL * np.maximum(bound_gv, 1e-30))
+    # grad_values = row2im(G W^T) (LatticeGPU.cuh:2187-2284): the adjoint of the gather, accumulated in fp64
+    gr = (G64 @ W64.T).reshape(m, 9, v)
+    gr_abs = (np.abs(G64) @ np.abs(W64).T).reshape(m, 9, v)
+    ref_gv, bound_gv = np.zeros((m, v)), np.zeros((m, v))
+    np.add.at(ref_gv, nbr[ok], gr[ok])
+    np.add.at(bound_gv, nbr[ok], gr_abs[ok])
+    assert np.all(np.abs(N(vals.grad) - ref_gv) <= RTOL * np.maximum(bound_gv, 1e-30))
 
 
 @pytest.mark.parametrize("n_points,aggressor", [(5000, "fused"), (12000, "fused"), (45000, "fused"), (12000, "per-slot bf16x3")])

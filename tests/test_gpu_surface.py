@@ -232,9 +232,13 @@ def test_lattice_object_semantics():
         lat.im2row(lat, 7, 1, False)
 
 
-def test_expand_adds_vertices_and_keeps_rows():
+def test_expand_matches_oracle_on_the_same_jitter():
+    """Lattice::expand (Lattice.cu:292-348): the positions repeated `point_multiplier` times plus Gaussian noise are inserted into a
+    copy of the table.  The jitter is reproducible under torch.manual_seed (same generator, same call shape), so the expanded
+    table is compared with the oracle's incremental build on exactly those positions: keys and row ids bit-exact."""
     from lattice_net_amd.synthetic import cube_cloud
-    pos = T(cube_cloud(500, 41))
+    pos_np = cube_cloud(500, 41)
+    pos = T(pos_np)
     lat = make_lattice(0.3, 20000)
     lat.begin_splat()
     lat.splat_standalone(pos, torch.ones((500, 3), device=dev()))
@@ -249,6 +253,24 @@ def test_expand_adds_vertices_and_keeps_rows():
     assert tuple(ex.values().shape) == (m2, 3)
     np.testing.assert_array_equal(N(ex.values()[:m]), N(lat.values()))
     assert float(ex.values()[m:].abs().sum()) == 0.0
+    # the same jitter again (Lattice.cu:311-318: repeat, then + randn * stddev), then the oracle's serial insertion order
+    torch.manual_seed(0)
+    rep = pos.repeat(4, 1)
+    jittered = N(rep + torch.randn_like(rep) * 0.2)
+    sig = np.full((3,), 0.3, np.float32)
+    t = O.OracleHashTable(20000, 3)
+    O.build_splat(t, O.scale_positions(pos_np, sig))
+    assert t.nr_filled == m and np.array_equal(t.keys[:m], keys_before)
+    O.build_splat(t, O.scale_positions(jittered, sig), write=False)
+    assert t.nr_filled == m2
+    np.testing.assert_array_equal(N(ex.hash_table().m_keys_tensor[:m2]), t.keys[:m2])
+    # and the expanded table answers lookups like the oracle's: slice_no_precomputation indices of fresh query points
+    q = cube_cloud(300, 42)
+    ex.set_values(torch.zeros((m2, 3), device=dev()))
+    _, qi, qw = ex.slice_standalone_no_precomputation(T(q))
+    _, oi, ow = O.slice_no_precomputation(t, np.zeros((m2, 3), np.float32), O.scale_positions(q, sig))
+    np.testing.assert_array_equal(N(qi), oi)
+    np.testing.assert_array_equal(N(qw), ow)
 
 
 def test_create_from_cfg_and_splat(tmp_path):
@@ -369,6 +391,56 @@ def test_fp16_feature_path_splat_conv_slice_end_to_end():
     ii = torch.from_numpy(oidx.astype(np.int64)).reshape(n, 4)
     out_ref = (conv_ref[ii] * wi).sum(1)
     (out_ref * G.cpu().double()).sum().backward()
+    close(N(out.float()), out_ref.detach().numpy(), scale=float(out_ref.abs().max()), rtol=4e-3)
+    close(N(lvh.grad.float()), v64.grad.numpy(), scale=float(v64.grad.abs().max()), rtol=4e-3)
+    close(N(W.grad.float()), w64.grad.numpy(), scale=float(w64.grad.abs().max()), rtol=4e-3)
+
+
+def test_c5_full_size_fp16_feature_chain():
+    """BASELINE.json configs[4] as ONE run: 4 aggregated scans (480 k points), capacity 400 000, V = F = 64, fp16 point features /
+    lattice values / filter bank with fp32 accumulation — splat -> convolution -> slice, forward and backward, against an fp64
+    evaluation of the same fp16 inputs on the oracle's indices and neighbour list."""
+    from lattice_net_amd import ConvIm2RowLattice, SliceLattice, SplatLattice
+    from lattice_net_amd.synthetic import lidar_cloud
+    parts = [lidar_cloud(120000, s) + np.array([6.0 * s, 0.0, 0.0], np.float32) for s in range(4)]
+    pos_np = np.ascontiguousarray(np.concatenate(parts, 0))
+    n, v, f = pos_np.shape[0], 64, 64
+    rng = np.random.default_rng(5)
+    vals = torch.tensor(rng.standard_normal((n, v)), dtype=torch.float16, device=dev())
+    W = torch.tensor(rng.standard_normal((9 * v, f)) / np.sqrt(9 * v), dtype=torch.float16, device=dev(), requires_grad=True)
+    G = torch.tensor(rng.standard_normal((n, f)), dtype=torch.float16, device=dev())
+    lat = make_lattice(0.9, 400000)
+    pos = T(pos_np)
+    lv, wrap, idx, w = SplatLattice.apply(lat, pos, vals)
+    m = lat.nr_lattice_vertices()
+    t, oidx, ow = oracle_table(pos_np, 0.9, 400000)
+    assert m == t.nr_filled
+    np.testing.assert_array_equal(N(idx), oidx)
+    np.testing.assert_array_equal(N(w), ow)
+    expect = np.zeros((m, v), np.float64)
+    np.add.at(expect, oidx, np.repeat(vals.cpu().double().numpy(), 4, axis=0) * ow[:, None])
+    close(N(lv[:m]), expect, rtol=1e-5)  # fp16 rows accumulated in fp32
+    lvh = lv[:m].half().requires_grad_(True)
+    cv, cwrap = ConvIm2RowLattice.apply(lvh, lat, W, 1)
+    out = SliceLattice.apply(cv, cwrap.lattice, pos, idx, w)
+    assert cv.dtype == torch.float16 and out.dtype == torch.float16 and out.shape == (n, f)
+    out.backward(G)
+    torch.cuda.synchronize()
+    nbr_np = O.neighbour_rows(t.keys[:m], t, 1, 1, 1, False)
+    np.testing.assert_array_equal(N(lat.neighbours(lat, 1, False)), nbr_np)
+    nbr = torch.from_numpy(nbr_np.astype(np.int64))
+    v64 = lvh.detach().cpu().double().requires_grad_(True)
+    w64 = W.detach().cpu().double().requires_grad_(True)
+    padded = torch.cat([v64, torch.zeros((1, v), dtype=torch.float64)], 0)
+    rows = padded[torch.where(nbr >= 0, nbr, torch.full_like(nbr, m))].reshape(m, 9 * v)
+    conv_ref = rows @ w64
+    wi = torch.from_numpy(ow.astype(np.float64)).reshape(n, 4, 1)
+    ii = torch.from_numpy(oidx.astype(np.int64)).reshape(n, 4)
+    out_ref = (conv_ref[ii] * wi).sum(1)
+    (out_ref * G.cpu().double()).sum().backward()
+    # fp16 outputs: half an ulp of fp16 (4.9e-4 relative) on values of the size of the scale, plus the rounding of the fp16
+    # convolution output that the slice reads; the run-to-run order of the hot-vertex atomics is below both
+    close(N(cv.float()), conv_ref.detach().numpy(), scale=float(conv_ref.abs().max()), rtol=2e-3)
     close(N(out.float()), out_ref.detach().numpy(), scale=float(out_ref.abs().max()), rtol=4e-3)
     close(N(lvh.grad.float()), v64.grad.numpy(), scale=float(v64.grad.abs().max()), rtol=4e-3)
     close(N(W.grad.float()), w64.grad.numpy(), scale=float(w64.grad.abs().max()), rtol=4e-3)
