@@ -109,10 +109,13 @@ class CapturedNetworkStep:
     cloud of the same size — set `p.grad = None` itself is NOT needed (done here), and must not synchronise."""
 
     def __init__(self, step: Callable[[], torch.Tensor], lattice: Lattice, parameters, *, row_slack: float = 0.07,
-                 stream: Optional[torch.cuda.Stream] = None, optimizer: Optional[torch.optim.Optimizer] = None):
+                 stream: Optional[torch.cuda.Stream] = None, optimizer: Optional[torch.optim.Optimizer] = None,
+                 calibration_loaders: Optional[Sequence[Callable[[], None]]] = None):
         """`optimizer` (optional): its step() is captured behind the backward pass, so that a training loop is nothing but replays —
-        it must have been built with `capturable=True` (torch.optim.Adam / AdamW / SGD ...: the step count lives on the device)."""
-        from .lattice_blocks import reset_gn_workspaces
+        it must have been built with `capturable=True` (torch.optim.Adam / AdamW / SGD ...: the step count lives on the device).
+        `calibration_loaders` (optional): functions that each load one cloud into the tensors `step` reads; the row bounds then
+        cover the largest lattice of all of them (a bound calibrated on one cloud drops vertices of a larger one: check())."""
+        from .lattice_blocks import new_gn_workspace, reset_gn_workspaces, use_gn_workspace
         self.step, self.lattice, self.stream = step, lattice, stream
         self.optimizer = optimizer
         if optimizer is not None and not all(g.get("capturable", False) for g in optimizer.param_groups):
@@ -120,14 +123,26 @@ class CapturedNetworkStep:
         self.parameters = list(parameters)
         Lattice.start_level_trace()
         try:
-            self.eager_loss = step()
+            for load in (calibration_loaders or [None]):
+                if load is not None:
+                    load()
+                self.eager_loss = step()
             torch.cuda.synchronize()
         finally:
             self.levels = Lattice.stop_level_trace()
         lv = sorted(self.levels)
+        # bounds are handed to the levels by position (finest first): the traced levels must be exactly lattice.m_lvl, +1, +2, ...
+        if not lv or lv != list(range(lattice.m_lvl, lattice.m_lvl + len(lv))):
+            raise ValueError(f"the calibration step built lattice levels {lv}, expected consecutive levels starting at {lattice.m_lvl} "
+                             "(every builder — splat, distribute, create_verts, coarsen — records its level: did `step` use `lattice`?)")
         bounds = [min(lattice.capacity(), ((int(self.levels[k] * (1.0 + row_slack)) + 255) // 256) * 256) for k in lv]
         self.bounds = dict(zip(lv, bounds))
+        for k in lv:
+            if self.levels[k] > self.bounds[k]:
+                raise ValueError(f"lattice level {k} has {self.levels[k]} vertices, more than its capacity allows as a row bound ({self.bounds[k]})")
         lattice.set_static_rows(bounds[0], coarse_bounds=bounds[1:])
+        # this step's own GroupNorm accumulators (never shared with eager launches, never freed while the graph lives)
+        self._gn_entry = new_gn_workspace(lattice._dev())
 
         def guarded():
             reset_gn_workspaces()
@@ -144,7 +159,7 @@ class CapturedNetworkStep:
         self.own_stream = stream is None
         self.stream = side
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
+        with torch.cuda.stream(side), use_gn_workspace(self._gn_entry):
             for _ in range(3 if optimizer is not None else 2):  # torch: three warm-up iterations before capturing an optimizer
                 for p in self.parameters:
                     p.grad = None
@@ -154,9 +169,14 @@ class CapturedNetworkStep:
         for p in self.parameters:
             p.grad = None
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.stream(side):
-            with torch.cuda.graph(self.graph, stream=side):
-                self.loss = guarded()
+        Lattice.start_static_build_log()
+        try:
+            with torch.cuda.stream(side), use_gn_workspace(self._gn_entry):
+                with torch.cuda.graph(self.graph, stream=side):
+                    self.loss = guarded()
+        finally:
+            # (level, row bound, pinned report word) of every table the graph builds: what check() reads after a replay
+            self.builds = Lattice.stop_static_build_log()
         torch.cuda.synchronize()
         self.grads = [p.grad for p in self.parameters]  # this graph's gradient tensors (another capture rebinds p.grad)
 
@@ -176,7 +196,7 @@ class CapturedNetworkStep:
             pending.pop(0).synchronize()
         self._launches = getattr(self, "_launches", 0) + 1
         stream = self.stream
-        if self._launches % int(os.environ.get("LN_GRAPH_SYNC_EVERY", "8")) == 0:
+        if self._launches % max(1, int(os.environ.get("LN_GRAPH_SYNC_EVERY", "8"))) == 0:
             stream.synchronize()
         caller = torch.cuda.current_stream()
         join = self.own_stream and caller != stream  # a caller that works on the capture stream itself needs no joins
@@ -190,6 +210,22 @@ class CapturedNetworkStep:
             caller.wait_stream(stream)  # the caller's next operations see the loss and the gradients
         pending.append(ev)
         return self.loss
+
+    def check(self):
+        """After a synchronise: every lattice level the last replay built stayed inside its static row bound and no bucket
+        overflowed.  Returns {level: vertex count}; raises LatticeNetHipError otherwise — the cloud must then be redone eagerly
+        (`lattice.set_static_rows(None)`), its replayed result is not usable (vertices beyond a bound were left un-inserted)."""
+        from . import _lib
+        out = {}
+        for level, bound, word in self.builds:
+            nr, status = Lattice.decode_report(word[0])
+            if status & (_lib.LN_STATUS_BUCKET_OVERFLOW | _lib.LN_STATUS_TABLE_FULL | _lib.LN_STATUS_KEY_RANGE):
+                raise _lib.LatticeNetHipError(f"replayed build of lattice level {level} failed (status bits {status}): redo this cloud eagerly")
+            if nr > bound:
+                raise _lib.LatticeNetHipError(f"lattice level {level} of this cloud has {nr} vertices, its static row bound is {bound}: "
+                                              "rows beyond the bound were dropped; redo this cloud eagerly or re-capture with larger bounds")
+            out[level] = max(out.get(level, 0), nr)
+        return out
 
     def bind_gradients(self):
         """Binds this graph's gradient tensors as `p.grad` (they hold the last replay's gradients; another capture over the same

@@ -130,7 +130,7 @@ extern "C" int ln_max_centre_backward(const float* grad_out, const float* max_va
     LN_REQUIRE(grad_gamma_beta, LN_ERR_ARG, "ln_max_centre_backward: null parameter-gradient buffer");
     hipStream_t st = (hipStream_t)stream;
     if (n == 0) {
-        if (hipMemsetAsync(grad_gamma_beta, 0, (size_t)2 * c * sizeof(float), st) != hipSuccess)
+        if (ln_zero_async(grad_gamma_beta, (size_t)2 * c * sizeof(float), st) != LN_OK)
             return ln_check_launch("ln_max_centre_backward(memset)");
         return LN_OK;
     }

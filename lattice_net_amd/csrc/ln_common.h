@@ -27,6 +27,12 @@ int ln_check_launch(const char* what);
         }                            \
     } while (0)
 
+// Zero-fill of `bytes` bytes (a multiple of 4, 4-byte aligned) as a KERNEL on `st`.  Used instead of hipMemsetAsync everywhere:
+// inside a captured hipGraph a memset node in front of ln_canonicalize's marking pass did not take effect on replay (the bitmap
+// kept the previous replay's bits — a memory fault as soon as the replayed cloud differed from the captured one; ROCm 7.2,
+// MI355X), a kernel node does.
+int ln_zero_async(void* p, size_t bytes, hipStream_t st);
+
 // ---- per-kernel live timing (ln_profile_begin / ln_profile_end) ------------------------------
 // Every launch goes through LN_LAUNCH.  When profiling is armed for NAME, the launch is bracketed
 // by hipEventRecord on the SAME stream the kernel is launched on.

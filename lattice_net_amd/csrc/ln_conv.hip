@@ -1026,7 +1026,7 @@ extern "C" int ln_conv_grad_filter(const int* nbr, const float* values_neigh, co
     hipStream_t st = (hipStream_t)stream;
     const int total = filter_extent * val_dim * nr_filters;
     if (m == 0) {
-        (void)hipMemsetAsync(grad_filter, 0, (size_t)total * sizeof(float), st);
+        (void)ln_zero_async(grad_filter, (size_t)total * sizeof(float), st);
         return ln_check_launch("ln_conv_grad_filter");
     }
     if (ln_gf_mfma_supported(val_dim, nr_filters)) {

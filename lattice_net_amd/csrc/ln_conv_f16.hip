@@ -316,7 +316,7 @@ extern "C" int ln_conv_grad_filter_f16(const int* nbr, const void* values_neigh,
     hipStream_t st = (hipStream_t)stream;
     const int total = filter_extent * val_dim * nr_filters;
     if (m == 0) {
-        (void)hipMemsetAsync(grad_filter, 0, (size_t)total * sizeof(float), st);
+        (void)ln_zero_async(grad_filter, (size_t)total * sizeof(float), st);
         return ln_check_launch("ln_conv_grad_filter_f16");
     }
     LN_REQUIRE(workspace && workspace_bytes >= ln_conv_grad_filter_f16_workspace_bytes(m, filter_extent, val_dim, nr_filters), LN_ERR_WORKSPACE,

@@ -221,7 +221,7 @@ extern "C" int ln_csr_build(const int* idx, long long tokens, int groups_upper, 
     p += ln_align256c((size_t)groups_upper * 4);
     int* pos = reinterpret_cast<int*>(p);
     p += ln_align256c((size_t)(tokens < 1 ? 1 : tokens) * 4);
-    if (hipMemsetAsync(cnt, 0, (size_t)groups_upper * 4, st) != hipSuccess) return ln_check_launch("ln_csr_build(memset)");
+    if (ln_zero_async(cnt, (size_t)groups_upper * 4, st) != LN_OK) return ln_check_launch("ln_csr_build(memset)");
     if (tokens > 0)
         LN_LAUNCH("k_csr_count", k_csr_count, dim3(ln_div_up(tokens, 256)), dim3(256), 0, st, idx, tokens, groups_upper, cnt, pos);
     return ln_csr_from_counts(idx, pos, tokens, cnt, groups_upper, *csr, p, ln_csr_scan_workspace_bytes(groups_upper), st);
@@ -562,7 +562,7 @@ extern "C" int ln_csr_segment_max(const LnCsr* csr, const int* grp_row, long lon
     if (rows == 0) return LN_OK;
     hipStream_t st = (hipStream_t)stream;
     const long long work = (long long)rows * channels;
-    if (hipMemsetAsync(packed_ws, 0, (size_t)work * sizeof(unsigned long long), st) != hipSuccess)
+    if (ln_zero_async(packed_ws, (size_t)work * sizeof(unsigned long long), st) != LN_OK)
         return ln_check_launch("ln_csr_segment_max(memset)");
     if (max_segments > 0)
         LN_LAUNCH("k_csr_segment_max", k_csr_segment_max, dim3(ln_seg_grid(max_segments, channels)), dim3(256), 0, st, csr->csr_tok,
@@ -589,7 +589,7 @@ extern "C" int ln_csr_group_sizes(const LnCsr* csr, const int* grp_row, int grou
     LN_REQUIRE(rows == 0 || (csr && csr->grp_start && counts), LN_ERR_ARG, "ln_csr_group_sizes: null buffer");
     if (rows == 0) return LN_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(counts, 0, (size_t)rows * sizeof(int), st) != hipSuccess) return ln_check_launch("ln_csr_group_sizes(memset)");
+    if (ln_zero_async(counts, (size_t)rows * sizeof(int), st) != LN_OK) return ln_check_launch("ln_csr_group_sizes(memset)");
     LN_LAUNCH("k_csr_group_sizes", k_csr_group_sizes, dim3(ln_div_up(groups_upper, 256)), dim3(256), 0, st, csr->grp_start, grp_row, groups_upper,
               counts);
     return ln_check_launch("ln_csr_group_sizes");

@@ -361,8 +361,8 @@ extern "C" int ln_linear_act_backward(const float* x, const float* w, const floa
     hipStream_t st = (hipStream_t)stream;
     const int pairs = cin * cout;
     if (rows == 0) {
-        (void)hipMemsetAsync(grad_w, 0, sizeof(float) * pairs, st);
-        if (grad_b) (void)hipMemsetAsync(grad_b, 0, sizeof(float) * cout, st);
+        (void)ln_zero_async(grad_w, sizeof(float) * pairs, st);
+        if (grad_b) (void)ln_zero_async(grad_b, sizeof(float) * cout, st);
         return ln_check_launch("ln_linear_act_backward");
     }
     if (grad_x) {

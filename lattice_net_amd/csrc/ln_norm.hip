@@ -287,7 +287,7 @@ extern "C" int ln_group_norm_forward_rows(const float* x, const float* gamma, co
     double* acc = static_cast<double*>(workspace);
     // next_workspace != NULL: the caller alternates two workspaces and promises `workspace` is zero (it was `next_workspace` of
     // the previous call on this stream, or freshly zeroed); this call zero-fills `next_workspace` on its way out.
-    if (!next_workspace && hipMemsetAsync(acc, 0, ln_group_norm_workspace_bytes(channels), st) != hipSuccess)
+    if (!next_workspace && ln_zero_async(acc, ln_group_norm_workspace_bytes(channels), st) != LN_OK)
         return ln_check_launch("ln_group_norm_forward(memset)");
     LN_LAUNCH("k_gn_stats", k_gn_stats, dim3(ln_gn_stats_grid(m, channels)), dim3(256), 0, st, x, (const float*)nullptr, (const float*)nullptr, 0, m,
               channels, acc, rows_device);
@@ -318,7 +318,7 @@ extern "C" int ln_group_norm_backward_rows(const float* x, const float* grad_y, 
                "ln_group_norm_backward: x / grad_y / grad_x must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     double* acc = static_cast<double*>(workspace);
-    if (!next_workspace && hipMemsetAsync(acc, 0, ln_group_norm_workspace_bytes(channels), st) != hipSuccess)
+    if (!next_workspace && ln_zero_async(acc, ln_group_norm_workspace_bytes(channels), st) != LN_OK)
         return ln_check_launch("ln_group_norm_backward(memset)");
     LN_LAUNCH("k_gn_stats", k_gn_stats, dim3(ln_gn_stats_grid(m, channels)), dim3(256), 0, st, x, grad_y, scale_shift, relu, m, channels, acc, rows_device);
     LN_LAUNCH("k_gn_backward_apply", k_gn_backward_apply, dim3(ln_gn_apply_grid(m, channels)), dim3(256), 0, st, x, grad_y, acc, gamma, mean_rstd,

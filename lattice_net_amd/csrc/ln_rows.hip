@@ -143,7 +143,7 @@ static int ln_slice_forward_impl(const float* values, const int* idx, const floa
     if (rc) return rc;
     LN_REQUIRE(n == 0 || w, LN_ERR_ARG, "ln_slice_forward: null weights");
     if (n == 0) {
-        if (zero_fill && zero_elems > 0) (void)hipMemsetAsync(zero_fill, 0, sizeof(float) * zero_elems, (hipStream_t)stream);
+        if (zero_fill && zero_elems > 0) (void)ln_zero_async(zero_fill, sizeof(float) * zero_elems, (hipStream_t)stream);
         return LN_OK;
     }
     LN_DISPATCH_VEC(val_dim, {

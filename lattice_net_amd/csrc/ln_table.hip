@@ -173,6 +173,21 @@ static int ln_check_table(const LnTable* t, const char* who) {
     return LN_OK;
 }
 
+__global__ void __launch_bounds__(256) ln_k_zero_words(unsigned int* __restrict__ p, size_t words) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += stride) p[i] = 0u;
+}
+
+int ln_zero_async(void* p, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return LN_OK;
+    LN_REQUIRE(p != nullptr && (reinterpret_cast<uintptr_t>(p) & 3) == 0 && (bytes & 3) == 0, LN_ERR_ARG, "ln_zero_async: unaligned fill");
+    const size_t words = bytes / 4;
+    int blocks = ln_div_up((long long)words, 256 * 4);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(ln_k_zero_words, dim3(blocks), dim3(256), 0, st, static_cast<unsigned int*>(p), words);
+    return ln_check_launch("ln_zero_async");
+}
+
 // {vertex count, status bits, the build's sequence number} as ONE 64-bit word into pinned host memory (LnTable.host_counters):
 // count | status << 32 | seq << 40.  A single aligned 8-byte store needs no release fence in front of it — the fence of the
 // three-word form made the last workgroup of a build write back its whole L2 (buffer_wbl2) twice.
@@ -1108,14 +1123,16 @@ __global__ void __launch_bounds__(256) k_canon_idx(int* __restrict__ idx, long l
 
 template <int D>
 static int ln_canonicalize_impl(const LnTable& t, int* idx, long long tokens, const LnCsr* csr, const BuildWs& ws, hipStream_t st) {
-    if (hipMemsetAsync(ws.bitmap, 0, (size_t)ws.nb * 4 * sizeof(unsigned long long), st) != hipSuccess) return ln_check_launch("ln_canonicalize(memset)");
+    const int dbg = ln_debug_mask();
+    if (dbg & 256) return LN_OK;
+    if (ln_zero_async(ws.bitmap, (size_t)ws.nb * 4 * sizeof(unsigned long long), st)) return LN_ERR_LAUNCH;
     const int slot_blocks = ln_div_up(t.capacity, 256);
     LN_LAUNCH("k_canon_mark", k_canon_mark, dim3(slot_blocks), dim3(256), 0, st, t, ws.bitmap);
     LN_LAUNCH("k_scan_blocks", k_scan_blocks, dim3(1), dim3(1024), 0, st, (const int*)nullptr, ws.bitmap, ws.nb, ws.block_prefix, t.nr_filled, t.status,
               (int*)nullptr, 0, 1);
-    LN_LAUNCH("k_canon_slots", k_canon_slots<D>, dim3(slot_blocks), dim3(256), 0, st, t, ws.bitmap, ws.block_prefix, ws.tok_pos);
-    if (idx) LN_LAUNCH("k_canon_idx", k_canon_idx, dim3(ws.nb), dim3(256), 0, st, idx, tokens, ws.tok_pos);
-    if (csr && csr->seg_desc && csr->seg_count)
+    if (!(dbg & 512)) LN_LAUNCH("k_canon_slots", k_canon_slots<D>, dim3(slot_blocks), dim3(256), 0, st, t, ws.bitmap, ws.block_prefix, ws.tok_pos);
+    if (idx && !(dbg & 64)) LN_LAUNCH("k_canon_idx", k_canon_idx, dim3(ws.nb), dim3(256), 0, st, idx, tokens, ws.tok_pos);
+    if (csr && csr->seg_desc && csr->seg_count && !(dbg & 32))
         LN_LAUNCH("k_canon_segs", k_canon_segs, dim3(ln_div_up((long long)LN_XCD_GROUPS * csr->seg_region, 256)), dim3(256), 0, st,
                   reinterpret_cast<int4*>(csr->seg_desc), csr->seg_count, csr->seg_region, ws.tok_pos);
     return ln_check_launch("ln_canonicalize");

@@ -20,6 +20,7 @@ import ctypes as C
 import itertools
 import os
 import re
+import weakref
 from typing import Optional, Sequence
 
 import torch
@@ -64,18 +65,36 @@ def _build_sizes(tokens: int, capacity: int):
     return hit
 
 
-_STATIC_PINNED = [None, 0]  # [pinned int32[256, 4], next row]
+class _PinnedReportPool:
+    """8-byte aligned report slots (16 bytes each) in pinned host memory for the tables of the static-rows mode.  A captured
+    graph keeps writing to the slot of every table it built for as long as it is replayed, long after the per-forward table
+    object is gone: slots handed out during a stream capture are never reused; slots handed out eagerly go back to the free
+    list when their table dies.  Blocks of 256 slots are allocated on demand, outside captures only, and never freed."""
+
+    def __init__(self):
+        self.blocks = []
+        self.free = []
+
+    def take(self, owner) -> torch.Tensor:
+        capturing = torch.cuda.is_current_stream_capturing()
+        if not self.free:
+            if capturing:
+                raise _lib.LatticeNetHipError("static-rows mode: the pinned report pool is exhausted inside a stream capture; run the "
+                                              "step eagerly once before capturing it (the pool grows outside captures only)")
+            block = torch.zeros((256, 4), dtype=torch.int32, pin_memory=True)
+            self.blocks.append(block)
+            self.free.extend((len(self.blocks) - 1, r) for r in reversed(range(256)))
+        b, r = self.free.pop()
+        if not capturing:
+            weakref.finalize(owner, self.free.append, (b, r))
+        return self.blocks[b][r]
 
 
-def _static_pinned() -> torch.Tensor:
-    """One row of a pinned int32[256, 4] block, handed out round-robin; the block is allocated once (outside any stream capture:
-    the first static-rows build of a process has to run eagerly) and never freed (see HashTable.c_table)."""
-    if _STATIC_PINNED[0] is None:
-        if torch.cuda.is_current_stream_capturing():
-            raise _lib.LatticeNetHipError("static-rows mode: run the step eagerly once before capturing it (pinned counter block)")
-        _STATIC_PINNED[0] = torch.zeros((256, 4), dtype=torch.int32, pin_memory=True)
-    _STATIC_PINNED[1] = (_STATIC_PINNED[1] + 1) % 256
-    return _STATIC_PINNED[0][_STATIC_PINNED[1]]
+_STATIC_PINNED = _PinnedReportPool()
+
+
+def _static_pinned(owner) -> torch.Tensor:
+    return _STATIC_PINNED.take(owner)
 
 
 def _require_cuda(t: torch.Tensor, name: str):
@@ -187,7 +206,7 @@ class HashTable:
             if self._static_rows is not None:
                 # static-rows mode: a captured graph keeps writing to this address for as long as it is replayed, long after
                 # this (per-forward) table object is gone — the buffer comes from a pool that is never freed
-                self._pinned = _static_pinned()
+                self._pinned = _static_pinned(self)
             else:
                 self._pinned = torch.zeros((4,), dtype=torch.int32, pin_memory=True)
             self._pinned_np = self._pinned.numpy().view("int64")  # same memory: the host polls the build's 64-bit report word
@@ -510,6 +529,8 @@ class Lattice:
                 st.csr_cache[(idx.data_ptr(), idx._version, idx.numel())] = (csr_buf, csr, max_seg, st.entries, idx)
 
         issue(False)
+        if Lattice._static_build_log is not None and ht._static_rows is not None:
+            Lattice._static_build_log.append((self.m_lvl, int(ht._static_rows), ht._pinned_np))
         # A bucketed build that reports LN_STATUS_BUCKET_OVERFLOW is replayed on the atomic path, together with the
         # work that was queued behind it (nr_lattice_vertices() is where the status is read).
         # (static-rows mode: the launches may be inside a stream capture, where nothing can be replayed; an overflowing
@@ -616,6 +637,7 @@ class Lattice:
         tv = ht.m_values_tensor
         # splatCacheNaive (LatticeGPU.cuh:926-973) as a token-balanced reduce; begin_splat zeroed the table values
         self._after_build(lambda: self._accumulate_and_prefetch(values, idx, w, tv, v, d + 1, n * (d + 1)))
+        self._trace_level()
         return idx, w
 
     def just_create_verts(self, positions_raw: torch.Tensor, return_indices_and_weights: bool):  # Lattice.cu:244-290
@@ -623,6 +645,7 @@ class Lattice:
         d = positions_raw.shape[1]
         self._ensure_table(d, 1, positions_raw)
         idx, w = self._build(positions_raw, bool(return_indices_and_weights))
+        self._trace_level()
         return idx, w
 
     def distribute(self, positions_raw: torch.Tensor, values: torch.Tensor, reset_hashmap: bool = True):  # Lattice.cu:351-410
@@ -1142,6 +1165,24 @@ class Lattice:
 
     # calibration of the static-rows mode for a whole network: every build made while a trace is open records (level, vertices)
     _level_trace = None
+    # builds issued in static-rows mode while a log is open: (level, row bound, pinned report word) — what a captured step keeps
+    # to check its replays (CapturedNetworkStep.check)
+    _static_build_log = None
+
+    @staticmethod
+    def start_static_build_log():
+        Lattice._static_build_log = []
+
+    @staticmethod
+    def stop_static_build_log():
+        log, Lattice._static_build_log = Lattice._static_build_log or [], None
+        return log
+
+    @staticmethod
+    def decode_report(word: int):
+        """(vertex count, status bits) of a build's 64-bit report word (LnTable.host_counters)."""
+        word = int(word)
+        return word & 0xFFFFFFFF, (word >> 32) & 0xFF
 
     @staticmethod
     def start_level_trace():
@@ -1239,8 +1280,7 @@ class Lattice:
         arr = getattr(ht, "_pinned_np", None)
         if arr is None:
             raise _lib.LatticeNetHipError("no build has run on this lattice yet")
-        word = int(arr[0])
-        nr, status = word & 0xFFFFFFFF, (word >> 32) & 0xFF
+        nr, status = Lattice.decode_report(arr[0])
         bound = ht._static_rows
         if status & _lib.LN_STATUS_BUCKET_OVERFLOW:
             raise _lib.LatticeNetHipError("the bucketed build overflowed inside a static-rows step: redo this cloud in eager mode "

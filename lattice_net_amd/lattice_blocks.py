@@ -45,25 +45,60 @@ class BatchNormLatticeModule(torch.nn.Module):  # mods:570-583
 
     def forward(self, lattice_values, lattice_py):
         _require_2d(lattice_values)
+        if lattice_py is not None and lattice_py.rows_device() is not None:
+            # static-rows mode: the value matrix is taller than its lattice and torch's BatchNorm would count the padding rows
+            raise ValueError("BatchNormLatticeModule cannot run in static-rows mode (its statistics would include the padded rows); "
+                             "use GroupNorm blocks, or run eagerly (set_static_rows(None))")
         lattice_values = self.bn(lattice_values)
         lattice_py.set_values(lattice_values)
         return lattice_values, lattice_py
 
 
 _GN_WORKSPACES = {}
+_GN_PRIVATE = [None]  # accumulator pair of the captured step being warmed up / captured (use_gn_workspace)
+
+
+def new_gn_workspace(device, nbytes: int = 0):
+    """A zero-initialised accumulator pair for GroupNorm launches.  `nbytes` 0: large enough for the widest supported layer."""
+    if nbytes <= 0:
+        nbytes = int(_lib.load().ln_group_norm_workspace_bytes(1024))
+    n = max(nbytes // 8, 1)
+    return {"bufs": [torch.zeros((n,), dtype=torch.float64, device=device), torch.zeros((n,), dtype=torch.float64, device=device)],
+            "dirty": [0, 0], "cur": 0}
+
+
+class use_gn_workspace:
+    """Context: GroupNorm launches inside it alternate between the two buffers of `entry` instead of the (device, stream) pair.
+    A captured step owns such an entry for life: eager GroupNorm launches between its replays (validation passes, other models)
+    use the shared pair, so they can neither desynchronise the host's idea of which of the graph's buffers is zero nor free a
+    buffer the graph points at."""
+
+    def __init__(self, entry):
+        self.entry = entry
+
+    def __enter__(self):
+        self.prev, _GN_PRIVATE[0] = _GN_PRIVATE[0], self.entry
+        return self.entry
+
+    def __exit__(self, *exc):
+        _GN_PRIVATE[0] = self.prev
+        return False
 
 
 def _gn_workspace_pair(device, stream: int, nbytes: int):
     """(this call's accumulators, the next call's, bytes of the latter to zero) for GroupNorm launches on (device, stream): two
     zero-initialised buffers used alternately — every call zeroes what the other buffer's last user dirtied, so no call needs
     a fill launch of its own."""
-    key = (device, stream)
-    entry = _GN_WORKSPACES.get(key)
-    if entry is None or entry["bufs"][0].numel() * 8 < nbytes:
-        n = max(nbytes // 8, 1)
-        entry = {"bufs": [torch.zeros((n,), dtype=torch.float64, device=device), torch.zeros((n,), dtype=torch.float64, device=device)],
-                 "dirty": [0, 0], "cur": 0}
-        _GN_WORKSPACES[key] = entry
+    entry = _GN_PRIVATE[0]
+    if entry is not None:
+        if entry["bufs"][0].numel() * 8 < nbytes or entry["bufs"][0].device != device:
+            raise _lib.LatticeNetHipError("the captured step's GroupNorm accumulators are too small for this layer / on another device")
+    else:
+        key = (device, stream)
+        entry = _GN_WORKSPACES.get(key)
+        if entry is None or entry["bufs"][0].numel() * 8 < nbytes:
+            entry = new_gn_workspace(device, nbytes)
+            _GN_WORKSPACES[key] = entry
     cur = entry["cur"]
     nxt = cur ^ 1
     entry["cur"] = nxt
@@ -74,19 +109,20 @@ def _gn_workspace_pair(device, stream: int, nbytes: int):
 
 
 def reset_gn_workspaces(device=None):
-    """Zero-fills the GroupNorm accumulator pairs of the CURRENT stream and restarts their alternation.  A captured step calls this
-    first, so that every replay starts from the state the capture started from whatever ran on the stream in between (and whether
-    the step holds an even or an odd number of GroupNorm launches)."""
-    for (dev, stream), entry in _GN_WORKSPACES.items():
-        if (device is None or dev == device) and stream == _lib.stream_ptr(dev):
-            entry["bufs"][0].zero_()
-            entry["bufs"][1].zero_()
-            entry["dirty"] = [0, 0]
-            entry["cur"] = 0
+    """Zero-fills the GroupNorm accumulator pair in use — the private pair of the captured step being built (use_gn_workspace), else
+    the pairs of the CURRENT stream — and restarts its alternation.  A captured step calls this first, so that every replay starts
+    from the state the capture started from (whether the step holds an even or an odd number of GroupNorm launches)."""
+    entries = [_GN_PRIVATE[0]] if _GN_PRIVATE[0] is not None else \
+        [e for (dev, stream), e in _GN_WORKSPACES.items() if (device is None or dev == device) and stream == _lib.stream_ptr(dev)]
+    for entry in entries:
+        entry["bufs"][0].zero_()
+        entry["bufs"][1].zero_()
+        entry["dirty"] = [0, 0]
+        entry["cur"] = 0
 
 
 def _gn_check(rc: int, what: str, device, stream: int):
-    if rc != 0:
+    if rc != 0 and _GN_PRIVATE[0] is None:
         _GN_WORKSPACES.pop((device, stream), None)  # the zero invariant of the pair may be broken: start over with fresh buffers
     _lib.check(rc, what)
 

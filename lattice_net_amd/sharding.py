@@ -21,7 +21,10 @@ def init(backend: str, device=None):
         return None
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29511")
+    if "MASTER_PORT" not in os.environ:
+        # launchers (torch.distributed.run, the tests) set the port; a bare multi-process launch gets one derived from the common
+        # parent process, so that two jobs started side by side on one host do not meet on a fixed port
+        os.environ["MASTER_PORT"] = str(29500 + os.getppid() % 2000)
     kwargs = {}
     if backend == "nccl" and device is not None:
         kwargs["device_id"] = device

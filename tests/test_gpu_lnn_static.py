@@ -112,12 +112,38 @@ def test_lnn_training_step_as_one_graph(tmp_path):
         loss = cap.launch()
         torch.cuda.synchronize()
         assert abs(float(loss) - ref) <= 2e-5 * abs(ref), (float(loss), ref)
+        counts = cap.check()  # every level the replay built stayed inside its bound
+        assert sorted(counts) == [1, 2, 3] and all(counts[k] <= cap.bounds[k] for k in counts)
     worst = 0.0
     for k, q in net.named_parameters():
         if q.grad is None:
             continue
         worst = max(worst, float((q.grad - grads_a[k]).abs().max()) / max(float(grads_a[k].abs().max()), 1e-12))
     assert worst <= 1e-2, worst
+    # The rest runs on the capture stream (the loop form CapturedNetworkStep.launch recommends).
+    from lattice_net_amd import LatticeNetHipError
+    from lattice_net_amd.lattice_blocks import group_norm_rows
+    gn = torch.nn.GroupNorm(32, 192).to(pos.device)
+    big = torch.from_numpy(synthetic.lidar_cloud(pos.shape[0], 9)).to(pos.device) * 3.0
+    with torch.cuda.stream(cap.stream):
+        # an ODD number of eager GroupNorm launches, wider than anything in the network, between two replays: the graph owns its
+        # accumulator pair, so neither the alternation nor a reallocation of the shared (device, stream) pair can reach it
+        group_norm_rows(torch.randn((777, 192), device=pos.device), gn, True)
+        pos.copy_(pos_b)
+        loss = cap.launch()
+        cap.stream.synchronize()
+        assert abs(float(loss) - ref_b) <= 2e-5 * abs(ref_b), (float(loss), ref_b)
+        # a cloud with far more lattice vertices than the calibration cloud: the replay drops vertices, check() must say so
+        pos.copy_(big)
+        cap.launch()
+        cap.stream.synchronize()
+        with pytest.raises(LatticeNetHipError, match="static row bound|status bits"):
+            cap.check()
+        pos.copy_(pos_a)
+        loss = cap.launch()
+        cap.stream.synchronize()
+        assert abs(float(loss) - ref_a) <= 2e-5 * abs(ref_a)
+        cap.check()
 
 
 

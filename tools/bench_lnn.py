@@ -95,6 +95,7 @@ def make_graph_step(args, preset, cfg_text, net, opt, gen, dev, nll_loss_gather,
     state = {}
     pending = []  # the host stays at most two optimizer steps ahead of the GPU (fewer aborts than without: DESIGN.md 4.7)
 
+    make_graph_step.captures = scans  # (main() checks the row bounds of every replayed build after the timed loop)
     if args.graph_optimizer:
         return lambda: scans[0].launch()
 
@@ -221,6 +222,8 @@ def main():
             print("step", it, float(loss), flush=True)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
+    for cap in getattr(make_graph_step, "captures", []) if args.graph else []:
+        cap.check()  # raises if a replayed build left its static row bounds (its step would have trained on a truncated lattice)
     if args.host_profile:
         pr.disable()
         pstats.Stats(pr).sort_stats("tottime").print_stats(35)

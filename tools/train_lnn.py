@@ -103,7 +103,15 @@ def main():
             held["logsoftmax"] = logsoftmax.detach()
             return loss.detach()
 
-        cap = CapturedNetworkStep(one, lattice, list(net.parameters()), row_slack=0.10)
+        def loader(c):
+            def load():
+                pos_s.copy_(c[0])
+                vals_s.copy_(c[1])
+                target_s.copy_(c[2])
+            return load
+
+        # row bounds over every cloud of the rotation (+10 %); replays are checked against them below
+        cap = CapturedNetworkStep(one, lattice, list(net.parameters()), row_slack=0.10, calibration_loaders=[loader(c) for c in clouds])
     import contextlib
     loop_stream = contextlib.ExitStack()
     if cap is not None:
@@ -123,6 +131,17 @@ def main():
             sharding.barrier(dist)
             t_start, timed_from = time.perf_counter(), step
         pos, vals, target = clouds[step % len(clouds)]
+        if cap is not None and step % 32 == 31:
+            # every replayed build must have stayed inside its static row bounds (vertices beyond a bound are dropped silently on the
+            # device): one wait per 32 steps; on a violation the rest of the run is eager
+            torch.cuda.current_stream().synchronize()
+            try:
+                cap.check()
+            except Exception as exc:  # noqa: BLE001
+                print(f"[train_lnn] rank {rank}: {exc}; continuing in eager mode", flush=True)
+                loop_stream.close()
+                lattice.set_static_rows(None)
+                cap = None
         if cap is not None:
             pos_s.copy_(pos)
             vals_s.copy_(vals)
