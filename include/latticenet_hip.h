@@ -110,12 +110,13 @@ const char* ln_version(void);
  * against and refuses a stale library) */
 const char* ln_abi_hash(void);
 
-/* Live per-kernel timing with HIP events recorded on the launch stream (used by bench.py for the
- * roofline line).  ln_profile_begin arms bracketing of every launch of the kernel called
- * `kernel_name` (see ln_kernel_names), up to max_samples launches; ln_profile_end waits for the
- * recorded events, returns the summed duration and the number of launches, and disarms. */
+/* Live per-kernel timing (used by bench.py for the roofline block).  ln_profile_begin arms timing of every launch of the
+ * kernels named in `kernel_names` (one name of ln_kernel_names, or several separated by commas), up to max_samples launches in
+ * total: each such launch carries a (start, stop) event pair bound to the dispatch itself (hipExtLaunchKernelGGL), i.e. the
+ * kernel's own duration as rocprofv3 reports it.  ln_profile_end waits for the recorded pairs, returns the summed duration and
+ * the number of launches, and disarms.  Launches inside a stream capture cannot be timed this way (do not arm across one). */
 const char* ln_kernel_names(void);
-int ln_profile_begin(const char* kernel_name, int max_samples);
+int ln_profile_begin(const char* kernel_names, int max_samples);
 int ln_profile_end(double* total_ms, int* launches);
 
 /* HashTable::clear (src/HashTable.cu:49-57): entries=-1, keys=0, nr_filled=0 (+ our slots/status)

@@ -33,24 +33,30 @@ _ROUND_ROWS = 256 * 64  # one 64-vertex tile on every CU of an MI355X
 class CapturedStep:
     def __init__(self, step: Callable[[], object], lattices: Sequence[Lattice], *, row_slack: float = 0.06, regions: bool = True,
                  region_indices: Optional[Callable[[], torch.Tensor]] = None, stream: Optional[torch.cuda.Stream] = None,
-                 before_capture: Optional[Callable[[], None]] = None):
+                 before_capture: Optional[Callable[[], None]] = None, calibration_steps: Optional[Sequence[Callable[[], object]]] = None,
+                 more_steps: Optional[Sequence[Callable[[], object]]] = None):
         """`step`: the function to capture.  `lattices`: the Lattice objects it builds (each gets a static row bound).
         `region_indices`: returns the splat-index tensor of the calibration step when kd region planes are wanted (they are
         balanced on the token counts of that build); None: no regions.  `before_capture`: called right before the warm-up and
         the capture to drop references to earlier autograd graphs (a parameter's AccumulateGrad node lives as long as one of
-        them does and would run on the stream it was created on, which a capture of another stream cannot include)."""
+        them does and would run on the stream it was created on, which a capture of another stream cannot include).
+        `calibration_steps`: functions like `step` on OTHER clouds; when given, the row bounds (largest vertex count over them
+        x (1 + row_slack)) and the region planes (first of them) come from these instead of from `step`'s own cloud.
+        `more_steps`: further step functions — the same step reading other input tensors — each captured into a graph of its
+        own that shares the lattices, their bounds and workspaces with the first: `launch(i)` replays graph i.  A pool of
+        distinct clouds can then rotate through one captured scan without copying inputs."""
         self.step = step
         self.lattices = list(lattices)
         self.stream = stream
-        self.vertices = []
-        self.result = step()  # calibration (eager: reads the vertex counts back)
-        for lat in self.lattices:
-            m = lat.nr_lattice_vertices()
-            self.vertices.append(m)
-            if regions and region_indices is not None:
-                lat.set_region_planes(lat.balanced_region_planes(region_indices()))
-        if regions and region_indices is not None:
-            self.result = step()  # the eager reference result with the regions in place
+        self.vertices = [0] * len(self.lattices)
+        for ci, cal in enumerate(list(calibration_steps) if calibration_steps else [step]):
+            self.result = cal()  # calibration (eager: reads the vertex counts back)
+            for li, lat in enumerate(self.lattices):
+                self.vertices[li] = max(self.vertices[li], lat.nr_lattice_vertices())
+                if ci == 0 and regions and region_indices is not None:
+                    lat.set_region_planes(lat.balanced_region_planes(region_indices()))
+        if calibration_steps or (regions and region_indices is not None):
+            self.result = step()  # the eager reference result of `step` itself, with the regions in place
         torch.cuda.synchronize()
         for lat, m in zip(self.lattices, self.vertices):
             rows = min(lat.capacity(), ((int(m * (1.0 + row_slack)) + 255) // 256) * 256)
@@ -60,6 +66,8 @@ class CapturedStep:
             if snapped >= m * (1.0 + 0.5 * row_slack):
                 rows = snapped
             lat.set_static_rows(rows)
+        self.bounds = [lat.m_hash_table._static_rows for lat in self.lattices]
+        steps = [step] + list(more_steps or [])
         if before_capture is not None:
             before_capture()
         side = torch.cuda.Stream()
@@ -67,24 +75,31 @@ class CapturedStep:
         with torch.cuda.stream(side):
             for _ in range(2):
                 step()
+            for s in steps[1:]:
+                s()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        self.graphs, self.captured_results = [], []
         if before_capture is not None:
-            before_capture()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.captured = step()
+            before_capture()  # (once: the captures share torch's capture stream, and their results must stay referenced)
+        for s in steps:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.captured_results.append(s())
+            self.graphs.append(g)
+        self.graph, self.captured = self.graphs[0], self.captured_results[0]
 
-    def launch(self):
-        """One replay, on `stream` if one was given (asynchronous)."""
+    def launch(self, which: int = 0):
+        """One replay of graph `which`, on `stream` if one was given (asynchronous)."""
         if self.stream is None:
-            self.graph.replay()
+            self.graphs[which].replay()
         else:
             with torch.cuda.stream(self.stream):
-                self.graph.replay()
+                self.graphs[which].replay()
 
     def check(self):
-        """After a synchronise: every replayed build inside its row bound, no bucket overflow.  Returns the vertex counts."""
+        """After a synchronise: the LAST replayed build of every lattice inside its row bound, no bucket overflow.  Returns the
+        vertex counts."""
         return [lat.static_build_report()[0] for lat in self.lattices]
 
     def release(self):

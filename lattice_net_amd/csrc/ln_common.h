@@ -34,18 +34,22 @@ int ln_check_launch(const char* what);
 int ln_zero_async(void* p, size_t bytes, hipStream_t st);
 
 // ---- per-kernel live timing (ln_profile_begin / ln_profile_end) ------------------------------
-// Every launch goes through LN_LAUNCH.  When profiling is armed for NAME, the launch is bracketed
-// by hipEventRecord on the SAME stream the kernel is launched on.
-struct LnProfScope {
+// Every launch goes through LN_LAUNCH.  When profiling is armed for NAME the kernel is launched with hipExtLaunchKernelGGL and a
+// (start, stop) event pair: the pair brackets the DISPATCH itself (the kernel's own begin / end timestamps, what rocprofv3
+// reports as its duration), not the gaps in front of it as hipEventRecord calls around the launch would.
+#include <hip/hip_ext.h>
+struct LnProfEvents {
+    hipEvent_t start, stop;
     bool armed;
-    hipStream_t stream;
-    LnProfScope(const char* name, hipStream_t st);
-    ~LnProfScope();
 };
-#define LN_LAUNCH(NAME, KERNEL, GRID, BLOCK, LDS, STREAM, ...)                  \
-    do {                                                                        \
-        LnProfScope ln_prof_scope_(NAME, STREAM);                               \
-        hipLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, STREAM, __VA_ARGS__);      \
+LnProfEvents ln_prof_next(const char* name);
+#define LN_LAUNCH(NAME, KERNEL, GRID, BLOCK, LDS, STREAM, ...)                                                              \
+    do {                                                                                                                    \
+        const LnProfEvents ln_prof_ev_ = ln_prof_next(NAME);                                                                \
+        if (ln_prof_ev_.armed)                                                                                              \
+            hipExtLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, STREAM, ln_prof_ev_.start, ln_prof_ev_.stop, 0, __VA_ARGS__);  \
+        else                                                                                                                \
+            hipLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, STREAM, __VA_ARGS__);                                              \
     } while (0)
 
 // ---- key packing -----------------------------------------------------------------------

@@ -56,13 +56,13 @@ int ln_debug_mask() {
 }
 
 // ------------------------------------------------------------------------------------------
-// live per-kernel timing: HIP events recorded around each launch of ONE named kernel, on the
-// stream it is launched on (bench.py's roofline line is computed from these)
+// live per-kernel timing: a (start, stop) event pair bound to each dispatch of the armed kernels
+// (bench.py's roofline block is computed from these)
 // ------------------------------------------------------------------------------------------
 #include <vector>
 namespace {
 struct LnProfState {
-    char name[64] = "";
+    char names[256] = "";  // ",name1,name2," — the kernels whose launches are timed
     int max_samples = 0;
     std::vector<hipEvent_t> starts, stops;
     size_t used = 0;
@@ -70,24 +70,26 @@ struct LnProfState {
 LnProfState g_prof;
 }  // namespace
 
-LnProfScope::LnProfScope(const char* name, hipStream_t st) : armed(false), stream(st) {
-    if (g_prof.max_samples > 0 && g_prof.used < g_prof.starts.size() && strcmp(name, g_prof.name) == 0) {
-        armed = true;
-        (void)hipEventRecord(g_prof.starts[g_prof.used], stream);
+LnProfEvents ln_prof_next(const char* name) {
+    LnProfEvents ev{nullptr, nullptr, false};
+    if (g_prof.max_samples > 0 && g_prof.used < g_prof.starts.size()) {
+        char key[72];
+        snprintf(key, sizeof(key), ",%s,", name);
+        if (strstr(g_prof.names, key)) {
+            ev.start = g_prof.starts[g_prof.used];
+            ev.stop = g_prof.stops[g_prof.used];
+            ev.armed = true;
+            ++g_prof.used;
+        }
     }
-}
-LnProfScope::~LnProfScope() {
-    if (armed) {
-        (void)hipEventRecord(g_prof.stops[g_prof.used], stream);
-        ++g_prof.used;
-    }
+    return ev;
 }
 
 extern "C" const char* ln_kernel_names(void) { return "k_bucket_rows,k_canon_idx,k_canon_mark,k_canon_segs,k_canon_slots,k_conv_backward_fused,k_conv_generic,k_conv_generic_f16,k_conv_mfma,k_conv_mfma_f16,k_conv_split_bank,k_conv_sum_partials,k_csr_count,k_csr_fill,k_csr_group_sizes,k_csr_reduce_segments,k_csr_scan_local,k_csr_scan_top,k_csr_segment_max,k_csr_segment_max_decode,k_finalize,k_gather_backward,k_gather_forward,k_gn_apply,k_gn_backward_apply,k_gn_stats,k_grad_filter_f16,k_grad_filter_generic,k_grad_filter_mfma,k_grad_filter_mfma_f16,k_im2row,k_im2rowindices,k_insert_coarse,k_insert_points,k_linear_act_backward_w,k_linear_act_backward_x,k_linear_act_forward,k_linear_reduce_slabs,k_mark_first,k_max_centre_backward,k_max_centre_forward,k_max_centre_sum,k_neighbours,k_point_keys,k_reduce_and_neighbours,k_reduce_slabs,k_reduce_slabs_f32,k_retrieve_points,k_row2im,k_sc_reduce_slabs,k_sc_scatter_atomic,k_scan_blocks,k_scatter_point_rows,k_seg_min,k_slice_classify_backward,k_slice_classify_forward,k_slice_forward,k_slice_forward_f16,k_table_clear"; }
 
-extern "C" int ln_profile_begin(const char* kernel_name, int max_samples) {
-    LN_REQUIRE(kernel_name && strlen(kernel_name) < sizeof(g_prof.name) && max_samples > 0, LN_ERR_ARG, "ln_profile_begin: bad args");
-    LN_REQUIRE(g_prof.max_samples == 0, LN_ERR_ARG, "ln_profile_begin: profiling already armed for %s", g_prof.name);
+extern "C" int ln_profile_begin(const char* kernel_names, int max_samples) {
+    LN_REQUIRE(kernel_names && strlen(kernel_names) + 3 < sizeof(g_prof.names) && max_samples > 0, LN_ERR_ARG, "ln_profile_begin: bad args");
+    LN_REQUIRE(g_prof.max_samples == 0, LN_ERR_ARG, "ln_profile_begin: profiling already armed for %s", g_prof.names);
     g_prof.starts.resize(max_samples);
     g_prof.stops.resize(max_samples);
     for (int i = 0; i < max_samples; ++i) {
@@ -96,7 +98,7 @@ extern "C" int ln_profile_begin(const char* kernel_name, int max_samples) {
             return LN_ERR_LAUNCH;
         }
     }
-    strcpy(g_prof.name, kernel_name);
+    snprintf(g_prof.names, sizeof(g_prof.names), ",%s,", kernel_names);
     g_prof.used = 0;
     g_prof.max_samples = max_samples;
     return LN_OK;
@@ -125,7 +127,7 @@ extern "C" int ln_profile_end(double* total_ms, int* launches) {
     g_prof.stops.clear();
     g_prof.used = 0;
     g_prof.max_samples = 0;
-    g_prof.name[0] = 0;
+    g_prof.names[0] = 0;
     return rc;
 }
 extern "C" const char* ln_version(void) { return "latticenet_hip 0.2 (gfx950)"; }
