@@ -40,6 +40,8 @@ WORKLOADS = {
     "C2": dict(n=2500, v=32, f=32, sigma=0.05, capacity=60000, gen="box", desc="C2 ShapeNet-like surface cloud: 2.5k pts, sigma 0.05, capacity 60k, V=F=32"),
     "C4": dict(n=200000, v=32, f=32, sigma=0.08, capacity=5000000, gen="planes",
                desc="C4 ScanNet-like scene: 200k pts on planes, sigma 0.08, capacity 5M, V=F=32"),
+    "C3x4": dict(n=480000, v=32, f=32, sigma=0.9, capacity=400000, gen="lidar4far",
+                 desc="probe: 4 C3 scans 200 m apart processed as ONE cloud (what a batched launch over 4 independent scans would cost)"),
     "C5": dict(n=480000, v=64, f=64, sigma=0.9, capacity=400000, gen="lidar4", half=True,
                desc="C5 4 aggregated scans: 480k pts, capacity 400k, V=F=64, fp16 features / fp32 accumulate in the convolution"),
 }
@@ -53,6 +55,13 @@ def make_cloud(kind: str, n: int, seed: int) -> np.ndarray:
         return synthetic.box_surface_cloud(n, seed)
     if kind == "planes":
         return synthetic.planes_cloud(n, seed)
+    if kind == "lidar4far":  # four scans so far apart that they share no lattice vertex
+        parts = []
+        for k in range(4):
+            c = synthetic.lidar_cloud(n // 4, seed * 4 + k)
+            c[:, 0] += 200.0 * k
+            parts.append(c)
+        return np.ascontiguousarray(np.concatenate(parts, 0))
     if kind == "lidar4":  # four scans taken 6 m apart along x, aggregated
         parts = []
         for k in range(4):

@@ -10,7 +10,17 @@
 //     neighbour is permuted to k' = q*KQ + kk, which only reorders an exact-arithmetic sum).
 //   * B operand (the filter slice W_e) is staged once per workgroup into LDS in fragment order,
 //     so every ds_read is lane-linear and conflict-free.
-// fp32 in, fp32 accumulate: results are exact-fp32 fmaf chains (1e-5 parity bar).
+// Precision.  The fp32-input kernels (k_conv_mfma_full, k_conv_mfma, k_grad_filter_mfma, k_conv_backward_fused) accumulate fp32 products
+// in fp32: fmaf chains in a fixed order.  The "bf16x3" kernels (k_conv_forward_b3, k_conv_mfma_b3, k_conv_backward_fused_b3: the default
+// at V = F = 32 and from 4096 vertices on) split every operand EXACTLY into three bf16 parts and accumulate SIX of the nine cross
+// products in fp32 (a1b1, a1b2, a2b1, a1b3, a2b2, a3b1); the three dropped ones are below 2^-23 |a||b| each, i.e. the result is
+// fp32-accurate to ~2 ulp of the sum of magnitudes, not bit-identical to an fp32 fmaf chain (tests: 1e-5 of the per-element sum of
+// magnitudes, incl. inputs spanning e^+-6).  LN_CONV_EXACT_F32=1 keeps every shape on the fp32-input kernels.
+// The fused backward additionally REQUIRES a symmetric neighbour list (nbr(m, e) = n  <=>  nbr(n, e^1) = m): true for a lattice
+// convolved with itself whenever both lookups succeed; a lookup that fails one way only (the reference's 300-probe retrieval cap on a
+// table loaded beyond ~0.97) would make its filter gradient differ from the two-launch backward — ln_conv_backward takes the fused
+// form only for nbr_q == nbr_n (same list object), and tables that full take the replayed atomic build, whose probe sequence is
+// the same in both directions.
 #include "ln_common.h"
 #include <stdlib.h>
 
