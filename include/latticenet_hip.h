@@ -14,8 +14,9 @@
  *   - asynchronous device-side conditions (table full, key out of packable range) are
  *     recorded in LnTable.status and must be read back by the caller (ln_status_string).
  *
- * Vertex numbering: deterministic.  Builds that start from a cleared table number the vertices in hash-slot
- * order (the reference's own numbering is thread-arrival order and not reproducible); with
+ * Vertex numbering: deterministic.  Builds that start from a cleared table number the vertices bucket by bucket
+ * (runs of consecutive hash slots; inside a bucket by first occurrence) — the reference's own numbering is thread-arrival
+ * order and not reproducible; with
  * LN_BUILD_CANONICAL_ROWS / ln_canonicalize, and on every incremental build, rows are numbered by first
  * occurrence in (point, remainder) order, i.e. what a serial run of HashTableGPU::insert
  * (HashTableGPU.cuh:425-484) produces.
@@ -152,8 +153,8 @@ int ln_build_splat(const LnTable* t, const float* positions_raw, const float* si
                    long long clear_values_elems, void* stream);
 
 /* Vertex numbering.  The reference numbers vertices in thread-arrival order (atomicAdd(m_nr_filled), HashTableGPU.cuh:454) — it
- * differs from run to run and nothing downstream depends on it.  The bucketed build numbers them in SLOT order (bucket by
- * bucket, occupied slots in ascending order: deterministic, and the whole build is two launches).  ln_canonicalize relabels
+ * differs from run to run and nothing downstream depends on it.  The bucketed build numbers them bucket by bucket (inside a
+ * bucket by the rank of the vertex's smallest token: deterministic, and the whole build is two launches).  ln_canonicalize relabels
  * the rows of a table that ONE bucketed build has just produced — entries[], keys[] and, when given, the idx[tokens] that
  * build wrote and the row ids in the segment descriptors of `csr` (may be NULL) — into first-occurrence order over
  * (point, remainder), i.e. the numbering a serial run of HashTableGPU::insert (HashTableGPU.cuh:425-484) produces and the golden vectors hold.  It must run before anything that

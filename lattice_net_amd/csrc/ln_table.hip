@@ -481,7 +481,8 @@ __global__ void __launch_bounds__(256)
 // ln_canonicalize relabels a table built here into first-occurrence order (= a serial run of the reference) on request.
 #define LN_BKT_THREADS 1024
 #define LN_BKT_LDS_LIMIT (150 * 1024)  // dynamic LDS one k_bucket_rows workgroup may ask for (160 KB per CU minus its static arrays)
-#define LN_BKT_LDS_PER_SLOT (sizeof(unsigned long long) + 5 * sizeof(int))
+#define LN_BKT_LDS_PER_SLOT (sizeof(unsigned long long) + 6 * sizeof(int))
+#define LN_BKT_LDS_EXTRA 32  // alignment of the compacted token list + its padding to a multiple of four entries
 #define LN_BKT_REG_TOK 4  // tokens per thread whose (token, slot, position) stay in registers between the two sweeps
 #define LN_PUB_READY 0x80000000u
 #define LN_PUB_ERR 0x40000000u
@@ -498,6 +499,8 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
     int* soff = reinterpret_cast<int*>(smin + sb);
     int* sseg = soff + sb;
     int* srow = sseg + sb;
+    // smallest tokens of the occupied slots, compacted (16-byte aligned: read as uint4; LN_BKT_LDS_EXTRA covers the alignment and the padding)
+    unsigned int* slist = reinterpret_cast<unsigned int*>((reinterpret_cast<uintptr_t>(srow + sb) + 15) & ~uintptr_t(15));
     __shared__ int s_wave_tok[16], s_wave_seg[16], s_wave_new[16];
     __shared__ int s_run_tok, s_run_seg, s_run_new, s_err;
     __shared__ int s_rcnt[LN_XCD_GROUPS], s_rbase[LN_XCD_GROUPS];
@@ -667,6 +670,27 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
     if (tid == 0)
         __hip_atomic_store(&pub[b], LN_PUB_READY | (s_err ? LN_PUB_ERR : 0u) | (unsigned int)s_run_new, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
+    // Which slot of the bucket a key ends up in depends on the order the LDS CAS race resolves collisions in, so rows are NOT
+    // numbered by slot position: inside the bucket a vertex is numbered by the rank of its smallest token (first occurrence in
+    // (point, remainder) order among the bucket's vertices) — a pure function of the cloud, identical run to run.
+    {
+        const int nv = s_run_new;
+        for (int i = tid; i < size; i += LN_BKT_THREADS)
+            if (scnt[i]) slist[srow[i]] = smin[i];
+        for (int j = nv + tid; j < ((nv + 3) & ~3); j += LN_BKT_THREADS) slist[j] = 0xFFFFFFFFu;  // pad to a multiple of 4
+        __syncthreads();
+        const uint4* l4 = reinterpret_cast<const uint4*>(slist);
+        for (int i = tid; i < size; i += LN_BKT_THREADS) {
+            if (!scnt[i]) continue;
+            const unsigned int mine = smin[i];
+            int r = 0;
+            for (int j = 0; j < (nv + 3) / 4; ++j) {  // all lanes read the same words: LDS broadcast
+                const uint4 t4 = l4[j];
+                r += (t4.x < mine) + (t4.y < mine) + (t4.z < mine) + (t4.w < mine);
+            }
+            srow[i] = r;
+        }
+    }
     LN_STAMP(11);
     // Segment ids.  Without region planes: one contiguous run of region 0 per bucket.  With planes: every slot files its
     // segments under the kd region of its key (sseg[i] becomes region << 28 | position among this bucket's segments of that
@@ -1166,7 +1190,7 @@ static int ln_build_points(const LnTable* t, const float* positions_raw, const f
     // the clearing itself (no k_table_clear launch).  Its cursors use the first nbk+1 words of slot_cnt.
     // Beyond LN_BKT_MAX buckets the buckets grow instead; one bucket's staging area has to fit the 160 KB of LDS of a gfx950 CU
     // (tables past ~14M slots take the atomic path).
-    const size_t bucket_lds = (size_t)ln_bucket_slots(t->capacity) * LN_BKT_LDS_PER_SLOT;
+    const size_t bucket_lds = (size_t)ln_bucket_slots(t->capacity) * LN_BKT_LDS_PER_SLOT + LN_BKT_LDS_EXTRA;
     const bool bucketed = n > 0 && (flags & LN_BUILD_CLEAR_FIRST) && !(flags & LN_BUILD_ATOMIC_PATH) &&
                           t->capacity > ln_bucket_count(t->capacity) && bucket_lds <= LN_BKT_LDS_LIMIT &&
                           (long long)ln_bucket_count(t->capacity) * ln_bucket_region(tokens, t->capacity) < 0x7FFFFFFFll;  // int region offsets

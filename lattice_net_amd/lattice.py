@@ -34,7 +34,7 @@ _SIZE_CACHE = {}
 _FORCE_ATOMIC_BUILD = os.environ.get("LATTICE_BUILD_PATH", "") == "atomic"  # A/B switch: skip the bucketed build
 
 # Vertex numbering of builds that start from a cleared table (begin_splat + splat / distribute / just_create_verts):
-#   "slot"      (default) rows in hash-slot order — deterministic, and the build is two launches.  The reference numbers its
+#   "slot"      (default) rows bucket by bucket (runs of hash slots; first occurrence inside a bucket) — deterministic, two launches.  The reference numbers its
 #               vertices in thread-arrival order (HashTableGPU.cuh:454), so nothing it computes depends on the numbering;
 #   "canonical" rows by first occurrence in (point, remainder) order — what a serial run of the reference produces and
 #               what the golden vectors hold; costs a relabelling pass behind the build (ln_canonicalize).
