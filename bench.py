@@ -517,6 +517,12 @@ def main():
         for _ in range(3):
             eager_step()
         torch.cuda.synchronize()
+        if extras and latency is not None:  # the same step without graphs: one Python autograd pass per scan (round 1's execution)
+            t1 = time.perf_counter()
+            for _ in range(50):
+                eager_step()
+            torch.cuda.synchronize()
+            latency["eager_us_per_scan"] = round((time.perf_counter() - t1) / 50 * 1e6, 1)
         roofline = roofline_entry(args.roofline_kernel)
     if extras:
         for name in [k for k in args.extra_kernels.split(",") if k and k != args.roofline_kernel]:
