@@ -40,6 +40,8 @@ WORKLOADS = {
     "C2": dict(n=2500, v=32, f=32, sigma=0.05, capacity=60000, gen="box", desc="C2 ShapeNet-like surface cloud: 2.5k pts, sigma 0.05, capacity 60k, V=F=32"),
     "C4": dict(n=200000, v=32, f=32, sigma=0.08, capacity=5000000, gen="planes",
                desc="C4 ScanNet-like scene: 200k pts on planes, sigma 0.08, capacity 5M, V=F=32"),
+    "C4probe": dict(n=200000, v=32, f=32, sigma=0.08, capacity=1600000, gen="planes",
+                    desc="probe: C4 hashed into 2 x tokens = 1.6M slots instead of the cfg's 5M"),
     "C3x4": dict(n=480000, v=32, f=32, sigma=0.9, capacity=400000, gen="lidar4far",
                  desc="probe: 4 C3 scans 200 m apart processed as ONE cloud (what a batched launch over 4 independent scans would cost)"),
     "C5": dict(n=480000, v=64, f=64, sigma=0.9, capacity=400000, gen="lidar4", half=True,

@@ -162,6 +162,13 @@ int ln_build_splat(const LnTable* t, const float* positions_raw, const float* si
  * LN_BUILD_CANONICAL_ROWS makes ln_build_splat / ln_distribute do this themselves. */
 int ln_canonicalize(const LnTable* t, int* idx, long long tokens, const LnCsr* csr, void* workspace, size_t workspace_bytes, void* stream);
 
+/* A host may let a build hash into fewer slots than the table owns (LnTable.capacity = the slots in use: clearing and emitting
+ * the slot range then costs what the cloud needs, not what the cfg's hash_table_capacity reserves — slot positions are not
+ * reference-visible, only row ids are).  ln_rehash re-inserts the existing vertices (rows 0 .. nr_filled-1 of keys[]) into the
+ * slot range [0, t->capacity) of the same buffers — call it with the larger capacity before an incremental build that may
+ * outgrow the smaller range.  Rows, keys and counters are untouched. */
+int ln_rehash(const LnTable* t, void* stream);
+
 /* splatCacheNaive (LatticeGPU.cuh:926-973): table_values[idx] += vals * w. */
 int ln_splat_accumulate(float* table_values, const float* vals, const int* idx, const float* w, int n, int pos_dim,
                         int val_dim, void* stream);

@@ -5,7 +5,7 @@ Drop-in for the hot path of AIS-Bonn/lattice_net: the `latticenet.Lattice` opera
 (include/latticenet_hip.h, lattice_net_amd/csrc); there is no CPU fallback.
 """
 from ._lib import LatticeNetHipError, LIB_PATH, load as load_library  # noqa: F401
-from .lattice import HashTable, Lattice, get_row_order, set_row_order  # noqa: F401
+from .lattice import HashTable, Lattice, get_row_order, set_hash_capacity_policy, set_row_order  # noqa: F401
 from .lattice_wrapper import LatticeWrapper  # noqa: F401
 from .lattice_funcs import *  # noqa: F401,F403
 from .model_params import ModelParams  # noqa: F401

@@ -85,7 +85,7 @@ LnProfEvents ln_prof_next(const char* name) {
     return ev;
 }
 
-extern "C" const char* ln_kernel_names(void) { return "k_bucket_rows,k_canon_idx,k_canon_mark,k_canon_segs,k_canon_slots,k_conv_backward_fused,k_conv_generic,k_conv_generic_f16,k_conv_mfma,k_conv_mfma_f16,k_conv_split_bank,k_conv_sum_partials,k_csr_count,k_csr_fill,k_csr_group_sizes,k_csr_reduce_segments,k_csr_scan_local,k_csr_scan_top,k_csr_segment_max,k_csr_segment_max_decode,k_finalize,k_gather_backward,k_gather_forward,k_gn_apply,k_gn_backward_apply,k_gn_stats,k_grad_filter_f16,k_grad_filter_generic,k_grad_filter_mfma,k_grad_filter_mfma_f16,k_im2row,k_im2rowindices,k_insert_coarse,k_insert_points,k_linear_act_backward_w,k_linear_act_backward_x,k_linear_act_forward,k_linear_reduce_slabs,k_mark_first,k_max_centre_backward,k_max_centre_forward,k_max_centre_sum,k_neighbours,k_point_keys,k_reduce_and_neighbours,k_reduce_slabs,k_reduce_slabs_f32,k_retrieve_points,k_row2im,k_sc_reduce_slabs,k_sc_scatter_atomic,k_scan_blocks,k_scatter_point_rows,k_seg_min,k_slice_classify_backward,k_slice_classify_forward,k_slice_forward,k_slice_forward_f16,k_table_clear"; }
+extern "C" const char* ln_kernel_names(void) { return "k_bucket_rows,k_canon_idx,k_canon_mark,k_canon_segs,k_canon_slots,k_conv_backward_fused,k_conv_generic,k_conv_generic_f16,k_conv_mfma,k_conv_mfma_f16,k_conv_split_bank,k_conv_sum_partials,k_csr_count,k_csr_fill,k_csr_group_sizes,k_csr_reduce_segments,k_csr_scan_local,k_csr_scan_top,k_csr_segment_max,k_csr_segment_max_decode,k_finalize,k_gather_backward,k_gather_forward,k_gn_apply,k_gn_backward_apply,k_gn_stats,k_grad_filter_f16,k_grad_filter_generic,k_grad_filter_mfma,k_grad_filter_mfma_f16,k_im2row,k_im2rowindices,k_insert_coarse,k_insert_points,k_linear_act_backward_w,k_linear_act_backward_x,k_linear_act_forward,k_linear_reduce_slabs,k_mark_first,k_max_centre_backward,k_max_centre_forward,k_max_centre_sum,k_neighbours,k_point_keys,k_reduce_and_neighbours,k_reduce_slabs,k_reduce_slabs_f32,k_rehash_clear,k_rehash_rows,k_retrieve_points,k_row2im,k_sc_reduce_slabs,k_sc_scatter_atomic,k_scan_blocks,k_scatter_point_rows,k_seg_min,k_slice_classify_backward,k_slice_classify_forward,k_slice_forward,k_slice_forward_f16,k_table_clear"; }
 
 extern "C" int ln_profile_begin(const char* kernel_names, int max_samples) {
     LN_REQUIRE(kernel_names && strlen(kernel_names) + 3 < sizeof(g_prof.names) && max_samples > 0, LN_ERR_ARG, "ln_profile_begin: bad args");
@@ -1239,6 +1239,49 @@ extern "C" int ln_distribute(const LnTable* t, const float* positions_raw, const
     LN_REQUIRE(val_dim >= 1, LN_ERR_ARG, "ln_distribute: val_dim=%d", val_dim);
     return ln_build_points(t, positions_raw, sigmas_host, n, idx, w, flags | LN_BUILD_WRITE_IDX, vals, val_dim, distributed, csr, workspace,
                            workspace_bytes, clear_values, clear_values_elems, stream, "ln_distribute");
+}
+
+// ------------------------------------------------------------------------------------------
+// ln_rehash: re-insert the existing vertices (rows 0 .. nr_filled-1, keys[]) into the slot range [0, t->capacity)
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_rehash_clear(LnTable t) {
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < t.capacity; i += stride) {
+        t.slot_keys[i] = LN_EMPTY_KEY;
+        t.slot_tok[i] = LN_EMPTY_TOK;
+        t.slot_cnt[i] = 0;
+        t.entries[i] = -1;
+    }
+}
+
+template <int D>
+__global__ void __launch_bounds__(256) k_rehash_rows(LnTable t) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= *t.nr_filled || r >= t.capacity) return;
+    int key[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) key[i] = t.keys[(size_t)r * D + i];
+    const uint64_t pk = KeyPack<D>::pack(key, t.key_format);  // (it was packable when it was inserted)
+    const LnProbe pr = LnProbe::of_key<D>(key, t.capacity, ln_bucket_slots(t.capacity));
+    for (int probes = 0; probes < t.capacity; ++probes) {
+        const int h = pr.slot(probes);
+        if (atomicCAS(&t.slot_keys[h], (unsigned long long)LN_EMPTY_KEY, (unsigned long long)pk) == LN_EMPTY_KEY) {
+            t.entries[h] = r;
+            t.slot_tok[h] = 0u;  // an existing vertex: never "first occurrence" of a later build (k_mark_first tests entries[h] >= 0)
+            return;
+        }
+    }
+    atomicOr(t.status, LN_STATUS_TABLE_FULL);
+}
+
+extern "C" int ln_rehash(const LnTable* t, void* stream) {
+    int rc = ln_check_table(t, "ln_rehash");
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    int blocks = ln_div_up(t->capacity, 256);
+    LN_LAUNCH("k_rehash_clear", k_rehash_clear, dim3(blocks > 4096 ? 4096 : blocks), dim3(256), 0, st, *t);
+    LN_DISPATCH_D(t->pos_dim, { LN_LAUNCH("k_rehash_rows", k_rehash_rows<D>, dim3(blocks), dim3(256), 0, st, *t); });
+    return ln_check_launch("ln_rehash");
 }
 
 extern "C" int ln_canonicalize(const LnTable* t, int* idx, long long tokens, const LnCsr* csr, void* workspace, size_t workspace_bytes,

@@ -27,7 +27,7 @@ import torch
 
 from . import _lib
 
-__all__ = ["Lattice", "HashTable", "set_row_order", "get_row_order"]
+__all__ = ["Lattice", "HashTable", "set_row_order", "get_row_order", "set_hash_capacity_policy"]
 
 
 _SIZE_CACHE = {}
@@ -39,6 +39,18 @@ _FORCE_ATOMIC_BUILD = os.environ.get("LATTICE_BUILD_PATH", "") == "atomic"  # A/
 #   "canonical" rows by first occurrence in (point, remainder) order — what a serial run of the reference produces and
 #               what the golden vectors hold; costs a relabelling pass behind the build (ln_canonicalize).
 _ROW_ORDER = [os.environ.get("LATTICE_ROW_ORDER", "slot")]
+
+
+# How many slots of the table a build hashes into: "tokens" (default) = min(capacity, max(16384, 2 x tokens of the build)) for
+# builds that start from a cleared table, "full" = always the cfg's capacity (what the reference does).
+_HASH_POLICY = [os.environ.get("LATTICE_HASH_CAPACITY", "tokens")]
+
+
+def set_hash_capacity_policy(policy: str) -> str:
+    if policy not in ("tokens", "full"):
+        raise ValueError(f"hash capacity policy must be 'tokens' or 'full', got {policy!r}")
+    prev, _HASH_POLICY[0] = _HASH_POLICY[0], policy
+    return prev
 
 
 def set_row_order(order: str) -> str:
@@ -112,8 +124,14 @@ class _TableStorage:
         self.capacity = int(capacity)
         self.pos_dim = int(pos_dim)
         self.device = device
-        self.keys = torch.empty((capacity, pos_dim), dtype=torch.int32, device=device)
-        self.entries = torch.empty((capacity,), dtype=torch.int32, device=device)
+        # Slots actually hashed into (0 = not chosen yet: all of them).  The cfg's capacity is an upper bound chosen for the largest
+        # cloud (5 M slots for ScanNet scenes that fill 2.5 % of them); a build that starts from a cleared table hashes into
+        # min(capacity, 2 x its tokens) slots instead, so that clearing / emitting the slot range costs what the cloud needs
+        # (Lattice._build).  Slot positions are internal — only row ids are reference-visible.  Never shrinks: the rows every
+        # earlier build wrote stay inside the range a later clear covers.
+        self.hash_capacity = 0
+        self.keys = torch.zeros((capacity, pos_dim), dtype=torch.int32, device=device)  # (zeros: rows beyond a build's reach are never touched)
+        self.entries = torch.full((capacity,), -1, dtype=torch.int32, device=device)  # (-1 = empty: slots beyond the hashed range stay so)
         self.slot_keys = torch.empty((capacity,), dtype=torch.int64, device=device)
         self.slot_tok = torch.empty((capacity,), dtype=torch.int32, device=device)
         self.slot_cnt = torch.zeros((capacity,), dtype=torch.int32, device=device)  # scratch that is all-zero between builds
@@ -126,10 +144,14 @@ class _TableStorage:
         self.replay = None  # [rebuild on the atomic path, then the work queued behind the build], see Lattice._build
         self.planes = None  # int32[8] device tensor: kd split planes of key space (LnCsr.planes), None = no regions
 
+    def hashed(self) -> int:
+        return self.hash_capacity or self.capacity
+
     def clone(self) -> "_TableStorage":
         s = _TableStorage.__new__(_TableStorage)
         s.uid = next(_TableStorage._uids)
         s.capacity, s.pos_dim, s.device = self.capacity, self.pos_dim, self.device
+        s.hash_capacity = self.hash_capacity
         s.key_format = self.key_format
         s.keys = self.keys.clone()
         s.entries = self.entries.clone()
@@ -187,7 +209,7 @@ class HashTable:
 
     def init(self, pos_dim: int, val_dim: int, device):  # HashTable.cu:21-47
         self._storage = _TableStorage(self.m_capacity, pos_dim, device)
-        self.m_values_tensor = torch.empty((self.m_capacity, val_dim), dtype=torch.float32, device=device)
+        self.m_values_tensor = torch.zeros((self.m_capacity, val_dim), dtype=torch.float32, device=device)
         self._counters = torch.zeros((2,), dtype=torch.int32, device=device)
         self.m_nr_filled_is_dirty = True
         self.clear(lazy=True)  # rides in the first build call; every other reader flushes it
@@ -211,7 +233,7 @@ class HashTable:
                 self._pinned = torch.zeros((4,), dtype=torch.int32, pin_memory=True)
             self._pinned_np = self._pinned.numpy().view("int64")  # same memory: the host polls the build's 64-bit report word
             self._readback_event = torch.cuda.Event()
-        key = (s.uid, self._counters.data_ptr(), self._static_rows)
+        key = (s.uid, self._counters.data_ptr(), self._static_rows, s.hashed())
         if getattr(self, "_c_table_key", None) == key:
             return self._c_table
         self._c_table_key = key
@@ -219,7 +241,7 @@ class HashTable:
         return self._c_table
 
     def _make_c_table(self, s) -> _lib.LnTable:
-        return _lib.LnTable(s.capacity, s.pos_dim, s.slot_keys.data_ptr(), s.slot_tok.data_ptr(), s.slot_cnt.data_ptr(), s.entries.data_ptr(),
+        return _lib.LnTable(s.hashed(), s.pos_dim, s.slot_keys.data_ptr(), s.slot_tok.data_ptr(), s.slot_cnt.data_ptr(), s.entries.data_ptr(),
                             s.keys.data_ptr(), self._counters.data_ptr(), self._counters.data_ptr() + 4, self._pinned.data_ptr(), 0,
                             s.key_format, self._static_rows or 0)
 
@@ -492,10 +514,14 @@ class Lattice:
             idx = torch.empty((n * (d + 1),), dtype=torch.int32, device=dev)
             w = torch.empty((n * (d + 1),), dtype=torch.float32, device=dev)
         tokens = n * (d + 1)
-        cap = ht.capacity()
         st = ht._storage
-        csr_buf, csr, max_seg = self._alloc_csr(tokens, cap, st.planes)
         clear_vals, do_clear = ht.take_pending_clear()  # begin_splat's clear rides in the same C call
+        self._choose_hash_capacity(tokens, fresh=do_clear)
+        cap = st.hashed()
+        csr_buf, csr, max_seg = self._alloc_csr(tokens, cap, st.planes)
+        # rows beyond the hashed range can never have been written (a build makes at most `tokens` <= hashed / 2 rows, and the
+        # range never shrinks): the value accumulator was allocated zeroed, only its first `cap` rows are cleared per build
+        clear_elems = 0 if clear_vals is None else min(int(clear_vals.shape[0]), cap) * int(clear_vals.shape[1])
 
         def issue(force_atomic: bool):
             lib = _lib.load()
@@ -506,7 +532,7 @@ class Lattice:
                 flags |= _lib.LN_BUILD_ATOMIC_PATH
             if _ROW_ORDER[0] == "canonical":
                 flags |= _lib.LN_BUILD_CANONICAL_ROWS
-            cv, cn = _lib.ptr(clear_vals), (0 if clear_vals is None else clear_vals.numel())
+            cv, cn = _lib.ptr(clear_vals), clear_elems
             ht.arm_count_readback()  # t is ht's cached struct: the sequence number travels in it
             if distributed is None:
                 rc = lib.ln_build_splat(C.byref(t), _lib.ptr(positions_raw), self._sigmas_host(), n, _lib.ptr(idx), _lib.ptr(w), flags,
@@ -537,6 +563,22 @@ class Lattice:
         # build is reported by static_build_report() instead)
         st.replay = [lambda: issue(True)] if (do_clear and ht._static_rows is None) else None
         return idx, w
+
+    def _choose_hash_capacity(self, tokens: int, fresh: bool):
+        """Before a build: a build that starts from a cleared table may (re)choose how many slots it hashes into; an incremental
+        build into a table that hashes into fewer slots than it owns first re-hashes the existing vertices into all of them
+        (ln_rehash), so that the cfg's capacity — not the first cloud's size — bounds what can still be inserted."""
+        ht = self.m_hash_table
+        st = ht._storage
+        if fresh:
+            want = st.capacity if _HASH_POLICY[0] == "full" else min(st.capacity, max(16384, 2 * int(tokens)))
+            st.hash_capacity = max(st.hash_capacity, want)
+        elif st.hash_capacity and st.hash_capacity < st.capacity:
+            ht.flush()
+            st.hash_capacity = st.capacity
+            t = ht.c_table()
+            _lib.check(_lib.load().ln_rehash(C.byref(t), self._stream()), "ln_rehash")
+            st.touch()
 
     def _after_build(self, fn):
         """Runs fn() now and again if the build it depends on has to be replayed."""
@@ -600,7 +642,9 @@ class Lattice:
         _, csr, _, grp_row, _ = self._csr(idx)
         counts = torch.empty((m,), dtype=torch.int32, device=self._dev())
         lib = _lib.load()
-        _lib.check(lib.ln_csr_group_sizes(C.byref(csr), _lib.ptr(grp_row), self.m_hash_table.capacity(), m, _lib.ptr(counts), self._stream()),
+        # groups are hash slots (the CSR a build emitted: as many as that build hashed into) or rows (ln_csr_build)
+        groups_upper = self.m_hash_table._storage.hashed() if grp_row is not None else self.m_hash_table.capacity()
+        _lib.check(lib.ln_csr_group_sizes(C.byref(csr), _lib.ptr(grp_row), groups_upper, m, _lib.ptr(counts), self._stream()),
                    "ln_csr_group_sizes")
         return counts
 
@@ -630,8 +674,7 @@ class Lattice:
             # whatever tensor was left there (out of bounds if it is shorter, Lattice.cu:230).  Install a fresh one.
             pending = getattr(ht, "_clear_pending", False)
             ht._clear_pending = False
-            ht.m_values_tensor = torch.empty((cap, v), dtype=torch.float32, device=self._dev(positions_raw)) if pending else \
-                torch.zeros((cap, v), dtype=torch.float32, device=self._dev(positions_raw))
+            ht.m_values_tensor = torch.zeros((cap, v), dtype=torch.float32, device=self._dev(positions_raw))
             ht._clear_pending = pending  # a deferred begin_splat clear zeroes the new accumulator inside the build call
         idx, w = self._build(positions_raw, True)
         tv = ht.m_values_tensor
@@ -669,7 +712,7 @@ class Lattice:
         if reset_hashmap:
             # deep copy + clear of three CAP-sized tensors (Lattice.cu:376-391) == fresh cleared buffers
             nh._storage = _TableStorage(oh.capacity(), d, dev)
-            nh.m_values_tensor = torch.empty((oh.capacity(), oh.val_dim() or v), dtype=torch.float32, device=dev)
+            nh.m_values_tensor = torch.zeros((oh.capacity(), oh.val_dim() or v), dtype=torch.float32, device=dev)
             nh._counters = torch.zeros((2,), dtype=torch.int32, device=dev)
             nh.clear(lazy=True)  # issued inside the build call
         else:
@@ -962,7 +1005,8 @@ class Lattice:
         lib = _lib.load()
         m = self.nr_lattice_vertices()
         tokens = m * (2 * (self.pos_dim() + 1) + 1)
-        cap = coarse.m_hash_table.capacity()
+        coarse._choose_hash_capacity(tokens, fresh=True)  # (the coarse table is new: its deferred clear is flushed by c_table() below)
+        cap = coarse.m_hash_table._storage.hashed()
         ws = self._workspace(_build_sizes(tokens, cap)[0])
         csr_buf, csr, _ = self._alloc_csr(tokens, cap)
         tf, tc = self.m_hash_table.c_table(), coarse.m_hash_table.c_table()

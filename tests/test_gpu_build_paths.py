@@ -220,8 +220,14 @@ def test_very_large_tables_number_rows_like_a_small_one(cap, atomic, monkeypatch
     rng = np.random.default_rng(77)
     pos_np = ((rng.random((40000, 3), dtype=np.float32) - 0.5) * 6).astype(np.float32)
     vals_np = rng.standard_normal((40000, 4)).astype(np.float32)
+    import lattice_net_amd as L
     small, si, sw, sm, _ = build(pos_np, 0.2, 200000, False, monkeypatch, vals_np)
-    big, bi, bw, bm, _ = build(pos_np, 0.2, cap, atomic, monkeypatch, vals_np)
+    prev = L.set_hash_capacity_policy("full")  # hash into ALL slots (the default would use 2 x tokens = 320 k of them)
+    try:
+        big, bi, bw, bm, _ = build(pos_np, 0.2, cap, atomic, monkeypatch, vals_np)
+        assert big.hash_table()._storage.hashed() == cap
+    finally:
+        L.set_hash_capacity_policy(prev)
     assert bm == sm and sm > 20000
     assert torch.equal(bi, si) and torch.equal(bw, sw)
     assert torch.equal(big.hash_table().m_keys_tensor[:bm], small.hash_table().m_keys_tensor[:sm])
@@ -265,3 +271,43 @@ def test_lattice_key_format_covers_wide_clouds(d, reach):
     far.just_create_verts(T(pos_np * 50.0), True)
     with pytest.raises(L.LatticeNetHipError, match="packed 64-bit"):
         far.nr_lattice_vertices()
+
+
+def test_builds_hash_into_what_the_cloud_needs_and_grow_on_demand():
+    """A build that starts from a cleared table hashes into min(capacity, max(16384, 2 x tokens)) slots of a larger table (same
+    rows, keys, neighbours as with all slots in use); the range never shrinks; an incremental build first re-hashes the existing
+    vertices into the whole table (ln_rehash), after which the cfg's capacity bounds what can be inserted."""
+    import lattice_net_amd as L
+    rng = np.random.default_rng(9)
+    pos_np = ((rng.random((3000, 3), dtype=np.float32) - 0.5) * 8).astype(np.float32)
+    more_np = ((rng.random((60000, 3), dtype=np.float32) - 0.5) * 30).astype(np.float32)
+    cap = 2_000_000
+    lat = make_lattice(0.3, cap)
+    lat.begin_splat()
+    idx, w = lat.just_create_verts(T(pos_np), True)
+    m = lat.nr_lattice_vertices()
+    st = lat.hash_table()._storage
+    assert st.hashed() == max(16384, 2 * 12000) and lat.capacity() == cap
+    t = O.OracleHashTable(cap, 3)
+    oidx, ow = O.build_splat(t, O.scale_positions(pos_np, np.full((3,), 0.3, np.float32)))
+    assert m == t.nr_filled
+    np.testing.assert_array_equal(N(idx), oidx)
+    np.testing.assert_array_equal(N(lat.hash_table().m_keys_tensor[:m]), t.keys[:m])
+    assert not N(lat.hash_table().m_keys_tensor[m:m + 4096]).any()
+    np.testing.assert_array_equal(N(lat.neighbours(None, 1, False)), O.neighbour_rows(t.keys[:m], t, 1, 1, 1, False))
+    # incremental build (no reset): 240 k more tokens than the 24 k-slot range could ever hold
+    lat.begin_splat(reset_hashmap=False)
+    idx2, w2 = lat.just_create_verts(T(more_np), True)
+    m2 = lat.nr_lattice_vertices()
+    assert st.hashed() == cap
+    oidx2, ow2 = O.build_splat(t, O.scale_positions(more_np, np.full((3,), 0.3, np.float32)))
+    assert m2 == t.nr_filled and m2 > 24000
+    np.testing.assert_array_equal(N(idx2), oidx2)
+    np.testing.assert_array_equal(N(lat.hash_table().m_keys_tensor[:m2]), t.keys[:m2])
+    np.testing.assert_array_equal(N(lat.neighbours(None, 1, False)), O.neighbour_rows(t.keys[:m2], t, 1, 1, 1, False))
+    # a fresh build of the small cloud afterwards keeps the grown range (it never shrinks) and still matches
+    lat.begin_splat()
+    idx3, _ = lat.just_create_verts(T(pos_np), True)
+    assert lat.nr_lattice_vertices() == m and st.hashed() == cap
+    np.testing.assert_array_equal(N(idx3), oidx)
+    assert not N(lat.hash_table().m_keys_tensor[m:m2 + 16]).any(), "rows of the larger earlier build must be zero again"
