@@ -174,7 +174,9 @@ LN_HD uint32_t ln_hash(const int* key) {
 #ifndef LN_BKT_MIN_COUNT
 #define LN_BKT_MIN_COUNT 256
 #endif
+#ifndef LN_BKT_MIN_SLOTS
 #define LN_BKT_MIN_SLOTS 256
+#endif
 LN_HD int ln_bucket_slots(int capacity) {
     int nb = (capacity + LN_BKT_SLOTS - 1) / LN_BKT_SLOTS;
     if (nb < LN_BKT_MIN_COUNT) {

@@ -333,7 +333,10 @@ __global__ void __launch_bounds__(256)
 // it collects "a key did not fit the packed format".
 // points per thread: 2 keeps the (block, bucket) global atomics low; wide lattices take 1 so that the staging arrays fit
 // the 64 KB of static LDS
-#define LN_KEYS_PTS_PER_THREAD ((D) <= 3 ? 2 : 1)
+#ifndef LN_KEYS_PTS_SMALL_D
+#define LN_KEYS_PTS_SMALL_D 2
+#endif
+#define LN_KEYS_PTS_PER_THREAD ((D) <= 3 ? LN_KEYS_PTS_SMALL_D : 1)
 #define LN_KEYS_PTS_PER_BLOCK (256 * LN_KEYS_PTS_PER_THREAD)
 template <int D>
 __global__ void __launch_bounds__(256)
@@ -479,7 +482,10 @@ __global__ void __launch_bounds__(256)
 // pair, and the bucket cursors back to zero (every workgroup read them before it published).
 // The reference numbers vertices by thread-arrival order (atomicAdd(m_nr_filled), HashTableGPU.cuh:454: not reproducible);
 // ln_canonicalize relabels a table built here into first-occurrence order (= a serial run of the reference) on request.
+#ifndef LN_BKT_THREADS
 #define LN_BKT_THREADS 1024
+#endif
+#define LN_BKT_WAVES (LN_BKT_THREADS / 64)
 #define LN_BKT_LDS_LIMIT (150 * 1024)  // dynamic LDS one k_bucket_rows workgroup may ask for (160 KB per CU minus its static arrays)
 #define LN_BKT_LDS_PER_SLOT (sizeof(unsigned long long) + 6 * sizeof(int))
 #define LN_BKT_LDS_EXTRA 32  // alignment of the compacted token list + its padding to a multiple of four entries
@@ -553,7 +559,7 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
     __syncthreads();  // (every cursor[] load of this workgroup has returned by now: the last bucket relies on it)
     int base = 0;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) base += s_wave_tok[k];
+    for (int k = 0; k < LN_BKT_WAVES; ++k) base += s_wave_tok[k];
     __syncthreads();  // s_wave_tok is reused by the scans below
     LN_STAMP(9);
 
@@ -644,7 +650,7 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
         __syncthreads();
         int wt = 0, wg = 0, wn = 0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {  // all 48 LDS reads issue together (a loop to `wave` waits for each in turn)
+        for (int k = 0; k < LN_BKT_WAVES; ++k) {  // all LDS reads issue together (a loop to `wave` waits for each in turn)
             const int a = s_wave_tok[k], g2 = s_wave_seg[k], n2 = s_wave_new[k];
             if (k < wave) {
                 wt += a;
@@ -742,7 +748,7 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
     int base_row = 0;
     unsigned int err_all = s_err ? LN_PUB_ERR : 0u;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
+    for (int k = 0; k < LN_BKT_WAVES; ++k) {
         base_row += s_wave_tok[k];
         err_all |= (unsigned int)s_wave_seg[k];
     }
