@@ -686,15 +686,22 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
         for (int j = nv + tid; j < ((nv + 3) & ~3); j += LN_BKT_THREADS) slist[j] = 0xFFFFFFFFu;  // pad to a multiple of 4
         __syncthreads();
         const uint4* l4 = reinterpret_cast<const uint4*>(slist);
-        for (int i = tid; i < size; i += LN_BKT_THREADS) {
-            if (!scnt[i]) continue;
-            const unsigned int mine = smin[i];
+        const int nv4 = (nv + 3) / 4;
+        // two lanes per slot, each counting over one half of the list (all lanes of a wave read the same words: LDS broadcast)
+        for (int i0 = 0; i0 < size; i0 += LN_BKT_THREADS / 2) {  // workgroup-uniform trip count (shuffle inside)
+            const int i = i0 + (tid >> 1);
+            const int h = tid & 1;
+            const bool ok = i < size && scnt[i] != 0;
+            const unsigned int mine = ok ? smin[i] : 0u;
+            const int j0 = h ? nv4 / 2 : 0, j1 = h ? nv4 : nv4 / 2;
             int r = 0;
-            for (int j = 0; j < (nv + 3) / 4; ++j) {  // all lanes read the same words: LDS broadcast
-                const uint4 t4 = l4[j];
-                r += (t4.x < mine) + (t4.y < mine) + (t4.z < mine) + (t4.w < mine);
-            }
-            srow[i] = r;
+            if (ok)
+                for (int j = j0; j < j1; ++j) {
+                    const uint4 t4 = l4[j];
+                    r += (t4.x < mine) + (t4.y < mine) + (t4.z < mine) + (t4.w < mine);
+                }
+            r += __shfl_xor(r, 1, 64);
+            if (ok && h == 0) srow[i] = r;
         }
     }
     LN_STAMP(11);
