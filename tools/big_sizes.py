@@ -8,6 +8,7 @@ import lattice_net_amd as L
 from lattice_net_amd import lattice as LM
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
+L.set_row_order("canonical")  # the two build paths are compared bit for bit: the bucketed one relabels into first-occurrence order
 for (n, d, sigma, cap, v) in [(4_000_000, 3, 0.02, 12_000_000, 32), (3_000_000, 5, 0.25, 16_000_000, 8), (8_000_000, 3, 0.05, 6_000_000, 64)]:
     pos = (torch.rand((n, d), device=dev) - 0.5) * 4.0
     vals = torch.randn((n, v), device=dev)
