@@ -44,6 +44,7 @@ _ROW_ORDER = [os.environ.get("LATTICE_ROW_ORDER", "slot")]
 # How many slots of the table a build hashes into: "tokens" (default) = min(capacity, max(16384, 2 x tokens of the build)) for
 # builds that start from a cleared table, "full" = always the cfg's capacity (what the reference does).
 _HASH_POLICY = [os.environ.get("LATTICE_HASH_CAPACITY", "tokens")]
+_STATIC_SLOTS_PER_ROW = float(os.environ.get("LATTICE_STATIC_SLOTS_PER_ROW", "2.3"))  # static-rows mode: slots hashed into per bounded row
 
 
 def set_hash_capacity_policy(policy: str) -> str:
@@ -567,11 +568,24 @@ class Lattice:
     def _choose_hash_capacity(self, tokens: int, fresh: bool):
         """Before a build: a build that starts from a cleared table may (re)choose how many slots it hashes into; an incremental
         build into a table that hashes into fewer slots than it owns first re-hashes the existing vertices into all of them
-        (ln_rehash), so that the cfg's capacity — not the first cloud's size — bounds what can still be inserted."""
+        (ln_rehash), so that the cfg's capacity — not the first cloud's size — bounds what can still be inserted.
+
+        Static-rows mode knows more than the token count: at most `bound` vertices exist, so _STATIC_SLOTS_PER_ROW x bound slots
+        keep the load factor of the headline configuration (46.6 k vertices in 100 k slots) whatever the tokens per vertex are
+        (a ScanNet scene: 800 k tokens on 129 k vertices -> 296 k slots = 578 bucket workgroups instead of 2048).  That range
+        may be SMALLER than what earlier eager builds hashed into: the slots given up are emptied here, once."""
         ht = self.m_hash_table
         st = ht._storage
         if fresh:
             want = st.capacity if _HASH_POLICY[0] == "full" else min(st.capacity, max(16384, 2 * int(tokens)))
+            bound = ht._static_rows
+            if bound is not None and _HASH_POLICY[0] != "full":
+                want = min(want, max(16384, int(_STATIC_SLOTS_PER_ROW * bound) + 1))
+                # (a capture cannot re-shape the table: without a warm-up build in static-rows mode the wider range stays)
+                if st.hash_capacity and want < st.hash_capacity and not torch.cuda.is_current_stream_capturing():
+                    st.entries[want:st.hash_capacity] = -1
+                    st.hash_capacity = want
+                    st.touch()
             st.hash_capacity = max(st.hash_capacity, want)
         elif st.hash_capacity and st.hash_capacity < st.capacity:
             ht.flush()
@@ -674,8 +688,17 @@ class Lattice:
             # whatever tensor was left there (out of bounds if it is shorter, Lattice.cu:230).  Install a fresh one.
             pending = getattr(ht, "_clear_pending", False)
             ht._clear_pending = False
-            ht.m_values_tensor = torch.zeros((cap, v), dtype=torch.float32, device=self._dev(positions_raw))
-            ht._clear_pending = pending  # a deferred begin_splat clear zeroes the new accumulator inside the build call
+            if pending:
+                # a deferred begin_splat clear zeroes the rows a build can reach (the hashed range) inside the build call: a second
+                # fill of the same rows here would only cost (6 MB per step at the headline configuration); rows beyond are zeroed once
+                self._choose_hash_capacity(n * (d + 1), fresh=True)
+                reach = min(cap, ht._storage.hashed())
+                ht.m_values_tensor = torch.empty((cap, v), dtype=torch.float32, device=self._dev(positions_raw))
+                if reach < cap:
+                    ht.m_values_tensor[reach:].zero_()
+            else:
+                ht.m_values_tensor = torch.zeros((cap, v), dtype=torch.float32, device=self._dev(positions_raw))
+            ht._clear_pending = pending
         idx, w = self._build(positions_raw, True)
         tv = ht.m_values_tensor
         # splatCacheNaive (LatticeGPU.cuh:926-973) as a token-balanced reduce; begin_splat zeroed the table values
