@@ -32,6 +32,8 @@ int ln_check_launch(const char* what);
 // kept the previous replay's bits — a memory fault as soon as the replayed cloud differed from the captured one; ROCm 7.2,
 // MI355X), a kernel node does.
 int ln_zero_async(void* p, size_t bytes, hipStream_t st);
+// out[i] = sum over s of partial[s * total + i], slabs added in order (ln_conv.hip)
+int ln_reduce_slabs_async(const float* partial, int nslabs, int total, float* out, hipStream_t st);
 
 // ---- per-kernel live timing (ln_profile_begin / ln_profile_end) ------------------------------
 // Every launch goes through LN_LAUNCH.  When profiling is armed for NAME the kernel is launched with hipExtLaunchKernelGGL and a

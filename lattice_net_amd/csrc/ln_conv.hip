@@ -993,6 +993,15 @@ __global__ void __launch_bounds__(256) k_reduce_slabs4(const float* __restrict__
     }
 }
 
+// out[i] = sum over s of partial[s * total + i], in slab order (deterministic); shared with the fp16 filter gradient
+int ln_reduce_slabs_async(const float* partial, int nslabs, int total, float* out, hipStream_t st) {
+    if (total % 64 == 0 && ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(partial)) & 15) == 0)
+        LN_LAUNCH("k_reduce_slabs", k_reduce_slabs4, dim3(total / 64), dim3(256), 0, st, partial, nslabs, total, out);
+    else
+        LN_LAUNCH("k_reduce_slabs", k_reduce_slabs, dim3(ln_div_up(total, 16)), dim3(256), 0, st, partial, nslabs, total, out);
+    return LN_OK;
+}
+
 // Any multiple of 16 in both dimensions: the [V, F] block of a slot is covered by sub-blocks of {64, 32, 16} x {64, 32, 16}.
 static bool ln_gf_mfma_supported(int val_dim, int nr_filters) { return val_dim % 16 == 0 && nr_filters % 16 == 0; }
 
@@ -1047,10 +1056,7 @@ extern "C" int ln_conv_grad_filter(const int* nbr, const float* values_neigh, co
         float* partial = static_cast<float*>(workspace);
         const int chunks = ln_gf_launch_partials(nbr, values_neigh, grad_out, m, filter_extent, val_dim, nr_filters, partial, st);
         // slabs are laid out [chunk][e][V*F]; summing over chunks with stride E*V*F
-        if (total % 64 == 0 && (reinterpret_cast<uintptr_t>(grad_filter) & 15) == 0)  // (always, for multiples of 16 in both dimensions)
-            LN_LAUNCH("k_reduce_slabs", k_reduce_slabs4, dim3(total / 64), dim3(256), 0, st, (const float*)partial, chunks, total, grad_filter);
-        else
-            LN_LAUNCH("k_reduce_slabs", k_reduce_slabs, dim3(ln_div_up(total, 16)), dim3(256), 0, st, partial, chunks, total, grad_filter);
+        (void)ln_reduce_slabs_async(partial, chunks, total, grad_filter, st);
     } else {
         LN_LAUNCH("k_grad_filter_generic", k_grad_filter_generic, dim3(ln_div_up(total, 256)), dim3(256), 0, st, nbr, values_neigh, grad_out, m,
                            filter_extent, val_dim, nr_filters, grad_filter);
@@ -1523,10 +1529,7 @@ extern "C" int ln_conv_backward(const int* nbr_q, const int* nbr_n, const float*
         break;
             switch (bwd_t) { LN_BWD_FUSED(1) LN_BWD_FUSED(2) LN_BWD_FUSED(3) LN_BWD_FUSED(4) }
 #undef LN_BWD_FUSED
-            if ((reinterpret_cast<uintptr_t>(grad_filter) & 15) == 0)
-                LN_LAUNCH("k_reduce_slabs", k_reduce_slabs4, dim3(total / 64), dim3(256), 0, st, (const float*)partial, wgs, total, grad_filter);
-            else
-                LN_LAUNCH("k_reduce_slabs", k_reduce_slabs, dim3(ln_div_up(total, 16)), dim3(256), 0, st, (const float*)partial, wgs, total, grad_filter);
+            (void)ln_reduce_slabs_async(partial, wgs, total, grad_filter, st);
             return ln_check_launch("ln_conv_backward");
         }
         const int conv_blocks = ln_div_up(mn, 64);

@@ -171,7 +171,7 @@ extern "C" int ln_conv_forward_f16(const int* nbr, const void* values_neigh, con
 // grid = (row chunks, E).  The contraction runs over lattice vertices (rows), so both MFMA operands are read
 // "down the rows": a sub-tile of 64 rows is staged TRANSPOSED in LDS (s_at[v][row], s_gt[f][row], row stride padded to
 // 68 halfs) and lane (i, q) reads 4 consecutive rows of column i as one 8-byte word.  Each wave owns whole 16x16 output
-// tiles D[v, f]; partial [V, F] blocks per row chunk go to slabs, summed by k_reduce_slabs_f32 (deterministic).
+// tiles D[v, f]; partial [V, F] blocks per row chunk go to slabs, summed by k_reduce_slabs4 / k_reduce_slabs (ln_conv.hip, deterministic).
 // ------------------------------------------------------------------------------------------
 #define LN_GF16_ROWS 512
 #define LN_GF16_SUB 64
@@ -296,14 +296,6 @@ __global__ void __launch_bounds__(256)
     }
 }
 
-__global__ void __launch_bounds__(256) k_reduce_slabs_f32(const float* __restrict__ partial, int nslabs, int total, float* __restrict__ out) {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= total) return;
-    float acc = 0.f;
-    for (int s = 0; s < nslabs; ++s) acc += partial[(size_t)s * total + g];
-    out[g] = acc;
-}
-
 extern "C" size_t ln_conv_grad_filter_f16_workspace_bytes(int m, int filter_extent, int val_dim, int nr_filters) {
     if (m <= 0) return 256;
     return (size_t)ln_div_up(m, LN_GF16_ROWS) * filter_extent * val_dim * nr_filters * sizeof(float) + 256;
@@ -352,6 +344,6 @@ extern "C" int ln_conv_grad_filter_f16(const int* nbr, const void* values_neigh,
                   lds, st, nbr, static_cast<const _Float16*>(values_neigh), static_cast<const _Float16*>(grad_out), m, filter_extent, val_dim,
                   nr_filters, partial);
     }
-    LN_LAUNCH("k_reduce_slabs_f32", k_reduce_slabs_f32, dim3(ln_div_up(total, 256)), dim3(256), 0, st, partial, chunks, total, grad_filter);
+    (void)ln_reduce_slabs_async(partial, chunks, total, grad_filter, st);  // (147 slabs of 147 KB at C5: one serial pass per output took 35 us)
     return ln_check_launch("ln_conv_grad_filter_f16");
 }

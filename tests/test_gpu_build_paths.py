@@ -311,3 +311,46 @@ def test_builds_hash_into_what_the_cloud_needs_and_grow_on_demand():
     assert lat.nr_lattice_vertices() == m and st.hashed() == cap
     np.testing.assert_array_equal(N(idx3), oidx)
     assert not N(lat.hash_table().m_keys_tensor[m:m2 + 16]).any(), "rows of the larger earlier build must be zero again"
+
+
+def test_static_rows_builds_hash_into_a_range_that_follows_the_row_bound():
+    """Static-rows mode: a build hashes into 2.3 x the row bound when that is less than 2 x its tokens (many tokens per vertex:
+    ScanNet-like scenes) — the range SHRINKS once, on the first static build outside a capture, the slots given up are emptied,
+    rows / keys / splat values still match the oracle, and leaving the mode lets the next eager build grow the range again."""
+    rng = np.random.default_rng(11)
+    # 30 k points on a coarse lattice: 120 k tokens on a few thousand vertices
+    pos_np = ((rng.random((30000, 3), dtype=np.float32) - 0.5) * 6).astype(np.float32)
+    vals_np = rng.standard_normal((30000, 8)).astype(np.float32)
+    sig = 0.25
+    cap = 1_000_000
+    lat = make_lattice(sig, cap)
+    lat.begin_splat()
+    lat.splat_standalone(T(pos_np), T(vals_np))
+    m = lat.nr_lattice_vertices()
+    st = lat.hash_table()._storage
+    assert st.hashed() == 240000 and m * 2.3 < 100000
+    bound = ((int(m * 1.06) + 255) // 256) * 256
+    lat.set_static_rows(bound)
+    lat.begin_splat()
+    idx, w = lat.splat_standalone(T(pos_np), T(vals_np))
+    want = max(16384, int(2.3 * bound) + 1)
+    assert st.hashed() == want
+    assert lat.static_build_report()[0] == m
+    assert (N(st.entries[want:240000]) == -1).all(), "slots outside the new range must read as empty"
+    t = O.OracleHashTable(cap, 3)
+    oidx, ow = O.build_splat(t, O.scale_positions(pos_np, np.full((3,), sig, np.float32)))
+    np.testing.assert_array_equal(N(idx), oidx)
+    np.testing.assert_array_equal(N(lat.hash_table().m_keys_tensor[:m]), t.keys[:m])
+    ovals = np.zeros((m, 8), np.float64)
+    np.add.at(ovals, oidx, np.repeat(vals_np.astype(np.float64), 4, axis=0) * ow[:, None])
+    got = N(lat.values())
+    assert got.shape[0] == bound
+    np.testing.assert_allclose(got[:m], ovals, rtol=1e-5, atol=1e-5 * np.abs(ovals).max())
+    assert not got[m:].any()
+    np.testing.assert_array_equal(N(lat.neighbours(None, 1, False))[:m], O.neighbour_rows(t.keys[:m], t, 1, 1, 1, False))
+    # back to eager mode: the next build from a cleared table hashes into 2 x tokens again and still matches
+    lat.set_static_rows(None)
+    lat.begin_splat()
+    idx2, _ = lat.splat_standalone(T(pos_np), T(vals_np))
+    assert st.hashed() == 240000 and lat.nr_lattice_vertices() == m
+    np.testing.assert_array_equal(N(idx2), oidx)
