@@ -542,8 +542,8 @@ def main():
     if extras:
         c0 = cs0.clouds[0]
         names = ["splat", "conv", "slice", "backward"]
-        acc_ms = dict.fromkeys(names, 0.0)
-        reps = 10
+        acc_ms = {nm: [] for nm in names}
+        reps = 15
         for _ in range(reps):
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
             W.grad = None
@@ -563,13 +563,13 @@ def main():
             ev[4].record()
             torch.cuda.synchronize()
             for k, nm in enumerate(names):
-                acc_ms[nm] += ev[k].elapsed_time(ev[k + 1])
-        us = {nm: acc_ms[nm] / reps * 1e3 for nm in names}
+                acc_ms[nm].append(ev[k].elapsed_time(ev[k + 1]))
+        us = {nm: float(np.median(acc_ms[nm])) * 1e3 for nm in names}  # (median: one host hiccup between two launches would own a mean)
         splat_bytes = n * (4.0 * d + 4.0 * v + 8.0 * (d + 1)) + m * (4.0 * d + 4.0 * v)
         slice_bytes = n * (8.0 * (d + 1) + 4.0 * v) + m * 4.0 * v
         ss_bytes = splat_bytes + slice_bytes
         stages = {"us": {k: round(x, 1) for k, x in us.items()},
-                  "note": "eager steps, event-to-event on the launch stream; `splat` = clear + hash build + accumulate (+ the neighbour "
+                  "note": "eager steps, event-to-event on the launch stream, median of 15; `splat` = clear + hash build + accumulate (+ the neighbour "
                           "prefetch issued behind it), `conv` includes the wait for the vertex-count readback"}
         if graph_mode and not half:
             # splat -> slice (forward) alone, in the benchmark's execution mode: one hipGraph per cloud, clouds rotating, scans in flight.
