@@ -2,7 +2,9 @@
 #pragma once
 #include "ln_common.h"
 
+#ifndef LN_CSR_SEG
 #define LN_CSR_SEG 16  // max CSR entries per segment (unit of work of the segment reduce)
+#endif
 
 size_t ln_csr_scan_workspace_bytes(int groups_upper);
 

@@ -354,3 +354,38 @@ def test_static_rows_builds_hash_into_a_range_that_follows_the_row_bound():
     idx2, _ = lat.splat_standalone(T(pos_np), T(vals_np))
     assert st.hashed() == 240000 and lat.nr_lattice_vertices() == m
     np.testing.assert_array_equal(N(idx2), oidx)
+
+
+def test_cloud_far_beyond_the_static_bound_fills_the_shrunk_range_without_hanging():
+    """A cloud with 80x the vertices of the static bound meets a hashed range (2.3 x bound slots) it cannot fit into: the build
+    must come back (no endless probing), flag the step through the report word, hand out no row >= bound, and the same lattice
+    must build the cloud correctly once static-rows mode is left."""
+    rng = np.random.default_rng(3)
+    small = ((rng.random((2000, 3), dtype=np.float32) - 0.5) * 4).astype(np.float32)
+    big = ((rng.random((60000, 3), dtype=np.float32) - 0.5) * 40).astype(np.float32)
+    lat = make_lattice(0.3, 1_000_000)
+    lat.begin_splat()
+    lat.splat_standalone(T(small), T(rng.standard_normal((2000, 8)).astype(np.float32)))
+    m = lat.nr_lattice_vertices()
+    bound = ((int(m * 1.06) + 255) // 256) * 256
+    lat.set_static_rows(bound)
+    lat.begin_splat()
+    lat.splat_standalone(T(small), T(rng.standard_normal((2000, 8)).astype(np.float32)))
+    torch.cuda.synchronize()
+    assert lat.static_build_report() == (m, 0) and lat.hash_table()._storage.hashed() == 16384
+    vb = T(rng.standard_normal((60000, 8)).astype(np.float32))
+    lat.begin_splat()
+    idx, _ = lat.splat_standalone(T(big), vb)
+    torch.cuda.synchronize()
+    import lattice_net_amd as L
+    with pytest.raises(L.LatticeNetHipError):
+        lat.static_build_report()
+    assert int(idx.max()) < bound and int((idx < 0).sum()) > 0
+    lat.set_static_rows(None)
+    lat.begin_splat()
+    idx2, _ = lat.splat_standalone(T(big), vb)
+    m2 = lat.nr_lattice_vertices()
+    t = O.OracleHashTable(1_000_000, 3)
+    oidx, _ = O.build_splat(t, O.scale_positions(big, np.full((3,), 0.3, np.float32)))
+    assert m2 == t.nr_filled and m2 > 50 * bound
+    np.testing.assert_array_equal(N(idx2), oidx)
