@@ -159,3 +159,68 @@ def test_reference_style_checkpoint_round_trip(cfg_path, tmp_path):
     assert not missing and not unexpected
     for (ka, va), (kb, vb) in zip(a.state_dict().items(), b.state_dict().items()):
         assert ka == kb and torch.equal(va, vb)
+
+
+def test_state_dict_key_space_is_the_reference_classes_attribute_names(cfg_path):
+    """every component of every state_dict key of the assembled LNN is a name the reference's class of the same name
+    assigns on `self` (tests/golden/reference_attribute_names.json, extracted from the reference's source by
+    tests/golden/make_reference_attribute_names.py), a ModuleList index, or a parameter name of a stock torch module.  A
+    checkpoint written by the reference addresses its tensors by exactly these paths."""
+    import json
+    import os
+    from lattice_net_amd.models import LNN
+    names = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_attribute_names.json")))
+    torch_params = {"Linear": {"weight", "bias"}, "GroupNorm": {"weight", "bias"}}
+
+    def allowed_names(cls):
+        e = names[cls]
+        if "weight_norm_of" in e:  # X = weight_norm_wrapper(Base): torch's WeightNorm replaces <name> by <name>_g / <name>_v
+            base = e["weight_norm_of"]
+            inner = allowed_names(base) if base in names else set(torch_params[base])
+            return (inner - {e["weight_norm_name"]}) | {e["weight_norm_name"] + "_g", e["weight_norm_name"] + "_v"}
+        return set(e["self_attributes"])
+
+    torch.manual_seed(0)
+    net = LNN(20, ModelParams.create(cfg_path), device="cpu")
+    checked = set()
+    for path, mod in net.named_modules():
+        cls = type(mod).__name__
+        mine = set(mod._modules) | set(mod._parameters) | set(mod._buffers)
+        if cls not in names:
+            # containers and stock torch layers only
+            assert cls in ("ModuleList", "Sequential", "GroupNorm", "Linear", "Dropout", "ReLU", "LeakyReLU", "Tanh", "LogSoftmax", "GELU",
+                           "Identity"), f"{path}: class {cls} does not exist in the reference's lattice_modules.py / models.py / utils.py"
+            assert mine <= torch_params.get(cls, set()) or cls in ("ModuleList", "Sequential")
+            continue
+        allowed = allowed_names(cls)
+        assert mine <= allowed, f"{path} ({cls}): {sorted(mine - allowed)} are not attributes of the reference's {cls}"
+        checked.add(cls)
+    # the network is made of the reference's classes, weight-normalised ones included
+    assert {"LNN", "PointNetModule", "LinearWN", "ConvLatticeIm2RowWNModule", "CoarsenAct", "GnReluFinefy", "ResnetBlock", "BottleneckBlock",
+            "GnReluConv", "GnRelu1x1", "GroupNormLatticeModule", "SliceFastCUDALatticeModule"} <= checked, sorted(checked)
+    sd = net.state_dict()
+    for path, mod in net.named_modules():  # tensors the reference's lattice operators own directly (created lazily there, eagerly here)
+        if type(mod).__name__ in ("ConvLatticeModule", "ConvLatticeIm2RowModule", "CoarsenLatticeModule", "FinefyLatticeModule"):
+            assert f"{path}.weight" in sd
+
+
+def test_every_class_of_the_reference_module_files_exists_under_the_same_name():
+    """The fixture's class list (reference lattice_modules.py incl. its weight-normalised aliases, models.py) against the reference's
+    import paths: `from latticenet_py.lattice.lattice_modules import *` finds every name (operator modules live in
+    lattice_net_amd.lattice_modules, network blocks in lattice_net_amd.lattice_blocks; the alias module joins them as the reference does)."""
+    import json
+    import os
+    import latticenet_py.lattice.lattice_modules as RM
+    import latticenet_py.lattice.models as RMD
+    import lattice_net_amd.lattice_modules as M
+    names = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_attribute_names.json")))
+    seen = 0
+    for cls, e in names.items():
+        if e["file"] == "lattice_modules.py":
+            assert hasattr(RM, cls), f"latticenet_py.lattice.lattice_modules.{cls} is missing"
+            seen += 1
+        elif e["file"] == "models.py":
+            assert hasattr(RMD, cls), f"latticenet_py.lattice.models.{cls} is missing"
+            seen += 1
+    assert seen >= 40
+    assert RM.ConvLatticeIm2RowWNModule is M.ConvLatticeIm2RowWNModule and RM.PointNetModule is M.PointNetModule
