@@ -420,12 +420,12 @@ def main():
             cs.capture()
         for i in range(pool * in_flight):  # validation replays (untimed): every captured graph once ...
             sets[i % in_flight].launch(i // in_flight)
-    for i in range(max(args.warmup, in_flight)):  # the W warm-up steps
-        sets[i % in_flight].launch(i // in_flight)
-    barrier()
-    if graph_mode:
+        barrier()
         errs = [cs.check() for cs in sets]  # ... compared with the eager results before anything is timed
         graph_err = {k: max(er[k] for er in errs) for k in errs[0]}
+    for i in range(max(args.warmup, in_flight)):  # the W warm-up steps, directly in front of the timed region
+        sets[i % in_flight].launch(i // in_flight)
+    barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):  # K steps = K scans, issued round-robin over the scans in flight, each taking the next cloud of its pool
         sets[i % in_flight].launch(i // in_flight)
