@@ -318,6 +318,9 @@ int ln_splat_accumulate_and_neighbours_f16(const LnCsr* csr, const int* grp_row,
                                            int val_dim, int src_div, int src_stride, float* dst, const LnTable* table, int query_rows_upper,
                                            int* nbr, void* stream);
 int ln_slice_forward_f16(const void* values_f16, const int* idx, const float* w, int n, int pos_dim, int val_dim, void* out_f16, void* stream);
+/* ... that also zero-fills the fp32 accumulator of this slice's backward pass (as ln_slice_forward_prepare_backward). */
+int ln_slice_forward_f16_prepare_backward(const void* values_f16, const int* idx, const float* w, int n, int pos_dim, int val_dim, void* out_f16,
+                                          float* grad_accumulator, long long grad_accumulator_elems, void* stream);
 
 /* Half-precision feature path of the convolution (BASELINE.json config 5 / SURVEY.md 8d C5: features fp16, accumulate
  * fp32).  Same arguments and flags as ln_conv_forward / ln_conv_grad_filter; values, filter bank, grad_out and out are

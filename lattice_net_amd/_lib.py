@@ -112,6 +112,7 @@ SIGNATURES = {
     "ln_csr_reduce_rows_f16": (_i, [_CSR, _vp, _ll, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "ln_splat_accumulate_and_neighbours_f16": (_i, [_CSR, _vp, _ll, _vp, _vp, _i, _i, _i, _vp, _T, _i, _vp, _vp]),
     "ln_slice_forward_f16": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "ln_slice_forward_f16_prepare_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _ll, _vp]),
     "ln_conv_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "ln_conv_forward_f16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "ln_conv_grad_filter_f16_workspace_bytes": (_sz, [_i, _i, _i, _i]),

@@ -78,6 +78,145 @@ __global__ void __launch_bounds__(256)
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// pos_dim 3 (E = 9), V and F in {32, 64}: the whole filter bank staged ONCE per workgroup, in MFMA fragment order, for T sub-tiles
+// of 64 vertices (blockDim.x = 256 T, the shape of ln_conv.hip's k_conv_forward_b3): 72 KB of LDS at V = F = 64, two workgroups
+// per CU.  The per-slot kernel above re-stages 8 KB per slot with two barriers and 2-byte global loads, and starts each
+// neighbour-row gather only after the previous slot's matrix instructions: 42 us at C5 (70 k vertices) against 2 x 21 here.
+//   fragment unit (e, s, nt, lane = (qq, fi)) = the 4 halfs W_e[k = qq * V/4 + 4 s + j][f = 16 nt + fi], j = 0..3 (8 bytes)
+//   bank [E*V, F]   : a thread reads 4 rows x 8 columns (four 16-byte loads) and writes the 8 units of its columns;
+//   bank^T [E*F, V] : a thread reads 8 consecutive k of one column (one 16-byte load) = two units.
+// ------------------------------------------------------------------------------------------
+typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
+template <int V, int NT, bool FLIP, bool WT>
+__global__ void __launch_bounds__(1024)
+    k_conv_f16_tiled(const int* __restrict__ nbr, const _Float16* __restrict__ values, const _Float16* __restrict__ filter, int m,
+                     _Float16* __restrict__ out) {
+    constexpr int E = 9, F = 16 * NT, KQ = V / 4, S = KQ / 4, G8 = KQ / 8;
+    static_assert(V % 32 == 0, "a lane's quarter row is read in 16-byte words");
+    __shared__ __attribute__((aligned(16))) halfx4 s_frag[E * S * NT * 64];
+    const int tid = threadIdx.x;
+    const int nthreads = blockDim.x;
+    const int lane = tid & 63;
+    const int i = lane & 15;
+    const int q = lane >> 4;
+    const int m0 = blockIdx.x * (nthreads / 4) + (tid >> 6) * 16;
+    const int my_row = m0 + i;
+    int nb[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) nb[e] = (my_row < m) ? nbr[(size_t)my_row * E + ((FLIP && e < E - 1) ? (e ^ 1) : e)] : -1;
+    constexpr int DEPTH = 4;  // ring of gathered quarter rows: DEPTH - 1 gathers in flight
+    halfx8 g[DEPTH][G8];
+    auto gather = [&](int e, halfx8 (&dst)[G8]) {
+        const halfx8* src = reinterpret_cast<const halfx8*>(values + (size_t)(nb[e] >= 0 ? nb[e] : 0) * V + q * KQ);
+#pragma unroll
+        for (int k = 0; k < G8; ++k) dst[k] = src[k];
+    };
+#pragma unroll
+    for (int k = 0; k < DEPTH - 1; ++k) gather(k, g[k]);
+    if constexpr (!WT) {
+        constexpr int ITEMS = E * (V / 4) * (F / 8);
+        for (int x = tid; x < ITEMS; x += nthreads) {
+            const int fo = x % (F / 8);
+            const int t2 = x / (F / 8);
+            const int kq = t2 % (V / 4);
+            const int e = t2 / (V / 4);
+            const int k0 = kq * 4, f0 = fo * 8;
+            halfx8 r[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r[j] = *reinterpret_cast<const halfx8*>(filter + ((size_t)(e * V + k0 + j)) * F + f0);
+            const int qq = k0 / KQ, s = (k0 - qq * KQ) >> 2;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int f = f0 + c;
+                s_frag[((e * S + s) * NT + (f >> 4)) * 64 + qq * 16 + (f & 15)] = halfx4{r[0][c], r[1][c], r[2][c], r[3][c]};
+            }
+        }
+    } else {
+        constexpr int ITEMS = E * F * (V / 8);
+        for (int x = tid; x < ITEMS; x += nthreads) {
+            const int ko = x % (V / 8);
+            const int t2 = x / (V / 8);
+            const int f = t2 % F;
+            const int e = t2 / F;
+            const halfx8 r = *reinterpret_cast<const halfx8*>(filter + ((size_t)(e * F + f)) * V + ko * 8);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int k0 = ko * 8 + 4 * h;
+                const int qq = k0 / KQ, s = (k0 - qq * KQ) >> 2;
+                s_frag[((e * S + s) * NT + (f >> 4)) * 64 + qq * 16 + (f & 15)] = halfx4{r[4 * h], r[4 * h + 1], r[4 * h + 2], r[4 * h + 3]};
+            }
+        }
+    }
+    floatx4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = floatx4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        halfx8 (&ge)[G8] = g[e % DEPTH];
+        if (e + DEPTH - 1 < E) gather(e + DEPTH - 1, g[(e + DEPTH - 1) % DEPTH]);
+        const bool present = nb[e] >= 0;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const halfx8 w8 = ge[s >> 1];
+            halfx4 a = (s & 1) ? halfx4{w8[4], w8[5], w8[6], w8[7]} : halfx4{w8[0], w8[1], w8[2], w8[3]};
+            if (!present) a = halfx4{0, 0, 0, 0};
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a, s_frag[((e * S + s) * NT + nt) * 64 + lane], acc[nt], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + q * 4 + r;
+            if (row < m) out[(size_t)row * F + nt * 16 + i] = (_Float16)acc[nt][r];
+        }
+}
+
+// sub-tiles per workgroup of k_conv_f16_tiled: the launch runs in rounds of 256 CUs x (workgroups that fit a CU's LDS); the T with the
+// cheapest rounds(T) * T wins, larger T (fewer bank stagings) on ties.  LN_F16_T = 1..4 forces it (experiments).
+static int ln_f16_subtiles(int m, size_t lds_bytes) {
+    static int forced = -1;
+    if (forced < 0) {
+        const char* e = getenv("LN_F16_T");
+        forced = e ? atoi(e) : 0;
+    }
+    if (forced >= 1 && forced <= 4) return forced;
+    const int per_cu = lds_bytes * 2 <= 150 * 1024 ? 2 : 1;
+    const int tiles = (m + 63) / 64;
+    int best = 1, best_cost = 1 << 30;
+    for (int t = 1; t <= 4; ++t) {
+        if (per_cu * t * 4 > 32) break;  // wave slots of a CU
+        const int wgs = (tiles + t - 1) / t;
+        const int cost = ((wgs + 256 * per_cu - 1) / (256 * per_cu)) * t;
+        if (cost <= best_cost) {
+            best = t;
+            best_cost = cost;
+        }
+    }
+    return best;
+}
+
+template <bool FLIP, bool WT>
+static bool ln_conv_f16_tiled(const int* nbr, const _Float16* values, const _Float16* filter, int m, int E, int val_dim, int nr_filters,
+                              _Float16* out, hipStream_t st) {
+    static const bool off = getenv("LN_F16_PER_SLOT") != nullptr;  // A/B: the per-slot kernel for every shape
+    if (off || E != 9 || ((reinterpret_cast<uintptr_t>(values) | reinterpret_cast<uintptr_t>(filter)) & 15) != 0) return false;
+#define LN_F16_TILED(VV, NN)                                                                                                         \
+    if (val_dim == VV && nr_filters == 16 * NN) {                                                                                    \
+        const int t = ln_f16_subtiles(m, (size_t)9 * VV * 16 * NN * 2);                                                               \
+        LN_LAUNCH("k_conv_mfma_f16", (k_conv_f16_tiled<VV, NN, FLIP, WT>), dim3(ln_div_up(m, 64 * t)), dim3(256 * t), 0, st, nbr, values, \
+                  filter, m, out);                                                                                                   \
+        return true;                                                                                                                 \
+    }
+    LN_F16_TILED(32, 2) LN_F16_TILED(64, 4) LN_F16_TILED(32, 4) LN_F16_TILED(64, 2)
+#undef LN_F16_TILED
+    return false;
+}
+
 // any shape: one thread per output element, fp32 accumulation
 __global__ void __launch_bounds__(256)
     k_conv_generic_f16(const int* __restrict__ nbr, const _Float16* __restrict__ values, const _Float16* __restrict__ filter, long long work,
@@ -126,7 +265,8 @@ static void ln_conv_f16_launch_v(int nr_filters, const int* nbr, const _Float16*
 template <bool FLIP, bool WT>
 static int ln_conv_f16_dispatch(const int* nbr, const _Float16* values, const _Float16* filter, int m, int E, int val_dim, int nr_filters,
                                 _Float16* out, hipStream_t st) {
-    bool done = false;
+    bool done = ln_conv_f16_tiled<FLIP, WT>(nbr, values, filter, m, E, val_dim, nr_filters, out, st);
+    if (done) return ln_check_launch("ln_conv_forward_f16");
     if (nr_filters % 16 == 0 && (reinterpret_cast<uintptr_t>(values) & 7) == 0) {
         done = true;
         switch (val_dim) {

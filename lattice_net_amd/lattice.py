@@ -1071,10 +1071,13 @@ class Lattice:
         lib = _lib.load()
         if vals.dtype == torch.float16:  # fp16 feature path: fp16 rows in, fp16 rows out, fp32 arithmetic
             out = torch.empty((n, self.val_dim()), dtype=torch.float16, device=self._dev())
-            _lib.check(lib.ln_slice_forward_f16(_lib.ptr(vals), _lib.ptr(idx), _lib.ptr(w), n, self.pos_dim(), self.val_dim(), _lib.ptr(out),
-                                                self._stream()), "ln_slice_forward_f16")
-            if grad_accumulator is not None:
-                grad_accumulator.zero_()
+            if grad_accumulator is None:
+                _lib.check(lib.ln_slice_forward_f16(_lib.ptr(vals), _lib.ptr(idx), _lib.ptr(w), n, self.pos_dim(), self.val_dim(), _lib.ptr(out),
+                                                    self._stream()), "ln_slice_forward_f16")
+            else:  # (an fp32 buffer: the backward scatter accumulates in fp32 whatever the features are)
+                _lib.check(lib.ln_slice_forward_f16_prepare_backward(_lib.ptr(vals), _lib.ptr(idx), _lib.ptr(w), n, self.pos_dim(), self.val_dim(),
+                                                                     _lib.ptr(out), _lib.ptr(grad_accumulator), grad_accumulator.numel(),
+                                                                     self._stream()), "ln_slice_forward_f16_prepare_backward")
             return out
         out = torch.empty((n, self.val_dim()), dtype=torch.float32, device=self._dev())
         if grad_accumulator is None:

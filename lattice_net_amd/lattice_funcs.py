@@ -234,8 +234,9 @@ class SliceLattice(Function):  # lattice_funcs.py:467-516
             sliced_values, splatting_indices, splatting_weights = lattice_structure.slice_standalone_no_precomputation(positions)
         else:
             # the [M, V] accumulator of the backward scatter is zero-filled by the forward launch when a gradient will be asked for
-            ctx.grad_accumulator = torch.empty_like(lattice_values) if (ctx.needs_input_grad[0] and lattice_values.dtype == torch.float32 and
-                                                                        lattice_values.is_contiguous()) else None  # (fp16 path: fresh zeros later)
+            # (fp32 also for fp16 features: the scatter accumulates in fp32 and the result is rounded once)
+            ctx.grad_accumulator = torch.empty(lattice_values.shape, dtype=torch.float32, device=lattice_values.device) if (
+                ctx.needs_input_grad[0] and lattice_values.dtype in (torch.float32, torch.float16) and lattice_values.is_contiguous()) else None
             sliced_values = lattice_structure.slice_standalone_with_precomputation(positions, splatting_indices, splatting_weights,
                                                                                    grad_accumulator=ctx.grad_accumulator)
         ctx.save_for_backward(positions, splatting_indices, splatting_weights)
