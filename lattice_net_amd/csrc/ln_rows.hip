@@ -167,7 +167,7 @@ extern "C" int ln_slice_forward_prepare_backward(const float* values, const int*
 
 // fp16 lattice values -> fp16 sliced rows (fp32 arithmetic): thread = (point, HV channels), HV = 8 (16-byte words) when the width
 // allows.  As in k_slice_forward: all indices and weights first, then the d+1 row gathers together (the first version fetched
-// index -> row -> weight vertex after vertex: four dependent round trips, 52 us at C5 against 3x us now), same summation order;
+// index -> row -> weight vertex after vertex: four dependent round trips, 52 us at C5 against 25 us now), same summation order;
 // `zero_fill`: the fp32 accumulator of this slice's backward pass, zeroed on the way.
 template <int DP1, int HV>
 __global__ void __launch_bounds__(256)
