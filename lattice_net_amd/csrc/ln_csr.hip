@@ -308,7 +308,12 @@ __device__ __forceinline__ void ln_reduce_chunk(const LnSegOfThread& so, const L
                         const int srow = pow2 ? (t >> shift) : (t / src_div);
                         const size_t off = (size_t)srow * src_stride + c * VEC;
                         if constexpr (HALF) {
-                            if constexpr (VEC == 4) {
+                            if constexpr (VEC == 8) {  // 16-byte words: a 64-channel fp16 row on 8 lanes, 8 segments per wave
+                                typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+                                const h8 v8 = *reinterpret_cast<const h8*>(src16 + off);
+#pragma unroll
+                                for (int k = 0; k < 8; ++k) x[u][k] = (float)v8[k];
+                            } else if constexpr (VEC == 4) {
                                 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
                                 const h4 v4 = *reinterpret_cast<const h4*>(src16 + off);
                                 x[u][0] = (float)v4[0]; x[u][1] = (float)v4[1]; x[u][2] = (float)v4[2]; x[u][3] = (float)v4[3];
@@ -349,7 +354,10 @@ __device__ __forceinline__ void ln_reduce_chunk(const LnSegOfThread& so, const L
         if (cok && head) {
             float* d = dst + (size_t)row * V + c * VEC;
             if ((beg == rbeg && run_end == rend) || a.dbg_plain) {  // this run is the whole group: no other writer
-                if constexpr (VEC == 4) {
+                if constexpr (VEC == 8) {
+                    *reinterpret_cast<float4*>(d) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                    *reinterpret_cast<float4*>(d + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+                } else if constexpr (VEC == 4) {
                     *reinterpret_cast<float4*>(d) = make_float4(acc[0], acc[1], acc[2], acc[3]);
                 } else {
                     d[0] = acc[0];
@@ -388,13 +396,16 @@ __global__ void __launch_bounds__(256)
 }
 
 static int ln_reduce_args(const char* who, const LnCsr* csr, const int* grp_row, long long max_segments, const void* src, bool half,
-                          const float* w, int val_dim, int src_div, int src_stride, float* dst, LnReduceArgs& a, bool& vec4, long long& work) {
+                          const float* w, int val_dim, int src_div, int src_stride, float* dst, LnReduceArgs& a, int& vec, long long& work) {
     LN_REQUIRE(max_segments >= 0 && val_dim >= 1 && src_div >= 1 && src_stride >= val_dim, LN_ERR_ARG, "%s: bad sizes", who);
     LN_REQUIRE(max_segments == 0 || (csr && csr->grp_start && csr->csr_tok && csr->seg_desc && csr->seg_count && src && w && dst),
                LN_ERR_ARG, "%s: null buffer", who);
-    vec4 = (val_dim % 4 == 0) && (src_stride % 4 == 0) && ((reinterpret_cast<uintptr_t>(src) & (half ? 7 : 15)) == 0) &&
-           ((reinterpret_cast<uintptr_t>(dst) & 15) == 0);
-    const int chunks = vec4 ? val_dim / 4 : val_dim;
+    const bool vec4 = (val_dim % 4 == 0) && (src_stride % 4 == 0) && ((reinterpret_cast<uintptr_t>(src) & (half ? 7 : 15)) == 0) &&
+                      ((reinterpret_cast<uintptr_t>(dst) & 15) == 0);
+    // fp16 rows of >= 64 channels: 16-byte words (8 halfs) per lane
+    const bool vec8 = vec4 && half && val_dim % 8 == 0 && val_dim >= 64 && src_stride % 8 == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0;
+    vec = vec8 ? 8 : (vec4 ? 4 : 1);
+    const int chunks = val_dim / vec;
     int lanes = 1;
     while (lanes < chunks && lanes < 64) lanes <<= 1;
     work = max_segments * lanes;
@@ -406,20 +417,22 @@ static int ln_reduce_args(const char* who, const LnCsr* csr, const int* grp_row,
 static int ln_csr_reduce_rows_impl(const char* who, const LnCsr* csr, const int* grp_row, long long max_segments, const void* src, bool half,
                                    const float* w, int val_dim, int src_div, int src_stride, float* dst, void* stream) {
     LnReduceArgs a;
-    bool vec4;
+    int vec;
     long long work;
-    int rc = ln_reduce_args(who, csr, grp_row, max_segments, src, half, w, val_dim, src_div, src_stride, dst, a, vec4, work);
+    int rc = ln_reduce_args(who, csr, grp_row, max_segments, src, half, w, val_dim, src_div, src_stride, dst, a, vec, work);
     if (rc) return rc;
     if (max_segments == 0) return LN_OK;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(ln_seg_grid(max_segments, a.lanes_per_seg)), block(256);
     if (half) {
-        if (vec4)
+        if (vec == 8)
+            LN_LAUNCH("k_csr_reduce_segments", (k_csr_reduce_segments<8, true>), grid, block, 0, st, a);
+        else if (vec == 4)
             LN_LAUNCH("k_csr_reduce_segments", (k_csr_reduce_segments<4, true>), grid, block, 0, st, a);
         else
             LN_LAUNCH("k_csr_reduce_segments", (k_csr_reduce_segments<1, true>), grid, block, 0, st, a);
     } else {
-        if (vec4)
+        if (vec == 4)
             LN_LAUNCH("k_csr_reduce_segments", (k_csr_reduce_segments<4, false>), grid, block, 0, st, a);
         else
             LN_LAUNCH("k_csr_reduce_segments", (k_csr_reduce_segments<1, false>), grid, block, 0, st, a);
@@ -443,9 +456,9 @@ static int ln_splat_tail_impl(const char* who, const LnCsr* csr, const int* grp_
                               const float* w, int val_dim, int src_div, int src_stride, float* dst, const LnTable* table,
                               int query_rows_upper, int* nbr, void* stream) {
     LnReduceArgs a;
-    bool vec4;
+    int vec;
     long long work;
-    int rc = ln_reduce_args(who, csr, grp_row, max_segments, src, half, w, val_dim, src_div, src_stride, dst, a, vec4, work);
+    int rc = ln_reduce_args(who, csr, grp_row, max_segments, src, half, w, val_dim, src_div, src_stride, dst, a, vec, work);
     if (rc) return rc;
     LN_REQUIRE(table && table->slot_keys && table->entries && table->keys && table->nr_filled && table->capacity > 0, LN_ERR_ARG,
                "%s: bad table", who);
@@ -458,13 +471,16 @@ static int ln_splat_tail_impl(const char* who, const LnCsr* csr, const int* grp_
     const dim3 grid(reduce_blocks + nbr_blocks), block(256);
 #define LN_FUSED_CASE(DD)                                                                                                              \
     case DD:                                                                                                                           \
-        if (half && vec4)                                                                                                              \
+        if (half && vec == 8)                                                                                                          \
+            LN_LAUNCH("k_reduce_and_neighbours", (k_reduce_and_neighbours<8, DD, true>), grid, block, 0, st, a, reduce_blocks, *table,  \
+                      query_rows_upper, nbr);                                                                                          \
+        else if (half && vec == 4)                                                                                                     \
             LN_LAUNCH("k_reduce_and_neighbours", (k_reduce_and_neighbours<4, DD, true>), grid, block, 0, st, a, reduce_blocks, *table,  \
                       query_rows_upper, nbr);                                                                                          \
         else if (half)                                                                                                                 \
             LN_LAUNCH("k_reduce_and_neighbours", (k_reduce_and_neighbours<1, DD, true>), grid, block, 0, st, a, reduce_blocks, *table,  \
                       query_rows_upper, nbr);                                                                                          \
-        else if (vec4)                                                                                                                 \
+        else if (vec == 4)                                                                                                             \
             LN_LAUNCH("k_reduce_and_neighbours", (k_reduce_and_neighbours<4, DD, false>), grid, block, 0, st, a, reduce_blocks, *table, \
                       query_rows_upper, nbr);                                                                                          \
         else                                                                                                                           \
