@@ -184,10 +184,10 @@ LN_HD int ln_bucket_slots(int capacity) {
     if (nb < LN_BKT_MIN_COUNT) {
         nb = capacity / LN_BKT_MIN_SLOTS;
         if (nb > LN_BKT_MIN_COUNT) nb = LN_BKT_MIN_COUNT;
-    } else if (nb < 2 * LN_BKT_MIN_COUNT) {
-        // between one and two workgroups per CU: a second, partly filled round of the bucket pass costs a whole round (C5: 336
-        // buckets of 5.7 k tokens 76 us, 256 buckets of 7.5 k tokens in one round 21 us less) -- stay at one bucket per CU, larger buckets
-        nb = LN_BKT_MIN_COUNT;
+    } else {
+        // whole rounds of one bucket workgroup per CU: a partly filled last round of the bucket pass costs a whole round (C5: 336
+        // buckets of 5.7 k tokens 76 us, 256 buckets of 7.5 k tokens 21 us less; C4: 614 -> 512 buckets, 267 -> 256 us per step)
+        nb = (nb / LN_BKT_MIN_COUNT) * LN_BKT_MIN_COUNT;
     }
     if (nb > LN_BKT_MAX) nb = LN_BKT_MAX;
     if (nb < 1) nb = 1;
