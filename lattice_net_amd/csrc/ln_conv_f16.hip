@@ -309,13 +309,12 @@ extern "C" int ln_conv_forward_f16(const int* nbr, const void* values_neigh, con
 // filter gradient from fp16 activations / gradients, accumulated in fp32:
 //   grad_filter[e*V+v, f] = sum_m values[nbr[m,e], v] * grad_out[m, f]
 // grid = (row chunks, E).  The contraction runs over lattice vertices (rows), so both MFMA operands are read
-// "down the rows": a sub-tile of 64 rows is staged TRANSPOSED in LDS (s_at[v][row], s_gt[f][row], row stride padded to
-// 68 halfs) and lane (i, q) reads 4 consecutive rows of column i as one 8-byte word.  Each wave owns whole 16x16 output
+// "down the rows": a sub-tile of 64 rows is staged row-major in LDS and read with the transposing LDS load of gfx950
+// (ds_read_b64_tr_b16: lane (i, q) receives 4 consecutive rows of column i).  Each wave owns whole 16x16 output
 // tiles D[v, f]; partial [V, F] blocks per row chunk go to slabs, summed by k_reduce_slabs4 / k_reduce_slabs (ln_conv.hip, deterministic).
 // ------------------------------------------------------------------------------------------
 #define LN_GF16_ROWS 512
 #define LN_GF16_SUB 64
-#define LN_GF16_STRIDE 68  // halfs per staged column: 34 words -> the 4 q-groups of a wave hit different banks
 template <int VT, int FT>
 __global__ void __launch_bounds__(256)
     k_grad_filter_mfma_f16(const int* __restrict__ nbr, const _Float16* __restrict__ values, const _Float16* __restrict__ grad_out, int m,
@@ -323,8 +322,15 @@ __global__ void __launch_bounds__(256)
     constexpr int V = VT * 16, F = FT * 16;
     constexpr int TILES = VT * FT;
     constexpr int TPW = (TILES + 3) / 4;
-    __shared__ __attribute__((aligned(16))) _Float16 s_at[V * LN_GF16_STRIDE];
-    __shared__ __attribute__((aligned(16))) _Float16 s_gt[F * LN_GF16_STRIDE];
+    // sub-tiles are staged ROW-major (one 8-byte LDS store per 4 channels; rows padded by 4 halfs so that the 4 rows a 16-lane
+    // group reads together start in different banks) and read "down the rows" with ds_read_b64_tr_b16: lane i of a 16-lane
+    // group passes the address of row i >> 2, columns 4 (i & 3).. of a 4 x 16 block and receives rows 0..3 of column i
+    // (tools/probes/tr_read_probe.cpp) - the MFMA operand of a contraction over rows.  (The first version stored every half
+    // on its own into transposed arrays: 256 two-byte LDS stores per thread and chunk.)
+    constexpr int SA = V + 4, SG = F + 4;
+    __shared__ __attribute__((aligned(16))) _Float16 s_a[LN_GF16_SUB * SA];
+    __shared__ __attribute__((aligned(16))) _Float16 s_g[LN_GF16_SUB * SG];
+    typedef short shortx4 __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -336,39 +342,57 @@ __global__ void __launch_bounds__(256)
     floatx4 acc[TPW];
 #pragma unroll
     for (int t = 0; t < TPW; ++t) acc[t] = floatx4{0.f, 0.f, 0.f, 0.f};
-    for (int sub = chunk_begin; sub < chunk_end; sub += LN_GF16_SUB) {
-        __syncthreads();
-        // stage transposed: a thread moves 4 consecutive channels of one row
-        for (int x = tid; x < LN_GF16_SUB * (V / 4); x += 256) {
+    // the rows of the NEXT sub-tile are fetched into registers (neighbour id -> row: two dependent round trips) while the matrix
+    // instructions of the current one run: VT + FT 8-byte words per thread
+    halfx4 ra[VT], rg[FT];
+    auto fetch = [&](int sub) {
+#pragma unroll
+        for (int k = 0; k < VT; ++k) {
+            const int x = tid + 256 * k;
             const int r = x / (V / 4), c4 = x - r * (V / 4);
             const int row = sub + r;
             const int nb = row < chunk_end ? nbr[(size_t)row * E + e] : -1;
-            halfx4 v = halfx4{0, 0, 0, 0};
-            if (nb >= 0) v = *reinterpret_cast<const halfx4*>(values + (size_t)nb * v_total + v_off + c4 * 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) s_at[(c4 * 4 + j) * LN_GF16_STRIDE + r] = v[j];
+            ra[k] = halfx4{0, 0, 0, 0};
+            if (nb >= 0) ra[k] = *reinterpret_cast<const halfx4*>(values + (size_t)nb * v_total + v_off + c4 * 4);
         }
-        for (int x = tid; x < LN_GF16_SUB * (F / 4); x += 256) {
+#pragma unroll
+        for (int k = 0; k < FT; ++k) {
+            const int x = tid + 256 * k;
             const int r = x / (F / 4), c4 = x - r * (F / 4);
             const int row = sub + r;
-            halfx4 g = halfx4{0, 0, 0, 0};
-            if (row < chunk_end) g = *reinterpret_cast<const halfx4*>(grad_out + (size_t)row * f_total + f_off + c4 * 4);
+            rg[k] = halfx4{0, 0, 0, 0};
+            if (row < chunk_end) rg[k] = *reinterpret_cast<const halfx4*>(grad_out + (size_t)row * f_total + f_off + c4 * 4);
+        }
+    };
+    if (chunk_begin < chunk_end) fetch(chunk_begin);
+    for (int sub = chunk_begin; sub < chunk_end; sub += LN_GF16_SUB) {
+        __syncthreads();  // the previous sub-tile's reads are done
 #pragma unroll
-            for (int j = 0; j < 4; ++j) s_gt[(c4 * 4 + j) * LN_GF16_STRIDE + r] = g[j];
+        for (int k = 0; k < VT; ++k) {
+            const int x = tid + 256 * k;
+            const int r = x / (V / 4), c4 = x - r * (V / 4);
+            *reinterpret_cast<halfx4*>(s_a + r * SA + c4 * 4) = ra[k];
+        }
+#pragma unroll
+        for (int k = 0; k < FT; ++k) {
+            const int x = tid + 256 * k;
+            const int r = x / (F / 4), c4 = x - r * (F / 4);
+            *reinterpret_cast<halfx4*>(s_g + r * SG + c4 * 4) = rg[k];
         }
         __syncthreads();
+        if (sub + LN_GF16_SUB < chunk_end) fetch(sub + LN_GF16_SUB);
 #pragma unroll
         for (int t = 0; t < TPW; ++t) {
             const int tile = wave + 4 * t;
             if (tile < TILES) {
                 const int vt = tile / FT, ft = tile - vt * FT;
-                const _Float16* pa = s_at + (vt * 16 + i) * LN_GF16_STRIDE + 4 * q;
-                const _Float16* pg = s_gt + (ft * 16 + i) * LN_GF16_STRIDE + 4 * q;
+                const _Float16* pa = s_a + (4 * q + (i >> 2)) * SA + vt * 16 + 4 * (i & 3);
+                const _Float16* pg = s_g + (4 * q + (i >> 2)) * SG + ft * 16 + 4 * (i & 3);
 #pragma unroll
                 for (int s = 0; s < LN_GF16_SUB / 16; ++s) {
-                    const halfx4 a = *reinterpret_cast<const halfx4*>(pa + 16 * s);
-                    const halfx4 b = *reinterpret_cast<const halfx4*>(pg + 16 * s);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, acc[t], 0, 0, 0);
+                    const shortx4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((shortx4 __attribute__((address_space(3)))*)(pa + 16 * s * SA));
+                    const shortx4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((shortx4 __attribute__((address_space(3)))*)(pg + 16 * s * SG));
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(halfx4, a), __builtin_bit_cast(halfx4, b), acc[t], 0, 0, 0);
                 }
             }
         }
