@@ -321,7 +321,7 @@ def test_scatter_max_and_pointnet_aggregation():
     assert pn.layers[0].weight_v.grad.abs().sum() > 0 and pn.layers[0].weight_g.grad.abs().sum() > 0
 
 
-@pytest.mark.parametrize("v,f", [(64, 64), (32, 32), (96, 64), (128, 128), (16, 48), (20, 24)])
+@pytest.mark.parametrize("v,f", [(64, 64), (32, 32), (32, 64), (64, 32), (96, 64), (128, 128), (16, 48), (20, 24)])
 def test_conv_fp16_feature_path_matches_fp64_reference(v, f):
     """BASELINE config 5 (C5): fp16 features, fp32 accumulation.  Forward, gradient wrt values and wrt the filter bank of
     ConvIm2RowLattice on half tensors against an fp64 evaluation of the same fp16 inputs."""
