@@ -349,7 +349,7 @@ def test_conv_fp16_feature_path_matches_fp64_reference(v, f):
     ref = rows @ w64
     (ref * G.cpu().double()).sum().backward()
     # results are rounded to fp16 once (rel 2^-11); the accumulation itself is fp32
-    close(N(out.float()), ref.detach().numpy(), scale=float(ref.abs().max()), rtol=2e-3)
+    close(N(out.detach().float()), ref.detach().numpy(), scale=float(ref.abs().max()), rtol=2e-3)
     close(N(vals.grad.float()), v64.grad.numpy(), scale=float(v64.grad.abs().max()), rtol=2e-3)
     close(N(W.grad.float()), w64.grad.numpy(), scale=float(w64.grad.abs().max()), rtol=2e-3)
 
@@ -444,3 +444,38 @@ def test_c5_full_size_fp16_feature_chain():
     close(N(out.float()), out_ref.detach().numpy(), scale=float(out_ref.abs().max()), rtol=4e-3)
     close(N(lvh.grad.float()), v64.grad.numpy(), scale=float(v64.grad.abs().max()), rtol=4e-3)
     close(N(W.grad.float()), w64.grad.numpy(), scale=float(w64.grad.abs().max()), rtol=4e-3)
+
+
+@pytest.mark.parametrize("d,v", [(3, 64), (3, 12), (2, 20), (4, 8), (5, 40)])
+def test_fp16_slice_forward_and_backward_by_width_and_dimension(d, v):
+    """k_slice_forward_f16 in both word sizes (16 bytes when the width is a multiple of 8, else 8), for several lattice
+    dimensions, with absent vertices (idx = -1) among the inputs, and its backward through the accumulator the forward
+    launch zeroes (ln_slice_forward_f16_prepare_backward) — against fp64 on the same fp16 inputs."""
+    from lattice_net_amd import SliceLattice
+    rng = np.random.default_rng(100 * d + v)
+    n = 3000
+    pos_np = ((rng.random((n, d), dtype=np.float32) - 0.5) * 3).astype(np.float32)
+    lat = make_lattice(0.3, 200000, d=d)
+    lat.begin_splat()
+    idx, w = lat.just_create_verts(T(pos_np), True)
+    m = lat.nr_lattice_vertices()
+    idx = idx.clone()
+    drop = torch.from_numpy(rng.random(idx.numel()) < 0.05).to(idx.device)
+    idx[drop] = -1  # vertices the table could not hold read as absent (Lattice.cu:771-786)
+    vals = torch.tensor(rng.standard_normal((m, v)), dtype=torch.float16, device=dev(), requires_grad=True)
+    G = torch.tensor(rng.standard_normal((n, v)), dtype=torch.float16, device=dev())
+    for _ in range(2):  # (the second pass meets a dirty accumulator from the first one's backward)
+        vals.grad = None
+        lat.set_values(vals.detach())
+        out = SliceLattice.apply(vals, lat, T(pos_np), idx, w)
+        assert out.dtype == torch.float16 and out.shape == (n, v)
+        out.backward(G)
+        assert vals.grad.dtype == torch.float16
+    i64 = idx.cpu().long().reshape(n, d + 1)
+    ok = (i64 >= 0).double().unsqueeze(-1)
+    w64 = w.cpu().double().reshape(n, d + 1, 1) * ok
+    v64 = vals.detach().cpu().double().requires_grad_(True)
+    ref = (v64[i64.clamp(min=0)] * w64).sum(1)
+    (ref * G.cpu().double()).sum().backward()
+    close(N(out.detach().float()), ref.detach().numpy(), scale=float(ref.abs().max()), rtol=2e-3)
+    close(N(vals.grad.float()), v64.grad.numpy(), scale=float(v64.grad.abs().max()), rtol=2e-3)
