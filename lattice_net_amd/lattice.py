@@ -572,7 +572,7 @@ class Lattice:
 
         Static-rows mode knows more than the token count: at most `bound` vertices exist, so _STATIC_SLOTS_PER_ROW x bound slots
         keep the load factor of the headline configuration (46.6 k vertices in 100 k slots) whatever the tokens per vertex are
-        (a ScanNet scene: 800 k tokens on 129 k vertices -> 296 k slots = 578 bucket workgroups instead of 2048).  That range
+        (a ScanNet scene: 800 k tokens on 129 k vertices -> 314 k slots = 512 bucket workgroups instead of 2048).  That range
         may be SMALLER than what earlier eager builds hashed into: the slots given up are emptied here, once."""
         ht = self.m_hash_table
         st = ht._storage
