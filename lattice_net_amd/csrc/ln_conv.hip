@@ -709,12 +709,17 @@ __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(T,
         for (int nt = 0; nt < NT; ++nt) {
             const u32x4* pb = s_frag + ((e * NT + nt) * 3) * 64 + lane;
             const bf16x8 b1 = __builtin_bit_cast(bf16x8, pb[0]), b2 = __builtin_bit_cast(bf16x8, pb[64]), b3 = __builtin_bit_cast(bf16x8, pb[128]);
+#ifdef LN_CONV_PROBE_NO_MFMA  // attribution build (wrong results): the gathers and operand loads stay, ONE matrix instruction per slot and tile
+            asm volatile("" ::"v"(a2), "v"(a3), "v"(b2), "v"(b3));  // (operands stay computed and loaded)
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, acc[nt], 0, 0, 0);
+#else
             acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, b1, acc[nt], 0, 0, 0);
             acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b3, acc[nt], 0, 0, 0);
             acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b2, acc[nt], 0, 0, 0);
             acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b1, acc[nt], 0, 0, 0);
             acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b2, acc[nt], 0, 0, 0);
             acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, acc[nt], 0, 0, 0);
+#endif
         }
     }
     // C/D layout: col = lane & 15, row = (lane >> 4) * 4 + reg
@@ -1398,12 +1403,17 @@ __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(T,
         for (int nt = 0; nt < NT; ++nt) {
             const u32x4* pb = s_frag + ((e * NT + nt) * 3) * 64 + lane;
             const bf16x8 b1 = __builtin_bit_cast(bf16x8, pb[0]), b2 = __builtin_bit_cast(bf16x8, pb[64]), b3 = __builtin_bit_cast(bf16x8, pb[128]);
+#ifdef LN_CONV_PROBE_NO_MFMA  // attribution build (wrong results): one matrix instruction instead of six
+            asm volatile("" ::"v"(a2), "v"(a3), "v"(b2), "v"(b3));
+            acc_v[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, acc_v[nt], 0, 0, 0);
+#else
             acc_v[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, b1, acc_v[nt], 0, 0, 0);
             acc_v[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b3, acc_v[nt], 0, 0, 0);
             acc_v[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b2, acc_v[nt], 0, 0, 0);
             acc_v[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b1, acc_v[nt], 0, 0, 0);
             acc_v[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b2, acc_v[nt], 0, 0, 0);
             acc_v[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, acc_v[nt], 0, 0, 0);
+#endif
         }
         // filter gradient: two 32-row steps; B fragments through the LDS transpose read (lane: 4 contiguous bf16 of row
         // row0 + (i >> 2), columns ft*16 + 4 (i & 3) ..; it receives rows row0..row0+3 of column ft*16 + i)
@@ -1450,12 +1460,17 @@ __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(T,
             }
             const bf16x8 v1 = __builtin_bit_cast(bf16x8, va[st][0]), v2 = __builtin_bit_cast(bf16x8, va[st][1]), v3 = __builtin_bit_cast(bf16x8, va[st][2]);
             floatx4& acc = st ? w1 : w0;
+#ifdef LN_CONV_PROBE_NO_MFMA
+            asm volatile("" ::"v"(v2), "v"(v3), "v"(b[1]), "v"(b[2]));
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, b[0], acc, 0, 0, 0);
+#else
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v3, b[0], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, b[2], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v2, b[1], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v2, b[0], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, b[1], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, b[0], acc, 0, 0, 0);
+#endif
         }
         acc_w[e] = w0 + w1;
     }
