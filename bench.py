@@ -311,7 +311,7 @@ def main():
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world} rank(s)", file=sys.stderr)
 
     import lattice_net_amd as L
-    from lattice_net_amd.capture import CapturedStep
+    from lattice_net_amd.capture import CapturedStep, concurrent_streams
     lib = L.load_library()
     if not args.autograd_threads:
         # run backward on the calling thread: the hand-off to torch's per-device autograd worker costs tens of
@@ -350,7 +350,7 @@ def main():
             self.clouds = [new_cloud(base + p) for p in range(pool)]
             self.calibration = [new_cloud(base + 32 + p) for p in range(2)] if graph_mode else []  # never replayed
             self.lat = L.Lattice(sigmas=[sigma] * d, capacity=cap, device=dev)
-            self.stream = torch.cuda.Stream() if k > 0 else None  # set 0 stays on the current stream
+            self.stream = scan_streams[k] if k > 0 else None  # set 0 stays on the current stream
             self.cap = None
 
         def step_on(self, c):
@@ -413,6 +413,8 @@ def main():
         sharding.barrier(dist)
         torch.cuda.synchronize()
 
+    # streams that land on different hardware queues (an RCCL communicator shifts the mapping: capture.concurrent_streams)
+    scan_streams = concurrent_streams(in_flight) if graph_mode else [None] * in_flight
     sets = [ScanSet(k) for k in range(in_flight)]
     graph_err = None
     if graph_mode:
@@ -594,7 +596,7 @@ def main():
                         c["chain_ref"] = c["state"]["cout"].detach().clone()
                     fns = [chain_on(c) for c in ch["clouds"]]
                     ch["cap"] = CapturedStep(fns[0], [ch["lat"]], row_slack=args.row_slack, regions=bool(args.regions),
-                                             region_indices=lambda ch=ch: ch["cal"][0]["state"]["cidx"], stream=torch.cuda.Stream(),
+                                             region_indices=lambda ch=ch: ch["cal"][0]["state"]["cidx"], stream=(scan_streams[k] if k > 0 else None),
                                              calibration_steps=[chain_on(c) for c in ch["cal"]], more_steps=fns[1:])
                     chains.append(ch)
                 for i in range(pool * in_flight):

@@ -240,3 +240,31 @@ def test_captured_step_helper_two_scans_in_flight():
         assert np.array_equal(sc["st"]["idx"].cpu().numpy(), idx_ref)
         assert rel(sc["st"]["out"].detach().cpu().numpy(), out_ref) < RTOL
         assert rel(sc["st"]["gw"].cpu().numpy(), gw_ref) < RTOL
+
+
+def test_concurrent_streams_are_distinct_and_start_with_the_current_stream():
+    """capture.concurrent_streams: k streams, the caller's current stream first, no stream twice; the streams it returns
+    pass its own overlap probe again (two spin kernels side by side take about as long as one)."""
+    import time
+    from lattice_net_amd.capture import concurrent_streams
+    streams = concurrent_streams(3)
+    assert len(streams) == 3 and streams[0] == torch.cuda.current_stream()
+    assert len({s.cuda_stream for s in streams}) == 3
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda._sleep(1000)
+    cycles = 400_000
+    ev0.record()
+    torch.cuda._sleep(cycles)
+    ev1.record()
+    torch.cuda.synchronize()
+    single_us = ev0.elapsed_time(ev1) * 1e3
+    best = 1e30
+    for _ in range(5):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for s in streams[1:]:
+            with torch.cuda.stream(s):
+                torch.cuda._sleep(cycles)
+        torch.cuda.synchronize()
+        best = min(best, (time.perf_counter() - t0) * 1e6)
+    assert best < 1.7 * single_us + 100.0, (best, single_us)

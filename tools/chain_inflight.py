@@ -12,7 +12,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import lattice_net_amd as L  # noqa: E402
 from lattice_net_amd import synthetic  # noqa: E402
-from lattice_net_amd.capture import CapturedStep  # noqa: E402
+from lattice_net_amd.capture import CapturedStep, concurrent_streams  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--in-flight", default="1,3")
@@ -25,6 +25,7 @@ dev = torch.device("cuda", 0)
 n, v, d, sigma, cap = args.n, 32, 3, 0.9, 100000
 kmax = max(int(k) for k in args.in_flight.split(","))
 chains = []
+streams = concurrent_streams(kmax + 1)[1:]  # streams on different hardware queues (capture.concurrent_streams)
 for k in range(kmax):
     rng = np.random.default_rng(1000 * k)
     c = {"lat": L.Lattice(sigmas=[sigma] * d, capacity=cap, device=dev), "st": {},
@@ -43,7 +44,7 @@ for k in range(kmax):
     ref = c["st"]["out"].detach().clone()
     c["m"] = c["st"]["m"]
     c["cap"] = CapturedStep(chain, [c["lat"]], row_slack=0.06, regions=bool(args.regions), region_indices=lambda c=c: c["st"]["idx"],
-                            stream=torch.cuda.Stream(), before_capture=c["st"].clear)
+                            stream=streams[k], before_capture=c["st"].clear)
     c["cap"].launch()
     torch.cuda.synchronize()
     err = float((c["st"]["out"] - ref).abs().max()) / max(float(ref.abs().max()), 1e-30)
