@@ -282,10 +282,11 @@ def main():
     ap.add_argument("--mode", default="graph", choices=["graph", "eager"],
                     help="graph (default): the whole step (forward + backward, ~9 launches) is captured into hipGraphs with the lattice in "
                          "static-rows mode and every timed step is one graph replay; eager: one Python autograd pass per step")
-    ap.add_argument("--in-flight", type=int, default=3,
+    ap.add_argument("--in-flight", type=int, default=4,
                     help="graph mode: independent scans in flight per GPU (own clouds, lattice, hipGraphs, stream each); the kernels of one "
-                         "scan are latency-bound chains at ~1 workgroup per CU, a second scan fills the idle slots.  1 = strictly one "
-                         "scan after the other")
+                         "scan are latency-bound chains at ~1 workgroup per CU, further scans fill the idle slots.  4 = one per hardware "
+                         "queue of the default HIP configuration (streams picked by capture.concurrent_streams); 1 = strictly one scan "
+                         "after the other")
     ap.add_argument("--pool", type=int, default=8,
                     help="graph mode: distinct clouds per scan in flight; every timed step takes the next one (one captured graph per cloud, "
                          "all sharing the scan's lattice, bounds and workspaces — no input copies)")

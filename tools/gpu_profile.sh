@@ -1,5 +1,5 @@
 #!/bin/bash
-# Run on the GPU box (through gpurun): rocprofv3 kernel statistics of bench.py — the default execution (three scans in flight) and
+# Run on the GPU box (through gpurun): rocprofv3 kernel statistics of bench.py — the default execution (four scans in flight) and
 # one scan at a time —, of the splat -> slice pair alone (tools/chain_inflight.py), and the two HBM-traffic PMC passes.
 # --extras 0: only capture / warm-up / timed replays + the eager steps that time the roofline group, so call counts are per step.
 # Outputs land in gpurun_out/prof_<tag>/ ; copy the summaries into profiles/ afterwards.
@@ -24,7 +24,7 @@ done
 F=$(find $OUT/fetch -name "*counter_collection.csv" | head -1); cp "$F" $OUT/pmc_fetch_size_counter_collection.csv
 W=$(find $OUT/write -name "*counter_collection.csv" | head -1); cp "$W" $OUT/pmc_write_size_counter_collection.csv
 python3 tools/pmc_traffic.py $OUT/pmc_fetch_size_counter_collection.csv $OUT/pmc_write_size_counter_collection.csv $OUT/pmc_traffic.json > /dev/null
-grep -h "^{\"metric\"" $OUT/stats.log > $OUT/bench_line_in_flight3.json
+grep -h "^{\"metric\"" $OUT/stats.log > $OUT/bench_line_in_flight_default.json
 grep -h "^{\"metric\"" $OUT/stats1.log > $OUT/bench_line_in_flight1.json
 rm -rf $OUT/stats $OUT/stats1 $OUT/chain $OUT/fetch $OUT/write
 for t in stats stats1 chain; do echo "== $t"; head -14 $OUT/${t}_kernel_stats.csv | cut -c1-150; done
