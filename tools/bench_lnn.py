@@ -47,6 +47,8 @@ def make_graph_step(args, preset, cfg_text, net, opt, gen, dev, nll_loss_gather,
         print("[bench_lnn] note: long runs of SEVERAL whole-network graphs replaying concurrently abort the HSA queue on this stack "
               "(ROCm 7.2, a few hundred steps in); one graph at a time (--in-flight 1) runs clean for as long as tried", flush=True)
     params = list(net.parameters())
+    from lattice_net_amd.capture import concurrent_streams
+    scan_streams = concurrent_streams(K + 1)[1:] if K > 1 else [None]  # streams on different hardware queues
     scans = []
     for k in range(K):
         with tempfile.NamedTemporaryFile("w", suffix=".cfg", delete=False) as f:
@@ -70,7 +72,7 @@ def make_graph_step(args, preset, cfg_text, net, opt, gen, dev, nll_loss_gather,
             if K > 1:
                 raise SystemExit("--graph-optimizer captures one scan per optimizer step (--in-flight 1)")
             graph_opt = torch.optim.AdamW(params, lr=1e-3, weight_decay=1e-4, amsgrad=True, fused=True, capturable=True)
-        cap = CapturedNetworkStep(one, lat, params, stream=torch.cuda.Stream() if K > 1 else None, optimizer=graph_opt)
+        cap = CapturedNetworkStep(one, lat, params, stream=scan_streams[k] if K > 1 else None, optimizer=graph_opt)
         scans.append(cap)
         if os.environ.get("LNN_DEBUG"):
             torch.cuda.synchronize()
