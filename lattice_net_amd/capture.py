@@ -54,25 +54,29 @@ def concurrent_streams(k: int, candidates: int = 16, spin_us: float = 250.0):
         torch.cuda.synchronize()
         return ev0.elapsed_time(ev1) * 1e3
 
+    import time
     one(cur, 1000)  # (first call: lazy initialisation)
     t = max(one(cur, cycles), 1.0)
     cycles = max(1000, int(cycles * spin_us / t))  # calibrated to ~spin_us
-    single = one(cur, cycles)
 
-    def overlaps(a, b):
-        import time
+    def wall(streams):
+        """Host wall time (best of 3) of one spin kernel on each of `streams`, launched back to back."""
         best = None
         for _ in range(3):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            with torch.cuda.stream(a):
-                torch.cuda._sleep(cycles)
-            with torch.cuda.stream(b):
-                torch.cuda._sleep(cycles)
+            for st in streams:
+                with torch.cuda.stream(st):
+                    torch.cuda._sleep(cycles)
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) * 1e6
             best = dt if best is None else min(best, dt)
-        return best < 1.6 * single + 60.0  # (two serialised spins take 2 x single; 60 us of launch / sync slack)
+        return best
+
+    single = wall([cur])  # the same clock as the pairs below: launch and synchronise overheads (a profiler's, too) cancel
+
+    def overlaps(a, b):
+        return wall([a, b]) < 1.5 * single + 20.0  # (two serialised spins take 2 x single)
 
     spare = []
     for _ in range(candidates):
