@@ -334,9 +334,10 @@ class Gn(_PreActBlock):  # mods:863-878
 class _PreConv(_PreActBlock):
     def __init__(self, in_channels, out_channels, dilation, bias, with_dropout, norm, act, act_after=False, device="cuda"):
         super().__init__()
-        self._setup(in_channels, norm, act, with_dropout, act_after, device)
+        # (the operator is registered before the norm, as in the reference's constructors: state_dict order, mods:939-940)
         self.conv = ConvLatticeIm2RowModule(in_channels=in_channels, out_channels=out_channels, neighbourhood_size=1, dilation=dilation,
                                             bias=bias, device=device)
+        self._setup(in_channels, norm, act, with_dropout, act_after, device)
 
     def forward(self, lv, ls):
         lv, ls = self._pre(lv, ls)
@@ -379,8 +380,8 @@ class _PreCoarsen(_PreActBlock):
     def __init__(self, in_channels, out_channels, norm, act, act_after=False, device="cuda"):
         super().__init__()
         self.in_channels, self.out_channels = in_channels, out_channels
-        self._setup(in_channels, norm, act, False, act_after, device)
         self.coarse = CoarsenLatticeModule(in_channels=in_channels, out_channels=out_channels, device=device)
+        self._setup(in_channels, norm, act, False, act_after, device)
 
     def forward(self, lv, ls, concat_connection=None):
         lv, ls = self._pre(lv, ls)
@@ -417,8 +418,8 @@ class _PreFinefy(_PreActBlock):
     def __init__(self, in_channels, out_channels, norm, act, act_after=False, device="cuda"):
         super().__init__()
         self.in_channels, self.out_channels = in_channels, out_channels
-        self._setup(in_channels, norm, act, False, act_after, device)
         self.fine = FinefyLatticeModule(in_channels=in_channels, out_channels=out_channels, device=device)
+        self._setup(in_channels, norm, act, False, act_after, device)
 
     def forward(self, lv_coarse, ls_coarse, ls_fine):
         lv_coarse, ls_coarse = self._pre(lv_coarse, ls_coarse)

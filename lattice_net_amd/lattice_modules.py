@@ -49,8 +49,9 @@ class _WeightNormed:
     def _install_weight_norm(self, v: torch.Tensor, g_dim: int):
         g_shape = [1] * v.dim()
         g_shape[g_dim] = v.shape[g_dim]
-        self.weight_v = torch.nn.Parameter(v)
+        # registration order of torch's WeightNorm.apply: <name>_g, then <name>_v, both behind the parameters that stay (bias)
         self.weight_g = torch.nn.Parameter(torch.full(g_shape, float(v.norm()), dtype=v.dtype, device=v.device))  # unfuse(): g := ||v||
+        self.weight_v = torch.nn.Parameter(v)
 
     @property
     def weight(self) -> torch.Tensor:
@@ -62,8 +63,8 @@ class LinearWN(_WeightNormed, torch.nn.Module):  # utils.py:291 (weight_norm_wra
         super().__init__()
         self.in_features, self.out_features = in_features, out_features
         b = _leaky_relu_init_bound(in_features, out_features)  # PointNetModule applies leaky_relu_init to its layers (mods:651)
-        self._install_weight_norm(torch.empty((out_features, in_features), device=device).uniform_(-b, b), g_dim=0)
         self.bias = torch.nn.Parameter(torch.zeros(out_features, device=device)) if bias else None
+        self._install_weight_norm(torch.empty((out_features, in_features), device=device).uniform_(-b, b), g_dim=0)
 
     def forward(self, x):
         return torch.nn.functional.linear(x, self.weight, self.bias)

@@ -1,0 +1,268 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/F10_reference_lnn.npz by EXECUTING the reference's own network definition
+(/root/reference/latticenet_py/lattice/models.py:70-266 `LNN`, lattice_modules.py, lattice_funcs.py, utils/utils.py) in this
+container, on the CPU in float64, over stand-ins for what the image lacks:
+
+  latticenet.Lattice   -> tests/oracle_lattice.OracleLattice (+ im2row / row2im, the two PyBridge methods only the reference's
+                          split convolution calls) — the NumPy oracle for every integer decision, the reference's formulas in
+                          float64 for the arithmetic (pinned by tests/test_oracle_network.py against central differences)
+  torch_scatter        -> scatter_mean / scatter_max / scatter_add written with index_add_ / NumPy (ties of scatter_max go to the
+                          smallest token, as torch_scatter's CPU kernel does)
+  easypbr, termcolor   -> no-ops (profiler hooks, coloured printing)
+  "cuda"               -> Tensor.to / Module.to map the device string to the CPU, torch.cuda.FloatTensor is a CPU tensor type
+  ModelParams (C++)    -> a plain object answering the getters the reference calls, from the values of tests/test_oracle_network.CFG
+
+ONE accommodation of a defect of the reference itself: Im2RowLattice.backward (lattice_funcs.py:239-246) computes
+`grad_values = lattice.row2im(...)` and then returns an undefined name `lattice_values` — as written every training step of a network
+with a GnReluConv raises NameError.  Every other backward of that file ends with `lattice_values = lattice_py.values()` after an
+in-place kernel (lattice_funcs.py:508-510, 597-598), and Lattice::row2im leaves its result in the lattice's values as well
+(Lattice.cu:646-667), so the evident intent is "return what row2im produced": the stand-in's row2im binds exactly that tensor to the
+module global `lattice_values` of the reference's lattice_funcs before it returns.  Nothing else of the reference is patched.
+
+What is written is DATA ONLY (no reference source, bytecode or text): the ordered state_dict keys with shapes AFTER the first forward
+(the reference creates some parameters lazily, lattice_modules.py:509-516, 554-556, 636-651), the seeds the parameters were refilled
+from (every tensor is regenerated from (seed, position in the key order, shape) by `seeded_parameter`, which the tests import), the
+logits, the loss, and every parameter gradient (norm of each, full tensors up to 4096 elements, a fixed strided sample above).
+
+Run in the build container only:  python tests/golden/make_reference_network_fixture.py"""
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+N_POINTS, NR_CLASSES, CLOUD_SEED, PARAM_SEED = 1500, 6, 0, 4242
+FULL_GRADIENT_MAX = 4096
+SAMPLE = 1024
+
+
+def seeded_parameter(position: int, key: str, shape, seed: int = PARAM_SEED) -> np.ndarray:
+    """The value of the `position`-th state_dict tensor: N(0, 1) scaled so that activations stay O(1) through the network;
+    magnitudes of weight-normalised layers and norm gains positive.  float64; the tests cast."""
+    rng = np.random.default_rng(seed + 7919 * position)
+    x = rng.standard_normal(tuple(shape))
+    if key.endswith(("weight_g", "gn.weight", "gamma")):
+        return 1.0 + 0.1 * x
+    if key.endswith(("bias", "beta")):
+        return 0.1 * x
+    fan = max(int(np.prod(shape[:-1])) if len(shape) > 1 else int(shape[0]), 1)
+    if key.endswith("linear_clasify.weight") or key.endswith("weight_v") or ".linear." in key or "linear_deltaW" in key:
+        fan = int(shape[-1])  # torch.nn.Linear stores [out, in]
+    return x * np.sqrt(2.0 / fan)
+
+
+def gradient_sample_index(numel: int) -> np.ndarray:
+    return np.linspace(0, numel - 1, SAMPLE).astype(np.int64)
+
+
+class PlainModelParams:
+    """The getters models.py:70-100 and prepare_cloud call, answered from tests/test_oracle_network.CFG."""
+    _v = dict(positions_mode="xyz", values_mode="none", pointnet_channels_per_layer=[16, 32], pointnet_start_nr_channels=32, nr_downsamples=2,
+              nr_blocks_down_stage=[1, 1], nr_blocks_bottleneck=1, nr_blocks_up_stage=[1, 1], nr_levels_down_with_normal_resnet=1,
+              nr_levels_up_with_normal_resnet=1, compression_factor=1.0, dropout_last_layer=0.0)
+
+    def __getattr__(self, name):
+        if name in self._v:
+            return lambda: self._v[name]
+        raise AttributeError(name)
+
+
+def install_stand_ins():
+    from tests.oracle_lattice import OracleLattice
+
+    class RefLattice(OracleLattice):
+        """OracleLattice + the PyBridge methods only the reference's Python calls (PyBridge.cxx:59-66, 98-99)."""
+
+        def _clone(self):
+            new = RefLattice(self.m_sigmas, self.cap, self.m_lvl)
+            new.table, new._values, new.m_positions = self.table, self._values, self.m_positions
+            new._nbr_cache = self._nbr_cache
+            return new
+
+        def distribute(self, positions_raw, values, reset_hashmap=True):
+            lat, rows, idx, w = super().distribute(positions_raw, values, reset_hashmap)
+            lat.__class__ = RefLattice
+            return lat, rows, idx, w
+
+        def create_coarse_verts_naive(self, positions_raw):
+            lat = super().create_coarse_verts_naive(positions_raw)
+            lat.__class__ = RefLattice
+            return lat
+
+        def gather_standalone_with_precomputation(self, positions_raw, idx, w):
+            # a freshly allocated tensor, as Lattice.cu:878-917 returns (not a view made inside the autograd Function: the reference
+            # modifies the result in place, lattice_modules.py:529)
+            return super().gather_standalone_with_precomputation(positions_raw, idx, w).clone()
+
+        @staticmethod
+        def get_expected_filter_extent(neighborhood_size):  # Lattice.cu:1359-1364 (static, from the last set_sigmas)
+            from lattice_net_amd.lattice import Lattice
+            assert neighborhood_size == 1
+            return 2 * (Lattice.m_expected_position_dimensions + 1) + 1
+
+        def im2row(self, lattice_neighbours, filter_extent, dilation, flip_neighbours):  # Lattice.cu:612-644
+            nb = lattice_neighbours
+            assert filter_extent == self.get_filter_extent(1)
+            return self._im2row(self._nbr(nb, dilation, flip_neighbours), nb.values()[: nb.nr_lattice_vertices()])
+
+        def row2im(self, rowified, dilation, filter_extent, nr_filters, lattice_neighbours):  # Lattice.cu:646-667, LatticeGPU.cuh:2187-2284
+            nb = lattice_neighbours
+            nbr = self._nbr(nb, dilation, False)
+            m, e = nbr.shape
+            v = rowified.shape[1] // e
+            out = torch.zeros((nb.nr_lattice_vertices(), v), dtype=rowified.dtype)
+            ok = (nbr >= 0).reshape(-1)
+            out.index_add_(0, nbr.reshape(-1)[ok], rowified.reshape(m * e, v)[ok])
+            self._values = out
+            sys.modules["latticenet_py.lattice.lattice_funcs"].lattice_values = out  # (the one accommodation, see the header)
+            return out
+
+    latticenet = types.ModuleType("latticenet")
+    latticenet.Lattice = RefLattice
+    latticenet.HashTable = object
+    sys.modules["latticenet"] = latticenet
+
+    easypbr = types.ModuleType("easypbr")
+
+    class Profiler:
+        is_profiling_gpu = staticmethod(lambda: False)
+        start = staticmethod(lambda name: None)
+        end = staticmethod(lambda name: None)
+
+    easypbr.Profiler, easypbr.Mesh, easypbr.Scene = Profiler, object, object
+    easypbr.__all__ = ["Profiler", "Mesh", "Scene"]
+    sys.modules["easypbr"] = easypbr
+
+    termcolor = types.ModuleType("termcolor")
+    termcolor.colored = lambda s, *a, **k: s
+    sys.modules["termcolor"] = termcolor
+
+    ts = types.ModuleType("torch_scatter")
+
+    def scatter_add(src, index, dim=0):
+        n = int(index.max()) + 1
+        out = torch.zeros((n,) + tuple(src.shape[1:]), dtype=src.dtype)
+        return out.index_add_(0, index, src)
+
+    def scatter_mean(src, index, dim=0):
+        s = scatter_add(src, index)
+        c = scatter_add(torch.ones(index.shape[0], dtype=src.dtype), index).clamp(min=1)
+        return s / c.reshape((-1,) + (1,) * (src.dim() - 1))
+
+    def scatter_max(src, index, dim=0):
+        n, c = int(index.max()) + 1, src.shape[1]
+        s, rows = src.detach().numpy(), index.numpy()
+        out = np.full((n, c), -np.inf)
+        np.maximum.at(out, rows, s)
+        tok = np.arange(rows.shape[0], dtype=np.int64)
+        arg = np.full((n, c), rows.shape[0], dtype=np.int64)  # torch_scatter: src.size(dim) where no element arrived
+        for ch in range(c):
+            hit = s[:, ch] == out[rows, ch]
+            np.minimum.at(arg[:, ch], rows[hit], tok[hit])
+        arg_t = torch.from_numpy(arg)
+        empty = arg_t == rows.shape[0]
+        val = src[arg_t.clamp(max=rows.shape[0] - 1), torch.arange(c).unsqueeze(0).expand(n, c)]  # differentiable gather of the winners
+        return val.masked_fill(empty, 0.0), arg_t
+
+    ts.scatter_add, ts.scatter_mean, ts.scatter_max = scatter_add, scatter_mean, scatter_max
+    sys.modules["torch_scatter"] = ts
+
+    # "cuda" -> the CPU
+    def no_cuda(args, kwargs):
+        args = tuple("cpu" if (isinstance(a, str) and a.startswith("cuda")) else a for a in args)
+        if isinstance(kwargs.get("device"), str) and kwargs["device"].startswith("cuda"):
+            kwargs = dict(kwargs, device="cpu")
+        return args, kwargs
+
+    t_to, m_to = torch.Tensor.to, torch.nn.Module.to
+
+    def tensor_to(self, *a, **k):
+        a, k = no_cuda(a, k)
+        return t_to(self, *a, **k)
+
+    def module_to(self, *a, **k):
+        a, k = no_cuda(a, k)
+        return m_to(self, *a, **k)
+
+    torch.Tensor.to, torch.nn.Module.to = tensor_to, module_to
+    torch.cuda.FloatTensor = torch.DoubleTensor  # lattice_modules.py:691 (a vector of ones); float64 like everything here
+
+    # the reference's package (a namespace package: this repository's alias package of the same name must not shadow it)
+    for name in [k for k in sys.modules if k == "latticenet_py" or k.startswith("latticenet_py.")]:
+        del sys.modules[name]
+    for name, sub in (("latticenet_py", ""), ("latticenet_py.lattice", "lattice"), ("latticenet_py.utils", "utils")):
+        pkg = types.ModuleType(name)
+        pkg.__path__ = [os.path.join(REF, "latticenet_py", sub)]
+        sys.modules[name] = pkg
+    return RefLattice
+
+
+def main():
+    assert os.path.isdir(os.path.join(REF, "latticenet_py")), "the reference tree is only mounted in the build container"
+    torch.set_default_dtype(torch.float64)
+    RefLattice = install_stand_ins()
+    import warnings
+    warnings.simplefilter("ignore")
+    models = importlib.import_module("latticenet_py.lattice.models")
+    from lattice_net_amd.synthetic import box_surface_cloud
+
+    lattice = RefLattice([0.08] * 3, 60000)
+    torch.manual_seed(0)
+    net = models.LNN(NR_CLASSES, PlainModelParams())
+    keys_at_construction = list(net.state_dict().keys())
+    pos = torch.from_numpy(box_surface_cloud(N_POINTS, CLOUD_SEED))  # float32 positions, as the loaders deliver them
+    vals = torch.zeros((N_POINTS, 1))
+    target = torch.from_numpy(np.random.default_rng(CLOUD_SEED).integers(0, NR_CLASSES, N_POINTS))
+    with torch.no_grad():
+        net(lattice, pos, vals)  # the first forward creates the lazy parameters (ln_eval.py:131-137 relies on it)
+    sd = net.state_dict()
+    keys = list(sd.keys())
+    shapes = [tuple(sd[k].shape) for k in keys]
+    with torch.no_grad():
+        for i, k in enumerate(keys):
+            sd[k].copy_(torch.from_numpy(seeded_parameter(i, k, shapes[i])).reshape(shapes[i]))
+    net.train()
+    logsoftmax, logits = net(lattice, pos, vals)
+    loss = torch.nn.functional.nll_loss(logsoftmax, target)
+    loss.backward()
+    named = dict(net.named_parameters())
+    out = {
+        "keys": np.array(keys), "keys_at_construction": np.array(keys_at_construction),
+        "shapes": np.array([",".join(map(str, s)) for s in shapes]),
+        "is_parameter": np.array([k in named for k in keys]),
+        "param_seed": np.int64(PARAM_SEED), "n_points": np.int64(N_POINTS), "nr_classes": np.int64(NR_CLASSES), "cloud_seed": np.int64(CLOUD_SEED),
+        "logits": logits.detach().numpy(), "loss": np.float64(loss.item()),
+        "nr_vertices_per_level": np.array([0]),
+    }
+    norms = []
+    for i, k in enumerate(keys):
+        if k not in named:
+            norms.append(np.nan)
+            continue
+        g = named[k].grad
+        assert g is not None, f"{k} received no gradient"
+        g = g.detach().numpy().reshape(-1)
+        norms.append(float(np.linalg.norm(g)))
+        if g.size <= FULL_GRADIENT_MAX:
+            out[f"grad_full/{i}"] = g.astype(np.float64)
+        else:
+            out[f"grad_sample/{i}"] = g[gradient_sample_index(g.size)].astype(np.float64)
+    out["grad_norms"] = np.array(norms)
+    path = os.path.join(HERE, "F10_reference_lnn.npz")
+    np.savez_compressed(path, **out)
+    print(f"{path}: {len(keys)} tensors ({len(keys_at_construction)} exist before the first forward), loss {loss.item():.6f}, "
+          f"{os.path.getsize(path) / 1024:.0f} KiB")
+    for k, s in zip(keys, shapes):
+        print(f"  {k:70s} {s}")
+
+
+if __name__ == "__main__":
+    main()

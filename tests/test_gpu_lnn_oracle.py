@@ -64,6 +64,54 @@ def test_whole_network_logits_and_gradients_match_the_oracle_network(tmp_path):
     assert not bad, f"parameter gradients off: {sorted(bad.items(), key=lambda kv: -kv[1])[:8]}"
 
 
+def test_whole_network_matches_the_reference_networks_own_output(tmp_path):
+    """The GPU network (C ABI underneath) against tests/golden/F10_reference_lnn.npz = logits, loss and parameter gradients of the
+    REFERENCE's own `LNN` Python (models.py:70-266, lattice_modules.py, lattice_funcs.py) executed in float64 over the oracle lattice
+    (tests/golden/make_reference_network_fixture.py): same cloud, same seeded parameters, 1e-4."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from make_reference_network_fixture import gradient_sample_index, seeded_parameter
+    from lattice_net_amd import Lattice, ModelParams
+    from lattice_net_amd.models import LNN
+    from lattice_net_amd.synthetic import box_surface_cloud
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "F10_reference_lnn.npz"))
+    n, c = int(fx["n_points"]), int(fx["nr_classes"])
+    p = tmp_path / "net.cfg"
+    p.write_text(CFG)
+    lattice = Lattice.create(str(p), "lattice")
+    net = LNN(c, ModelParams.create(str(p)))
+    sd = net.state_dict()
+    keys = [str(k) for k in fx["keys"]]
+    assert list(sd.keys()) == keys
+    for i, k in enumerate(keys):
+        sd[k].copy_(torch.from_numpy(seeded_parameter(i, k, sd[k].shape, int(fx["param_seed"]))).float())
+    pos = torch.from_numpy(box_surface_cloud(n, int(fx["cloud_seed"]))).to(dev())
+    target = torch.from_numpy(np.random.default_rng(int(fx["cloud_seed"])).integers(0, c, n)).to(dev())
+    logsoftmax, logits = net(lattice, pos, torch.zeros((n, 1), device=dev()))
+    loss = torch.nn.functional.nll_loss(logsoftmax, target)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert rel(logits.detach().cpu().numpy(), fx["logits"]) < TOL
+    assert abs(float(loss) - float(fx["loss"])) < TOL * abs(float(fx["loss"]))
+    named = dict(net.named_parameters())
+    gmax = float(np.nanmax(fx["grad_norms"]))
+    bad = {}
+    for i, k in enumerate(keys):
+        if k not in named:
+            continue
+        g = named[k].grad.detach().cpu().numpy().astype(np.float64).reshape(-1)
+        if f"grad_full/{i}" in fx:
+            ref = fx[f"grad_full/{i}"]
+        else:
+            ref, g = fx[f"grad_sample/{i}"], g[gradient_sample_index(g.size)]
+        # (same floor as above: tensors whose gradient vanishes analytically hold rounding noise only)
+        e = float(np.abs(g - ref).max()) / max(float(np.abs(ref).max()), 1e-3 * gmax / np.sqrt(max(ref.size, 1)))
+        if e > TOL:
+            bad[k] = e
+    assert not bad, f"parameter gradients off: {sorted(bad.items(), key=lambda kv: -kv[1])[:8]}"
+
+
 def test_distribute_module_post_processing_matches_oracle():
     """lattice_modules.py:66-94 on the GPU (segment reduce + index arithmetic) against torch on the oracle lattice."""
     from lattice_net_amd import Lattice
