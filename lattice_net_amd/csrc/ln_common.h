@@ -363,4 +363,5 @@ __global__ void __launch_bounds__(256)
 // Experiment knob (tools only): LN_DEBUG_MASK in the environment, read once.  0 in production.
 int ln_debug_mask();
 
+#define LN_SC_MAX_SLABS 768  // workgroups of a slice-classify backward launch = per-workgroup slabs of classifier gradients in its workspace
 static inline int ln_div_up(long long a, long long b) { return int((a + b - 1) / b); }

@@ -8,6 +8,13 @@
 // order-deterministic kernels are bit-identical to the CPU oracle.
 #include "ln_common.h"
 
+// wave-tiled slice + classifier kernels for the common shapes (ln_classify.hip); return 0 when the shape is not covered
+int ln_sc_forward_wave(const float* values, const float* delta_w, const float* lin_w, const float* lin_b, const int* idx, const float* w,
+                       int n, int pos_dim, int val_dim, int nr_classes, float* logits, hipStream_t st);
+int ln_sc_backward_wave(const float* grad_logits, const float* values, const float* delta_w, const float* lin_w, const int* idx,
+                        const float* w, int n, int pos_dim, int val_dim, int nr_classes, float* g_delta_w, float* grad_sliced,
+                        float* w_eff, float* slabs, int* grid_out, hipStream_t st);
+
 template <int VEC>
 struct VecT;
 template <>
@@ -560,6 +567,8 @@ extern "C" int ln_slice_classify_forward(const float* values, const float* delta
     LN_REQUIRE(nr_classes >= 1 && (n == 0 || (delta_w && lin_w && lin_b && w)), LN_ERR_ARG, "ln_slice_classify_forward: bad args");
     if (n == 0) return LN_OK;
     hipStream_t st = (hipStream_t)stream;
+    if (!(ln_debug_mask() & 64) && ln_sc_forward_wave(values, delta_w, lin_w, lin_b, idx, w, n, pos_dim, val_dim, nr_classes, logits, st))
+        return ln_check_launch("ln_slice_classify_forward");  // wave-tiled kernel (ln_classify.hip): V % 32 == 0, C <= 32, d in {2, 3}
     if (val_dim % 4 == 0 && (reinterpret_cast<uintptr_t>(values) & 15) == 0) {
         // float4 kernel: largest tile whose [C + PB, V+1] + 2 [PB, d+1] arrays fit 64 KiB and whose threads own <= 16 classes each
         for (int pb = 64; pb >= 16; pb >>= 1) {
@@ -851,7 +860,7 @@ static int ln_sc_backward_grid(int n, int pb) {
 
 extern "C" size_t ln_slice_classify_backward_workspace_bytes(int n, int pos_dim, int val_dim, int nr_classes) {
     if (n < 1) n = 1;
-    return (size_t)512 * ((size_t)nr_classes * val_dim + nr_classes) * sizeof(float) + 256;
+    return (size_t)LN_SC_MAX_SLABS * ((size_t)nr_classes * val_dim + nr_classes) * sizeof(float) + 256;
 }
 
 extern "C" int ln_slice_classify_backward(const float* grad_logits, const float* values, const float* delta_w, const float* lin_w,
@@ -865,6 +874,14 @@ extern "C" int ln_slice_classify_backward(const float* grad_logits, const float*
     if (n == 0) return LN_OK;
     LN_REQUIRE(workspace && workspace_bytes >= ln_slice_classify_backward_workspace_bytes(n, pos_dim, val_dim, nr_classes), LN_ERR_WORKSPACE,
                "ln_slice_classify_backward: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int dp1 = pos_dim + 1;
+    float* slabs = static_cast<float*>(workspace);
+    const int cv = nr_classes * val_dim;
+    int grid = 0;
+    const bool wave_kernel = !(ln_debug_mask() & 64) && ln_sc_backward_wave(grad_logits, values, delta_w, lin_w, idx, w, n, pos_dim, val_dim, nr_classes,
+                                                                          g_delta_w, grad_sliced, w_eff, slabs, &grid, st);
+    if (!wave_kernel) {
     const int cp = (nr_classes + 3) & ~3;
     const bool v4 = (val_dim % 4 == 0) && (cp * val_dim <= 256 * LN_SC_BLOCKS * 16) &&
                     ((reinterpret_cast<uintptr_t>(values) | reinterpret_cast<uintptr_t>(grad_sliced)) & 15) == 0;
@@ -883,10 +900,7 @@ extern "C" int ln_slice_classify_backward(const float* grad_logits, const float*
         lds = sizeof(float) * ((size_t)nr_classes * (val_dim + 1) + (size_t)pb * (2 * val_dim + nr_classes));
     }
     LN_REQUIRE(pb > 0, LN_ERR_UNSUPPORTED, "ln_slice_classify_backward: V=%d C=%d do not fit 64 KiB of LDS", val_dim, nr_classes);
-    const int grid = ln_sc_backward_grid(n, pb);
-    float* slabs = static_cast<float*>(workspace);
-    hipStream_t st = (hipStream_t)stream;
-    const int dp1 = pos_dim + 1;
+    grid = ln_sc_backward_grid(n, pb);
 #define LN_SC_BWD(P)                                                                                                               \
     if (pb == P) {                                                                                                                 \
         if (v4)                                                                                                                    \
@@ -898,8 +912,8 @@ extern "C" int ln_slice_classify_backward(const float* grad_logits, const float*
     }
     LN_SC_BWD(64) LN_SC_BWD(32) LN_SC_BWD(16) LN_SC_BWD(8)
 #undef LN_SC_BWD
+    }
     // the gradient tensors are accumulated into (Lattice.cu:1091-1115)
-    const int cv = nr_classes * val_dim;
     LN_LAUNCH("k_sc_reduce_slabs", ln_k_sum_slabs<true>, dim3(ln_div_up(cv, 16)), dim3(256), 0, st, slabs, grid, (long long)(cv + nr_classes), cv,
               g_lin_w);
     LN_LAUNCH("k_sc_reduce_slabs", ln_k_sum_slabs<true>, dim3(ln_div_up(nr_classes, 16)), dim3(256), 0, st, slabs + cv, grid,

@@ -77,10 +77,13 @@ def test_slice_and_gather_autograd_against_oracle():
     close(N(vals3.grad), O.gather_backwards(gg, oidx, ow, m, 3))
 
 
-@pytest.mark.parametrize("n,v,c", [(1500, 8, 20), (5000, 96, 20), (777, 128, 13), (300, 5, 3), (2500, 128, 50)])
+@pytest.mark.parametrize("n,v,c", [(1500, 8, 20), (5000, 96, 20), (777, 128, 13), (300, 5, 3), (2500, 128, 50), (4000, 64, 20), (3111, 32, 32), (129, 64, 1),
+                                   (2049, 160, 24)])
 def test_slice_classify_autograd_against_oracle(n, v, c):
-    """(5000, 96, 20) is the head of the SemanticKITTI LNN: several tiles per workgroup; (777, 128, 13) takes the
-    32-point tile; ragged last tiles everywhere."""
+    """(5000, 96, 20) is the head of the SemanticKITTI LNN.  V % 32 == 0 with up to 32 classes runs the wave-tiled kernels of
+    ln_classify.hip (forward: 64-point tiles, all accumulator widths 8 / 16 / 24 / 32; backward up to V = 128, so (2049, 160, 24)
+    pairs the wave-tiled forward with the general backward); the other shapes take the general kernels of ln_rows.hip; ragged
+    last tiles everywhere."""
     from lattice_net_amd import SliceClassifyLattice
     from lattice_net_amd.synthetic import cube_cloud
     pos_np = cube_cloud(n, 21)
