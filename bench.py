@@ -78,14 +78,18 @@ def algorithmic_work(kernel: str, n: int, m: int, d: int, v: int, f: int, e: int
     """(bound, unit, amount per launch) — SURVEY.md §8d per-unit figures x units per launch."""
     if kernel == "hash_build":  # k_point_keys + k_bucket_rows: read positions, write idx + w, write keys once (8d "splat fwd" minus the values)
         return "hbm", "GB/s", n * (4.0 * d + 8.0 * (d + 1)) + m * 4.0 * d
-    if kernel == "k_conv_mfma":
-        return "mfma", "TFLOP/s", 2.0 * m * e * v * f
+    if kernel == "k_conv_mfma":  # SURVEY 8d: HBM-bound below 64 channels (MFMA figures ride along: mfma_work)
+        if v >= 128:
+            return "mfma", "TFLOP/s", 2.0 * m * e * v * f
+        return "hbm", "GB/s", m * 4.0 * v + m * 4.0 * e + 4.0 * e * v * f + m * 4.0 * f
     if kernel == "k_conv_mfma_f16":
         return "mfma_f16", "TFLOP/s", 2.0 * m * e * v * f
     if kernel == "k_grad_filter_mfma":
         return "mfma", "TFLOP/s", 2.0 * m * e * v * f
-    if kernel == "k_conv_backward_fused":  # value gradient + filter gradient of the convolution in one launch (fp32 matrix cores)
-        return "mfma", "TFLOP/s", 4.0 * m * e * v * f
+    if kernel == "k_conv_backward_fused":  # value gradient + filter gradient of the convolution in one launch
+        if v >= 128:
+            return "mfma", "TFLOP/s", 4.0 * m * e * v * f
+        return "hbm", "GB/s", (m * 4.0 * f + m * 4.0 * e + 4.0 * e * v * f + m * 4.0 * v) + (m * 4.0 * v + m * 4.0 * f + m * 4.0 * e + 4.0 * e * v * f)
     if kernel in ("k_scatter_point_rows", "k_csr_reduce_segments"):  # splat accumulate / slice backward: read rows+idx+w, write vertex rows
         return "hbm", "GB/s", n * (4.0 * v + 8.0 * (d + 1)) + m * 4.0 * v
     if kernel == "k_reduce_and_neighbours":  # splat accumulate + same-level neighbour list in one launch
@@ -97,6 +101,18 @@ def algorithmic_work(kernel: str, n: int, m: int, d: int, v: int, f: int, e: int
     if kernel == "k_neighbours":
         return "hbm", "GB/s", m * (4.0 * d + 4.0 * e)
     raise ValueError(f"no algorithmic model for kernel {kernel}")
+
+
+def mfma_work(kernel: str, m: int, v: int, f: int, e: int, half: bool):
+    """(fp32-equivalent flop per launch, bf16 products executed per fp32 product) of the dense launches, or None."""
+    b3 = os.environ.get("LN_CONV_EXACT_F32", "0") != "1" and v % 32 == 0 and f % 16 == 0 and not half
+    if kernel in ("k_conv_mfma", "k_conv_mfma_f16"):
+        return 2.0 * m * e * v * f, (6.0 if b3 else 1.0)
+    if kernel == "k_conv_backward_fused":
+        return 4.0 * m * e * v * f, (6.0 if b3 else 1.0)
+    if kernel == "k_grad_filter_mfma":
+        return 2.0 * m * e * v * f, 1.0
+    return None
 
 
 KERNEL_GROUPS = {"hash_build": ["k_point_keys", "k_bucket_rows"]}  # launches that only make sense together
@@ -268,7 +284,9 @@ def main():
                     help="timed steps (scans).  The timed region has a fixed cost of ~0.3 ms (first graph launch, drain of the last scans in "
                          "flight, the final synchronize): it is 0.3 % of 2000 steps and 14 % of 20")
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS) + ["ops"],
+                    help="ops: only the per-operator roofline table of tools/ops_roofline.py (every SURVEY 8(a) row outside the headline chain)")
+    ap.add_argument("--ops-table", type=int, default=1, help="0 = leave the per-operator table out of the default line (rank 0, one GPU, workload C3)")
     ap.add_argument("--roofline-kernel", default="hash_build",
                     help="what the `roofline` block reports: the kernel (group) of the path that sits furthest below its bound — the hash "
                          "build (k_point_keys + k_bucket_rows, profiles/r3_kernel_stats.csv); its dispatches are timed live")
@@ -319,6 +337,18 @@ def main():
         # microseconds per step, which is comparable to the whole GPU time of this path
         torch.autograd.set_multithreading_enabled(False)
 
+    if args.workload == "ops":
+        from tools import ops_roofline
+        table = ops_roofline.run(dev, reps=24) if rank == 0 else None
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"metric": "per-operator roofline table, SURVEY 8(a) rows outside the headline chain (tools/ops_roofline.py)",
+                              "value": None, "unit": "us per call, GB/s, TFLOP/s (see entries)", "n_gpus": 1, "data": "synthetic",
+                              "config": {"workload": "C3 scan (120k LiDAR-like points, sigma 0.9, capacity 100k), SemanticKITTI network widths"},
+                              **table}), flush=True)
+        return
     cfg = WORKLOADS[args.workload]
     n, v, f, sigma, cap = cfg["n"], cfg["v"], cfg["f"], cfg["sigma"], cfg["capacity"]
     d, e = 3, 9
@@ -327,6 +357,9 @@ def main():
     in_flight = max(1, args.in_flight) if graph_mode else 1
     pool = max(1, args.pool) if graph_mode else 1
     # independent clouds per rank (weak scaling); parameters broadcast from rank 0 over RCCL
+    # LATTICE_BENCH_RANK_OFFSET=r (testing aid): a one-rank run works on the clouds rank r of a larger job would own
+    rank_offset = int(os.environ.get("LATTICE_BENCH_RANK_OFFSET", "0"))
+    torch.manual_seed(1234)  # the filter bank is the same in every run (checksums of different runs are comparable)
     bound_w = float(np.sqrt(3.0) * np.sqrt(2.0) / np.sqrt(f))  # kaiming-uniform fan_out (lattice_modules.py:202-207)
     W = ((torch.rand((e * v, f), device=dev) * 2 - 1) * bound_w)
     sharding.broadcast_parameters(dist, [W], src=0)
@@ -347,7 +380,7 @@ def main():
         one stream."""
 
         def __init__(self, k):
-            base = sharding.cloud_seed(rank, k) * 64
+            base = sharding.cloud_seed(rank + rank_offset, k) * 64
             self.clouds = [new_cloud(base + p) for p in range(pool)]
             self.calibration = [new_cloud(base + 32 + p) for p in range(2)] if graph_mode else []  # never replayed
             self.lat = L.Lattice(sigmas=[sigma] * d, capacity=cap, device=dev)
@@ -509,7 +542,18 @@ def main():
             achieved, peak, bound_kind = amount / avg_s / 1e12, MFMA_F16_PEAK_TFLOPS, "mfma"
         else:
             achieved, peak = amount / avg_s / 1e12, MFMA_F32_PEAK_TFLOPS
-        return {"bound": bound_kind, "achieved": round(achieved, 3), "peak": peak, "unit": unit, "frac": round(achieved / peak, 4),
+        mw = mfma_work(kernel, m, v, f, e, half)
+        mfma = None
+        if mw is not None:
+            # what the matrix pipe did: the bf16x3 kernels execute six bf16 products per fp32 product (v_mfma_f32_16x16x32_bf16,
+            # 2.5 PFLOP/s dense); the fp32-input kernels one v_mfma_f32_16x16x4_f32 product (157.3 TFLOP/s)
+            tf = mw[0] / avg_s / 1e12
+            ipeak = MFMA_F16_PEAK_TFLOPS if (mw[1] > 1.0 or half) else MFMA_F32_PEAK_TFLOPS
+            mfma = {"fp32_equivalent_tflops": round(tf, 2), "executed_tflops": round(tf * mw[1], 2), "instruction_peak_tflops": ipeak,
+                    "frac_of_instruction_peak": round(tf * mw[1] / ipeak, 4), "frac_fp32_equivalent_of_f32_peak": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
+                    "instruction": "bf16 (fp32 operands split three ways, 6 products per fp32 product)" if mw[1] > 1.0 else
+                                   ("f16" if half else "v_mfma_f32_16x16x4_f32")}
+        return {"bound": bound_kind, "achieved": round(achieved, 3), "peak": peak, "unit": unit, "frac": round(achieved / peak, 4), "mfma": mfma,
                 "traffic": pmc_traffic(kernel) if args.workload == "C3" else None, "kernel": "+".join(names),
                 "avg_us": round(avg_s * 1e6, 2), "avg_us_in_flight": round(per_group(loaded) * 1e6, 2) if loaded else None,
                 "launches_timed": alone[1],
@@ -532,7 +576,7 @@ def main():
     if extras:
         for name in [k for k in args.extra_kernels.split(",") if k and k != args.roofline_kernel]:
             try:
-                ent = roofline_entry(name, reps=6)
+                ent = roofline_entry(name, reps=24)
             except ValueError:
                 ent = None
             if ent:
@@ -659,6 +703,14 @@ def main():
             except Exception as exc:  # secondary number: never take the headline line down with it
                 unet = {"error": f"{type(exc).__name__}: {exc}"}
         copy_ceiling = stream_copy_ceiling(dev) if extras else None
+        ops_table = None
+        if world == 1 and args.ops_table and args.workload == "C3" and extras:
+            try:  # every SURVEY 8(a) row outside the headline chain: distribute, coarse build, level-crossing convolutions, gather,
+                  # slice_classify, the dense contraction at 64 / 128 channels (secondary numbers: never take the headline line down)
+                from tools import ops_roofline
+                ops_table = ops_roofline.run(dev, reps=24)
+            except Exception as exc:
+                ops_table = {"error": f"{type(exc).__name__}: {exc}"}
         exec_desc = (f"{in_flight} independent scan(s) in flight per GPU (own lattice, stream and {pool} clouds each); every step = one hipGraph "
                      f"replay of the whole forward + backward on the next cloud of the scan's pool; value = points of all K steps / wall time"
                      if graph_mode else "eager: one Python autograd pass per step")
@@ -666,7 +718,15 @@ def main():
             "metric": "Mpoints/sec splat+conv+slice fwd+bwd on 120k-pt SemanticKITTI scan",
             "value": round(value, 3), "unit": "Mpoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(max_elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f16 features / f32 accumulate" if half else "f32", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": "f16 features / f32 accumulate" if half else "f32 (convolution products bf16x3-emulated)",
+            "dtype_note": None if half else "fp32 everywhere; the convolutions split both fp32 operands three ways into bf16 and run 6 of the 9 "
+                          "partial products on the bf16 matrix cores with fp32 accumulation (1e-5 per element against fp64, "
+                          "tests/test_gpu_parity.py; LN_CONV_EXACT_F32=1 selects v_mfma_f32_16x16x4_f32 instead)",
+            "data": "synthetic",
+            "value_definition": f"throughput: {in_flight} scan(s) in flight per GPU, hipGraph replays (config.workload); the SURVEY 8(d) number — one "
+                                "pass at a time, hipEvent median — is value_8d_one_pass_mpoints_per_s = latency.mpoints_per_s",
+            "value_8d_one_pass_mpoints_per_s": latency["mpoints_per_s"] if latency else None,
             "config": {"workload": cfg["desc"] + f"; THROUGHPUT definition: {exec_desc}.  The latency of one scan alone is `latency`",
                        "points_per_gpu": n, "vertices": m, "val_dim": v, "nr_filters": f,
                        "sharding": f"{world} rank(s), independent clouds per GPU", "checksum": round(checksum, 3),
@@ -675,7 +735,7 @@ def main():
                        "bounds_and_planes_calibrated_on": "2 clouds per scan that are not in its pool" if graph_mode else None,
                        "vertices_per_scan": m_all, "graph_vs_eager": graph_err},
             "latency": latency, "roofline": roofline, "roofline_others": others, "stages": stages, "hbm_copy_ceiling": copy_ceiling,
-            "full_unet": unet, "cpu_baseline": cpu, "cpu_baseline_1thread": cpu1,
+            "full_unet": unet, "ops": ops_table, "cpu_baseline": cpu, "cpu_baseline_1thread": cpu1,
         }
     try:  # RCCL prints a version banner through C stdio, which a pipe buffers until exit: every rank flushes it now
         C.CDLL(None).fflush(None)

@@ -119,6 +119,10 @@ const char* ln_abi_hash(void);
 const char* ln_kernel_names(void);
 int ln_profile_begin(const char* kernel_names, int max_samples);
 int ln_profile_end(double* total_ms, int* launches);
+/* The same with a breakdown: kernel_names "*" arms every launch of the library; ln_profile_end_table ends the profiling like
+ * ln_profile_end and writes one line "name launches total_ms\n" per launch name that occurred (in order of first occurrence,
+ * NUL-terminated, truncated to out_bytes) — bench.py's per-operator roofline table. */
+int ln_profile_end_table(char* out, int out_bytes);
 
 /* HashTable::clear (src/HashTable.cu:49-57): entries=-1, keys=0, nr_filled=0 (+ our slots/status)
  * in one launch.  `values` (may be NULL) is zero-filled too: values_elems floats. */
@@ -156,10 +160,13 @@ int ln_build_splat(const LnTable* t, const float* positions_raw, const float* si
  * differs from run to run and nothing downstream depends on it.  The bucketed build numbers them bucket by bucket (inside a
  * bucket by the rank of the vertex's smallest token: deterministic, and the whole build is two launches).  ln_canonicalize relabels
  * the rows of a table that ONE bucketed build has just produced — entries[], keys[] and, when given, the idx[tokens] that
- * build wrote and the row ids in the segment descriptors of `csr` (may be NULL) — into first-occurrence order over
+ * build wrote and the row ids in the segment descriptors of `csr` — into first-occurrence order over
  * (point, remainder), i.e. the numbering a serial run of HashTableGPU::insert (HashTableGPU.cuh:425-484) produces and the golden vectors hold.  It must run before anything that
  * stores row ids elsewhere (accumulated values, neighbour lists).  workspace: ln_build_workspace_bytes(tokens, capacity).
- * LN_BUILD_CANONICAL_ROWS makes ln_build_splat / ln_distribute do this themselves. */
+ * LN_BUILD_CANONICAL_ROWS makes ln_build_splat / ln_distribute do this themselves.
+ * `csr` is the LnCsr that build filled: a bucketed build writes ROW ids into its segment descriptors, so it has to be relabelled
+ * with the table.  Passing NULL is only valid when that CSR is never used again (the caller discards it): a scatter through the
+ * stale descriptors would land on the old rows. */
 int ln_canonicalize(const LnTable* t, int* idx, long long tokens, const LnCsr* csr, void* workspace, size_t workspace_bytes, void* stream);
 
 /* A host may let a build hash into fewer slots than the table owns (LnTable.capacity = the slots in use: clearing and emitting

@@ -78,6 +78,7 @@ SIGNATURES = {
     "ln_kernel_names": (C.c_char_p, []),
     "ln_profile_begin": (_i, [C.c_char_p, _i]),
     "ln_profile_end": (_i, [C.POINTER(C.c_double), C.POINTER(_i)]),
+    "ln_profile_end_table": (_i, [C.c_char_p, _i]),
     "ln_table_clear": (_i, [_T, _vp, _ll, _vp]),
     "ln_build_workspace_bytes": (_sz, [_ll, _i]),
     "ln_build_splat": (_i, [_T, _vp, _vp, _i, _vp, _vp, _i, _CSR, _vp, _sz, _vp, _ll, _vp]),

@@ -330,26 +330,36 @@ __device__ __forceinline__ int ln_block_excl_scan_256(int v, int* s_tmp, int* to
 #endif
 
 #if defined(__HIPCC__)
-// out[g] (+)= sum over slabs of partial[s * stride + g], g < total.  16 outputs per workgroup, the slabs split over 16
+// out[g] (+)= sum over slabs of partial[s * stride + g], g < total (outputs g >= split go to out2[g - split] when out2 is given).  16 outputs per workgroup, the slabs split over 16
 // thread rows and combined through LDS (a single thread walking hundreds of slabs is latency-bound).  Launch with
 // grid = ceil(total / 16), block = 256.
 template <bool ACCUMULATE>
 __device__ __forceinline__ void ln_sum_slabs_body(int block_x, const float* __restrict__ partial, int nslabs, long long stride, int total,
-                                                  float* __restrict__ out) {
+                                                  float* __restrict__ out, float* __restrict__ out2 = nullptr, int split = 0) {
     __shared__ float s_part[16][17];
     const int o = threadIdx.x & 15;
     const int part = threadIdx.x >> 4;
     const int g = block_x * 16 + o;
     float acc = 0.0f;
     if (g < total)
-        for (int s = part; s < nslabs; s += 16) acc += partial[(size_t)s * stride + g];
+        for (int s0 = part; s0 < nslabs; s0 += 16 * 8) {  // eight loads in flight per thread (one at a time: ~10 us for 512 slabs)
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int sl = s0 + 16 * k;
+                v[k] = sl < nslabs ? partial[(size_t)sl * stride + g] : 0.0f;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc += v[k];
+        }
     s_part[part][o] = acc;
     __syncthreads();
     if (part == 0 && g < total) {
         float r = 0.0f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) r += s_part[k][o];
-        out[g] = ACCUMULATE ? out[g] + r : r;
+        float* dst = (out2 && g >= split) ? out2 + (g - split) : out + g;
+        *dst = ACCUMULATE ? *dst + r : r;
     }
 }
 
@@ -357,6 +367,13 @@ template <bool ACCUMULATE>
 __global__ void __launch_bounds__(256)
     ln_k_sum_slabs(const float* __restrict__ partial, int nslabs, long long stride, int total, float* __restrict__ out) {
     ln_sum_slabs_body<ACCUMULATE>(blockIdx.x, partial, nslabs, stride, total, out);
+}
+// the same with the outputs g >= split going to out2[g - split] (one launch for a weight block and its bias row)
+template <bool ACCUMULATE>
+__global__ void __launch_bounds__(256)
+    ln_k_sum_slabs2(const float* __restrict__ partial, int nslabs, long long stride, int total, float* __restrict__ out,
+                    float* __restrict__ out2, int split) {
+    ln_sum_slabs_body<ACCUMULATE>(blockIdx.x, partial, nslabs, stride, total, out, out2, split);
 }
 #endif
 

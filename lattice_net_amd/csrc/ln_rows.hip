@@ -914,10 +914,8 @@ extern "C" int ln_slice_classify_backward(const float* grad_logits, const float*
 #undef LN_SC_BWD
     }
     // the gradient tensors are accumulated into (Lattice.cu:1091-1115)
-    LN_LAUNCH("k_sc_reduce_slabs", ln_k_sum_slabs<true>, dim3(ln_div_up(cv, 16)), dim3(256), 0, st, slabs, grid, (long long)(cv + nr_classes), cv,
-              g_lin_w);
-    LN_LAUNCH("k_sc_reduce_slabs", ln_k_sum_slabs<true>, dim3(ln_div_up(nr_classes, 16)), dim3(256), 0, st, slabs + cv, grid,
-              (long long)(cv + nr_classes), nr_classes, g_lin_b);
+    LN_LAUNCH("k_sc_reduce_slabs", ln_k_sum_slabs2<true>, dim3(ln_div_up(cv + nr_classes, 16)), dim3(256), 0, st, slabs, grid,
+              (long long)(cv + nr_classes), cv + nr_classes, g_lin_w, g_lin_b, cv);
     if (g_values) {
         const long long work = (long long)n * dp1 * val_dim;
         LN_LAUNCH("k_sc_scatter_atomic", k_sc_scatter_atomic, dim3(ln_div_up(work, 256)), dim3(256), 0, st, grad_sliced, w_eff, idx, work, dp1,

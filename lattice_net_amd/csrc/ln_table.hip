@@ -65,6 +65,7 @@ struct LnProfState {
     char names[256] = "";  // ",name1,name2," — the kernels whose launches are timed
     int max_samples = 0;
     std::vector<hipEvent_t> starts, stops;
+    std::vector<const char*> sample_names;  // launch name of every sample (string literals of the LN_LAUNCH sites)
     size_t used = 0;
 };
 LnProfState g_prof;
@@ -75,10 +76,11 @@ LnProfEvents ln_prof_next(const char* name) {
     if (g_prof.max_samples > 0 && g_prof.used < g_prof.starts.size()) {
         char key[72];
         snprintf(key, sizeof(key), ",%s,", name);
-        if (strstr(g_prof.names, key)) {
+        if (!strcmp(g_prof.names, ",*,") || strstr(g_prof.names, key)) {
             ev.start = g_prof.starts[g_prof.used];
             ev.stop = g_prof.stops[g_prof.used];
             ev.armed = true;
+            g_prof.sample_names[g_prof.used] = name;
             ++g_prof.used;
         }
     }
@@ -92,6 +94,7 @@ extern "C" int ln_profile_begin(const char* kernel_names, int max_samples) {
     LN_REQUIRE(g_prof.max_samples == 0, LN_ERR_ARG, "ln_profile_begin: profiling already armed for %s", g_prof.names);
     g_prof.starts.resize(max_samples);
     g_prof.stops.resize(max_samples);
+    g_prof.sample_names.assign(max_samples, nullptr);
     for (int i = 0; i < max_samples; ++i) {
         if (hipEventCreate(&g_prof.starts[i]) != hipSuccess || hipEventCreate(&g_prof.stops[i]) != hipSuccess) {
             ln_set_error("ln_profile_begin: hipEventCreate failed");
@@ -129,6 +132,36 @@ extern "C" int ln_profile_end(double* total_ms, int* launches) {
     g_prof.max_samples = 0;
     g_prof.names[0] = 0;
     return rc;
+}
+extern "C" int ln_profile_end_table(char* out, int out_bytes) {
+    LN_REQUIRE(out && out_bytes > 0, LN_ERR_ARG, "ln_profile_end_table: null output");
+    struct Row { const char* name; int launches; double ms; };
+    std::vector<Row> rows;
+    int rc = LN_OK;
+    for (size_t i = 0; i < g_prof.used; ++i) {
+        float ms = 0.f;
+        if (hipEventSynchronize(g_prof.stops[i]) != hipSuccess || hipEventElapsedTime(&ms, g_prof.starts[i], g_prof.stops[i]) != hipSuccess) {
+            ln_set_error("ln_profile_end_table: event query failed");
+            rc = LN_ERR_LAUNCH;
+            break;
+        }
+        size_t r = 0;
+        while (r < rows.size() && strcmp(rows[r].name, g_prof.sample_names[i])) ++r;
+        if (r == rows.size()) rows.push_back(Row{g_prof.sample_names[i], 0, 0.0});
+        rows[r].launches += 1;
+        rows[r].ms += ms;
+    }
+    int at = 0;
+    out[0] = 0;
+    for (const Row& r : rows) {
+        const int w = snprintf(out + at, size_t(out_bytes - at), "%s %d %.6f\n", r.name, r.launches, r.ms);
+        if (w < 0 || w >= out_bytes - at) break;
+        at += w;
+    }
+    double total;
+    int launches;
+    const int rc2 = ln_profile_end(&total, &launches);  // releases the events
+    return rc ? rc : rc2;
 }
 extern "C" const char* ln_version(void) { return "latticenet_hip 0.2 (gfx950)"; }
 #ifndef LN_ABI_HASH
@@ -1202,7 +1235,7 @@ static int ln_build_points(const LnTable* t, const float* positions_raw, const f
     // The bucketed path needs a table it knows to be empty: it is taken when the clear rides in this call, and then does
     // the clearing itself (no k_table_clear launch).  Its cursors use the first nbk+1 words of slot_cnt.
     // Beyond LN_BKT_MAX buckets the buckets grow instead; one bucket's staging area has to fit the 160 KB of LDS of a gfx950 CU
-    // (tables past ~14M slots take the atomic path).
+    // (tables past ~9.8M slots — 32 bytes of LDS per slot of a bucket, LN_BKT_LDS_LIMIT — take the atomic path).
     const size_t bucket_lds = (size_t)ln_bucket_slots(t->capacity) * LN_BKT_LDS_PER_SLOT + LN_BKT_LDS_EXTRA;
     const bool bucketed = n > 0 && (flags & LN_BUILD_CLEAR_FIRST) && !(flags & LN_BUILD_ATOMIC_PATH) &&
                           t->capacity > ln_bucket_count(t->capacity) && bucket_lds <= LN_BKT_LDS_LIMIT &&

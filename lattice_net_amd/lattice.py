@@ -211,6 +211,7 @@ class HashTable:
     def init(self, pos_dim: int, val_dim: int, device):  # HashTable.cu:21-47
         self._storage = _TableStorage(self.m_capacity, pos_dim, device)
         self.m_values_tensor = torch.zeros((self.m_capacity, val_dim), dtype=torch.float32, device=device)
+        self._zero_beyond = (self.m_values_tensor, 0)  # (tensor, row from which it is known to be zero): see Lattice._build
         self._counters = torch.zeros((2,), dtype=torch.int32, device=device)
         self.m_nr_filled_is_dirty = True
         self.clear(lazy=True)  # rides in the first build call; every other reader flushes it
@@ -520,9 +521,18 @@ class Lattice:
         self._choose_hash_capacity(tokens, fresh=do_clear)
         cap = st.hashed()
         csr_buf, csr, max_seg = self._alloc_csr(tokens, cap, st.planes)
-        # rows beyond the hashed range can never have been written (a build makes at most `tokens` <= hashed / 2 rows, and the
-        # range never shrinks): the value accumulator was allocated zeroed, only its first `cap` rows are cleared per build
-        clear_elems = 0 if clear_vals is None else min(int(clear_vals.shape[0]), cap) * int(clear_vals.shape[1])
+        # HashTable::clear fills the whole tensor (HashTable.cu:49-57).  Here only the rows that can be non-zero are cleared: a build
+        # writes rows < its hashed range, so when THIS tensor is known to be zero from some row on (`_zero_beyond`: it was allocated
+        # zeroed by this class, or an earlier build of this table cleared it) the clear stops at max(hashed range, that row) — which
+        # also covers a hashed range that shrank since.  A tensor of unknown content (installed through set_values) is cleared whole.
+        clear_elems = 0
+        if clear_vals is not None:
+            rows = int(clear_vals.shape[0])
+            known = getattr(ht, "_zero_beyond", None)
+            zb = known[1] if (known is not None and known[0] is clear_vals) else None
+            clear_rows = rows if zb is None else min(rows, max(cap, zb))
+            clear_elems = clear_rows * int(clear_vals.shape[1])
+            ht._zero_beyond = (clear_vals, min(rows, cap))  # after this build: every row the build cannot reach is zero
 
         def issue(force_atomic: bool):
             lib = _lib.load()
@@ -600,6 +610,22 @@ class Lattice:
         st = self.m_hash_table._storage
         if getattr(st, "replay", None) is not None:
             st.replay.append(fn)
+
+    def canonicalize_rows(self, idx: torch.Tensor):
+        """Relabels the rows of the table the last (bucketed, slot-order) build produced, `idx` and the build's cached CSR into the
+        reference's serial numbering (ln_canonicalize), and drops every cache that holds the old row ids (neighbour lists)."""
+        ht = self.m_hash_table
+        st = ht._storage
+        lib = _lib.load()
+        tokens = int(idx.numel())
+        hit = st.csr_cache.get((idx.data_ptr(), idx._version, idx.numel()))
+        ws = self._workspace(_build_sizes(tokens, st.hashed())[0])
+        t = ht.c_table()
+        _lib.check(lib.ln_canonicalize(C.byref(t), _lib.ptr(idx), tokens, C.byref(hit[1]) if hit is not None else None, _lib.ptr(ws), ws.numel(),
+                                       self._stream()), "ln_canonicalize")
+        keep = {k: v for k, v in st.csr_cache.items() if hit is not None and v is hit}
+        st.touch()  # neighbour lists and any other CSR of this table name the old rows
+        st.csr_cache.update(keep)
 
     # ---------------------------------------------------------------- atomics-free scatter (CSR)
     def _csr(self, idx: torch.Tensor):
@@ -696,8 +722,10 @@ class Lattice:
                 ht.m_values_tensor = torch.empty((cap, v), dtype=torch.float32, device=self._dev(positions_raw))
                 if reach < cap:
                     ht.m_values_tensor[reach:].zero_()
+                ht._zero_beyond = (ht.m_values_tensor, reach)
             else:
                 ht.m_values_tensor = torch.zeros((cap, v), dtype=torch.float32, device=self._dev(positions_raw))
+                ht._zero_beyond = (ht.m_values_tensor, 0)
             ht._clear_pending = pending
         idx, w = self._build(positions_raw, True)
         tv = ht.m_values_tensor
@@ -736,6 +764,7 @@ class Lattice:
             # deep copy + clear of three CAP-sized tensors (Lattice.cu:376-391) == fresh cleared buffers
             nh._storage = _TableStorage(oh.capacity(), d, dev)
             nh.m_values_tensor = torch.zeros((oh.capacity(), oh.val_dim() or v), dtype=torch.float32, device=dev)
+            nh._zero_beyond = (nh.m_values_tensor, 0)
             nh._counters = torch.zeros((2,), dtype=torch.int32, device=dev)
             nh.clear(lazy=True)  # issued inside the build call
         else:

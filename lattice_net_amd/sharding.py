@@ -21,14 +21,21 @@ def init(backend: str, device=None):
         return None
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    if "MASTER_PORT" not in os.environ:
-        # launchers (torch.distributed.run, the tests) set the port; a bare multi-process launch gets one derived from the common
-        # parent process, so that two jobs started side by side on one host do not meet on a fixed port
-        os.environ["MASTER_PORT"] = str(29500 + os.getppid() % 2000)
     kwargs = {}
+    if "MASTER_PORT" not in os.environ:
+        # Launchers (torch.distributed.run, the tests) set the port.  Without one every rank must still arrive at the SAME port
+        # whatever started it (one shell or ssh session per rank, container entrypoints): a fixed default, outside torchrun's own
+        # 29500.  Two jobs side by side on one host have to be given different MASTER_PORTs by whoever starts them.
+        os.environ["MASTER_PORT"] = "29511"
+    import datetime
+    kwargs["timeout"] = datetime.timedelta(seconds=int(os.environ.get("LATTICE_RENDEZVOUS_TIMEOUT_S", "600")))
     if backend == "nccl" and device is not None:
         kwargs["device_id"] = device
-    dist.init_process_group(backend, rank=rank, world_size=world, **kwargs)
+    try:
+        dist.init_process_group(backend, rank=rank, world_size=world, **kwargs)
+    except Exception as exc:
+        raise RuntimeError(f"rendezvous of rank {rank}/{world} at {os.environ['MASTER_ADDR']}:{os.environ['MASTER_PORT']} failed "
+                           f"({type(exc).__name__}: {exc}); every rank needs the same MASTER_ADDR / MASTER_PORT") from exc
     return dist
 
 

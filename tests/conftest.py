@@ -33,7 +33,9 @@ def golden():
 def canonical_row_order():
     """The parity tests compare row ids with the golden vectors / the oracle, whose numbering is the serial run of the
     reference (first occurrence in (point, remainder) order): builds run with the relabelling pass (ln_canonicalize) behind
-    them.  tests/test_gpu_slot_order.py covers the default slot-order numbering (equal up to a row permutation)."""
+    them.  tests/test_gpu_slot_order.py covers the shipped default (slot-order) numbering on the same operator surface — build,
+    splat, same-level and level-crossing neighbour lists, convolutions forward + backward, distribute, slice, gather,
+    slice_classify — with rows matched through their keys."""
     try:
         from lattice_net_amd import lattice as _lat
     except Exception:  # package not importable (library not built): the tests that need it fail on their own

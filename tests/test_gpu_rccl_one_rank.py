@@ -75,3 +75,35 @@ def test_data_parallel_training_step_over_rccl_on_one_rank(graph):
     a, b = last.split("loss ")[1].split(";")[0].split(" -> ")
     assert float(b) < float(a), last
     assert "spread over ranks 0.000e+00" in last
+
+
+def _bench_line(cmd, env):
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')][-1])
+
+
+def test_two_rank_bench_control_flow_with_real_kernels():
+    """The N = 2 path of bench.py with the HIP kernels (LATTICE_BENCH_SHARE_GPU=1: both ranks on GPU 0, collectives over gloo — the
+    pool's boxes have one GPU; never a measurement): launched the way the driver launches it, n_gpus == 2, and the job's checksum is
+    the sum of what rank 0 and rank 1 compute alone on their own clouds (independent clouds per rank, filter bank broadcast from rank 0)."""
+    args = ["--steps", "16", "--warmup", "2", "--extras", "0", "--cpu-seconds", "0", "--full-unet", "0", "--pool", "2", "--in-flight", "2"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", LATTICE_BENCH_SHARE_GPU="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LATTICE_FORCE_DIST"):
+        env.pop(k, None)
+    port = 29900 + os.getpid() % 90
+    two = _bench_line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                       "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + args, env)
+    assert two["n_gpus"] == 2 and two["steps"] == 16 and two["scaling"] == "weak" and two["value"] > 0
+    env1 = dict(env)
+    env1.pop("LATTICE_BENCH_SHARE_GPU")
+    alone = []
+    for r in (0, 1):
+        line = _bench_line([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + args, dict(env1, LATTICE_BENCH_RANK_OFFSET=str(r)))
+        assert line["n_gpus"] == 1
+        alone.append(line)
+    c0, c1 = alone[0]["config"]["checksum"], alone[1]["config"]["checksum"]
+    assert alone[0]["config"]["vertices_per_scan"] != alone[1]["config"]["vertices_per_scan"], "the two ranks must work on different clouds"
+    assert abs(c0 - c1) > 1e-6 * abs(c0)
+    assert abs(two["config"]["checksum"] - (c0 + c1)) <= 2e-6 * abs(c0 + c1), (two["config"]["checksum"], c0, c1)
+    assert two["config"]["vertices_per_scan"] == alone[0]["config"]["vertices_per_scan"]  # the line's scan table is rank 0's

@@ -117,6 +117,7 @@ def test_canonicalize_after_slot_order_build_is_bit_exact(case):
     ws = torch.empty((LT._build_sizes(tokens, cap)[0],), dtype=torch.uint8, device=dev())
     t = lat.m_hash_table.c_table()
     _lib.check(lib.ln_canonicalize(C.byref(t), _lib.ptr(idx), tokens, None, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev())), "ln_canonicalize")
+    lat.m_hash_table._storage.touch()  # csr = NULL: the build's cached CSR still names the old rows and must not be used again
     torch.cuda.synchronize()
     to = O.OracleHashTable(cap, 3)
     oidx, ow = O.build_splat(to, O.scale_positions(pos_np, np.full((3,), sigma, np.float32)))
@@ -244,3 +245,104 @@ def test_splat_values_full_size_c3():
     pos_np = synthetic.lidar_cloud(120000, 0)
     lat = _splat_values_case(pos_np, rng.standard_normal((120000, 32)).astype(np.float32), 0.9, 100000)
     assert lat.nr_lattice_vertices() == 46538
+
+
+def test_slot_order_two_levels_distribute_and_heads_match_oracle():
+    """The shipped default numbering on the rest of the operator surface (the golden / parity suite runs under the canonical
+    relabelling): distribute, the coarse vertex set, both level-crossing neighbour lists with and without flip, the coarsening
+    convolution forward + backward, gather and slice_classify — rows matched through the keys, everything that does not mention rows
+    bit for bit (distributed rows, weights, gathered rows, logits)."""
+    import lattice_net_amd as L
+    from lattice_net_amd import synthetic
+    from lattice_net_amd.lattice_funcs import CoarsenLattice, GatherLattice, SliceClassifyLattice
+    n, sigma, cap, v, f, c = 9000, 0.9, 30000, 32, 64, 7
+    pos_np = synthetic.lidar_cloud(n, 5)
+    rng = np.random.default_rng(6)
+    pos = T(pos_np)
+    lat = L.Lattice(sigmas=[sigma] * 3, capacity=cap, device=dev())
+    lat.begin_splat()
+    fine, rows, idx, w = lat.distribute(pos, T(np.zeros((n, 1), np.float32)))
+    m = fine.nr_lattice_vertices()
+    sig = np.full((3,), sigma, np.float32)
+    tf = O.OracleHashTable(cap, 3)
+    orow, oidx, ow = O.distribute(tf, O.scale_positions(pos_np, sig), np.zeros((n, 1), np.float32))
+    assert m == tf.nr_filled
+    pf = row_permutation(N(fine.m_hash_table.m_keys_tensor)[:m], tf.keys[:m])
+    assert np.array_equal(pf[N(idx).astype(np.int64)], oidx)
+    assert np.array_equal(N(w), ow) and np.array_equal(N(rows), orow)
+    coarse = fine.create_coarse_verts_naive(pos)
+    mc = coarse.nr_lattice_vertices()
+    tc = O.OracleHashTable(cap, 3)
+    O.build_splat(tc, O.scale_positions(pos_np, 2 * sig), write=False)
+    assert mc == tc.nr_filled
+    pc = row_permutation(N(coarse.m_hash_table.m_keys_tensor)[:mc], tc.keys[:mc])
+
+    def as_oracle(gn, perm_q, perm_nb):  # a gpu neighbour list in the oracle's numbering of both lattices
+        gn = gn.astype(np.int64)
+        return np.where(gn >= 0, perm_nb[np.maximum(gn, 0)], gn)[np.argsort(perm_q)]
+    nbr_cf = {}
+    for flip in (False, True):
+        nbr_cf[flip] = O.neighbour_rows(tc.keys[:mc], tf, 2, 1, 1, flip)
+        assert np.array_equal(as_oracle(N(coarse.neighbours(fine, 1, flip)), pc, pf), nbr_cf[flip])
+        assert np.array_equal(as_oracle(N(fine.neighbours(coarse, 1, flip)), pf, pc), O.neighbour_rows(tf.keys[:m], tc, 1, 2, 1, flip))
+
+    def close(a, b):
+        np.testing.assert_allclose(np.asarray(a, np.float64), np.asarray(b, np.float64), rtol=RTOL, atol=RTOL * float(np.max(np.abs(b))))
+    # coarsening convolution (coarse query x fine table), forward + both gradients in fp64 on the oracle's list
+    lv_o = rng.standard_normal((m, v)).astype(np.float32)          # in the ORACLE's row order
+    fb_np = (rng.standard_normal((9 * v, f)) / np.sqrt(9 * v)).astype(np.float32)
+    g_o = rng.standard_normal((mc, f)).astype(np.float32)
+    lv = T(lv_o[pf]).requires_grad_(True)                          # gpu row r holds oracle row pf[r]
+    fb = T(fb_np).requires_grad_(True)
+    y, _ = CoarsenLattice.apply(lv, fine, fb, coarse)
+    y.backward(T(g_o[pc]))
+    rowsf = O.im2row(nbr_cf[False], lv_o).astype(np.float64)
+    close(N(y)[np.argsort(pc)], rowsf @ fb_np.astype(np.float64))
+    close(N(fb.grad), rowsf.T @ g_o.astype(np.float64))
+    gv = np.zeros((m, v), np.float64)
+    wb = fb_np.reshape(9, v, f).astype(np.float64)
+    for e in range(9):
+        ok = nbr_cf[False][:, e] >= 0
+        np.add.at(gv, nbr_cf[False][ok, e], g_o[ok].astype(np.float64) @ wb[e].T)
+    close(N(lv.grad)[np.argsort(pf)], gv)
+    # gather and slice_classify on the fine lattice
+    v8 = rng.standard_normal((m, 8)).astype(np.float32)
+    ga = GatherLattice.apply(T(v8[pf]), fine, pos, idx, w)
+    assert np.array_equal(N(ga), O.gather_with_precomputation(v8, oidx, ow, n))
+    vals_o = rng.standard_normal((m, 64)).astype(np.float32)
+    dw_np = (0.1 * rng.standard_normal((n, 4))).astype(np.float32)
+    lw_np, lb_np = rng.standard_normal((c, 64)).astype(np.float32), rng.standard_normal((c,)).astype(np.float32)
+    gl_np = rng.standard_normal((n, c)).astype(np.float32)
+    vals, dw, lw, lb = (T(x).requires_grad_(True) for x in (vals_o[pf], dw_np, lw_np, lb_np))
+    logits = SliceClassifyLattice.apply(vals, fine, pos, dw, lw, lb, c, idx, w)
+    assert np.array_equal(N(logits), O.slice_classify(vals_o, dw_np, lw_np, lb_np, oidx, ow, n))
+    logits.backward(T(gl_np))
+    ogv, ogd, ogw, ogb = O.slice_classify_backwards(gl_np, vals_o, dw_np, lw_np, lb_np, oidx, ow, n)
+    close(N(vals.grad)[np.argsort(pf)], ogv)
+    close(N(dw.grad), ogd)
+    close(N(lw.grad), ogw)
+    close(N(lb.grad), ogb)
+
+
+def test_canonicalize_rows_keeps_the_cached_csr_consistent():
+    """Lattice.canonicalize_rows relabels the build's cached CSR together with the table: a scatter through it afterwards lands on
+    the new rows (splat values equal the oracle's in the oracle's own numbering)."""
+    import lattice_net_amd as L
+    from lattice_net_amd import synthetic
+    n, v, sigma, cap = 8000, 32, 0.9, 20000
+    pos_np = synthetic.lidar_cloud(n, 7)
+    vals_np = np.random.default_rng(7).standard_normal((n, v)).astype(np.float32)
+    lat = L.Lattice(sigmas=[sigma] * 3, capacity=cap, device=dev())
+    lat.begin_splat()
+    idx, w = lat.just_create_verts(T(pos_np), True)
+    m = lat.nr_lattice_vertices()
+    lat.canonicalize_rows(idx)
+    t = O.OracleHashTable(cap, 3)
+    oidx, ow = O.build_splat(t, O.scale_positions(pos_np, np.full((3,), sigma, np.float32)))
+    assert np.array_equal(N(idx), oidx) and np.array_equal(N(lat.m_hash_table.m_keys_tensor)[:m], t.keys[:m])
+    out = torch.zeros((m, v), device=dev())
+    lat._scatter_rows(T(vals_np), idx, w, out, v, 4, v)  # through the cached (relabelled) CSR
+    ov = np.zeros((m, v), np.float32)
+    O.splat_accumulate(ov, vals_np, oidx, ow)
+    np.testing.assert_allclose(N(out), ov, rtol=RTOL, atol=RTOL * float(np.abs(ov).max()))
+    assert np.array_equal(N(lat.neighbours(lat, 1, False)), O.neighbour_rows(t.keys[:m], t, 1, 1, 1, False))

@@ -133,3 +133,73 @@ def test_generalized_soft_dice_loss_matches_the_one_hot_formula():
     assert torch.isfinite(logp.grad).all() and float(logp.grad.abs().sum()) > 0
     perfect = torch.log(onehot.clamp(min=1e-12))
     assert float(GeneralizedSoftDiceLoss(ignore_index=0)(perfect, target)) < 1e-5
+
+
+DP_WORKER = textwrap.dedent("""
+    import os, sys, numpy as np, torch
+    from lattice_net_amd import sharding
+    from lattice_net_amd.losses import LovaszSoftmax, nll_loss_gather
+    from lattice_net_amd.synthetic import box_surface_cloud
+    from tests.test_oracle_network import make_oracle_case
+    out_dir = sys.argv[1]
+    dist = sharding.init("gloo")
+    world, rank, _ = sharding.env_world()
+    # every rank starts from different parameters; rank 0's are broadcast (ln_train.py builds one model per process)
+    net, lattice, _, _, _ = make_oracle_case(n=8, seed=10 + rank)
+    sharding.broadcast_parameters(dist, list(net.parameters()) + list(net.buffers()))
+    n, c = 500, 6
+    pos = torch.from_numpy(box_surface_cloud(n, 100 + rank))             # cloud `rank` of the batch
+    target = torch.from_numpy(np.random.default_rng(100 + rank).integers(0, c, n))
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-3, weight_decay=1e-4, amsgrad=True)   # ln_train.py:165
+    logp, _ = net(lattice, pos, torch.zeros((n, 1), dtype=torch.float64))
+    loss = 0.5 * LovaszSoftmax(ignore_index=0)(logp, target) + 0.5 * nll_loss_gather(logp, target, ignore_index=0)   # ln_train.py:156-158
+    opt.zero_grad()
+    loss.backward()
+    sharding.allreduce_gradients(dist, net.parameters())
+    opt.step()
+    torch.save({k: v.clone() for k, v in net.state_dict().items()}, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+""")
+
+
+def test_data_parallel_step_equals_single_process_step_on_both_clouds(tmp_path):
+    """SURVEY 8f-4 as a checked computation (ln_train.py:156-189 with the gradient exchange of sharding.allreduce_gradients): two gloo
+    ranks x one cloud each, one AdamW step, against ONE process that runs both clouds and steps on the mean of the two losses — the
+    whole LNN in float64 on the CPU oracle lattice; every parameter of both ranks equals the single-process result to 1e-9."""
+    from lattice_net_amd.losses import LovaszSoftmax
+    from lattice_net_amd.synthetic import box_surface_cloud
+    from tests.test_oracle_network import make_oracle_case
+    script = tmp_path / "dp_worker.py"
+    script.write_text(DP_WORKER)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port",
+           str(port), str(script), str(tmp_path)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout + r.stderr
+    # the single process: rank 0's initial parameters, both clouds, gradient of the mean loss
+    net, lattice, _, _, _ = make_oracle_case(n=8, seed=10)
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-3, weight_decay=1e-4, amsgrad=True)
+    opt.zero_grad()
+    n, c = 500, 6
+    for k in range(2):
+        pos = torch.from_numpy(box_surface_cloud(n, 100 + k))
+        target = torch.from_numpy(np.random.default_rng(100 + k).integers(0, c, n))
+        logp, _ = net(lattice, pos, torch.zeros((n, 1), dtype=torch.float64))
+        loss = 0.5 * LovaszSoftmax(ignore_index=0)(logp, target) + 0.5 * nll_loss_gather(logp, target, ignore_index=0)
+        (loss / 2).backward()  # gradients accumulate: d(mean of the two losses)
+    before = {k: v.clone() for k, v in net.state_dict().items()}
+    opt.step()
+    want = net.state_dict()
+    got = [torch.load(tmp_path / f"rank{k}.pt") for k in range(2)]
+    moved = 0
+    for k, w in want.items():
+        for g in got:
+            assert torch.allclose(g[k], w, rtol=1e-9, atol=1e-12), k
+        moved += int(not torch.equal(before[k], w))
+    assert moved >= 60, "the optimizer step must have changed (nearly) every tensor"
