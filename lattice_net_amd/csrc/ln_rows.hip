@@ -567,7 +567,7 @@ extern "C" int ln_slice_classify_forward(const float* values, const float* delta
     LN_REQUIRE(nr_classes >= 1 && (n == 0 || (delta_w && lin_w && lin_b && w)), LN_ERR_ARG, "ln_slice_classify_forward: bad args");
     if (n == 0) return LN_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (!(ln_debug_mask() & 64) && ln_sc_forward_wave(values, delta_w, lin_w, lin_b, idx, w, n, pos_dim, val_dim, nr_classes, logits, st))
+    if (!(ln_debug_mask() & 1048576) && ln_sc_forward_wave(values, delta_w, lin_w, lin_b, idx, w, n, pos_dim, val_dim, nr_classes, logits, st))
         return ln_check_launch("ln_slice_classify_forward");  // wave-tiled kernel (ln_classify.hip): V % 32 == 0, C <= 32, d in {2, 3}
     if (val_dim % 4 == 0 && (reinterpret_cast<uintptr_t>(values) & 15) == 0) {
         // float4 kernel: largest tile whose [C + PB, V+1] + 2 [PB, d+1] arrays fit 64 KiB and whose threads own <= 16 classes each
@@ -879,7 +879,7 @@ extern "C" int ln_slice_classify_backward(const float* grad_logits, const float*
     float* slabs = static_cast<float*>(workspace);
     const int cv = nr_classes * val_dim;
     int grid = 0;
-    const bool wave_kernel = !(ln_debug_mask() & 64) && ln_sc_backward_wave(grad_logits, values, delta_w, lin_w, idx, w, n, pos_dim, val_dim, nr_classes,
+    const bool wave_kernel = !(ln_debug_mask() & 1048576) && ln_sc_backward_wave(grad_logits, values, delta_w, lin_w, idx, w, n, pos_dim, val_dim, nr_classes,
                                                                           g_delta_w, grad_sliced, w_eff, slabs, &grid, st);
     if (!wave_kernel) {
     const int cp = (nr_classes + 3) & ~3;

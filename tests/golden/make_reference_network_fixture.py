@@ -39,7 +39,7 @@ REF = "/root/reference"
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-N_POINTS, NR_CLASSES, CLOUD_SEED, PARAM_SEED = 1500, 6, 0, 4242
+N_POINTS, NR_CLASSES, CLOUD_SEED, PARAM_SEED = 1500, 6, 0, 4244
 FULL_GRADIENT_MAX = 4096
 SAMPLE = 1024
 
@@ -226,19 +226,27 @@ def main():
     sd = net.state_dict()
     keys = list(sd.keys())
     shapes = [tuple(sd[k].shape) for k in keys]
+    # The network has kinks (ReLU / LeakyReLU, the PointNet maximum, which also hands on the winner's barycentric weight): with ~10^6
+    # such decisions a float32 evaluation occasionally lands on the other side of one and gets a different, equally valid gradient
+    # (measured on the GPU with seed 4242: ONE flipped ReLU of a 32-channel GroupNorm moved every upstream gradient by ~1e-3 while
+    # the logits still agreed to 1e-5).  PARAM_SEED is therefore the first seed of 4242, 4243, ... for which BOTH float32 evaluations
+    # available — this package's network on the CPU oracle lattice in float32, and the GPU run (tools/probes/f10_probe.py) — show no
+    # such flip, i.e. every gradient within 3e-5 of the float64 run: the 1e-4 comparison of tests/test_gpu_lnn_oracle.py is then
+    # well-posed.  (--seed S --out PATH writes a candidate fixture for that search.)
+    chosen = PARAM_SEED if ARGS.seed is None else ARGS.seed
     with torch.no_grad():
         for i, k in enumerate(keys):
-            sd[k].copy_(torch.from_numpy(seeded_parameter(i, k, shapes[i])).reshape(shapes[i]))
+            sd[k].copy_(torch.from_numpy(seeded_parameter(i, k, shapes[i], chosen)).reshape(shapes[i]))
     net.train()
+    named = dict(net.named_parameters())
     logsoftmax, logits = net(lattice, pos, vals)
     loss = torch.nn.functional.nll_loss(logsoftmax, target)
     loss.backward()
-    named = dict(net.named_parameters())
     out = {
         "keys": np.array(keys), "keys_at_construction": np.array(keys_at_construction),
         "shapes": np.array([",".join(map(str, s)) for s in shapes]),
         "is_parameter": np.array([k in named for k in keys]),
-        "param_seed": np.int64(PARAM_SEED), "n_points": np.int64(N_POINTS), "nr_classes": np.int64(NR_CLASSES), "cloud_seed": np.int64(CLOUD_SEED),
+        "param_seed": np.int64(chosen), "n_points": np.int64(N_POINTS), "nr_classes": np.int64(NR_CLASSES), "cloud_seed": np.int64(CLOUD_SEED),
         "logits": logits.detach().numpy(), "loss": np.float64(loss.item()),
         "nr_vertices_per_level": np.array([0]),
     }
@@ -256,7 +264,7 @@ def main():
         else:
             out[f"grad_sample/{i}"] = g[gradient_sample_index(g.size)].astype(np.float64)
     out["grad_norms"] = np.array(norms)
-    path = os.path.join(HERE, "F10_reference_lnn.npz")
+    path = ARGS.out or os.path.join(HERE, "F10_reference_lnn.npz")
     np.savez_compressed(path, **out)
     print(f"{path}: {len(keys)} tensors ({len(keys_at_construction)} exist before the first forward), loss {loss.item():.6f}, "
           f"{os.path.getsize(path) / 1024:.0f} KiB")
@@ -265,4 +273,9 @@ def main():
 
 
 if __name__ == "__main__":
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seed", type=int, default=None)
+    ap.add_argument("--out", default=None)
+    ARGS = ap.parse_args()
     main()
