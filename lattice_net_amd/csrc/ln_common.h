@@ -306,6 +306,23 @@ __device__ __forceinline__ int ln_retrieve(const LnTable& t, const int* key) {
 #endif
 
 #if defined(__HIPCC__)
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every global load / store / atomic the wave has
+// in flight (s_waitcnt vmcnt(0)), which a kernel that keeps global round trips in flight ACROSS its barriers must not do.
+__device__ __forceinline__ void ln_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Inclusive prefix sum over the 64 lanes of a wave on the DPP network (no LDS round trips: __shfl_up is a ds_bpermute per step):
+// Hillis-Steele inside every row of 16 lanes (row_shr 1, 2, 4, 8; lanes without a source add 0), then the row totals are handed
+// on (row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3).
+__device__ __forceinline__ int ln_wave_incl_scan(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);
+    return v;
+}
+
 // Exclusive prefix sum of one int per thread over a 256-thread workgroup (4 waves): shuffle scan inside
 // each wave, wave totals through 4 LDS words.  `s_tmp` needs 5 ints; *total receives the block sum.
 __device__ __forceinline__ int ln_block_excl_scan_256(int v, int* s_tmp, int* total) {
@@ -325,6 +342,25 @@ __device__ __forceinline__ int ln_block_excl_scan_256(int v, int* s_tmp, int* to
         if (k < wave) wave_off += s_tmp[k];
     *total = s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3];
     __syncthreads();
+    return wave_off + incl - v;
+}
+// The same over WAVES waves (s_tmp: WAVES ints), with LDS-only barriers: global operations of the caller stay in flight across it.
+template <int WAVES>
+__device__ __forceinline__ int ln_block_excl_scan(int v, int* s_tmp, int* total) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int incl = ln_wave_incl_scan(v);
+    if (lane == 63) s_tmp[wave] = incl;
+    ln_lds_barrier();
+    int wave_off = 0, sum = 0;
+#pragma unroll
+    for (int k = 0; k < WAVES; ++k) {
+        const int w = s_tmp[k];
+        sum += w;
+        if (k < wave) wave_off += w;
+    }
+    *total = sum;
+    ln_lds_barrier();
     return wave_off + incl - v;
 }
 #endif

@@ -371,33 +371,42 @@ __global__ void __launch_bounds__(256)
 #endif
 #define LN_KEYS_PTS_PER_THREAD ((D) <= 3 ? LN_KEYS_PTS_SMALL_D : 1)
 #define LN_KEYS_PTS_PER_BLOCK (256 * LN_KEYS_PTS_PER_THREAD)
-template <int D>
-__global__ void __launch_bounds__(256)
+// TH = 256: a thread owns LN_KEYS_PTS_PER_THREAD whole points (all d+1 tokens each).
+// TH = 1024 (d <= 3): the SAME 512-point tile — i.e. the same number of (block, bucket) cursor atomics — on four times the waves: two
+// threads per point, each owning half of its d+1 tokens (both evaluate the point's simplex: a few hundred ALU operations against a
+// chain of returning LDS atomics and global round trips that four waves per SIMD overlap where one could not).
+template <int D, int TH>
+__global__ void __launch_bounds__(TH)
     k_point_keys(LnTable t, const float* __restrict__ pos_raw, LnScale<D> sc, int n, int sb, int nbk, int capb,
                  int* __restrict__ part_tok, unsigned long long* __restrict__ part_pk, int* __restrict__ tok_slot,
                  float* __restrict__ w, const float* __restrict__ vals, int val_dim, float* __restrict__ distributed,
                  int* __restrict__ seg_count, int seg_regions, float* __restrict__ clear_values, long long clear_values_elems,
                  unsigned int* __restrict__ pub) {
+    constexpr bool SPLIT = TH == 1024;                        // two threads per point
+    constexpr int PTS = TH == 256 ? LN_KEYS_PTS_PER_THREAD : 1;   // points a thread touches (TH = 512: one whole point per thread)
+    constexpr int RH = SPLIT ? (D + 2) / 2 : D + 1;           // tokens of a point a thread owns
+    constexpr int PTS_PER_BLOCK = SPLIT ? 512 : TH * PTS;
     __shared__ int s_cnt[LN_BKT_MAX];
     __shared__ int s_lbase[LN_BKT_MAX];
-    __shared__ int s_scan_tmp[8];
-    __shared__ unsigned long long s_stage_pk[LN_KEYS_PTS_PER_BLOCK * (D + 1)];
-    __shared__ int s_stage_tok[LN_KEYS_PTS_PER_BLOCK * (D + 1)];
-    __shared__ int s_stage_dst[LN_KEYS_PTS_PER_BLOCK * (D + 1)];
+    __shared__ int s_scan_tmp[TH / 64];
+    __shared__ unsigned long long s_stage_pk[PTS_PER_BLOCK * (D + 1)];
+    __shared__ int s_stage_tok[PTS_PER_BLOCK * (D + 1)];
+    __shared__ int s_stage_dst[PTS_PER_BLOCK * (D + 1)];
     int* cursor = t.slot_cnt;
     LN_STAMP(0);
-    for (int b = threadIdx.x; b < nbk; b += 256) s_cnt[b] = 0;
-    __syncthreads();
+    for (int b = threadIdx.x; b < nbk; b += TH) s_cnt[b] = 0;
+    ln_lds_barrier();
     LN_STAMP(1);
-    unsigned long long pk[LN_KEYS_PTS_PER_THREAD][D + 1];
-    int bkt[LN_KEYS_PTS_PER_THREAD][D + 1];
-    int rank[LN_KEYS_PTS_PER_THREAD][D + 1];
+    unsigned long long pk[PTS][RH];
+    int bkt[PTS][RH];
+    int rank[PTS][RH];
     bool bad_key = false;
+    const int r_first = SPLIT ? (threadIdx.x & 1) * RH : 0;
 #pragma unroll
-    for (int it = 0; it < LN_KEYS_PTS_PER_THREAD; ++it) {
-        const int p = blockIdx.x * LN_KEYS_PTS_PER_BLOCK + it * 256 + threadIdx.x;
+    for (int it = 0; it < PTS; ++it) {
+        const int p = SPLIT ? blockIdx.x * PTS_PER_BLOCK + (threadIdx.x >> 1) : blockIdx.x * PTS_PER_BLOCK + it * TH + threadIdx.x;
 #pragma unroll
-        for (int r = 0; r <= D; ++r) bkt[it][r] = -1;
+        for (int k = 0; k < RH; ++k) bkt[it][k] = -1;
         if (p >= n) continue;
         float pr[D];
 #pragma unroll
@@ -405,44 +414,49 @@ __global__ void __launch_bounds__(256)
         LnSimplex<D> s;
         ln_simplex<D>(pr, sc, s);
 #pragma unroll
-        for (int r = 0; r <= D; ++r) {
+        for (int k = 0; k < RH; ++k) {
+            const int r = r_first + k;
+            if (SPLIT && r > D) continue;  // (odd d + 1: the second thread of a point owns one token less)
             int key[D];
             ln_vertex_key<D>(s, r, key);
+            float bary = s.bary[0];
+#pragma unroll
+            for (int q = 1; q <= D; ++q) bary = (r == q) ? s.bary[q] : bary;
             const size_t tk = (size_t)p * (D + 1) + r;
             const bool lat_fmt = t.key_format == LN_KEYS_LATTICE;  // (vertex r of a simplex has remainder r: no modulo needed)
             const bool ok = lat_fmt ? KeyPack<D>::lattice_in_range(key, r) : KeyPack<D>::in_range(key, t.key_format);
             if (ok) {
-                pk[it][r] = lat_fmt ? KeyPack<D>::lattice_pack(key, r) : KeyPack<D>::pack(key, t.key_format);
-                bkt[it][r] = LnProbe::of_key<D>(key, t.capacity, sb).lo / sb;
-                rank[it][r] = atomicAdd(&s_cnt[bkt[it][r]], 1);
+                pk[it][k] = lat_fmt ? KeyPack<D>::lattice_pack(key, r) : KeyPack<D>::pack(key, t.key_format);
+                bkt[it][k] = LnProbe::of_key<D>(key, t.capacity, sb).lo / sb;
+                rank[it][k] = atomicAdd(&s_cnt[bkt[it][k]], 1);
             } else {
                 bad_key = true;
                 if (tok_slot) tok_slot[tk] = -1;
             }
-            if (w) w[tk] = ok ? s.bary[r] : -1.0f;
+            if (w) w[tk] = ok ? bary : -1.0f;
             if (distributed) {  // LatticeGPU.cuh:626-637: [pos_scaled(d) | val(V) | bary[r]] per simplex vertex
                 const int row_len = D + val_dim + 1;
                 float* o = distributed + tk * row_len;
 #pragma unroll
                 for (int i = 0; i < D; ++i) o[i] = pr[i] / sc.sigma[i];
                 for (int j = 0; j < val_dim; ++j) o[D + j] = vals[(size_t)p * val_dim + j];
-                o[D + val_dim] = s.bary[r];
+                o[D + val_dim] = bary;
             }
         }
     }
     if (bad_key) atomicOr(&t.slot_cnt[nbk], 1);
     LN_STAMP(2);
-    __syncthreads();
+    ln_lds_barrier();
     LN_STAMP(3);
     // Region cursors (one returning global atomic per (block, bucket), all of a thread row in flight together) and, for the
-    // staged write below, the exclusive prefix of this block's per-bucket counts (one 256-wide scan per row of buckets).
+    // staged write below, the exclusive prefix of this block's per-bucket counts (one TH-wide scan per row of buckets).
     int block_tokens = 0;
-    for (int k0 = 0; k0 < nbk; k0 += 256) {  // block-uniform trip count
+    for (int k0 = 0; k0 < nbk; k0 += TH) {  // block-uniform trip count
         const int b = k0 + threadIdx.x;
         const int c = b < nbk ? s_cnt[b] : 0;
         const int at = c ? atomicAdd(&cursor[b], c) : 0;  // in flight across the scan below
         int row_total;
-        const int ex = ln_block_excl_scan_256(c, s_scan_tmp, &row_total);  // (has its own barriers)
+        const int ex = ln_block_excl_scan<TH / 64>(c, s_scan_tmp, &row_total);  // (has its own barriers)
         if (b < nbk) {
             s_lbase[b] = block_tokens + ex;
             if (c) s_cnt[b] = at;
@@ -450,28 +464,28 @@ __global__ void __launch_bounds__(256)
         block_tokens += row_total;
     }
     LN_STAMP(4);
-    __syncthreads();
+    ln_lds_barrier();
     LN_STAMP(5);
     // Stage the block's tokens in LDS sorted by bucket, then write them out in that order: the lanes of a wave then cover a
     // few runs of consecutive region entries instead of 64 different cache lines per store instruction (the scattered form
     // of these two stores was a third of this kernel's time).
 #pragma unroll
-    for (int it = 0; it < LN_KEYS_PTS_PER_THREAD; ++it) {
-        const int p = blockIdx.x * LN_KEYS_PTS_PER_BLOCK + it * 256 + threadIdx.x;
+    for (int it = 0; it < PTS; ++it) {
+        const int p = SPLIT ? blockIdx.x * PTS_PER_BLOCK + (threadIdx.x >> 1) : blockIdx.x * PTS_PER_BLOCK + it * TH + threadIdx.x;
 #pragma unroll
-        for (int r = 0; r <= D; ++r) {
-            if (bkt[it][r] < 0) continue;
-            const int tk = p * (D + 1) + r;
-            const int at = s_cnt[bkt[it][r]] + rank[it][r];
-            const int j = s_lbase[bkt[it][r]] + rank[it][r];
+        for (int k = 0; k < RH; ++k) {
+            if (bkt[it][k] < 0) continue;
+            const int tk = p * (D + 1) + r_first + k;
+            const int at = s_cnt[bkt[it][k]] + rank[it][k];
+            const int j = s_lbase[bkt[it][k]] + rank[it][k];
             s_stage_tok[j] = tk;
-            s_stage_pk[j] = pk[it][r];
-            s_stage_dst[j] = at < capb ? bkt[it][r] * capb + at : -1;  // (regions are < 2^31 entries in total: checked by the host)
+            s_stage_pk[j] = pk[it][k];
+            s_stage_dst[j] = at < capb ? bkt[it][k] * capb + at : -1;  // (regions are < 2^31 entries in total: checked by the host)
         }
     }
-    __syncthreads();
+    ln_lds_barrier();
     LN_STAMP(6);
-    for (int j = threadIdx.x; j < block_tokens; j += 256) {
+    for (int j = threadIdx.x; j < block_tokens; j += TH) {
         const int dst = s_stage_dst[j];
         const int tk = s_stage_tok[j];
         if (dst >= 0) {
@@ -483,8 +497,8 @@ __global__ void __launch_bounds__(256)
     }
     {  // Clear duties, LAST: nothing in this kernel reads what they write, and a workgroup barrier waits for the stores issued
        // before it (1.6 us at C3 when they came first); here only the end of the kernel does.
-        const long long stride = (long long)gridDim.x * 256;
-        const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+        const long long stride = (long long)gridDim.x * TH;
+        const long long g = (long long)blockIdx.x * TH + threadIdx.x;
         if (clear_values) {
             const long long n4 = clear_values_elems >> 2;
             float4* v4 = reinterpret_cast<float4*>(clear_values);
@@ -505,7 +519,10 @@ __global__ void __launch_bounds__(256)
     LN_STAMP(7);
 }
 
-// Pass 2: one workgroup per bucket.  LDS: keys[sb] | count[sb] | min token[sb] | token offset[sb] | segment offset[sb] | row[sb].
+// Pass 2: one workgroup per bucket.  LDS: keys[sb] | count[sb] | min token[sb] | token offset[sb] | segment offset[sb] | row[sb] | rank[sb] | compacted minima.
+// Its barriers order LDS traffic only (ln_lds_barrier) wherever nothing else is needed: __syncthreads() also waits for every global
+// operation a wave has in flight — the agent-scope store that publishes the bucket's count (~1.5 us to the memory side) held the
+// whole workgroup at the next barrier, the slot stores of the emit phase at the last one.
 // This is the LAST kernel of a bucketed build.  Rows are numbered in SLOT order: row of a new vertex = (new vertices of all
 // buckets before this one) + (occupied slots before it inside the bucket).  The only cross-workgroup quantity is that per-
 // bucket count, handed on through `pub` (one word per bucket: ready bit | error bit | count) with relaxed agent-scope
@@ -520,7 +537,7 @@ __global__ void __launch_bounds__(256)
 #endif
 #define LN_BKT_WAVES (LN_BKT_THREADS / 64)
 #define LN_BKT_LDS_LIMIT (150 * 1024)  // dynamic LDS one k_bucket_rows workgroup may ask for (160 KB per CU minus its static arrays)
-#define LN_BKT_LDS_PER_SLOT (sizeof(unsigned long long) + 6 * sizeof(int))
+#define LN_BKT_LDS_PER_SLOT (sizeof(unsigned long long) + 7 * sizeof(int))
 #define LN_BKT_LDS_EXTRA 32  // alignment of the compacted token list + its padding to a multiple of four entries
 #define LN_BKT_REG_TOK 4  // tokens per thread whose (token, slot, position) stay in registers between the two sweeps
 #define LN_PUB_READY 0x80000000u
@@ -531,7 +548,7 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
     k_bucket_rows(LnTable t, int sb, int nbk, int capb, int* __restrict__ cursor, const int* __restrict__ part_tok,
                   const unsigned long long* __restrict__ part_pk, int* __restrict__ part_slot, int* __restrict__ part_pos,
                   int* __restrict__ idx_out, LnCsr csr, unsigned int* __restrict__ pub) {
-    extern __shared__ unsigned long long s_mem[];
+    extern __shared__ __attribute__((aligned(16))) unsigned long long s_mem[];
     unsigned long long* skeys = s_mem;
     int* scnt = reinterpret_cast<int*>(skeys + sb);
     unsigned int* smin = reinterpret_cast<unsigned int*>(scnt + sb);
@@ -539,7 +556,11 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
     int* sseg = soff + sb;
     int* srow = sseg + sb;
     // smallest tokens of the occupied slots, compacted (16-byte aligned: read as uint4; LN_BKT_LDS_EXTRA covers the alignment and the padding)
-    unsigned int* slist = reinterpret_cast<unsigned int*>((reinterpret_cast<uintptr_t>(srow + sb) + 15) & ~uintptr_t(15));
+    int* srank = srow + sb;  // in-bucket rank of the compacted vertices (partial counts added up)
+    // (an OFFSET from the 16-byte aligned base, not an address rounded up through an integer cast: the compiler then keeps the LDS
+    // address space — the cast turned every access into a FLAT instruction, whose s_waitcnt vmcnt(0) waited ~1.5 us for the
+    // agent-scope store that publishes the bucket's count)
+    unsigned int* slist = reinterpret_cast<unsigned int*>(s_mem) + ((8 * sb + 3) & ~3);  // 2 sb words of keys + six int arrays
     __shared__ int s_wave_tok[16], s_wave_seg[16], s_wave_new[16];
     __shared__ int s_run_tok, s_run_seg, s_run_new, s_err;
     __shared__ int s_rcnt[LN_XCD_GROUPS], s_rbase[LN_XCD_GROUPS];
@@ -558,27 +579,18 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
         scnt[i] = 0;
         smin[i] = LN_EMPTY_TOK;
     }
-    __syncthreads();
+    ln_lds_barrier();
     const int b = s_ticket;
     const int lo = b * sb;
     const int size = min(sb, t.capacity - lo);
-    // CSR offset of this bucket = tokens of all buckets before it
+    // CSR offset of this bucket = tokens of all buckets before it.  The cursors of the earlier buckets and the bucket's own are
+    // fetched together (one round trip), the register-resident tokens behind them (fetching those unconditionally, 4 x 1024 entries
+    // whatever the cursor says, saved the dependency and cost more in reads: 20.2 -> 21.3 us).
+    const size_t in0 = (size_t)b * capb;
     int before = 0;
     for (int i = tid; i < b; i += LN_BKT_THREADS) before += min(cursor[i], capb);
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) before += __shfl_xor(before, off, 64);
-    if (lane == 0) s_wave_tok[wave] = before;
     const int my_cursor = cursor[b];
     const int ntok = min(my_cursor, capb);
-    if (tid == 0) {
-        s_run_tok = 0;
-        s_run_seg = 0;
-        s_run_new = 0;
-        s_err = my_cursor > capb ? 1 : 0;  // region overflow: tokens were dropped by pass 1
-    }
-    if (tid < LN_XCD_GROUPS) s_rcnt[tid] = 0;
-    const size_t in0 = (size_t)b * capb;
-    // issue the loads of the register-resident tokens before the barrier
     int r_tk[LN_BKT_REG_TOK], r_ls[LN_BKT_REG_TOK], r_pos[LN_BKT_REG_TOK];
     unsigned long long r_pk[LN_BKT_REG_TOK];
 #pragma unroll
@@ -589,11 +601,21 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
         r_tk[k] = j < ntok ? part_tok[in0 + j] : -1;
         r_pk[k] = j < ntok ? part_pk[in0 + j] : LN_EMPTY_KEY;
     }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) before += __shfl_xor(before, off, 64);
+    if (lane == 0) s_wave_tok[wave] = before;
+    if (tid == 0) {
+        s_run_tok = 0;
+        s_run_seg = 0;
+        s_run_new = 0;
+        s_err = my_cursor > capb ? 1 : 0;  // region overflow: tokens were dropped by pass 1
+    }
+    if (tid < LN_XCD_GROUPS) s_rcnt[tid] = 0;
     __syncthreads();  // (every cursor[] load of this workgroup has returned by now: the last bucket relies on it)
     int base = 0;
 #pragma unroll
     for (int k = 0; k < LN_BKT_WAVES; ++k) base += s_wave_tok[k];
-    __syncthreads();  // s_wave_tok is reused by the scans below
+    ln_lds_barrier();  // s_wave_tok is reused by the scans below
     LN_STAMP(9);
 
     // Called by every lane of the wave (invalid lanes carry no token): the wave-level grouping below uses shuffles.
@@ -644,7 +666,8 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
         }
     };
 #pragma unroll
-    for (int k = 0; k < LN_BKT_REG_TOK; ++k) place(r_tk[k] >= 0, r_tk[k], r_pk[k], r_ls[k], r_pos[k]);
+    for (int k = 0; k < LN_BKT_REG_TOK; ++k)
+        if (__ballot(r_tk[k] >= 0)) place(r_tk[k] >= 0, r_tk[k], r_pk[k], r_ls[k], r_pos[k]);  // (wave-uniform: the votes inside need whole waves)
     for (int j0 = LN_BKT_REG_TOK * LN_BKT_THREADS; j0 < ntok; j0 += LN_BKT_THREADS) {
         const int j = j0 + tid;
         const bool valid = j < ntok;
@@ -655,7 +678,7 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
             part_pos[in0 + j] = pos;
         }
     }
-    __syncthreads();
+    ln_lds_barrier();
     LN_STAMP(10);
     // exclusive scans of the per-slot token counts, segment counts and occupancy (-> row of the slot inside the bucket)
     for (int start = 0; start < size; start += LN_BKT_THREADS) {
@@ -663,16 +686,7 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
         const int c = (i < size) ? scnt[i] : 0;
         const int g = (c + LN_CSR_SEG - 1) / LN_CSR_SEG;
         const int nw = c ? 1 : 0;
-        int ic = c, ig = g;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int oc = __shfl_up(ic, off, 64);
-            const int og = __shfl_up(ig, off, 64);
-            if (lane >= off) {
-                ic += oc;
-                ig += og;
-            }
-        }
+        const int ic = ln_wave_incl_scan(c), ig = ln_wave_incl_scan(g);
         const unsigned long long occ = __ballot(nw);
         const int in_wave_new = __popcll(occ & ((1ull << lane) - 1ull));
         if (lane == 63) {
@@ -680,7 +694,7 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
             s_wave_seg[wave] = ig;
             s_wave_new[wave] = __popcll(occ);
         }
-        __syncthreads();
+        ln_lds_barrier();
         int wt = 0, wg = 0, wn = 0;
 #pragma unroll
         for (int k = 0; k < LN_BKT_WAVES; ++k) {  // all LDS reads issue together (a loop to `wave` waits for each in turn)
@@ -691,20 +705,24 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
                 wn += n2;
             }
         }
-        const int rt = s_run_tok, rg = s_run_seg, rn = s_run_new;
+        // (a bucket of at most one trip starts from zero without reading the running totals: no barrier needed before the last
+        // thread overwrites them)
+        const bool multi = size > LN_BKT_THREADS;
+        const int rt = multi ? s_run_tok : 0, rg = multi ? s_run_seg : 0, rn = multi ? s_run_new : 0;
         if (i < size) {
             soff[i] = rt + wt + ic - c;
             sseg[i] = rg + wg + ig - g;
             srow[i] = rn + wn + in_wave_new;
         }
-        __syncthreads();
+        if (multi) ln_lds_barrier();  // (every thread has read the running totals of this trip)
         if (tid == LN_BKT_THREADS - 1) {
             s_run_tok = rt + wt + ic;
             s_run_seg = rg + wg + ig;
             s_run_new = rn + wn + __popcll(occ);
         }
-        __syncthreads();
+        ln_lds_barrier();
     }
+    LN_STAMP(16);
     // hand the count on as early as it is known
     if (tid == 0)
         __hip_atomic_store(&pub[b], LN_PUB_READY | (s_err ? LN_PUB_ERR : 0u) | (unsigned int)s_run_new, __ATOMIC_RELAXED,
@@ -717,25 +735,38 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
         for (int i = tid; i < size; i += LN_BKT_THREADS)
             if (scnt[i]) slist[srow[i]] = smin[i];
         for (int j = nv + tid; j < ((nv + 3) & ~3); j += LN_BKT_THREADS) slist[j] = 0xFFFFFFFFu;  // pad to a multiple of 4
-        __syncthreads();
+        for (int j = tid; j < nv; j += LN_BKT_THREADS) srank[j] = 0;
+        ln_lds_barrier();
+        LN_STAMP(17);
         const uint4* l4 = reinterpret_cast<const uint4*>(slist);
         const int nv4 = (nv + 3) / 4;
-        // two lanes per slot, each counting over one half of the list (all lanes of a wave read the same words: LDS broadcast)
-        for (int i0 = 0; i0 < size; i0 += LN_BKT_THREADS / 2) {  // workgroup-uniform trip count (shuffle inside)
-            const int i = i0 + (tid >> 1);
-            const int h = tid & 1;
-            const bool ok = i < size && scnt[i] != 0;
-            const unsigned int mine = ok ? smin[i] : 0u;
-            const int j0 = h ? nv4 / 2 : 0, j1 = h ? nv4 : nv4 / 2;
-            int r = 0;
-            if (ok)
-                for (int j = j0; j < j1; ++j) {
-                    const uint4 t4 = l4[j];
-                    r += (t4.x < mine) + (t4.y < mine) + (t4.z < mine) + (t4.w < mine);
+        // Rank of every vertex's smallest token among the bucket's nv minima (all pairs, ~180 x 180 at C3).  The threads form a
+        // (vertex, chunk) grid over the COMPACTED list: chunks = threads / nv, every thread counts over its share of the list with
+        // four loads in flight (the lanes of a wave read the same words: LDS broadcast) and adds its partial count to its vertex
+        // with one LDS add.  (Two lanes per SLOT, occupied or not, each walking half the list one load at a time: 2.3 us of the pass.)
+        const int chunks = max(1, min(LN_BKT_THREADS / max(nv, 1), nv4));
+        const int vpp = LN_BKT_THREADS / chunks;      // vertices per trip
+        const int per = (nv4 + chunks - 1) / chunks;  // 16-byte words per chunk
+        for (int v0 = 0; v0 < nv; v0 += vpp) {        // one trip unless the bucket holds more vertices than the workgroup has threads
+            const int v = v0 + tid % vpp, ch = tid / vpp;
+            if (v < nv && ch < chunks) {
+                const unsigned int mine = slist[v];
+                const int j0 = ch * per, j1 = min(nv4, j0 + per);
+                int r = 0;
+                for (int j = j0; j < j1; j += 4) {
+                    uint4 t4[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) t4[k] = l4[min(j + k, nv4 - 1)];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (j + k < j1) r += (t4[k].x < mine) + (t4[k].y < mine) + (t4[k].z < mine) + (t4[k].w < mine);
                 }
-            r += __shfl_xor(r, 1, 64);
-            if (ok && h == 0) srow[i] = r;
+                if (r) atomicAdd(&srank[v], r);
+            }
         }
+        ln_lds_barrier();
+        for (int i = tid; i < size; i += LN_BKT_THREADS)
+            if (scnt[i]) srow[i] = srank[srow[i]];  // (srow[i] held the slot's position in the compacted list)
     }
     LN_STAMP(11);
     // Segment ids.  Without region planes: one contiguous run of region 0 per bucket.  With planes: every slot files its
@@ -752,7 +783,7 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
                 sseg[i] = (r << 28) | atomicAdd(&s_rcnt[r], (c + LN_CSR_SEG - 1) / LN_CSR_SEG);
             }
         }
-        __syncthreads();
+        ln_lds_barrier();
     }
     // first segment id of this bucket (per region): one returning global atomic, left in flight across the look-back below
     int seg_base_reg = 0;
@@ -784,7 +815,7 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
         s_wave_tok[wave] = rows_before;
         s_wave_seg[wave] = int(err_before);
     }
-    __syncthreads();
+    ln_lds_barrier();
     int base_row = 0;
     unsigned int err_all = s_err ? LN_PUB_ERR : 0u;
 #pragma unroll
@@ -833,7 +864,7 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
         __syncthreads();  // (tid 0 has read cursor[nbk])
         for (int i = tid; i <= nbk; i += LN_BKT_THREADS) cursor[i] = 0;  // all-zero between builds; every reader has published
     }
-    __syncthreads();  // srow[] now holds the final row of every slot
+    ln_lds_barrier();  // srow[] now holds the final row of every slot
     LN_STAMP(13);
 #pragma unroll
     for (int k = 0; k < LN_BKT_REG_TOK; ++k) {
@@ -1235,7 +1266,7 @@ static int ln_build_points(const LnTable* t, const float* positions_raw, const f
     // The bucketed path needs a table it knows to be empty: it is taken when the clear rides in this call, and then does
     // the clearing itself (no k_table_clear launch).  Its cursors use the first nbk+1 words of slot_cnt.
     // Beyond LN_BKT_MAX buckets the buckets grow instead; one bucket's staging area has to fit the 160 KB of LDS of a gfx950 CU
-    // (tables past ~9.8M slots — 32 bytes of LDS per slot of a bucket, LN_BKT_LDS_LIMIT — take the atomic path).
+    // (tables past ~8.7M slots — 36 bytes of LDS per slot of a bucket, LN_BKT_LDS_LIMIT — take the atomic path).
     const size_t bucket_lds = (size_t)ln_bucket_slots(t->capacity) * LN_BKT_LDS_PER_SLOT + LN_BKT_LDS_EXTRA;
     const bool bucketed = n > 0 && (flags & LN_BUILD_CLEAR_FIRST) && !(flags & LN_BUILD_ATOMIC_PATH) &&
                           t->capacity > ln_bucket_count(t->capacity) && bucket_lds <= LN_BKT_LDS_LIMIT &&
@@ -1255,9 +1286,20 @@ static int ln_build_points(const LnTable* t, const float* positions_raw, const f
             const int nbk = ln_bucket_count(t->capacity);
             const size_t lds = bucket_lds;
             int* dropped_idx = write_idx ? idx : (int*)nullptr;  // tokens that never reach a bucket get idx = -1 in pass 1
-            LN_LAUNCH("k_point_keys", k_point_keys<D>, dim3(ln_div_up(n, LN_KEYS_PTS_PER_BLOCK)), dim3(256), 0, st, *t, positions_raw, sc, n, sb,
-                      nbk, ws.capb, ws.part_tok, ws.part_pk, dropped_idx, write_idx ? w : (float*)nullptr, vals, val_dim, distributed,
-                      csr->seg_count, csr->planes ? LN_XCD_GROUPS : 1, clear_values, clear_values_elems, ws.pub);
+            // the same 512-point tile (the same number of cursor atomics) on 512 threads (a whole point each), 1024 (half a point each) or
+            // 256 (two points each): LN_DEBUG_MASK & 2097152 selects 256, & 4194304 selects 1024 (A/B)
+            if (D <= 3 && (ln_debug_mask() & 4194304))
+                LN_LAUNCH("k_point_keys", (k_point_keys<D, (D <= 3 ? 1024 : 256)>), dim3(ln_div_up(n, 512)), dim3(1024), 0, st, *t, positions_raw, sc, n, sb,
+                          nbk, ws.capb, ws.part_tok, ws.part_pk, dropped_idx, write_idx ? w : (float*)nullptr, vals, val_dim, distributed,
+                          csr->seg_count, csr->planes ? LN_XCD_GROUPS : 1, clear_values, clear_values_elems, ws.pub);
+            else if (D <= 3 && !(ln_debug_mask() & 2097152))
+                LN_LAUNCH("k_point_keys", (k_point_keys<D, (D <= 3 ? 512 : 256)>), dim3(ln_div_up(n, 512)), dim3(512), 0, st, *t, positions_raw, sc, n, sb,
+                          nbk, ws.capb, ws.part_tok, ws.part_pk, dropped_idx, write_idx ? w : (float*)nullptr, vals, val_dim, distributed,
+                          csr->seg_count, csr->planes ? LN_XCD_GROUPS : 1, clear_values, clear_values_elems, ws.pub);
+            else
+                LN_LAUNCH("k_point_keys", (k_point_keys<D, 256>), dim3(ln_div_up(n, LN_KEYS_PTS_PER_BLOCK)), dim3(256), 0, st, *t, positions_raw, sc, n, sb,
+                          nbk, ws.capb, ws.part_tok, ws.part_pk, dropped_idx, write_idx ? w : (float*)nullptr, vals, val_dim, distributed,
+                          csr->seg_count, csr->planes ? LN_XCD_GROUPS : 1, clear_values, clear_values_elems, ws.pub);
             LN_LAUNCH("k_bucket_rows", k_bucket_rows<D>, dim3(nbk), dim3(LN_BKT_THREADS), lds, st, *t, sb, nbk, ws.capb, t->slot_cnt,
                       ws.part_tok, ws.part_pk, ws.part_slot, ws.part_pos, dropped_idx, *csr, ws.pub);
             rc = ln_check_launch(who);

@@ -35,14 +35,14 @@ for _ in range(reps):
     lat.nr_lattice_vertices()
     torch.cuda.synchronize()
     s = stamps.cpu().numpy().astype(np.float64) / 100.0  # 100 MHz -> microseconds
-    for name, first, last, nwg in (("k_point_keys", 0, 7, None), ("k_bucket_rows", 8, 15, None)):
+    for name, first, last, nwg in (("k_point_keys", 0, 7, None), ("k_bucket_rows", 8, 17, None)):
         rows = s[(s[:, first] > 0)]
         t0 = rows[:, first].min()
         rel = rows[:, first:last + 1] - t0
         acc.setdefault(name, []).append(rel)
 lib.ln_debug_set_stamps(None)
 labels = {"k_point_keys": ["start", "clear issued+sync", "keys+LDS rank done", "sync", "scan+global atomics", "sync", "LDS staging+sync", "stores issued (end)"],
-          "k_bucket_rows": ["start", "init+loads+sync", "place (LDS CAS/add/min)", "scans + publish", "look-back done", "emit slots", "token stores", "(segment ids done, before look-back)"]}
+          "k_bucket_rows": ["start", "init+loads+sync", "place (LDS CAS/add/min)", "scans + publish", "look-back done", "emit slots", "token stores", "(segment ids done, before look-back)", "(scans done, before publish)", "(minima compacted, before the in-bucket rank)"]}
 for name, runs in acc.items():
     m = np.mean([r.mean(0) for r in runs], 0)
     mx = np.mean([r.max(0) for r in runs], 0)
