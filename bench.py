@@ -120,7 +120,7 @@ KERNEL_GROUPS = {"hash_build": ["k_point_keys", "k_bucket_rows"]}  # launches th
 
 def pmc_traffic(kernel: str):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r<round>_pmc_traffic.json, newest round), or None."""
-    for rnd in (3, 2, 1):
+    for rnd in (4, 3, 2, 1):
         path = os.path.join(ROOT, "profiles", f"r{rnd}_pmc_traffic.json")
         try:
             with open(path) as f:
