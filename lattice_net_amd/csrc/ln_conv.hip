@@ -1009,22 +1009,248 @@ int ln_reduce_slabs_async(const float* partial, int nslabs, int total, float* ou
     return LN_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// Filter gradient on the bf16 matrix cores with exactly 3-way split operands (the arithmetic of k_conv_mfma_b3: x = hi + mid + lo,
+// six of the nine cross products, fp32 accumulation; 1e-5 per element against fp64).
+//   grad_filter[e][v, f] = sum_rows values[nbr[row, e], v] * grad_out[row, f]
+// The contraction runs over lattice vertices, and the gradient rows G[row, :] are THE SAME for all nine slots: a workgroup owns a
+// chunk of rows and a [16 VT, 16 FT] block of every slot's [V, F] matrix, walks its chunk in sub-tiles of 64 rows, splits and
+// stages G once per sub-tile and the gathered neighbour rows A_e once per slot (three bf16 planes each, row-major; the matrix
+// operands are read "down the rows" with ds_read_b64_tr_b16), and keeps the E x (tiles per wave) accumulators in registers.
+// The waves form a 2 x 2 grid over the block: a wave owns VT/2 x FT/2 tiles and reads (VT/2 + FT/2) x 3 fragments for
+// VT/2 x FT/2 x 6 matrix instructions per 32-row step.  The next slot's rows (ids -> rows: two dependent round trips) are fetched
+// while the matrix instructions of the current one run.  One [E, V, F] slab per row chunk, summed by k_reduce_slabs4.
+// (k_grad_filter_mfma, one slot per workgroup on v_mfma_f32_16x16x4_f32, ran at 43-46 % of the fp32 matrix peak: 191 us for
+// M = 46.5 k, V = F = 128.)
+// ------------------------------------------------------------------------------------------
+typedef short gf_short4 __attribute__((ext_vector_type(4)));
+#define LN_GFB_SUB 64
+#define LN_GFB_EG 3   // slots per workgroup: E = 9 as three groups (gridDim.y); the gradient rows are split three times instead of nine
+template <int VT, int FT, int E>
+__global__ void __launch_bounds__(256, 2)
+    k_grad_filter_b3(const int* __restrict__ nbr, const float* __restrict__ values, const float* __restrict__ grad_out, int m, int rows_per_wg,
+                     float* __restrict__ partial, int v_total, int f_total) {
+    constexpr int V = VT * 16, F = FT * 16;
+    constexpr int EG = LN_GFB_EG;
+    static_assert(E % EG == 0, "slot groups");
+    constexpr int TPV = VT / 2, TPF = FT / 2;        // tiles of a wave
+    constexpr int RSA = V + 8, RSG = F + 8;          // bf16 elements per staged row (+16 bytes: the four rows a tr read touches start in different banks)
+    constexpr int PA = LN_GFB_SUB * RSA, PG = LN_GFB_SUB * RSG;  // one plane
+    constexpr int A4 = LN_GFB_SUB * V / 4 / 256, G4 = LN_GFB_SUB * F / 4 / 256;  // float4 fetched per thread and sub-tile
+    static_assert(A4 >= 1 && G4 >= 1 && VT % 2 == 0 && FT % 2 == 0, "block shape");
+    extern __shared__ __attribute__((aligned(16))) unsigned short s_gfb[];
+    unsigned short* s_a = s_gfb;                     // [3][64][RSA]
+    unsigned short* s_g = s_gfb + 3 * PA;            // [3][64][RSG]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int col_blocks = f_total / F;
+    const int v_off = (blockIdx.z / col_blocks) * V, f_off = (blockIdx.z % col_blocks) * F;
+    const int e0 = blockIdx.y * EG;
+    const int chunk_begin = blockIdx.x * rows_per_wg;
+    const int chunk_end = min(chunk_begin + rows_per_wg, m);
+    const int wv = wave >> 1, wf = wave & 1;         // the wave's place in the 2 x 2 grid
+
+    floatx4 acc[EG][TPV][TPF];
+#pragma unroll
+    for (int e = 0; e < EG; ++e)
+#pragma unroll
+        for (int a = 0; a < TPV; ++a)
+#pragma unroll
+            for (int b = 0; b < TPF; ++b) acc[e][a][b] = floatx4{0.f, 0.f, 0.f, 0.f};
+    float4 ra[A4], rg[G4];
+    int ids[EG][A4];  // neighbour ids of the sub-tile's rows for the group's slots: fetched one sub-tile ahead, so that a slot's
+                      // row reads depend on registers only (ids -> rows were two dependent round trips per slot: the kernel ran at their latency)
+    auto fetch_ids = [&](int sub) {
+#pragma unroll
+        for (int e = 0; e < EG; ++e)
+#pragma unroll
+            for (int k = 0; k < A4; ++k) {
+                const int row = sub + (tid + 256 * k) / (V / 4);
+                ids[e][k] = row < chunk_end ? nbr[(size_t)row * E + e0 + e] : -1;
+            }
+    };
+    auto fetch_a = [&](const int (&nb)[A4]) {
+#pragma unroll
+        for (int k = 0; k < A4; ++k) {
+            const int x4 = tid + 256 * k;
+            const int c4 = x4 % (V / 4);
+            ra[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (nb[k] >= 0) ra[k] = *reinterpret_cast<const float4*>(values + (size_t)nb[k] * v_total + v_off + c4 * 4);
+        }
+    };
+    auto fetch_g = [&](int sub) {
+#pragma unroll
+        for (int k = 0; k < G4; ++k) {
+            const int x4 = tid + 256 * k;
+            const int r = x4 / (F / 4), c4 = x4 - r * (F / 4);
+            const int row = sub + r;
+            rg[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < chunk_end) rg[k] = *reinterpret_cast<const float4*>(grad_out + (size_t)row * f_total + f_off + c4 * 4);
+        }
+    };
+    auto stage = [&](const float4& x, unsigned short* dst, int plane) {  // four consecutive channels of one row -> three planes
+        unsigned int h[4], md[4], lo[4];
+        ln_split3_bits(x.x, h[0], md[0], lo[0]);
+        ln_split3_bits(x.y, h[1], md[1], lo[1]);
+        ln_split3_bits(x.z, h[2], md[2], lo[2]);
+        ln_split3_bits(x.w, h[3], md[3], lo[3]);
+        *reinterpret_cast<uint2*>(dst) = make_uint2((h[0] >> 16) | h[1], (h[2] >> 16) | h[3]);
+        *reinterpret_cast<uint2*>(dst + plane) = make_uint2((md[0] >> 16) | md[1], (md[2] >> 16) | md[3]);
+        *reinterpret_cast<uint2*>(dst + 2 * plane) = make_uint2((lo[0] >> 16) | lo[1], (lo[2] >> 16) | lo[3]);
+    };
+    auto frag = [&](const unsigned short* base, int rs) {  // 8 bf16 down the rows: rows 8q..8q+7 of the 32-row step, one column
+        const gf_short4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((gf_short4 __attribute__((address_space(3)))*)(base));
+        const gf_short4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((gf_short4 __attribute__((address_space(3)))*)(base + 4 * rs));
+        u32x4 p;
+        p[0] = (unsigned int)(unsigned short)lo4[0] | ((unsigned int)(unsigned short)lo4[1] << 16);
+        p[1] = (unsigned int)(unsigned short)lo4[2] | ((unsigned int)(unsigned short)lo4[3] << 16);
+        p[2] = (unsigned int)(unsigned short)hi4[0] | ((unsigned int)(unsigned short)hi4[1] << 16);
+        p[3] = (unsigned int)(unsigned short)hi4[2] | ((unsigned int)(unsigned short)hi4[3] << 16);
+        return __builtin_bit_cast(bf16x8, p);
+    };
+    if (chunk_begin < chunk_end) {
+        fetch_ids(chunk_begin);
+        fetch_g(chunk_begin);
+        fetch_a(ids[0]);
+    }
+    for (int sub = chunk_begin; sub < chunk_end; sub += LN_GFB_SUB) {
+        int nxt[A4];  // slot e0's ids of the NEXT sub-tile (the other slots' are fetched when this sub-tile's are used up)
+#pragma unroll
+        for (int k = 0; k < A4; ++k) {
+            const int row = sub + LN_GFB_SUB + (tid + 256 * k) / (V / 4);
+            nxt[k] = row < chunk_end ? nbr[(size_t)row * E + e0] : -1;
+        }
+#pragma unroll
+        for (int e = 0; e < EG; ++e) {
+            __syncthreads();  // the matrix instructions of the previous slot are done with s_a (and, at e = 0, with s_g)
+            if (e == 0) {
+#pragma unroll
+                for (int k = 0; k < G4; ++k) {
+                    const int x4 = tid + 256 * k;
+                    const int r = x4 / (F / 4), c4 = x4 - r * (F / 4);
+                    stage(rg[k], s_g + r * RSG + c4 * 4, PG);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < A4; ++k) {
+                const int x4 = tid + 256 * k;
+                const int r = x4 / (V / 4), c4 = x4 - r * (V / 4);
+                stage(ra[k], s_a + r * RSA + c4 * 4, PA);
+            }
+            __syncthreads();
+            if (e + 1 < EG) {
+                fetch_a(ids[e + 1]);  // in flight during the matrix instructions below
+            } else if (sub + LN_GFB_SUB < chunk_end) {
+                fetch_g(sub + LN_GFB_SUB);
+                fetch_a(nxt);
+                fetch_ids(sub + LN_GFB_SUB);
+            }
+#pragma unroll
+            for (int st = 0; st < LN_GFB_SUB / 32; ++st) {
+                const int row0 = 32 * st + 8 * q + (i >> 2);
+                bf16x8 fa[TPV][3], fb[TPF][3];
+#pragma unroll
+                for (int a = 0; a < TPV; ++a)
+#pragma unroll
+                    for (int part = 0; part < 3; ++part) fa[a][part] = frag(s_a + part * PA + row0 * RSA + (wv * TPV + a) * 16 + (i & 3) * 4, RSA);
+#pragma unroll
+                for (int b = 0; b < TPF; ++b)
+#pragma unroll
+                    for (int part = 0; part < 3; ++part) fb[b][part] = frag(s_g + part * PG + row0 * RSG + (wf * TPF + b) * 16 + (i & 3) * 4, RSG);
+#pragma unroll
+                for (int a = 0; a < TPV; ++a)
+#pragma unroll
+                    for (int b = 0; b < TPF; ++b) {
+                        floatx4 c = acc[e][a][b];
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a][2], fb[b][0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a][0], fb[b][2], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a][1], fb[b][1], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a][1], fb[b][0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a][0], fb[b][1], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a][0], fb[b][0], c, 0, 0, 0);
+                        acc[e][a][b] = c;
+                    }
+            }
+        }
+    }
+    // D: column = lane & 15 (f), row = q * 4 + reg (v)
+#pragma unroll
+    for (int e = 0; e < EG; ++e) {
+        float* dst = partial + ((size_t)blockIdx.x * E + e0 + e) * ((size_t)v_total * f_total) + (size_t)v_off * f_total + f_off;
+#pragma unroll
+        for (int a = 0; a < TPV; ++a)
+#pragma unroll
+            for (int b = 0; b < TPF; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    dst[(size_t)((wv * TPV + a) * 16 + q * 4 + r) * f_total + (wf * TPF + b) * 16 + i] = acc[e][a][b][r];
+    }
+}
+
+// rows per workgroup of the bf16x3 filter gradient: as few as fill the chip (>= 512 workgroups over chunks x slot groups x sub-blocks) while the
+// slabs the chunks write (and k_reduce_slabs4 reads back) stay under LN_GFB_SLAB_BYTES; a multiple of the 64-row sub-tile
+#define LN_GFB_SLAB_BYTES (24ll << 20)
+static bool ln_gfb_block(int val_dim, int nr_filters, int* vs, int* fs) {
+    static const int cand[6][2] = {{64, 64}, {32, 96}, {96, 32}, {64, 32}, {32, 64}, {32, 32}};
+    for (auto& c : cand)
+        if (val_dim % c[0] == 0 && nr_filters % c[1] == 0) {
+            *vs = c[0];
+            *fs = c[1];
+            return true;
+        }
+    return false;
+}
+static int ln_gfb_rows(int m, int filter_extent, int val_dim, int nr_filters) {
+    int vs = 0, fs = 0;
+    if (filter_extent != 9 || !ln_gfb_block(val_dim, nr_filters, &vs, &fs)) return 0;  // (the kernel is instantiated for E = 9: d = 3)
+    const long long z = (long long)(val_dim / vs) * (nr_filters / fs) * (filter_extent / LN_GFB_EG);  // workgroups per row chunk
+    const long long slab = (long long)filter_extent * val_dim * nr_filters * 4;
+    long long chunks = (512 + z - 1) / z;                                   // two workgroups per CU ...
+    const long long cap = LN_GFB_SLAB_BYTES / slab > 0 ? LN_GFB_SLAB_BYTES / slab : 1;
+    if (chunks > cap) chunks = cap;                                         // ... unless the slabs would cost more than the products
+    long long rows = ((m + chunks - 1) / chunks + LN_GFB_SUB - 1) / LN_GFB_SUB * LN_GFB_SUB;
+    if (rows < LN_GFB_SUB) rows = LN_GFB_SUB;
+    return int(rows);
+}
+static bool ln_gfb_enabled(int m, int filter_extent, int val_dim, int nr_filters) {
+    int vs, fs;
+    return filter_extent == 9 && m >= LN_CONV_B3_MIN_ROWS && ln_conv_b3_enabled() && !(ln_debug_mask() & 8388608) &&
+           ln_gfb_block(val_dim, nr_filters, &vs, &fs);
+}
+
 // Any multiple of 16 in both dimensions: the [V, F] block of a slot is covered by sub-blocks of {64, 32, 16} x {64, 32, 16}.
 static bool ln_gf_mfma_supported(int val_dim, int nr_filters) { return val_dim % 16 == 0 && nr_filters % 16 == 0; }
 
 extern "C" size_t ln_conv_grad_filter_workspace_bytes(int m, int filter_extent, int val_dim, int nr_filters) {
     if (!ln_gf_mfma_supported(val_dim, nr_filters) || m <= 0) return 256;
     // one [E, V, F] slab per row chunk; the fused backward of a same-lattice convolution (ln_conv_backward) has its own chunking
-    const int chunks = ln_bwd_fused_shape(filter_extent, val_dim, nr_filters) ? max(ln_div_up(m, LN_GF_ROWS), ln_bwd_workgroups(m))
-                                                                              : ln_div_up(m, LN_GF_ROWS);
+    int chunks = ln_bwd_fused_shape(filter_extent, val_dim, nr_filters) ? max(ln_div_up(m, LN_GF_ROWS), ln_bwd_workgroups(m))
+                                                                        : ln_div_up(m, LN_GF_ROWS);
+    const int rows_b3 = ln_gfb_rows(m, filter_extent, val_dim, nr_filters);  // (whichever of the two forms runs: LN_DEBUG_MASK can switch)
+    if (rows_b3 > 0) chunks = max(chunks, ln_div_up(m, rows_b3));
     return (size_t)chunks * filter_extent * val_dim * nr_filters * sizeof(float) + 256;
 }
 
 // stage 1 of the MFMA filter gradient: per-row-chunk partial blocks -> slabs [chunk][E*V*F]; returns the chunk count
 static int ln_gf_launch_partials(const int* nbr, const float* values_neigh, const float* grad_out, int m, int filter_extent, int val_dim,
                                  int nr_filters, float* partial, hipStream_t st) {
-    const int chunks = ln_div_up(m, LN_GF_ROWS);
     const dim3 block(256);
+    if (ln_gfb_enabled(m, filter_extent, val_dim, nr_filters)) {  // bf16 matrix cores, gradient rows split once for all nine slots
+        int vs = 0, fs = 0;
+        ln_gfb_block(val_dim, nr_filters, &vs, &fs);
+        const int rows = ln_gfb_rows(m, filter_extent, val_dim, nr_filters);
+        const int chunks_b3 = ln_div_up(m, rows);
+        const dim3 grid(chunks_b3, filter_extent / LN_GFB_EG, (val_dim / vs) * (nr_filters / fs));
+        const size_t lds = (size_t)3 * LN_GFB_SUB * ((vs + 8) + (fs + 8)) * sizeof(unsigned short);
+#define LN_GFB_CASE(A, B)                                                                                                              \
+    if (vs == 16 * A && fs == 16 * B)                                                                                                  \
+        LN_LAUNCH("k_grad_filter_mfma", (k_grad_filter_b3<A, B, 9>), grid, block, lds, st, nbr, values_neigh, grad_out, m, rows, partial, val_dim, \
+                  nr_filters);
+        LN_GFB_CASE(4, 4) LN_GFB_CASE(2, 6) LN_GFB_CASE(6, 2) LN_GFB_CASE(4, 2) LN_GFB_CASE(2, 4) LN_GFB_CASE(2, 2)
+#undef LN_GFB_CASE
+        return chunks_b3;
+    }
+    const int chunks = ln_div_up(m, LN_GF_ROWS);
     // uniform tiling (both dimensions multiples of the widest tile that divides them): ONE launch, gridDim.z = sub-blocks
     for (int t = 4; t >= 1; t >>= 1) {
         if (val_dim % (16 * t) == 0 && nr_filters % (16 * t) == 0) {

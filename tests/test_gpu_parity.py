@@ -311,7 +311,8 @@ def test_conv_forward_and_filter_gradient(v, f):
     close(N(gf), ref, scale=scale)
 
 
-@pytest.mark.parametrize("v,f", [(32, 32), (64, 32), (96, 96), (128, 64), (128, 128), (32, 80), (64, 64), (64, 192)])
+@pytest.mark.parametrize("v,f", [(32, 32), (64, 32), (96, 96), (128, 64), (128, 128), (32, 80), (64, 64), (64, 192), (96, 32), (32, 64), (32, 96),
+                                 (160, 96)])
 def test_conv_large_lattice_split_bf16_path(v, f):
     """Lattices of >= 4096 vertices with a channel count that is a multiple of 32 take the kernels on the bf16 matrix cores with
     exactly 3-way split operands (ln_conv.hip: k_conv_mfma_b3 per slot; k_conv_forward_b3 / k_conv_backward_fused_b3 at V = F = 32);
