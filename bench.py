@@ -111,7 +111,7 @@ def mfma_work(kernel: str, m: int, v: int, f: int, e: int, half: bool):
     if kernel == "k_conv_backward_fused":
         return 4.0 * m * e * v * f, (6.0 if b3 else 1.0)
     if kernel == "k_grad_filter_mfma":
-        return 2.0 * m * e * v * f, 1.0
+        return 2.0 * m * e * v * f, (6.0 if (b3 and f % 32 == 0 and m >= 4096) else 1.0)
     return None
 
 

@@ -125,9 +125,11 @@ def run(dev=None, reps: int = 24):
         kk = _profile(lib, fn, reps)
         # which matrix instruction a launch issues (ln_conv.hip): the convolutions take the bf16x3 form when the gathered width is a
         # multiple of 32 and the produced one a multiple of 16 (per-slot kernel behind k_conv_split_bank, or the 32 x 32 fast paths);
-        # the filter gradient is on v_mfma_f32_16x16x4_f32
+        # the filter gradient when both widths are multiples of 32 and the lattice has >= 4096 vertices (k_grad_filter_b3), else it
+        # is on v_mfma_f32_16x16x4_f32
         b3_fwd = v % 32 == 0 and f % 16 == 0
         b3_vg = f % 32 == 0 and v % 16 == 0
+        b3_fg = v % 32 == 0 and f % 32 == 0 and mq >= 4096  # k_grad_filter_b3 (launch name k_grad_filter_mfma)
         fwd_fl, vg_fl, fg_fl = 2.0 * mq * E * v * f, 2.0 * mn * E * v * f, 2.0 * mq * E * v * f
         if not bwd:
             by = mn * 4 * v + mq * 4 * E + 4 * E * v * f + mq * 4 * f
@@ -135,7 +137,7 @@ def run(dev=None, reps: int = 24):
         else:  # forward + value gradient (the forward with V <-> F) + filter gradient
             by = (mn * 4 * v + mq * 4 * E + 4 * E * v * f + mq * 4 * f) + (mq * 4 * f + mn * 4 * E + 4 * E * v * f + mn * 4 * v) + \
                  (mn * 4 * v + mq * 4 * f + mq * 4 * E + 4 * E * v * f)
-            dense = {"k_conv_mfma": (fwd_fl + vg_fl, b3_fwd and b3_vg), "k_grad_filter_mfma": (fg_fl, False),
+            dense = {"k_conv_mfma": (fwd_fl + vg_fl, b3_fwd and b3_vg), "k_grad_filter_mfma": (fg_fl, b3_fg),
                      "k_conv_backward_fused": (vg_fl + fg_fl, True)}
             if any(x["kernel"] == "k_conv_backward_fused" for x in kk):
                 dense["k_conv_mfma"] = (fwd_fl, b3_fwd)
