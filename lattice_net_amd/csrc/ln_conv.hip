@@ -1024,10 +1024,17 @@ int ln_reduce_slabs_async(const float* partial, int nslabs, int total, float* ou
 // M = 46.5 k, V = F = 128.)
 // ------------------------------------------------------------------------------------------
 typedef short gf_short4 __attribute__((ext_vector_type(4)));
+#ifndef LN_GFB_SUB
 #define LN_GFB_SUB 64
+#endif
+#ifndef LN_GFB_WAVES
+#define LN_GFB_WAVES 2
+#endif
+#ifndef LN_GFB_EG
 #define LN_GFB_EG 3   // slots per workgroup: E = 9 as three groups (gridDim.y); the gradient rows are split three times instead of nine
+#endif
 template <int VT, int FT, int E>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, LN_GFB_WAVES)
     k_grad_filter_b3(const int* __restrict__ nbr, const float* __restrict__ values, const float* __restrict__ grad_out, int m, int rows_per_wg,
                      float* __restrict__ partial, int v_total, int f_total) {
     constexpr int V = VT * 16, F = FT * 16;

@@ -1,0 +1,21 @@
+import ctypes as C, os, sys, torch, numpy as np
+sys.path.insert(0, os.getcwd())
+import lattice_net_amd as L
+from lattice_net_amd import synthetic
+from lattice_net_amd.lattice_funcs import ConvIm2RowLattice
+lib = L.load_library(); dev = torch.device("cuda", 0)
+pos = torch.from_numpy(synthetic.lidar_cloud(120000, 0)).to(dev)
+lat = L.Lattice(sigmas=[0.9]*3, capacity=100000, device=dev); lat.begin_splat(); lat.just_create_verts(pos, False); m = lat.nr_lattice_vertices()
+for v, f in ((64, 64), (128, 128), (96, 96), (128, 64), (64, 32)):
+    lv = torch.randn((m, v), device=dev, requires_grad=True); fb = (torch.randn((9*v, f), device=dev)*0.05).requires_grad_(True); g = torch.randn((m, f), device=dev)
+    def step():
+        lv.grad = fb.grad = None
+        y, _ = ConvIm2RowLattice.apply(lv, lat, fb, 1); y.backward(g)
+    for _ in range(3): step()
+    torch.cuda.synchronize()
+    lib.ln_profile_begin(b"k_grad_filter_mfma", 64)
+    for _ in range(10): step()
+    torch.cuda.synchronize()
+    ms, cnt = C.c_double(0), C.c_int(0); lib.ln_profile_end(C.byref(ms), C.byref(cnt))
+    print(f"V {v} F {f}: grad filter {ms.value/cnt.value*1e3:.1f} us", end="; ")
+print()
