@@ -110,3 +110,18 @@ def test_reference_python_package_aliases():
     from latticenet_py.lattice.lattice_wrapper import LatticeWrapper  # noqa: F401
     from latticenet_py.lattice.lovasz_loss import LovaszSoftmax  # noqa: F401
     from latticenet_py.lattice.models import LNN, prepare_cloud  # noqa: F401
+
+
+def test_workspace_size_functions_are_total_over_odd_shapes():
+    """Host-only entry points (no GPU call): every *_workspace_bytes function returns a positive size for any plausible shape —
+    filter extents that are not 9, widths that are not multiples of anything, empty lattices (a division by a zero workgroup count
+    in the block-shape heuristics of the bf16x3 filter gradient once killed the process for filter_extent < 3)."""
+    import ctypes as C
+    import itertools
+    from lattice_net_amd import _lib
+    lib = _lib.load()
+    for m, e, v, f in itertools.product([0, 1, 100, 4096, 46538, 5000000], [1, 3, 5, 7, 9, 15], [1, 4, 8, 32, 64, 96, 128, 1024], [1, 6, 16, 32, 96, 128]):
+        assert lib.ln_conv_grad_filter_workspace_bytes(m, e, v, f) >= 256
+        assert lib.ln_conv_forward_workspace_bytes(m, e, v, f) >= 0
+    for n, d, v, c in itertools.product([0, 1, 1000, 120000], [1, 2, 3, 6], [1, 8, 64, 96], [1, 20, 50]):
+        assert lib.ln_slice_classify_backward_workspace_bytes(n, d, v, c) > 0

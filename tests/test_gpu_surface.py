@@ -482,3 +482,31 @@ def test_fp16_slice_forward_and_backward_by_width_and_dimension(d, v):
     (ref * G.cpu().double()).sum().backward()
     close(N(out.detach().float()), ref.detach().numpy(), scale=float(ref.abs().max()), rtol=2e-3)
     close(N(vals.grad.float()), v64.grad.numpy(), scale=float(v64.grad.abs().max()), rtol=2e-3)
+
+
+@pytest.mark.parametrize("d,n,v,c", [(2, 3000, 64, 9), (2, 1111, 32, 20), (4, 2000, 64, 12), (2, 2500, 96, 32)])
+def test_slice_classify_other_lattice_dimensions(d, n, v, c):
+    """pos_dim 2 takes the wave-tiled kernels of ln_classify.hip in their (d + 1) = 3 instantiation (tokens per tile: 192 / 48, not a
+    whole number of waves); pos_dim 4 the general kernels.  Logits bit for bit, gradients 1e-5, against the oracle."""
+    from lattice_net_amd import SliceClassifyLattice
+    rng = np.random.default_rng(100 * d + v)
+    pos_np = rng.uniform(-1.0, 1.0, (n, d)).astype(np.float32)
+    lat = make_lattice(0.2, 30000, d=d)
+    lat.begin_splat()
+    idx, w = lat.just_create_verts(T(pos_np), True)
+    m = lat.nr_lattice_vertices()
+    t, oidx, ow = oracle_table(pos_np, 0.2, 30000)
+    assert t.nr_filled == m and np.array_equal(N(idx), oidx)
+    vals_np = rng.standard_normal((m, v)).astype(np.float32)
+    dw_np = (0.1 * rng.standard_normal((n, d + 1))).astype(np.float32)
+    lw_np, lb_np = rng.standard_normal((c, v)).astype(np.float32), rng.standard_normal((c,)).astype(np.float32)
+    gl_np = rng.standard_normal((n, c)).astype(np.float32)
+    vals, dw, lw, lb = (T(x).requires_grad_(True) for x in (vals_np, dw_np, lw_np, lb_np))
+    logits = SliceClassifyLattice.apply(vals, lat, T(pos_np), dw, lw, lb, c, idx, w)
+    np.testing.assert_array_equal(N(logits), O.slice_classify(vals_np, dw_np, lw_np, lb_np, oidx, ow, n))
+    logits.backward(T(gl_np))
+    gv, gd, gw, gb = O.slice_classify_backwards(gl_np, vals_np, dw_np, lw_np, lb_np, oidx, ow, n)
+    close(N(vals.grad), gv)
+    close(N(dw.grad), gd)
+    close(N(lw.grad), gw)
+    close(N(lb.grad), gb)
