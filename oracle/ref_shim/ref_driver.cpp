@@ -187,8 +187,18 @@ int ref_gather_backwards(float* grad, int n, int d, int v, int capacity, int* ke
 int ref_slice_classify(const float* positions, float* logits, const float* delta_w, const float* lin_w,
                        const float* lin_b, int n, int d, int v, int nr_classes, int capacity, int* keys, int* entries,
                        float* values, int* nr_filled, int* idx, float* w) {
-    if (d != 3 || nr_classes != 5) return -3;
+    if (d != 3) return -3;
     HashTableGPU t = make_table(capacity, d, keys, entries, values, nr_filled);
+    if (nr_classes == 20) {  // the SemanticKITTI head (fixture F11): V = 32 / 64
+        if (v == 64)
+            serial_launch(n, [&] { slice_classify_with_precomputation<3, 64, 20>(positions, logits, delta_w, lin_w, lin_b, n, idx, w, t); });
+        else if (v == 32)
+            serial_launch(n, [&] { slice_classify_with_precomputation<3, 32, 20>(positions, logits, delta_w, lin_w, lin_b, n, idx, w, t); });
+        else
+            return -2;
+        return 0;
+    }
+    if (nr_classes != 5) return -3;
     REF_DISPATCH_V(v, serial_launch(n, [&] {
                        slice_classify_with_precomputation<3, VV, 5>(positions, logits, delta_w, lin_w, lin_b, n, idx, w,
                                                                     t);
@@ -201,8 +211,24 @@ int ref_slice_classify_backwards(float* grad_logits, float* initial_values, int 
                                  float* delta_w, float* lin_w, float* lin_b, float* g_values, float* g_delta_w,
                                  float* g_lin_w, float* g_lin_b, int capacity, int* keys, int* entries, float* values,
                                  int* nr_filled, int* idx, float* w) {
-    if (d != 3 || nr_classes != 5) return -3;
+    if (d != 3) return -3;
     HashTableGPU t = make_table(capacity, d, keys, entries, values, nr_filled);
+    if (nr_classes == 20) {
+        if (v == 64)
+            serial_launch(n, [&] {
+                slice_classify_backwards_with_precomputation<3, 64, 20>(n, grad_logits, initial_values, idx, w, delta_w, lin_w, lin_b, g_values,
+                                                                        g_delta_w, g_lin_w, g_lin_b, t);
+            });
+        else if (v == 32)
+            serial_launch(n, [&] {
+                slice_classify_backwards_with_precomputation<3, 32, 20>(n, grad_logits, initial_values, idx, w, delta_w, lin_w, lin_b, g_values,
+                                                                        g_delta_w, g_lin_w, g_lin_b, t);
+            });
+        else
+            return -2;
+        return 0;
+    }
+    if (nr_classes != 5) return -3;
     REF_DISPATCH_V(v, serial_launch(n, [&] {
                        slice_classify_backwards_with_precomputation<3, VV, 5>(n, grad_logits, initial_values, idx, w,
                                                                               delta_w, lin_w, lin_b, g_values, g_delta_w,

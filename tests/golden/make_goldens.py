@@ -271,6 +271,34 @@ def main():
                                     lattice_values=lat_vals, delta_w=dw, lin_w=lw, lin_b=lb, logits=logits, grad_logits=gl,
                                     g_values=g_vals, g_delta_w=g_dw, g_lin_w=g_lw, g_lin_b=g_lb)
 
+    # ---------------- F11: slice_classify at the widths of the SemanticKITTI head (C = 20; V = 64 and 32), ragged tiles ----------------
+    # (the shapes the wave-tiled kernels of ln_classify.hip take: 64-point tiles forward, 16-point tiles backward; n = 1111 leaves both ragged)
+    rng = np.random.default_rng(11)
+    n, d, c, cap, sigma = 1111, 3, 20, 20000, 0.45
+    pos_raw = rng.uniform(-1, 1, (n, d)).astype(F32)
+    pos = scaled(pos_raw, sigma)
+    t = RefTable(cap, d, 1)
+    idx, w = splat(lib, t, pos)
+    m = t.m
+    f11 = dict(pos_raw=pos_raw, sigma=F32(sigma), capacity=I32(cap), nr_filled=I32(m), idx=idx, w=w)
+    f11["delta_w"] = dw = (0.1 * rng.standard_normal((n, d + 1))).astype(F32)
+    f11["grad_logits"] = gl = rng.standard_normal((n, c)).astype(F32)
+    for v in (64, 32):
+        lat_vals = rng.standard_normal((m, v)).astype(F32)
+        tv = with_values(t, lat_vals)
+        lw = rng.standard_normal((c, v)).astype(F32)
+        lb = rng.standard_normal((c,)).astype(F32)
+        logits = np.zeros((n, c), F32)
+        check(lib.ref_slice_classify(P(pos), P(logits), P(dw), P(lw), P(lb), n, d, v, c, *tv.args(), P(idx), P(w)), "slice_classify F11")
+        g_vals, g_dw, g_lw, g_lb = np.zeros((m, v), F32), np.zeros((n, d + 1), F32), np.zeros((c, v), F32), np.zeros((c,), F32)
+        gl_arg = gl.copy()  # (kept alive across the call: the kernel takes a non-const pointer)
+        check(lib.ref_slice_classify_backwards(P(gl_arg), P(lat_vals), n, d, v, c, P(dw), P(lw), P(lb), P(g_vals), P(g_dw), P(g_lw),
+                                               P(g_lb), *tv.args(), P(idx), P(w)), "slice_classify_bwd F11")
+        assert np.array_equal(gl_arg, gl)
+        f11.update({f"lattice_values_{v}": lat_vals, f"lin_w_{v}": lw, f"lin_b_{v}": lb, f"logits_{v}": logits, f"g_values_{v}": g_vals,
+                    f"g_delta_w_{v}": g_dw, f"g_lin_w_{v}": g_lw, f"g_lin_b_{v}": g_lb})
+    out["F11_slice_classify_kitti_head"] = f11
+
     # ---------------- F7: near-full table (probe chains, 300-probe retrieve cap) ----------------
     rng = np.random.default_rng(7)
     n, d, v, sigma = 3000, 3, 1, 0.05

@@ -161,6 +161,29 @@ def test_f5_distribute(golden):
     assert lat.pos_dim() == 3 and lat.val_dim() == 2
 
 
+@pytest.mark.parametrize("v", [64, 32])
+def test_f11_slice_classify_kitti_head(golden, v):
+    """The wave-tiled kernels (ln_classify.hip: 64-point tiles forward, 16-point MFMA tiles backward; n = 1111 leaves both ragged)
+    against the reference's own kernels at the SemanticKITTI head's shape, C = 20: logits bit for bit, gradients 1e-5."""
+    g = golden("F11_slice_classify_kitti_head")
+    lat = make_lattice(g["sigma"], g["capacity"])
+    pos = T(g["pos_raw"])
+    lat.begin_splat()
+    idx, w = lat.just_create_verts(pos, True)
+    np.testing.assert_array_equal(N(idx), g["idx"])
+    lat.set_values(T(g[f"lattice_values_{v}"]))
+    dw, lw, lb = T(g["delta_w"]), T(g[f"lin_w_{v}"]), T(g[f"lin_b_{v}"])
+    logits = lat.slice_classify_with_precomputation(pos, dw, lw, lb, 20, idx, w)
+    np.testing.assert_array_equal(N(logits), g[f"logits_{v}"])
+    gv = torch.zeros_like(lat.values())
+    gdw, glw, glb = torch.zeros_like(dw), torch.zeros_like(lw), torch.zeros_like(lb)
+    lat.slice_classify_backwards_with_precomputation(T(g["grad_logits"]), pos, lat.values(), dw, lw, lb, 20, gv, gdw, glw, glb, idx, w)
+    close(N(gv), g[f"g_values_{v}"])
+    close(N(gdw), g[f"g_delta_w_{v}"])
+    close(N(glw), g[f"g_lin_w_{v}"])
+    close(N(glb), g[f"g_lin_b_{v}"])
+
+
 def test_f6_slice_classify(golden):
     g = golden("F6_slice_classify")
     lat = make_lattice(g["sigma"], g["capacity"])

@@ -156,6 +156,24 @@ def test_f6_slice_classify(golden):
     close(gb, g["g_lin_b"])
 
 
+def test_f11_slice_classify_kitti_head(golden):
+    """The oracle against the reference's kernels at the SemanticKITTI head's shape (C = 20, V = 64 / 32): logits bit for bit."""
+    g = golden("F11_slice_classify_kitti_head")
+    t, pos, idx, w = build(g)
+    assert t.nr_filled == int(g["nr_filled"])
+    np.testing.assert_array_equal(idx, g["idx"])
+    n = g["pos_raw"].shape[0]
+    for v in (64, 32):
+        logits = O.slice_classify(g[f"lattice_values_{v}"], g["delta_w"], g[f"lin_w_{v}"], g[f"lin_b_{v}"], idx, w, n)
+        np.testing.assert_array_equal(logits, g[f"logits_{v}"])
+        gv, gd, gw, gb = O.slice_classify_backwards(g["grad_logits"], g[f"lattice_values_{v}"], g["delta_w"], g[f"lin_w_{v}"], g[f"lin_b_{v}"],
+                                                    idx, w, n)
+        close(gv, g[f"g_values_{v}"])
+        close(gd, g[f"g_delta_w_{v}"])
+        close(gw, g[f"g_lin_w_{v}"], scale=np.max(np.abs(g[f"g_lin_w_{v}"])))
+        close(gb, g[f"g_lin_b_{v}"])
+
+
 def test_f7_near_full_table_probe_cap(golden):
     g = golden("F7_near_full")
     t, pos, idx, w = build(g)
