@@ -265,8 +265,22 @@ __global__ void __launch_bounds__(256)
 }
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#ifndef LN_CONV_B3_PIPE
+#define LN_CONV_B3_PIPE(V) ((V) <= 96)  // fragments read one chain ahead: +12 registers, pays up to 96 channels (at 128 it spills at 3 waves)
+#endif
+#ifndef LN_CONV_LDS_E
+#define LN_CONV_LDS_E 16  // filter extents up to 2 (d + 1) + 1 with d <= 6 keep their neighbour ids in LDS
+#endif
+#ifndef LN_CONV_PROBE
+#define LN_CONV_PROBE 0  // timing ablations (wrong results): 1 no matrix products, 2 no operand split, 4 no bank staging, 8 no gather
+#endif
+// Waves per SIMD by gathered width (registers: 2 x V/4 row quarters + the staged bank slice + 4 NT accumulators; LDS: 36-48 KB bank
+// slice + 4 KB ids per workgroup): 3 up to 128 channels (<= 168 registers, 3 x 52 KB of LDS), 2 above (192 / 256 channels need
+// 174 / 220 registers: at 3 they spill, 1.77 ms instead of 0.63 at 256 x 256).  Measured at 46 k rows, 2 -> 3 waves: 64 x 64 37.7 -> 32.1 us,
+// 96 x 96 2 x 48.4 -> 2 x 40.8, 128 x 128 129 -> 122, 32 -> 64 20.7 -> 16.1.
+#define LN_CONV_B3_WAVES(V) ((V) <= 128 ? 3 : 2)
 template <int V, int NT, bool FLIP>
-__global__ void __launch_bounds__(256) LN_CONV_WAVES_ATTR
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LN_CONV_B3_WAVES(V), LN_CONV_B3_WAVES(V))))
     k_conv_mfma_b3(const int* __restrict__ nbr, const float* __restrict__ values, const u32x4* __restrict__ bank, int m, int E,
                    float* __restrict__ out, int f_total, int f_off, int e_per) {
     const int e_begin = blockIdx.z * e_per;  // slot split, as in k_conv_mfma
@@ -294,11 +308,29 @@ __global__ void __launch_bounds__(256) LN_CONV_WAVES_ATTR
 
     float a_cur[KQ], a_nxt[KQ];
     u32x4 w_nxt[W16];
-    auto issue = [&](int e, float (&a)[KQ]) {
-        const int es = (FLIP && e < E - 1) ? (e ^ 1) : e;
-        const int nb = (my_row < m) ? nbr[(size_t)my_row * E + es] : -1;
+#pragma unroll
+    for (int k = 0; k < KQ; ++k) a_nxt[k] = 0.f;
+    // Loads ahead of the products of slot e: the gathered quarter row and the bank slice of slot e + 1 (global), the
+    // neighbour id of slot e + 2 (LDS).  The ids of the workgroup's 64 rows are copied into LDS once, coalesced (the launch
+    // requires E <= LN_CONV_LDS_E): a per-lane global id load inside the loop is either waited for on the spot or, hoisted a
+    // slot ahead by hand, sunk back to its use by the compiler.  Only the first slot's id comes straight from global memory,
+    // beside that copy.
+    __shared__ int s_nbr[64 * LN_CONV_LDS_E];
+    {
+        const size_t g0 = (size_t)blockIdx.x * 64 * E, g_end = (size_t)m * E;
+        for (int x = tid; x < 64 * E; x += 256) s_nbr[x] = (g0 + x < g_end) ? nbr[g0 + x] : -1;
+    }
+    auto slot_of = [&](int e) -> int { return (FLIP && e < E - 1) ? (e ^ 1) : e; };
+    const int* my_ids = s_nbr + ((tid >> 6) * 16 + i) * E;
+    auto load_nb = [&](int e) -> int { return e < e_end ? my_ids[slot_of(e)] : -1; };
+    // DEEP (V <= 64): an absent neighbour's row is zeroed when it becomes a_cur, so the gather is not waited for before the
+    // products of the current slot.  Wider rows: zeroed at issue — the wave waits for its gather first, which staggers the two
+    // workgroups of a CU (one gathers while the other multiplies); measured better from 96 channels on (128 x 128 at 46 k rows:
+    // 124 vs 130 us), worse below (64 x 64: 40 vs 35 us).
+    constexpr bool DEEP = V <= 64;
+    auto issue = [&](int e, int nb, float (&a)[KQ]) {
         ln_load_quarter<KQ>(values + (size_t)(nb >= 0 ? nb : 0) * V + q * KQ, a);
-        if (nb < 0) {
+        if (!DEEP && nb < 0) {
 #pragma unroll
             for (int k = 0; k < KQ; ++k) a[k] = 0.f;
         }
@@ -316,11 +348,35 @@ __global__ void __launch_bounds__(256) LN_CONV_WAVES_ATTR
             if (BANK16 % 256 == 0 || x < BANK16) s_b[x] = w_nxt[s];
         }
     };
-    issue(e_begin, a_cur);
+    int nb_nxt = my_row < m ? nbr[(size_t)my_row * E + slot_of(e_begin)] : -1, nb_nn = -1;
+    issue(e_begin, nb_nxt, a_cur);
+    if (nb_nxt < 0) {
+#pragma unroll
+        for (int k = 0; k < KQ; ++k) a_cur[k] = 0.f;
+    }
     stage();
     __syncthreads();
+    nb_nxt = load_nb(e_begin + 1);
     for (int e = e_begin; e < e_end; ++e) {
-        if (e + 1 < e_end) issue(e + 1, a_nxt);
+        if (e + 1 < e_end) {
+            nb_nn = load_nb(e + 2);
+#if LN_CONV_PROBE & 8
+#pragma unroll
+            for (int k = 0; k < KQ; ++k) a_nxt[k] = a_cur[k] * 1.5f;
+#elif LN_CONV_PROBE & 4
+            ln_load_quarter<KQ>(values + (size_t)(nb_nxt >= 0 ? nb_nxt : 0) * V + q * KQ, a_nxt);
+#else
+            issue(e + 1, nb_nxt, a_nxt);
+#endif
+        }
+        constexpr bool PIPE = LN_CONV_B3_PIPE(V);
+        u32x4 fb[2][3];
+        if constexpr (PIPE) {
+#pragma unroll
+            for (int x = 0; x < 3; ++x) fb[0][x] = s_b[x * 64 + lane];
+            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 48, 0);  // the first step's split
+        }
 #pragma unroll
         for (int st = 0; st < S; ++st) {
             // three bf16x8 fragments of this lane's 8 channels: two bf16 per dword, the LOWER channel in the low half-word
@@ -334,11 +390,37 @@ __global__ void __launch_bounds__(256) LN_CONV_WAVES_ATTR
                 p2[j] = (m0_ >> 16) | m1_;
                 p3[j] = (l0 >> 16) | l1;
             }
+#if LN_CONV_PROBE & 2
+            p1 = u32x4{__float_as_uint(a_cur[st * 8]), __float_as_uint(a_cur[st * 8 + 1]), __float_as_uint(a_cur[st * 8 + 2]), __float_as_uint(a_cur[st * 8 + 3])};
+            p2 = u32x4{__float_as_uint(a_cur[st * 8 + 4]), __float_as_uint(a_cur[st * 8 + 5]), __float_as_uint(a_cur[st * 8 + 6]), __float_as_uint(a_cur[st * 8 + 7])};
+            p3 = p1;
+#endif
             const bf16x8 a1 = __builtin_bit_cast(bf16x8, p1), a2 = __builtin_bit_cast(bf16x8, p2), a3 = __builtin_bit_cast(bf16x8, p3);
+#if LN_CONV_PROBE & 1
+            acc[0][0] += __uint_as_float((p1[0] ^ p2[1] ^ p3[2]) + (p1[1] ^ p2[2] ^ p3[3]) + (p1[2] ^ p2[3] ^ p3[0]) + (p1[3] ^ p2[0] ^ p3[1]));
+            continue;
+#endif
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const u32x4* pb = s_b + ((st * NT + nt) * 3) * 64 + lane;
-                const bf16x8 b1 = __builtin_bit_cast(bf16x8, pb[0]), b2 = __builtin_bit_cast(bf16x8, pb[64]), b3 = __builtin_bit_cast(bf16x8, pb[128]);
+                // PIPE: the three bank fragments of the NEXT chain are read from LDS ahead of this chain's six products, which
+                // then issue back to back (an instruction between two products on one accumulator costs ~43 cycles,
+                // MI355X_MICROARCH.md); the vector-ALU work of the next step's split goes between chains.  The order is pinned
+                // with scheduling groups (DS read 0x100, MFMA 0x008, VALU 0x002).
+                const int idx = st * NT + nt;
+                bf16x8 b1, b2, b3;
+                if constexpr (PIPE) {
+                    if (idx + 1 < S * NT) {
+#pragma unroll
+                        for (int x = 0; x < 3; ++x) fb[(idx + 1) & 1][x] = s_b[((idx + 1) * 3 + x) * 64 + lane];
+                        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, (48 + NT - 1) / NT + 2, 0);
+                    b1 = __builtin_bit_cast(bf16x8, fb[idx & 1][0]), b2 = __builtin_bit_cast(bf16x8, fb[idx & 1][1]), b3 = __builtin_bit_cast(bf16x8, fb[idx & 1][2]);
+                } else {
+                    const u32x4* pb = s_b + (idx * 3) * 64 + lane;
+                    b1 = __builtin_bit_cast(bf16x8, pb[0]), b2 = __builtin_bit_cast(bf16x8, pb[64]), b3 = __builtin_bit_cast(bf16x8, pb[128]);
+                }
                 // small terms first, the dominant product last
                 acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, b1, acc[nt], 0, 0, 0);
                 acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b3, acc[nt], 0, 0, 0);
@@ -349,12 +431,17 @@ __global__ void __launch_bounds__(256) LN_CONV_WAVES_ATTR
             }
         }
         if (e + 1 < e_end) {
+#if !(LN_CONV_PROBE & 4)
             __syncthreads();  // every wave is done with W_e
             stage();
             __syncthreads();
-#pragma unroll
-            for (int k = 0; k < KQ; ++k) a_cur[k] = a_nxt[k];
+#endif
         }
+        // unconditional (a_nxt is initialised): no register of a_cur is ever undefined on a path through the loop — with
+        // undefined lanes in the loop-carried registers hipcc 7.2 has mis-assigned the operands of the split's pack instructions
+#pragma unroll
+        for (int k = 0; k < KQ; ++k) a_cur[k] = (!DEEP || nb_nxt >= 0) ? a_nxt[k] : 0.f;
+        nb_nxt = nb_nn;
     }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -554,7 +641,7 @@ static bool ln_conv_b3_enabled() {
     return v == 1;
 }
 static size_t ln_conv_bank_bytes(int m, int E, int val_dim, int nr_filters) {
-    if (val_dim % 32 != 0 || nr_filters % 16 != 0 || m < LN_CONV_B3_MIN_ROWS || !ln_conv_b3_enabled()) return 0;
+    if (val_dim % 32 != 0 || nr_filters % 16 != 0 || m < LN_CONV_B3_MIN_ROWS || E > LN_CONV_LDS_E || !ln_conv_b3_enabled()) return 0;
     return (((size_t)E * val_dim * nr_filters * 3 * sizeof(unsigned short)) + 255) & ~size_t(255);
 }
 

@@ -334,8 +334,38 @@ def test_conv_forward_and_filter_gradient(v, f):
     close(N(gf), ref, scale=scale)
 
 
+@pytest.mark.parametrize("v", [32, 64, 96, 128, 160, 192, 256])
+def test_conv_one_hot_bank_every_instance(v):
+    """Every instantiation of the per-slot kernels (gathered width v; column chunks of 128 / 64 / 32 / 16 filters; both neighbour
+    orders) against a bank with ONE non-zero entry per filter and small-integer values: the result is exact whatever the kernel,
+    and a single mis-packed operand half shows as a wrong integer.  (hipcc 7.2 has mis-assigned the operands of the split's
+    pack instructions when loop-carried registers were undefined on a path — DESIGN.md §4.3; the random-value tests above see
+    that as a 1e-1 error, this one names the channel.)"""
+    from lattice_net_amd.synthetic import cube_cloud
+    lat = make_lattice(0.05, 200000)
+    lat.begin_splat()
+    lat.just_create_verts(T(cube_cloud(30000, 11)), False)
+    m = lat.nr_lattice_vertices()
+    assert m >= 4096
+    rng = np.random.default_rng(v)
+    vals = rng.integers(-7, 8, (m, v)).astype(np.float32)
+    lat.set_values(T(vals))
+    for f in (240, 64, 48, 16):          # 128 + 64 + 32 + 16 | 64 | 32 + 16 | 16
+        for flip in (False, True):
+            slot = rng.integers(0, 9, f)
+            chan = rng.integers(0, v, f)
+            gain = rng.integers(1, 4, f).astype(np.float32)
+            bank = np.zeros((9, v, f), np.float32)
+            bank[slot, chan, np.arange(f)] = gain
+            got = N(lat.convolve_im2row_standalone(T(bank.reshape(9 * v, f)), 1, lat, flip).values())
+            rows = N(lat.im2row(lat, 9, 1, flip)).reshape(m, 9, v)
+            exp = rows[:, slot, chan] * gain[None, :]
+            bad = np.argwhere(got != exp)
+            assert bad.size == 0, (f, flip, bad[:8].tolist(), got[tuple(bad[0])], exp[tuple(bad[0])])
+
+
 @pytest.mark.parametrize("v,f", [(32, 32), (64, 32), (96, 96), (128, 64), (128, 128), (32, 80), (64, 64), (64, 192), (96, 32), (32, 64), (32, 96),
-                                 (160, 96)])
+                                 (160, 96), (64, 128), (192, 48), (256, 64)])
 def test_conv_large_lattice_split_bf16_path(v, f):
     """Lattices of >= 4096 vertices with a channel count that is a multiple of 32 take the kernels on the bf16 matrix cores with
     exactly 3-way split operands (ln_conv.hip: k_conv_mfma_b3 per slot; k_conv_forward_b3 / k_conv_backward_fused_b3 at V = F = 32);
