@@ -334,6 +334,44 @@ def test_conv_forward_and_filter_gradient(v, f):
     close(N(gf), ref, scale=scale)
 
 
+@pytest.mark.parametrize("v,f", [(32, 32), (64, 64), (128, 128), (96, 32), (64, 128), (32, 96), (256, 64), (48, 80), (192, 192)])
+def test_conv_small_integer_operands_are_exact(v, f):
+    """Small-integer values, filter bank and upstream gradient: every product and every partial sum is an integer below 2^24, so
+    the convolution, the filter gradient and the value gradient are exact in fp32 whatever the summation order, the slab
+    reduction or the operand split (a bf16x3 split of a small integer is the integer) — any difference from the int64 result is
+    a wrong operand, not rounding.  Covers the fused 32 x 32 kernels, the per-slot kernels and k_grad_filter_b3."""
+    from lattice_net_amd import ConvIm2RowLattice
+    from lattice_net_amd.synthetic import cube_cloud
+    lat = make_lattice(0.05, 200000)
+    lat.begin_splat()
+    lat.just_create_verts(T(cube_cloud(30000, 11)), False)
+    m = lat.nr_lattice_vertices()
+    rng = np.random.default_rng(7 * v + f)
+    vals_np = rng.integers(-7, 8, (m, v)).astype(np.float32)
+    W_np = rng.integers(-3, 4, (9 * v, f)).astype(np.float32)
+    G_np = (rng.integers(-3, 4, (m, f)) * (rng.random((m, 1)) < 0.25)).astype(np.float32)   # 3/4 of the rows carry no gradient
+    vals = T(vals_np).requires_grad_(True)
+    W = T(W_np).requires_grad_(True)
+    out, _ = ConvIm2RowLattice.apply(vals, lat, W, 1)
+    (out * T(G_np)).sum().backward()
+    lat.set_values(T(vals_np))
+    # float64 BLAS products of integers below 2^53 are exact
+    rows = N(lat.im2row(lat, 9, 1, False)).astype(np.float64)
+    nbr = torch.from_numpy(N(lat.neighbours(lat, 1, False)).astype(np.int64))
+    W64, G64 = W_np.astype(np.float64), G_np.astype(np.float64)
+    assert np.array_equal(N(out.detach()).astype(np.float64), rows @ W64)
+    gw = rows.T @ G64
+    assert float(np.max(np.abs(gw))) < 2 ** 24
+    assert np.array_equal(N(W.grad).astype(np.float64), gw)
+    # value gradient = row2im of G W^T: scatter-add of the per-slot products to the neighbour rows
+    gr = torch.from_numpy((G64 @ W64.T).reshape(m, 9, v))
+    gx = torch.zeros((m, v), dtype=torch.float64)
+    for e in range(9):
+        ok = nbr[:, e] >= 0
+        gx.index_add_(0, nbr[ok, e], gr[ok, e])
+    assert np.array_equal(N(vals.grad).astype(np.float64), gx.numpy())
+
+
 @pytest.mark.parametrize("v", [32, 64, 96, 128, 160, 192, 256])
 def test_conv_one_hot_bank_every_instance(v):
     """Every instantiation of the per-slot kernels (gathered width v; column chunks of 128 / 64 / 32 / 16 filters; both neighbour

@@ -21,11 +21,15 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--shapes", default="64x64,128x128,64x128,128x64,96x96,32x64,256x256")
+    ap.add_argument("--row-order", default="", help="canonical: rows numbered in first-occurrence order (ln_canonicalize) instead of slot order")
     a = ap.parse_args()
     import lattice_net_amd as L
     from lattice_net_amd import synthetic
     dev = torch.device("cuda", 0)
     lib = L.load_library()
+    if a.row_order:
+        from lattice_net_amd import lattice as _lat
+        _lat.set_row_order(a.row_order)
     pos = torch.from_numpy(synthetic.lidar_cloud(120000, 0)).to(dev)
     lat = L.Lattice(sigmas=[0.9] * 3, capacity=100000, device=dev)
     lat.begin_splat()
