@@ -372,6 +372,47 @@ def test_conv_small_integer_operands_are_exact(v, f):
     assert np.array_equal(N(vals.grad).astype(np.float64), gx.numpy())
 
 
+@pytest.mark.parametrize("lo,hi", [(4096, 16384), (16385, 32768), (32769, 49152)])
+def test_fused_32_channel_kernels_exact_at_every_subtile_count(lo, hi):
+    """k_conv_forward_b3<T> / k_conv_backward_fused_b3<T> (the headline chain's convolution, V = F = 32) are instantiated for T = 1, 2, 3
+    sub-tiles of 64 vertices per workgroup, chosen from the vertex count (ln_bwd_subtiles: <= 16 384 / <= 32 768 / above at 256 CUs).
+    Small-integer operands: forward, value gradient and filter gradient must equal the float64 (exact) result bit for bit."""
+    from lattice_net_amd import ConvIm2RowLattice
+    from lattice_net_amd.synthetic import cube_cloud
+    pos = T(cube_cloud(30000, 5))
+    lat, sigma = None, 0.4
+    while sigma > 0.02:                                       # finer lattice -> more vertices: take the first sigma that lands in range
+        cand = make_lattice(sigma, 200000)
+        cand.begin_splat()
+        cand.just_create_verts(pos, False)
+        if lo <= cand.nr_lattice_vertices() <= hi:
+            lat = cand
+            break
+        sigma /= 1.12
+    assert lat is not None, "no sigma puts the cube cloud's vertex count into the range"
+    m, v, f = lat.nr_lattice_vertices(), 32, 32
+    rng = np.random.default_rng(m)
+    vals_np = rng.integers(-7, 8, (m, v)).astype(np.float32)
+    W_np = rng.integers(-3, 4, (9 * v, f)).astype(np.float32)
+    G_np = (rng.integers(-3, 4, (m, f)) * (rng.random((m, 1)) < 0.25)).astype(np.float32)
+    vals = T(vals_np).requires_grad_(True)
+    W = T(W_np).requires_grad_(True)
+    out, _ = ConvIm2RowLattice.apply(vals, lat, W, 1)
+    (out * T(G_np)).sum().backward()
+    lat.set_values(T(vals_np))
+    rows = N(lat.im2row(lat, 9, 1, False)).astype(np.float64)
+    nbr = torch.from_numpy(N(lat.neighbours(lat, 1, False)).astype(np.int64))
+    W64, G64 = W_np.astype(np.float64), G_np.astype(np.float64)
+    assert np.array_equal(N(out.detach()).astype(np.float64), rows @ W64)
+    assert np.array_equal(N(W.grad).astype(np.float64), rows.T @ G64)
+    gr = torch.from_numpy((G64 @ W64.T).reshape(m, 9, v))
+    gx = torch.zeros((m, v), dtype=torch.float64)
+    for e in range(9):
+        ok = nbr[:, e] >= 0
+        gx.index_add_(0, nbr[ok, e], gr[ok, e])
+    assert np.array_equal(N(vals.grad).astype(np.float64), gx.numpy())
+
+
 @pytest.mark.parametrize("v", [32, 64, 96, 128, 160, 192, 256])
 def test_conv_one_hot_bank_every_instance(v):
     """Every instantiation of the per-slot kernels (gathered width v; column chunks of 128 / 64 / 32 / 16 filters; both neighbour
