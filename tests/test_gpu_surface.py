@@ -357,6 +357,41 @@ def test_conv_fp16_feature_path_matches_fp64_reference(v, f):
     close(N(W.grad.float()), w64.grad.numpy(), scale=float(w64.grad.abs().max()), rtol=2e-3)
 
 
+@pytest.mark.parametrize("v,f,n,sigma", [(64, 64, 6000, 0.12), (32, 32, 6000, 0.12), (64, 32, 6000, 0.12), (128, 128, 6000, 0.12),
+                                         (64, 64, 30000, 0.05), (32, 64, 30000, 0.05)])
+def test_conv_fp16_small_integer_operands_are_exact(v, f, n, sigma):
+    """The fp16 kernels (k_conv_f16 / k_conv_f16_tiled / k_grad_filter_mfma_f16) with small-integer operands: every partial sum is an
+    integer far below 2^24 (fp32 accumulation) and every result below 2048 (exact in fp16), so forward and both gradients must equal
+    the float64 result bit for bit — a wrong operand lane cannot hide in a tolerance."""
+    from lattice_net_amd import ConvIm2RowLattice
+    from lattice_net_amd.synthetic import cube_cloud
+    lat = make_lattice(sigma, 200000)
+    lat.begin_splat()
+    lat.just_create_verts(T(cube_cloud(n, 31)), False)
+    m = lat.nr_lattice_vertices()
+    rng = np.random.default_rng(v * 11 + f + n)
+    vals_np = rng.integers(-2, 3, (m, v)).astype(np.float64)
+    W_np = (rng.integers(-1, 2, (9 * v, f)) * (rng.random((9 * v, f)) < 0.5)).astype(np.float64)
+    G_np = (rng.integers(-1, 2, (m, f)) * (rng.random((m, 1)) < 0.125)).astype(np.float64)
+    vals = torch.tensor(vals_np, dtype=torch.float16, device=dev(), requires_grad=True)
+    W = torch.tensor(W_np, dtype=torch.float16, device=dev(), requires_grad=True)
+    out, _ = ConvIm2RowLattice.apply(vals, lat, W, 1)
+    (out.float() * torch.tensor(G_np, dtype=torch.float32, device=dev())).sum().backward()
+    nbr = torch.from_numpy(N(lat.neighbours(lat, 1, False)).astype(np.int64))
+    padded = torch.cat([torch.from_numpy(vals_np), torch.zeros((1, v), dtype=torch.float64)], 0)
+    rows = padded[torch.where(nbr >= 0, nbr, torch.full_like(nbr, m))].reshape(m, 9 * v).numpy()
+    ref, gw = rows @ W_np, rows.T @ G_np
+    gr = torch.from_numpy((G_np @ W_np.T).reshape(m, 9, v))
+    gx = torch.zeros((m, v), dtype=torch.float64)
+    for e in range(9):
+        ok = nbr[:, e] >= 0
+        gx.index_add_(0, nbr[ok, e], gr[ok, e])
+    assert max(np.abs(ref).max(), np.abs(gw).max(), float(gx.abs().max())) < 2048
+    assert np.array_equal(N(out.detach().float()).astype(np.float64), ref)
+    assert np.array_equal(N(W.grad.float()).astype(np.float64), gw)
+    assert np.array_equal(N(vals.grad.float()).astype(np.float64), gx.numpy())
+
+
 def test_fp16_feature_path_splat_conv_slice_end_to_end():
     """C5-style chain on half features: splat of fp16 point features (fp32 table), fp16 convolution, fp16 slice, and the
     backward pass through all three, against an fp64 evaluation of the same fp16 inputs."""
