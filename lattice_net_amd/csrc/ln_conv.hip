@@ -268,6 +268,9 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #ifndef LN_CONV_B3_PIPE
 #define LN_CONV_B3_PIPE(V) ((V) <= 96)  // fragments read one chain ahead: +12 registers, pays up to 96 channels (at 128 it spills at 3 waves)
 #endif
+#ifndef LN_CONV_B3_DEEP
+#define LN_CONV_B3_DEEP(V) ((V) <= 96)
+#endif
 #ifndef LN_CONV_LDS_E
 #define LN_CONV_LDS_E 16  // filter extents up to 2 (d + 1) + 1 with d <= 6 keep their neighbour ids in LDS
 #endif
@@ -323,11 +326,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LN_CON
     auto slot_of = [&](int e) -> int { return (FLIP && e < E - 1) ? (e ^ 1) : e; };
     const int* my_ids = s_nbr + ((tid >> 6) * 16 + i) * E;
     auto load_nb = [&](int e) -> int { return e < e_end ? my_ids[slot_of(e)] : -1; };
-    // DEEP (V <= 64): an absent neighbour's row is zeroed when it becomes a_cur, so the gather is not waited for before the
-    // products of the current slot.  Wider rows: zeroed at issue — the wave waits for its gather first, which staggers the two
-    // workgroups of a CU (one gathers while the other multiplies); measured better from 96 channels on (128 x 128 at 46 k rows:
-    // 124 vs 130 us), worse below (64 x 64: 40 vs 35 us).
-    constexpr bool DEEP = V <= 64;
+    // DEEP (V <= 96): an absent neighbour's row is zeroed when it becomes a_cur, so the gather is not waited for before the
+    // products of the current slot.  Wider rows: zeroed at issue — the wave waits for its gather first.  A/B with everything else
+    // in place, 46 k rows, deferred vs at issue: 32 -> 64 16.1 vs 17.8 us, 64 x 64 30.6 vs 32.1, 96 x 96 2 x 38.7 vs 2 x 41.1,
+    // 128 x 128 116-117 vs 115-118 (equal), 128 -> 64 62-63 vs 61 (the 32 extra selects per slot show).
+    constexpr bool DEEP = LN_CONV_B3_DEEP(V);
     auto issue = [&](int e, int nb, float (&a)[KQ]) {
         ln_load_quarter<KQ>(values + (size_t)(nb >= 0 ? nb : 0) * V + q * KQ, a);
         if (!DEEP && nb < 0) {
