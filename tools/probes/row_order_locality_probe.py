@@ -26,8 +26,19 @@ def part(x):
     x = (x | (x << 2)) & 0x9249249
     return x
 mort = part(k[:, 0] >> 2) | (part(k[:, 1] >> 2) << 1) | (part(k[:, 2] >> 2) << 2)
-orders = {"slot order": torch.arange(m, device=dev), "spatial (Morton of key / 4)": torch.argsort(mort, stable=True),
-          "random": torch.randperm(m, device=dev)}
+spatial = torch.argsort(mort, stable=True)
+# spatial AND XCD-aware: workgroup t (64 rows) runs on XCD t % 8 (round-robin dispatch), so hand XCD k the k-th eighth of the
+# Morton order: chunk c of the sorted rows becomes tile (c % (T/8)) * 8 + c / (T/8)
+T8 = (m // 64) // 8
+c = torch.arange(T8 * 8, device=dev)
+tile_of_chunk = (c % T8) * 8 + c // T8
+xcd = torch.arange(m, device=dev)
+src_rows = (c[:, None] * 64 + torch.arange(64, device=dev)[None, :])            # Morton positions of chunk c
+dst_rows = (tile_of_chunk[:, None] * 64 + torch.arange(64, device=dev)[None, :])  # where they go
+perm_pos = torch.arange(m, device=dev)
+perm_pos[dst_rows.reshape(-1)] = src_rows.reshape(-1)
+orders = {"slot order": torch.arange(m, device=dev), "spatial (Morton of key / 4)": spatial,
+          "spatial, an eighth per XCD": spatial[perm_pos], "random": torch.randperm(m, device=dev)}
 torch.manual_seed(0)
 for v, f in ((32, 32), (64, 64), (128, 128)):
     vals0 = torch.randn((m, v), device=dev)
