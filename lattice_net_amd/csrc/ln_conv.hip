@@ -282,8 +282,11 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // 174 / 220 registers: at 3 they spill, 1.77 ms instead of 0.63 at 256 x 256).  Measured at 46 k rows, 2 -> 3 waves: 64 x 64 37.7 -> 32.1 us,
 // 96 x 96 2 x 48.4 -> 2 x 40.8, 128 x 128 129 -> 122, 32 -> 64 20.7 -> 16.1.
 #define LN_CONV_B3_WAVES(V) ((V) <= 128 ? 3 : 2)
-template <int V, int NT, bool FLIP>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LN_CONV_B3_WAVES(V), LN_CONV_B3_WAVES(V))))
+// T sub-tiles of 64 rows per workgroup (256 T threads) share ONE staging of the slot's bank slice: T = 3 (one workgroup per CU, the
+// shape of k_conv_forward_b3) re-reads the bank from L2 and writes it to LDS a third as often as T = 1 (three workgroups per CU) —
+// at 46 k rows x 64 channels the bank traffic of T = 1 (727 workgroups x 9 slices of 24 KB = 157 MB) exceeds the gathered rows (107 MB).
+template <int V, int NT, bool FLIP, int T>
+__global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(LN_CONV_B3_WAVES(V), LN_CONV_B3_WAVES(V))))
     k_conv_mfma_b3(const int* __restrict__ nbr, const float* __restrict__ values, const u32x4* __restrict__ bank, int m, int E,
                    float* __restrict__ out, int f_total, int f_off, int e_per) {
     const int e_begin = blockIdx.z * e_per;  // slot split, as in k_conv_mfma
@@ -293,15 +296,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LN_CON
     constexpr int KQ = V / 4;
     constexpr int S = KQ / 8;                 // MFMA steps per slot
     constexpr int BANK16 = S * NT * 3 * 64;   // 16-byte fragments of one (slot, chunk) slice
-    constexpr int W16 = (BANK16 + 255) / 256;
+    constexpr int THREADS = 256 * T;
+    constexpr int W16 = (BANK16 + THREADS - 1) / THREADS;
     static_assert(V % 32 == 0, "bf16x3 path: V must be a multiple of 32");
+    static_assert(T == 1 || LN_CONV_B3_WAVES(V) == T, "T > 1: one workgroup per CU, its waves are the SIMDs' whole occupancy");
     __shared__ u32x4 s_b[BANK16];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int i = lane & 15;
     const int q = lane >> 4;
-    const int m0 = blockIdx.x * 64 + wave * 16;
+    const int m0 = blockIdx.x * (64 * T) + wave * 16;
     const int my_row = m0 + i;
     f_off += blockIdx.y * F;
 
@@ -318,10 +323,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LN_CON
     // requires E <= LN_CONV_LDS_E): a per-lane global id load inside the loop is either waited for on the spot or, hoisted a
     // slot ahead by hand, sunk back to its use by the compiler.  Only the first slot's id comes straight from global memory,
     // beside that copy.
-    __shared__ int s_nbr[64 * LN_CONV_LDS_E];
+    __shared__ int s_nbr[64 * T * LN_CONV_LDS_E];
     {
-        const size_t g0 = (size_t)blockIdx.x * 64 * E, g_end = (size_t)m * E;
-        for (int x = tid; x < 64 * E; x += 256) s_nbr[x] = (g0 + x < g_end) ? nbr[g0 + x] : -1;
+        const size_t g0 = (size_t)blockIdx.x * (64 * T) * E, g_end = (size_t)m * E;
+        for (int x = tid; x < 64 * T * E; x += THREADS) s_nbr[x] = (g0 + x < g_end) ? nbr[g0 + x] : -1;
     }
     auto slot_of = [&](int e) -> int { return (FLIP && e < E - 1) ? (e ^ 1) : e; };
     const int* my_ids = s_nbr + ((tid >> 6) * 16 + i) * E;
@@ -340,15 +345,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LN_CON
         const u32x4* src = bank + ((size_t)e * gridDim.y + blockIdx.y) * BANK16;
 #pragma unroll
         for (int s = 0; s < W16; ++s) {
-            const int x = tid + s * 256;
-            if (BANK16 % 256 == 0 || x < BANK16) w_nxt[s] = src[x];
+            const int x = tid + s * THREADS;
+            if (BANK16 % THREADS == 0 || x < BANK16) w_nxt[s] = src[x];
         }
     };
     auto stage = [&]() {  // straight copy: the bank is already in fragment order
 #pragma unroll
         for (int s = 0; s < W16; ++s) {
-            const int x = tid + s * 256;
-            if (BANK16 % 256 == 0 || x < BANK16) s_b[x] = w_nxt[s];
+            const int x = tid + s * THREADS;
+            if (BANK16 % THREADS == 0 || x < BANK16) s_b[x] = w_nxt[s];
         }
     };
     int nb_nxt = my_row < m ? nbr[(size_t)my_row * E + slot_of(e_begin)] : -1, nb_nn = -1;
@@ -658,6 +663,20 @@ extern "C" size_t ln_conv_forward_workspace_bytes(int m, int filter_extent, int 
     return bank + (nsplit > 1 ? (size_t)nsplit * m * nr_filters * sizeof(float) : 0) + 256;
 }
 
+// Sub-tiles per workgroup of the bf16x3 per-slot kernel: 3 (one 768-thread workgroup per CU) where the kernel runs at three waves per
+// SIMD and there are at least as many such workgroups as CUs; LN_CONV_B3_T=1|3 forces it (A/B, read once).
+template <int V>
+static int ln_conv_b3_subtiles(int m, int chunks) {
+    static int forced = -1;
+    if (forced < 0) {
+        const char* e = getenv("LN_CONV_B3_T");
+        forced = e ? atoi(e) : 0;
+    }
+    if (LN_CONV_B3_WAVES(V) != 3) return 1;
+    if (forced == 1 || forced == 3) return forced;
+    return (long long)ln_div_up(m, 192) * chunks >= LN_BWD_CUS * 3 / 4 ? 3 : 1;
+}
+
 template <int V, bool FLIP, bool WT>
 static bool ln_conv_launch_v(int nr_filters, const int* nbr, const float* values, const float* filter, int m, int E, float* out,
                              void* workspace, size_t workspace_bytes, hipStream_t st) {
@@ -689,8 +708,14 @@ static bool ln_conv_launch_v(int nr_filters, const int* nbr, const float* values
                 if (b3) {                                                                                                           \
                     LN_LAUNCH("k_conv_split_bank", (k_conv_split_bank<V, NTC, WT>), dim3(ln_div_up(V * 16 * NTC, 256), E, cnt), block, 0, st, filter, \
                               nr_filters, f_off, bank + bank_off);                                                                  \
-                    LN_LAUNCH("k_conv_mfma", (k_conv_mfma_b3<V, NTC, FLIP>), dim3(ln_div_up(m, 64), cnt, nsplit), block, 0, st, nbr, values, \
-                              reinterpret_cast<const u32x4*>(bank + bank_off), m, E, dst, nr_filters, f_off, e_per);                \
+                    if (ln_conv_b3_subtiles<V>(m, cnt * nsplit) == 3) {                                                             \
+                        if constexpr (LN_CONV_B3_WAVES(V) == 3)                                                                     \
+                            LN_LAUNCH("k_conv_mfma", (k_conv_mfma_b3<V, NTC, FLIP, 3>), dim3(ln_div_up(m, 192), cnt, nsplit), dim3(768), 0, st, nbr, \
+                                      values, reinterpret_cast<const u32x4*>(bank + bank_off), m, E, dst, nr_filters, f_off, e_per); \
+                    } else {                                                                                                        \
+                        LN_LAUNCH("k_conv_mfma", (k_conv_mfma_b3<V, NTC, FLIP, 1>), dim3(ln_div_up(m, 64), cnt, nsplit), block, 0, st, nbr, values, \
+                                  reinterpret_cast<const u32x4*>(bank + bank_off), m, E, dst, nr_filters, f_off, e_per);            \
+                    }                                                                                                               \
                     bank_off += (size_t)E * cnt * V * 16 * NTC * 3;                                                                 \
                     done_b3 = true;                                                                                                 \
                 }                                                                                                                   \
