@@ -266,7 +266,7 @@ __global__ void __launch_bounds__(256)
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #ifndef LN_CONV_B3_PIPE
-#define LN_CONV_B3_PIPE(V) ((V) <= 96)  // fragments read one chain ahead: +12 registers, pays up to 96 channels (at 128 it spills at 3 waves)
+#define LN_CONV_B3_PIPE(V) ((V) <= 128)  // fragments read one chain ahead: +12 registers (the register estimate at the use decides: at 128 channels only with T = 3)
 #endif
 #ifndef LN_CONV_B3_DEEP
 #define LN_CONV_B3_DEEP(V) ((V) <= 96)
