@@ -1145,6 +1145,9 @@ typedef short gf_short4 __attribute__((ext_vector_type(4)));
 #ifndef LN_GFB_WAVES
 #define LN_GFB_WAVES 2
 #endif
+#ifndef LN_GFB_PROBE
+#define LN_GFB_PROBE 0  // timing ablations (wrong results): 1 no matrix products / fragment reads, 2 no gather, 4 no operand split
+#endif
 #ifndef LN_GFB_EG
 #define LN_GFB_EG 3   // slots per workgroup: E = 9 as three groups (gridDim.y); the gradient rows are split three times instead of nine
 #endif
@@ -1197,7 +1200,11 @@ __global__ void __launch_bounds__(256, LN_GFB_WAVES)
             const int x4 = tid + 256 * k;
             const int c4 = x4 % (V / 4);
             ra[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+#if LN_GFB_PROBE & 2
+            ra[k] = make_float4(1.f + nb[k], 2.f, 3.f + c4, 4.f);
+#else
             if (nb[k] >= 0) ra[k] = *reinterpret_cast<const float4*>(values + (size_t)nb[k] * v_total + v_off + c4 * 4);
+#endif
         }
     };
     auto fetch_g = [&](int sub) {
@@ -1212,10 +1219,15 @@ __global__ void __launch_bounds__(256, LN_GFB_WAVES)
     };
     auto stage = [&](const float4& x, unsigned short* dst, int plane) {  // four consecutive channels of one row -> three planes
         unsigned int h[4], md[4], lo[4];
+#if LN_GFB_PROBE & 4
+        h[0] = md[0] = lo[0] = __float_as_uint(x.x); h[1] = md[1] = lo[1] = __float_as_uint(x.y);
+        h[2] = md[2] = lo[2] = __float_as_uint(x.z); h[3] = md[3] = lo[3] = __float_as_uint(x.w);
+#else
         ln_split3_bits(x.x, h[0], md[0], lo[0]);
         ln_split3_bits(x.y, h[1], md[1], lo[1]);
         ln_split3_bits(x.z, h[2], md[2], lo[2]);
         ln_split3_bits(x.w, h[3], md[3], lo[3]);
+#endif
         *reinterpret_cast<uint2*>(dst) = make_uint2((h[0] >> 16) | h[1], (h[2] >> 16) | h[3]);
         *reinterpret_cast<uint2*>(dst + plane) = make_uint2((md[0] >> 16) | md[1], (md[2] >> 16) | md[3]);
         *reinterpret_cast<uint2*>(dst + 2 * plane) = make_uint2((lo[0] >> 16) | lo[1], (lo[2] >> 16) | lo[3]);
@@ -1268,7 +1280,7 @@ __global__ void __launch_bounds__(256, LN_GFB_WAVES)
                 fetch_ids(sub + LN_GFB_SUB);
             }
 #pragma unroll
-            for (int st = 0; st < LN_GFB_SUB / 32; ++st) {
+            for (int st = 0; st < ((LN_GFB_PROBE & 1) ? 0 : LN_GFB_SUB / 32); ++st) {
                 const int row0 = 32 * st + 8 * q + (i >> 2);
                 bf16x8 fa[TPV][3], fb[TPF][3];
 #pragma unroll
