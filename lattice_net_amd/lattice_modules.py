@@ -124,6 +124,11 @@ def _identity_rows(device, rows: int) -> torch.Tensor:
     return bufs[-1][:rows]
 
 
+def _conv_workspace(lib, rows: int, cin: int, cout: int, device):
+    nbytes = int(lib.ln_conv_forward_workspace_bytes(rows, 1, cin, cout))
+    return torch.empty((nbytes,), dtype=torch.uint8, device=device) if nbytes > 256 else None
+
+
 class LinearMfmaFunction(torch.autograd.Function):
     """y = x @ w^T for a per-vertex 1x1 layer (GnRelu1x1 and friends: no bias, no activation) on the MFMA kernels of the lattice
     convolution (csrc/ln_conv.hip) — a convolution with a filter extent of 1 over the identity neighbour list; `w` [cout, cin]
@@ -138,8 +143,10 @@ class LinearMfmaFunction(torch.autograd.Function):
         cout = w.shape[0]
         ident = _identity_rows(x.device, rows)
         y = torch.empty((rows, cout), dtype=torch.float32, device=x.device)
-        _lib.check(lib.ln_conv_forward(_lib.ptr(ident), _lib.ptr(x), _lib.ptr(w), rows, 1, cin, cout, 2, _lib.ptr(y), _lib.stream_ptr(x.device)),
-                   "ln_conv_forward(1x1)")  # 2 = LN_CONV_TRANSPOSED_FILTER
+        # with its workspace the convolution takes the bf16x3 kernel from 4096 rows on (widths that are multiples of 32 / 16)
+        ws = _conv_workspace(lib, rows, cin, cout, x.device)
+        _lib.check(lib.ln_conv_forward_ws(_lib.ptr(ident), _lib.ptr(x), _lib.ptr(w), rows, 1, cin, cout, 2, _lib.ptr(y), _lib.ptr(ws),
+                                          0 if ws is None else ws.numel(), _lib.stream_ptr(x.device)), "ln_conv_forward(1x1)")  # 2 = LN_CONV_TRANSPOSED_FILTER
         ctx.save_for_backward(x, w)
         return y
 
@@ -156,8 +163,9 @@ class LinearMfmaFunction(torch.autograd.Function):
         gx = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
-            _lib.check(lib.ln_conv_forward(_lib.ptr(ident), _lib.ptr(grad_y), _lib.ptr(w), rows, 1, cout, cin, 0, _lib.ptr(gx), stream),
-                       "ln_conv_forward(1x1, grad_x)")
+            ws_x = _conv_workspace(lib, rows, cout, cin, dev)
+            _lib.check(lib.ln_conv_forward_ws(_lib.ptr(ident), _lib.ptr(grad_y), _lib.ptr(w), rows, 1, cout, cin, 0, _lib.ptr(gx), _lib.ptr(ws_x),
+                                              0 if ws_x is None else ws_x.numel(), stream), "ln_conv_forward(1x1, grad_x)")
         gw = torch.empty_like(w)
         ws = torch.empty((lib.ln_conv_grad_filter_workspace_bytes(rows, 1, cout, cin),), dtype=torch.uint8, device=dev)
         _lib.check(lib.ln_conv_grad_filter(_lib.ptr(ident), _lib.ptr(grad_y), _lib.ptr(x), rows, 1, cout, cin, _lib.ptr(gw), _lib.ptr(ws), ws.numel(),
