@@ -445,6 +445,33 @@ def test_conv_one_hot_bank_every_instance(v, sigma):
             assert bad.size == 0, (f, flip, bad[:8].tolist(), got[tuple(bad[0])], exp[tuple(bad[0])])
 
 
+@pytest.mark.parametrize("d,sigma,n,three_subtiles", [(2, 0.008, 60000, True), (4, 0.22, 20000, False), (2, 0.02, 60000, False), (4, 0.1, 20000, True)])
+def test_conv_one_hot_bank_other_dimensions(d, sigma, n, three_subtiles):
+    """The bf16x3 per-slot kernel takes the filter extent at run time (7 slots for d = 2, 11 for d = 4; neighbour ids staged in LDS for
+    E <= 16): large lattices in two and four dimensions, one and three sub-tiles per workgroup, one-hot bank, exact."""
+    from lattice_net_amd.synthetic import cube_cloud
+    lat = make_lattice(sigma, 400000, d)
+    lat.begin_splat()
+    lat.just_create_verts(T(cube_cloud(n, 3, d=d)), False)
+    m, E = lat.nr_lattice_vertices(), 2 * (d + 1) + 1
+    assert (m >= 36864) if three_subtiles else (4096 <= m <= 36672), m
+    rng = np.random.default_rng(d)
+    for v, f in ((64, 80), (128, 64), (32, 48)):
+        vals = rng.integers(-7, 8, (m, v)).astype(np.float32)
+        lat.set_values(T(vals))
+        for flip in (False, True):
+            slot = rng.integers(0, E, f)
+            chan = rng.integers(0, v, f)
+            gain = rng.integers(1, 4, f).astype(np.float32)
+            bank = np.zeros((E, v, f), np.float32)
+            bank[slot, chan, np.arange(f)] = gain
+            got = N(lat.convolve_im2row_standalone(T(bank.reshape(E * v, f)), 1, lat, flip).values())
+            rows = N(lat.im2row(lat, E, 1, flip)).reshape(m, E, v)
+            exp = rows[:, slot, chan] * gain[None, :]
+            bad = np.argwhere(got != exp)
+            assert bad.size == 0, (d, m, v, f, flip, bad[:8].tolist())
+
+
 @pytest.mark.parametrize("v,f", [(32, 32), (64, 32), (96, 96), (128, 64), (128, 128), (32, 80), (64, 64), (64, 192), (96, 32), (32, 64), (32, 96),
                                  (160, 96), (64, 128), (192, 48), (256, 64)])
 def test_conv_large_lattice_split_bf16_path(v, f):
