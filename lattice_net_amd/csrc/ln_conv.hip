@@ -610,7 +610,9 @@ __global__ void __launch_bounds__(256) ln_k_sum_partials(const float* __restrict
 }
 
 // Split of the per-slot convolution over the filter slots: 1 (no split) while the vertex tiles alone fill the chip.
+#ifndef LN_CONV_SPLIT_TILES
 #define LN_CONV_SPLIT_TILES 512  // workgroups aimed at (two per CU)
+#endif
 template <int V>
 static int ln_conv_slots_per_split(int m, int E, int nr_filters) {
     constexpr int NT_MAX = (V * 16 * 8 * 4 <= 32 * 1024) ? 8 : ((V * 16 * 4 * 4 <= 48 * 1024) ? 4 : 2);

@@ -21,6 +21,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--shapes", default="64x64,128x128,64x128,128x64,96x96,32x64,256x256")
+    ap.add_argument("--coarse", type=int, default=0, help="time on the level-2 (1) or level-3 (2) lattice of the same cloud instead of the finest")
     ap.add_argument("--row-order", default="", help="canonical: rows numbered in first-occurrence order (ln_canonicalize) instead of slot order")
     a = ap.parse_args()
     import lattice_net_amd as L
@@ -34,6 +35,8 @@ def main():
     lat = L.Lattice(sigmas=[0.9] * 3, capacity=100000, device=dev)
     lat.begin_splat()
     dl, _, _, _ = lat.distribute(pos, torch.zeros((120000, 1), device=dev))
+    for _ in range(a.coarse):
+        dl = dl.create_coarse_verts_naive(pos)
     m = dl.nr_lattice_vertices()
     nbr = dl.neighbours(dl, 1, False).long()
     torch.manual_seed(1)
