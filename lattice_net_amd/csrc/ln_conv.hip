@@ -377,7 +377,8 @@ __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(LN
             issue(e + 1, nb_nxt, a_nxt);
 #endif
         }
-        constexpr bool PIPE = LN_CONV_B3_PIPE(V);
+        // (at 128 channels with one sub-tile per workgroup the staged bank slice takes 24-48 registers per thread: the double buffer spills there)
+        constexpr bool PIPE = LN_CONV_B3_PIPE(V) && (V <= 96 || T == 3 || NT == 1);
         u32x4 fb[2][3];
         if constexpr (PIPE) {
 #pragma unroll
