@@ -48,6 +48,89 @@ WORKLOADS = {
                desc="C5 4 aggregated scans: 480k pts, capacity 400k, V=F=64, fp16 features / fp32 accumulate in the convolution"),
 }
 
+FINAL_LINE_LIMIT = 4096  # bytes: the driver keeps only the tail of stdout, so the LAST line must stay far below that
+
+
+def _pick(src, keys):
+    return {k: src[k] for k in keys if isinstance(src, dict) and k in src and src[k] is not None}
+
+
+def compact_line(full: dict, details_file: str = "bench_details.json") -> dict:
+    """The ONE line the driver parses: headline, config, roofline of the dominant kernel group, the splat+slice fractions and
+    the CPU baseline.  Everything else of `full` (per-operator table, other kernels, stages, latency, whole-network step,
+    prose) lives in `details_file` and on an earlier stdout line prefixed `DETAILS `.  Optional keys are dropped, last first,
+    until the line fits FINAL_LINE_LIMIT; the contract keys never are."""
+    cfg = full.get("config") or {}
+    line = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                     "scaling", "vs_baseline", "dtype", "data")}
+    line["config"] = _pick(cfg, ("workload", "points_per_gpu", "vertices", "val_dim", "nr_filters", "scans_in_flight",
+                                 "clouds_per_scan_pool", "sharding", "checksum"))
+    if isinstance(line["config"].get("workload"), str):
+        line["config"]["workload"] = line["config"]["workload"][:240]
+    line["roofline"] = (_pick(full.get("roofline"), ("bound", "kernel", "avg_us", "achieved", "peak", "unit", "frac", "traffic"))
+                        if full.get("roofline") else None)
+    if line["roofline"] is not None:
+        line["roofline"].setdefault("traffic", None)
+    cpu = full.get("cpu_baseline")
+    line["cpu_baseline"] = (_pick(cpu, ("value", "unit", "cores", "kind", "sample")) if cpu else None)
+    if line["cpu_baseline"] and isinstance(line["cpu_baseline"].get("sample"), str):
+        line["cpu_baseline"]["sample"] = line["cpu_baseline"]["sample"][:160]
+    optional = []  # (key, value), most important first
+    optional.append(("value_8d_one_pass_mpoints_per_s", full.get("value_8d_one_pass_mpoints_per_s")))
+    st = full.get("stages") or {}
+    ss = {}
+    for key, short in (("splat_plus_slice", "one_scan"), ("splat_plus_slice_in_flight", "in_flight")):
+        if isinstance(st.get(key), dict) and "frac_of_hbm_peak" in st[key]:
+            ss[short] = st[key]["frac_of_hbm_peak"]
+    optional.append(("splat_plus_slice_frac_of_hbm_peak", ss or None))
+    c1 = full.get("cpu_baseline_1thread")
+    optional.append(("cpu_baseline_1thread", _pick(c1, ("value", "unit", "cores")) if c1 else None))
+    lat = full.get("latency") or {}
+    optional.append(("latency_us", _pick(lat, ("us_per_scan_median", "eager_us_per_scan")) or None))
+    un = full.get("full_unet") or {}
+    unet = _pick(un, ("ms_per_step",))
+    if isinstance(un.get("graph"), dict) and "ms_per_step" in un["graph"]:
+        unet["graph_ms_per_step"] = un["graph"]["ms_per_step"]
+    optional.append(("full_unet_ms", unet or None))
+    for k in ("ms_per_step_min_over_ranks", "ms_per_step_max_over_ranks"):
+        optional.append((k, full.get(k)))
+    cc = full.get("hbm_copy_ceiling") or {}
+    optional.append(("hbm_copy_ceiling_GBs", cc.get("GBs")))
+    optional.append(("details_file", details_file))
+    for k, val in optional:
+        if val is not None:
+            line[k] = val
+    dropped = []
+    for k, _ in reversed(optional[:-1]):
+        if len(json.dumps(line)) < FINAL_LINE_LIMIT - 256:
+            break
+        if k in line:
+            dropped.append(k)
+            del line[k]
+    if len(json.dumps(line)) >= FINAL_LINE_LIMIT - 256:  # still too long: only the two free-text fields can be the cause
+        line["config"]["workload"] = str(line["config"].get("workload", ""))[:80]
+        if line.get("cpu_baseline"):
+            line["cpu_baseline"].pop("sample", None)
+    if dropped:
+        line["dropped_for_length"] = dropped
+    return line
+
+
+def emit(full: dict, details_path: str | None = None) -> dict:
+    """Write `full` to bench_details.json, print it on a `DETAILS ` line, then print the compact line LAST."""
+    details_path = details_path or os.path.join(ROOT, "bench_details.json")
+    try:
+        with open(details_path, "w") as fh:
+            json.dump(full, fh, indent=1)
+    except OSError as ex:  # a read-only tree must not cost the headline
+        print(f"[bench] could not write {details_path}: {ex}", file=sys.stderr)
+    line = compact_line(full, os.path.basename(details_path))
+    text = json.dumps(line)
+    assert len(text) < FINAL_LINE_LIMIT, len(text)
+    print("DETAILS " + json.dumps(full), flush=True)
+    print(text, flush=True)  # the last line on stdout
+    return line
+
 
 def make_cloud(kind: str, n: int, seed: int) -> np.ndarray:
     from lattice_net_amd import synthetic
@@ -317,6 +400,8 @@ def main():
 
     from lattice_net_amd import sharding
     world, rank, local_rank = sharding.env_world()
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    cores = sharding.pin_launch_thread(local_rank, local_world)  # before anything touches the GPU
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the lattice backend has no CPU path)")
     # LATTICE_BENCH_SHARE_GPU=1 (testing aid for a one-GPU box): every rank runs on GPU 0 and the ranks talk over gloo,
@@ -344,10 +429,10 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         if rank == 0:
-            print(json.dumps({"metric": "per-operator roofline table, SURVEY 8(a) rows outside the headline chain (tools/ops_roofline.py)",
-                              "value": None, "unit": "us per call, GB/s, TFLOP/s (see entries)", "n_gpus": 1, "data": "synthetic",
-                              "config": {"workload": "C3 scan (120k LiDAR-like points, sigma 0.9, capacity 100k), SemanticKITTI network widths"},
-                              **table}), flush=True)
+            emit({"metric": "per-operator roofline table, SURVEY 8(a) rows outside the headline chain (tools/ops_roofline.py)",
+                  "value": None, "unit": "us per call, GB/s, TFLOP/s (see entries)", "n_gpus": 1, "data": "synthetic",
+                  "config": {"workload": "C3 scan (120k LiDAR-like points, sigma 0.9, capacity 100k), SemanticKITTI network widths"},
+                  **table}, os.path.join(ROOT, "bench_ops_details.json"))
         return
     cfg = WORKLOADS[args.workload]
     n, v, f, sigma, cap = cfg["n"], cfg["v"], cfg["f"], cfg["sigma"], cfg["capacity"]
@@ -472,7 +557,7 @@ def main():
             cs.check()
     checksum_local = sum(float(c["state"]["out"].double().abs().sum().item()) for cs in sets for c in cs.clouds if "out" in c["state"])
     m_all = [[c.get("m_real", c["state"].get("m")) for c in cs.clouds] for cs in sets]
-    max_elapsed = sharding.max_over_ranks(dist, elapsed, dev)
+    min_elapsed, max_elapsed = sharding.min_max_over_ranks(dist, elapsed, dev)
     checksum = sharding.gather_sum(dist, checksum_local, dev)
     cs0 = sets[0]
     m = int(np.mean([x for x in m_all[0] if x]))  # vertices of a typical scan (the algorithmic byte counts below use it)
@@ -736,7 +821,11 @@ def main():
                        "vertices_per_scan": m_all, "graph_vs_eager": graph_err},
             "latency": latency, "roofline": roofline, "roofline_others": others, "stages": stages, "hbm_copy_ceiling": copy_ceiling,
             "full_unet": unet, "ops": ops_table, "cpu_baseline": cpu, "cpu_baseline_1thread": cpu1,
+            "host_cores_of_rank0": len(cores),
         }
+        if world > 1:  # spread of the ranks' own clocks over the same K steps (value uses the max)
+            line["ms_per_step_min_over_ranks"] = round(min_elapsed / args.steps * 1e3, 4)
+            line["ms_per_step_max_over_ranks"] = round(max_elapsed / args.steps * 1e3, 4)
     try:  # RCCL prints a version banner through C stdio, which a pipe buffers until exit: every rank flushes it now
         C.CDLL(None).fflush(None)
     except OSError:
@@ -745,7 +834,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(line), flush=True)  # the last line on stdout
+        emit(line)
 
 
 if __name__ == "__main__":

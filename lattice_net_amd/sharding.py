@@ -26,7 +26,8 @@ def init(backend: str, device=None):
         # Launchers (torch.distributed.run, the tests) set the port.  Without one every rank must still arrive at the SAME port
         # whatever started it (one shell or ssh session per rank, container entrypoints): a fixed default, outside torchrun's own
         # 29500.  Two jobs side by side on one host have to be given different MASTER_PORTs by whoever starts them.
-        os.environ["MASTER_PORT"] = "29511"
+        # LATTICE_JOB_ID (any integer) moves the default so that two launcher-less jobs on one host do not meet in one store.
+        os.environ["MASTER_PORT"] = str(29511 + int(os.environ.get("LATTICE_JOB_ID", "0")) % 2000)
     import datetime
     kwargs["timeout"] = datetime.timedelta(seconds=int(os.environ.get("LATTICE_RENDEZVOUS_TIMEOUT_S", "600")))
     if backend == "nccl" and device is not None:
@@ -37,6 +38,24 @@ def init(backend: str, device=None):
         raise RuntimeError(f"rendezvous of rank {rank}/{world} at {os.environ['MASTER_ADDR']}:{os.environ['MASTER_PORT']} failed "
                            f"({type(exc).__name__}: {exc}); every rank needs the same MASTER_ADDR / MASTER_PORT") from exc
     return dist
+
+
+def pin_launch_thread(local_rank: int, local_world: int) -> List[int]:
+    """Pins the calling (kernel-launching) thread's process to an own slice of the host's cores BEFORE the first GPU call: a
+    step of the hot path is ~100 us of GPU time, so the launch thread is on the critical path, and eight unpinned ranks migrate
+    across sockets.  The cores this process may already use are cut into `local_world` contiguous slices (contiguous logical
+    CPUs share a NUMA node on the MI355X hosts); rank r takes slice r.  LATTICE_NO_AFFINITY=1 opts out; a no-op for one rank
+    or without sched_setaffinity.  Returns the cores in use afterwards."""
+    have = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else []
+    if local_world <= 1 or os.environ.get("LATTICE_NO_AFFINITY") or len(have) < 2 * local_world:
+        return have
+    per = len(have) // local_world
+    mine = have[local_rank * per:(local_rank + 1) * per]
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return have
+    return mine
 
 
 def clouds_of_rank(num_clouds: int, world: int, rank: int) -> List[int]:
@@ -61,6 +80,14 @@ def max_over_ranks(dist, value: float, device) -> float:
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def min_max_over_ranks(dist, value: float, device):
+    """(min, max) of `value` over the ranks (one all-reduce of the pair [-v, v] with MAX)."""
+    t = torch.tensor([-value, value], dtype=torch.float64, device=device)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(-t[0].item()), float(t[1].item())
 
 
 def gather_sum(dist, value: float, device) -> float:

@@ -152,3 +152,62 @@ def test_captured_network_step_rejects_a_non_capturable_optimizer():
     opt = torch.optim.AdamW([p], lr=1e-3)
     with pytest.raises(ValueError, match="capturable"):
         CapturedNetworkStep(lambda: None, None, [p], optimizer=opt)
+
+
+def test_bench_final_line_is_short_whatever_the_details_hold():
+    """bench.compact_line: the contract keys, the roofline and the CPU baseline survive; bulk (per-operator table, prose, per-scan
+    vertex tables) never reaches the line the driver tails (round 4's 20 KB line could not be parsed)."""
+    import json
+    import bench
+    full = {"metric": "Mpoints/sec splat+conv+slice fwd+bwd on 120k-pt SemanticKITTI scan", "value": 1270.15, "unit": "Mpoints/s", "n_gpus": 8,
+            "steps": 20, "warmup": 5, "ms_per_step": 0.0945, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (convolution products bf16x3-emulated)", "dtype_note": "x" * 5000, "data": "synthetic",
+            "value_8d_one_pass_mpoints_per_s": 903.9, "ms_per_step_min_over_ranks": 0.09, "ms_per_step_max_over_ranks": 0.0945,
+            "config": {"workload": "C3 " + "w" * 3000, "points_per_gpu": 120000, "vertices": 46482, "val_dim": 32, "nr_filters": 32,
+                       "scans_in_flight": 4, "clouds_per_scan_pool": 8, "sharding": "8 rank(s)", "checksum": 1.5,
+                       "vertices_per_scan": [[46482] * 8] * 4, "row_bounds": [50000] * 4},
+            "latency": {"us_per_scan_median": 132.8, "eager_us_per_scan": 206.0, "what": "y" * 500},
+            "roofline": {"bound": "hbm", "achieved": 175.1, "peak": 8000.0, "unit": "GB/s", "frac": 0.0219, "mfma": None, "traffic": 45452229,
+                         "kernel": "k_point_keys+k_bucket_rows", "avg_us": 33.33, "timing": "z" * 900},
+            "roofline_others": [{"kernel": "k", "note": "n" * 400}] * 8,
+            "stages": {"us": {"splat": 96.0}, "splat_plus_slice": {"frac_of_hbm_peak": 0.1008, "what": "q" * 300},
+                       "splat_plus_slice_in_flight": {"frac_of_hbm_peak": 0.1643}},
+            "hbm_copy_ceiling": {"GBs": 5170.1, "what": "copy"}, "full_unet": {"ms_per_step": 5.29, "graph": {"ms_per_step": 4.08}},
+            "ops": {"entries": [{"row": "a%d" % i, "note": "o" * 700} for i in range(20)]},
+            "cpu_baseline": {"value": 0.618, "unit": "Mpoints/s", "cores": 16, "kind": "port", "sample": "s" * 2000, "other_thread_counts": [1] * 50},
+            "cpu_baseline_1thread": {"value": 0.45, "unit": "Mpoints/s", "cores": 1, "kind": "port", "sample": "t" * 2000}}
+    assert len(json.dumps(full)) > 20000
+    line = bench.compact_line(full)
+    text = json.dumps(line)
+    assert len(text) < 4096 - 256 and json.loads(text) == line
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert line[k] == full[k]
+    assert line["roofline"] == {"bound": "hbm", "kernel": "k_point_keys+k_bucket_rows", "avg_us": 33.33, "achieved": 175.1, "peak": 8000.0,
+                                "unit": "GB/s", "frac": 0.0219, "traffic": 45452229}
+    assert line["cpu_baseline"]["value"] == 0.618 and line["cpu_baseline"]["cores"] == 16 and line["cpu_baseline"]["kind"] == "port"
+    assert line["config"]["workload"].startswith("C3 ") and line["config"]["points_per_gpu"] == 120000 and "vertices_per_scan" not in line["config"]
+    assert line["splat_plus_slice_frac_of_hbm_peak"] == {"one_scan": 0.1008, "in_flight": 0.1643}
+    assert line["value_8d_one_pass_mpoints_per_s"] == 903.9 and line["ms_per_step_max_over_ranks"] == 0.0945
+    assert "ops" not in line and "roofline_others" not in line and line["details_file"] == "bench_details.json"
+    # a line without the optional legs (profiling runs: --extras 0 --cpu-seconds 0) and with traffic unknown
+    bare = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                 "vs_baseline", "dtype", "data", "config")}
+    bare.update(roofline={"bound": "hbm", "achieved": 1.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.0001, "kernel": "k", "avg_us": 1.0},
+                cpu_baseline=None, stages=None, latency=None, full_unet=None)
+    line = bench.compact_line(bare)
+    assert line["roofline"]["traffic"] is None and line["cpu_baseline"] is None and len(json.dumps(line)) < 2048
+
+
+def test_launch_thread_pinning_cuts_the_allowed_cores_into_rank_slices():
+    import os
+    from lattice_net_amd import sharding
+    have = sorted(os.sched_getaffinity(0))
+    try:
+        assert sharding.pin_launch_thread(0, 1) == have  # one rank: untouched
+        if len(have) >= 4:
+            mine = sharding.pin_launch_thread(1, 2)
+            assert mine == have[len(have) // 2: 2 * (len(have) // 2)] and sorted(os.sched_getaffinity(0)) == mine
+    finally:
+        os.sched_setaffinity(0, have)
+    lo, hi = sharding.min_max_over_ranks(None, 2.5, "cpu")
+    assert (lo, hi) == (2.5, 2.5)
