@@ -249,7 +249,7 @@ def cpu_baseline(cfg, seconds: float, threads: int = 0, min_steps: int = 3):
     finally:
         torch.set_num_threads(before)
     med = float(np.median(times))
-    return {"value": n / med / 1e6, "unit": "Mpoints/s", "cores": used, "kind": "port",
+    return {"value": round(n / med / 1e6, 4), "unit": "Mpoints/s", "cores": used, "kind": "port",
             "sample": f"{len(times)} full-size steps of the same workload (median {med * 1e3:.1f} ms/step), "
                       f"pure-PyTorch CPU fallback oracle/torch_fallback.py, torch threads={used}, os.cpu_count()={os.cpu_count()}"}
 
