@@ -462,6 +462,311 @@ __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(LN
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Per-slot convolution, wide form (k_conv_rows32_b3): the same bf16x3 contraction on v_mfma_f32_32x32x16_bf16 with BOTH operands
+// arriving in LDS by LDS-DMA (global_load_lds_dwordx4), no staging registers:
+//   * A (gathered rows).  Measured with tools/probes/gather_layout_probe.cpp at 46 538 rows x 9 slots x 512 B: loads shaped like the
+//     MFMA fragment (lane (i, q) reads its quarter of row i: 64 lines touched per wave-instruction) gather at 3.5 TB/s = 61 us per pass
+//     whatever the cache hit rate; 8 adjacent lanes per 128-byte line gather at 7.0 TB/s = 31 us.  k_conv_mfma_b3 gathers fragment-shaped
+//     AND once per 64-column chunk (two passes at 128 filters): its 100 us at 128 x 128 is that gather.  Here a wave fetches the
+//     32-channel chunk of its 32 rows as 4 wave-instructions of 8 rows x 128 B into a private 4 KB LDS region (no workgroup barrier
+//     for A: the wave's own vmcnt orders it), ONCE for all output columns of the launch, and reads its fragments with ds_read_b128.
+//     The region is XOR-swizzled through the SOURCE addresses (the DMA writes lane-linear): 16-byte column c of row r sits at
+//     position c ^ ((r >> 1) & 7), conflict-free for the four 16-lane groups of ds_read_b128.
+//   * B (the pre-split bank, k_conv_split_bank32) comes in chunks of 32 channels x (32 NT) columns x 3 parts = 6 NT KB, double
+//     buffered: ONE barrier per chunk, and every 1 KB fragment read from LDS feeds 32 rows (the 16-row form: 16).
+// Workgroup = 4 waves x 32 rows; 64 KB of LDS at 128 columns -> two workgroups per CU, whose barriers overlap.
+// Absent neighbours and rows past m read a zero row, so the DMA needs no predication.
+// ------------------------------------------------------------------------------------------
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+// One LDS-DMA wave-instruction (64 lanes x 16 bytes -> LDS bytes [lds_dst, lds_dst + 1024)), issued from inline asm so that hipcc
+// does not know an LDS write is pending: with the builtin it puts `s_waitcnt vmcnt(0)` in front of the next ds_read of ANY LDS
+// object, i.e. waits for the chunk just requested.  The kernel orders the data itself (counted vmcnt + barrier).  hipcc's own vmcnt
+// accounting stays safe: it only ever assumes FEWER loads outstanding than there are, so its waits are stricter, never laxer.
+__device__ __forceinline__ void ln_glds16(const void* gsrc, unsigned int lds_dst) {
+    unsigned int keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+__device__ __forceinline__ unsigned int ln_lds_addr(const void* p) {
+    return (unsigned int)(size_t)(__attribute__((address_space(3))) const char*)(const char*)p;
+}
+__device__ __attribute__((aligned(256))) float g_ln_zero_row[1024];  // zero-initialised: the source of absent neighbours' rows
+
+// Bank for k_conv_rows32_b3: [e][y][kc][(s * NT + nt) * 3 + part][lane = h * 32 + n][8 bf16] with
+// value = part of W[e][kc * 32 + s * 16 + h * 8 + j][f_off + (y * NT + nt) * 32 + n]
+template <int V, int NT, bool WT>
+__global__ void __launch_bounds__(256)
+    k_conv_split_bank32(const float* __restrict__ filter, int f_total, int f_off, unsigned short* __restrict__ bank) {
+    constexpr int F = 32 * NT;
+    constexpr int CHUNK = 2 * NT * 3 * 64 * 8;  // bf16 elements per (slot, column chunk, channel chunk)
+    const int e = blockIdx.y;
+    const int y = blockIdx.z;
+    const int fo = f_off + y * F;
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= V * F) return;
+    const int k = WT ? (x % V) : (x / F);
+    const int f = WT ? (x / V) : (x - k * F);
+    const size_t src = WT ? ((size_t)e * f_total + fo + f) * V + k : ((size_t)e * V + k) * f_total + fo + f;
+    unsigned int h, md, l;
+    ln_split3_bits(filter[src], h, md, l);
+    const int kc = k >> 5, s = (k >> 4) & 1, hh = (k >> 3) & 1, j = k & 7;
+    unsigned short* dst = bank + (((size_t)e * gridDim.z + y) * (V / 32) + kc) * CHUNK;
+    const int base = (((s * NT + (f >> 5)) * 3) * 64 + hh * 32 + (f & 31)) * 8 + j;
+    dst[base] = (unsigned short)(h >> 16);
+    dst[base + 64 * 8] = (unsigned short)(md >> 16);
+    dst[base + 2 * 64 * 8] = (unsigned short)(l >> 16);
+}
+
+// -DLN_STAMPS builds: per-wave phase accounting of k_conv_rows32_b3 (tools/probes/r32_phase_probe.py) with s_memtime (shader
+// cycles; its lgkmcnt wait falls on phase boundaries where no LDS read is outstanding or all are about to be consumed)
+#ifdef LN_STAMPS
+#define LN_R32_CYC() ((unsigned)__builtin_amdgcn_s_memtime())
+#define LN_R32_PHASE(k)                                           \
+    do {                                                          \
+        __builtin_amdgcn_sched_barrier(0);                        \
+        const unsigned now_ = LN_R32_CYC();                       \
+        ph[k] += (now_ - t_prev) & 0xFFFFFu;                      \
+        t_prev = now_;                                            \
+        __builtin_amdgcn_sched_barrier(0);                        \
+    } while (0)
+#else
+#define LN_R32_PHASE(k) do { } while (0)
+#endif
+#ifndef LN_CONV_R32_SPREAD
+#define LN_CONV_R32_SPREAD 0
+#endif
+#ifndef LN_CONV_R32_PROBE
+#define LN_CONV_R32_PROBE 0  // timing ablations (wrong results): 1 no matrix products, 2 no operand split, 4 no A gather (one row), 8 no B staging
+#endif
+// Workgroup = RT row tiles of 32 rows x CH column groups of 32 NTW columns: RT * CH waves, wave (rt, ch) owns the [32 x 32 NTW]
+// block of the output.  The CH waves of a row tile share its gathered A chunk (double buffered: the partner may still be reading
+// while the next one is requested) and request a CH-th of its four pieces each.  At 128 columns: RT = 6, CH = 2, NTW = 2 — twelve
+// waves (three per SIMD, covering each other's LDS reads and operand splits), 192 rows, 108 KB of LDS, one workgroup per CU,
+// 243 workgroups for the 46.5 k rows of the SemanticKITTI lattice (four waves x 32 rows x 128 columns with two workgroups per CU
+// measured 89 us there: 108 CUs hold two of the 364 workgroups and a lone wave per SIMD leaves the matrix pipe idle during its
+// 1100-cycle prelude of LDS reads and splits — tools/probes/r32_phase_probe.py).
+template <int V, int NTW, int CH, int RT, bool FLIP>
+__global__ void __launch_bounds__(64 * RT * CH) __attribute__((amdgpu_waves_per_eu((RT * CH + 3) / 4, (RT * CH + 3) / 4)))
+    k_conv_rows32_b3(const int* __restrict__ nbr, const float* __restrict__ values, const u32x4* __restrict__ bank, int m, int E,
+                     float* __restrict__ out, int f_total, int f_off, int e_per) {
+    const int e_begin = blockIdx.z * e_per;  // slot split, as in k_conv_mfma
+    const int e_end = min(E, e_begin + e_per);
+    out += (size_t)blockIdx.z * m * f_total;
+    constexpr int NT = NTW * CH;             // 32-column tiles of the workgroup
+    constexpr int W = RT * CH;               // waves
+    constexpr int R = 32 * RT;               // rows
+    constexpr int NKC = V / 32;              // channel chunks per slot
+    constexpr int BCH16 = 2 * NT * 3 * 64;   // 16-byte fragments of one bank chunk (1 KB = 64 of them per wave-instruction)
+    constexpr int BPIECES = BCH16 / 64;      // 6 NT wave-instructions per chunk
+    constexpr int BPW = (BPIECES + W - 1) / W;  // ... per wave
+    constexpr int APW = 4 / CH;              // A pieces per wave (of the four of its row tile)
+    constexpr int G = 2 * NTW;               // MFMA groups (K-step, column tile) per chunk and wave: 6 products each
+    static_assert(V % 32 == 0 && (CH == 1 || CH == 2 || CH == 4) && W <= 16, "rows32 shape");
+    __shared__ u32x4 s_b[2][BCH16];
+    __shared__ u32x4 s_a[CH > 1 ? 2 : 1][RT][256];  // per row tile: 32 rows x 8 positions of 16 bytes
+    __shared__ int s_nbr[R * LN_CONV_LDS_E];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rt = wave / CH, ch = wave % CH;
+    const int i = lane & 31;
+    const int h = lane >> 5;
+    const int m0 = blockIdx.x * R + rt * 32;
+    f_off += blockIdx.y * (32 * NT) + ch * (32 * NTW);
+    {
+        const size_t g0 = (size_t)blockIdx.x * R * E, g_end = (size_t)m * E;
+        for (int x = tid; x < R * E; x += 64 * W) s_nbr[x] = (g0 + x < g_end) ? nbr[g0 + x] : -1;
+    }
+    auto slot_of = [&](int e) -> int { return (FLIP && e < E - 1) ? (e ^ 1) : e; };
+    // A piece j of a row tile covers its rows 8j .. 8j+7: lane -> (row 8j + (lane >> 3), position lane & 7); this wave requests
+    // pieces ch * APW .. ch * APW + APW - 1
+    const int a_row = lane >> 3;
+    const int* my_ids = s_nbr + (rt * 32 + ch * APW * 8 + a_row) * E;
+    const unsigned int lds_b = __builtin_amdgcn_readfirstlane(ln_lds_addr(&s_b[0][0]));
+    const unsigned int lds_a = __builtin_amdgcn_readfirstlane(ln_lds_addr(&s_a[0][0][0]) + (unsigned)(rt * 4096 + ch * APW * 1024));
+    const u32x4* bank_y = bank + (size_t)blockIdx.y * NKC * BCH16 + lane;   // + e * gridDim.y * NKC * BCH16 + kc * BCH16
+    const size_t bank_e = (size_t)gridDim.y * NKC * BCH16;
+    // float offset of this lane's 16 bytes inside a gathered row's 32-channel chunk (the XOR swizzle, on the source side)
+    int a_off[APW];
+#pragma unroll
+    for (int j = 0; j < APW; ++j) a_off[j] = (((lane & 7) ^ (((8 * (ch * APW + j) + a_row) >> 1) & 7)) * 4);
+    // piece k of the NEXT chunk (e_n, kc_n): k < BPW this wave's share of the bank chunk, then its A pieces
+    int ids[APW];
+    auto dma_piece = [&](int k, int e_n, int kc_n, int buf_n) {
+        if (k < BPW) {
+            const int p = wave + W * k;
+            if (BPIECES % W == 0 || p < BPIECES)
+                ln_glds16(bank_y + (size_t)e_n * bank_e + (size_t)kc_n * BCH16 + p * 64, lds_b + (unsigned)(buf_n * BCH16 + p * 64) * 16u);
+        } else {
+            const int j = k - BPW;
+            const int nb = ids[j];
+            const float* src = (nb >= 0 ? values + (size_t)nb * V : g_ln_zero_row) + kc_n * 32 + a_off[j];
+#if LN_CONV_R32_PROBE & 4
+            src = values + (size_t)(m0 + 8 * (ch * APW + j) + a_row < m ? m0 + 8 * (ch * APW + j) + a_row : 0) * V + a_off[j];
+#endif
+            ln_glds16(src, lds_a + (unsigned)((CH > 1 ? buf_n : 0) * (RT * 4096) + j * 1024));
+        }
+    };
+    constexpr int NPIECES = BPW + APW;
+    floatx16 acc[NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+    const int total = (e_end - e_begin) * NKC;
+    // chunk t of the walk = (slot e_begin + t / NKC, channel chunk t % NKC); past the end the last chunk is requested again
+    // (nobody reads it) instead of branching around every request
+    auto chunk_e = [&](int t) -> int { return e_begin + min(t, total - 1) / NKC; };
+    auto chunk_kc = [&](int t) -> int { return min(t, total - 1) % NKC; };
+    auto load_ids = [&](int t) {
+        const int sl = slot_of(chunk_e(t));
+#pragma unroll
+        for (int j = 0; j < APW; ++j) ids[j] = my_ids[j * 8 * E + sl];
+    };
+    const int a_sw = (i >> 1) & 7;
+    u32x4 araw[2][2];
+    auto read_a = [&](int buf) {
+        const u32x4* my_a = &s_a[CH > 1 ? buf : 0][rt][0] + i * 8;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j2 = 0; j2 < 2; ++j2) araw[s][j2] = my_a[(s * 4 + h * 2 + j2) ^ a_sw];
+    };
+    bf16x8 ap[2][3];
+    auto split_step = [&](int s, bf16x8 (&dst)[2][3]) {
+        u32x4 p1, p2, p3;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned int h0, m0_, l0, h1, m1_, l1;
+            ln_split3_bits(__uint_as_float(araw[s][j >> 1][(2 * j) & 3]), h0, m0_, l0);
+            ln_split3_bits(__uint_as_float(araw[s][j >> 1][(2 * j + 1) & 3]), h1, m1_, l1);
+            p1[j] = (h0 >> 16) | h1;
+            p2[j] = (m0_ >> 16) | m1_;
+            p3[j] = (l0 >> 16) | l1;
+        }
+#if LN_CONV_R32_PROBE & 2
+        p1 = araw[s][0];
+        p2 = araw[s][1];
+        p3 = p1;
+#endif
+        dst[s][0] = __builtin_bit_cast(bf16x8, p1), dst[s][1] = __builtin_bit_cast(bf16x8, p2), dst[s][2] = __builtin_bit_cast(bf16x8, p3);
+    };
+
+    // Software pipeline, per wave: while the products of chunk t issue, the rows of chunk t + 1 (landed before the barrier of
+    // iteration t) are read from LDS and split, so a chunk's products start right behind its barrier.  In flight across an
+    // iteration: the bank chunk t + 1 and the rows of chunk t + 2.
+    __syncthreads();  // the ids
+    load_ids(0);
+#pragma unroll
+    for (int k = 0; k < NPIECES; ++k) dma_piece(k, chunk_e(0), chunk_kc(0), 0);
+    if constexpr (CH > 1) {
+        load_ids(1);
+#pragma unroll
+        for (int k = BPW; k < NPIECES; ++k) dma_piece(k, chunk_e(1), chunk_kc(1), 1);
+        load_ids(2);
+    } else {
+        load_ids(1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    read_a(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if constexpr (CH == 1) {
+#pragma unroll
+        for (int k = BPW; k < NPIECES; ++k) dma_piece(k, chunk_e(1), chunk_kc(1), 0);
+        load_ids(2);
+    }
+    split_step(0, ap);
+    split_step(1, ap);
+#ifdef LN_STAMPS
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
+    const unsigned long long wall0 = wall_clock64();
+    unsigned t_prev = LN_R32_CYC();
+#endif
+    for (int it = 0; it < total; ++it) {
+        LN_R32_PHASE(0);  // tail of the previous chunk (loop control, address arithmetic)
+        // everything requested so far has landed behind this wait + barrier: the bank chunk `it` and the rows of chunk it + 1;
+        // and everybody is done reading the buffers the next requests overwrite
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        LN_R32_PHASE(1);  // waiting for the chunks
+        __builtin_amdgcn_s_barrier();
+        LN_R32_PHASE(2);  // waiting for the other waves
+        const u32x4* sb = &s_b[it & 1][0] + ch * (NTW * 3 * 64) + lane;  // fragment ((s * NT + ch * NTW + nt) * 3 + part) * 64 + lane
+        u32x4 fb[2][NTW][3];
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+            for (int x = 0; x < 3; ++x) fb[0][nt][x] = sb[(nt * 3 + x) * 64];
+        read_a((it + 1) & 1);  // rows of chunk it + 1
+        const int e1 = chunk_e(it + 1), kc1 = chunk_kc(it + 1);
+        const int e2 = chunk_e(it + 2), kc2 = chunk_kc(it + 2);
+        bf16x8 ap_n[2][3];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if (s == 0) {
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+                    for (int x = 0; x < 3; ++x) fb[1][nt][x] = sb[((NT + nt) * 3 + x) * 64];
+            }
+#if LN_CONV_R32_PROBE & 1
+            acc[0][0] += __uint_as_float(fb[s][0][0][0] ^ fb[s][NTW - 1][1][1] ^ fb[s][0][2][2]) + (float)ap[s][0][0] + (float)ap[s][1][1] + (float)ap[s][2][2];
+#else
+            // the NTW accumulation chains of a K-step advance together (product p of every column tile, then product p + 1):
+            // small terms first, the dominant product last
+#define LN_R32_PRODUCT(PA, PB)                                                                                                        \
+    _Pragma("unroll") for (int nt = 0; nt < NTW; ++nt)                                                                                \
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[s][PA], __builtin_bit_cast(bf16x8, fb[s][nt][PB]), acc[nt], 0, 0, 0);
+            LN_R32_PRODUCT(2, 0) LN_R32_PRODUCT(0, 2) LN_R32_PRODUCT(1, 1) LN_R32_PRODUCT(1, 0) LN_R32_PRODUCT(0, 1) LN_R32_PRODUCT(0, 0)
+#undef LN_R32_PRODUCT
+#endif
+            if (s == 0) {
+                // requests behind the first K-step: bank chunk it + 1, rows of chunk it + 2 (CH == 1: into the private region the
+                // rows of chunk it + 1 have just been read from, once those reads have returned)
+#pragma unroll
+                for (int k = 0; k < BPW; ++k) {
+#if !(LN_CONV_R32_PROBE & 8)
+                    dma_piece(k, e1, kc1, (it + 1) & 1);
+#endif
+                }
+                if constexpr (CH == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int k = BPW; k < NPIECES; ++k) dma_piece(k, e2, kc2, it & 1);
+                load_ids(it + 3);
+            }
+            split_step(s, ap_n);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int x = 0; x < 3; ++x) ap[s][x] = ap_n[s][x];
+        LN_R32_PHASE(5);  // products issued, fragments read, next rows split, next chunks requested
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the redundant last requests must not outlive the workgroup's LDS
+#ifdef LN_STAMPS
+    if (g_ln_stamps_conv && lane == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+        unsigned long long* o = g_ln_stamps_conv + ((size_t)blockIdx.x * W + wave) * 10;
+        o[0] = wall0;
+        o[1] = wall_clock64();
+        o[2] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);
+        for (int k = 0; k < 6; ++k) o[3 + k] = ph[k];
+        o[9] = total;
+    }
+#endif
+    // accumulator register r of lane (i, h): row 8 (r >> 2) + 4 h + (r & 3), column i
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + 8 * (r >> 2) + 4 * h + (r & 3);
+            if (row < m) out[(size_t)row * f_total + f_off + nt * 32 + i] = acc[nt][r];
+        }
+    }
+}
+
 // (Round-2 first attempt, kept for the record: the same kernel on v_mfma_f32_16x16x32_bf16 with 3-way split operands — a = a1 + a2 + a3 in
 // bf16, six products of total order <= 4, fp32 accumulation; accurate to the same 1e-5 bar — with the filter bank pre-split
 // once per call.  2.5x less matrix time on paper, but the per-slot kernel is not bound by the matrix pipe even at 46 k
@@ -651,6 +956,14 @@ static bool ln_conv_b3_enabled() {
     }
     return v == 1;
 }
+static bool ln_conv_rows32_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("LN_CONV_ROWS32");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v == 1;
+}
 static size_t ln_conv_bank_bytes(int m, int E, int val_dim, int nr_filters) {
     if (val_dim % 32 != 0 || nr_filters % 16 != 0 || m < LN_CONV_B3_MIN_ROWS || E > LN_CONV_LDS_E || !ln_conv_b3_enabled()) return 0;
     return (((size_t)E * val_dim * nr_filters * 3 * sizeof(unsigned short)) + 255) & ~size_t(255);
@@ -701,6 +1014,26 @@ static bool ln_conv_launch_v(int nr_filters, const int* nbr, const float* values
     float* dst = nsplit > 1 ? reinterpret_cast<float*>(slab_ws) : out;
     int f_off = 0;
     size_t bank_off = 0;  // bf16 elements
+    // wide form (both operands by LDS-DMA, 32-row MFMA tiles, every output column in one pass over the gathered rows): column
+    // chunks of 128, then one narrower chunk.  LN_CONV_ROWS32=0 keeps the 16-row kernels (A/B; read once)
+    if constexpr (V % 32 == 0) {
+        if (b3 && nr_filters % 32 == 0 && ln_conv_rows32_enabled()) {
+#define LN_CONV_R32(NTC, NTWW, CHH, RTT)                                                                                            \
+    {                                                                                                                               \
+        const int cnt = (nr_filters - f_off) / (32 * NTC);                                                                          \
+        if (cnt > 0) {                                                                                                              \
+            LN_LAUNCH("k_conv_split_bank", (k_conv_split_bank32<V, NTC, WT>), dim3(ln_div_up(V * 32 * NTC, 256), E, cnt), block, 0, st, filter, \
+                      nr_filters, f_off, bank + bank_off);                                                                          \
+            LN_LAUNCH("k_conv_mfma", (k_conv_rows32_b3<V, NTWW, CHH, RTT, FLIP>), dim3(ln_div_up(m, 32 * RTT), cnt, nsplit),        \
+                      dim3(64 * RTT * CHH), 0, st, nbr, values, reinterpret_cast<const u32x4*>(bank + bank_off), m, E, dst, nr_filters, f_off, e_per); \
+            bank_off += (size_t)E * cnt * V * 32 * NTC * 3;                                                                         \
+            f_off += cnt * 32 * NTC;                                                                                                \
+        }                                                                                                                           \
+    }
+            LN_CONV_R32(4, 2, 2, 6) LN_CONV_R32(3, 3, 1, 4) LN_CONV_R32(2, 1, 2, 6) LN_CONV_R32(1, 1, 1, 4)
+#undef LN_CONV_R32
+        }
+    }
     // all chunks of the widest size go out as ONE launch (gridDim.y = their count), then at most one launch per narrower size
 #define LN_CONV_CHUNKS(NTC)                                                                                                         \
     if constexpr (NT_MAX >= NTC) {                                                                                                  \
