@@ -533,10 +533,22 @@ __global__ void __launch_bounds__(256)
         __builtin_amdgcn_sched_barrier(0);                        \
     } while (0)
 #else
+// (the scheduling barrier stays in the product build: left free, hipcc moves the split of the next rows and the fragment reads across
+// the phase boundaries and the kernel is 5-8 % slower than the instrumented build)
+#ifndef LN_CONV_R32_PIN
+#define LN_CONV_R32_PIN 1
+#endif
+#if LN_CONV_R32_PIN
+#define LN_R32_PHASE(k) __builtin_amdgcn_sched_barrier(0)
+#else
 #define LN_R32_PHASE(k) do { } while (0)
 #endif
+#endif
 #ifndef LN_CONV_R32_SPREAD
-#define LN_CONV_R32_SPREAD 0
+#define LN_CONV_R32_SPREAD 0  // 1: the requests of an iteration go out in two halves
+#endif
+#ifndef LN_CONV_R32_SKEW
+#define LN_CONV_R32_SKEW 0    // 1: the second K-step's products are held back behind the next barrier
 #endif
 #ifndef LN_CONV_R32_PROBE
 #define LN_CONV_R32_PROBE 0  // timing ablations (wrong results): 1 no matrix products, 2 no operand split, 4 no A gather (one row), 8 no B staging
@@ -549,7 +561,7 @@ __global__ void __launch_bounds__(256)
 // measured 89 us there: 108 CUs hold two of the 364 workgroups and a lone wave per SIMD leaves the matrix pipe idle during its
 // 1100-cycle prelude of LDS reads and splits — tools/probes/r32_phase_probe.py).
 template <int V, int NTW, int CH, int RT, bool FLIP>
-__global__ void __launch_bounds__(64 * RT * CH) __attribute__((amdgpu_waves_per_eu((RT * CH + 3) / 4, (RT * CH + 3) / 4)))
+__global__ void __launch_bounds__(64 * RT * CH) __attribute__((amdgpu_waves_per_eu((RT * CH + 3) / 4, (RT * CH) % 6 == 0 ? 3 : 2)))
     k_conv_rows32_b3(const int* __restrict__ nbr, const float* __restrict__ values, const u32x4* __restrict__ bank, int m, int E,
                      float* __restrict__ out, int f_total, int f_off, int e_per) {
     const int e_begin = blockIdx.z * e_per;  // slot split, as in k_conv_mfma
@@ -643,9 +655,10 @@ __global__ void __launch_bounds__(64 * RT * CH) __attribute__((amdgpu_waves_per_
             unsigned int h0, m0_, l0, h1, m1_, l1;
             ln_split3_bits(__uint_as_float(araw[s][j >> 1][(2 * j) & 3]), h0, m0_, l0);
             ln_split3_bits(__uint_as_float(araw[s][j >> 1][(2 * j + 1) & 3]), h1, m1_, l1);
-            p1[j] = (h0 >> 16) | h1;
-            p2[j] = (m0_ >> 16) | m1_;
-            p3[j] = (l0 >> 16) | l1;
+            // two bf16 per dword, the lower channel in the low half-word: one byte permute per pair (the top halves of both words)
+            p1[j] = __builtin_amdgcn_perm(h1, h0, 0x07060302u);
+            p2[j] = __builtin_amdgcn_perm(m1_, m0_, 0x07060302u);
+            p3[j] = __builtin_amdgcn_perm(l1, l0, 0x07060302u);
         }
 #if LN_CONV_R32_PROBE & 2
         p1 = araw[s][0];
@@ -655,9 +668,11 @@ __global__ void __launch_bounds__(64 * RT * CH) __attribute__((amdgpu_waves_per_
         dst[s][0] = __builtin_bit_cast(bf16x8, p1), dst[s][1] = __builtin_bit_cast(bf16x8, p2), dst[s][2] = __builtin_bit_cast(bf16x8, p3);
     };
 
-    // Software pipeline, per wave: while the products of chunk t issue, the rows of chunk t + 1 (landed before the barrier of
-    // iteration t) are read from LDS and split, so a chunk's products start right behind its barrier.  In flight across an
-    // iteration: the bank chunk t + 1 and the rows of chunk t + 2.
+    // Software pipeline, per wave.  While the products of chunk t issue, the rows of chunk t + 1 (landed before the barrier of
+    // iteration t) are read from LDS and split; and the products of a chunk's SECOND K-step are held back until the barrier of the
+    // next iteration has been passed, so that the matrix pipe has work while the first fragments of the new chunk are on their way
+    // from LDS (every wave of the workgroup leaves the barrier in the same state).  In flight across an iteration: the bank chunk
+    // t + 1 and the rows of chunk t + 2.  Two register sets of split operands alternate (iterations come in pairs: no copies).
     __syncthreads();  // the ids
     load_ids(0);
 #pragma unroll
@@ -679,14 +694,45 @@ __global__ void __launch_bounds__(64 * RT * CH) __attribute__((amdgpu_waves_per_
         for (int k = BPW; k < NPIECES; ++k) dma_piece(k, chunk_e(1), chunk_kc(1), 0);
         load_ids(2);
     }
+    bf16x8 ap_b[2][3];
     split_step(0, ap);
     split_step(1, ap);
 #ifdef LN_STAMPS
-    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long wall0 = wall_clock64();
     unsigned t_prev = LN_R32_CYC();
 #endif
-    for (int it = 0; it < total; ++it) {
+    u32x4 fb0[NTW][3], fb1[NTW][3];  // fragments of the first / second K-step
+    // products of K-step s of one chunk: the NTW accumulation chains advance together (product p of every column tile, then
+    // product p + 1); small terms first, the dominant product last
+    auto products = [&](bf16x8 (&a)[3], u32x4 (&f)[NTW][3]) {
+#if LN_CONV_R32_PROBE & 1
+        acc[0][0] += __uint_as_float(f[0][0][0] ^ f[NTW - 1][1][1] ^ f[0][2][2]) + (float)a[0][0] + (float)a[1][1] + (float)a[2][2];
+#else
+#define LN_R32_PRODUCT(PA, PB)                                                                                                        \
+    _Pragma("unroll") for (int nt = 0; nt < NTW; ++nt)                                                                                \
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA], __builtin_bit_cast(bf16x8, f[nt][PB]), acc[nt], 0, 0, 0);
+        LN_R32_PRODUCT(2, 0) LN_R32_PRODUCT(0, 2) LN_R32_PRODUCT(1, 1) LN_R32_PRODUCT(1, 0) LN_R32_PRODUCT(0, 1) LN_R32_PRODUCT(0, 0)
+#undef LN_R32_PRODUCT
+#endif
+    };
+    auto requests = [&](int it, int first, int last) {  // pieces [first, last) of: bank chunk it + 1, rows of chunk it + 2
+        const int e1 = chunk_e(it + 1), kc1 = chunk_kc(it + 1);
+        const int e2 = chunk_e(it + 2), kc2 = chunk_kc(it + 2);
+#pragma unroll
+        for (int k = first; k < last; ++k) {
+            if (k < BPW) {
+#if !(LN_CONV_R32_PROBE & 8)
+                dma_piece(k, e1, kc1, (it + 1) & 1);
+#endif
+            } else {
+                // (CH == 1: into the private region the rows of chunk it + 1 have just been read from, once those reads have returned)
+                if (CH == 1 && k == BPW) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                dma_piece(k, e2, kc2, it & 1);
+            }
+        }
+    };
+    auto iteration = [&](int it, bf16x8 (&cur)[2][3], bf16x8 (&nxt)[2][3]) {
         LN_R32_PHASE(0);  // tail of the previous chunk (loop control, address arithmetic)
         // everything requested so far has landed behind this wait + barrier: the bank chunk `it` and the rows of chunk it + 1;
         // and everybody is done reading the buffers the next requests overwrite
@@ -695,65 +741,63 @@ __global__ void __launch_bounds__(64 * RT * CH) __attribute__((amdgpu_waves_per_
         __builtin_amdgcn_s_barrier();
         LN_R32_PHASE(2);  // waiting for the other waves
         const u32x4* sb = &s_b[it & 1][0] + ch * (NTW * 3 * 64) + lane;  // fragment ((s * NT + ch * NTW + nt) * 3 + part) * 64 + lane
-        u32x4 fb[2][NTW][3];
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-            for (int x = 0; x < 3; ++x) fb[0][nt][x] = sb[(nt * 3 + x) * 64];
+            for (int x = 0; x < 3; ++x) fb0[nt][x] = sb[(nt * 3 + x) * 64];
         read_a((it + 1) & 1);  // rows of chunk it + 1
-        const int e1 = chunk_e(it + 1), kc1 = chunk_kc(it + 1);
-        const int e2 = chunk_e(it + 2), kc2 = chunk_kc(it + 2);
-        bf16x8 ap_n[2][3];
+        LN_R32_PHASE(3);  // LDS reads issued
+#if LN_CONV_R32_SKEW
+        if (it > 0) products(nxt[1], fb1);  // second K-step of chunk it - 1 (its operands are in the other register set)
+        LN_R32_PHASE(4);  // held-back products issued
+        requests(it, 0, LN_CONV_R32_SPREAD ? NPIECES / 2 : NPIECES);
+        load_ids(it + 3);
+        LN_R32_PHASE(5);  // requests issued
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            if (s == 0) {
+        for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-                for (int nt = 0; nt < NTW; ++nt)
-#pragma unroll
-                    for (int x = 0; x < 3; ++x) fb[1][nt][x] = sb[((NT + nt) * 3 + x) * 64];
-            }
-#if LN_CONV_R32_PROBE & 1
-            acc[0][0] += __uint_as_float(fb[s][0][0][0] ^ fb[s][NTW - 1][1][1] ^ fb[s][0][2][2]) + (float)ap[s][0][0] + (float)ap[s][1][1] + (float)ap[s][2][2];
+            for (int x = 0; x < 3; ++x) fb1[nt][x] = sb[((NT + nt) * 3 + x) * 64];
+        products(cur[0], fb0);
+        LN_R32_PHASE(6);  // first K-step's products issued
+        split_step(0, nxt);
+        if (LN_CONV_R32_SPREAD) requests(it, NPIECES / 2, NPIECES);
+        split_step(1, nxt);
+        LN_R32_PHASE(7);  // next rows split
 #else
-            // the NTW accumulation chains of a K-step advance together (product p of every column tile, then product p + 1):
-            // small terms first, the dominant product last
-#define LN_R32_PRODUCT(PA, PB)                                                                                                        \
-    _Pragma("unroll") for (int nt = 0; nt < NTW; ++nt)                                                                                \
-        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[s][PA], __builtin_bit_cast(bf16x8, fb[s][nt][PB]), acc[nt], 0, 0, 0);
-            LN_R32_PRODUCT(2, 0) LN_R32_PRODUCT(0, 2) LN_R32_PRODUCT(1, 1) LN_R32_PRODUCT(1, 0) LN_R32_PRODUCT(0, 1) LN_R32_PRODUCT(0, 0)
-#undef LN_R32_PRODUCT
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+            for (int x = 0; x < 3; ++x) fb1[nt][x] = sb[((NT + nt) * 3 + x) * 64];
+        products(cur[0], fb0);
+        LN_R32_PHASE(4);  // first K-step's products issued
+        requests(it, 0, LN_CONV_R32_SPREAD ? NPIECES / 2 : NPIECES);
+        load_ids(it + 3);
+        LN_R32_PHASE(5);  // requests issued
+        split_step(0, nxt);
+        products(cur[1], fb1);
+        LN_R32_PHASE(6);  // second K-step's products issued
+        if (LN_CONV_R32_SPREAD) requests(it, NPIECES / 2, NPIECES);
+        split_step(1, nxt);
+        LN_R32_PHASE(7);  // next rows split
 #endif
-            if (s == 0) {
-                // requests behind the first K-step: bank chunk it + 1, rows of chunk it + 2 (CH == 1: into the private region the
-                // rows of chunk it + 1 have just been read from, once those reads have returned)
-#pragma unroll
-                for (int k = 0; k < BPW; ++k) {
-#if !(LN_CONV_R32_PROBE & 8)
-                    dma_piece(k, e1, kc1, (it + 1) & 1);
-#endif
-                }
-                if constexpr (CH == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int k = BPW; k < NPIECES; ++k) dma_piece(k, e2, kc2, it & 1);
-                load_ids(it + 3);
-            }
-            split_step(s, ap_n);
-        }
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int x = 0; x < 3; ++x) ap[s][x] = ap_n[s][x];
-        LN_R32_PHASE(5);  // products issued, fragments read, next rows split, next chunks requested
+    };
+    for (int it = 0; it < total; it += 2) {
+        iteration(it, ap, ap_b);
+        if (it + 1 < total) iteration(it + 1, ap_b, ap);
     }
+#if LN_CONV_R32_SKEW
+    if (total & 1) products(ap[1], fb1);
+    else products(ap_b[1], fb1);
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the redundant last requests must not outlive the workgroup's LDS
 #ifdef LN_STAMPS
     if (g_ln_stamps_conv && lane == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
-        unsigned long long* o = g_ln_stamps_conv + ((size_t)blockIdx.x * W + wave) * 10;
+        unsigned long long* o = g_ln_stamps_conv + ((size_t)blockIdx.x * W + wave) * 12;
         o[0] = wall0;
         o[1] = wall_clock64();
         o[2] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);
-        for (int k = 0; k < 6; ++k) o[3 + k] = ph[k];
-        o[9] = total;
+        for (int k = 0; k < 8; ++k) o[3 + k] = ph[k];
+        o[11] = total;
     }
 #endif
     // accumulator register r of lane (i, h): row 8 (r >> 2) + 4 h + (r & 3), column i
@@ -1017,7 +1061,10 @@ static bool ln_conv_launch_v(int nr_filters, const int* nbr, const float* values
     // wide form (both operands by LDS-DMA, 32-row MFMA tiles, every output column in one pass over the gathered rows): column
     // chunks of 128, then one narrower chunk.  LN_CONV_ROWS32=0 keeps the 16-row kernels (A/B; read once)
     if constexpr (V % 32 == 0) {
-        if (b3 && nr_filters % 32 == 0 && ln_conv_rows32_enabled()) {
+        // taken from 96 gathered channels on (below, the 16-row kernels' gathers are as fast: 64 x 64 27 vs 29 us at 46 k rows) and
+        // while the 192-row workgroups alone fill half the chip (no slot split in this form)
+        if (b3 && nr_filters % 32 == 0 && V >= 96 && nsplit == 1 && (long long)ln_div_up(m, 192) * ln_div_up(nr_filters, 128) >= LN_BWD_CUS / 2 &&
+            ln_conv_rows32_enabled()) {
 #define LN_CONV_R32(NTC, NTWW, CHH, RTT)                                                                                            \
     {                                                                                                                               \
         const int cnt = (nr_filters - f_off) / (32 * NTC);                                                                          \
