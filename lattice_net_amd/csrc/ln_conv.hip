@@ -1534,18 +1534,25 @@ typedef short gf_short4 __attribute__((ext_vector_type(4)));
 #ifndef LN_GFB_EG
 #define LN_GFB_EG 3   // slots per workgroup: E = 9 as three groups (gridDim.y); the gradient rows are split three times instead of nine
 #endif
-template <int VT, int FT, int E>
-__global__ void __launch_bounds__(256, LN_GFB_WAVES)
+// WV x WF waves, each owning (VT / WV) x (FT / WF) tiles of 16 x 16 per slot.  2 x 2 waves on a 64 x 64 block (two workgroups per CU)
+// is the round-4 shape; at 128 x 128 the block is the whole [V, F] face on 4 x 4 waves (one 1024-thread workgroup per CU): every
+// gathered row is fetched ONCE for all its channels and used against all filters, the gradient rows once per slot group — with
+// 64 x 64 sub-blocks the rows were gathered twice and the gradient rows read six times (571 MB through the CUs' load path for
+// 285 MB here; the kernel ran at that rate).
+template <int VT, int FT, int E, int WV, int WF>
+__global__ void __launch_bounds__(64 * WV * WF, (WV * WF) > 8 ? 1 : LN_GFB_WAVES)
     k_grad_filter_b3(const int* __restrict__ nbr, const float* __restrict__ values, const float* __restrict__ grad_out, int m, int rows_per_wg,
                      float* __restrict__ partial, int v_total, int f_total) {
     constexpr int V = VT * 16, F = FT * 16;
     constexpr int EG = LN_GFB_EG;
     static_assert(E % EG == 0, "slot groups");
-    constexpr int TPV = VT / 2, TPF = FT / 2;        // tiles of a wave
+    constexpr int TPV = VT / WV, TPF = FT / WF;      // tiles of a wave
+    constexpr int THREADS = 64 * WV * WF;
     constexpr int RSA = V + 8, RSG = F + 8;          // bf16 elements per staged row (+16 bytes: the four rows a tr read touches start in different banks)
     constexpr int PA = LN_GFB_SUB * RSA, PG = LN_GFB_SUB * RSG;  // one plane
-    constexpr int A4 = LN_GFB_SUB * V / 4 / 256, G4 = LN_GFB_SUB * F / 4 / 256;  // float4 fetched per thread and sub-tile
-    static_assert(A4 >= 1 && G4 >= 1 && VT % 2 == 0 && FT % 2 == 0, "block shape");
+    constexpr int A4 = LN_GFB_SUB * V / 4 / THREADS, G4 = LN_GFB_SUB * F / 4 / THREADS;  // float4 fetched per thread and sub-tile
+    static_assert(A4 >= 1 && G4 >= 1 && VT % WV == 0 && FT % WF == 0 && (LN_GFB_SUB * V / 4) % THREADS == 0 && (LN_GFB_SUB * F / 4) % THREADS == 0,
+                  "block shape");
     extern __shared__ __attribute__((aligned(16))) unsigned short s_gfb[];
     unsigned short* s_a = s_gfb;                     // [3][64][RSA]
     unsigned short* s_g = s_gfb + 3 * PA;            // [3][64][RSG]
@@ -1556,7 +1563,7 @@ __global__ void __launch_bounds__(256, LN_GFB_WAVES)
     const int e0 = blockIdx.y * EG;
     const int chunk_begin = blockIdx.x * rows_per_wg;
     const int chunk_end = min(chunk_begin + rows_per_wg, m);
-    const int wv = wave >> 1, wf = wave & 1;         // the wave's place in the 2 x 2 grid
+    const int wv = wave / WF, wf = wave % WF;        // the wave's place in the WV x WF grid
 
     floatx4 acc[EG][TPV][TPF];
 #pragma unroll
@@ -1573,14 +1580,14 @@ __global__ void __launch_bounds__(256, LN_GFB_WAVES)
         for (int e = 0; e < EG; ++e)
 #pragma unroll
             for (int k = 0; k < A4; ++k) {
-                const int row = sub + (tid + 256 * k) / (V / 4);
+                const int row = sub + (tid + THREADS * k) / (V / 4);
                 ids[e][k] = row < chunk_end ? nbr[(size_t)row * E + e0 + e] : -1;
             }
     };
     auto fetch_a = [&](const int (&nb)[A4]) {
 #pragma unroll
         for (int k = 0; k < A4; ++k) {
-            const int x4 = tid + 256 * k;
+            const int x4 = tid + THREADS * k;
             const int c4 = x4 % (V / 4);
             ra[k] = make_float4(0.f, 0.f, 0.f, 0.f);
 #if LN_GFB_PROBE & 2
@@ -1593,7 +1600,7 @@ __global__ void __launch_bounds__(256, LN_GFB_WAVES)
     auto fetch_g = [&](int sub) {
 #pragma unroll
         for (int k = 0; k < G4; ++k) {
-            const int x4 = tid + 256 * k;
+            const int x4 = tid + THREADS * k;
             const int r = x4 / (F / 4), c4 = x4 - r * (F / 4);
             const int row = sub + r;
             rg[k] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1634,7 +1641,7 @@ __global__ void __launch_bounds__(256, LN_GFB_WAVES)
         int nxt[A4];  // slot e0's ids of the NEXT sub-tile (the other slots' are fetched when this sub-tile's are used up)
 #pragma unroll
         for (int k = 0; k < A4; ++k) {
-            const int row = sub + LN_GFB_SUB + (tid + 256 * k) / (V / 4);
+            const int row = sub + LN_GFB_SUB + (tid + THREADS * k) / (V / 4);
             nxt[k] = row < chunk_end ? nbr[(size_t)row * E + e0] : -1;
         }
 #pragma unroll
@@ -1643,14 +1650,14 @@ __global__ void __launch_bounds__(256, LN_GFB_WAVES)
             if (e == 0) {
 #pragma unroll
                 for (int k = 0; k < G4; ++k) {
-                    const int x4 = tid + 256 * k;
+                    const int x4 = tid + THREADS * k;
                     const int r = x4 / (F / 4), c4 = x4 - r * (F / 4);
                     stage(rg[k], s_g + r * RSG + c4 * 4, PG);
                 }
             }
 #pragma unroll
             for (int k = 0; k < A4; ++k) {
-                const int x4 = tid + 256 * k;
+                const int x4 = tid + THREADS * k;
                 const int r = x4 / (V / 4), c4 = x4 - r * (V / 4);
                 stage(ra[k], s_a + r * RSA + c4 * 4, PA);
             }
@@ -1707,10 +1714,19 @@ __global__ void __launch_bounds__(256, LN_GFB_WAVES)
 // rows per workgroup of the bf16x3 filter gradient: as few as fill the chip (>= 512 workgroups over chunks x slot groups x sub-blocks) while the
 // slabs the chunks write (and k_reduce_slabs4 reads back) stay under LN_GFB_SLAB_BYTES; a multiple of the 64-row sub-tile
 #define LN_GFB_SLAB_BYTES (24ll << 20)
+// LN_GFB_WIDE=0 keeps the 64 x 64 sub-blocks of round 4 (A/B; read once)
+static bool ln_gfb_wide() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("LN_GFB_WIDE");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v == 1;
+}
 static bool ln_gfb_block(int val_dim, int nr_filters, int* vs, int* fs) {
-    static const int cand[6][2] = {{64, 64}, {32, 96}, {96, 32}, {64, 32}, {32, 64}, {32, 32}};
+    static const int cand[10][2] = {{128, 128}, {128, 64}, {64, 128}, {96, 96}, {64, 64}, {32, 96}, {96, 32}, {64, 32}, {32, 64}, {32, 32}};
     for (auto& c : cand)
-        if (val_dim % c[0] == 0 && nr_filters % c[1] == 0) {
+        if (val_dim % c[0] == 0 && nr_filters % c[1] == 0 && (ln_gfb_wide() || (c[0] + c[1] <= 128))) {
             *vs = c[0];
             *fs = c[1];
             return true;
@@ -1722,8 +1738,10 @@ static int ln_gfb_rows(int m, int filter_extent, int val_dim, int nr_filters) {
     if (filter_extent != 9 || !ln_gfb_block(val_dim, nr_filters, &vs, &fs)) return 0;  // (the kernel is instantiated for E = 9: d = 3)
     const long long z = (long long)(val_dim / vs) * (nr_filters / fs) * (filter_extent / LN_GFB_EG);  // workgroups per row chunk
     const long long slab = (long long)filter_extent * val_dim * nr_filters * 4;
-    long long chunks = (512 + z - 1) / z;                                   // two workgroups per CU ...
-    const long long cap = LN_GFB_SLAB_BYTES / slab > 0 ? LN_GFB_SLAB_BYTES / slab : 1;
+    const bool one_per_cu = vs * fs > 64 * 96;                              // blocks on more than eight waves take a whole CU
+    long long chunks = ((one_per_cu ? 256 : 512) + z - 1) / z;              // (else two workgroups per CU) ...
+    const long long budget = one_per_cu ? 2 * LN_GFB_SLAB_BYTES : LN_GFB_SLAB_BYTES;
+    const long long cap = budget / slab > 0 ? budget / slab : 1;
     if (chunks > cap) chunks = cap;                                         // ... unless the slabs would cost more than the products
     long long rows = ((m + chunks - 1) / chunks + LN_GFB_SUB - 1) / LN_GFB_SUB * LN_GFB_SUB;
     if (rows < LN_GFB_SUB) rows = LN_GFB_SUB;
@@ -1759,11 +1777,23 @@ static int ln_gf_launch_partials(const int* nbr, const float* values_neigh, cons
         const int chunks_b3 = ln_div_up(m, rows);
         const dim3 grid(chunks_b3, filter_extent / LN_GFB_EG, (val_dim / vs) * (nr_filters / fs));
         const size_t lds = (size_t)3 * LN_GFB_SUB * ((vs + 8) + (fs + 8)) * sizeof(unsigned short);
-#define LN_GFB_CASE(A, B)                                                                                                              \
-    if (vs == 16 * A && fs == 16 * B)                                                                                                  \
-        LN_LAUNCH("k_grad_filter_mfma", (k_grad_filter_b3<A, B, 9>), grid, block, lds, st, nbr, values_neigh, grad_out, m, rows, partial, val_dim, \
-                  nr_filters);
-        LN_GFB_CASE(4, 4) LN_GFB_CASE(2, 6) LN_GFB_CASE(6, 2) LN_GFB_CASE(4, 2) LN_GFB_CASE(2, 4) LN_GFB_CASE(2, 2)
+#define LN_GFB_CASE(A, B, WVV, WFF)                                                                                                    \
+    if (vs == 16 * A && fs == 16 * B) {                                                                                                \
+        static bool attr_set = false;                                                                                                  \
+        if (!attr_set && lds > 64 * 1024) {                                                                                            \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grad_filter_b3<A, B, 9, WVV, WFF>),                             \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                           \
+            attr_set = true;                                                                                                           \
+        }                                                                                                                              \
+        LN_LAUNCH("k_grad_filter_mfma", (k_grad_filter_b3<A, B, 9, WVV, WFF>), grid, dim3(64 * WVV * WFF), lds, st, nbr, values_neigh, grad_out, \
+                  m, rows, partial, val_dim, nr_filters);                                                                              \
+    }
+#ifndef LN_GFB_W128F
+#define LN_GFB_W128F 2  // waves across the filters of a 128 x 128 block: 4 x 2 waves (512 threads, 248 registers; measured 101 us at 46 k rows
+                        // against 118 for 4 x 4 waves, whose 128-register budget spills 13 dwords, and 132 for 64 x 64 sub-blocks)
+#endif
+        LN_GFB_CASE(8, 8, 4, LN_GFB_W128F) LN_GFB_CASE(8, 4, 4, 2) LN_GFB_CASE(4, 8, 2, 4) LN_GFB_CASE(6, 6, 3, 2)
+        LN_GFB_CASE(4, 4, 2, 2) LN_GFB_CASE(2, 6, 2, 2) LN_GFB_CASE(6, 2, 2, 2) LN_GFB_CASE(4, 2, 2, 2) LN_GFB_CASE(2, 4, 2, 2) LN_GFB_CASE(2, 2, 2, 2)
 #undef LN_GFB_CASE
         return chunks_b3;
     }

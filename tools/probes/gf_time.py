@@ -13,9 +13,18 @@ for v, f in ((64, 64), (128, 128), (96, 96), (128, 64), (64, 32)):
         y, _ = ConvIm2RowLattice.apply(lv, lat, fb, 1); y.backward(g)
     for _ in range(3): step()
     torch.cuda.synchronize()
-    lib.ln_profile_begin(b"k_grad_filter_mfma", 64)
-    for _ in range(10): step()
-    torch.cuda.synchronize()
-    ms, cnt = C.c_double(0), C.c_int(0); lib.ln_profile_end(C.byref(ms), C.byref(cnt))
-    print(f"V {v} F {f}: grad filter {ms.value/cnt.value*1e3:.1f} us", end="; ")
-print()
+    out = []
+    for name in (b"k_grad_filter_mfma", b"k_reduce_slabs"):
+        lib.ln_profile_begin(name, 64)
+        for _ in range(10): step()
+        torch.cuda.synchronize()
+        ms, cnt = C.c_double(0), C.c_int(0); lib.ln_profile_end(C.byref(ms), C.byref(cnt))
+        out.append(ms.value / max(cnt.value, 1) * 1e3)
+    ref = torch.zeros_like(fb)
+    nb = lat.neighbours(lat, 1, False).long()
+    with torch.no_grad():
+        for e in range(9):
+            ok = nb[:, e] >= 0
+            ref[e * v:(e + 1) * v] = (lv.detach()[nb[ok, e]].double().T @ g[ok].double()).float()
+    err = float((fb.grad - ref).abs().max() / ref.abs().max())
+    print(f"V {v} F {f}: grad filter {out[0]:.1f} us + slab sum {out[1]:.1f} us   rel err {err:.1e}")
