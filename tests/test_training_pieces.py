@@ -203,3 +203,45 @@ def test_data_parallel_step_equals_single_process_step_on_both_clouds(tmp_path):
             assert torch.allclose(g[k], w, rtol=1e-9, atol=1e-12), k
         moved += int(not torch.equal(before[k], w))
     assert moved >= 60, "the optimizer step must have changed (nearly) every tensor"
+
+
+def test_losses_and_scores_match_the_references_own_python_on_f13(golden):
+    """F13 (tests/golden/make_losses_fixture.py): the reference's LovaszSoftmax (lovasz_loss.py:23), GeneralizedSoftDiceLoss
+    (diceloss.py:8) and Scores (callbacks/scores.py:8-110) executed in this container on seeded inputs — plain, an ignore class,
+    classes absent from the cloud, every point of one class, one point, 20 confident classes; three clouds accumulated for the
+    scores.  The reference's losses only run in float32 (they build float32 one-hot tensors): this package's are evaluated in
+    float32 against them (values and gradients 2e-6 of the largest entry) and in float64 against the same numbers at the
+    resolution of the reference's float32 cumulative sums."""
+    from lattice_net_amd.losses import GeneralizedSoftDiceLoss
+    f = golden("F13_losses")
+    for name in [str(x) for x in f["case_names"]]:
+        logp64, labels, ignore = torch.from_numpy(f[f"{name}/logp"]), torch.from_numpy(f[f"{name}/labels"]), int(f[f"{name}/ignore"])
+        for dtype, rtol, gtol in ((torch.float32, 2e-6, 2e-6), (torch.float64, 5e-6, 3e-5)):  # (the reference's own float32 cumsums)
+            for red in ("mean", "sum"):
+                x = logp64.to(dtype).clone().requires_grad_(True)
+                loss = LovaszSoftmax(ignore_index=ignore, reduction=red)(x, labels)
+                ref = float(f[f"{name}/lovasz_{red}"])
+                assert abs(float(loss) - ref) <= rtol * max(abs(ref), 1.0), (name, red, dtype, float(loss), ref)
+                loss.backward()
+                g_ref = f[f"{name}/lovasz_{red}_grad"].astype(np.float64)
+                assert np.max(np.abs(x.grad.double().numpy() - g_ref)) <= gtol * max(np.max(np.abs(g_ref)), 1e-30), (name, red, dtype)
+            per_class = LovaszSoftmax(ignore_index=ignore, reduction="none")(logp64.to(dtype), labels)
+            ref_pc = f[f"{name}/lovasz_none"].astype(np.float64)
+            assert per_class.shape[0] == ref_pc.shape[0] and np.allclose(per_class.double().numpy(), ref_pc, rtol=5e-6, atol=5e-7), name
+            x = logp64.to(dtype).clone().requires_grad_(True)
+            loss = GeneralizedSoftDiceLoss(ignore_index=ignore)(x, labels)
+            ref = float(f[f"{name}/dice"])
+            assert abs(float(loss) - ref) <= 5e-6 * max(abs(ref), 1.0), (name, dtype, float(loss), ref)
+            loss.backward()
+            g_ref = f[f"{name}/dice_grad"].astype(np.float64)
+            assert np.max(np.abs(x.grad.double().numpy() - g_ref)) <= 5 * gtol * max(np.max(np.abs(g_ref)), 1e-30), (name, dtype)
+    s = Scores()
+    unl = int(f["scores/unlabeled_idx"])
+    for k in range(3):
+        s.accumulate_scores(torch.from_numpy(f[f"scores/{k}/probs"]), torch.from_numpy(f[f"scores/{k}/gt"]), unl)
+        avg, d = s.compute_stats()
+        assert sorted(d) == f[f"scores/{k}/iou_classes"].tolist()
+        assert np.allclose([d[i] for i in sorted(d)], f[f"scores/{k}/iou_values"], rtol=0, atol=1e-15)
+        assert abs(avg - float(f[f"scores/{k}/avg_iou"])) < 1e-15
+        s.update_best()
+        assert abs(s.best_iou - float(f[f"scores/{k}/best_iou"])) < 1e-15
