@@ -24,7 +24,9 @@ What is written is DATA ONLY (no reference source, bytecode or text): the ordere
 from (every tensor is regenerated from (seed, position in the key order, shape) by `seeded_parameter`, which the tests import), the
 logits, the loss, and every parameter gradient (norm of each, full tensors up to 4096 elements, a fixed strided sample above).
 
-Run in the build container only:  python tests/golden/make_reference_network_fixture.py"""
+Run in the build container only:  python tests/golden/make_reference_network_fixture.py            (F10, 1500 points)
+                                  python tests/golden/make_reference_network_fixture.py --case kitti   (F12: the SemanticKITTI model of
+                                  config/lnn_train_semantic_kitti.cfg:36-47 at 120 000 points; logits of a fixed 4096-point sample)"""
 import importlib
 import os
 import sys
@@ -42,6 +44,25 @@ if ROOT not in sys.path:
 N_POINTS, NR_CLASSES, CLOUD_SEED, PARAM_SEED = 1500, 6, 0, 4244
 FULL_GRADIENT_MAX = 4096
 SAMPLE = 1024
+# --case kitti (F12): BASELINE.json configs[2] at its own size — the model block of config/lnn_train_semantic_kitti.cfg:36-47 (20 classes,
+# lattice_gpu :62-69: sigma 0.9, capacity 100000) on the 120 000-point synthetic LiDAR scan of bench.py.  46.5 k / 11.4 k / 2.6 k lattice
+# vertices: every bf16x3 / wide / three-sub-tile convolution kernel, k_grad_filter_b3 and the wave-tiled classifier are inside the comparison.
+# param_seed: the network has kinks (ReLU / LeakyReLU, the PointNet maximum that also hands on the winner's barycentric weight, the
+# "fewer than 4 points" rule): with 46.5 k vertices a float32 evaluation lands on the other side of one of ~10^8 such decisions in about
+# half of all (seed, run) pairs — the GPU result is not bitwise reproducible from run to run at this size (atomic accumulations in the
+# torch glue), so the SAME seed can flip in one run and not in the next (tools/probes/f12_scale_probe.py: seeds 5001-5008, three runs).
+# One flip moves ~9 rows of the PointNet output by ~1e-3 and, through the GroupNorm statistics and the receptive field, 5-40 % of the
+# logits by more than 1e-4.  5003 showed no flip in any run (logits within 1.8e-5 of the float64 fixture everywhere); the GPU test is
+# nevertheless written to recognise a flip (localised: median error and the bulk of the points stay at rounding level) instead of failing on it.
+KITTI = dict(n_points=120000, nr_classes=20, cloud_seed=0, param_seed=5003, sigma=0.9, capacity=100000, logits_sample=4096,
+             model=dict(positions_mode="xyz", values_mode="none", pointnet_channels_per_layer=[16, 32], pointnet_start_nr_channels=32,
+                        nr_downsamples=2, nr_blocks_down_stage=[1, 1, 1], nr_blocks_bottleneck=1, nr_blocks_up_stage=[1, 1, 1],
+                        nr_levels_down_with_normal_resnet=3, nr_levels_up_with_normal_resnet=3, compression_factor=1.0, dropout_last_layer=0.0))
+
+
+def logits_sample_index(n_points: int, count: int) -> np.ndarray:
+    """The fixed sample of points whose logits the full-size fixture stores."""
+    return np.linspace(0, n_points - 1, count).astype(np.int64)
 
 
 def seeded_parameter(position: int, key: str, shape, seed: int = PARAM_SEED) -> np.ndarray:
@@ -64,7 +85,12 @@ def gradient_sample_index(numel: int) -> np.ndarray:
 
 
 class PlainModelParams:
-    """The getters models.py:70-100 and prepare_cloud call, answered from tests/test_oracle_network.CFG."""
+    """The getters models.py:70-100 and prepare_cloud call, answered from tests/test_oracle_network.CFG (or the table handed in)."""
+
+    def __init__(self, values=None):
+        if values is not None:
+            self._v = values
+
     _v = dict(positions_mode="xyz", values_mode="none", pointnet_channels_per_layer=[16, 32], pointnet_start_nr_channels=32, nr_downsamples=2,
               nr_blocks_down_stage=[1, 1], nr_blocks_bottleneck=1, nr_blocks_up_stage=[1, 1], nr_levels_down_with_normal_resnet=1,
               nr_levels_up_with_normal_resnet=1, compression_factor=1.0, dropout_last_layer=0.0)
@@ -214,13 +240,23 @@ def main():
     models = importlib.import_module("latticenet_py.lattice.models")
     from lattice_net_amd.synthetic import box_surface_cloud
 
-    lattice = RefLattice([0.08] * 3, 60000)
-    torch.manual_seed(0)
-    net = models.LNN(NR_CLASSES, PlainModelParams())
+    kitti = ARGS.case == "kitti"
+    n_points, nr_classes, cloud_seed, param_seed = ((KITTI["n_points"], KITTI["nr_classes"], KITTI["cloud_seed"], KITTI["param_seed"]) if kitti
+                                                    else (N_POINTS, NR_CLASSES, CLOUD_SEED, PARAM_SEED))
+    if kitti:
+        from lattice_net_amd.synthetic import lidar_cloud
+        lattice = RefLattice([KITTI["sigma"]] * 3, KITTI["capacity"])
+        torch.manual_seed(0)
+        net = models.LNN(nr_classes, PlainModelParams(KITTI["model"]))
+        pos = torch.from_numpy(lidar_cloud(n_points, cloud_seed))
+    else:
+        lattice = RefLattice([0.08] * 3, 60000)
+        torch.manual_seed(0)
+        net = models.LNN(nr_classes, PlainModelParams())
+        pos = torch.from_numpy(box_surface_cloud(n_points, cloud_seed))  # float32 positions, as the loaders deliver them
     keys_at_construction = list(net.state_dict().keys())
-    pos = torch.from_numpy(box_surface_cloud(N_POINTS, CLOUD_SEED))  # float32 positions, as the loaders deliver them
-    vals = torch.zeros((N_POINTS, 1))
-    target = torch.from_numpy(np.random.default_rng(CLOUD_SEED).integers(0, NR_CLASSES, N_POINTS))
+    vals = torch.zeros((n_points, 1))
+    target = torch.from_numpy(np.random.default_rng(cloud_seed).integers(0, nr_classes, n_points))
     with torch.no_grad():
         net(lattice, pos, vals)  # the first forward creates the lazy parameters (ln_eval.py:131-137 relies on it)
     sd = net.state_dict()
@@ -233,7 +269,7 @@ def main():
     # available — this package's network on the CPU oracle lattice in float32, and the GPU run (tools/probes/f10_probe.py) — show no
     # such flip, i.e. every gradient within 3e-5 of the float64 run: the 1e-4 comparison of tests/test_gpu_lnn_oracle.py is then
     # well-posed.  (--seed S --out PATH writes a candidate fixture for that search.)
-    chosen = PARAM_SEED if ARGS.seed is None else ARGS.seed
+    chosen = param_seed if ARGS.seed is None else ARGS.seed
     with torch.no_grad():
         for i, k in enumerate(keys):
             sd[k].copy_(torch.from_numpy(seeded_parameter(i, k, shapes[i], chosen)).reshape(shapes[i]))
@@ -246,10 +282,14 @@ def main():
         "keys": np.array(keys), "keys_at_construction": np.array(keys_at_construction),
         "shapes": np.array([",".join(map(str, s)) for s in shapes]),
         "is_parameter": np.array([k in named for k in keys]),
-        "param_seed": np.int64(chosen), "n_points": np.int64(N_POINTS), "nr_classes": np.int64(NR_CLASSES), "cloud_seed": np.int64(CLOUD_SEED),
-        "logits": logits.detach().numpy(), "loss": np.float64(loss.item()),
+        "param_seed": np.int64(chosen), "n_points": np.int64(n_points), "nr_classes": np.int64(nr_classes), "cloud_seed": np.int64(cloud_seed),
+        "logits": (logits.detach().numpy()[logits_sample_index(n_points, KITTI["logits_sample"])] if kitti else logits.detach().numpy()),
+        "loss": np.float64(loss.item()),
         "nr_vertices_per_level": np.array([0]),
     }
+    if kitti:
+        out["logits_abs_max"] = np.float64(logits.detach().abs().max().item())
+        out["logits_checksum"] = np.float64(logits.detach().double().abs().sum().item())
     norms = []
     for i, k in enumerate(keys):
         if k not in named:
@@ -264,7 +304,7 @@ def main():
         else:
             out[f"grad_sample/{i}"] = g[gradient_sample_index(g.size)].astype(np.float64)
     out["grad_norms"] = np.array(norms)
-    path = ARGS.out or os.path.join(HERE, "F10_reference_lnn.npz")
+    path = ARGS.out or os.path.join(HERE, "F12_reference_lnn_kitti.npz" if kitti else "F10_reference_lnn.npz")
     np.savez_compressed(path, **out)
     print(f"{path}: {len(keys)} tensors ({len(keys_at_construction)} exist before the first forward), loss {loss.item():.6f}, "
           f"{os.path.getsize(path) / 1024:.0f} KiB")
@@ -277,5 +317,6 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--seed", type=int, default=None)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--case", default="small", choices=["small", "kitti"], help="kitti: F12, the SemanticKITTI model at 120 000 points")
     ARGS = ap.parse_args()
     main()

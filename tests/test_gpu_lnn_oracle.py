@@ -175,3 +175,58 @@ def test_pointnet_rule_fewer_than_four_points_matches_oracle(tmp_path):
         assert np.abs(rows[~must_be_zero]).sum(1).min() > 0, tag
     assert rel(seen["gpu"].numpy(), seen["cpu"].numpy()) < 1e-5
     assert rel(g_lv.cpu().numpy(), o_lv.numpy()) < 1e-5
+
+
+def test_semantic_kitti_network_at_full_size_matches_the_reference_networks_own_output():
+    """BASELINE.json configs[2] at its own size (120 000 points; 46.5 k / 11.4 k / 2.6 k lattice vertices): the GPU network against
+    tests/golden/F12_reference_lnn_kitti.npz = the REFERENCE's own `LNN` Python with the model block of
+    config/lnn_train_semantic_kitti.cfg:36-47 executed in float64 over the oracle lattice (make_reference_network_fixture.py --case
+    kitti).  Every large-lattice kernel is inside this comparison: the bf16x3 16-row and wide (k_conv_rows32_b3) convolutions and
+    their flipped / transposed backward forms, k_grad_filter_b3, the fused 32-channel kernels at three sub-tiles, the level-crossing
+    convolutions, the wave-tiled slice_classify.
+
+    What is asserted, and why not 1e-4 per entry as at 1500 points (F10): the network has ~10^8 kinks at this size (ReLU, the PointNet
+    maximum with the winner's barycentric weight) and the GPU run is not bitwise reproducible (atomics in the torch glue), so any
+    (seed, run) can land one decision on the other side — a LOCALISED O(1e-3) difference that the GroupNorm statistics and the receptive
+    field then spread thinly (tools/probes/f12_scale_probe.py; the fixture's seed showed none in three runs).  Asserted always: the
+    logits' checksum and the loss to 1e-4, median logit error <= 2e-5 of the largest logit, >= 50 % of the sampled points within 1e-4,
+    relative L2 error of the logits <= 2e-2, every gradient tensor's relative L2 error <= 0.15 and norm within 6e-2 (a wrong operand
+    in any kernel is O(1)).  Asserted when no decision flipped (every sampled logit within 1e-4 — the expected case): gradients to
+    2e-2 relative L2 / 1e-2 in norm (ReLU derivatives flip in the backward pass even then; the measured worst is 5e-3 / 2e-3)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from make_reference_network_fixture import gradient_sample_index, logits_sample_index
+    from tests.test_model_assembly import kitti_fixture_case
+    fx, net, lattice, pos, target = kitti_fixture_case(dev(), torch.float32)
+    n = pos.shape[0]
+    logsoftmax, logits = net(lattice, pos.to(dev()), torch.zeros((n, 1), device=dev()))
+    loss = torch.nn.functional.nll_loss(logsoftmax, target.to(dev()))
+    loss.backward()
+    torch.cuda.synchronize()
+    cs = float(logits.detach().double().abs().sum())
+    assert abs(cs - float(fx["logits_checksum"])) <= TOL * float(fx["logits_checksum"])
+    assert abs(float(loss.detach()) - float(fx["loss"])) <= TOL * abs(float(fx["loss"]))
+    lg = logits.detach().cpu().double().numpy()[logits_sample_index(n, fx["logits"].shape[0])]
+    err = np.abs(lg - fx["logits"]) / np.abs(fx["logits"]).max()
+    rel_l2 = float(np.linalg.norm(lg - fx["logits"]) / np.linalg.norm(fx["logits"]))
+    within = float((err.max(1) <= TOL).mean())
+    assert np.median(err) <= 2e-5 and within >= 0.5 and rel_l2 <= 2e-2, (float(np.median(err)), within, rel_l2, float(err.max()))
+    no_flip = bool(err.max() <= TOL)
+    named = dict(net.named_parameters())
+    gmax = float(np.nanmax(fx["grad_norms"]))
+    worst_l2, worst_norm = (0.0, ""), (0.0, "")
+    for i, k in enumerate(str(k) for k in fx["keys"]):
+        if k not in named:
+            continue
+        g = named[k].grad.detach().cpu().double().numpy().reshape(-1)
+        ref_norm = float(fx["grad_norms"][i])
+        worst_norm = max(worst_norm, (abs(float(np.linalg.norm(g)) - ref_norm) / max(ref_norm, 1e-3 * gmax), k))
+        if f"grad_full/{i}" in fx:
+            ref = fx[f"grad_full/{i}"]
+        else:
+            ref, g = fx[f"grad_sample/{i}"], g[gradient_sample_index(g.size)]
+        floor = 1e-3 * gmax * np.sqrt(ref.size / max(named[k].numel(), 1))
+        worst_l2 = max(worst_l2, (float(np.linalg.norm(g - ref)) / max(float(np.linalg.norm(ref)), floor), k))
+    l2_bar, norm_bar = (2e-2, 1e-2) if no_flip else (0.15, 6e-2)
+    assert worst_l2[0] <= l2_bar and worst_norm[0] <= norm_bar, (no_flip, worst_l2, worst_norm, float(err.max()), within)

@@ -300,3 +300,100 @@ def test_network_definition_reproduces_the_reference_networks_logits_and_gradien
             ref, g = fx[f"grad_sample/{i}"], g[gradient_sample_index(g.size)]
         assert np.abs(g - ref).max() <= 1e-9 * max(np.abs(ref).max(), 1e-6), k
         assert abs(np.linalg.norm(named[k].grad.numpy()) - fx["grad_norms"][i]) <= 1e-9 * max(fx["grad_norms"][i], 1e-6), k
+
+
+KITTI_CFG = """
+model: {
+    positions_mode: "xyz"
+    values_mode: "none"
+    pointnet_layers: [16,32]
+    pointnet_start_nr_channels: 32
+    nr_downsamples: 2
+    nr_blocks_down_stage: [1,1,1]
+    nr_blocks_bottleneck: 1
+    nr_blocks_up_stage: [1,1,1]
+    nr_levels_down_with_normal_resnet: 3
+    nr_levels_up_with_normal_resnet: 3
+    compression_factor: 1.0
+    dropout_last_layer: 0.0
+}
+lattice_gpu: {
+    hash_table_capacity: 100000
+    nr_sigmas: 1
+    sigma_0: "0.9 3"
+}
+"""  # the model and lattice blocks of config/lnn_train_semantic_kitti.cfg:36-47,62-69
+
+
+def kitti_fixture_case(device, dtype):
+    """(fixture F12, network with the fixture's seeded parameters, positions, target): BASELINE.json configs[2] at its own size."""
+    import os
+    import sys
+    import tempfile
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from make_reference_network_fixture import seeded_parameter
+    from lattice_net_amd import Lattice
+    from lattice_net_amd.models import LNN
+    from lattice_net_amd.synthetic import lidar_cloud
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "F12_reference_lnn_kitti.npz"))
+    n, c = int(fx["n_points"]), int(fx["nr_classes"])
+    with tempfile.NamedTemporaryFile("w", suffix=".cfg") as f:
+        f.write(KITTI_CFG)
+        f.flush()
+        mp = ModelParams.create(f.name)
+        cfg_lattice = Lattice.create(f.name, "lattice")  # (also sets the static lattice dimension the modules size their banks with)
+    net = LNN(c, mp, device=device).to(dtype)
+    sd = net.state_dict()
+    keys = [str(k) for k in fx["keys"]]
+    assert list(sd.keys()) == keys and [",".join(map(str, sd[k].shape)) for k in keys] == [str(x) for x in fx["shapes"]]
+    for i, k in enumerate(keys):
+        sd[k].copy_(torch.from_numpy(seeded_parameter(i, k, sd[k].shape, int(fx["param_seed"]))).to(dtype))
+    pos = torch.from_numpy(lidar_cloud(n, int(fx["cloud_seed"])))
+    target = torch.from_numpy(np.random.default_rng(int(fx["cloud_seed"])).integers(0, c, n))
+    return fx, net, cfg_lattice, pos, target
+
+
+def compare_with_network_fixture(fx, net, logits, loss, tol, floor_rel):
+    """Logits of the fixture's point sample, loss, every parameter gradient (full or the fixed strided sample) and gradient norm."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from make_reference_network_fixture import gradient_sample_index, logits_sample_index
+    lg = logits.detach().cpu().double().numpy()
+    if lg.shape[0] != fx["logits"].shape[0]:
+        lg = lg[logits_sample_index(lg.shape[0], fx["logits"].shape[0])]
+    assert np.abs(lg - fx["logits"]).max() <= tol * np.abs(fx["logits"]).max(), float(np.abs(lg - fx["logits"]).max() / np.abs(fx["logits"]).max())
+    assert abs(float(loss) - float(fx["loss"])) <= tol * abs(float(fx["loss"]))
+    named = dict(net.named_parameters())
+    gmax = float(np.nanmax(fx["grad_norms"]))
+    bad = {}
+    for i, k in enumerate(str(k) for k in fx["keys"]):
+        if k not in named:
+            continue
+        g = named[k].grad.detach().cpu().double().numpy().reshape(-1)
+        norm = float(np.linalg.norm(g))
+        if f"grad_full/{i}" in fx:
+            ref = fx[f"grad_full/{i}"]
+        else:
+            ref, g = fx[f"grad_sample/{i}"], g[gradient_sample_index(g.size)]
+        # (floor: tensors whose gradient vanishes analytically — biases in front of a normalisation — hold rounding noise only)
+        e = float(np.abs(g - ref).max()) / max(float(np.abs(ref).max()), floor_rel * gmax / np.sqrt(max(ref.size, 1)))
+        en = abs(norm - float(fx["grad_norms"][i])) / max(float(fx["grad_norms"][i]), floor_rel * gmax)
+        if max(e, en) > tol:
+            bad[k] = (e, en)
+    assert not bad, f"parameter gradients off: {sorted(bad.items(), key=lambda kv: -max(kv[1]))[:8]}"
+
+
+def test_network_definition_reproduces_the_reference_network_at_semantic_kitti_size():
+    """F12 = the reference's own `LNN` (models.py:70-266) with the model block of config/lnn_train_semantic_kitti.cfg:36-47 executed in
+    float64 over the oracle lattice on the 120 000-point scan of BASELINE.json configs[2] (46.5 k / 11.4 k / 2.6 k vertices).  This
+    package's network on the same oracle lattice, float64, same seeded parameters: logits of the fixture's 4096-point sample, loss
+    and every parameter gradient to 1e-9."""
+    from tests.oracle_lattice import OracleLattice
+    fx, net, _, pos, target = kitti_fixture_case("cpu", torch.float64)
+    lattice = OracleLattice([0.9] * 3, 100000)
+    logsoftmax, logits = net(lattice, pos, torch.zeros((pos.shape[0], 1), dtype=torch.float64))
+    loss = torch.nn.functional.nll_loss(logsoftmax, target)
+    loss.backward()
+    assert abs(float(logits.detach().abs().sum()) - float(fx["logits_checksum"])) <= 1e-9 * float(fx["logits_checksum"])
+    compare_with_network_fixture(fx, net, logits, loss, tol=1e-9, floor_rel=1e-6)
