@@ -1084,10 +1084,11 @@ static bool ln_conv_launch_v(int nr_filters, const int* nbr, const float* values
     // all chunks of the widest size go out as ONE launch (gridDim.y = their count), then at most one launch per narrower size
 #define LN_CONV_CHUNKS(NTC)                                                                                                         \
     if constexpr (NT_MAX >= NTC) {                                                                                                  \
-        const int cnt = (nr_filters - f_off) / (16 * NTC);                                                                          \
+        /* (256 gathered channels x 32 columns spills in the bf16x3 form: those lattices take 16 columns per workgroup) */          \
+        const int cnt = (b3 && V >= 256 && NTC > 1) ? 0 : (nr_filters - f_off) / (16 * NTC);                                        \
         if (cnt > 0) {                                                                                                              \
             bool done_b3 = false;                                                                                                   \
-            if constexpr (V % 32 == 0 && V * 16 * NTC * 6 <= 64 * 1024) {                                                           \
+            if constexpr (V % 32 == 0 && V * 16 * NTC * 6 <= 64 * 1024 && (V < 256 || NTC == 1)) { /* 256 x 32 columns spills */      \
                 if (b3) {                                                                                                           \
                     LN_LAUNCH("k_conv_split_bank", (k_conv_split_bank<V, NTC, WT>), dim3(ln_div_up(V * 16 * NTC, 256), E, cnt), block, 0, st, filter, \
                               nr_filters, f_off, bank + bank_off);                                                                  \

@@ -49,3 +49,32 @@ def test_no_packed_fp32_instructions_in_the_library():
         found = sorted(set(re.findall(r"v_pk_(?:fma|mul|add)_f32|v_pk_mov_b32", text)))
         assert not found, f"packed fp32 instructions in the device code: {found}"
     assert instructions > 100000  # the disassembly really happened
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"), reason="llvm-readelf of the ROCm toolchain not found")
+def test_no_kernel_of_the_library_spills_registers():
+    """Code-object metadata of every kernel: .vgpr_spill_count is 0 (vector registers spilled to scratch memory: such a hot loop runs
+    2-3x slower, and the spill comes and goes with unrelated edits — round 4 shipped k_conv_mfma_b3<256, 2, *, 1> with 5-6 spilled
+    registers).  Scalar registers parked in vector-register lanes (.sgpr_spill_count, k_bucket_rows: 26) cost no memory traffic and
+    are not counted."""
+    from lattice_net_amd import _lib
+    blob = open(_lib.LIB_PATH, "rb").read()
+    kernels, spilled = 0, []
+    for co in _code_objects(blob):
+        with tempfile.NamedTemporaryFile(suffix=".co", delete=False) as f:
+            f.write(co)
+        try:
+            meta = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", f.name], capture_output=True, text=True, check=True).stdout
+        finally:
+            os.unlink(f.name)
+        # one YAML map per kernel under amdhsa.kernels; the keys of a map are sorted, so .name precedes the spill counts
+        for m in re.finditer(r"\.name:\s+(\S+)(.*?)\.vgpr_spill_count:\s+(\d+)", meta, re.S):
+            name, between, vspill = m.group(1), m.group(2), int(m.group(3))
+            if ".name:" in between:
+                continue  # (an argument's .name, not the kernel's)
+            sspill = re.search(r"\.sgpr_spill_count:\s+(\d+)", between)
+            kernels += 1
+            if vspill:
+                spilled.append((name, vspill, int(sspill.group(1)) if sspill else 0))
+    assert kernels > 300, kernels
+    assert not spilled, spilled
