@@ -1,5 +1,6 @@
 // Half-precision feature path of the lattice convolution (BASELINE.json config 5 / SURVEY.md §8d C5: "features fp16,
-// accumulate fp32"): the same gather-GEMM as ln_conv.hip on v_mfma_f32_16x16x16_f16 — fp16 operands, fp32 accumulators
+// accumulate fp32"): the same gather-GEMM as ln_conv.hip on gfx950's v_mfma_f32_16x16x32_f16 (K = 32 per instruction: twice the
+// flop per issue slot of the CDNA3-era 16x16x16 form, which remains for gathered widths that are not multiples of 32) — fp16 operands, fp32 accumulators
 // — for the forward pass and the gradient wrt the values, and the filter gradient accumulated in fp32 (fmaf) from fp16
 // activations and gradients.
 //
@@ -15,15 +16,18 @@
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef _Float16 halfx4 __attribute__((ext_vector_type(4)));
 
+typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
 template <int V, int NT, bool FLIP, bool WT>
 __global__ void __launch_bounds__(256)
     k_conv_mfma_f16(const int* __restrict__ nbr, const _Float16* __restrict__ values, const _Float16* __restrict__ filter, int m, int E,
                     _Float16* __restrict__ out, int f_total, int f_off) {
     constexpr int F = 16 * NT;
-    constexpr int KQ = V / 4;   // halfs per lane per neighbour
-    constexpr int S = KQ / 4;   // MFMA steps per neighbour
+    constexpr int KQ = V / 4;            // halfs per lane per neighbour
+    constexpr bool K32 = V % 32 == 0;    // v_mfma_f32_16x16x32_f16: lane group q supplies 8 halfs per step
+    constexpr int KS = K32 ? 8 : 4;      // halfs per lane and step
+    constexpr int S = KQ / KS;           // MFMA steps per neighbour
     static_assert(V % 16 == 0, "V must be a multiple of 16");
-    __shared__ __attribute__((aligned(16))) _Float16 s_b[V * F];  // [((s*NT + nt)*64 + lane)*4 + j]
+    __shared__ __attribute__((aligned(16))) _Float16 s_b[V * F];  // [((s*NT + nt)*64 + lane)*KS + j]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -37,16 +41,19 @@ __global__ void __launch_bounds__(256)
     for (int nt = 0; nt < NT; ++nt) acc[nt] = floatx4{0.f, 0.f, 0.f, 0.f};
 
     for (int e = 0; e < E; ++e) {
-        halfx4 a[S];
+        _Float16 a[KQ];
         const int es = (FLIP && e < E - 1) ? (e ^ 1) : e;
         const int nb = (my_row < m) ? nbr[(size_t)my_row * E + es] : -1;
         if (nb >= 0) {
             const halfx4* src = reinterpret_cast<const halfx4*>(values + (size_t)nb * V + q * KQ);
 #pragma unroll
-            for (int s = 0; s < S; ++s) a[s] = src[s];
+            for (int s = 0; s < KQ / 4; ++s) {
+                const halfx4 w4 = src[s];
+                a[4 * s] = w4[0], a[4 * s + 1] = w4[1], a[4 * s + 2] = w4[2], a[4 * s + 3] = w4[3];
+            }
         } else {
 #pragma unroll
-            for (int s = 0; s < S; ++s) a[s] = halfx4{0, 0, 0, 0};
+            for (int k = 0; k < KQ; ++k) a[k] = (_Float16)0;
         }
         __syncthreads();  // previous iteration's reads of s_b are done
         for (int x = tid; x < V * F; x += 256) {
@@ -55,15 +62,22 @@ __global__ void __launch_bounds__(256)
             const int qq = k / KQ;
             const int r = k - qq * KQ;
             const size_t src = WT ? ((size_t)e * f_total + f_off + f) * V + k : ((size_t)e * V + k) * f_total + f_off + f;
-            s_b[((((r >> 2) * NT) + (f >> 4)) * 64 + qq * 16 + (f & 15)) * 4 + (r & 3)] = filter[src];
+            s_b[((((r / KS) * NT) + (f >> 4)) * 64 + qq * 16 + (f & 15)) * KS + (r % KS)] = filter[src];
         }
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < S; ++s) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const halfx4 b = *reinterpret_cast<const halfx4*>(s_b + ((s * NT + nt) * 64 + lane) * 4);
-                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a[s], b, acc[nt], 0, 0, 0);
+                if constexpr (K32) {
+                    const halfx8 b = *reinterpret_cast<const halfx8*>(s_b + ((s * NT + nt) * 64 + lane) * 8);
+                    const halfx8 a8 = {a[8 * s], a[8 * s + 1], a[8 * s + 2], a[8 * s + 3], a[8 * s + 4], a[8 * s + 5], a[8 * s + 6], a[8 * s + 7]};
+                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a8, b, acc[nt], 0, 0, 0);
+                } else {
+                    const halfx4 b = *reinterpret_cast<const halfx4*>(s_b + ((s * NT + nt) * 64 + lane) * 4);
+                    const halfx4 a4 = {a[4 * s], a[4 * s + 1], a[4 * s + 2], a[4 * s + 3]};
+                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a4, b, acc[nt], 0, 0, 0);
+                }
             }
         }
     }
@@ -83,18 +97,18 @@ __global__ void __launch_bounds__(256)
 // of 64 vertices (blockDim.x = 256 T, the shape of ln_conv.hip's k_conv_forward_b3): 72 KB of LDS at V = F = 64, two workgroups
 // per CU.  The per-slot kernel above re-stages 8 KB per slot with two barriers and 2-byte global loads, and starts each
 // neighbour-row gather only after the previous slot's matrix instructions: 42 us at C5 (70 k vertices) against 2 x 21 here.
-//   fragment unit (e, s, nt, lane = (qq, fi)) = the 4 halfs W_e[k = qq * V/4 + 4 s + j][f = 16 nt + fi], j = 0..3 (8 bytes)
-//   bank [E*V, F]   : a thread reads 4 rows x 8 columns (four 16-byte loads) and writes the 8 units of its columns;
-//   bank^T [E*F, V] : a thread reads 8 consecutive k of one column (one 16-byte load) = two units.
+//   fragment unit (e, s, nt, lane = (qq, fi)) = the 8 halfs W_e[k = qq * V/4 + 8 s + j][f = 16 nt + fi], j = 0..7 (16 bytes: one
+//                     operand of v_mfma_f32_16x16x32_f16)
+//   bank [E*V, F]   : a thread reads 8 rows x 8 columns (eight 16-byte loads) and writes the 8 units of its columns;
+//   bank^T [E*F, V] : a thread reads 8 consecutive k of one column (one 16-byte load) = one unit.
 // ------------------------------------------------------------------------------------------
-typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
 template <int V, int NT, bool FLIP, bool WT>
 __global__ void __launch_bounds__(1024)
     k_conv_f16_tiled(const int* __restrict__ nbr, const _Float16* __restrict__ values, const _Float16* __restrict__ filter, int m,
                      _Float16* __restrict__ out) {
-    constexpr int E = 9, F = 16 * NT, KQ = V / 4, S = KQ / 4, G8 = KQ / 8;
-    static_assert(V % 32 == 0, "a lane's quarter row is read in 16-byte words");
-    __shared__ __attribute__((aligned(16))) halfx4 s_frag[E * S * NT * 64];
+    constexpr int E = 9, F = 16 * NT, KQ = V / 4, S = KQ / 8, G8 = KQ / 8;
+    static_assert(V % 32 == 0, "a lane's quarter row is read in 16-byte words, each one operand of a K = 32 step");
+    __shared__ __attribute__((aligned(16))) halfx8 s_frag[E * S * NT * 64];
     const int tid = threadIdx.x;
     const int nthreads = blockDim.x;
     const int lane = tid & 63;
@@ -115,21 +129,22 @@ __global__ void __launch_bounds__(1024)
 #pragma unroll
     for (int k = 0; k < DEPTH - 1; ++k) gather(k, g[k]);
     if constexpr (!WT) {
-        constexpr int ITEMS = E * (V / 4) * (F / 8);
+        constexpr int ITEMS = E * (V / 8) * (F / 8);
         for (int x = tid; x < ITEMS; x += nthreads) {
             const int fo = x % (F / 8);
             const int t2 = x / (F / 8);
-            const int kq = t2 % (V / 4);
-            const int e = t2 / (V / 4);
-            const int k0 = kq * 4, f0 = fo * 8;
-            halfx8 r[4];
+            const int k8 = t2 % (V / 8);
+            const int e = t2 / (V / 8);
+            const int k0 = k8 * 8, f0 = fo * 8;
+            halfx8 r[8];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) r[j] = *reinterpret_cast<const halfx8*>(filter + ((size_t)(e * V + k0 + j)) * F + f0);
-            const int qq = k0 / KQ, s = (k0 - qq * KQ) >> 2;
+            for (int j = 0; j < 8; ++j) r[j] = *reinterpret_cast<const halfx8*>(filter + ((size_t)(e * V + k0 + j)) * F + f0);
+            const int qq = k0 / KQ, s = (k0 - qq * KQ) >> 3;
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 const int f = f0 + c;
-                s_frag[((e * S + s) * NT + (f >> 4)) * 64 + qq * 16 + (f & 15)] = halfx4{r[0][c], r[1][c], r[2][c], r[3][c]};
+                s_frag[((e * S + s) * NT + (f >> 4)) * 64 + qq * 16 + (f & 15)] =
+                    halfx8{r[0][c], r[1][c], r[2][c], r[3][c], r[4][c], r[5][c], r[6][c], r[7][c]};
             }
         }
     } else {
@@ -139,13 +154,9 @@ __global__ void __launch_bounds__(1024)
             const int t2 = x / (V / 8);
             const int f = t2 % F;
             const int e = t2 / F;
-            const halfx8 r = *reinterpret_cast<const halfx8*>(filter + ((size_t)(e * F + f)) * V + ko * 8);
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int k0 = ko * 8 + 4 * h;
-                const int qq = k0 / KQ, s = (k0 - qq * KQ) >> 2;
-                s_frag[((e * S + s) * NT + (f >> 4)) * 64 + qq * 16 + (f & 15)] = halfx4{r[4 * h], r[4 * h + 1], r[4 * h + 2], r[4 * h + 3]};
-            }
+            const int k0 = ko * 8;
+            const int qq = k0 / KQ, s = (k0 - qq * KQ) >> 3;
+            s_frag[((e * S + s) * NT + (f >> 4)) * 64 + qq * 16 + (f & 15)] = *reinterpret_cast<const halfx8*>(filter + ((size_t)(e * F + f)) * V + k0);
         }
     }
     floatx4 acc[NT];
@@ -159,12 +170,11 @@ __global__ void __launch_bounds__(1024)
         const bool present = nb[e] >= 0;
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-            const halfx8 w8 = ge[s >> 1];
-            halfx4 a = (s & 1) ? halfx4{w8[4], w8[5], w8[6], w8[7]} : halfx4{w8[0], w8[1], w8[2], w8[3]};
-            if (!present) a = halfx4{0, 0, 0, 0};
+            halfx8 a = ge[s];
+            if (!present) a = halfx8{0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a, s_frag[((e * S + s) * NT + nt) * 64 + lane], acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, s_frag[((e * S + s) * NT + nt) * 64 + lane], acc[nt], 0, 0, 0);
         }
     }
 #pragma unroll
@@ -310,7 +320,8 @@ extern "C" int ln_conv_forward_f16(const int* nbr, const void* values_neigh, con
 //   grad_filter[e*V+v, f] = sum_m values[nbr[m,e], v] * grad_out[m, f]
 // grid = (row chunks, E).  The contraction runs over lattice vertices (rows), so both MFMA operands are read
 // "down the rows": a sub-tile of 64 rows is staged row-major in LDS and read with the transposing LDS load of gfx950
-// (ds_read_b64_tr_b16: lane (i, q) receives 4 consecutive rows of column i).  Each wave owns whole 16x16 output
+// (ds_read_b64_tr_b16: lane (i, q) receives 4 consecutive rows of column i; two of them = the 8 rows 8q..8q+7 of a 32-row step of
+// v_mfma_f32_16x16x32_f16).  Each wave owns whole 16x16 output
 // tiles D[v, f]; partial [V, F] blocks per row chunk go to slabs, summed by k_reduce_slabs4 / k_reduce_slabs (ln_conv.hip, deterministic).
 // ------------------------------------------------------------------------------------------
 #define LN_GF16_ROWS 512
@@ -331,6 +342,7 @@ __global__ void __launch_bounds__(256)
     __shared__ __attribute__((aligned(16))) _Float16 s_a[LN_GF16_SUB * SA];
     __shared__ __attribute__((aligned(16))) _Float16 s_g[LN_GF16_SUB * SG];
     typedef short shortx4 __attribute__((ext_vector_type(4)));
+    typedef short shortx8 __attribute__((ext_vector_type(8)));
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -386,13 +398,17 @@ __global__ void __launch_bounds__(256)
             const int tile = wave + 4 * t;
             if (tile < TILES) {
                 const int vt = tile / FT, ft = tile - vt * FT;
-                const _Float16* pa = s_a + (4 * q + (i >> 2)) * SA + vt * 16 + 4 * (i & 3);
-                const _Float16* pg = s_g + (4 * q + (i >> 2)) * SG + ft * 16 + 4 * (i & 3);
+                const _Float16* pa = s_a + (8 * q + (i >> 2)) * SA + vt * 16 + 4 * (i & 3);
+                const _Float16* pg = s_g + (8 * q + (i >> 2)) * SG + ft * 16 + 4 * (i & 3);
 #pragma unroll
-                for (int s = 0; s < LN_GF16_SUB / 16; ++s) {
-                    const shortx4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((shortx4 __attribute__((address_space(3)))*)(pa + 16 * s * SA));
-                    const shortx4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((shortx4 __attribute__((address_space(3)))*)(pg + 16 * s * SG));
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(halfx4, a), __builtin_bit_cast(halfx4, b), acc[t], 0, 0, 0);
+                for (int s = 0; s < LN_GF16_SUB / 32; ++s) {
+                    const shortx4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((shortx4 __attribute__((address_space(3)))*)(pa + 32 * s * SA));
+                    const shortx4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((shortx4 __attribute__((address_space(3)))*)(pa + (32 * s + 4) * SA));
+                    const shortx4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((shortx4 __attribute__((address_space(3)))*)(pg + 32 * s * SG));
+                    const shortx4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((shortx4 __attribute__((address_space(3)))*)(pg + (32 * s + 4) * SG));
+                    const shortx8 a = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                    const shortx8 b = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(halfx8, a), __builtin_bit_cast(halfx8, b), acc[t], 0, 0, 0);
                 }
             }
         }

@@ -52,3 +52,37 @@ total = sum(gpu_us(e) for e in rows)
 print(f"torch operators: {total / steps:.0f} us of GPU time per step")
 for e in rows[:30]:
     print(f"{e.key[:34]:34s} {e.count / steps:6.1f}/step {gpu_us(e) / steps:8.1f} us/step   {str(e.input_shapes)[:110]}")
+
+# ---- where the fill / zero launches come from: Python call sites of the zero-filling constructors and in-place fills (CUDA tensors)
+if os.environ.get("LNN_FILL_SITES", "1") == "1":
+    import collections
+    import traceback
+    sites = collections.Counter()
+
+    def site():
+        for fr in reversed(traceback.extract_stack()[:-2]):
+            if "lattice_net_amd" in fr.filename or fr.filename.endswith(("bench_lnn.py", "lnn_torch_ops.py")):
+                return f"{os.path.basename(fr.filename)}:{fr.lineno} {fr.line.strip()[:90]}"
+        return "torch internals"
+
+    def wrap_fn(mod, name):
+        orig = getattr(mod, name)
+
+        def fn(*a, **k):
+            out = orig(*a, **k)
+            t = out if torch.is_tensor(out) else (a[0] if a and torch.is_tensor(a[0]) else None)
+            if t is not None and t.is_cuda:
+                sites[(name, site())] += 1
+            return out
+        setattr(mod, name, fn)
+        return orig
+
+    saved = [(torch, n_, wrap_fn(torch, n_)) for n_ in ("zeros", "zeros_like", "full", "ones", "ones_like", "full_like")]
+    saved += [(torch.Tensor, n_, wrap_fn(torch.Tensor, n_)) for n_ in ("zero_", "fill_", "new_zeros", "new_full", "masked_fill", "masked_fill_")]
+    step()
+    torch.cuda.synchronize()
+    for mod, n_, orig in saved:
+        setattr(mod, n_, orig)
+    print(f"zero-filling calls of one step by Python call site ({sum(sites.values())} in all; autograd's own zero gradients are not seen here):")
+    for (fn_name, where), c in sites.most_common(40):
+        print(f"  {c:3d} x {fn_name:12s} {where}")
