@@ -547,6 +547,9 @@ __global__ void __launch_bounds__(256)
 #ifndef LN_CONV_R32_SPREAD
 #define LN_CONV_R32_SPREAD 0  // 1: the requests of an iteration go out in two halves
 #endif
+#ifndef LN_CONV_R32_PRIO
+#define LN_CONV_R32_PRIO 0    // 1..3: s_setprio around the products of a K-step
+#endif
 #ifndef LN_CONV_R32_SKEW
 #define LN_CONV_R32_SKEW 0    // 1: the second K-step's products are held back behind the next barrier
 #endif
@@ -633,11 +636,12 @@ __global__ void __launch_bounds__(64 * RT * CH) __attribute__((amdgpu_waves_per_
     // (nobody reads it) instead of branching around every request
     auto chunk_e = [&](int t) -> int { return e_begin + min(t, total - 1) / NKC; };
     auto chunk_kc = [&](int t) -> int { return min(t, total - 1) % NKC; };
-    auto load_ids = [&](int t) {
-        const int sl = slot_of(chunk_e(t));
+    auto load_ids_of_slot = [&](int e_) {
+        const int sl = slot_of(e_);
 #pragma unroll
         for (int j = 0; j < APW; ++j) ids[j] = my_ids[j * 8 * E + sl];
     };
+    auto load_ids = [&](int t) { load_ids_of_slot(chunk_e(t)); };
     const int a_sw = (i >> 1) & 7;
     u32x4 araw[2][2];
     auto read_a = [&](int buf) {
@@ -652,13 +656,15 @@ __global__ void __launch_bounds__(64 * RT * CH) __attribute__((amdgpu_waves_per_
         u32x4 p1, p2, p3;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            unsigned int h0, m0_, l0, h1, m1_, l1;
-            ln_split3_bits(__uint_as_float(araw[s][j >> 1][(2 * j) & 3]), h0, m0_, l0);
-            ln_split3_bits(__uint_as_float(araw[s][j >> 1][(2 * j + 1) & 3]), h1, m1_, l1);
-            // two bf16 per dword, the lower channel in the low half-word: one byte permute per pair (the top halves of both words)
-            p1[j] = __builtin_amdgcn_perm(h1, h0, 0x07060302u);
-            p2[j] = __builtin_amdgcn_perm(m1_, m0_, 0x07060302u);
-            p3[j] = __builtin_amdgcn_perm(l1, l0, 0x07060302u);
+            // x = hi + mid + lo with each part the top 16 bits of the remainder (ln_split3_bits), written out so that only the two
+            // masks the subtractions need are computed: the byte permutes below take the top half-words of x, r1 and r2 directly.
+            // Two bf16 per dword, the lower channel in the low half-word.
+            const float x0 = __uint_as_float(araw[s][j >> 1][(2 * j) & 3]), x1 = __uint_as_float(araw[s][j >> 1][(2 * j + 1) & 3]);
+            const float r10 = x0 - __uint_as_float(__float_as_uint(x0) & 0xFFFF0000u), r11 = x1 - __uint_as_float(__float_as_uint(x1) & 0xFFFF0000u);
+            const float r20 = r10 - __uint_as_float(__float_as_uint(r10) & 0xFFFF0000u), r21 = r11 - __uint_as_float(__float_as_uint(r11) & 0xFFFF0000u);
+            p1[j] = __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
+            p2[j] = __builtin_amdgcn_perm(__float_as_uint(r11), __float_as_uint(r10), 0x07060302u);
+            p3[j] = __builtin_amdgcn_perm(__float_as_uint(r21), __float_as_uint(r20), 0x07060302u);
         }
 #if LN_CONV_R32_PROBE & 2
         p1 = araw[s][0];
@@ -706,6 +712,9 @@ __global__ void __launch_bounds__(64 * RT * CH) __attribute__((amdgpu_waves_per_
     // products of K-step s of one chunk: the NTW accumulation chains advance together (product p of every column tile, then
     // product p + 1); small terms first, the dominant product last
     auto products = [&](bf16x8 (&a)[3], u32x4 (&f)[NTW][3]) {
+#if LN_CONV_R32_PRIO
+        __builtin_amdgcn_s_setprio(LN_CONV_R32_PRIO);
+#endif
 #if LN_CONV_R32_PROBE & 1
         acc[0][0] += __uint_as_float(f[0][0][0] ^ f[NTW - 1][1][1] ^ f[0][2][2]) + (float)a[0][0] + (float)a[1][1] + (float)a[2][2];
 #else
@@ -715,10 +724,27 @@ __global__ void __launch_bounds__(64 * RT * CH) __attribute__((amdgpu_waves_per_
         LN_R32_PRODUCT(2, 0) LN_R32_PRODUCT(0, 2) LN_R32_PRODUCT(1, 1) LN_R32_PRODUCT(1, 0) LN_R32_PRODUCT(0, 1) LN_R32_PRODUCT(0, 0)
 #undef LN_R32_PRODUCT
 #endif
+#if LN_CONV_R32_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+    };
+    // the walk's next three chunks, advanced once per iteration (no division in the loop); past the end they stay on the last chunk
+    int w_e[3], w_kc[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) w_e[k] = chunk_e(k + 1), w_kc[k] = chunk_kc(k + 1);
+    auto advance = [&](int it) {  // after iteration `it`: w[k] becomes chunk it + 2 + k
+        w_e[0] = w_e[1], w_kc[0] = w_kc[1];
+        w_e[1] = w_e[2], w_kc[1] = w_kc[2];
+        if (it + 4 < total) {
+            if (++w_kc[2] == NKC) {
+                w_kc[2] = 0;
+                ++w_e[2];
+            }
+        }
     };
     auto requests = [&](int it, int first, int last) {  // pieces [first, last) of: bank chunk it + 1, rows of chunk it + 2
-        const int e1 = chunk_e(it + 1), kc1 = chunk_kc(it + 1);
-        const int e2 = chunk_e(it + 2), kc2 = chunk_kc(it + 2);
+        const int e1 = w_e[0], kc1 = w_kc[0];
+        const int e2 = w_e[1], kc2 = w_kc[1];
 #pragma unroll
         for (int k = first; k < last; ++k) {
             if (k < BPW) {
@@ -751,7 +777,7 @@ __global__ void __launch_bounds__(64 * RT * CH) __attribute__((amdgpu_waves_per_
         if (it > 0) products(nxt[1], fb1);  // second K-step of chunk it - 1 (its operands are in the other register set)
         LN_R32_PHASE(4);  // held-back products issued
         requests(it, 0, LN_CONV_R32_SPREAD ? NPIECES / 2 : NPIECES);
-        load_ids(it + 3);
+        load_ids_of_slot(w_e[2]);
         LN_R32_PHASE(5);  // requests issued
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt)
@@ -771,7 +797,7 @@ __global__ void __launch_bounds__(64 * RT * CH) __attribute__((amdgpu_waves_per_
         products(cur[0], fb0);
         LN_R32_PHASE(4);  // first K-step's products issued
         requests(it, 0, LN_CONV_R32_SPREAD ? NPIECES / 2 : NPIECES);
-        load_ids(it + 3);
+        load_ids_of_slot(w_e[2]);
         LN_R32_PHASE(5);  // requests issued
         split_step(0, nxt);
         products(cur[1], fb1);
@@ -780,6 +806,7 @@ __global__ void __launch_bounds__(64 * RT * CH) __attribute__((amdgpu_waves_per_
         split_step(1, nxt);
         LN_R32_PHASE(7);  // next rows split
 #endif
+        advance(it);
     };
     for (int it = 0; it < total; it += 2) {
         iteration(it, ap, ap_b);
