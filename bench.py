@@ -161,8 +161,8 @@ def algorithmic_work(kernel: str, n: int, m: int, d: int, v: int, f: int, e: int
     """(bound, unit, amount per launch) — SURVEY.md §8d per-unit figures x units per launch."""
     if kernel == "hash_build":  # k_point_keys + k_bucket_rows: read positions, write idx + w, write keys once (8d "splat fwd" minus the values)
         return "hbm", "GB/s", n * (4.0 * d + 8.0 * (d + 1)) + m * 4.0 * d
-    if kernel == "k_conv_mfma":  # SURVEY 8d: HBM-bound below 64 channels (MFMA figures ride along: mfma_work)
-        if v >= 128:
+    if kernel == "k_conv_mfma":  # SURVEY 8d: HBM-bound below 64 channels, MFMA-bound from 64 on (MFMA figures ride along: mfma_work)
+        if v >= 64:
             return "mfma", "TFLOP/s", 2.0 * m * e * v * f
         return "hbm", "GB/s", m * 4.0 * v + m * 4.0 * e + 4.0 * e * v * f + m * 4.0 * f
     if kernel == "k_conv_mfma_f16":
@@ -170,7 +170,7 @@ def algorithmic_work(kernel: str, n: int, m: int, d: int, v: int, f: int, e: int
     if kernel == "k_grad_filter_mfma":
         return "mfma", "TFLOP/s", 2.0 * m * e * v * f
     if kernel == "k_conv_backward_fused":  # value gradient + filter gradient of the convolution in one launch
-        if v >= 128:
+        if v >= 64:
             return "mfma", "TFLOP/s", 4.0 * m * e * v * f
         return "hbm", "GB/s", (m * 4.0 * f + m * 4.0 * e + 4.0 * e * v * f + m * 4.0 * v) + (m * 4.0 * v + m * 4.0 * f + m * 4.0 * e + 4.0 * e * v * f)
     if kernel in ("k_scatter_point_rows", "k_csr_reduce_segments"):  # splat accumulate / slice backward: read rows+idx+w, write vertex rows
@@ -203,7 +203,7 @@ KERNEL_GROUPS = {"hash_build": ["k_point_keys", "k_bucket_rows"]}  # launches th
 
 def pmc_traffic(kernel: str):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r<round>_pmc_traffic.json, newest round), or None."""
-    for rnd in (4, 3, 2, 1):
+    for rnd in (5, 4, 3, 2, 1):
         path = os.path.join(ROOT, "profiles", f"r{rnd}_pmc_traffic.json")
         try:
             with open(path) as f:

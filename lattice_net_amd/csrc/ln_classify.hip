@@ -7,8 +7,9 @@
 // Forward (k_slice_classify_forward_wave): tile = 64 points, channels in chunks of 32 (= one 128-byte line per vertex row).
 //   gather : 8 lanes per point read the chunk of each of the d+1 vertex rows as one line (float4 per lane), the sliced
 //            features h = sum_r row_r * (w_r + delta_w_r) go to LDS [64][33];
-//   linear : lane p owns point p and ALL classes in registers; the classifier weights are wave-uniform, so they come through
-//            the scalar cache (s_load) and cost no vector or LDS instruction: per (class, channel) one v_mul + one v_add.
+//   linear : lane p owns point p and ALL classes in registers; the classifier weights are wave-uniform and are broadcast from
+//            LDS (staged once per workgroup; an s_load variant through the scalar cache measured slower and was dropped):
+//            per (class, channel) one v_mul + one v_add.
 //   Every logit is still the serial sum over v ascending of W[c,v] * h[p,v] with separate multiply and add, then + b[c]
 //   (compiled with -ffp-contract=off): bit-identical to the golden vectors.
 //
@@ -28,15 +29,6 @@ __device__ __forceinline__ void ln_wave_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-
-typedef float v16f __attribute__((ext_vector_type(16)));
-// s_load_dwordx16 into SGPRs, issued where it is written; ln_swait is the matching s_waitcnt, tied to the registers it releases
-template <int BYTE_OFFSET>
-__device__ __forceinline__ void ln_sload16(v16f& r, const float* p, float& pin) {
-    // `pin`: a vector value of the arithmetic around the load; the compiler keeps the instruction between its producers and consumers
-    asm volatile("s_load_dwordx16 %0, %2, %3" : "=s"(r), "+v"(pin) : "s"(p), "n"(BYTE_OFFSET));
-}
-__device__ __forceinline__ void ln_swait(v16f& a, float& pin) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+v"(pin)); }
 
 #ifndef LN_SCW_PROBE
 #define LN_SCW_PROBE 0

@@ -67,16 +67,21 @@ struct LnProfState {
     std::vector<hipEvent_t> starts, stops;
     std::vector<const char*> sample_names;  // launch name of every sample (string literals of the LN_LAUNCH sites)
     size_t used = 0;
+    long long dropped = 0;  // matching launches that found every event pair taken
 };
 LnProfState g_prof;
 }  // namespace
 
 LnProfEvents ln_prof_next(const char* name) {
     LnProfEvents ev{nullptr, nullptr, false};
-    if (g_prof.max_samples > 0 && g_prof.used < g_prof.starts.size()) {
+    if (g_prof.max_samples > 0) {
         char key[72];
         snprintf(key, sizeof(key), ",%s,", name);
         if (!strcmp(g_prof.names, ",*,") || strstr(g_prof.names, key)) {
+            if (g_prof.used >= g_prof.starts.size()) {
+                ++g_prof.dropped;
+                return ev;
+            }
             ev.start = g_prof.starts[g_prof.used];
             ev.stop = g_prof.stops[g_prof.used];
             ev.armed = true;
@@ -103,6 +108,7 @@ extern "C" int ln_profile_begin(const char* kernel_names, int max_samples) {
     }
     snprintf(g_prof.names, sizeof(g_prof.names), ",%s,", kernel_names);
     g_prof.used = 0;
+    g_prof.dropped = 0;
     g_prof.max_samples = max_samples;
     return LN_OK;
 }
@@ -153,10 +159,28 @@ extern "C" int ln_profile_end_table(char* out, int out_bytes) {
     }
     int at = 0;
     out[0] = 0;
+    bool truncated = false;
     for (const Row& r : rows) {
         const int w = snprintf(out + at, size_t(out_bytes - at), "%s %d %.6f\n", r.name, r.launches, r.ms);
-        if (w < 0 || w >= out_bytes - at) break;
+        if (w < 0 || w >= out_bytes - at) {
+            out[at] = 0;
+            truncated = true;
+            break;
+        }
         at += w;
+    }
+    // samples that found no free event pair (ln_profile_begin's max_samples) and rows that did not fit `out` are reported, not dropped
+    // silently: a last line "DROPPED <samples> <rows>" and LN_ERR_ARG
+    const long long dropped = g_prof.dropped;
+    if (dropped > 0 || truncated) {
+        char tail[64];
+        const int w = snprintf(tail, sizeof(tail), "DROPPED %lld %d\n", dropped, truncated ? 1 : 0);
+        if (w > 0 && w < out_bytes) {
+            if (at + w >= out_bytes) at = out_bytes - w - 1;
+            memcpy(out + at, tail, size_t(w) + 1);
+        }
+        ln_set_error("ln_profile_end_table: %lld launches were not sampled (max_samples) / the table did not fit %d bytes", dropped, out_bytes);
+        if (!rc) rc = LN_ERR_ARG;
     }
     double total;
     int launches;

@@ -211,7 +211,7 @@ class HashTable:
     def init(self, pos_dim: int, val_dim: int, device):  # HashTable.cu:21-47
         self._storage = _TableStorage(self.m_capacity, pos_dim, device)
         self.m_values_tensor = torch.zeros((self.m_capacity, val_dim), dtype=torch.float32, device=device)
-        self._zero_beyond = (self.m_values_tensor, 0)  # (tensor, row from which it is known to be zero): see Lattice._build
+        self._zero_beyond = (weakref.ref(self.m_values_tensor), 0)  # (weak reference to the tensor, row from which it is known to be zero): see Lattice._build
         self._counters = torch.zeros((2,), dtype=torch.int32, device=device)
         self.m_nr_filled_is_dirty = True
         self.clear(lazy=True)  # rides in the first build call; every other reader flushes it
@@ -333,6 +333,7 @@ class HashTable:
     def set_values(self, new_values: torch.Tensor):  # HashTable.cu:112-115
         self.flush()  # a deferred clear must hit the OLD values tensor, not the one being installed
         self.m_values_tensor = new_values.contiguous()
+        self._zero_beyond = None  # content unknown: the next clear covers the whole tensor
 
 
 def _parse_lattice_cfg(path: str) -> dict:
@@ -528,11 +529,11 @@ class Lattice:
         clear_elems = 0
         if clear_vals is not None:
             rows = int(clear_vals.shape[0])
-            known = getattr(ht, "_zero_beyond", None)
-            zb = known[1] if (known is not None and known[0] is clear_vals) else None
+            known = getattr(ht, "_zero_beyond", None)  # (a weak reference: a replaced accumulator is not kept alive by this note)
+            zb = known[1] if (known is not None and known[0]() is clear_vals) else None
             clear_rows = rows if zb is None else min(rows, max(cap, zb))
             clear_elems = clear_rows * int(clear_vals.shape[1])
-            ht._zero_beyond = (clear_vals, min(rows, cap))  # after this build: every row the build cannot reach is zero
+            ht._zero_beyond = (weakref.ref(clear_vals), min(rows, cap))  # after this build: every row the build cannot reach is zero
 
         def issue(force_atomic: bool):
             lib = _lib.load()
@@ -599,6 +600,7 @@ class Lattice:
             st.hash_capacity = max(st.hash_capacity, want)
         elif st.hash_capacity and st.hash_capacity < st.capacity:
             ht.flush()
+            ht._zero_beyond = None  # the hashed range widens under an uncleared table: the next clear covers the whole accumulator
             st.hash_capacity = st.capacity
             t = ht.c_table()
             _lib.check(_lib.load().ln_rehash(C.byref(t), self._stream()), "ln_rehash")
@@ -613,7 +615,9 @@ class Lattice:
 
     def canonicalize_rows(self, idx: torch.Tensor):
         """Relabels the rows of the table the last (bucketed, slot-order) build produced, `idx` and the build's cached CSR into the
-        reference's serial numbering (ln_canonicalize), and drops every cache that holds the old row ids (neighbour lists)."""
+        reference's serial numbering (ln_canonicalize), and drops every cache that holds the old row ids (neighbour lists).
+        PRECONDITION: call it straight after the build — value rows already accumulated (splat, set_values) and tensors derived from
+        the old numbering (neighbour lists handed out, splat indices other than `idx`) are NOT permuted."""
         ht = self.m_hash_table
         st = ht._storage
         lib = _lib.load()
@@ -722,10 +726,10 @@ class Lattice:
                 ht.m_values_tensor = torch.empty((cap, v), dtype=torch.float32, device=self._dev(positions_raw))
                 if reach < cap:
                     ht.m_values_tensor[reach:].zero_()
-                ht._zero_beyond = (ht.m_values_tensor, reach)
+                ht._zero_beyond = (weakref.ref(ht.m_values_tensor), reach)
             else:
                 ht.m_values_tensor = torch.zeros((cap, v), dtype=torch.float32, device=self._dev(positions_raw))
-                ht._zero_beyond = (ht.m_values_tensor, 0)
+                ht._zero_beyond = (weakref.ref(ht.m_values_tensor), 0)
             ht._clear_pending = pending
         idx, w = self._build(positions_raw, True)
         tv = ht.m_values_tensor
@@ -764,7 +768,7 @@ class Lattice:
             # deep copy + clear of three CAP-sized tensors (Lattice.cu:376-391) == fresh cleared buffers
             nh._storage = _TableStorage(oh.capacity(), d, dev)
             nh.m_values_tensor = torch.zeros((oh.capacity(), oh.val_dim() or v), dtype=torch.float32, device=dev)
-            nh._zero_beyond = (nh.m_values_tensor, 0)
+            nh._zero_beyond = (weakref.ref(nh.m_values_tensor), 0)
             nh._counters = torch.zeros((2,), dtype=torch.int32, device=dev)
             nh.clear(lazy=True)  # issued inside the build call
         else:

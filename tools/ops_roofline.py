@@ -48,12 +48,13 @@ def _profile(lib, fn, reps, warmup=3):
     for _ in range(reps):
         fn()
     torch.cuda.synchronize()
-    buf = C.create_string_buffer(8192)
-    if lib.ln_profile_end_table(buf, len(buf)) != 0:
+    buf = C.create_string_buffer(16384)
+    if lib.ln_profile_end_table(buf, len(buf)) != 0:  # (also when launches went unsampled or rows did not fit: "DROPPED" line)
         raise RuntimeError(lib.ln_last_error_string())
     kernels = []
     for line in buf.value.decode().splitlines():
         name, cnt, ms = line.split()
+        assert name != "DROPPED"
         kernels.append({"kernel": name, "launches_per_call": round(int(cnt) / reps, 2), "avg_us": round(float(ms) / int(cnt) * 1e3, 2),
                         "us_per_call": round(float(ms) / reps * 1e3, 2)})
     return kernels
@@ -78,6 +79,13 @@ def _entry(row, what, kernels, hbm_bytes, reps, dense=None, note=None):
                               "executed_tflops": round((6.0 if b3 else 1.0) * tf, 2), "peak_tflops": peak,
                               "frac_of_instruction_peak": round((6.0 if b3 else 1.0) * tf / peak, 4),
                               "frac_fp32_equivalent_of_f32_peak": round(tf / MFMA_F32_PEAK_TFLOPS, 4)})
+        # the row's headline figure is the bound the launches sit closer to: a dense launch on the matrix cores is priced against the
+        # dense bf16 / fp32 MFMA peak when that fraction exceeds the HBM one (HBM-bound below 64 channels, MFMA-bound from 128)
+        if e["mfma"]:
+            top = max(e["mfma"], key=lambda r: r["frac_of_instruction_peak"])
+            e["hbm"] = {"achieved": e["achieved"], "peak": e["peak"], "unit": e["unit"], "frac": e["frac"]}
+            if e["frac"] is None or top["frac_of_instruction_peak"] > e["frac"]:
+                e.update(bound="mfma", achieved=top["executed_tflops"], peak=top["peak_tflops"], unit="TFLOP/s", frac=top["frac_of_instruction_peak"])
     if note:
         e["note"] = note
     return e
