@@ -1576,7 +1576,11 @@ __global__ void __launch_bounds__(64 * WV * WF, (WV * WF) > 8 ? 1 : LN_GFB_WAVES
     static_assert(E % EG == 0, "slot groups");
     constexpr int TPV = VT / WV, TPF = FT / WF;      // tiles of a wave
     constexpr int THREADS = 64 * WV * WF;
-    constexpr int RSA = V + 8, RSG = F + 8;          // bf16 elements per staged row (+16 bytes: the four rows a tr read touches start in different banks)
+    // bf16 elements per staged row: + 32 bytes, i.e. a row stride that is an odd multiple of 8 dwords.  A transposing read is served in
+    // two groups of 32 lanes; with the row mapping of `frag` below a group touches 8 CONSECUTIVE rows x 32 bytes, which then fall on 8
+    // disjoint sets of 8 banks.  (Round 4's + 16 bytes with rows {8q .. 8q+3} per 16 lanes put rows r and r + 2 on overlapping banks and
+    // the two halves of a group on the same ones: SQ_LDS_BANK_CONFLICT was 41 % of the LDS-array cycles, profiles/r5_pmc_lds.json.)
+    constexpr int RSA = V + 16, RSG = F + 16;
     constexpr int PA = LN_GFB_SUB * RSA, PG = LN_GFB_SUB * RSG;  // one plane
     constexpr int A4 = LN_GFB_SUB * V / 4 / THREADS, G4 = LN_GFB_SUB * F / 4 / THREADS;  // float4 fetched per thread and sub-tile
     static_assert(A4 >= 1 && G4 >= 1 && VT % WV == 0 && FT % WF == 0 && (LN_GFB_SUB * V / 4) % THREADS == 0 && (LN_GFB_SUB * F / 4) % THREADS == 0,
@@ -1650,9 +1654,10 @@ __global__ void __launch_bounds__(64 * WV * WF, (WV * WF) > 8 ? 1 : LN_GFB_WAVES
         *reinterpret_cast<uint2*>(dst + plane) = make_uint2((md[0] >> 16) | md[1], (md[2] >> 16) | md[3]);
         *reinterpret_cast<uint2*>(dst + 2 * plane) = make_uint2((lo[0] >> 16) | lo[1], (lo[2] >> 16) | lo[3]);
     };
-    auto frag = [&](const unsigned short* base, int rs) {  // 8 bf16 down the rows: rows 8q..8q+7 of the 32-row step, one column
+    auto frag = [&](const unsigned short* base, int rs) {  // 8 bf16 down the rows: rows 4q..4q+3 and 16+4q..16+4q+3 of the 32-row step
+        // (the order of the contraction inside a step is free as long as both operands use the same one), one column
         const gf_short4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((gf_short4 __attribute__((address_space(3)))*)(base));
-        const gf_short4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((gf_short4 __attribute__((address_space(3)))*)(base + 4 * rs));
+        const gf_short4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((gf_short4 __attribute__((address_space(3)))*)(base + 16 * rs));
         u32x4 p;
         p[0] = (unsigned int)(unsigned short)lo4[0] | ((unsigned int)(unsigned short)lo4[1] << 16);
         p[1] = (unsigned int)(unsigned short)lo4[2] | ((unsigned int)(unsigned short)lo4[3] << 16);
@@ -1699,7 +1704,7 @@ __global__ void __launch_bounds__(64 * WV * WF, (WV * WF) > 8 ? 1 : LN_GFB_WAVES
             }
 #pragma unroll
             for (int st = 0; st < ((LN_GFB_PROBE & 1) ? 0 : LN_GFB_SUB / 32); ++st) {
-                const int row0 = 32 * st + 8 * q + (i >> 2);
+                const int row0 = 32 * st + 4 * q + (i >> 2);
                 bf16x8 fa[TPV][3], fb[TPF][3];
 #pragma unroll
                 for (int a = 0; a < TPV; ++a)
@@ -1806,7 +1811,7 @@ static int ln_gf_launch_partials(const int* nbr, const float* values_neigh, cons
         const int rows = ln_gfb_rows(m, filter_extent, val_dim, nr_filters);
         const int chunks_b3 = ln_div_up(m, rows);
         const dim3 grid(chunks_b3, filter_extent / LN_GFB_EG, (val_dim / vs) * (nr_filters / fs));
-        const size_t lds = (size_t)3 * LN_GFB_SUB * ((vs + 8) + (fs + 8)) * sizeof(unsigned short);
+        const size_t lds = (size_t)3 * LN_GFB_SUB * ((vs + 16) + (fs + 16)) * sizeof(unsigned short);
 #define LN_GFB_CASE(A, B, WVV, WFF)                                                                                                    \
     if (vs == 16 * A && fs == 16 * B) {                                                                                                \
         static bool attr_set = false;                                                                                                  \

@@ -333,12 +333,12 @@ __global__ void __launch_bounds__(256)
     constexpr int V = VT * 16, F = FT * 16;
     constexpr int TILES = VT * FT;
     constexpr int TPW = (TILES + 3) / 4;
-    // sub-tiles are staged ROW-major (one 8-byte LDS store per 4 channels; rows padded by 4 halfs so that the 4 rows a 16-lane
-    // group reads together start in different banks) and read "down the rows" with ds_read_b64_tr_b16: lane i of a 16-lane
+    // sub-tiles are staged ROW-major (one 8-byte LDS store per 4 channels; rows padded by 16 halfs, see SA below) and read "down
+    // the rows" with ds_read_b64_tr_b16: lane i of a 16-lane
     // group passes the address of row i >> 2, columns 4 (i & 3).. of a 4 x 16 block and receives rows 0..3 of column i
     // (tools/probes/tr_read_probe.cpp) - the MFMA operand of a contraction over rows.  (The first version stored every half
     // on its own into transposed arrays: 256 two-byte LDS stores per thread and chunk.)
-    constexpr int SA = V + 4, SG = F + 4;
+    constexpr int SA = V + 16, SG = F + 16;  // row stride = an odd multiple of 8 dwords: the 8 consecutive rows a 32-lane group of a transposing read touches fall on disjoint banks
     __shared__ __attribute__((aligned(16))) _Float16 s_a[LN_GF16_SUB * SA];
     __shared__ __attribute__((aligned(16))) _Float16 s_g[LN_GF16_SUB * SG];
     typedef short shortx4 __attribute__((ext_vector_type(4)));
@@ -398,14 +398,15 @@ __global__ void __launch_bounds__(256)
             const int tile = wave + 4 * t;
             if (tile < TILES) {
                 const int vt = tile / FT, ft = tile - vt * FT;
-                const _Float16* pa = s_a + (8 * q + (i >> 2)) * SA + vt * 16 + 4 * (i & 3);
-                const _Float16* pg = s_g + (8 * q + (i >> 2)) * SG + ft * 16 + 4 * (i & 3);
+                // rows 4q..4q+3 and 16+4q..16+4q+3 of the 32-row step (any order of the contraction that both operands share)
+                const _Float16* pa = s_a + (4 * q + (i >> 2)) * SA + vt * 16 + 4 * (i & 3);
+                const _Float16* pg = s_g + (4 * q + (i >> 2)) * SG + ft * 16 + 4 * (i & 3);
 #pragma unroll
                 for (int s = 0; s < LN_GF16_SUB / 32; ++s) {
                     const shortx4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((shortx4 __attribute__((address_space(3)))*)(pa + 32 * s * SA));
-                    const shortx4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((shortx4 __attribute__((address_space(3)))*)(pa + (32 * s + 4) * SA));
+                    const shortx4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((shortx4 __attribute__((address_space(3)))*)(pa + (32 * s + 16) * SA));
                     const shortx4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((shortx4 __attribute__((address_space(3)))*)(pg + 32 * s * SG));
-                    const shortx4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((shortx4 __attribute__((address_space(3)))*)(pg + (32 * s + 4) * SG));
+                    const shortx4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((shortx4 __attribute__((address_space(3)))*)(pg + (32 * s + 16) * SG));
                     const shortx8 a = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
                     const shortx8 b = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
                     acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(halfx8, a), __builtin_bit_cast(halfx8, b), acc[t], 0, 0, 0);

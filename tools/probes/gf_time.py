@@ -1,5 +1,5 @@
 import ctypes as C, os, sys, torch, numpy as np
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import lattice_net_amd as L
 from lattice_net_amd import synthetic
 from lattice_net_amd.lattice_funcs import ConvIm2RowLattice
