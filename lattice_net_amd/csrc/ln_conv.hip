@@ -1154,6 +1154,9 @@ static bool ln_conv_launch_v(int nr_filters, const int* nbr, const float* values
 //   B = W_e split while the bank is staged: one 16-byte fragment per (slot, column tile, part, lane (f, q)) = W[e][8q..8q+7][f].
 // After the one barrier behind the staging the slot loop is gathers, register splits and 12 matrix instructions per slot and wave.
 // ------------------------------------------------------------------------------------------
+#ifndef LN_FWD_LINE
+#define LN_FWD_LINE 1  // 0: the fragment-shaped gathers of rounds 2-4 (A/B)
+#endif
 template <int T>
 __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(T, T)))
     k_conv_forward_b3(const int* __restrict__ nbr, const float* __restrict__ values, const float* __restrict__ filter, int m,
@@ -1163,6 +1166,17 @@ __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(T,
     constexpr int FRAG16 = E * NT * 3 * 64;  // 16-byte fragments of the split bank (54 KB)
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[FRAG16 * 16];
     const u32x4* s_frag = reinterpret_cast<const u32x4*>(s_raw);
+#if LN_FWD_LINE
+    // Line-shaped gathers (round 5).  Loads shaped like the MFMA fragment — lane (i, q) reads its 32-byte quarter of row i — touch 64
+    // different 128-byte lines per wave-instruction and run at half the rate of loads in which 8 adjacent lanes read one whole row
+    // (tools/probes/gather_layout_probe.cpp: 3.5 vs 7.0 TB/s whatever the hit rate).  So lane l loads piece l & 7 (16 bytes) of rows
+    // l >> 3 and 8 + (l >> 3) of the wave's 16, and the wave re-shapes the 2 KB through a private LDS region: two 16-byte stores, two
+    // 16-byte reads per slot.  Piece p of row r sits at position p ^ f(r), f(r) = ((r >> 1) & 7) ^ (((r >> 2) & 1) << 1):
+    // conflict-free for the 16-lane groups of ds_read_b128 under the (i, q) mapping (checked exhaustively) and for the stores
+    // (8 adjacent lanes = one row).  LDS operations of one wave execute in program order: no barrier, only a compiler fence.
+    __shared__ __attribute__((aligned(16))) floatx4 s_x[4 * T][16 * 8];
+    __shared__ int s_nbr[64 * T * E];
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int i = lane & 15;
@@ -1184,16 +1198,48 @@ __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(T,
 #pragma unroll
         for (int j = 0; j < 8; ++j) wv[s][j] = (x < ITEMS) ? filter[(size_t)(ev8 * 8 + j) * F + f] : 0.f;
     }
+#if LN_FWD_LINE
+    {
+        const size_t g0 = (size_t)blockIdx.x * (64 * T) * E, g_end = (size_t)m * E;
+        for (int x = tid; x < 64 * T * E; x += THREADS) s_nbr[x] = (g0 + x < g_end) ? nbr[g0 + x] : -1;
+    }
+    __syncthreads();
+    const int wv_ = tid >> 6;
+    const int lr = lane >> 3;  // the two rows this lane loads: lr and 8 + lr
+    int nb[2][E];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < E; ++e) nb[j][e] = s_nbr[(wv_ * 16 + 8 * j + lr) * E + e];
+    auto fsw = [](int r) -> int { return ((r >> 1) & 7) ^ (((r >> 2) & 1) << 1); };
+    floatx4* xw[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) xw[j] = &s_x[wv_][(8 * j + lr) * 8 + ((lane & 7) ^ fsw(8 * j + lr))];
+    const floatx4* xr0 = &s_x[wv_][i * 8 + ((2 * q) ^ fsw(i))];
+    const floatx4* xr1 = &s_x[wv_][i * 8 + ((2 * q + 1) ^ fsw(i))];
+#else
     int nb[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) nb[e] = (my_row < m) ? nbr[(size_t)my_row * E + e] : -1;
+#endif
 #ifndef LN_FWD_DEPTH
 #define LN_FWD_DEPTH 4
 #endif
     constexpr int DEPTH = LN_FWD_DEPTH;  // ring of gathered quarter rows: DEPTH - 1 gathers in flight (4: 14.9 us, 7: 15.7, 10 = all nine up front: 17.1)
+#if LN_FWD_LINE
+    floatx4 a[DEPTH][2];
+    auto gather = [&](int e, floatx4 (&dst)[2]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            dst[j] = *reinterpret_cast<const floatx4*>(values + (size_t)(nb[j][e] >= 0 ? nb[j][e] : 0) * V + (lane & 7) * 4);
+    };
+#pragma unroll
+    for (int k = 0; k < DEPTH - 1 && k < E; ++k) gather(k, a[k]);
+#else
     float a[DEPTH][KQ];
 #pragma unroll
     for (int k = 0; k < DEPTH - 1 && k < E; ++k) ln_load_quarter<KQ>(values + (size_t)(nb[k] >= 0 ? nb[k] : 0) * V + q * KQ, a[k]);
+#endif
     // bank -> split -> LDS fragments (16-byte unit ((e * NT + f / 16) * 3 + part) * 64 + (v / 8) * 16 + f % 16 holds rows v..v+7)
     u32x4* s_frag_w = reinterpret_cast<u32x4*>(s_raw);
 #pragma unroll
@@ -1219,15 +1265,35 @@ __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(T,
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < E; ++e) {
+#if LN_FWD_LINE
+        if (e + DEPTH - 1 < E) gather(e + DEPTH - 1, a[(e + DEPTH - 1) % DEPTH]);
+        // rows of absent neighbours are zeroed by the lane that loaded them; then the wave's 16 x 32 floats change shape through LDS
+#pragma unroll
+        for (int j = 0; j < 2; ++j) *xw[j] = (nb[j][e] >= 0) ? a[e % DEPTH][j] : floatx4{0.f, 0.f, 0.f, 0.f};
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const floatx4 lo4 = *xr0, hi4 = *xr1;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const float ae[KQ] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+        #else
         float (&ae)[KQ] = a[e % DEPTH];
         if (e + DEPTH - 1 < E)
             ln_load_quarter<KQ>(values + (size_t)(nb[e + DEPTH - 1] >= 0 ? nb[e + DEPTH - 1] : 0) * V + q * KQ, a[(e + DEPTH - 1) % DEPTH]);
+#endif
         u32x4 p1, p2, p3;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             unsigned int h0, m0_, l0, h1, m1_, l1;
+#if LN_FWD_LINE
+            ln_split3_bits(ae[2 * j], h0, m0_, l0);
+            ln_split3_bits(ae[2 * j + 1], h1, m1_, l1);
+#else
             ln_split3_bits(nb[e] >= 0 ? ae[2 * j] : 0.f, h0, m0_, l0);
             ln_split3_bits(nb[e] >= 0 ? ae[2 * j + 1] : 0.f, h1, m1_, l1);
+#endif
             p1[j] = (h0 >> 16) | h1;
             p2[j] = (m0_ >> 16) | m1_;
             p3[j] = (l0 >> 16) | l1;
