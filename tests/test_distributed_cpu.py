@@ -33,9 +33,11 @@ def _worker(rank, world, port, out_dir):
     checksum = float(out.double().abs().sum())
     total = sharding.gather_sum(dist, checksum, dev)
     tmax = sharding.max_over_ranks(dist, 1.0 + rank, dev)
+    tlo, thi = sharding.min_max_over_ranks(dist, 1.0 + rank, dev)     # the spread bench.py puts on the line at N > 1
+    cores = sharding.pin_launch_thread(rank, world)                    # each rank on its own slice of the host's cores
     sharding.barrier(dist)
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), W=W.numpy(), m=lat.m, checksum=checksum, total=total, tmax=tmax,
-             pos0=pos[0].numpy())
+             pos0=pos[0].numpy(), tlo=tlo, thi=thi, cores=np.array(cores))
     dist.destroy_process_group()
 
 
@@ -48,6 +50,9 @@ def test_two_rank_sharding(tmp_path):
     assert r[0]["total"] == r[1]["total"]
     assert abs(float(r[0]["total"]) - (float(r[0]["checksum"]) + float(r[1]["checksum"]))) < 1e-6 * float(r[0]["total"])
     assert float(r[0]["tmax"]) == float(r[1]["tmax"]) == 2.0       # whole-job time = slowest rank
+    assert [float(r[i]["tlo"]) for i in range(2)] == [1.0, 1.0] and [float(r[i]["thi"]) for i in range(2)] == [2.0, 2.0]
+    if len(os.sched_getaffinity(0)) >= 4:                          # disjoint core slices
+        assert not set(r[0]["cores"].tolist()) & set(r[1]["cores"].tolist())
 
 
 def test_cloud_assignment_round_robin():
