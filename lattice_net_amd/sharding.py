@@ -40,17 +40,69 @@ def init(backend: str, device=None):
     return dist
 
 
-def pin_launch_thread(local_rank: int, local_world: int) -> List[int]:
-    """Pins the calling (kernel-launching) thread's process to an own slice of the host's cores BEFORE the first GPU call: a
-    step of the hot path is ~100 us of GPU time, so the launch thread is on the critical path, and eight unpinned ranks migrate
-    across sockets.  The cores this process may already use are cut into `local_world` contiguous slices (contiguous logical
-    CPUs share a NUMA node on the MI355X hosts); rank r takes slice r.  LATTICE_NO_AFFINITY=1 opts out; a no-op for one rank
-    or without sched_setaffinity.  Returns the cores in use afterwards."""
+def _parse_cpulist(text: str) -> List[int]:
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        out.extend(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def gpu_numa_nodes(sysfs_root: str = "/sys") -> List[int]:
+    """NUMA node of every AMD GPU of the host in PCI-address order (the order HIP enumerates devices in by default), read from
+    sysfs — no GPU call.  Display controllers (class 0x03..) and processing accelerators (class 0x12..) of vendor 0x1002; -1 where
+    the kernel does not know the node."""
+    base = os.path.join(sysfs_root, "bus", "pci", "devices")
+    found = []
+    try:
+        names = sorted(os.listdir(base))
+    except OSError:
+        return []
+    for name in names:
+        try:
+            with open(os.path.join(base, name, "vendor")) as f:
+                if f.read().strip().lower() != "0x1002":
+                    continue
+            with open(os.path.join(base, name, "class")) as f:
+                cls = f.read().strip().lower()
+            if not (cls.startswith("0x03") or cls.startswith("0x12")):
+                continue
+            with open(os.path.join(base, name, "numa_node")) as f:
+                found.append(int(f.read().strip()))
+        except (OSError, ValueError):
+            continue
+    return found
+
+
+def pin_launch_thread(local_rank: int, local_world: int, sysfs_root: str = "/sys") -> List[int]:
+    """Pins the calling (kernel-launching) process to cores of its own BEFORE the first GPU call: a step of the hot path is ~100 us
+    of GPU time, so the launch thread is on the critical path, and eight unpinned ranks migrate across sockets.
+    Where sysfs names the NUMA node of every GPU (and there are at least `local_world` GPUs), rank r takes the cores of GPU r's node
+    that this process may use, divided among the ranks whose GPUs share that node; otherwise the allowed cores are cut into
+    `local_world` contiguous slices.  LATTICE_NO_AFFINITY=1 opts out; a no-op for one rank or without sched_setaffinity.
+    Returns the cores in use afterwards."""
     have = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else []
     if local_world <= 1 or os.environ.get("LATTICE_NO_AFFINITY") or len(have) < 2 * local_world:
         return have
-    per = len(have) // local_world
-    mine = have[local_rank * per:(local_rank + 1) * per]
+    mine = None
+    nodes = gpu_numa_nodes(sysfs_root)
+    if len(nodes) >= local_world and all(n >= 0 for n in nodes[:local_world]):
+        node = nodes[local_rank]
+        try:
+            with open(os.path.join(sysfs_root, "devices", "system", "node", f"node{node}", "cpulist")) as f:
+                node_cpus = [c for c in _parse_cpulist(f.read()) if c in set(have)]
+        except (OSError, ValueError):
+            node_cpus = []
+        sharers = [r for r in range(local_world) if nodes[r] == node]
+        per = len(node_cpus) // max(len(sharers), 1)
+        if per >= 1:
+            k = sharers.index(local_rank)
+            mine = node_cpus[k * per:(k + 1) * per]
+    if not mine:
+        per = len(have) // local_world
+        mine = have[local_rank * per:(local_rank + 1) * per]
     try:
         os.sched_setaffinity(0, mine)
     except OSError:

@@ -211,3 +211,40 @@ def test_launch_thread_pinning_cuts_the_allowed_cores_into_rank_slices():
         os.sched_setaffinity(0, have)
     lo, hi = sharding.min_max_over_ranks(None, 2.5, "cpu")
     assert (lo, hi) == (2.5, 2.5)
+
+
+def test_launch_thread_pinning_follows_the_numa_node_of_the_ranks_gpu(tmp_path):
+    """sharding.pin_launch_thread with a sysfs that names the GPUs' NUMA nodes (a fake tree): two GPUs on node 1, one on node 0; the
+    ranks of node 1 share its cores, the rank of node 0 gets all of node 0's; devices of other vendors / classes are ignored."""
+    import os
+    from lattice_net_amd import sharding
+    have = sorted(os.sched_getaffinity(0))
+    if len(have) < 6:
+        pytest.skip("needs six cores")
+    half = len(have) // 2
+    node_cpus = {0: have[:half], 1: have[half:]}
+    devs = {"0000:05:00.0": ("0x1002", "0x120000", 1), "0000:26:00.0": ("0x1002", "0x030000", 0), "0000:45:00.0": ("0x1002", "0x120000", 1),
+            "0000:01:00.0": ("0x8086", "0x020000", 0), "0000:46:00.0": ("0x1002", "0x040300", 1)}
+    for name, (vendor, cls, node) in devs.items():
+        d = tmp_path / "bus" / "pci" / "devices" / name
+        d.mkdir(parents=True)
+        (d / "vendor").write_text(vendor + "\n")
+        (d / "class").write_text(cls + "\n")
+        (d / "numa_node").write_text(str(node) + "\n")
+    for node, cpus in node_cpus.items():
+        d = tmp_path / "devices" / "system" / "node" / f"node{node}"
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(",".join(str(c) for c in cpus) + "\n")
+    assert sharding.gpu_numa_nodes(str(tmp_path)) == [1, 0, 1]
+    assert sharding._parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    try:
+        got = []
+        for rank in range(3):
+            os.sched_setaffinity(0, have)
+            got.append(sharding.pin_launch_thread(rank, 3, sysfs_root=str(tmp_path)))
+        per = len(node_cpus[1]) // 2
+        assert got[0] == node_cpus[1][:per] and got[2] == node_cpus[1][per:2 * per] and got[1] == node_cpus[0]
+        os.sched_setaffinity(0, have)
+        assert sharding.pin_launch_thread(1, 2, sysfs_root=str(tmp_path / "nothing_here")) == have[half:2 * half]  # no sysfs: contiguous slices
+    finally:
+        os.sched_setaffinity(0, have)
