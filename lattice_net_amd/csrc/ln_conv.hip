@@ -590,7 +590,8 @@ __global__ void __launch_bounds__(64 * RT * CH) __attribute__((amdgpu_waves_per_
     const int i = lane & 31;
     const int h = lane >> 5;
     const int m0 = blockIdx.x * R + rt * 32;
-    f_off += blockIdx.y * (32 * NT) + ch * (32 * NTW);
+    const int f_wg = f_off + blockIdx.y * (32 * NT);  // first column of the workgroup
+    f_off = f_wg + ch * (32 * NTW);                    // ... of this wave
     {
         const size_t g0 = (size_t)blockIdx.x * R * E, g_end = (size_t)m * E;
         for (int x = tid; x < R * E; x += 64 * W) s_nbr[x] = (g0 + x < g_end) ? nbr[g0 + x] : -1;
@@ -679,7 +680,20 @@ __global__ void __launch_bounds__(64 * RT * CH) __attribute__((amdgpu_waves_per_
     // next iteration has been passed, so that the matrix pipe has work while the first fragments of the new chunk are on their way
     // from LDS (every wave of the workgroup leaves the barrier in the same state).  In flight across an iteration: the bank chunk
     // t + 1 and the rows of chunk t + 2.  Two register sets of split operands alternate (iterations come in pairs: no copies).
-    __syncthreads();  // the ids
+    // A tile none of whose rows has any neighbour (static-rows mode launches over a row BOUND: the tiles past the lattice's real rows
+    // hold -1 everywhere) writes zeros and leaves: 46.5 k rows under a 6 % bound are 257 workgroups of 192 rows — one more than the
+    // chip has CUs, i.e. a second round for nothing (the whole-network graph ran 0.17 ms slower with the 192-row split-K tiles).
+    {
+        bool any = false;
+        for (int x = tid; x < R * E; x += 64 * W) any |= s_nbr[x] >= 0;
+        if (!__syncthreads_or(any)) {  // (also the barrier behind the id copy)
+            for (int x = tid; x < R * (32 * NT / 4); x += 64 * W) {
+                const int row = blockIdx.x * R + x / (32 * NT / 4), c4 = x % (32 * NT / 4);
+                if (row < m) *reinterpret_cast<float4*>(out + (size_t)row * f_total + f_wg + c4 * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            return;
+        }
+    }
     load_ids(0);
 #pragma unroll
     for (int k = 0; k < NPIECES; ++k) dma_piece(k, chunk_e(0), chunk_kc(0), 0);
@@ -834,6 +848,204 @@ __global__ void __launch_bounds__(64 * RT * CH) __attribute__((amdgpu_waves_per_
         for (int r = 0; r < 16; ++r) {
             const int row = m0 + 8 * (r >> 2) + 4 * h + (r & 3);
             if (row < m) out[(size_t)row * f_total + f_off + nt * 32 + i] = acc[nt][r];
+        }
+    }
+}
+
+// Split-K form of the wide convolution (k_conv_rows32sk_b3): the two waves of a row tile share the COLUMNS and split the two K-steps of
+// every 32-channel chunk between them (wave kh takes channels 16 kh .. 16 kh + 15), each with its own accumulators for all NT column
+// tiles; the pair's partial sums meet once, through LDS, behind the slot loop.  Against the column-split form (k_conv_rows32_b3 with
+// CH = 2): a wave splits only the 8 floats per lane of ITS K-step (the operand split is no longer done twice), reads half the bank
+// fragments, and a workgroup of 6 x 2 waves covers 192 rows for ANY number of column tiles — 96 filters (three tiles) had to run as
+// four waves x 128 rows with two workgroups per CU (0.31 of the matrix pipe against 0.43 at 128 filters).
+template <int V, int NT, int RT, bool FLIP>
+__global__ void __launch_bounds__(128 * RT) __attribute__((amdgpu_waves_per_eu((2 * RT + 3) / 4, (2 * RT) % 6 == 0 ? 3 : 2)))
+    k_conv_rows32sk_b3(const int* __restrict__ nbr, const float* __restrict__ values, const u32x4* __restrict__ bank, int m, int E,
+                       float* __restrict__ out, int f_total, int f_off, int e_per) {
+    const int e_begin = blockIdx.z * e_per;
+    const int e_end = min(E, e_begin + e_per);
+    out += (size_t)blockIdx.z * m * f_total;
+    constexpr int W = 2 * RT;                // waves
+    constexpr int R = 32 * RT;               // rows
+    constexpr int NKC = V / 32;              // channel chunks per slot
+    constexpr int BCH16 = 2 * NT * 3 * 64;   // 16-byte fragments of one bank chunk
+    constexpr int BPIECES = BCH16 / 64;
+    constexpr int BPW = (BPIECES + W - 1) / W;
+    constexpr int APW = 2;                   // A pieces per wave (of the four of its row tile)
+    constexpr int NPIECES = BPW + APW;
+    static_assert(V % 32 == 0 && NT >= 1 && NT <= 4 && W <= 16, "rows32sk shape");
+    // the partial sums of the kh = 1 waves (RT tiles x NT x 16 registers x 64 lanes x 4 bytes) are parked over s_b and s_a at the end
+    constexpr int PARK16 = RT * NT * 16 * 64 / 4;
+    constexpr int POOL16 = (2 * BCH16 + 2 * RT * 256) > PARK16 ? (2 * BCH16 + 2 * RT * 256) : PARK16;
+    __shared__ u32x4 s_pool[POOL16];
+    u32x4* s_b = s_pool;                     // [2][BCH16]
+    u32x4* s_a = s_pool + 2 * BCH16;         // [2][RT][256]: per row tile 32 rows x 8 positions of 16 bytes
+    __shared__ int s_nbr[R * LN_CONV_LDS_E];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rt = wave >> 1, kh = wave & 1;
+    const int i = lane & 31;
+    const int h = lane >> 5;
+    const int m0 = blockIdx.x * R + rt * 32;
+    f_off += blockIdx.y * (32 * NT);
+    {
+        const size_t g0 = (size_t)blockIdx.x * R * E, g_end = (size_t)m * E;
+        for (int x = tid; x < R * E; x += 64 * W) s_nbr[x] = (g0 + x < g_end) ? nbr[g0 + x] : -1;
+    }
+    auto slot_of = [&](int e) -> int { return (FLIP && e < E - 1) ? (e ^ 1) : e; };
+    const int a_row = lane >> 3;  // A piece j of a row tile = rows 8j .. 8j+7; this wave requests pieces 2 kh and 2 kh + 1
+    const int* my_ids = s_nbr + (rt * 32 + kh * 16 + a_row) * E;
+    const unsigned int lds_b = __builtin_amdgcn_readfirstlane(ln_lds_addr(s_b));
+    const unsigned int lds_a = __builtin_amdgcn_readfirstlane(ln_lds_addr(s_a) + (unsigned)(rt * 4096 + kh * 2048));
+    const u32x4* bank_y = bank + (size_t)blockIdx.y * NKC * BCH16 + lane;
+    const size_t bank_e = (size_t)gridDim.y * NKC * BCH16;
+    int a_off[APW];
+#pragma unroll
+    for (int j = 0; j < APW; ++j) a_off[j] = (((lane & 7) ^ (((8 * (kh * APW + j) + a_row) >> 1) & 7)) * 4);
+    int ids[APW];
+    auto dma_piece = [&](int k, int e_n, int kc_n, int buf_n) {
+        if (k < BPW) {
+            const int p = wave + W * k;
+            if (BPIECES % W == 0 || p < BPIECES)
+                ln_glds16(bank_y + (size_t)e_n * bank_e + (size_t)kc_n * BCH16 + p * 64, lds_b + (unsigned)(buf_n * BCH16 + p * 64) * 16u);
+        } else {
+            const int j = k - BPW;
+            const int nb = ids[j];
+            const float* src = (nb >= 0 ? values + (size_t)nb * V : g_ln_zero_row) + kc_n * 32 + a_off[j];
+            ln_glds16(src, lds_a + (unsigned)(buf_n * (RT * 4096) + j * 1024));
+        }
+    };
+    floatx16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+    const int total = (e_end - e_begin) * NKC;
+    auto chunk_e = [&](int t) -> int { return e_begin + min(t, total - 1) / NKC; };
+    auto chunk_kc = [&](int t) -> int { return min(t, total - 1) % NKC; };
+    auto load_ids_of_slot = [&](int e_) {
+        const int sl = slot_of(e_);
+#pragma unroll
+        for (int j = 0; j < APW; ++j) ids[j] = my_ids[j * 8 * E + sl];
+    };
+    const int a_sw = (i >> 1) & 7;
+    u32x4 araw[2];  // this wave's K-step of the NEXT chunk's rows: channels 16 kh + 8 h .. + 7 of row i
+    auto read_a = [&](int buf) {
+        const u32x4* my_a = s_a + (buf * RT + rt) * 256 + i * 8;
+#pragma unroll
+        for (int j2 = 0; j2 < 2; ++j2) araw[j2] = my_a[(kh * 4 + h * 2 + j2) ^ a_sw];
+    };
+    auto split = [&](bf16x8 (&dst)[3]) {
+        u32x4 p1, p2, p3;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float x0 = __uint_as_float(araw[j >> 1][(2 * j) & 3]), x1 = __uint_as_float(araw[j >> 1][(2 * j + 1) & 3]);
+            const float r10 = x0 - __uint_as_float(__float_as_uint(x0) & 0xFFFF0000u), r11 = x1 - __uint_as_float(__float_as_uint(x1) & 0xFFFF0000u);
+            const float r20 = r10 - __uint_as_float(__float_as_uint(r10) & 0xFFFF0000u), r21 = r11 - __uint_as_float(__float_as_uint(r11) & 0xFFFF0000u);
+            p1[j] = __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
+            p2[j] = __builtin_amdgcn_perm(__float_as_uint(r11), __float_as_uint(r10), 0x07060302u);
+            p3[j] = __builtin_amdgcn_perm(__float_as_uint(r21), __float_as_uint(r20), 0x07060302u);
+        }
+        dst[0] = __builtin_bit_cast(bf16x8, p1), dst[1] = __builtin_bit_cast(bf16x8, p2), dst[2] = __builtin_bit_cast(bf16x8, p3);
+    };
+    // the walk's next three chunks (as in k_conv_rows32_b3)
+    int w_e[3], w_kc[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) w_e[k] = chunk_e(k + 1), w_kc[k] = chunk_kc(k + 1);
+    auto advance = [&](int it) {
+        w_e[0] = w_e[1], w_kc[0] = w_kc[1];
+        w_e[1] = w_e[2], w_kc[1] = w_kc[2];
+        if (it + 4 < total) {
+            if (++w_kc[2] == NKC) {
+                w_kc[2] = 0;
+                ++w_e[2];
+            }
+        }
+    };
+    {   // a tile without any neighbour (past the real rows of a static-rows launch) writes zeros and leaves (see k_conv_rows32_b3)
+        bool any = false;
+        for (int x = tid; x < R * E; x += 64 * W) any |= s_nbr[x] >= 0;
+        if (!__syncthreads_or(any)) {
+            for (int x = tid; x < R * (32 * NT / 4); x += 64 * W) {
+                const int row = blockIdx.x * R + x / (32 * NT / 4), c4 = x % (32 * NT / 4);
+                if (row < m) *reinterpret_cast<float4*>(out + (size_t)row * f_total + f_off + c4 * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            return;
+        }
+    }
+    load_ids_of_slot(chunk_e(0));
+#pragma unroll
+    for (int k = 0; k < NPIECES; ++k) dma_piece(k, chunk_e(0), chunk_kc(0), 0);
+    load_ids_of_slot(chunk_e(1));
+#pragma unroll
+    for (int k = BPW; k < NPIECES; ++k) dma_piece(k, chunk_e(1), chunk_kc(1), 1);
+    load_ids_of_slot(chunk_e(2));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    read_a(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    bf16x8 ap[3], ap_b[3];
+    split(ap);
+    auto iteration = [&](int it, bf16x8 (&cur)[3], bf16x8 (&nxt)[3]) {
+        LN_R32_PHASE(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // bank chunk `it` and the rows of chunk it + 1 have landed ...
+        __builtin_amdgcn_s_barrier();                      // ... everybody's, and everybody is done with the buffers overwritten next
+        LN_R32_PHASE(2);
+        const u32x4* sb = s_b + (it & 1) * BCH16 + kh * (NT * 3 * 64) + lane;  // fragment ((kh * NT + nt) * 3 + part) * 64 + lane
+        u32x4 fb[NT][3];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int x = 0; x < 3; ++x) fb[nt][x] = sb[(nt * 3 + x) * 64];
+        read_a((it + 1) & 1);
+        LN_R32_PHASE(3);
+        // the NT accumulation chains advance together; small terms first, the dominant product last
+#define LN_R32SK_PRODUCT(PA, PB)                                                                                                       \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                                                                  \
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[PA], __builtin_bit_cast(bf16x8, fb[nt][PB]), acc[nt], 0, 0, 0);
+        LN_R32SK_PRODUCT(2, 0) LN_R32SK_PRODUCT(0, 2) LN_R32SK_PRODUCT(1, 1) LN_R32SK_PRODUCT(1, 0) LN_R32SK_PRODUCT(0, 1) LN_R32SK_PRODUCT(0, 0)
+#undef LN_R32SK_PRODUCT
+        LN_R32_PHASE(4);
+        // requests: bank chunk it + 1, rows of chunk it + 2
+#pragma unroll
+        for (int k = 0; k < BPW; ++k) dma_piece(k, w_e[0], w_kc[0], (it + 1) & 1);
+#pragma unroll
+        for (int k = BPW; k < NPIECES; ++k) dma_piece(k, w_e[1], w_kc[1], it & 1);
+        load_ids_of_slot(w_e[2]);
+        LN_R32_PHASE(5);
+        split(nxt);
+        LN_R32_PHASE(7);
+        advance(it);
+    };
+    for (int it = 0; it < total; it += 2) {
+        iteration(it, ap, ap_b);
+        if (it + 1 < total) iteration(it + 1, ap_b, ap);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the redundant last requests must not outlive the workgroup's LDS
+    __builtin_amdgcn_s_barrier();                      // nobody reads s_b / s_a any more: the pool becomes the parking area
+    floatx4* park = reinterpret_cast<floatx4*>(s_pool) + (size_t)rt * NT * 4 * 64 + lane;  // [rt][nt][quad][lane] x 16 bytes
+    if (kh == 1) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd)
+                park[(nt * 4 + qd) * 64] = floatx4{acc[nt][4 * qd], acc[nt][4 * qd + 1], acc[nt][4 * qd + 2], acc[nt][4 * qd + 3]};
+    }
+    __syncthreads();
+    if (kh == 0) {
+        // accumulator register r of lane (i, h): row 8 (r >> 2) + 4 h + (r & 3), column i
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const floatx4 o = park[(nt * 4 + qd) * 64];
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int row = m0 + 8 * qd + 4 * h + r4;
+                    if (row < m) out[(size_t)row * f_total + f_off + nt * 32 + i] = acc[nt][4 * qd + r4] + o[r4];
+                }
+            }
         }
     }
 }
@@ -1092,6 +1304,18 @@ static bool ln_conv_launch_v(int nr_filters, const int* nbr, const float* values
         // while the 192-row workgroups alone fill half the chip (no slot split in this form)
         if (b3 && nr_filters % 32 == 0 && V >= 96 && nsplit == 1 && (long long)ln_div_up(m, 192) * ln_div_up(nr_filters, 128) >= LN_BWD_CUS / 2 &&
             ln_conv_rows32_enabled()) {
+#define LN_CONV_R32SK(NTC, RTT)                                                                                                     \
+    {                                                                                                                               \
+        const int cnt = (nr_filters - f_off) / (32 * NTC);                                                                          \
+        if (cnt > 0) {                                                                                                              \
+            LN_LAUNCH("k_conv_split_bank", (k_conv_split_bank32<V, NTC, WT>), dim3(ln_div_up(V * 32 * NTC, 256), E, cnt), block, 0, st, filter, \
+                      nr_filters, f_off, bank + bank_off);                                                                          \
+            LN_LAUNCH("k_conv_mfma", (k_conv_rows32sk_b3<V, NTC, RTT, FLIP>), dim3(ln_div_up(m, 32 * RTT), cnt, nsplit),            \
+                      dim3(128 * RTT), 0, st, nbr, values, reinterpret_cast<const u32x4*>(bank + bank_off), m, E, dst, nr_filters, f_off, e_per); \
+            bank_off += (size_t)E * cnt * V * 32 * NTC * 3;                                                                         \
+            f_off += cnt * 32 * NTC;                                                                                                \
+        }                                                                                                                           \
+    }
 #define LN_CONV_R32(NTC, NTWW, CHH, RTT)                                                                                            \
     {                                                                                                                               \
         const int cnt = (nr_filters - f_off) / (32 * NTC);                                                                          \
@@ -1104,8 +1328,20 @@ static bool ln_conv_launch_v(int nr_filters, const int* nbr, const float* values
             f_off += cnt * 32 * NTC;                                                                                                \
         }                                                                                                                           \
     }
+            // 96 columns (three tiles: no even split of the columns over a pair of waves) take the split-K pairs: 96 -> 96 62.5 -> 54.1 us,
+            // 128 -> 96 80.7 -> 69.1 us at 46.5 k rows; at 128 / 64 columns the column-split pairs are faster (80 vs 85, 50.6 vs 52 us:
+            // the pair's partial sums cost a pass through LDS at the end).  LN_CONV_R32_SK=0: column-split everywhere (A/B; read once)
+            static int sk = -1;
+            if (sk < 0) {
+                const char* ev = getenv("LN_CONV_R32_SK");
+                sk = (ev && ev[0] == '0') ? 0 : 1;
+            }
+            if (sk == 1 && (nr_filters - f_off) % 128 == 96) {
+                LN_CONV_R32(4, 2, 2, 6) LN_CONV_R32SK(3, 6)
+            }
             LN_CONV_R32(4, 2, 2, 6) LN_CONV_R32(3, 3, 1, 4) LN_CONV_R32(2, 1, 2, 6) LN_CONV_R32(1, 1, 1, 4)
 #undef LN_CONV_R32
+#undef LN_CONV_R32SK
         }
     }
     // all chunks of the widest size go out as ONE launch (gridDim.y = their count), then at most one launch per narrower size

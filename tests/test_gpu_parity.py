@@ -432,8 +432,8 @@ def test_conv_one_hot_bank_every_instance(v, sigma):
     vals = rng.integers(-7, 8, (m, v)).astype(np.float32)
     lat.set_values(T(vals))
     # 16-row kernels: 128 + 64 + 32 + 16 | 64 | 32 + 16 | 16 columns per launch; wide form (k_conv_rows32_b3, from 96 channels and
-    # multiples of 32 filters on): 128 + 96 | 128 + 32 | 64 | 32
-    for f in (240, 64, 48, 16) + ((224, 160, 32) if v >= 96 else ()):
+    # multiples of 32 filters on): 128 + 96 (the 96 on the split-K pairs, k_conv_rows32sk_b3) | 128 + 32 | 96 | 64 | 32
+    for f in (240, 64, 48, 16) + ((224, 160, 96, 32) if v >= 96 else ()):
         for flip in (False, True):
             slot = rng.integers(0, 9, f)
             chan = rng.integers(0, v, f)
