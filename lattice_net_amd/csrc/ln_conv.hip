@@ -1439,7 +1439,17 @@ __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(T,
         const size_t g0 = (size_t)blockIdx.x * (64 * T) * E, g_end = (size_t)m * E;
         for (int x = tid; x < 64 * T * E; x += THREADS) s_nbr[x] = (g0 + x < g_end) ? nbr[g0 + x] : -1;
     }
-    __syncthreads();
+    {   // a tile without any neighbour (past the real rows of a static-rows launch: 257 tiles of 192 rows for 256 CUs) writes zeros and leaves
+        bool any = false;
+        for (int x = tid; x < 64 * T * E; x += THREADS) any |= s_nbr[x] >= 0;
+        if (!__syncthreads_or(any)) {
+            for (int x = tid; x < 64 * T * (F / 4); x += THREADS) {
+                const int row = blockIdx.x * (64 * T) + x / (F / 4);
+                if (row < m) *reinterpret_cast<float4*>(out + (size_t)row * F + (x % (F / 4)) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            return;
+        }
+    }
     const int wv_ = tid >> 6;
     const int lr = lane >> 3;  // the two rows this lane loads: lr and 8 + lr
     int nb[2][E];
