@@ -102,6 +102,9 @@ __global__ void __launch_bounds__(256)
 //   bank [E*V, F]   : a thread reads 8 rows x 8 columns (eight 16-byte loads) and writes the 8 units of its columns;
 //   bank^T [E*F, V] : a thread reads 8 consecutive k of one column (one 16-byte load) = one unit.
 // ------------------------------------------------------------------------------------------
+#ifndef LN_F16_LINE
+#define LN_F16_LINE 1  // 0: fragment-shaped gathers at 64 channels too (A/B)
+#endif
 template <int V, int NT, bool FLIP, bool WT>
 __global__ void __launch_bounds__(1024)
     k_conv_f16_tiled(const int* __restrict__ nbr, const _Float16* __restrict__ values, const _Float16* __restrict__ filter, int m,
@@ -116,15 +119,41 @@ __global__ void __launch_bounds__(1024)
     const int q = lane >> 4;
     const int m0 = blockIdx.x * (nthreads / 4) + (tid >> 6) * 16;
     const int my_row = m0 + i;
-    int nb[E];
-#pragma unroll
-    for (int e = 0; e < E; ++e) nb[e] = (my_row < m) ? nbr[(size_t)my_row * E + ((FLIP && e < E - 1) ? (e ^ 1) : e)] : -1;
+    // V = 64 (128-byte rows): line-shaped gathers as in k_conv_forward_b3 (ln_conv.hip) — lane l loads piece l & 7 (16 bytes) of rows
+    // l >> 3 and 8 + (l >> 3) of the wave's 16, and the wave re-shapes its 2 KB through a private, XOR-swizzled LDS region into the
+    // fragment shape (lane (i, q) = pieces 2q, 2q + 1 of row i).  The fragment-shaped loads gathered 81 MB in 23 us = 3.5 TB/s at C5:
+    // the rate of that shape whatever the hit rate (tools/probes/gather_layout_probe.cpp).
+    constexpr bool LINE = (V == 64) && LN_F16_LINE;
     constexpr int DEPTH = 4;  // ring of gathered quarter rows: DEPTH - 1 gathers in flight
+    __shared__ __attribute__((aligned(16))) halfx8 s_x[LINE ? 16 : 1][16 * 8];
+    __shared__ int s_nbr[LINE ? 256 * E : 1];
+    int nb[LINE ? 2 : 1][E];
     halfx8 g[DEPTH][G8];
-    auto gather = [&](int e, halfx8 (&dst)[G8]) {
-        const halfx8* src = reinterpret_cast<const halfx8*>(values + (size_t)(nb[e] >= 0 ? nb[e] : 0) * V + q * KQ);
+    const int wv_ = tid >> 6, lr = lane >> 3;
+    auto fsw = [](int r) -> int { return ((r >> 1) & 7) ^ (((r >> 2) & 1) << 1); };
+    if constexpr (LINE) {
+        const int rows_wg = nthreads / 4;
+        const size_t g0 = (size_t)blockIdx.x * rows_wg * E, g_end = (size_t)m * E;
+        for (int x = tid; x < rows_wg * E; x += nthreads) s_nbr[x] = (g0 + x < g_end) ? nbr[g0 + x] : -1;
+        __syncthreads();
 #pragma unroll
-        for (int k = 0; k < G8; ++k) dst[k] = src[k];
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < E; ++e) nb[j][e] = s_nbr[(wv_ * 16 + 8 * j + lr) * E + ((FLIP && e < E - 1) ? (e ^ 1) : e)];
+    } else {
+#pragma unroll
+        for (int e = 0; e < E; ++e) nb[0][e] = (my_row < m) ? nbr[(size_t)my_row * E + ((FLIP && e < E - 1) ? (e ^ 1) : e)] : -1;
+    }
+    auto gather = [&](int e, halfx8 (&dst)[G8]) {
+        if constexpr (LINE) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                dst[j] = *reinterpret_cast<const halfx8*>(values + (size_t)(nb[j][e] >= 0 ? nb[j][e] : 0) * V + (lane & 7) * 8);
+        } else {
+            const halfx8* src = reinterpret_cast<const halfx8*>(values + (size_t)(nb[0][e] >= 0 ? nb[0][e] : 0) * V + q * KQ);
+#pragma unroll
+            for (int k = 0; k < G8; ++k) dst[k] = src[k];
+        }
     };
 #pragma unroll
     for (int k = 0; k < DEPTH - 1; ++k) gather(k, g[k]);
@@ -165,9 +194,28 @@ __global__ void __launch_bounds__(1024)
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-        halfx8 (&ge)[G8] = g[e % DEPTH];
         if (e + DEPTH - 1 < E) gather(e + DEPTH - 1, g[(e + DEPTH - 1) % DEPTH]);
-        const bool present = nb[e] >= 0;
+        halfx8 ge[G8];
+        bool present;
+        if constexpr (LINE) {
+            // rows of absent neighbours are zeroed by the lane that loaded them; LDS operations of one wave execute in program order
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                s_x[wv_][(8 * j + lr) * 8 + ((lane & 7) ^ fsw(8 * j + lr))] = (nb[j][e] >= 0) ? g[e % DEPTH][j] : halfx8{0, 0, 0, 0, 0, 0, 0, 0};
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            ge[0] = s_x[wv_][i * 8 + ((2 * q) ^ fsw(i))];
+            ge[1] = s_x[wv_][i * 8 + ((2 * q + 1) ^ fsw(i))];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            present = true;
+        } else {
+#pragma unroll
+            for (int k = 0; k < G8; ++k) ge[k] = g[e % DEPTH][k];
+            present = nb[0][e] >= 0;
+        }
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             halfx8 a = ge[s];
@@ -200,6 +248,9 @@ static int ln_f16_subtiles(int m, size_t lds_bytes) {
     int best = 1, best_cost = 1 << 30;
     for (int t = 1; t <= 4; ++t) {
         if (per_cu * t * 4 > 32) break;  // wave slots of a CU
+        // (one workgroup per CU: a single sub-tile would leave the CU with four waves — 39 us instead of 21 at C5 — unless the lattice
+        // is too small to give every CU more)
+        if (per_cu == 1 && t < 3 && tiles >= 3 * 256) continue;
         const int wgs = (tiles + t - 1) / t;
         const int cost = ((wgs + 256 * per_cu - 1) / (256 * per_cu)) * t;
         if (cost <= best_cost) {
@@ -217,7 +268,8 @@ static bool ln_conv_f16_tiled(const int* nbr, const _Float16* values, const _Flo
     if (off || E != 9 || ((reinterpret_cast<uintptr_t>(values) | reinterpret_cast<uintptr_t>(filter)) & 15) != 0) return false;
 #define LN_F16_TILED(VV, NN)                                                                                                         \
     if (val_dim == VV && nr_filters == 16 * NN) {                                                                                    \
-        const int t = ln_f16_subtiles(m, (size_t)9 * VV * 16 * NN * 2);                                                               \
+        /* (at 64 channels: + the re-shaping regions of up to 16 waves and the ids, see the kernel) */                               \
+        const int t = ln_f16_subtiles(m, (size_t)9 * VV * 16 * NN * 2 + ((VV == 64 && LN_F16_LINE) ? 16 * 2048 + 256 * 9 * 4 : 0));  \
         LN_LAUNCH("k_conv_mfma_f16", (k_conv_f16_tiled<VV, NN, FLIP, WT>), dim3(ln_div_up(m, 64 * t)), dim3(256 * t), 0, st, nbr, values, \
                   filter, m, out);                                                                                                   \
         return true;                                                                                                                 \
