@@ -128,6 +128,11 @@ int ln_profile_end_table(char* out, int out_bytes);
  * in one launch.  `values` (may be NULL) is zero-filled too: values_elems floats. */
 int ln_table_clear(const LnTable* t, float* values, long long values_elems, void* stream);
 
+/* The freshly allocated structure buffers of a table in one launch (the reference's HashTable::init issues one fill per tensor,
+ * src/HashTable.cu:21-47): `arena` holds `words` 32-bit words; words [minus_begin, minus_end) are set to -1 (the entries), every
+ * other word to 0 (keys, slot counters, the device counters, a placeholder values row — carved from the arena by the host). */
+int ln_arena_init(int* arena, long long words, long long minus_begin, long long minus_end, void* stream);
+
 /* Scratch needed by ln_build_splat / ln_distribute / ln_coarsen for `tokens` insertions. */
 size_t ln_build_workspace_bytes(long long tokens, int capacity);
 
@@ -391,6 +396,36 @@ size_t ln_max_centre_backward_workspace_bytes(long long n, int k, int c);
 int ln_max_centre_backward(const float* grad_out, const float* max_vals, const unsigned char* arg_max, const float* gamma,
                            long long n, int k, int c, float* grad_x, float* grad_gamma_beta, void* workspace,
                            size_t workspace_bytes, void* stream);
+
+/* ---- launch diet of the glue around the lattice operators in a training step ----------------------------------------------
+ * Weight normalisation of the reference's weight_norm_wrapper with v_dim=None (latticenet_py/lattice/utils.py:72-158; LinearWN,
+ * ConvLatticeIm2RowWN, CoarsenLatticeWN, FinefyLatticeWN):  w = v * g / ||v||_F  for v [rows, cols] and one magnitude per row
+ * (g_dim 0, g [rows]) or per column (g_dim 1, g [cols]); at most 1024 magnitudes, rows * cols <= 2^24.  One workgroup each way,
+ * sums in a fixed order.  `norm`: one float written by the forward call and read by the backward call.
+ *   grad_g[j] = sum_k grad_w[j,k] v[j,k] / n      grad_v = grad_w * g / n - v * (sum_j g[j] sum_k grad_w[j,k] v[j,k]) / n^3 */
+int ln_weight_norm_forward(const float* v, const float* g, int rows, int cols, int g_dim, float* w, float* norm, void* stream);
+int ln_weight_norm_backward(const float* v, const float* g, const float* grad_w, const float* norm, int rows, int cols, int g_dim,
+                            float* grad_v, float* grad_g, void* stream);
+
+/* DistributeLatticeModule's per-token tail (lattice_modules.py:72-94) in one pass: distributed / out [tokens, width] rows whose
+ * first pos_dim columns are positions; position_sums [m, pos_dim] and counts [m] per vertex (ln_csr_reduce_rows of the positions
+ * with unit weights, ln_csr_group_sizes);  out[t, :pos_dim] = d[t, :pos_dim] - sums[idx[t]] / max(counts[idx[t]], 1), the other
+ * columns copied; rows of tokens with idx[t] <= 0 (no vertex, or vertex 0 = the "invalid" bucket) are zero. */
+int ln_distribute_centre(const float* distributed, const int* splat_idx, const float* position_sums, const int* counts, long long tokens,
+                         int width, int pos_dim, float* out, void* stream);
+
+/* The vertex-side reduction of PointNetModule (lattice_modules.py:688-712: scatter_max, scatter_add of ones, index_select of the
+ * winning tokens' barycentric weights, cat, masked_fill(nr_points < 4), keep mask of vertex 0) over the token adjacency `csr`:
+ *   out [rows, 2 * channels] = [max over the row's tokens of src[t, :] | bary[argmax token * bary_stride]]
+ *   out_arg [rows, channels] = winning token, -1 where the row is dropped (fewer than min_points tokens, row 0) or has no token.
+ * Backward wrt src, token-major (every element of grad_src [tokens, channels] is written: no fill, no scatter):
+ *   grad_src[t, c] = grad_out[idx[t] * grad_stride + c] if out_arg[idx[t], c] == t else 0. */
+size_t ln_pointnet_reduce_workspace_bytes(int rows, int channels);
+int ln_pointnet_reduce_forward(const LnCsr* csr, const int* grp_row, long long max_segments, const float* src, int channels,
+                               const float* bary, int bary_stride, int rows, int min_points, void* workspace, size_t workspace_bytes,
+                               float* out, int* out_arg, void* stream);
+int ln_pointnet_reduce_backward(const float* grad_out, int grad_stride, const int* out_arg, const int* splat_idx, long long tokens,
+                                int channels, float* grad_src, void* stream);
 
 #ifdef __cplusplus
 }

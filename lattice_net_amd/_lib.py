@@ -121,6 +121,13 @@ SIGNATURES = {
     "ln_linear_act_forward": (_i, [_vp, _vp, _vp, _ll, _i, _i, C.c_float, _vp, _vp]),
     "ln_linear_act_backward_workspace_bytes": (_sz, [_i, _i]),
     "ln_linear_act_backward": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _i, C.c_float, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ln_arena_init": (_i, [_vp, _ll, _ll, _ll, _vp]),
+    "ln_weight_norm_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "ln_weight_norm_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "ln_distribute_centre": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _i, _vp, _vp]),
+    "ln_pointnet_reduce_workspace_bytes": (_sz, [_i, _i]),
+    "ln_pointnet_reduce_forward": (_i, [_CSR, _vp, _ll, _vp, _i, _vp, _i, _i, _i, _vp, _sz, _vp, _vp, _vp]),
+    "ln_pointnet_reduce_backward": (_i, [_vp, _i, _vp, _vp, _ll, _i, _vp, _vp]),
     "ln_max_centre_forward": (_i, [_vp, _vp, _vp, _ll, _i, _i, _vp, _vp, _vp, _vp]),
     "ln_max_centre_backward_workspace_bytes": (_sz, [_ll, _i, _i]),
     "ln_max_centre_backward": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _i, _vp, _vp, _vp, _sz, _vp]),

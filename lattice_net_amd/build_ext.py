@@ -14,7 +14,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 OUT = os.path.join(PKG, "liblatticenet_hip.so")
 OBJ_DIR = os.path.join(ROOT, "build", "obj")
-SOURCES = ["ln_table.hip", "ln_rows.hip", "ln_conv.hip", "ln_csr.hip", "ln_norm.hip", "ln_conv_f16.hip", "ln_mlp.hip", "ln_centre.hip", "ln_classify.hip"]
+SOURCES = ["ln_table.hip", "ln_rows.hip", "ln_conv.hip", "ln_csr.hip", "ln_norm.hip", "ln_conv_f16.hip", "ln_mlp.hip", "ln_centre.hip", "ln_classify.hip", "ln_glue.hip"]
 import glob
 import hashlib
 

@@ -526,7 +526,7 @@ __device__ __forceinline__ float ln_ordered_to_float(unsigned int o) {
 __global__ void __launch_bounds__(256)
     k_csr_segment_max(const int* __restrict__ csr_tok, const int4* __restrict__ seg_desc, const int* __restrict__ seg_count, long long seg_region,
                       const int* __restrict__ grp_row, const float* __restrict__ src, int channels,
-                      unsigned long long* __restrict__ packed) {
+                      unsigned long long* __restrict__ packed, int* __restrict__ counts) {
   for (LnSegWalk wk(blockIdx.x, gridDim.x, channels, seg_count, seg_region); wk.more(); wk.next()) {
     const LnSegOfThread so = wk.here();
     const long long sid = so.sid;
@@ -551,6 +551,12 @@ __global__ void __launch_bounds__(256)
         *d = best;
     else
         atomicMax(d, best);
+    if (counts && c == 0) {  // vertex degree on the side (the fused PointNet reduction needs it; integer adds: order-free)
+        if (only_segment)
+            counts[row] = end - beg;
+        else
+            atomicAdd(counts + row, end - beg);
+    }
   }
 }
 
@@ -583,10 +589,88 @@ extern "C" int ln_csr_segment_max(const LnCsr* csr, const int* grp_row, long lon
     if (max_segments > 0)
         LN_LAUNCH("k_csr_segment_max", k_csr_segment_max, dim3(ln_seg_grid(max_segments, channels)), dim3(256), 0, st, csr->csr_tok,
                   reinterpret_cast<const int4*>(csr->seg_desc), csr->seg_count, csr->seg_region, grp_row, src, channels,
-                  static_cast<unsigned long long*>(packed_ws));
+                  static_cast<unsigned long long*>(packed_ws), (int*)nullptr);
     LN_LAUNCH("k_csr_segment_max_decode", k_csr_segment_max_decode, dim3(ln_div_up(work, 256)), dim3(256), 0, st,
               static_cast<const unsigned long long*>(packed_ws), work, out_max, out_arg);
     return ln_check_launch("ln_csr_segment_max");
+}
+
+// ---- the whole vertex-side reduction of PointNetModule (lattice_modules.py:688-712) in three launches ------------------------
+//   out[row, :C]  = max over the row's tokens of src[t, :C]            out[row, C:] = bary[argmax token]
+//   rows with fewer than `min_points` tokens and row 0 (the "invalid" bucket) are zero; arg = -1 there and where no token is
+// (the reference: scatter_max, scatter_add of ones, index_select, cat, masked_fill, a multiplication by a keep mask).
+__global__ void __launch_bounds__(256)
+    k_pointnet_reduce_decode(const unsigned long long* __restrict__ packed, const int* __restrict__ counts, const float* __restrict__ bary,
+                             int bary_stride, long long work, int channels, int min_points, float* __restrict__ out, int* __restrict__ out_arg) {
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= work) return;
+    const long long row = g / channels;
+    const int c = int(g - row * channels);
+    const unsigned long long p = packed[g];
+    float mx = 0.f, bw = 0.f;
+    int arg = -1;
+    if (p != 0ull && row != 0 && counts[row] >= min_points) {
+        mx = ln_ordered_to_float((unsigned int)(p >> 32));
+        arg = int(0xFFFFFFFFu - (unsigned int)(p & 0xFFFFFFFFull));
+        bw = bary[(size_t)arg * bary_stride];
+    }
+    out[row * 2 * channels + c] = mx;
+    out[row * 2 * channels + channels + c] = bw;
+    out_arg[g] = arg;
+}
+
+// gradient of the maxima wrt the per-token rows, token-major (every element written: no zero fill, no scatter):
+//   grad_src[t, c] = grad_out[row, c] if arg[row, c] == t else 0,   row = idx[t]
+__global__ void __launch_bounds__(256)
+    k_pointnet_reduce_backward(const float* __restrict__ grad_out, int grad_stride, const int* __restrict__ arg, const int* __restrict__ idx,
+                               long long work, int channels, float* __restrict__ grad_src) {
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= work) return;
+    const long long t = g / channels;
+    const int c = int(g - t * channels);
+    const int row = idx[t];
+    float x = 0.f;
+    if (row > 0 && arg[(size_t)row * channels + c] == (int)t) x = grad_out[(size_t)row * grad_stride + c];
+    grad_src[g] = x;
+}
+
+extern "C" size_t ln_pointnet_reduce_workspace_bytes(int rows, int channels) {
+    if (rows < 0 || channels < 1) return 256;
+    return (size_t)rows * channels * sizeof(unsigned long long) + (size_t)rows * sizeof(int) + 256;
+}
+
+extern "C" int ln_pointnet_reduce_forward(const LnCsr* csr, const int* grp_row, long long max_segments, const float* src, int channels,
+                                          const float* bary, int bary_stride, int rows, int min_points, void* workspace,
+                                          size_t workspace_bytes, float* out, int* out_arg, void* stream) {
+    LN_REQUIRE(max_segments >= 0 && channels >= 1 && rows >= 0 && bary_stride >= 1, LN_ERR_ARG, "ln_pointnet_reduce_forward: bad sizes");
+    if (rows == 0) return LN_OK;
+    LN_REQUIRE(csr && csr->grp_start && csr->csr_tok && csr->seg_desc && csr->seg_count && src && bary && workspace && out && out_arg,
+               LN_ERR_ARG, "ln_pointnet_reduce_forward: null buffer");
+    LN_REQUIRE(workspace_bytes >= ln_pointnet_reduce_workspace_bytes(rows, channels), LN_ERR_WORKSPACE,
+               "ln_pointnet_reduce_forward: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const long long work = (long long)rows * channels;
+    unsigned long long* packed = static_cast<unsigned long long*>(workspace);
+    int* counts = reinterpret_cast<int*>(packed + work);
+    if (ln_zero_async(workspace, (size_t)work * sizeof(unsigned long long) + (size_t)rows * sizeof(int), st) != LN_OK)
+        return ln_check_launch("ln_pointnet_reduce_forward(memset)");
+    if (max_segments > 0)
+        LN_LAUNCH("k_csr_segment_max", k_csr_segment_max, dim3(ln_seg_grid(max_segments, channels)), dim3(256), 0, st, csr->csr_tok,
+                  reinterpret_cast<const int4*>(csr->seg_desc), csr->seg_count, csr->seg_region, grp_row, src, channels, packed, counts);
+    LN_LAUNCH("k_pointnet_reduce_decode", k_pointnet_reduce_decode, dim3(ln_div_up(work, 256)), dim3(256), 0, st, packed, counts, bary, bary_stride,
+              work, channels, min_points, out, out_arg);
+    return ln_check_launch("ln_pointnet_reduce_forward");
+}
+
+extern "C" int ln_pointnet_reduce_backward(const float* grad_out, int grad_stride, const int* arg, const int* splat_idx, long long tokens,
+                                           int channels, float* grad_src, void* stream) {
+    LN_REQUIRE(tokens >= 0 && channels >= 1 && grad_stride >= channels, LN_ERR_ARG, "ln_pointnet_reduce_backward: bad sizes");
+    if (tokens == 0) return LN_OK;
+    LN_REQUIRE(grad_out && arg && splat_idx && grad_src, LN_ERR_ARG, "ln_pointnet_reduce_backward: null buffer");
+    const long long work = tokens * channels;
+    LN_LAUNCH("k_pointnet_reduce_backward", k_pointnet_reduce_backward, dim3(ln_div_up(work, 256)), dim3(256), 0, (hipStream_t)stream, grad_out,
+              grad_stride, arg, splat_idx, work, channels, grad_src);
+    return ln_check_launch("ln_pointnet_reduce_backward");
 }
 
 // degree of every row: number of tokens whose group maps to it

@@ -92,7 +92,7 @@ LnProfEvents ln_prof_next(const char* name) {
     return ev;
 }
 
-extern "C" const char* ln_kernel_names(void) { return "k_bucket_rows,k_canon_idx,k_canon_mark,k_canon_segs,k_canon_slots,k_conv_backward_fused,k_conv_generic,k_conv_generic_f16,k_conv_mfma,k_conv_mfma_f16,k_conv_split_bank,k_conv_sum_partials,k_csr_count,k_csr_fill,k_csr_group_sizes,k_csr_reduce_segments,k_csr_scan_local,k_csr_scan_top,k_csr_segment_max,k_csr_segment_max_decode,k_finalize,k_gather_backward,k_gather_forward,k_gn_apply,k_gn_backward_apply,k_gn_stats,k_grad_filter_f16,k_grad_filter_generic,k_grad_filter_mfma,k_grad_filter_mfma_f16,k_im2row,k_im2rowindices,k_insert_coarse,k_insert_points,k_linear_act_backward_w,k_linear_act_backward_x,k_linear_act_forward,k_linear_reduce_slabs,k_mark_first,k_max_centre_backward,k_max_centre_forward,k_max_centre_sum,k_neighbours,k_point_keys,k_reduce_and_neighbours,k_reduce_slabs,k_rehash_clear,k_rehash_rows,k_retrieve_points,k_row2im,k_sc_reduce_slabs,k_sc_scatter_atomic,k_scan_blocks,k_scatter_point_rows,k_seg_min,k_slice_classify_backward,k_slice_classify_forward,k_slice_forward,k_slice_forward_f16,k_table_clear"; }
+extern "C" const char* ln_kernel_names(void) { return "k_bucket_rows,k_canon_idx,k_canon_mark,k_canon_segs,k_canon_slots,k_conv_backward_fused,k_conv_generic,k_conv_generic_f16,k_conv_mfma,k_conv_mfma_f16,k_conv_split_bank,k_conv_sum_partials,k_csr_count,k_csr_fill,k_csr_group_sizes,k_csr_reduce_segments,k_csr_scan_local,k_csr_scan_top,k_csr_segment_max,k_csr_segment_max_decode,k_distribute_centre,k_finalize,k_gather_backward,k_gather_forward,k_gn_apply,k_gn_backward_apply,k_gn_stats,k_grad_filter_f16,k_grad_filter_generic,k_grad_filter_mfma,k_grad_filter_mfma_f16,k_im2row,k_im2rowindices,k_insert_coarse,k_insert_points,k_linear_act_backward_w,k_linear_act_backward_x,k_linear_act_forward,k_linear_reduce_slabs,k_mark_first,k_max_centre_backward,k_max_centre_forward,k_max_centre_sum,k_neighbours,k_point_keys,k_pointnet_reduce_backward,k_pointnet_reduce_decode,k_reduce_and_neighbours,k_reduce_slabs,k_rehash_clear,k_rehash_rows,k_retrieve_points,k_row2im,k_sc_reduce_slabs,k_sc_scatter_atomic,k_scan_blocks,k_scatter_point_rows,k_seg_min,k_slice_classify_backward,k_slice_classify_forward,k_slice_forward,k_slice_forward_f16,k_table_clear,k_weight_norm_backward,k_weight_norm_forward,ln_k_arena_init"; }
 
 extern "C" int ln_profile_begin(const char* kernel_names, int max_samples) {
     LN_REQUIRE(kernel_names && strlen(kernel_names) + 3 < sizeof(g_prof.names) && max_samples > 0, LN_ERR_ARG, "ln_profile_begin: bad args");
@@ -245,6 +245,24 @@ int ln_zero_async(void* p, size_t bytes, hipStream_t st) {
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(ln_k_zero_words, dim3(blocks), dim3(256), 0, st, static_cast<unsigned int*>(p), words);
     return ln_check_launch("ln_zero_async");
+}
+
+// One launch for the freshly allocated structure buffers of a table (keys = 0 | entries = -1 | slot counters, device counters and
+// a placeholder values row = 0, carved from ONE allocation by the host): words [minus_begin, minus_end) become -1, the rest 0.
+__global__ void __launch_bounds__(256) ln_k_arena_init(int* __restrict__ p, size_t words, size_t minus_begin, size_t minus_end) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += stride) p[i] = (i >= minus_begin && i < minus_end) ? -1 : 0;
+}
+
+extern "C" int ln_arena_init(int* arena, long long words, long long minus_begin, long long minus_end, void* stream) {
+    LN_REQUIRE(words >= 0 && minus_begin >= 0 && minus_begin <= minus_end && minus_end <= words, LN_ERR_ARG, "ln_arena_init: bad ranges");
+    if (words == 0) return LN_OK;
+    LN_REQUIRE(arena != nullptr, LN_ERR_ARG, "ln_arena_init: null buffer");
+    int blocks = ln_div_up(words, 256 * 4);
+    if (blocks > 4096) blocks = 4096;
+    LN_LAUNCH("ln_k_arena_init", ln_k_arena_init, dim3(blocks), dim3(256), 0, (hipStream_t)stream, arena, (size_t)words, (size_t)minus_begin,
+              (size_t)minus_end);
+    return ln_check_launch("ln_arena_init");
 }
 
 // {vertex count, status bits, the build's sequence number} as ONE 64-bit word into pinned host memory (LnTable.host_counters):

@@ -115,27 +115,42 @@ def _require_cuda(t: torch.Tensor, name: str):
         raise ValueError(f"{name} must live on a ROCm/HIP device (got {t.device}); the lattice backend has no CPU path")
 
 
+def _pad4(words: int) -> int:
+    return (int(words) + 3) & ~3
+
+
 class _TableStorage:
     """Structure buffers shared shallowly between lattice clones (Lattice.cu:88-92)."""
 
     _uids = itertools.count(1)
 
-    def __init__(self, capacity: int, pos_dim: int, device):
+    def __init__(self, capacity: int, pos_dim: int, device, spare_row_width: int = 0):
         self.uid = next(_TableStorage._uids)  # never reused (unlike id()): cache keys may outlive the storage they name
         self.capacity = int(capacity)
         self.pos_dim = int(pos_dim)
         self.device = device
+        self.fresh_counters = None  # int32[2] zeros / float32 [1, spare_row_width] zeros carved from the same allocation, for the
+        self.fresh_row = None       # table that is created together with this storage (one launch instead of five fills)
         # Slots actually hashed into (0 = not chosen yet: all of them).  The cfg's capacity is an upper bound chosen for the largest
         # cloud (5 M slots for ScanNet scenes that fill 2.5 % of them); a build that starts from a cleared table hashes into
         # min(capacity, 2 x its tokens) slots instead, so that clearing / emitting the slot range costs what the cloud needs
         # (Lattice._build).  Slot positions are internal — only row ids are reference-visible.  Never shrinks: the rows every
         # earlier build wrote stay inside the range a later clear covers.
         self.hash_capacity = 0
-        self.keys = torch.zeros((capacity, pos_dim), dtype=torch.int32, device=device)  # (zeros: rows beyond a build's reach are never touched)
-        self.entries = torch.full((capacity,), -1, dtype=torch.int32, device=device)  # (-1 = empty: slots beyond the hashed range stay so)
+        # keys = 0 (rows beyond a build's reach are never touched) | entries = -1 (empty: slots beyond the hashed range stay so) |
+        # slot_cnt = 0 (scratch that is all-zero between builds) | counters | placeholder row: ONE allocation, ONE launch
+        capacity, pos_dim = self.capacity, self.pos_dim
+        kw, ew, cw, sw = _pad4(capacity * pos_dim), _pad4(capacity), _pad4(capacity), _pad4(max(int(spare_row_width), 0))
+        arena = torch.empty((kw + ew + cw + 4 + sw,), dtype=torch.int32, device=device)
+        _lib.check(_lib.load().ln_arena_init(_lib.ptr(arena), arena.numel(), kw, kw + capacity, _lib.stream_ptr(arena.device)), "ln_arena_init")
+        self.keys = arena[: capacity * pos_dim].view(capacity, pos_dim)
+        self.entries = arena[kw: kw + capacity]
+        self.slot_cnt = arena[kw + ew: kw + ew + capacity]
+        self.fresh_counters = arena[kw + ew + cw: kw + ew + cw + 2]
+        if spare_row_width > 0:
+            self.fresh_row = arena[kw + ew + cw + 4: kw + ew + cw + 4 + spare_row_width].view(torch.float32).view(1, spare_row_width)
         self.slot_keys = torch.empty((capacity,), dtype=torch.int64, device=device)
         self.slot_tok = torch.empty((capacity,), dtype=torch.int32, device=device)
-        self.slot_cnt = torch.zeros((capacity,), dtype=torch.int32, device=device)  # scratch that is all-zero between builds
         # every table built from positions holds lattice points only: the wide packed-key format (LnTable.key_format); the target
         # of the key-based coarsening (create_coarse_verts) receives halved fine keys and switches to the raw format
         self.key_format = _lib.LN_KEYS_LATTICE
@@ -152,6 +167,7 @@ class _TableStorage:
         s = _TableStorage.__new__(_TableStorage)
         s.uid = next(_TableStorage._uids)
         s.capacity, s.pos_dim, s.device = self.capacity, self.pos_dim, self.device
+        s.fresh_counters = s.fresh_row = None
         s.hash_capacity = self.hash_capacity
         s.key_format = self.key_format
         s.keys = self.keys.clone()
@@ -212,7 +228,7 @@ class HashTable:
         self._storage = _TableStorage(self.m_capacity, pos_dim, device)
         self.m_values_tensor = torch.zeros((self.m_capacity, val_dim), dtype=torch.float32, device=device)
         self._zero_beyond = (weakref.ref(self.m_values_tensor), 0)  # (weak reference to the tensor, row from which it is known to be zero): see Lattice._build
-        self._counters = torch.zeros((2,), dtype=torch.int32, device=device)
+        self._counters = self._storage.fresh_counters
         self.m_nr_filled_is_dirty = True
         self.clear(lazy=True)  # rides in the first build call; every other reader flushes it
 
@@ -769,7 +785,7 @@ class Lattice:
             nh._storage = _TableStorage(oh.capacity(), d, dev)
             nh.m_values_tensor = torch.zeros((oh.capacity(), oh.val_dim() or v), dtype=torch.float32, device=dev)
             nh._zero_beyond = (weakref.ref(nh.m_values_tensor), 0)
-            nh._counters = torch.zeros((2,), dtype=torch.int32, device=dev)
+            nh._counters = nh._storage.fresh_counters
             nh.clear(lazy=True)  # issued inside the build call
         else:
             nh._storage = oh._storage.clone()
@@ -1041,9 +1057,10 @@ class Lattice:
         coarse.m_sigmas = [s * 2.0 for s in self.m_sigmas]  # Lattice.cu:679-682 / 718-722
         coarse._sigmas_tensor = None
         ht = HashTable(capacity)
-        ht._storage = _TableStorage(capacity, d, dev)
-        ht.m_values_tensor = torch.zeros((1, self.val_dim()), dtype=torch.float32, device=dev)
-        ht._counters = torch.zeros((2,), dtype=torch.int32, device=dev)
+        ht._storage = _TableStorage(capacity, d, dev, spare_row_width=self.val_dim())
+        # [1, val_dim] zeros: a placeholder until the coarse values exist
+        ht.m_values_tensor = ht._storage.fresh_row if ht._storage.fresh_row is not None else torch.zeros((1, self.val_dim()), dtype=torch.float32, device=dev)
+        ht._counters = ht._storage.fresh_counters
         levels = getattr(self.m_hash_table, "_static_levels", None)
         if self.m_hash_table._static_rows is not None:  # static-rows mode: every level needs its own bound
             if not levels or coarse.m_lvl not in levels:

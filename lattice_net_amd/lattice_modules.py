@@ -40,6 +40,38 @@ def _leaky_relu_init_bound(n_in: int, n_out: int, extent: int = 1, alpha: float 
     return math.sqrt(3.0) * gain * math.sqrt(2.0 / ((n_in + n_out) * extent))
 
 
+FUSED_GLUE = {"weight_norm", "distribute", "pointnet"}  # tests remove entries to compare the fused glue kernels (csrc/ln_glue.hip) with the torch chains they replace
+
+
+class WeightNormFunction(torch.autograd.Function):
+    """w = v * g / ||v||_F (utils.py:72-158, v_dim=None) as one launch each way (csrc/ln_glue.hip) instead of the norm / div / mul
+    chain and its ~10 backward launches on a parameter of a few thousand numbers."""
+
+    @staticmethod
+    def forward(ctx, v, g, g_dim):
+        lib = _lib.load()
+        v, gc = v.contiguous(), g.contiguous()
+        rows, cols = v.shape
+        w = torch.empty_like(v)
+        norm = torch.empty((1,), dtype=torch.float32, device=v.device)
+        _lib.check(lib.ln_weight_norm_forward(_lib.ptr(v), _lib.ptr(gc), rows, cols, g_dim, _lib.ptr(w), _lib.ptr(norm), _lib.stream_ptr(v.device)),
+                   "ln_weight_norm_forward")
+        ctx.save_for_backward(v, gc, norm)
+        ctx.g_dim = g_dim
+        return w
+
+    @staticmethod
+    def backward(ctx, grad_w):
+        lib = _lib.load()
+        v, g, norm = ctx.saved_tensors
+        grad_w = grad_w.contiguous()
+        rows, cols = v.shape
+        gv, gg = torch.empty_like(v), torch.empty_like(g)
+        _lib.check(lib.ln_weight_norm_backward(_lib.ptr(v), _lib.ptr(g), _lib.ptr(grad_w), _lib.ptr(norm), rows, cols, ctx.g_dim, _lib.ptr(gv),
+                                               _lib.ptr(gg), _lib.stream_ptr(v.device)), "ln_weight_norm_backward")
+        return gv, gg, None
+
+
 class _WeightNormed:
     """The reference's weight_norm_wrapper (utils.py:72-158) with v_dim=None: parameters `weight_v` (direction, the
     layer's weight shape) and `weight_g` (one magnitude per output unit, kept along `g_dim`), effective weight
@@ -52,10 +84,15 @@ class _WeightNormed:
         # registration order of torch's WeightNorm.apply: <name>_g, then <name>_v, both behind the parameters that stay (bias)
         self.weight_g = torch.nn.Parameter(torch.full(g_shape, float(v.norm()), dtype=v.dtype, device=v.device))  # unfuse(): g := ||v||
         self.weight_v = torch.nn.Parameter(v)
+        self._g_dim = g_dim
 
     @property
     def weight(self) -> torch.Tensor:
-        return self.weight_v * (self.weight_g / self.weight_v.norm())
+        v, g = self.weight_v, self.weight_g
+        if "weight_norm" in FUSED_GLUE and v.is_cuda and v.dtype == torch.float32 and g.dtype == torch.float32 and v.dim() == 2 and 1 <= g.numel() <= 1024 and \
+                0 < v.numel() <= (1 << 24) and getattr(self, "_g_dim", None) in (0, 1):
+            return WeightNormFunction.apply(v, g, self._g_dim)
+        return v * (g / v.norm())
 
 
 class LinearWN(_WeightNormed, torch.nn.Module):  # utils.py:291 (weight_norm_wrapper(Linear, g_dim=0, v_dim=None))
@@ -188,6 +225,61 @@ def linear_leaky_relu(x, weight, bias, slope: float):
     return torch.nn.functional.leaky_relu(y, slope) if slope >= 0 else y
 
 
+_UNIT_WEIGHTS = {}
+
+
+def _unit_weights(device, tokens: int) -> torch.Tensor:
+    """float32 ones [tokens] (the weights of an unweighted segment reduce); grown, never freed: a captured hipGraph may point at
+    an earlier, shorter buffer."""
+    bufs = _UNIT_WEIGHTS.setdefault(device, [])
+    if not bufs or bufs[-1].shape[0] < tokens:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("the unit weights would be allocated inside a stream capture: run the step eagerly once first")
+        size = 1 << 16
+        while size < tokens:
+            size *= 2
+        bufs.append(torch.ones((size,), dtype=torch.float32, device=device))
+    return bufs[-1][:tokens]
+
+
+class PointNetReduceFunction(torch.autograd.Function):
+    """The vertex side of PointNetModule (lattice_modules.py:688-712): per-vertex max of the token features with the barycentric
+    weight of each winning token appended, vertices with fewer than four tokens and vertex 0 zeroed.  `distributed` [tokens, width]
+    holds the barycentric weight in its last column and takes no gradient (it comes from DistributeLattice)."""
+
+    @staticmethod
+    def forward(ctx, x, distributed, lattice, splatting_indices):
+        import ctypes as C
+        lib = _lib.load()
+        x = x.contiguous()
+        tokens, c = x.shape
+        if splatting_indices.numel() != tokens or distributed.shape[0] != tokens:
+            raise ValueError("features, distributed rows and splat indices must describe the same tokens")
+        m = lattice.nr_lattice_vertices()
+        _, csr, max_seg, grp_row, _ = lattice._csr(splatting_indices)
+        dev = x.device
+        width = distributed.shape[1]
+        ws = torch.empty((lib.ln_pointnet_reduce_workspace_bytes(m, c),), dtype=torch.uint8, device=dev)
+        out = torch.empty((m, 2 * c), dtype=torch.float32, device=dev)
+        arg = torch.empty((m, c), dtype=torch.int32, device=dev)
+        _lib.check(lib.ln_pointnet_reduce_forward(C.byref(csr), _lib.ptr(grp_row), max_seg, _lib.ptr(x), c,
+                                                  distributed.data_ptr() + 4 * (width - 1), width, m, 4, _lib.ptr(ws), ws.numel(), _lib.ptr(out),
+                                                  _lib.ptr(arg), _lib.stream_ptr(dev)), "ln_pointnet_reduce_forward")
+        ctx.save_for_backward(arg, splatting_indices)
+        ctx.tokens, ctx.channels = tokens, c
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        arg, idx = ctx.saved_tensors
+        grad_out = grad_out.contiguous()
+        gx = torch.empty((ctx.tokens, ctx.channels), dtype=torch.float32, device=grad_out.device)
+        _lib.check(_lib.load().ln_pointnet_reduce_backward(_lib.ptr(grad_out), grad_out.shape[1], _lib.ptr(arg), _lib.ptr(idx), ctx.tokens,
+                                                           ctx.channels, _lib.ptr(gx), _lib.stream_ptr(grad_out.device)),
+                   "ln_pointnet_reduce_backward")
+        return gx, None, None, None
+
+
 class SplatLatticeModule(torch.nn.Module):  # lattice_modules.py:46-51
     def forward(self, lattice_py, positions, values):
         lv, ls_wrap, indices, weights = SplatLattice.apply(lattice_py, positions, values)
@@ -203,8 +295,20 @@ class DistributeLatticeModule(torch.nn.Module):  # lattice_modules.py:52-96
         wrap, distributed, splatting_indices, splatting_weights = DistributeLattice.apply(lattice, positions, values, reset_hashmap)
         distributed_lattice = wrap.lattice
         pos_dim = positions.shape[1]
-        distributed_positions = distributed[:, :pos_dim].contiguous()
         nr_rows = distributed_lattice.nr_lattice_vertices()
+        if "distribute" in FUSED_GLUE and distributed.is_cuda and distributed.dtype == torch.float32 and distributed.is_contiguous() and \
+                not distributed.requires_grad:
+            # sums of the positions straight from the token rows, degrees, then ONE pass for mean / subtract / zeroing
+            tokens, width = distributed.shape
+            sums = torch.zeros((nr_rows, pos_dim), dtype=torch.float32, device=distributed.device)
+            distributed_lattice._scatter_rows(distributed, splatting_indices, _unit_weights(distributed.device, tokens), sums, pos_dim, 1, width)
+            counts = distributed_lattice.vertex_point_counts(splatting_indices)
+            centred = torch.empty_like(distributed)
+            _lib.check(_lib.load().ln_distribute_centre(_lib.ptr(distributed), _lib.ptr(splatting_indices), _lib.ptr(sums), _lib.ptr(counts), tokens,
+                                                        width, pos_dim, _lib.ptr(centred), _lib.stream_ptr(distributed.device)),
+                       "ln_distribute_centre")
+            return distributed_lattice, centred, splatting_indices, splatting_weights
+        distributed_positions = distributed[:, :pos_dim].contiguous()
         sums = torch.zeros((nr_rows, pos_dim), dtype=distributed.dtype, device=distributed.device)
         ones = torch.ones((splatting_indices.numel(),), dtype=distributed.dtype, device=distributed.device)
         distributed_lattice._scatter_rows(distributed_positions, splatting_indices, ones, sums, pos_dim, 1, pos_dim)
@@ -246,6 +350,14 @@ class PointNetModule(torch.nn.Module):  # lattice_modules.py:618-733 (the step r
         x = distributed[:, : distributed.shape[1] - 1]
         for layer in self.layers:  # linear + LeakyReLU(0.2) per token, fused (mods:669-671)
             x = linear_leaky_relu(x, layer.weight, layer.bias, self.act.negative_slope)
+        if "pointnet" in FUSED_GLUE and x.is_cuda and x.dtype == torch.float32 and distributed.is_contiguous() and not distributed.requires_grad:
+            # scatter_max + degrees + the winners' barycentric weights + both zeroing rules in three launches (mods:688-712)
+            reduced = PointNetReduceFunction.apply(x, distributed, lattice_py, indices)
+            lattice_py.set_values(reduced)
+            reduced, lattice_py = self.last_conv(reduced, lattice_py)
+            reduced = self.act(reduced)
+            lattice_py.set_values(reduced)
+            return reduced, lattice_py
         reduced, argmax = ScatterMaxLattice.apply(x, lattice_py, indices)               # mods:688
         nr_points = lattice_py.vertex_point_counts(indices).unsqueeze(1)                  # mods:692
         safe = torch.where(argmax >= 0, argmax, torch.zeros_like(argmax)).long()

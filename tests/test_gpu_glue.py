@@ -1,0 +1,131 @@
+"""The fused glue kernels of csrc/ln_glue.hip / ln_csr.hip (weight normalisation, DistributeLatticeModule's per-token tail, the
+vertex-side reduction of PointNetModule, the one-launch table arena) against the torch operator chains they replace — the chains
+are the reference's own formulation (lattice_modules.py:72-94, 688-712; utils.py:72-158)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+ALL_FUSED = ("weight_norm", "distribute", "pointnet")
+
+
+def dev():
+    return torch.device("cuda", 0)
+
+
+@pytest.mark.parametrize("rows,cols,g_dim", [(16, 5, 0), (32, 16, 0), (64, 32, 0), (297, 32, 1), (1152, 128, 1), (7, 1, 0), (1, 9, 1),
+                                             (1000, 3, 0), (3, 1000, 1)])
+def test_weight_norm_matches_the_torch_chain(rows, cols, g_dim):
+    from lattice_net_amd.lattice_modules import WeightNormFunction
+    gen = torch.Generator().manual_seed(rows * 31 + cols)
+    v64 = torch.randn((rows, cols), generator=gen, dtype=torch.float64)
+    g_shape = (rows, 1) if g_dim == 0 else (1, cols)
+    g64 = torch.rand(g_shape, generator=gen, dtype=torch.float64) + 0.5
+    gw64 = torch.randn((rows, cols), generator=gen, dtype=torch.float64)
+    v64.requires_grad_(True)
+    g64.requires_grad_(True)
+    w64 = v64 * (g64 / v64.norm())
+    w64.backward(gw64)
+    v = v64.detach().float().to(dev()).requires_grad_(True)
+    g = g64.detach().float().to(dev()).requires_grad_(True)
+    w = WeightNormFunction.apply(v, g, g_dim)
+    w.backward(gw64.float().to(dev()))
+    for got, exp in ((w, w64), (v.grad, v64.grad), (g.grad, g64.grad)):
+        exp = exp.detach().numpy()
+        np.testing.assert_allclose(got.detach().cpu().numpy(), exp, rtol=0, atol=2e-6 * max(float(np.abs(exp).max()), 1e-30))
+    assert g.grad.shape == g.shape
+
+
+def test_weight_normed_layers_take_the_fused_form_and_agree_with_the_chain():
+    import lattice_net_amd.lattice_modules as M
+    torch.manual_seed(1)
+    lin = M.LinearWN(12, 24, device=dev())
+    x = torch.randn((50, 12), device=dev())
+    outs = {}
+    for fused in (True, False):
+        M.FUSED_GLUE = set(ALL_FUSED) if fused else set(ALL_FUSED) - {"weight_norm"}
+        try:
+            lin.zero_grad()
+            y = lin(x)
+            y.square().sum().backward()
+            outs[fused] = (y.detach().clone(), lin.weight_v.grad.clone(), lin.weight_g.grad.clone())
+        finally:
+            M.FUSED_GLUE = set(ALL_FUSED)
+    for a, b in zip(outs[True], outs[False]):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5 * float(b.abs().max()))
+
+
+def _distribute(n=5000, seed=3, sigma=0.9, values=2):
+    from lattice_net_amd import Lattice
+    from lattice_net_amd.lattice_modules import DistributeLatticeModule
+    from lattice_net_amd.synthetic import lidar_cloud
+    pos = torch.from_numpy(lidar_cloud(n, seed)).to(dev())
+    vals = torch.from_numpy(np.random.default_rng(seed).standard_normal((n, values)).astype(np.float32)).to(dev())
+    lat = Lattice(sigmas=[sigma] * 3, capacity=8 * n, device=dev())
+    return DistributeLatticeModule()(lat, pos, vals)
+
+
+def test_distribute_tail_matches_the_torch_chain():
+    import lattice_net_amd.lattice_modules as M
+    got = _distribute()
+    M.FUSED_GLUE = set(ALL_FUSED) - {"distribute"}
+    try:
+        exp = _distribute()
+    finally:
+        M.FUSED_GLUE = set(ALL_FUSED)
+    assert got[0].nr_lattice_vertices() == exp[0].nr_lattice_vertices()
+    assert torch.equal(got[2], exp[2]) and torch.equal(got[3], exp[3])
+    idx = got[2].cpu().numpy()
+    assert (idx <= 0).any()                                     # tokens of vertex 0 exist: their rows are zero
+    assert not got[1].cpu().numpy()[idx <= 0].any()
+    # (the position sums of vertices with several segments are combined with float atomics: the last bit may differ run to run)
+    a, b = got[1].cpu().numpy(), exp[1].cpu().numpy()
+    assert np.array_equal(a == 0, b == 0) or np.abs(a - b).max() < 1e-6
+    np.testing.assert_allclose(a, b, rtol=0, atol=2e-6 * float(np.abs(b).max()))
+    assert np.array_equal(a[:, 3:], b[:, 3:])                   # everything but the centred positions: copied bit for bit
+
+
+def test_pointnet_reduction_is_bitwise_the_torch_chain():
+    import lattice_net_amd.lattice_modules as M
+    dist_lat, distributed, idx, _ = _distribute(n=6000, seed=8)
+    torch.manual_seed(0)
+    pn = M.PointNetModule([16, 32], 32, nr_input_channels=distributed.shape[1] - 1)
+    seen = {}
+    hook = pn.last_conv.register_forward_pre_hook(lambda mod, args: seen.__setitem__("in", args[0].detach().clone()))
+    outs = {}
+    for fused in (True, False):
+        M.FUSED_GLUE = set(ALL_FUSED) if fused else set(ALL_FUSED) - {"pointnet"}
+        try:
+            pn.zero_grad()
+            lat = dist_lat  # (PointNetModule only sets values on it)
+            lv, _ = pn(lat, distributed, idx)
+            lv.square().mean().backward()
+            outs[fused] = (seen["in"], lv.detach().clone(), [p.grad.clone() for p in pn.parameters()])
+        finally:
+            M.FUSED_GLUE = set(ALL_FUSED)
+    hook.remove()
+    a, b = outs[True], outs[False]
+    assert torch.equal(a[0], b[0])                               # the reduced rows entering the convolution: identical
+    m = a[0].shape[0]
+    counts = dist_lat.vertex_point_counts(idx).cpu().numpy()
+    dropped = (counts < 4) | (np.arange(m) == 0)
+    assert dropped.any() and not a[0].cpu().numpy()[dropped].any()
+    assert torch.equal(a[1], b[1])
+    for ga, gb in zip(a[2], b[2]):
+        torch.testing.assert_close(ga, gb, rtol=1e-5, atol=1e-6 * float(gb.abs().max()) + 1e-12)
+
+
+def test_fresh_table_buffers_come_initialised_from_one_arena():
+    from lattice_net_amd.lattice import _TableStorage
+    s = _TableStorage(1001, 3, dev(), spare_row_width=5)
+    assert s.keys.shape == (1001, 3) and not s.keys.any()
+    assert s.entries.shape == (1001,) and bool((s.entries == -1).all())
+    assert s.slot_cnt.shape == (1001,) and not s.slot_cnt.any()
+    assert s.fresh_counters.shape == (2,) and not s.fresh_counters.any()
+    assert s.fresh_row.shape == (1, 5) and s.fresh_row.dtype == torch.float32 and not s.fresh_row.any()
+    for t in (s.keys, s.entries, s.slot_cnt, s.fresh_counters, s.fresh_row):
+        assert t.data_ptr() % 16 == 0
+    c = s.clone()
+    assert c.keys.data_ptr() != s.keys.data_ptr() and bool((c.entries == -1).all())
