@@ -427,6 +427,17 @@ int ln_pointnet_reduce_forward(const LnCsr* csr, const int* grp_row, long long m
 int ln_pointnet_reduce_backward(const float* grad_out, int grad_stride, const int* out_arg, const int* splat_idx, long long tokens,
                                 int channels, float* grad_src, void* stream);
 
+/* Mean negative log-likelihood of the training loop (ln_train.py:130, torch.nn.NLLLoss(ignore_index=...)): log_probs [n, classes]
+ * float, target [n] int64; ignore_index: a label value that is skipped (pass a value no label takes, e.g. LLONG_MIN, for none).
+ * loss_count [2]: {loss = -sum lp[i, y_i] / max(count, 1), max(count, 1)} (count = labels not ignored); labels outside
+ * [0, classes) are clamped, as in the gather formulation it replaces.  Backward writes every element of grad_log_probs [n, classes]:
+ * -grad_loss / count at (i, y_i) of the labels that count, 0 elsewhere.  Sums in a fixed order (deterministic). */
+size_t ln_nll_workspace_bytes(void);
+int ln_nll_forward(const float* log_probs, const long long* target, long long n, int classes, long long ignore_index, void* workspace,
+                   size_t workspace_bytes, float* loss_count, void* stream);
+int ln_nll_backward(const long long* target, const float* grad_loss, const float* loss_count, long long n, int classes,
+                    long long ignore_index, float* grad_log_probs, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -92,7 +92,7 @@ LnProfEvents ln_prof_next(const char* name) {
     return ev;
 }
 
-extern "C" const char* ln_kernel_names(void) { return "k_bucket_rows,k_canon_idx,k_canon_mark,k_canon_segs,k_canon_slots,k_conv_backward_fused,k_conv_generic,k_conv_generic_f16,k_conv_mfma,k_conv_mfma_f16,k_conv_split_bank,k_conv_sum_partials,k_csr_count,k_csr_fill,k_csr_group_sizes,k_csr_reduce_segments,k_csr_scan_local,k_csr_scan_top,k_csr_segment_max,k_csr_segment_max_decode,k_distribute_centre,k_finalize,k_gather_backward,k_gather_forward,k_gn_apply,k_gn_backward_apply,k_gn_stats,k_grad_filter_f16,k_grad_filter_generic,k_grad_filter_mfma,k_grad_filter_mfma_f16,k_im2row,k_im2rowindices,k_insert_coarse,k_insert_points,k_linear_act_backward_w,k_linear_act_backward_x,k_linear_act_forward,k_linear_reduce_slabs,k_mark_first,k_max_centre_backward,k_max_centre_forward,k_max_centre_sum,k_neighbours,k_point_keys,k_pointnet_reduce_backward,k_pointnet_reduce_decode,k_reduce_and_neighbours,k_reduce_slabs,k_rehash_clear,k_rehash_rows,k_retrieve_points,k_row2im,k_sc_reduce_slabs,k_sc_scatter_atomic,k_scan_blocks,k_scatter_point_rows,k_seg_min,k_slice_classify_backward,k_slice_classify_forward,k_slice_forward,k_slice_forward_f16,k_table_clear,k_weight_norm_backward,k_weight_norm_forward,ln_k_arena_init"; }
+extern "C" const char* ln_kernel_names(void) { return "k_bucket_rows,k_canon_idx,k_canon_mark,k_canon_segs,k_canon_slots,k_conv_backward_fused,k_conv_generic,k_conv_generic_f16,k_conv_mfma,k_conv_mfma_f16,k_conv_split_bank,k_conv_sum_partials,k_csr_count,k_csr_fill,k_csr_group_sizes,k_csr_reduce_segments,k_csr_scan_local,k_csr_scan_top,k_csr_segment_max,k_csr_segment_max_decode,k_distribute_centre,k_finalize,k_gather_backward,k_gather_forward,k_gn_apply,k_gn_backward_apply,k_gn_stats,k_grad_filter_f16,k_grad_filter_generic,k_grad_filter_mfma,k_grad_filter_mfma_f16,k_im2row,k_im2rowindices,k_insert_coarse,k_insert_points,k_linear_act_backward_w,k_linear_act_backward_x,k_linear_act_forward,k_linear_reduce_slabs,k_mark_first,k_max_centre_backward,k_max_centre_forward,k_max_centre_sum,k_neighbours,k_nll_backward,k_nll_finish,k_nll_partials,k_point_keys,k_pointnet_reduce_backward,k_pointnet_reduce_decode,k_reduce_and_neighbours,k_reduce_slabs,k_rehash_clear,k_rehash_rows,k_retrieve_points,k_row2im,k_sc_reduce_slabs,k_sc_scatter_atomic,k_scan_blocks,k_scatter_point_rows,k_seg_min,k_slice_classify_backward,k_slice_classify_forward,k_slice_forward,k_slice_forward_f16,k_table_clear,k_weight_norm_backward,k_weight_norm_forward,ln_k_arena_init"; }
 
 extern "C" int ln_profile_begin(const char* kernel_names, int max_samples) {
     LN_REQUIRE(kernel_names && strlen(kernel_names) + 3 < sizeof(g_prof.names) && max_samples > 0, LN_ERR_ARG, "ln_profile_begin: bad args");

@@ -129,3 +129,26 @@ def test_fresh_table_buffers_come_initialised_from_one_arena():
         assert t.data_ptr() % 16 == 0
     c = s.clone()
     assert c.keys.data_ptr() != s.keys.data_ptr() and bool((c.entries == -1).all())
+
+
+@pytest.mark.parametrize("n,c,ignore", [(120000, 20, None), (5000, 20, 0), (777, 5, 3), (64, 4, 1), (1, 2, None)])
+def test_fused_nll_matches_the_gather_formulation(n, c, ignore):
+    import lattice_net_amd.losses as L
+    gen = torch.Generator().manual_seed(n + c)
+    logits = torch.randn((n, c), generator=gen)
+    target = torch.randint(0, c, (n,), generator=gen)
+    if n == 64:
+        target[:] = ignore                                       # every label ignored: loss 0, gradient 0
+    out = {}
+    for fused in (True, False):
+        L.FUSED_NLL = fused
+        try:
+            x = logits.to(dev()).requires_grad_(True)
+            lp = torch.log_softmax(x.double() if not fused else x, dim=1)
+            loss = L.nll_loss_gather(lp, target.to(dev()), ignore)
+            (loss * 3.0).backward()
+            out[fused] = (float(loss), x.grad.double().cpu().numpy())
+        finally:
+            L.FUSED_NLL = True
+    assert abs(out[True][0] - out[False][0]) <= 2e-6 * max(abs(out[False][0]), 1e-30) + 1e-12
+    np.testing.assert_allclose(out[True][1], out[False][1], rtol=0, atol=2e-6 * max(float(np.abs(out[False][1]).max()), 1e-30))

@@ -53,6 +53,25 @@ print(f"torch operators: {total / steps:.0f} us of GPU time per step")
 for e in rows[:30]:
     print(f"{e.key[:34]:34s} {e.count / steps:6.1f}/step {gpu_us(e) / steps:8.1f} us/step   {str(e.input_shapes)[:110]}")
 
+fills = [e for e in prof.key_averages(group_by_input_shape=True) if e.key in ("aten::fill_", "aten::zero_", "aten::zeros", "aten::zeros_like", "aten::new_zeros", "aten::masked_fill_")]
+print("fill-like operators by input shape (all of them; aten::zeros / zero_ call fill_):")
+for e in sorted(fills, key=lambda e: -e.count):
+    print(f"  {e.key:18s} {e.count / steps:6.1f}/step {gpu_us(e) / steps:8.1f} us/step   {str(e.input_shapes)[:110]}")
+
+# the operator chain above every fill (the autograd engine and C++ operators create zeros no Python hook sees)
+import collections as _c
+chains = _c.Counter()
+for e in prof.events():
+    if e.name == "aten::fill_" and getattr(e, "device_time_total", 0) > 0:
+        names, p_ = [], e.cpu_parent
+        while p_ is not None and len(names) < 4:
+            names.append(p_.name[:48])
+            p_ = p_.cpu_parent
+        chains[(str(e.input_shapes)[:40], " < ".join(names))] += 1
+print("fills that launched a kernel, by (shape, parents):")
+for (shape, chain), c in chains.most_common(40):
+    print(f"  {c / steps:5.1f}/step  {shape:40s} {chain}")
+
 # ---- where the fill / zero launches come from: Python call sites of the zero-filling constructors and in-place fills (CUDA tensors)
 if os.environ.get("LNN_FILL_SITES", "1") == "1":
     import collections
