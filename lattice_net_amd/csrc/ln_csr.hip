@@ -523,14 +523,17 @@ __device__ __forceinline__ float ln_ordered_to_float(unsigned int o) {
 // one lane per (segment, channel): running max over <=16 tokens; value and token are packed into 64 bits
 // (ordered value in the high word, ~token in the low word -> ties go to the smallest token) so that the
 // segments of a hot vertex combine with one 64-bit atomicMax.
+template <int VEC>
 __global__ void __launch_bounds__(256)
     k_csr_segment_max(const int* __restrict__ csr_tok, const int4* __restrict__ seg_desc, const int* __restrict__ seg_count, long long seg_region,
                       const int* __restrict__ grp_row, const float* __restrict__ src, int channels,
                       unsigned long long* __restrict__ packed, int* __restrict__ counts) {
-  for (LnSegWalk wk(blockIdx.x, gridDim.x, channels, seg_count, seg_region); wk.more(); wk.next()) {
+  // a lane owns VEC consecutive channels of its segment's rows (VEC = 4: one 16-byte load per token and lane, four tokens in flight)
+  const int lanes = channels / VEC;
+  for (LnSegWalk wk(blockIdx.x, gridDim.x, lanes, seg_count, seg_region); wk.more(); wk.next()) {
     const LnSegOfThread so = wk.here();
     const long long sid = so.sid;
-    const int c = so.lane_in_seg;
+    const int c = so.lane_in_seg * VEC;
     if (!so.active) continue;
     const int4 sd = seg_desc[sid];
     const int grp = sd.x;
@@ -539,18 +542,44 @@ __global__ void __launch_bounds__(256)
     const int beg = sd.y;
     const int end = beg + min(LN_SEG, sd.z);
     const bool only_segment = sd.w == 0 && sd.z <= LN_SEG;
-    unsigned long long best = 0ull;
-    for (int e = beg; e < end; ++e) {
-        const int t = csr_tok[e];
-        const unsigned long long p = ((unsigned long long)ln_float_to_ordered(src[(size_t)t * channels + c]) << 32) |
-                                     (unsigned long long)(0xFFFFFFFFu - (unsigned int)t);
-        best = p > best ? p : best;
+    unsigned long long best[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) best[k] = 0ull;
+    constexpr int U = 4;
+    for (int e0 = beg; e0 < end; e0 += U) {
+        int tk[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) tk[u] = (e0 + u < end) ? csr_tok[e0 + u] : -1;
+        float x[U][VEC];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (tk[u] >= 0) {
+                if constexpr (VEC == 4) {
+                    const float4 v4 = *reinterpret_cast<const float4*>(src + (size_t)tk[u] * channels + c);
+                    x[u][0] = v4.x; x[u][1] = v4.y; x[u][2] = v4.z; x[u][3] = v4.w;
+                } else {
+                    x[u][0] = src[(size_t)tk[u] * channels + c];
+                }
+            }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (tk[u] >= 0) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    const unsigned long long p = ((unsigned long long)ln_float_to_ordered(x[u][k]) << 32) |
+                                                 (unsigned long long)(0xFFFFFFFFu - (unsigned int)tk[u]);
+                    best[k] = p > best[k] ? p : best[k];
+                }
+            }
     }
     unsigned long long* d = packed + (size_t)row * channels + c;
-    if (only_segment)
-        *d = best;
-    else
-        atomicMax(d, best);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        if (only_segment)
+            d[k] = best[k];
+        else
+            atomicMax(d + k, best[k]);
+    }
     if (counts && c == 0) {  // vertex degree on the side (the fused PointNet reduction needs it; integer adds: order-free)
         if (only_segment)
             counts[row] = end - beg;
@@ -575,6 +604,17 @@ __global__ void __launch_bounds__(256)
     }
 }
 
+static void ln_launch_segment_max(const LnCsr* csr, const int* grp_row, long long max_segments, const float* src, int channels,
+                                  unsigned long long* packed, int* counts, hipStream_t st) {
+    const bool vec4 = channels % 4 == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0;
+    if (vec4)
+        LN_LAUNCH("k_csr_segment_max", k_csr_segment_max<4>, dim3(ln_seg_grid(max_segments, channels / 4)), dim3(256), 0, st, csr->csr_tok,
+                  reinterpret_cast<const int4*>(csr->seg_desc), csr->seg_count, csr->seg_region, grp_row, src, channels, packed, counts);
+    else
+        LN_LAUNCH("k_csr_segment_max", k_csr_segment_max<1>, dim3(ln_seg_grid(max_segments, channels)), dim3(256), 0, st, csr->csr_tok,
+                  reinterpret_cast<const int4*>(csr->seg_desc), csr->seg_count, csr->seg_region, grp_row, src, channels, packed, counts);
+}
+
 extern "C" int ln_csr_segment_max(const LnCsr* csr, const int* grp_row, long long max_segments, const float* src, int channels,
                                   int rows, void* packed_ws, float* out_max, int* out_arg, void* stream) {
     LN_REQUIRE(max_segments >= 0 && channels >= 1 && rows >= 0, LN_ERR_ARG, "ln_csr_segment_max: bad sizes");
@@ -587,9 +627,7 @@ extern "C" int ln_csr_segment_max(const LnCsr* csr, const int* grp_row, long lon
     if (ln_zero_async(packed_ws, (size_t)work * sizeof(unsigned long long), st) != LN_OK)
         return ln_check_launch("ln_csr_segment_max(memset)");
     if (max_segments > 0)
-        LN_LAUNCH("k_csr_segment_max", k_csr_segment_max, dim3(ln_seg_grid(max_segments, channels)), dim3(256), 0, st, csr->csr_tok,
-                  reinterpret_cast<const int4*>(csr->seg_desc), csr->seg_count, csr->seg_region, grp_row, src, channels,
-                  static_cast<unsigned long long*>(packed_ws), (int*)nullptr);
+        ln_launch_segment_max(csr, grp_row, max_segments, src, channels, static_cast<unsigned long long*>(packed_ws), nullptr, st);
     LN_LAUNCH("k_csr_segment_max_decode", k_csr_segment_max_decode, dim3(ln_div_up(work, 256)), dim3(256), 0, st,
               static_cast<const unsigned long long*>(packed_ws), work, out_max, out_arg);
     return ln_check_launch("ln_csr_segment_max");
@@ -621,17 +659,39 @@ __global__ void __launch_bounds__(256)
 
 // gradient of the maxima wrt the per-token rows, token-major (every element written: no zero fill, no scatter):
 //   grad_src[t, c] = grad_out[row, c] if arg[row, c] == t else 0,   row = idx[t]
+// A thread owns VEC consecutive channels of one token (VEC = 4: 16-byte loads of the winners' ids and a 16-byte store).
+template <int VEC>
 __global__ void __launch_bounds__(256)
     k_pointnet_reduce_backward(const float* __restrict__ grad_out, int grad_stride, const int* __restrict__ arg, const int* __restrict__ idx,
                                long long work, int channels, float* __restrict__ grad_src) {
-    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // over tokens * channels / VEC
     if (g >= work) return;
-    const long long t = g / channels;
-    const int c = int(g - t * channels);
+    const int per_row = channels / VEC;
+    const long long t = g / per_row;
+    const int c = int(g - t * per_row) * VEC;
     const int row = idx[t];
-    float x = 0.f;
-    if (row > 0 && arg[(size_t)row * channels + c] == (int)t) x = grad_out[(size_t)row * grad_stride + c];
-    grad_src[g] = x;
+    float x[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) x[k] = 0.f;
+    if (row > 0) {
+        if constexpr (VEC == 4) {
+            const int4 a = *reinterpret_cast<const int4*>(arg + (size_t)row * channels + c);
+            const int tt = (int)t;
+            if (a.x == tt || a.y == tt || a.z == tt || a.w == tt) {
+                const float* gr = grad_out + (size_t)row * grad_stride + c;
+                if (a.x == tt) x[0] = gr[0];
+                if (a.y == tt) x[1] = gr[1];
+                if (a.z == tt) x[2] = gr[2];
+                if (a.w == tt) x[3] = gr[3];
+            }
+        } else {
+            if (arg[(size_t)row * channels + c] == (int)t) x[0] = grad_out[(size_t)row * grad_stride + c];
+        }
+    }
+    if constexpr (VEC == 4)
+        *reinterpret_cast<float4*>(grad_src + g * 4) = make_float4(x[0], x[1], x[2], x[3]);
+    else
+        grad_src[g] = x[0];
 }
 
 extern "C" size_t ln_pointnet_reduce_workspace_bytes(int rows, int channels) {
@@ -655,8 +715,7 @@ extern "C" int ln_pointnet_reduce_forward(const LnCsr* csr, const int* grp_row, 
     if (ln_zero_async(workspace, (size_t)work * sizeof(unsigned long long) + (size_t)rows * sizeof(int), st) != LN_OK)
         return ln_check_launch("ln_pointnet_reduce_forward(memset)");
     if (max_segments > 0)
-        LN_LAUNCH("k_csr_segment_max", k_csr_segment_max, dim3(ln_seg_grid(max_segments, channels)), dim3(256), 0, st, csr->csr_tok,
-                  reinterpret_cast<const int4*>(csr->seg_desc), csr->seg_count, csr->seg_region, grp_row, src, channels, packed, counts);
+        ln_launch_segment_max(csr, grp_row, max_segments, src, channels, packed, counts, st);
     LN_LAUNCH("k_pointnet_reduce_decode", k_pointnet_reduce_decode, dim3(ln_div_up(work, 256)), dim3(256), 0, st, packed, counts, bary, bary_stride,
               work, channels, min_points, out, out_arg);
     return ln_check_launch("ln_pointnet_reduce_forward");
@@ -667,9 +726,14 @@ extern "C" int ln_pointnet_reduce_backward(const float* grad_out, int grad_strid
     LN_REQUIRE(tokens >= 0 && channels >= 1 && grad_stride >= channels, LN_ERR_ARG, "ln_pointnet_reduce_backward: bad sizes");
     if (tokens == 0) return LN_OK;
     LN_REQUIRE(grad_out && arg && splat_idx && grad_src, LN_ERR_ARG, "ln_pointnet_reduce_backward: null buffer");
-    const long long work = tokens * channels;
-    LN_LAUNCH("k_pointnet_reduce_backward", k_pointnet_reduce_backward, dim3(ln_div_up(work, 256)), dim3(256), 0, (hipStream_t)stream, grad_out,
-              grad_stride, arg, splat_idx, work, channels, grad_src);
+    const bool vec4 = channels % 4 == 0 && ((reinterpret_cast<uintptr_t>(arg) | reinterpret_cast<uintptr_t>(grad_src)) & 15) == 0;
+    const long long work = tokens * channels / (vec4 ? 4 : 1);
+    if (vec4)
+        LN_LAUNCH("k_pointnet_reduce_backward", k_pointnet_reduce_backward<4>, dim3(ln_div_up(work, 256)), dim3(256), 0, (hipStream_t)stream,
+                  grad_out, grad_stride, arg, splat_idx, work, channels, grad_src);
+    else
+        LN_LAUNCH("k_pointnet_reduce_backward", k_pointnet_reduce_backward<1>, dim3(ln_div_up(work, 256)), dim3(256), 0, (hipStream_t)stream,
+                  grad_out, grad_stride, arg, splat_idx, work, channels, grad_src);
     return ln_check_launch("ln_pointnet_reduce_backward");
 }
 
