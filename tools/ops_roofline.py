@@ -119,6 +119,39 @@ def run(dev=None, reps: int = 24):
                       N * (4 * D + 4 * 1 + 8 * (D + 1)) + m * 4 * D + N * (D + 1) * (D + 1 + 1) * 4, reps,
                       note=f"{m} vertices; algorithmic bytes = splat-forward reads / writes without the value rows + the distributed rows"))
 
+    # ---- a4 tail / f1: the glue of DistributeLatticeModule and PointNetModule (lattice_modules.py:72-94, 688-712) as fused launches
+    from lattice_net_amd.lattice_modules import DistributeLatticeModule, PointNetReduceFunction
+    dmod = DistributeLatticeModule()
+
+    def distribute_module():
+        state["dm"] = dmod(fresh(), pos, vals1)
+    k = _profile(lib, distribute_module, reps)
+    tail = [x for x in k if x["kernel"] in ("k_distribute_centre", "k_csr_reduce_segments", "k_csr_group_sizes", "ln_k_zero_words")]
+    T, wd = N * (D + 1), D + 1 + 1
+    ops.append(_entry("a4", "DistributeLatticeModule tail: per-vertex mean position, centred rows, vertex-0 rule (mods:72-94)", tail,
+                      T * (2 * wd * 4 + 4) + m * (4 * D + 4), reps,
+                      note="algorithmic bytes = distributed rows read + centred rows written + indices + per-vertex sums and degrees; the "
+                           "launches of the hash build itself are the row above"))
+    dlm, drows, didx, _ = state["dm"]
+    feat = torch.randn((T, 32), device=dev, requires_grad=True)
+    gred = torch.randn((dlm.nr_lattice_vertices(), 64), device=dev)
+
+    def pn_fwd():
+        state["pn"] = PointNetReduceFunction.apply(feat, drows, dlm, didx)
+    k = _profile(lib, pn_fwd, reps)
+    mm = dlm.nr_lattice_vertices()
+    ops.append(_entry("f1", "PointNet vertex reduction forward: max + winners' barycentric weights + <4-points / vertex-0 rules, C = 32 (mods:688-712)",
+                      k, T * (32 * 4 + 4) + mm * (64 * 4 + 32 * 4 + 4), reps,
+                      note="algorithmic bytes = token features + indices read, [M, 2C] rows + [M, C] winners written"))
+
+    def pn_bwd():
+        feat.grad = None
+        PointNetReduceFunction.apply(feat, drows, dlm, didx).backward(gred)
+    k = _profile(lib, pn_bwd, reps)
+    kb = [x for x in k if x["kernel"] == "k_pointnet_reduce_backward"]
+    ops.append(_entry("f1", "PointNet vertex reduction backward (token-major, every element written once)", kb,
+                      T * (32 * 4 + 4) + mm * (32 * 4 + 32 * 4), reps))
+
     # ---- a9 coarse vertex set (Lattice.cu:706-740): keys only from positions / (2 sigma)
     def coarse():
         state["c1"] = dl.create_coarse_verts_naive(pos)
