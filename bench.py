@@ -64,7 +64,7 @@ def compact_line(full: dict, details_file: str = "bench_details.json") -> dict:
     line = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
                                      "scaling", "vs_baseline", "dtype", "data")}
     line["config"] = _pick(cfg, ("workload", "points_per_gpu", "vertices", "val_dim", "nr_filters", "scans_in_flight",
-                                 "clouds_per_scan_pool", "sharding", "checksum"))
+                                 "clouds_per_scan_pool", "sharding", "checksum", "prewarm"))
     if isinstance(line["config"].get("workload"), str):
         line["config"]["workload"] = line["config"]["workload"][:240]
     line["roofline"] = (_pick(full.get("roofline"), ("bound", "kernel", "avg_us", "achieved", "peak", "unit", "frac", "traffic"))
@@ -367,6 +367,10 @@ def main():
                     help="timed steps (scans).  The timed region has a fixed cost of ~0.3 ms (first graph launch, drain of the last scans in "
                          "flight, the final synchronize): it is 0.3 % of 2000 steps and 14 % of 20")
     ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--prewarm-ms", type=float, default=60.0,
+                    help="untimed replays for this long BEFORE the W warm-up steps, so that W + K short steps run at the clocks of a busy GPU "
+                         "(measured: after set-up and validation the chip needs tens of ms of load to reach them: K = 20 steps ran at "
+                         "94.9 us per scan behind W = 5, 88.6 behind W = 2000, 85.3 in a 2000-step run).  0 = off")
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS) + ["ops"],
                     help="ops: only the per-operator roofline table of tools/ops_roofline.py (every SURVEY 8(a) row outside the headline chain)")
     ap.add_argument("--ops-table", type=int, default=1, help="0 = leave the per-operator table out of the default line (rank 0, one GPU, workload C3)")
@@ -544,6 +548,14 @@ def main():
         barrier()
         errs = [cs.check() for cs in sets]  # ... compared with the eager results before anything is timed
         graph_err = {k: max(er[k] for er in errs) for k in errs[0]}
+    prewarm_steps = 0
+    if args.prewarm_ms > 0:  # part of the set-up, like capture and validation: brings the GPU to the clocks of sustained load
+        t_pre = time.perf_counter()
+        while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
+            for i in range(8 * in_flight):
+                sets[i % in_flight].launch(i // in_flight)
+            prewarm_steps += 8 * in_flight
+            torch.cuda.synchronize()
     for i in range(max(args.warmup, in_flight)):  # the W warm-up steps, directly in front of the timed region
         sets[i % in_flight].launch(i // in_flight)
     barrier()
@@ -815,7 +827,8 @@ def main():
             "config": {"workload": cfg["desc"] + f"; THROUGHPUT definition: {exec_desc}.  The latency of one scan alone is `latency`",
                        "points_per_gpu": n, "vertices": m, "val_dim": v, "nr_filters": f,
                        "sharding": f"{world} rank(s), independent clouds per GPU", "checksum": round(checksum, 3),
-                       "scans_in_flight": in_flight, "clouds_per_scan_pool": pool, "kd_regions": bool(args.regions and graph_mode),
+                       "scans_in_flight": in_flight, "clouds_per_scan_pool": pool,
+                       "prewarm": f"{prewarm_steps} untimed replays ({args.prewarm_ms:g} ms) before the W warm-up steps" if prewarm_steps else None, "kd_regions": bool(args.regions and graph_mode),
                        "row_bounds": [cs.cap.bounds[0] for cs in sets] if graph_mode else None,
                        "bounds_and_planes_calibrated_on": "2 clouds per scan that are not in its pool" if graph_mode else None,
                        "vertices_per_scan": m_all, "graph_vs_eager": graph_err},
