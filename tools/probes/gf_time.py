@@ -13,6 +13,11 @@ for v, f in ((64, 64), (128, 128), (96, 96), (128, 64), (64, 32)):
         y, _ = ConvIm2RowLattice.apply(lv, lat, fb, 1); y.backward(g)
     for _ in range(3): step()
     torch.cuda.synchronize()
+    import time
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < float(os.environ.get("LN_OPS_PREWARM_MS", "30")):  # the clocks of a busy GPU
+        for _ in range(4): step()
+        torch.cuda.synchronize()
     out = []
     for name in (b"k_grad_filter_mfma", b"k_reduce_slabs"):
         lib.ln_profile_begin(name, 64)
