@@ -258,12 +258,18 @@ int ln_row2im(const int* nbr, const float* rowified, int m, int filter_extent, i
  * out = values @ W^T for W = `filter` [F, V] under LN_CONV_TRANSPOSED_FILTER. */
 #define LN_CONV_FLIP_NEIGHBOURS 1
 #define LN_CONV_TRANSPOSED_FILTER 2
+/* ln_conv_forward_ws only: the first ln_conv_bank_workspace_bytes(...) bytes of `workspace` still hold what an earlier call with the
+ * SAME filter contents, sizes (m, filter_extent, val_dim, nr_filters) and flags left there (the filter split into bf16 parts in the
+ * layout of the kernel those sizes select): the split launch is skipped.  For hosts that convolve repeatedly with unchanged
+ * weights (inference; several clouds per optimizer step) and keep one workspace per layer. */
+#define LN_CONV_BANK_READY 4
 int ln_conv_forward(const int* nbr, const float* values_neigh, const float* filter, int m, int filter_extent, int val_dim,
                     int nr_filters, int flags, float* out, void* stream);
 /* ln_conv_forward with scratch.  When the lattice has few vertices (coarse levels of a U-Net: fewer vertex tiles than CUs) the
  * contraction is split over the filter slots and the partial sums are added by a second launch; that needs
  * ln_conv_forward_workspace_bytes(m, filter_extent, val_dim, nr_filters) bytes of 16-byte aligned scratch (256 when no
  * split applies).  Without enough scratch it runs unsplit, exactly as ln_conv_forward. */
+size_t ln_conv_bank_workspace_bytes(int m, int filter_extent, int val_dim, int nr_filters); /* the split-bank part (0: no split bank for these sizes) */
 size_t ln_conv_forward_workspace_bytes(int m, int filter_extent, int val_dim, int nr_filters);
 int ln_conv_forward_ws(const int* nbr, const float* values_neigh, const float* filter, int m, int filter_extent, int val_dim,
                        int nr_filters, int flags, float* out, void* workspace, size_t workspace_bytes, void* stream);

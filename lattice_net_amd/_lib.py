@@ -22,6 +22,7 @@ LN_BUILD_CANONICAL_ROWS = 8
 LN_NOT_VISITED = -2
 LN_CONV_FLIP_NEIGHBOURS = 1
 LN_CONV_TRANSPOSED_FILTER = 2
+LN_CONV_BANK_READY = 4
 LN_MAX_POS_DIM = 6
 LN_KEYS_RAW = 0
 LN_KEYS_LATTICE = 1
@@ -100,6 +101,7 @@ SIGNATURES = {
     "ln_row2im": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "ln_conv_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "ln_conv_forward_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "ln_conv_bank_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "ln_conv_forward_ws": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "ln_conv_grad_filter_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "ln_conv_grad_filter": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),

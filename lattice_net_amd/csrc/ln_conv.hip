@@ -1252,6 +1252,12 @@ static size_t ln_conv_bank_bytes(int m, int E, int val_dim, int nr_filters) {
     return (((size_t)E * val_dim * nr_filters * 3 * sizeof(unsigned short)) + 255) & ~size_t(255);
 }
 
+extern "C" size_t ln_conv_bank_workspace_bytes(int m, int filter_extent, int val_dim, int nr_filters) {
+    if (m <= 0 || nr_filters % 16 != 0) return 0;
+    const bool small_filter = filter_extent == 9 && (size_t)filter_extent * val_dim * nr_filters * 4 <= 64 * 1024 && val_dim <= 32;
+    return small_filter ? 0 : ln_conv_bank_bytes(m, filter_extent, val_dim, nr_filters);
+}
+
 extern "C" size_t ln_conv_forward_workspace_bytes(int m, int filter_extent, int val_dim, int nr_filters) {
     if (m <= 0 || nr_filters % 16 != 0) return 256;
     const int e_per = ln_conv_slots_per_split_rt(m, filter_extent, val_dim, nr_filters);
@@ -1275,6 +1281,10 @@ static int ln_conv_b3_subtiles(int m, int chunks) {
     if (forced == 1 || forced == 3) return forced;
     return (long long)ln_div_up(m, 192) * chunks >= LN_BWD_CUS * 3 / 4 ? 3 : 1;
 }
+
+// LN_CONV_BANK_READY of the call in progress: the workspace already holds the split bank of this filter (written by an earlier call
+// with the same sizes and flags), so the k_conv_split_bank launches are skipped
+static thread_local bool g_ln_bank_ready = false;
 
 template <int V, bool FLIP, bool WT>
 static bool ln_conv_launch_v(int nr_filters, const int* nbr, const float* values, const float* filter, int m, int E, float* out,
@@ -1308,7 +1318,7 @@ static bool ln_conv_launch_v(int nr_filters, const int* nbr, const float* values
     {                                                                                                                               \
         const int cnt = (nr_filters - f_off) / (32 * NTC);                                                                          \
         if (cnt > 0) {                                                                                                              \
-            LN_LAUNCH("k_conv_split_bank", (k_conv_split_bank32<V, NTC, WT>), dim3(ln_div_up(V * 32 * NTC, 256), E, cnt), block, 0, st, filter, \
+            if (!g_ln_bank_ready) LN_LAUNCH("k_conv_split_bank", (k_conv_split_bank32<V, NTC, WT>), dim3(ln_div_up(V * 32 * NTC, 256), E, cnt), block, 0, st, filter, \
                       nr_filters, f_off, bank + bank_off);                                                                          \
             LN_LAUNCH("k_conv_mfma", (k_conv_rows32sk_b3<V, NTC, RTT, FLIP>), dim3(ln_div_up(m, 32 * RTT), cnt, nsplit),            \
                       dim3(128 * RTT), 0, st, nbr, values, reinterpret_cast<const u32x4*>(bank + bank_off), m, E, dst, nr_filters, f_off, e_per); \
@@ -1320,7 +1330,7 @@ static bool ln_conv_launch_v(int nr_filters, const int* nbr, const float* values
     {                                                                                                                               \
         const int cnt = (nr_filters - f_off) / (32 * NTC);                                                                          \
         if (cnt > 0) {                                                                                                              \
-            LN_LAUNCH("k_conv_split_bank", (k_conv_split_bank32<V, NTC, WT>), dim3(ln_div_up(V * 32 * NTC, 256), E, cnt), block, 0, st, filter, \
+            if (!g_ln_bank_ready) LN_LAUNCH("k_conv_split_bank", (k_conv_split_bank32<V, NTC, WT>), dim3(ln_div_up(V * 32 * NTC, 256), E, cnt), block, 0, st, filter, \
                       nr_filters, f_off, bank + bank_off);                                                                          \
             LN_LAUNCH("k_conv_mfma", (k_conv_rows32_b3<V, NTWW, CHH, RTT, FLIP>), dim3(ln_div_up(m, 32 * RTT), cnt, nsplit),        \
                       dim3(64 * RTT * CHH), 0, st, nbr, values, reinterpret_cast<const u32x4*>(bank + bank_off), m, E, dst, nr_filters, f_off, e_per); \
@@ -1353,7 +1363,7 @@ static bool ln_conv_launch_v(int nr_filters, const int* nbr, const float* values
             bool done_b3 = false;                                                                                                   \
             if constexpr (V % 32 == 0 && V * 16 * NTC * 6 <= 64 * 1024 && (V < 256 || NTC == 1)) { /* 256 x 32 columns spills */      \
                 if (b3) {                                                                                                           \
-                    LN_LAUNCH("k_conv_split_bank", (k_conv_split_bank<V, NTC, WT>), dim3(ln_div_up(V * 16 * NTC, 256), E, cnt), block, 0, st, filter, \
+                    if (!g_ln_bank_ready) LN_LAUNCH("k_conv_split_bank", (k_conv_split_bank<V, NTC, WT>), dim3(ln_div_up(V * 16 * NTC, 256), E, cnt), block, 0, st, filter, \
                               nr_filters, f_off, bank + bank_off);                                                                  \
                     if (ln_conv_b3_subtiles<V>(m, cnt * nsplit) == 3) {                                                             \
                         if constexpr (LN_CONV_B3_WAVES(V) == 3)                                                                     \
@@ -1626,11 +1636,16 @@ extern "C" int ln_conv_forward_ws(const int* nbr, const float* values_neigh, con
                                   int nr_filters, int flags, float* out, void* workspace, size_t workspace_bytes, void* stream) {
     LN_REQUIRE(m >= 0 && filter_extent >= 1 && val_dim >= 1 && nr_filters >= 1, LN_ERR_ARG, "ln_conv_forward: bad sizes");
     LN_REQUIRE(m == 0 || (nbr && values_neigh && filter && out), LN_ERR_ARG, "ln_conv_forward: null buffer");
-    LN_REQUIRE((flags & ~3) == 0, LN_ERR_ARG, "ln_conv_forward: unknown flags %d", flags);
+    LN_REQUIRE((flags & ~7) == 0, LN_ERR_ARG, "ln_conv_forward: unknown flags %d", flags);
     if (m == 0) return LN_OK;
     hipStream_t st = (hipStream_t)stream;
     void* ws = workspace;
     const size_t wb = workspace_bytes;
+    struct BankReady {  // (scoped: the flag never outlives the call)
+        explicit BankReady(bool on) { g_ln_bank_ready = on; }
+        ~BankReady() { g_ln_bank_ready = false; }
+    } bank_ready((flags & LN_CONV_BANK_READY) != 0 && workspace != nullptr);
+    flags &= 3;
     switch (flags) {
         case 0: return ln_conv_dispatch<false, false>(nbr, values_neigh, filter, m, filter_extent, val_dim, nr_filters, out, ws, wb, st);
         case LN_CONV_FLIP_NEIGHBOURS: return ln_conv_dispatch<true, false>(nbr, values_neigh, filter, m, filter_extent, val_dim, nr_filters, out, ws, wb, st);

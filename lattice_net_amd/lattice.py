@@ -115,6 +115,9 @@ def _require_cuda(t: torch.Tensor, name: str):
         raise ValueError(f"{name} must live on a ROCm/HIP device (got {t.device}); the lattice backend has no CPU path")
 
 
+_BANK_CACHE = os.environ.get("LATTICE_BANK_CACHE", "1") != "0"  # keep the split bank of an unchanged filter (convolve_im2row_standalone)
+
+
 def _pad4(words: int) -> int:
     return (int(words) + 3) & ~3
 
@@ -929,10 +932,29 @@ class Lattice:
         else:
             # few vertices (coarse levels): the kernel splits the contraction over the filter slots and needs room for the partials
             wsb = int(lib.ln_conv_forward_workspace_bytes(m, filter_extent, v, nr_filters))
-            ws = torch.empty((wsb,), dtype=torch.uint8, device=self._dev()) if wsb > 256 else None
+            # The split bank of an unchanged filter is kept with the filter tensor (same storage, same version, same sizes -> same
+            # kernel and bank layout): repeated convolutions with fixed weights (inference: no gradient wanted for the filter) skip
+            # the split launch.  Only where the workspace is the bank alone (no slot-split partials, which concurrent streams would
+            # share) and never inside a stream capture (a replayed graph must re-split the weights the optimizer changed in between).
+            ws = None
+            key = None
+            bank_b = int(lib.ln_conv_bank_workspace_bytes(m, filter_extent, v, nr_filters))
+            if bank_b > 0 and wsb == bank_b + 256 and _BANK_CACHE and not (torch.is_grad_enabled() and filter_bank.requires_grad) and \
+                    not torch.cuda.is_current_stream_capturing():
+                key = (filter_bank.data_ptr(), filter_bank._version, m, filter_extent, v, nr_filters, flags)
+                hit = getattr(filter_bank, "_ln_split_bank", None)
+                if hit is not None and hit[0] == key:
+                    ws, flags = hit[1], flags | _lib.LN_CONV_BANK_READY
+            if ws is None and wsb > 256:
+                ws = torch.empty((wsb,), dtype=torch.uint8, device=self._dev())
             _lib.check(lib.ln_conv_forward_ws(_lib.ptr(nbr), _lib.ptr(vals), _lib.ptr(filter_bank), m, filter_extent, v, nr_filters, flags,
                                               _lib.ptr(out), _lib.ptr(ws), 0 if ws is None else ws.numel(), self._stream()),
                        "ln_conv_forward")
+            if key is not None and not (flags & _lib.LN_CONV_BANK_READY):
+                try:
+                    filter_bank._ln_split_bank = (key, ws)
+                except AttributeError:
+                    pass
         conv = Lattice._clone_of(self)
         conv.m_name = "convolved_lattice"
         conv.m_hash_table.set_values(out)

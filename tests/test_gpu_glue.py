@@ -152,3 +152,44 @@ def test_fused_nll_matches_the_gather_formulation(n, c, ignore):
             L.FUSED_NLL = True
     assert abs(out[True][0] - out[False][0]) <= 2e-6 * max(abs(out[False][0]), 1e-30) + 1e-12
     np.testing.assert_allclose(out[True][1], out[False][1], rtol=0, atol=2e-6 * max(float(np.abs(out[False][1]).max()), 1e-30))
+
+
+def test_split_bank_of_an_unchanged_filter_is_reused_and_invalidated_by_in_place_changes():
+    import ctypes as C
+    import lattice_net_amd as L
+    from lattice_net_amd.synthetic import lidar_cloud
+    lib = L.load_library()
+    pos = torch.from_numpy(lidar_cloud(60000, 2)).to(dev())
+    lat = L.Lattice(sigmas=[0.9] * 3, capacity=100000, device=dev())
+    lat.begin_splat()
+    lat.just_create_verts(pos, False)
+    m = lat.nr_lattice_vertices()
+    vals = torch.randn((m, 128), device=dev())
+    bank = torch.randn((9 * 128, 128), device=dev()) * 0.05
+    lat.set_values(vals)
+
+    def conv_and_count():
+        assert lib.ln_profile_begin(b"k_conv_split_bank", 16) == 0
+        y = lat.convolve_im2row_standalone(bank, 1, lat, False).values().clone()
+        torch.cuda.synchronize()
+        ms, cnt = C.c_double(0), C.c_int(0)
+        assert lib.ln_profile_end(C.byref(ms), C.byref(cnt)) == 0
+        return y, cnt.value
+
+    y0, n0 = conv_and_count()
+    y1, n1 = conv_and_count()
+    assert n0 >= 1 and n1 == 0 and torch.equal(y0, y1)             # second call: no split launch, same result
+    bank.mul_(2.0)                                                   # in place: the version counter moves, the bank is split again
+    y2, n2 = conv_and_count()
+    assert n2 >= 1
+    torch.testing.assert_close(y2, 2.0 * y0, rtol=1e-5, atol=1e-5 * float(y0.abs().max()))
+    wanted = bank.clone().requires_grad_(True)                       # a filter that wants a gradient is never served from the cache
+    lat.set_values(vals)
+    with torch.enable_grad():
+        assert lib.ln_profile_begin(b"k_conv_split_bank", 16) == 0
+        for _ in range(2):
+            lat.convolve_im2row_standalone(wanted, 1, lat, False)
+        torch.cuda.synchronize()
+        ms, cnt = C.c_double(0), C.c_int(0)
+        assert lib.ln_profile_end(C.byref(ms), C.byref(cnt)) == 0
+    assert cnt.value >= 2
