@@ -481,11 +481,12 @@ def main():
                 W.grad = None
                 lv, wrap, idx, w = L.SplatLattice.apply(self.lat, c["pos"], c["vals"])  # clear + hash build + accumulate
                 m = self.lat.nr_lattice_vertices()                                      # eager: the path's one host readback
-                lv = lv[:m].requires_grad_(True)
-                if half:  # fp16 feature path: fp16 point features, lattice values and filter bank; fp32 accumulation everywhere
-                    cv, cwrap = L.ConvIm2RowLattice.apply(lv.half(), self.lat, W.half(), 1)
+                if half:  # fp16 feature path: fp16 point features, lattice values and filter bank (rounded per step from the fp32
+                    # master copy inside the operator, its gradient returned in fp32); fp32 accumulation everywhere
+                    lv = lv[:m].half().requires_grad_(True)
                 else:
-                    cv, cwrap = L.ConvIm2RowLattice.apply(lv, self.lat, W, 1)          # neighbour list + gather-GEMM
+                    lv = lv[:m].requires_grad_(True)
+                cv, cwrap = L.ConvIm2RowLattice.apply(lv, self.lat, W, 1)              # neighbour list + gather-GEMM
                 out = L.SliceLattice.apply(cv, cwrap.lattice, c["pos"], idx, w)        # slice
                 out.backward(c["G"])                                                    # slice bwd, conv bwd (values + filter)
                 c["state"].update(m=m, out=out, gv=lv.grad, gw=W.grad, idx=idx)
@@ -695,11 +696,8 @@ def main():
             lv, wrap, idx, w = L.SplatLattice.apply(cs0.lat, c0["pos"], c0["vals"])
             ev[1].record()
             mm = cs0.lat.nr_lattice_vertices()
-            lv = lv[:mm].requires_grad_(True)
-            if half:
-                cv, cwrap = L.ConvIm2RowLattice.apply(lv.half(), cs0.lat, W.half(), 1)
-            else:
-                cv, cwrap = L.ConvIm2RowLattice.apply(lv, cs0.lat, W, 1)
+            lv = (lv[:mm].half() if half else lv[:mm]).requires_grad_(True)
+            cv, cwrap = L.ConvIm2RowLattice.apply(lv, cs0.lat, W, 1)
             ev[2].record()
             out = L.SliceLattice.apply(cv, cwrap.lattice, c0["pos"], idx, w)
             ev[3].record()

@@ -961,7 +961,7 @@ class Lattice:
         return conv
 
     def convolve_im2row_backward(self, grad_out: torch.Tensor, filter_bank: torch.Tensor, dilation: int,
-                                 query: Optional["Lattice"], neighbours: Optional["Lattice"]):
+                                 query: Optional["Lattice"], neighbours: Optional["Lattice"], filter_grad_fp32: bool = False):
         """Both gradients of `query.convolve_im2row_standalone(filter_bank, dilation, neighbours, False)` in one call:
         (grad wrt the neighbour values, grad wrt the filter bank), both as gather-GEMMs on the current stream.
         `self` is unused beyond device bookkeeping; `query` / `neighbours` default to self."""
@@ -1003,7 +1003,7 @@ class Lattice:
             flags = _lib.LN_CONV_FLIP_NEIGHBOURS | _lib.LN_CONV_TRANSPOSED_FILTER
             _lib.check(lib.ln_conv_forward_f16(_lib.ptr(nbr_n), _lib.ptr(grad_out), _lib.ptr(filter_bank), mn, E, f, v, flags, _lib.ptr(gvals),
                                                main), "ln_conv_forward_f16")
-            return gvals, gf.to(torch.float16)
+            return gvals, (gf if filter_grad_fp32 else gf.to(torch.float16))  # (fp32 master weights: the kernel's own fp32 sums)
         # (Measured on MI355X: running the filter gradient on a second stream made the step SLOWER, 0.254 -> 0.286 ms:
         # both kernels already fill the chip and the event hand-offs cost more than the overlap.  What does pay is
         # putting the slab sum of the filter gradient into the value-gradient launch: ln_conv_backward.)

@@ -138,6 +138,11 @@ class ConvIm2RowLattice(Function):  # lattice_funcs.py:250-320
     @staticmethod
     def forward(ctx, lattice_values, lattice, filter_bank, dilation):
         lattice.set_values(lattice_values)
+        # fp16 features with fp32 master weights (the usual mixed-precision arrangement): the bank is rounded to fp16 here, per call,
+        # and its gradient comes back in fp32 straight from the filter-gradient kernel's fp32 sums — no fp32 -> fp16 -> fp32 round trip
+        ctx.mixed = lattice_values.dtype == torch.float16 and filter_bank.dtype == torch.float32
+        if ctx.mixed:
+            filter_bank = filter_bank.detach().half()
         convolved_lattice = lattice.convolve_im2row_standalone(filter_bank, dilation, lattice, False)
         ctx.save_for_backward(filter_bank, lattice_values)
         ctx.lattice = lattice
@@ -156,7 +161,8 @@ class ConvIm2RowLattice(Function):  # lattice_funcs.py:250-320
         lattice.set_values(lattice_values)
         # funcs:298-313: grad_filter = im2row^T @ grad, grad_values = conv(grad, flipped neighbours, re-laid-out bank);
         # both run as gather-GEMMs
-        grad_values, grad_filter = lattice.convolve_im2row_backward(grad_lattice_values, filter_bank, dilation, lattice, lattice)
+        grad_values, grad_filter = lattice.convolve_im2row_backward(grad_lattice_values, filter_bank, dilation, lattice, lattice,
+                                                                    filter_grad_fp32=ctx.mixed)
         ctx.lattice = 0
         return grad_values, None, grad_filter, None
 

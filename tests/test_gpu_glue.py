@@ -193,3 +193,29 @@ def test_split_bank_of_an_unchanged_filter_is_reused_and_invalidated_by_in_place
         ms, cnt = C.c_double(0), C.c_int(0)
         assert lib.ln_profile_end(C.byref(ms), C.byref(cnt)) == 0
     assert cnt.value >= 2
+
+
+def test_fp16_features_with_fp32_master_weights_return_the_filter_gradient_in_fp32():
+    import lattice_net_amd as L
+    from lattice_net_amd.synthetic import lidar_cloud
+    pos = torch.from_numpy(lidar_cloud(30000, 5)).to(dev())
+    lat = L.Lattice(sigmas=[0.9] * 3, capacity=100000, device=dev())
+    lat.begin_splat()
+    lat.just_create_verts(pos, False)
+    m = lat.nr_lattice_vertices()
+    torch.manual_seed(2)
+    vals = torch.randn((m, 64), device=dev()).half()
+    bank = torch.randn((9 * 64, 64), device=dev()) * 0.05
+    g = torch.randn((m, 64), device=dev()).half()
+    res = {}
+    for mixed in (True, False):
+        lv = vals.clone().requires_grad_(True)
+        w = bank.clone().requires_grad_(True)
+        y, _ = L.ConvIm2RowLattice.apply(lv, lat, w if mixed else w.half(), 1)
+        y.backward(g)
+        res[mixed] = (y.detach(), lv.grad, w.grad)
+    assert res[True][2].dtype == torch.float32 and res[True][1].dtype == torch.float16
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    a, b = res[True][2], res[False][2]                             # fp32 sums vs the same sums rounded to fp16 and back
+    assert float((a - b).abs().max()) <= 1e-3 * float(a.abs().max())
+    assert float((a.half().float() - b).abs().max()) == 0.0
