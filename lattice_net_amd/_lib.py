@@ -59,6 +59,7 @@ class LnCsr(C.Structure):
         ("seg_count", C.c_void_p),
         ("seg_region", C.c_longlong),
         ("planes", C.c_void_p),
+        ("dense", C.c_int),
     ]
 
 

@@ -251,7 +251,9 @@ struct LnReduceArgs {
 // batch's ids with the current gathers (6 trips instead of 10): 18.4 us; all 16 ids + 8 gathers in flight (4 trips, 128
 // VGPRs): 19.3 us; plain stores instead of the hot-vertex atomics: no change; 44 MB instead of 79 MB of L2 misses (kd
 // regions, LnCsr.planes): no change; 71 instead of 104 SGPRs (8 instead of 6 workgroups per CU admitted): no change.
-template <int VEC, bool HALF>
+// WG: also combine runs across the wave boundaries of the workgroup (dense clouds: LnCsr.dense; two barriers per block and ten more
+// registers, which cost the sparse C3 scan 10 % — hence a variant of its own, chosen by the host)
+template <int VEC, bool HALF, bool WG>
 __device__ __forceinline__ void ln_reduce_chunk(const LnSegOfThread& so, const LnReduceArgs& a) {
     const int* __restrict__ csr_tok = a.csr_tok;
     const int4* __restrict__ seg_desc = a.seg_desc;
@@ -351,7 +353,41 @@ __device__ __forceinline__ void ln_reduce_chunk(const LnSegOfThread& so, const L
         }
         const int prev_grp = __shfl_up(grp, lanes_per_seg, 64);
         const bool head = (grp_in_wave == 0) || (prev_grp != grp);
-        if (cok && head) {
+        // ... and across the wave boundaries of the workgroup: a run that reaches the end of its wave takes in the FIRST run of the
+        // next wave(s) when it is the same group.  On dense clouds (C5: 27 tokens per vertex) most rows have several segments and a
+        // run cut by a wave boundary costs lanes x VEC float atomics per piece: plain stores instead of the atomics took the C5 splat
+        // from 104 to 71 us (tools/probes/reduce_locality_probe.py), three of four boundaries are inside a workgroup.
+        bool absorbed = false;
+        if constexpr (WG) {
+            __shared__ float s_first_acc[4][64 * VEC];  // the first run of every wave: [lane in segment][VEC]
+            __shared__ int s_first_key[4], s_first_end[4], s_first_whole[4], s_last_key[4];
+            const int wave = threadIdx.x >> 6;
+            const int key = (active && row >= 0) ? grp : -1;
+            const int first_key = __shfl(key, 0, 64);
+            const int last_key = __shfl(key, (groups_per_wave - 1) * lanes_per_seg, 64);
+            __syncthreads();  // (the arrays may still be read from the previous block of segments / channel chunk)
+            if (grp_in_wave == 0) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) s_first_acc[wave][lc * VEC + k] = cok ? acc[k] : 0.f;
+                if (lc == 0) {
+                    s_first_key[wave] = key;
+                    s_first_end[wave] = run_end;
+                    s_first_whole[wave] = (first_key >= 0 && first_key == last_key) ? 1 : 0;
+                    s_last_key[wave] = last_key;
+                }
+            }
+            __syncthreads();
+            absorbed = head && grp_in_wave == 0 && wave > 0 && key >= 0 && s_last_key[wave - 1] == key;
+            if (head && key >= 0 && key == last_key && !absorbed) {
+                for (int w2 = wave + 1; w2 < 4 && s_first_key[w2] == key; ++w2) {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) acc[k] += s_first_acc[w2][lc * VEC + k];
+                    run_end = max(run_end, s_first_end[w2]);
+                    if (!s_first_whole[w2]) break;
+                }
+            }
+        }
+        if (cok && head && !absorbed) {
             float* d = dst + (size_t)row * V + c * VEC;
             if ((beg == rbeg && run_end == rend) || a.dbg_plain) {  // this run is the whole group: no other writer
                 if constexpr (VEC == 8) {
@@ -371,24 +407,24 @@ __device__ __forceinline__ void ln_reduce_chunk(const LnSegOfThread& so, const L
 }
 
 // body of the segment reduce for workgroup `block_x` of `nblocks`
-template <int VEC, bool HALF>
+template <int VEC, bool HALF, bool WG>
 __device__ __forceinline__ void ln_reduce_body(int block_x, int nblocks, const LnReduceArgs& a) {
     for (LnSegWalk wk(block_x, nblocks, a.lanes_per_seg, a.seg_count, a.seg_region); wk.more(); wk.next())
-        ln_reduce_chunk<VEC, HALF>(wk.here(), a);
+        ln_reduce_chunk<VEC, HALF, WG>(wk.here(), a);
 }
 
-template <int VEC, bool HALF>
-__global__ void __launch_bounds__(256) k_csr_reduce_segments(LnReduceArgs a) { ln_reduce_body<VEC, HALF>(blockIdx.x, gridDim.x, a); }
+template <int VEC, bool HALF, bool WG>
+__global__ void __launch_bounds__(256) k_csr_reduce_segments(LnReduceArgs a) { ln_reduce_body<VEC, HALF, WG>(blockIdx.x, gridDim.x, a); }
 
 // Horizontal fusion of the two launches that follow a splat build and do not depend on each other: workgroups
 // [0, reduce_blocks) accumulate the point features onto the vertices (segment reduce), the rest run the same-level
 // neighbour traversal.  One launch instead of two, and the traversal's short, latency-bound workgroups fill the CUs
 // the reduce's tail leaves idle.
-template <int VEC, int D, bool HALF>
+template <int VEC, int D, bool HALF, bool WG>
 __global__ void __launch_bounds__(256)
     k_reduce_and_neighbours(LnReduceArgs a, int reduce_blocks, LnTable t, int query_rows_upper, int* __restrict__ nbr) {
     if ((int)blockIdx.x < reduce_blocks) {
-        ln_reduce_body<VEC, HALF>(blockIdx.x, reduce_blocks, a);
+        ln_reduce_body<VEC, HALF, WG>(blockIdx.x, reduce_blocks, a);
     } else {
         const long long g = (long long)(blockIdx.x - reduce_blocks) * 256 + threadIdx.x;
         ln_neighbours_body<D>(g, t, query_rows_upper, t, 1.0f, 1, 0, nbr);
@@ -424,19 +460,23 @@ static int ln_csr_reduce_rows_impl(const char* who, const LnCsr* csr, const int*
     if (max_segments == 0) return LN_OK;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(ln_seg_grid(max_segments, a.lanes_per_seg)), block(256);
-    if (half) {
-        if (vec == 8)
-            LN_LAUNCH("k_csr_reduce_segments", (k_csr_reduce_segments<8, true>), grid, block, 0, st, a);
-        else if (vec == 4)
-            LN_LAUNCH("k_csr_reduce_segments", (k_csr_reduce_segments<4, true>), grid, block, 0, st, a);
-        else
-            LN_LAUNCH("k_csr_reduce_segments", (k_csr_reduce_segments<1, true>), grid, block, 0, st, a);
-    } else {
-        if (vec == 4)
-            LN_LAUNCH("k_csr_reduce_segments", (k_csr_reduce_segments<4, false>), grid, block, 0, st, a);
-        else
-            LN_LAUNCH("k_csr_reduce_segments", (k_csr_reduce_segments<1, false>), grid, block, 0, st, a);
+    const bool wg = csr->dense != 0 && vec >= 4;  // dense cloud: combine across the waves of a workgroup
+#define LN_REDUCE_LAUNCH(VV, HH)                                                                                                     \
+    {                                                                                                                                \
+        if (wg)                                                                                                                      \
+            LN_LAUNCH("k_csr_reduce_segments", (k_csr_reduce_segments<VV, HH, (VV >= 4)>), grid, block, 0, st, a);                   \
+        else                                                                                                                         \
+            LN_LAUNCH("k_csr_reduce_segments", (k_csr_reduce_segments<VV, HH, false>), grid, block, 0, st, a);                       \
     }
+    if (half) {
+        if (vec == 8) LN_REDUCE_LAUNCH(8, true)
+        else if (vec == 4) LN_REDUCE_LAUNCH(4, true)
+        else LN_REDUCE_LAUNCH(1, true)
+    } else {
+        if (vec == 4) LN_REDUCE_LAUNCH(4, false)
+        else LN_REDUCE_LAUNCH(1, false)
+    }
+#undef LN_REDUCE_LAUNCH
     return ln_check_launch(who);
 }
 
@@ -469,25 +509,26 @@ static int ln_splat_tail_impl(const char* who, const LnCsr* csr, const int* grp_
     const int reduce_blocks = ln_seg_grid(max_segments, a.lanes_per_seg);  // a multiple of LN_XCD_GROUPS
     const int nbr_blocks = ln_div_up((long long)query_rows_upper * (2 * (d + 1) + 1), 256);
     const dim3 grid(reduce_blocks + nbr_blocks), block(256);
-#define LN_FUSED_CASE(DD)                                                                                                              \
-    case DD:                                                                                                                           \
-        if (half && vec == 8)                                                                                                          \
-            LN_LAUNCH("k_reduce_and_neighbours", (k_reduce_and_neighbours<8, DD, true>), grid, block, 0, st, a, reduce_blocks, *table,  \
-                      query_rows_upper, nbr);                                                                                          \
-        else if (half && vec == 4)                                                                                                     \
-            LN_LAUNCH("k_reduce_and_neighbours", (k_reduce_and_neighbours<4, DD, true>), grid, block, 0, st, a, reduce_blocks, *table,  \
-                      query_rows_upper, nbr);                                                                                          \
-        else if (half)                                                                                                                 \
-            LN_LAUNCH("k_reduce_and_neighbours", (k_reduce_and_neighbours<1, DD, true>), grid, block, 0, st, a, reduce_blocks, *table,  \
-                      query_rows_upper, nbr);                                                                                          \
-        else if (vec == 4)                                                                                                             \
-            LN_LAUNCH("k_reduce_and_neighbours", (k_reduce_and_neighbours<4, DD, false>), grid, block, 0, st, a, reduce_blocks, *table, \
-                      query_rows_upper, nbr);                                                                                          \
-        else                                                                                                                           \
-            LN_LAUNCH("k_reduce_and_neighbours", (k_reduce_and_neighbours<1, DD, false>), grid, block, 0, st, a, reduce_blocks, *table, \
-                      query_rows_upper, nbr);                                                                                          \
+#define LN_FUSED_LAUNCH(VV, DD, HH)                                                                                                  \
+    {                                                                                                                                \
+        if (wg)                                                                                                                      \
+            LN_LAUNCH("k_reduce_and_neighbours", (k_reduce_and_neighbours<VV, DD, HH, (VV >= 4)>), grid, block, 0, st, a, reduce_blocks, \
+                      *table, query_rows_upper, nbr);                                                                                \
+        else                                                                                                                         \
+            LN_LAUNCH("k_reduce_and_neighbours", (k_reduce_and_neighbours<VV, DD, HH, false>), grid, block, 0, st, a, reduce_blocks,  \
+                      *table, query_rows_upper, nbr);                                                                                \
+    }
+#define LN_FUSED_CASE(DD)                                                                                                            \
+    case DD:                                                                                                                         \
+        if (half && vec == 8) LN_FUSED_LAUNCH(8, DD, true)                                                                           \
+        else if (half && vec == 4) LN_FUSED_LAUNCH(4, DD, true)                                                                      \
+        else if (half) LN_FUSED_LAUNCH(1, DD, true)                                                                                  \
+        else if (vec == 4) LN_FUSED_LAUNCH(4, DD, false)                                                                             \
+        else LN_FUSED_LAUNCH(1, DD, false)                                                                                           \
         break;
+    const bool wg = csr->dense != 0 && vec >= 4;
     switch (d) { LN_FUSED_CASE(1) LN_FUSED_CASE(2) LN_FUSED_CASE(3) LN_FUSED_CASE(4) LN_FUSED_CASE(5) LN_FUSED_CASE(6) }
+#undef LN_FUSED_LAUNCH
 #undef LN_FUSED_CASE
     return ln_check_launch(who);
 }

@@ -115,6 +115,7 @@ def _require_cuda(t: torch.Tensor, name: str):
         raise ValueError(f"{name} must live on a ROCm/HIP device (got {t.device}); the lattice backend has no CPU path")
 
 
+_DENSE_TOKENS_PER_VERTEX = float(os.environ.get("LATTICE_DENSE_TOKENS_PER_VERTEX", "16"))  # LnCsr.dense from here on (0: always, 1e9: never)
 _BANK_CACHE = os.environ.get("LATTICE_BANK_CACHE", "1") != "0"  # keep the split bank of an unchanged filter (convolve_im2row_standalone)
 
 
@@ -671,10 +672,18 @@ class Lattice:
         st.csr_cache[key] = entry
         return entry
 
+    def _dense_hint(self, tokens: int) -> int:
+        """LnCsr.dense: 1 when the cloud puts about 16 or more tokens on a vertex (judged by the row bound in static-rows mode, else
+        by the vertex count of the last build this table reported — a fresh table answers 0; the hint only selects a kernel variant)."""
+        ht = self.m_hash_table
+        m = ht._static_rows if ht._static_rows is not None else ht.m_nr_filled
+        return 1 if (m is not None and m > 0 and tokens >= _DENSE_TOKENS_PER_VERTEX * m) else 0
+
     def _scatter_rows(self, src: torch.Tensor, idx: torch.Tensor, w: torch.Tensor, dst: torch.Tensor, val_dim: int, src_div: int,
                       src_stride: int):
         """dst[row] += sum of the row's contributions (segment-balanced reduce over the CSR adjacency); dst pre-zeroed."""
         _, csr, max_seg, grp_row, _ = self._csr(idx)
+        csr.dense = self._dense_hint(idx.numel())
         lib = _lib.load()
         fn, what = (lib.ln_csr_reduce_rows_f16, "ln_csr_reduce_rows_f16") if src.dtype == torch.float16 else \
             (lib.ln_csr_reduce_rows, "ln_csr_reduce_rows")
@@ -833,6 +842,7 @@ class Lattice:
         t = ht.c_table()
         fn, what = (lib.ln_splat_accumulate_and_neighbours_f16, "ln_splat_accumulate_and_neighbours_f16") if values.dtype == torch.float16 \
             else (lib.ln_splat_accumulate_and_neighbours, "ln_splat_accumulate_and_neighbours")
+        csr.dense = self._dense_hint(tokens)  # (issued behind the build, before its vertex count is known: the previous build's)
         _lib.check(fn(C.byref(csr), _lib.ptr(grp_row), max_seg, _lib.ptr(values), _lib.ptr(w), val_dim, src_div, val_dim, _lib.ptr(dst),
                       C.byref(t), rows_upper, _lib.ptr(nbr), self._stream()), what)
         st.nbr_cache[("prefetch", st.uid, st.version, self.m_lvl)] = (nbr,)

@@ -161,8 +161,8 @@ class ConvIm2RowLattice(Function):  # lattice_funcs.py:250-320
         lattice.set_values(lattice_values)
         # funcs:298-313: grad_filter = im2row^T @ grad, grad_values = conv(grad, flipped neighbours, re-laid-out bank);
         # both run as gather-GEMMs
-        grad_values, grad_filter = lattice.convolve_im2row_backward(grad_lattice_values, filter_bank, dilation, lattice, lattice,
-                                                                    filter_grad_fp32=ctx.mixed)
+        extra = {"filter_grad_fp32": True} if ctx.mixed else {}  # (only this backend knows the argument; other lattices never see it)
+        grad_values, grad_filter = lattice.convolve_im2row_backward(grad_lattice_values, filter_bank, dilation, lattice, lattice, **extra)
         ctx.lattice = 0
         return grad_values, None, grad_filter, None
 

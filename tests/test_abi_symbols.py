@@ -34,7 +34,7 @@ def test_struct_layout_matches_header():
     assert C.sizeof(_lib.LnTable) == 88
     assert [f[0] for f in _lib.LnTable._fields_] == ["capacity", "pos_dim", "slot_keys", "slot_tok", "slot_cnt", "entries", "keys",
                                                      "nr_filled", "status", "host_counters", "host_seq", "key_format", "row_limit"]
-    assert C.sizeof(_lib.LnCsr) == 48  # 4 pointers + seg_region + planes
+    assert C.sizeof(_lib.LnCsr) == 56  # 4 pointers + seg_region + planes + the dense hint (int, padded)
 
 
 def test_version_and_kernel_names():

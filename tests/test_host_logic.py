@@ -138,7 +138,7 @@ def test_static_rows_and_region_planes_argument_checks():
         lat.set_region_planes([0] * 7)               # needs a built table
     with pytest.raises(LatticeNetHipError):
         lat.static_build_report()                    # no build has run
-    assert [f[0] for f in _lib.LnCsr._fields_] == ["grp_start", "csr_tok", "seg_desc", "seg_count", "seg_region", "planes"]
+    assert [f[0] for f in _lib.LnCsr._fields_] == ["grp_start", "csr_tok", "seg_desc", "seg_count", "seg_region", "planes", "dense"]
     assert _lib.LN_XCD_GROUPS == 8
 
 
