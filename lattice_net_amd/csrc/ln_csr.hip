@@ -564,7 +564,10 @@ __device__ __forceinline__ float ln_ordered_to_float(unsigned int o) {
 // one lane per (segment, channel): running max over <=16 tokens; value and token are packed into 64 bits
 // (ordered value in the high word, ~token in the low word -> ties go to the smallest token) so that the
 // segments of a hot vertex combine with one 64-bit atomicMax.
-template <int VEC>
+// COMB (lanes per segment a power of two <= 64, so that no segment straddles a wave): the segments of one row that sit side by side in a
+// wave, and across the waves of the workgroup, are combined before anything is written — as in ln_reduce_chunk.  The 64-bit atomics were
+// half of the kernel on the C3 cloud (43 -> 20 us with plain stores: 69 % of its tokens sit on vertices with several segments).
+template <int VEC, bool COMB>
 __global__ void __launch_bounds__(256)
     k_csr_segment_max(const int* __restrict__ csr_tok, const int4* __restrict__ seg_desc, const int* __restrict__ seg_count, long long seg_region,
                       const int* __restrict__ grp_row, const float* __restrict__ src, int channels,
@@ -574,19 +577,26 @@ __global__ void __launch_bounds__(256)
   for (LnSegWalk wk(blockIdx.x, gridDim.x, lanes, seg_count, seg_region); wk.more(); wk.next()) {
     const LnSegOfThread so = wk.here();
     const long long sid = so.sid;
-    const int c = so.lane_in_seg * VEC;
-    if (!so.active) continue;
-    const int4 sd = seg_desc[sid];
-    const int grp = sd.x;
-    const int row = ((seg_count[LN_XCD_GROUPS + 1] & 1) || !grp_row) ? grp : grp_row[grp];
-    if (row < 0) continue;
-    const int beg = sd.y;
-    const int end = beg + min(LN_SEG, sd.z);
-    const bool only_segment = sd.w == 0 && sd.z <= LN_SEG;
+    const int lc = so.lane_in_seg;
+    const int c = lc * VEC;
+    int row = -1, beg = 0, end = 0, rbeg = 0, rend = 0;
+    if (so.active) {
+        const int4 sd = seg_desc[sid];
+        const int grp = sd.x;
+        row = ((seg_count[LN_XCD_GROUPS + 1] & 1) || !grp_row) ? grp : grp_row[grp];
+        beg = sd.y;
+        end = beg + min(LN_SEG, sd.z);
+        rbeg = beg - sd.w;
+        rend = beg + sd.z;
+    }
+    if constexpr (!COMB) {
+        if (row < 0) continue;
+    }
     unsigned long long best[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) best[k] = 0ull;
     constexpr int U = 4;
+    if (row >= 0)
     for (int e0 = beg; e0 < end; e0 += U) {
         int tk[U];
 #pragma unroll
@@ -613,19 +623,77 @@ __global__ void __launch_bounds__(256)
                 }
             }
     }
+    int run_end = end;
+    bool writes = row >= 0;  // this lane group writes its run
+    if constexpr (COMB) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int groups_per_wave = 64 / lanes, g = lane / lanes;
+        // segmented suffix maximum over the lane groups of the wave (the segments of a row are neighbours)
+        for (int off = 1; off < groups_per_wave; off <<= 1) {
+            const int delta = off * lanes;
+            const int o_row = __shfl_down(row, delta, 64);
+            const int o_end = __shfl_down(run_end, delta, 64);
+            unsigned long long o_best[VEC];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) o_best[k] = __shfl_down(best[k], delta, 64);
+            if (g + off < groups_per_wave && o_row == row && row >= 0) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) best[k] = o_best[k] > best[k] ? o_best[k] : best[k];
+                run_end = max(run_end, o_end);
+            }
+        }
+        const int prev_row = __shfl_up(row, lanes, 64);
+        const bool head = (g == 0) || (prev_row != row);
+        // ... and over the wave boundaries of the workgroup
+        __shared__ unsigned long long s_first_best[4][64 * VEC];
+        __shared__ int s_first_row[4], s_first_end[4], s_first_whole[4], s_last_row[4];
+        const int first_row = __shfl(row, 0, 64);
+        const int last_row = __shfl(row, (groups_per_wave - 1) * lanes, 64);
+        __syncthreads();
+        if (g == 0) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) s_first_best[wave][lc * VEC + k] = best[k];
+            if (lc == 0) {
+                s_first_row[wave] = row;
+                s_first_end[wave] = run_end;
+                s_first_whole[wave] = (first_row >= 0 && first_row == last_row) ? 1 : 0;
+                s_last_row[wave] = last_row;
+            }
+        }
+        __syncthreads();
+        const bool absorbed = head && g == 0 && wave > 0 && row >= 0 && s_last_row[wave - 1] == row;
+        if (head && row >= 0 && row == last_row && !absorbed) {
+            for (int w2 = wave + 1; w2 < 4 && s_first_row[w2] == row; ++w2) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    const unsigned long long o = s_first_best[w2][lc * VEC + k];
+                    best[k] = o > best[k] ? o : best[k];
+                }
+                run_end = max(run_end, s_first_end[w2]);
+                if (!s_first_whole[w2]) break;
+            }
+        }
+        writes = row >= 0 && head && !absorbed;
+    }
+    if (!writes) continue;
+    const bool whole_row = beg == rbeg && run_end == rend;  // no other writer
     unsigned long long* d = packed + (size_t)row * channels + c;
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
-        if (only_segment)
+#ifdef LN_SEGMAX_PLAIN  // timing ablation (wrong results): what the 64-bit atomics cost
+        d[k] = best[k];
+#else
+        if (whole_row)
             d[k] = best[k];
         else
             atomicMax(d + k, best[k]);
+#endif
     }
     if (counts && c == 0) {  // vertex degree on the side (the fused PointNet reduction needs it; integer adds: order-free)
-        if (only_segment)
-            counts[row] = end - beg;
+        if (whole_row)
+            counts[row] = run_end - beg;
         else
-            atomicAdd(counts + row, end - beg);
+            atomicAdd(counts + row, run_end - beg);
     }
   }
 }
@@ -648,12 +716,16 @@ __global__ void __launch_bounds__(256)
 static void ln_launch_segment_max(const LnCsr* csr, const int* grp_row, long long max_segments, const float* src, int channels,
                                   unsigned long long* packed, int* counts, hipStream_t st) {
     const bool vec4 = channels % 4 == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0;
-    if (vec4)
-        LN_LAUNCH("k_csr_segment_max", k_csr_segment_max<4>, dim3(ln_seg_grid(max_segments, channels / 4)), dim3(256), 0, st, csr->csr_tok,
-                  reinterpret_cast<const int4*>(csr->seg_desc), csr->seg_count, csr->seg_region, grp_row, src, channels, packed, counts);
-    else
-        LN_LAUNCH("k_csr_segment_max", k_csr_segment_max<1>, dim3(ln_seg_grid(max_segments, channels)), dim3(256), 0, st, csr->csr_tok,
-                  reinterpret_cast<const int4*>(csr->seg_desc), csr->seg_count, csr->seg_region, grp_row, src, channels, packed, counts);
+    const int lanes = vec4 ? channels / 4 : channels;
+    const bool comb = lanes <= 64 && (lanes & (lanes - 1)) == 0;  // no segment straddles a wave: runs can be combined before they are written
+#define LN_SEGMAX(VV, CC)                                                                                                            \
+    LN_LAUNCH("k_csr_segment_max", (k_csr_segment_max<VV, CC>), dim3(ln_seg_grid(max_segments, lanes)), dim3(256), 0, st, csr->csr_tok, \
+              reinterpret_cast<const int4*>(csr->seg_desc), csr->seg_count, csr->seg_region, grp_row, src, channels, packed, counts)
+    if (vec4 && comb) LN_SEGMAX(4, true);
+    else if (vec4) LN_SEGMAX(4, false);
+    else if (comb) LN_SEGMAX(1, true);
+    else LN_SEGMAX(1, false);
+#undef LN_SEGMAX
 }
 
 extern "C" int ln_csr_segment_max(const LnCsr* csr, const int* grp_row, long long max_segments, const float* src, int channels,

@@ -943,13 +943,15 @@ class Lattice:
             # few vertices (coarse levels): the kernel splits the contraction over the filter slots and needs room for the partials
             wsb = int(lib.ln_conv_forward_workspace_bytes(m, filter_extent, v, nr_filters))
             # The split bank of an unchanged filter is kept with the filter tensor (same storage, same version, same sizes -> same
-            # kernel and bank layout): repeated convolutions with fixed weights (inference: no gradient wanted for the filter) skip
-            # the split launch.  Only where the workspace is the bank alone (no slot-split partials, which concurrent streams would
-            # share) and never inside a stream capture (a replayed graph must re-split the weights the optimizer changed in between).
+            # kernel and bank layout): repeated convolutions with FROZEN weights skip the split launch.  Only for filters that do not
+            # require a gradient: the version counter is the only change detector there is, and the fused optimizers update
+            # parameters without moving it (measured: torch.optim.AdamW(fused=True) leaves p._version untouched,
+            # tools/probes/fused_adamw_version_probe.py — a cache keyed on it served stale banks to a training run).  Only where the
+            # workspace is the bank alone (no slot-split partials, which concurrent streams would share), never inside a stream capture.
             ws = None
             key = None
             bank_b = int(lib.ln_conv_bank_workspace_bytes(m, filter_extent, v, nr_filters))
-            if bank_b > 0 and wsb == bank_b + 256 and _BANK_CACHE and not (torch.is_grad_enabled() and filter_bank.requires_grad) and \
+            if bank_b > 0 and wsb == bank_b + 256 and _BANK_CACHE and not filter_bank.requires_grad and \
                     not torch.cuda.is_current_stream_capturing():
                 key = (filter_bank.data_ptr(), filter_bank._version, m, filter_extent, v, nr_filters, flags)
                 hit = getattr(filter_bank, "_ln_split_bank", None)

@@ -183,9 +183,9 @@ def test_split_bank_of_an_unchanged_filter_is_reused_and_invalidated_by_in_place
     y2, n2 = conv_and_count()
     assert n2 >= 1
     torch.testing.assert_close(y2, 2.0 * y0, rtol=1e-5, atol=1e-5 * float(y0.abs().max()))
-    wanted = bank.clone().requires_grad_(True)                       # a filter that wants a gradient is never served from the cache
-    lat.set_values(vals)
-    with torch.enable_grad():
+    wanted = bank.clone().requires_grad_(True)                       # a trainable filter is never served from the cache, not even under
+    lat.set_values(vals)                                             # no_grad: fused optimizers update parameters without moving the version counter
+    with torch.no_grad():
         assert lib.ln_profile_begin(b"k_conv_split_bank", 16) == 0
         for _ in range(2):
             lat.convolve_im2row_standalone(wanted, 1, lat, False)

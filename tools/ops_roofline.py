@@ -282,10 +282,12 @@ def run(dev=None, reps: int = 24):
             y.backward(g)
         conv_case("a7", f"ConvIm2RowLattice forward V = F = {v}", cfwd, m, m, v, v, False)
 
-        def cinf():  # inference: no gradient wanted, filter unchanged since the previous call -> its split bank is reused
+        fb_frozen = fb.detach().clone()
+
+        def cinf():  # inference with frozen weights (no gradient required for the filter): its split bank is reused from call to call
             with torch.no_grad():
-                state["y"], _ = ConvIm2RowLattice.apply(lv, dl, fb, 1)
-        conv_case("a7", f"ConvIm2RowLattice forward V = F = {v}, inference (unchanged filter: split bank reused)", cinf, m, m, v, v, False)
+                state["y"], _ = ConvIm2RowLattice.apply(lv, dl, fb_frozen, 1)
+        conv_case("a7", f"ConvIm2RowLattice forward V = F = {v}, frozen filter (split bank reused)", cinf, m, m, v, v, False)
         conv_case("a7", f"ConvIm2RowLattice forward + backward V = F = {v} (one autograd call)", cbwd, m, m, v, v, True)
     return {"scan": {"points": N, "vertices": m, "coarse_vertices": m1, "sigma": SIGMA, "capacity": CAP, "pos_dim": D}, "reps": reps, "ops": ops}
 
