@@ -460,7 +460,9 @@ static int ln_csr_reduce_rows_impl(const char* who, const LnCsr* csr, const int*
     if (max_segments == 0) return LN_OK;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(ln_seg_grid(max_segments, a.lanes_per_seg)), block(256);
-    const bool wg = csr->dense != 0 && vec >= 4;  // dense cloud: combine across the waves of a workgroup
+    // dense cloud, or wide rows (16+ lanes per segment: a wave then holds four segments or fewer, so every second to fourth segment of a
+    // row is cut by a wave boundary — at 96 fp32 channels on the C3 cloud 50.2 -> 42.4 us): combine across the waves of a workgroup
+    const bool wg = (csr->dense != 0 || a.lanes_per_seg >= 16) && vec >= 4;
 #define LN_REDUCE_LAUNCH(VV, HH)                                                                                                     \
     {                                                                                                                                \
         if (wg)                                                                                                                      \
@@ -526,7 +528,7 @@ static int ln_splat_tail_impl(const char* who, const LnCsr* csr, const int* grp_
         else if (vec == 4) LN_FUSED_LAUNCH(4, DD, false)                                                                             \
         else LN_FUSED_LAUNCH(1, DD, false)                                                                                           \
         break;
-    const bool wg = csr->dense != 0 && vec >= 4;
+    const bool wg = (csr->dense != 0 || a.lanes_per_seg >= 16) && vec >= 4;
     switch (d) { LN_FUSED_CASE(1) LN_FUSED_CASE(2) LN_FUSED_CASE(3) LN_FUSED_CASE(4) LN_FUSED_CASE(5) LN_FUSED_CASE(6) }
 #undef LN_FUSED_LAUNCH
 #undef LN_FUSED_CASE

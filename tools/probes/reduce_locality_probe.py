@@ -8,7 +8,7 @@ import bench  # noqa: E402
 import lattice_net_amd as L  # noqa: E402
 wl = sys.argv[1] if len(sys.argv) > 1 else "C5"
 cfg = bench.WORKLOADS[wl]
-n, v, half = cfg["n"], cfg["v"], bool(cfg.get("half"))
+n, v, half = cfg["n"], int(os.environ.get("V", cfg["v"])), bool(cfg.get("half"))  # V=96: the row width of the slice_classify scatter
 dev = torch.device("cuda", 0)
 pos = torch.from_numpy(bench.make_cloud(cfg["gen"], n, 0)).to(dev)
 vals = torch.randn((n, v), device=dev)
