@@ -610,6 +610,11 @@ def main():
     eager_step = cs0.step_on(cs0.clouds[0])
 
     def time_kernels(names, reps, load):
+        if args.prewarm_ms > 0:  # untimed steps first: the chip has idled through the host-side bookkeeping before this (see --prewarm-ms)
+            t_pre = time.perf_counter()
+            while (time.perf_counter() - t_pre) * 1e3 < min(args.prewarm_ms, 25.0):
+                eager_step()
+            torch.cuda.synchronize()
         if lib.ln_profile_begin(",".join(names).encode(), 16 * reps * len(names) + 16) != 0:
             return None
         for r in range(reps):
