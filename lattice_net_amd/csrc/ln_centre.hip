@@ -13,7 +13,10 @@
 
 #define LN_MC_MAX_K 8
 #define LN_MC_MAX_C 64
-#define LN_MC_ITERS 16  // points per thread
+#ifndef LN_MC_ITERS
+#define LN_MC_ITERS 4  // points per thread.  (16 until round 5: 268 workgroups for 120 k points, one wave per SIMD walking 16 dependent
+                       // iterations: forward 23.2 / backward 37.4 us; 4: 12.7 / 15.5 us + 1.6 us more in the slab sum; 2: 13.5 / 18.2 + 6.5)
+#endif
 
 // thread t of a workgroup: channel c = t % C, point lane pl = t / C; lanes = 256 / C point lanes are live
 __global__ void __launch_bounds__(256)
