@@ -297,7 +297,7 @@ class DistributeLatticeModule(torch.nn.Module):  # lattice_modules.py:52-96
         pos_dim = positions.shape[1]
         nr_rows = distributed_lattice.nr_lattice_vertices()
         if "distribute" in FUSED_GLUE and distributed.is_cuda and distributed.dtype == torch.float32 and distributed.is_contiguous() and \
-                not distributed.requires_grad:
+                not distributed.requires_grad and splatting_indices.dtype == torch.int32 and splatting_indices.is_contiguous():
             # sums of the positions straight from the token rows, degrees, then ONE pass for mean / subtract / zeroing
             tokens, width = distributed.shape
             sums = torch.zeros((nr_rows, pos_dim), dtype=torch.float32, device=distributed.device)
@@ -350,7 +350,8 @@ class PointNetModule(torch.nn.Module):  # lattice_modules.py:618-733 (the step r
         x = distributed[:, : distributed.shape[1] - 1]
         for layer in self.layers:  # linear + LeakyReLU(0.2) per token, fused (mods:669-671)
             x = linear_leaky_relu(x, layer.weight, layer.bias, self.act.negative_slope)
-        if "pointnet" in FUSED_GLUE and x.is_cuda and x.dtype == torch.float32 and distributed.is_contiguous() and not distributed.requires_grad:
+        if "pointnet" in FUSED_GLUE and x.is_cuda and x.dtype == torch.float32 and distributed.dtype == torch.float32 and \
+                distributed.is_contiguous() and not distributed.requires_grad and indices.dtype == torch.int32:
             # scatter_max + degrees + the winners' barycentric weights + both zeroing rules in three launches (mods:688-712)
             reduced = PointNetReduceFunction.apply(x, distributed, lattice_py, indices)
             lattice_py.set_values(reduced)
