@@ -219,3 +219,70 @@ def test_fp16_features_with_fp32_master_weights_return_the_filter_gradient_in_fp
     a, b = res[True][2], res[False][2]                             # fp32 sums vs the same sums rounded to fp16 and back
     assert float((a - b).abs().max()) <= 1e-3 * float(a.abs().max())
     assert float((a.half().float() - b).abs().max()) == 0.0
+
+
+def test_segment_reduce_variants_agree_and_match_a_float64_scatter():
+    """The workgroup-combining form of the CSR segment reduce (LnCsr.dense / wide rows) against the plain form and against an fp64
+    index_add, on a cloud with hot vertices (hundreds of tokens each) — at 32 channels (8 lanes per segment) and 96 (32 lanes)."""
+    import lattice_net_amd as L
+    import lattice_net_amd.lattice as LL
+    from lattice_net_amd.synthetic import lidar_cloud
+    n = 60000
+    pos = torch.from_numpy(lidar_cloud(n, 11)).to(dev())
+    lat = L.Lattice(sigmas=[1.4] * 3, capacity=100000, device=dev())      # coarse cells: many tokens per vertex
+    lat.begin_splat()
+    idx, w = lat.splat_standalone(pos, torch.zeros((n, 1), device=dev()))
+    m = lat.nr_lattice_vertices()
+    counts = np.bincount(idx.cpu().numpy()[idx.cpu().numpy() >= 0], minlength=m)
+    assert counts.max() > 200 and 4 * n / m > 10                           # many tokens per vertex, with hot vertices (the test sets the hint itself)
+    for v in (32, 96):
+        vals = torch.randn((n, v), device=dev())
+        ref = torch.zeros((m, v), dtype=torch.float64, device=dev())
+        ok = idx >= 0
+        ref.index_add_(0, idx[ok].long(), (vals.double().repeat_interleave(4, 0) * w.double().unsqueeze(1))[ok])
+        got = {}
+        saved = LL._DENSE_TOKENS_PER_VERTEX
+        for name, thr in (("combined", 0.0), ("plain", 1e9)):
+            LL._DENSE_TOKENS_PER_VERTEX = thr
+            try:
+                dst = torch.zeros((m, v), dtype=torch.float32, device=dev())
+                lat._scatter_rows(vals, idx, w, dst, v, 4, v)
+                got[name] = dst
+            finally:
+                LL._DENSE_TOKENS_PER_VERTEX = saved
+        scale = float(ref.abs().max())
+        for name, dst in got.items():
+            assert float((dst.double() - ref).abs().max()) <= 2e-6 * scale, name
+        assert float((got["combined"] - got["plain"]).abs().max()) <= 2e-6 * scale
+
+
+def test_segment_max_with_hot_vertices_is_exact():
+    """k_csr_segment_max in its run-combining form (C = 32, 64: 8 / 16 lanes per segment) and its plain form (C = 7) against the
+    NumPy oracle in canonical row order, with ties, on a cloud whose hottest vertices span several waves."""
+    from oracle import lattice_oracle as O
+    import lattice_net_amd as L
+    import lattice_net_amd.lattice as LL
+    from lattice_net_amd import ScatterMaxLattice
+    from lattice_net_amd.synthetic import lidar_cloud
+    n = 40000
+    pos_np = lidar_cloud(n, 12)
+    previous_order = LL.set_row_order("canonical")
+    try:
+        lat = L.Lattice(sigmas=[1.4] * 3, capacity=100000, device=dev())
+        lat.begin_splat()
+        idx, _ = lat.splat_standalone(torch.from_numpy(pos_np).to(dev()), torch.zeros((n, 1), device=dev()))
+        m = lat.nr_lattice_vertices()
+        tab = O.OracleHashTable(100000, 3)
+        oidx, _ = O.build_splat(tab, O.scale_positions(pos_np, np.full((3,), 1.4, np.float32)))
+        assert np.array_equal(oidx.ravel(), idx.cpu().numpy().ravel())
+        assert np.bincount(oidx[oidx >= 0].ravel()).max() > 600          # more than 32 segments: spans waves and workgroups
+        rng = np.random.default_rng(5)
+        for c in (32, 64, 7):
+            f = rng.standard_normal((4 * n, c)).astype(np.float32)
+            f[::3] = np.round(f[::3])
+            vmax, arg = ScatterMaxLattice.apply(torch.from_numpy(f).to(dev()), lat, idx)
+            omax, oarg = O.scatter_max(f, oidx, m)
+            assert np.array_equal(vmax.cpu().numpy(), omax) and np.array_equal(arg.cpu().numpy(), oarg), c
+            assert np.array_equal(lat.vertex_point_counts(idx).cpu().numpy(), O.vertex_point_counts(oidx, m))
+    finally:
+        LL.set_row_order(previous_order)
