@@ -123,6 +123,8 @@ def test_static_rows_and_region_planes_argument_checks():
         lat.set_static_rows(1001)
     lat.set_static_rows(512)
     assert lat.nr_lattice_vertices() == 512          # no table exists yet: nothing was read from a device
+    # LnCsr.dense (kernel-variant hint of the segment reduces): 16 or more tokens per bounded row
+    assert lat._dense_hint(16 * 512) == 1 and lat._dense_hint(16 * 512 - 1) == 0
     assert lat.clone_lattice().nr_lattice_vertices() == 512  # clones (e.g. the convolved lattice) inherit the bound
     # whole-network mode: one bound per lattice level, handed down to clones; the device-side row count is only offered in
     # static mode (and only once a table exists)
@@ -132,6 +134,10 @@ def test_static_rows_and_region_planes_argument_checks():
     assert lat.rows_device() is None                 # no counters yet
     lat.set_static_rows(None)
     assert lat.m_hash_table._static_levels is None and lat.rows_device() is None
+    assert lat._dense_hint(10 ** 9) == 0             # no bound and no build reported a vertex count yet: the plain variant
+    lat.m_hash_table.m_nr_filled = 100
+    assert lat._dense_hint(1600) == 1 and lat._dense_hint(1599) == 0
+    lat.m_hash_table.m_nr_filled = -1
     Lattice.start_level_trace()
     assert Lattice.stop_level_trace() == {}
     with pytest.raises(LatticeNetHipError):
