@@ -236,10 +236,61 @@ __device__ __forceinline__ void ln_split3_bits(float x, unsigned int& hi, unsign
     lo = __float_as_uint(r2) & 0xFFFF0000u;
 }
 
+// One block of the slab sum (k_reduce_slabs4 below): 64 outputs as 16 float4 columns x 16 slab groups (every thread has its
+// <= ceil(nslabs / 16) float4 loads in flight at once), combined through LDS in a fixed order.  total % 64 == 0.
+__device__ __forceinline__ void ln_reduce_slabs4_block(int vb, const float* __restrict__ partial, int nslabs, int total, float* __restrict__ out) {
+    __shared__ float4 s_part[16][16];
+    const int c = threadIdx.x & 15;
+    const int g = threadIdx.x >> 4;
+    const size_t col = (size_t)vb * 16 + c;  // float4 column
+    const size_t stride4 = (size_t)total / 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s0 = g; s0 < nslabs; s0 += 16 * 8) {
+        float4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int sl = s0 + 16 * k;
+            v[k] = sl < nslabs ? reinterpret_cast<const float4*>(partial)[(size_t)sl * stride4 + col] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            acc.x += v[k].x; acc.y += v[k].y; acc.z += v[k].z; acc.w += v[k].w;
+        }
+    }
+    s_part[g][c] = acc;
+    __syncthreads();
+    if (g == 0) {
+        float4 r = s_part[0][c];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) {
+            const float4 t = s_part[k][c];
+            r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
+        }
+        reinterpret_cast<float4*>(out)[col] = r;
+    }
+}
+
+// Horizontal fusion in the backward pass of a convolution: the slab sum of the FILTER gradient (slabs written by the previous
+// launch) rides in the launch that splits the bank of the VALUE-gradient convolution — two short launches that do not depend on each
+// other become one (18 slab sums of ~5 us per step of the SemanticKITTI network).  The split kernels take the extra workgroups
+// [split_x, gridDim.x) of every (y, z) plane: virtual block ((z * gridDim.y + y) * (gridDim.x - split_x) + x - split_x).
+struct LnSlabSum {
+    const float* partial;
+    int nslabs, total;
+    float* out;
+};
+#define LN_SLAB_SUM_IN_SPLIT(job, split_x)                                                                                       \
+    if ((int)blockIdx.x >= (split_x)) {                                                                                          \
+        const int vb_ = ((int)(blockIdx.z * gridDim.y + blockIdx.y)) * ((int)gridDim.x - (split_x)) + ((int)blockIdx.x - (split_x)); \
+        if (vb_ < (job).total / 64) ln_reduce_slabs4_block(vb_, (job).partial, (job).nslabs, (job).total, (job).out);           \
+        return;                                                                                                                  \
+    }
+
 // Filter slice of (slot e, column chunk y), split and in fragment order: [e][y][((s * NT + nt) * 3 + part) * 64 + lane][8 bf16]
 template <int V, int NT, bool WT>
 __global__ void __launch_bounds__(256)
-    k_conv_split_bank(const float* __restrict__ filter, int f_total, int f_off, unsigned short* __restrict__ bank) {
+    k_conv_split_bank(const float* __restrict__ filter, int f_total, int f_off, unsigned short* __restrict__ bank, int split_x, LnSlabSum job) {
+    LN_SLAB_SUM_IN_SPLIT(job, split_x)
     constexpr int F = 16 * NT;
     constexpr int KQ = V / 4;
     constexpr int S = KQ / 8;
@@ -499,7 +550,8 @@ __device__ __attribute__((aligned(256))) float g_ln_zero_row[1024];  // zero-ini
 // value = part of W[e][kc * 32 + s * 16 + h * 8 + j][f_off + (y * NT + nt) * 32 + n]
 template <int V, int NT, bool WT>
 __global__ void __launch_bounds__(256)
-    k_conv_split_bank32(const float* __restrict__ filter, int f_total, int f_off, unsigned short* __restrict__ bank) {
+    k_conv_split_bank32(const float* __restrict__ filter, int f_total, int f_off, unsigned short* __restrict__ bank, int split_x, LnSlabSum job) {
+    LN_SLAB_SUM_IN_SPLIT(job, split_x)
     constexpr int F = 32 * NT;
     constexpr int CHUNK = 2 * NT * 3 * 64 * 8;  // bf16 elements per (slot, column chunk, channel chunk)
     const int e = blockIdx.y;
@@ -1285,6 +1337,14 @@ static int ln_conv_b3_subtiles(int m, int chunks) {
 // LN_CONV_BANK_READY of the call in progress: the workspace already holds the split bank of this filter (written by an earlier call
 // with the same sizes and flags), so the k_conv_split_bank launches are skipped
 static thread_local bool g_ln_bank_ready = false;
+// slab sum waiting for a split launch to ride in (set by ln_conv_backward around its value-gradient convolution)
+static thread_local LnSlabSum g_ln_slab_job = {nullptr, 0, 0, nullptr};
+static LnSlabSum ln_take_slab_job() {
+    const LnSlabSum j = g_ln_slab_job;
+    g_ln_slab_job = LnSlabSum{nullptr, 0, 0, nullptr};
+    return j;
+}
+static int ln_slab_extra_blocks(const LnSlabSum& j, int planes) { return j.partial ? ln_div_up(j.total / 64, planes) : 0; }
 
 template <int V, bool FLIP, bool WT>
 static bool ln_conv_launch_v(int nr_filters, const int* nbr, const float* values, const float* filter, int m, int E, float* out,
@@ -1318,8 +1378,12 @@ static bool ln_conv_launch_v(int nr_filters, const int* nbr, const float* values
     {                                                                                                                               \
         const int cnt = (nr_filters - f_off) / (32 * NTC);                                                                          \
         if (cnt > 0) {                                                                                                              \
-            if (!g_ln_bank_ready) LN_LAUNCH("k_conv_split_bank", (k_conv_split_bank32<V, NTC, WT>), dim3(ln_div_up(V * 32 * NTC, 256), E, cnt), block, 0, st, filter, \
-                      nr_filters, f_off, bank + bank_off);                                                                          \
+            if (!g_ln_bank_ready) {                                                                                                 \
+                const LnSlabSum job_ = ln_take_slab_job();                                                                          \
+                const int sx_ = ln_div_up(V * 32 * NTC, 256);                                                                       \
+                LN_LAUNCH("k_conv_split_bank", (k_conv_split_bank32<V, NTC, WT>), dim3(sx_ + ln_slab_extra_blocks(job_, E * cnt), E, cnt), block, 0, st, \
+                          filter, nr_filters, f_off, bank + bank_off, sx_, job_);                                                    \
+            }                                                                                                                       \
             LN_LAUNCH("k_conv_mfma", (k_conv_rows32sk_b3<V, NTC, RTT, FLIP>), dim3(ln_div_up(m, 32 * RTT), cnt, nsplit),            \
                       dim3(128 * RTT), 0, st, nbr, values, reinterpret_cast<const u32x4*>(bank + bank_off), m, E, dst, nr_filters, f_off, e_per); \
             bank_off += (size_t)E * cnt * V * 32 * NTC * 3;                                                                         \
@@ -1330,8 +1394,12 @@ static bool ln_conv_launch_v(int nr_filters, const int* nbr, const float* values
     {                                                                                                                               \
         const int cnt = (nr_filters - f_off) / (32 * NTC);                                                                          \
         if (cnt > 0) {                                                                                                              \
-            if (!g_ln_bank_ready) LN_LAUNCH("k_conv_split_bank", (k_conv_split_bank32<V, NTC, WT>), dim3(ln_div_up(V * 32 * NTC, 256), E, cnt), block, 0, st, filter, \
-                      nr_filters, f_off, bank + bank_off);                                                                          \
+            if (!g_ln_bank_ready) {                                                                                                 \
+                const LnSlabSum job_ = ln_take_slab_job();                                                                          \
+                const int sx_ = ln_div_up(V * 32 * NTC, 256);                                                                       \
+                LN_LAUNCH("k_conv_split_bank", (k_conv_split_bank32<V, NTC, WT>), dim3(sx_ + ln_slab_extra_blocks(job_, E * cnt), E, cnt), block, 0, st, \
+                          filter, nr_filters, f_off, bank + bank_off, sx_, job_);                                                    \
+            }                                                                                                                       \
             LN_LAUNCH("k_conv_mfma", (k_conv_rows32_b3<V, NTWW, CHH, RTT, FLIP>), dim3(ln_div_up(m, 32 * RTT), cnt, nsplit),        \
                       dim3(64 * RTT * CHH), 0, st, nbr, values, reinterpret_cast<const u32x4*>(bank + bank_off), m, E, dst, nr_filters, f_off, e_per); \
             bank_off += (size_t)E * cnt * V * 32 * NTC * 3;                                                                         \
@@ -1363,8 +1431,12 @@ static bool ln_conv_launch_v(int nr_filters, const int* nbr, const float* values
             bool done_b3 = false;                                                                                                   \
             if constexpr (V % 32 == 0 && V * 16 * NTC * 6 <= 64 * 1024 && (V < 256 || NTC == 1)) { /* 256 x 32 columns spills */      \
                 if (b3) {                                                                                                           \
-                    if (!g_ln_bank_ready) LN_LAUNCH("k_conv_split_bank", (k_conv_split_bank<V, NTC, WT>), dim3(ln_div_up(V * 16 * NTC, 256), E, cnt), block, 0, st, filter, \
-                              nr_filters, f_off, bank + bank_off);                                                                  \
+                    if (!g_ln_bank_ready) {                                                                                         \
+                        const LnSlabSum job_ = ln_take_slab_job();                                                                  \
+                        const int sx_ = ln_div_up(V * 16 * NTC, 256);                                                               \
+                        LN_LAUNCH("k_conv_split_bank", (k_conv_split_bank<V, NTC, WT>), dim3(sx_ + ln_slab_extra_blocks(job_, E * cnt), E, cnt), block, 0, \
+                                  st, filter, nr_filters, f_off, bank + bank_off, sx_, job_);                                        \
+                    }                                                                                                               \
                     if (ln_conv_b3_subtiles<V>(m, cnt * nsplit) == 3) {                                                             \
                         if constexpr (LN_CONV_B3_WAVES(V) == 3)                                                                     \
                             LN_LAUNCH("k_conv_mfma", (k_conv_mfma_b3<V, NTC, FLIP, 3>), dim3(ln_div_up(m, 192), cnt, nsplit), dim3(768), 0, st, nbr, \
@@ -1822,35 +1894,7 @@ __global__ void __launch_bounds__(256) k_reduce_slabs(const float* __restrict__ 
 // total % 64 == 0: 64 outputs per workgroup as 16 float4 columns x 16 slab groups (every thread has its <= ceil(nslabs / 16)
 // float4 loads in flight at once), combined through LDS in a fixed order
 __global__ void __launch_bounds__(256) k_reduce_slabs4(const float* __restrict__ partial, int nslabs, int total, float* __restrict__ out) {
-    __shared__ float4 s_part[16][16];
-    const int c = threadIdx.x & 15;
-    const int g = threadIdx.x >> 4;
-    const size_t col = (size_t)blockIdx.x * 16 + c;  // float4 column
-    const size_t stride4 = (size_t)total / 4;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s0 = g; s0 < nslabs; s0 += 16 * 8) {
-        float4 v[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int sl = s0 + 16 * k;
-            v[k] = sl < nslabs ? reinterpret_cast<const float4*>(partial)[(size_t)sl * stride4 + col] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            acc.x += v[k].x; acc.y += v[k].y; acc.z += v[k].z; acc.w += v[k].w;
-        }
-    }
-    s_part[g][c] = acc;
-    __syncthreads();
-    if (g == 0) {
-        float4 r = s_part[0][c];
-#pragma unroll
-        for (int k = 1; k < 16; ++k) {
-            const float4 t = s_part[k][c];
-            r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
-        }
-        reinterpret_cast<float4*>(out)[col] = r;
-    }
+    ln_reduce_slabs4_block(blockIdx.x, partial, nslabs, total, out);
 }
 
 // out[i] = sum over s of partial[s * total + i], in slab order (deterministic); shared with the fp16 filter gradient
@@ -2179,9 +2223,20 @@ static int ln_gf_launch_partials(const int* nbr, const float* values_neigh, cons
     return chunks;  // unreachable: both dimensions are multiples of 16 (ln_gf_mfma_supported)
 }
 
+static int ln_conv_grad_filter_impl(const int* nbr, const float* values_neigh, const float* grad_out, int m, int filter_extent, int val_dim,
+                                    int nr_filters, float* grad_filter, void* workspace, size_t workspace_bytes, void* stream, bool defer_sum);
+
 extern "C" int ln_conv_grad_filter(const int* nbr, const float* values_neigh, const float* grad_out, int m, int filter_extent,
                                    int val_dim, int nr_filters, float* grad_filter, void* workspace, size_t workspace_bytes,
                                    void* stream) {
+    return ln_conv_grad_filter_impl(nbr, values_neigh, grad_out, m, filter_extent, val_dim, nr_filters, grad_filter, workspace, workspace_bytes,
+                                    stream, false);
+}
+
+// defer_sum: leave the slab sum as g_ln_slab_job for the next bank split of this thread to carry (ln_conv_backward; the caller
+// launches it itself if nothing took it)
+static int ln_conv_grad_filter_impl(const int* nbr, const float* values_neigh, const float* grad_out, int m, int filter_extent, int val_dim,
+                                    int nr_filters, float* grad_filter, void* workspace, size_t workspace_bytes, void* stream, bool defer_sum) {
     LN_REQUIRE(m >= 0 && filter_extent >= 1 && val_dim >= 1 && nr_filters >= 1, LN_ERR_ARG, "ln_conv_grad_filter: bad sizes");
     LN_REQUIRE(grad_filter && (m == 0 || (nbr && values_neigh && grad_out)), LN_ERR_ARG, "ln_conv_grad_filter: null buffer");
     hipStream_t st = (hipStream_t)stream;
@@ -2198,7 +2253,10 @@ extern "C" int ln_conv_grad_filter(const int* nbr, const float* values_neigh, co
         float* partial = static_cast<float*>(workspace);
         const int chunks = ln_gf_launch_partials(nbr, values_neigh, grad_out, m, filter_extent, val_dim, nr_filters, partial, st);
         // slabs are laid out [chunk][e][V*F]; summing over chunks with stride E*V*F
-        (void)ln_reduce_slabs_async(partial, chunks, total, grad_filter, st);
+        if (defer_sum && total % 64 == 0 && ((reinterpret_cast<uintptr_t>(grad_filter) | reinterpret_cast<uintptr_t>(partial)) & 15) == 0)
+            g_ln_slab_job = LnSlabSum{partial, chunks, total, grad_filter};
+        else
+            (void)ln_reduce_slabs_async(partial, chunks, total, grad_filter, st);
     } else {
         LN_LAUNCH("k_grad_filter_generic", k_grad_filter_generic, dim3(ln_div_up(total, 256)), dim3(256), 0, st, nbr, values_neigh, grad_out, m,
                            filter_extent, val_dim, nr_filters, grad_filter);
@@ -2698,12 +2756,23 @@ extern "C" int ln_conv_backward(const int* nbr_q, const int* nbr_n, const float*
 #undef LN_BWD_FULL
     }
     if (fused) return ln_check_launch("ln_conv_backward");
-    int rc = ln_conv_grad_filter(nbr_q, values_neigh, grad_out, mq, filter_extent, val_dim, nr_filters, grad_filter, workspace, workspace_bytes,
-                                 stream);
-    if (rc) return rc;
+    static int fuse_sum = -1;  // LN_BWD_SLAB_SUM_IN_SPLIT=0: the slab sum as a launch of its own (A/B; read once)
+    if (fuse_sum < 0) {
+        const char* ev = getenv("LN_BWD_SLAB_SUM_IN_SPLIT");
+        fuse_sum = (ev && ev[0] == '0') ? 0 : 1;
+    }
+    int rc = ln_conv_grad_filter_impl(nbr_q, values_neigh, grad_out, mq, filter_extent, val_dim, nr_filters, grad_filter, workspace, workspace_bytes,
+                                      stream, fuse_sum == 1);
+    if (rc) {
+        (void)ln_take_slab_job();
+        return rc;
+    }
     // the value-gradient convolution may split over the filter slots: its partial slabs go behind the filter gradient's
     size_t gf_bytes = (ln_conv_grad_filter_workspace_bytes(mq, filter_extent, val_dim, nr_filters) + 255) & ~size_t(255);
     char* conv_ws = (workspace && workspace_bytes > gf_bytes) ? static_cast<char*>(workspace) + gf_bytes : nullptr;
-    return ln_conv_forward_ws(nbr_n, grad_out, filter, mn, filter_extent, nr_filters, val_dim, LN_CONV_FLIP_NEIGHBOURS | LN_CONV_TRANSPOSED_FILTER,
-                              grad_values, conv_ws, conv_ws ? workspace_bytes - gf_bytes : 0, stream);
+    rc = ln_conv_forward_ws(nbr_n, grad_out, filter, mn, filter_extent, nr_filters, val_dim, LN_CONV_FLIP_NEIGHBOURS | LN_CONV_TRANSPOSED_FILTER,
+                            grad_values, conv_ws, conv_ws ? workspace_bytes - gf_bytes : 0, stream);
+    const LnSlabSum left = ln_take_slab_job();  // no bank split in that convolution (fp32 form, small filter): the sum as a launch of its own
+    if (left.partial) (void)ln_reduce_slabs_async(left.partial, left.nslabs, left.total, left.out, st);
+    return rc ? rc : ln_check_launch("ln_conv_backward");
 }
