@@ -19,7 +19,7 @@ for v, f in ((64, 64), (128, 128), (96, 96), (128, 64), (64, 32)):
         for _ in range(4): step()
         torch.cuda.synchronize()
     out = []
-    for name in (b"k_grad_filter_mfma", b"k_reduce_slabs"):
+    for name in (b"k_grad_filter_mfma", b"k_reduce_slabs", b"k_conv_split_bank"):
         lib.ln_profile_begin(name, 64)
         for _ in range(10): step()
         torch.cuda.synchronize()
@@ -32,4 +32,6 @@ for v, f in ((64, 64), (128, 128), (96, 96), (128, 64), (64, 32)):
             ok = nb[:, e] >= 0
             ref[e * v:(e + 1) * v] = (lv.detach()[nb[ok, e]].double().T @ g[ok].double()).float()
     err = float((fb.grad - ref).abs().max() / ref.abs().max())
-    print(f"V {v} F {f}: grad filter {out[0]:.1f} us + slab sum {out[1]:.1f} us   rel err {err:.1e}")
+    # (the slab sum rides in the bank-split launch of the value-gradient convolution since round 5: a separate k_reduce_slabs launch only
+    #  where that convolution has no bank to split; the split launches are two per step: forward bank, value-gradient bank + slab sum)
+    print(f"V {v} F {f}: grad filter {out[0]:.1f} us + slab sum {out[1]:.1f} us (bank split launches, one of them carrying the sum: {out[2]:.1f} us each)   rel err {err:.1e}")
