@@ -406,6 +406,13 @@ int ln_max_centre_backward(const float* grad_out, const float* max_vals, const u
                            long long n, int k, int c, float* grad_x, float* grad_gamma_beta, void* workspace,
                            size_t workspace_bytes, void* stream);
 
+/* Both gradients of a per-row linear layer y = x w^T (x [rows, cin], w [cout, cin]: the 1 x 1 layers of the blocks, run as lattice
+ * convolutions over the identity neighbour list `ident` [rows, 1] = 0 .. rows-1): grad_w [cout, cin] and grad_x [rows, cin] (may be
+ * NULL).  One call so that the slab sum of the weight gradient rides in the bank split of the input gradient's convolution. */
+size_t ln_linear_backward_workspace_bytes(int rows, int cin, int cout);
+int ln_linear_backward(const int* ident, const float* x, const float* grad_y, const float* w, int rows, int cin, int cout, float* grad_x,
+                       float* grad_w, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- launch diet of the glue around the lattice operators in a training step ----------------------------------------------
  * Weight normalisation of the reference's weight_norm_wrapper with v_dim=None (latticenet_py/lattice/utils.py:72-158; LinearWN,
  * ConvLatticeIm2RowWN, CoarsenLatticeWN, FinefyLatticeWN):  w = v * g / ||v||_F  for v [rows, cols] and one magnitude per row

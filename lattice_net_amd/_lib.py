@@ -131,6 +131,8 @@ SIGNATURES = {
     "ln_pointnet_reduce_workspace_bytes": (_sz, [_i, _i]),
     "ln_pointnet_reduce_forward": (_i, [_CSR, _vp, _ll, _vp, _i, _vp, _i, _i, _i, _vp, _sz, _vp, _vp, _vp]),
     "ln_pointnet_reduce_backward": (_i, [_vp, _i, _vp, _vp, _ll, _i, _vp, _vp]),
+    "ln_linear_backward_workspace_bytes": (_sz, [_i, _i, _i]),
+    "ln_linear_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "ln_nll_workspace_bytes": (_sz, []),
     "ln_nll_forward": (_i, [_vp, _vp, _ll, _i, _ll, _vp, _sz, _vp, _vp]),
     "ln_nll_backward": (_i, [_vp, _vp, _vp, _ll, _i, _ll, _vp, _vp]),

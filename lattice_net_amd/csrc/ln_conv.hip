@@ -2776,3 +2776,33 @@ extern "C" int ln_conv_backward(const int* nbr_q, const int* nbr_n, const float*
     if (left.partial) (void)ln_reduce_slabs_async(left.partial, left.nslabs, left.total, left.out, st);
     return rc ? rc : ln_check_launch("ln_conv_backward");
 }
+
+// Both gradients of a per-row linear layer y = x w^T (w [cout, cin]; a 1 x 1 lattice convolution over the identity neighbour list
+// `ident` [rows, 1]) in one call: grad_w [cout, cin] = the filter gradient with grad_y as the gathered rows and x as the gradient rows,
+// grad_x = grad_y w as a plain-bank convolution — in that order, so that the slab sum of the first rides in the bank split of the
+// second (as in ln_conv_backward).  grad_x may be NULL.  workspace: ln_linear_backward_workspace_bytes.
+extern "C" size_t ln_linear_backward_workspace_bytes(int rows, int cin, int cout) {
+    const size_t gf = (ln_conv_grad_filter_workspace_bytes(rows, 1, cout, cin) + 255) & ~size_t(255);
+    return gf + ln_conv_forward_workspace_bytes(rows, 1, cout, cin) + 256;
+}
+
+extern "C" int ln_linear_backward(const int* ident, const float* x, const float* grad_y, const float* w, int rows, int cin, int cout,
+                                  float* grad_x, float* grad_w, void* workspace, size_t workspace_bytes, void* stream) {
+    LN_REQUIRE(rows >= 0 && cin >= 1 && cout >= 1 && grad_w, LN_ERR_ARG, "ln_linear_backward: bad sizes / null output");
+    LN_REQUIRE(workspace && workspace_bytes >= ln_linear_backward_workspace_bytes(rows, cin, cout), LN_ERR_WORKSPACE,
+               "ln_linear_backward: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t gf_bytes = (ln_conv_grad_filter_workspace_bytes(rows, 1, cout, cin) + 255) & ~size_t(255);
+    int rc = ln_conv_grad_filter_impl(ident, grad_y, x, rows, 1, cout, cin, grad_w, workspace, gf_bytes, stream, grad_x != nullptr);
+    if (rc) {
+        (void)ln_take_slab_job();
+        return rc;
+    }
+    if (grad_x && rows > 0) {
+        char* conv_ws = static_cast<char*>(workspace) + gf_bytes;
+        rc = ln_conv_forward_ws(ident, grad_y, w, rows, 1, cout, cin, 0, grad_x, conv_ws, workspace_bytes - gf_bytes, stream);
+    }
+    const LnSlabSum left = ln_take_slab_job();
+    if (left.partial) (void)ln_reduce_slabs_async(left.partial, left.nslabs, left.total, left.out, st);
+    return rc ? rc : ln_check_launch("ln_linear_backward");
+}

@@ -197,16 +197,12 @@ class LinearMfmaFunction(torch.autograd.Function):
         dev = x.device
         ident = _identity_rows(dev, rows)
         stream = _lib.stream_ptr(dev)
-        gx = None
-        if ctx.needs_input_grad[0]:
-            gx = torch.empty_like(x)
-            ws_x = _conv_workspace(lib, rows, cout, cin, dev)
-            _lib.check(lib.ln_conv_forward_ws(_lib.ptr(ident), _lib.ptr(grad_y), _lib.ptr(w), rows, 1, cout, cin, 0, _lib.ptr(gx), _lib.ptr(ws_x),
-                                              0 if ws_x is None else ws_x.numel(), stream), "ln_conv_forward(1x1, grad_x)")
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         gw = torch.empty_like(w)
-        ws = torch.empty((lib.ln_conv_grad_filter_workspace_bytes(rows, 1, cout, cin),), dtype=torch.uint8, device=dev)
-        _lib.check(lib.ln_conv_grad_filter(_lib.ptr(ident), _lib.ptr(grad_y), _lib.ptr(x), rows, 1, cout, cin, _lib.ptr(gw), _lib.ptr(ws), ws.numel(),
-                                           stream), "ln_conv_grad_filter(1x1)")
+        # weight gradient first, then the input gradient's convolution: the slab sum of the first rides in the bank split of the second
+        ws = torch.empty((lib.ln_linear_backward_workspace_bytes(rows, cin, cout),), dtype=torch.uint8, device=dev)
+        _lib.check(lib.ln_linear_backward(_lib.ptr(ident), _lib.ptr(x), _lib.ptr(grad_y), _lib.ptr(w), rows, cin, cout, _lib.ptr(gx), _lib.ptr(gw),
+                                          _lib.ptr(ws), ws.numel(), stream), "ln_linear_backward")
         return gx, gw
 
 
