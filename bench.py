@@ -64,7 +64,7 @@ def compact_line(full: dict, details_file: str = "bench_details.json") -> dict:
     line = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
                                      "scaling", "vs_baseline", "dtype", "data")}
     line["config"] = _pick(cfg, ("workload", "points_per_gpu", "vertices", "val_dim", "nr_filters", "scans_in_flight",
-                                 "clouds_per_scan_pool", "sharding", "checksum", "prewarm"))
+                                 "clouds_per_scan_pool", "sharding", "checksum", "prewarm", "slot_order"))
     if isinstance(line["config"].get("workload"), str):
         line["config"]["workload"] = line["config"]["workload"][:240]
     line["roofline"] = (_pick(full.get("roofline"), ("bound", "kernel", "avg_us", "achieved", "peak", "unit", "frac", "traffic"))
@@ -398,6 +398,10 @@ def main():
     ap.add_argument("--regions", type=int, default=int(os.environ.get("LN_BENCH_REGIONS", "1")),
                     help="1 (default, graph mode): kd region planes (calibrated on a cloud OUTSIDE the pool) so that the scatter kernels walk "
                          "one compact region of the lattice per XCD")
+    ap.add_argument("--slot-order", default=os.environ.get("LATTICE_SLOT_ORDER", "space"), choices=["space", "hash"],
+                    help="space (default): the kd planes also order the SLOTS of the table, so that rows follow space (LnTable.planes: XCD-local "
+                         "gathers in the convolutions and the slice); hash: planes steer the segment walks only (rounds 2-5; A/B)")
+    ap.add_argument("--plane-levels", type=int, default=int(os.environ.get("LN_BENCH_PLANE_LEVELS", "3")), help="depth of the kd partition (3..6)")
     ap.add_argument("--row-slack", type=float, default=0.06,
                     help="graph mode: static row bound = largest vertex count of the calibration clouds x (1 + slack), rounded up to 256")
     args = ap.parse_args()
@@ -420,6 +424,9 @@ def main():
 
     import lattice_net_amd as L
     from lattice_net_amd.capture import CapturedStep, concurrent_streams
+    from lattice_net_amd import lattice as _lattice_mod
+    _lattice_mod.set_slot_order(args.slot_order)
+    os.environ["LATTICE_PLANE_LEVELS"] = str(args.plane_levels)
     lib = L.load_library()
     if not args.autograd_threads:
         # run backward on the calling thread: the hand-off to torch's per-device autograd worker costs tens of
@@ -832,6 +839,7 @@ def main():
                        "sharding": f"{world} rank(s), independent clouds per GPU", "checksum": round(checksum, 3),
                        "scans_in_flight": in_flight, "clouds_per_scan_pool": pool,
                        "prewarm": f"{prewarm_steps} untimed replays ({args.prewarm_ms:g} ms) before the W warm-up steps" if prewarm_steps else None, "kd_regions": bool(args.regions and graph_mode),
+                       "slot_order": args.slot_order if (args.regions and graph_mode) else "hash", "plane_levels": args.plane_levels,
                        "row_bounds": [cs.cap.bounds[0] for cs in sets] if graph_mode else None,
                        "bounds_and_planes_calibrated_on": "2 clouds per scan that are not in its pool" if graph_mode else None,
                        "vertices_per_scan": m_all, "graph_vs_eager": graph_err},

@@ -79,6 +79,19 @@ typedef struct LnTable {
                                       leaves vertices that would get a row >= row_limit un-inserted — idx = -1, no entries[] /
                                       keys[] row — so that no consumer can index past the host's tensors; nr_filled still
                                       counts them, which is how the host notices (nr_filled > row_limit) */
+    const int* planes;             /* NULL, or 2^plane_levels - 1 device ints: a kd partition of KEY space that orders the SLOTS (and
+                                      with them the rows) of this table by space.  Heap order: node i has the children 2i+1 (key below
+                                      the plane) and 2i+2 (key >= plane), level l compares key[l % pos_dim].  A key starts probing in
+                                      the run of whole buckets that belongs to its leaf (the hash picks the slot inside the run), rows
+                                      are numbered bucket by bucket, so the vertices of a leaf own one contiguous row range and the
+                                      gathers of the path (9 neighbour rows per vertex, d+1 rows per point) stay inside one XCD's L2.
+                                      The planes must stay what they were when the table's contents were inserted (retrieval uses the
+                                      same function); change them only in front of a build that starts with a clear.  Unbalanced planes
+                                      overfill buckets (LN_STATUS_BUCKET_OVERFLOW -> the atomic path, which spills); balanced ones
+                                      come from the host's calibration (Lattice.balanced_region_planes).  See csrc/ln_common.h */
+    int plane_levels;              /* 3 .. 6 (fewer levels are used when the bucket count is not a multiple of 2^plane_levels) */
+    int* row_regions;              /* NULL, or LN_XCD_GROUPS + 1 device ints a bucketed build over a space-ordered table fills: the first row
+                                      of each of the 8 top-level kd regions and the row count — the argument of ln_conv_row_partition */
 } LnTable;
 
 /* Adjacency "group -> the tokens that touch it" in CSR form, cut into segments of at most 16
@@ -101,8 +114,9 @@ typedef struct LnCsr {
                              into LN_XCD_GROUPS compact regions — key[0] >= planes[0] picks the half, key[1] against
                              planes[1 + half] the quarter, key[2] against planes[3 + quarter] the region.  A bucketed
                              build then files every vertex's segments under its region, and the scatter kernels let
-                             XCD r walk region r: the d+1 gathers of a point row meet in ONE L2.  The planes only steer
-                             work placement (any values are correct); balanced ones come from ln_region_planes. */
+                             XCD r walk region r: the d+1 gathers of a point row meet in ONE L2.  These planes only steer
+                             work placement (any values are correct).  When the table itself is space-ordered
+                             (LnTable.planes) the region of a vertex is that of its bucket and this array is only a flag. */
     int dense;            /* host-side hint for the segment reduces (any value is correct): non-zero = dense cloud, about 16 or more
                              tokens per vertex — most vertices then own several segments, and the reduce combines partial sums across
                              the waves of a workgroup before it resorts to atomics (C5: 104 -> 84 us; costs the sparse C3 scan 10 %) */
@@ -283,6 +297,12 @@ int ln_conv_grad_filter(const int* nbr, const float* values_neigh, const float* 
                         int val_dim, int nr_filters, float* grad_filter, void* workspace, size_t workspace_bytes,
                         void* stream);
 
+/* Work placement hint for the vertex-tiled convolution kernels (ln_conv_forward*, ln_conv_backward) of the CALLING THREAD: `row_starts`
+ * = LnTable.row_regions of the space-ordered table whose rows the following calls convolve over (device memory, 9 ints, read by the
+ * kernels at run time), or NULL to reset.  XCD x then works on the row tiles of kd region x, whose neighbour rows share its L2.
+ * Purely a speed matter: any contents give correct results. */
+int ln_conv_row_partition(const int* row_starts);
+
 /* slice_with_precomputation (LatticeGPU.cuh:2552-2595). */
 int ln_slice_forward(const float* values, const int* idx, const float* w, int n, int pos_dim, int val_dim, float* out,
                      void* stream);
@@ -290,6 +310,14 @@ int ln_slice_forward(const float* values, const int* idx, const float* w, int n,
  * backward pass of this slice scatters into (ln_csr_reduce_rows / ln_slice_backward need it zeroed), saving that fill launch. */
 int ln_slice_forward_prepare_backward(const float* values, const int* idx, const float* w, int n, int pos_dim, int val_dim, float* out,
                                       float* grad_accumulator, long long grad_accumulator_elems, void* stream);
+/* slice_with_precomputation for the indices a build of `t` wrote, with the points taken in the order of that build's slot CSR (`csr`,
+ * as ln_build_splat / ln_distribute filled it; groups = hash slots) instead of input order: over a space-ordered table
+ * (LnTable.planes) the d+1 value rows of the points a workgroup slices then sit in one kd region, i.e. in one XCD's L2.  Same
+ * arithmetic per point, bit-identical output rows.  grad_accumulator (may be NULL) as ln_slice_forward_prepare_backward.  Widths the
+ * ordered kernel does not cover run ln_slice_forward. */
+int ln_slice_forward_ordered(const LnTable* t, const LnCsr* csr, const float* values, const int* idx, const float* w, int n, int val_dim,
+                             float* out, float* grad_accumulator, long long grad_accumulator_elems, void* stream);
+
 /* slice_no_precomputation (LatticeGPU.cuh:2598-2750): also writes idx/w (-1 where absent). */
 int ln_slice_no_precomputation(const LnTable* t, const float* values, const float* positions_raw, const float* sigmas_host,
                                int n, int val_dim, float* out, int* idx, float* w, void* stream);

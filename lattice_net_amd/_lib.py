@@ -46,6 +46,9 @@ class LnTable(C.Structure):
         ("host_seq", C.c_int),
         ("key_format", C.c_int),
         ("row_limit", C.c_int),
+        ("planes", C.c_void_p),
+        ("plane_levels", C.c_int),
+        ("row_regions", C.c_void_p),
     ]
 
 
@@ -108,6 +111,8 @@ SIGNATURES = {
     "ln_conv_grad_filter": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "ln_slice_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "ln_slice_forward_prepare_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _ll, _vp]),
+    "ln_slice_forward_ordered": (_i, [_T, _CSR, _vp, _vp, _vp, _i, _i, _vp, _vp, _ll, _vp]),
+    "ln_conv_row_partition": (_i, [_vp]),
     "ln_slice_no_precomputation": (_i, [_T, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "ln_slice_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "ln_gather_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),

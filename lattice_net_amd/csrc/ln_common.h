@@ -168,9 +168,7 @@ LN_HD uint32_t ln_hash(const int* key) {
 #endif
 #define LN_BKT_MAX 2048
 #define LN_XCD_GROUPS 8
-#ifndef LN_CELL_SHIFT
-#define LN_CELL_SHIFT (-1)
-#endif
+#define LN_MAX_PLANE_LEVELS 6
 // At least LN_BKT_MIN_COUNT buckets (one bucket = one workgroup of the build: fewer buckets than CUs leave CUs idle) as long
 // as they keep >= LN_BKT_MIN_SLOTS slots each.
 #ifndef LN_BKT_MIN_COUNT
@@ -198,39 +196,40 @@ LN_HD int ln_bucket_count(int capacity) {
     const int sb = ln_bucket_slots(capacity);
     return (capacity + sb - 1) / sb;
 }
-// Slots per XCD group (0 = this table is not grouped: too few buckets).  Group g owns the slots [g * gs, (g + 1) * gs).
-LN_HD int ln_group_slots(int capacity, int sb) {
-    const int nbk = (capacity + sb - 1) / sb;
-    if (LN_CELL_SHIFT < 0 || nbk < 2 * LN_XCD_GROUPS || nbk % LN_XCD_GROUPS != 0) return 0;
-    return (nbk / LN_XCD_GROUPS) * sb;
-}
-// Which slot a key starts probing at.  The table is cut into LN_XCD_GROUPS groups of whole buckets, one per XCD (a MI355X
-// dispatches workgroup b to XCD b % 8, each XCD has its own 4 MB L2).  The GROUP comes from a hash of the key's CELL — the
-// cube of 2^LN_CELL_SHIFT lattice units it falls in — the slot inside the group from the reference's hash of the key.  All
-// vertices of a cell land in one group, spread evenly over its buckets (so bucket loads stay as uniform as with plain
-// hashing); the d+1 vertices of a point's simplex span <= d units per coordinate and mostly share a cell.  The build emits
-// its segment, point and vertex lists per group, and every gather / scatter kernel lets XCD g walk group g's list: a
-// point row or vertex row is then fetched by ~1.4 XCD L2s instead of by every XCD that happens to touch it (d+1 for the
-// scatters, all 8 for the convolution).  The slot layout is internal (only row ids are reference-visible).
-// LN_CELL_SHIFT < 0 switches the grouping off (h0 = hash % capacity) — the DEFAULT: measured on the C3 LiDAR scan with
-// 16-unit cells, the token load of the 8 groups is too uneven (a handful of cells next to the sensor hold most tokens; an
-// XCD cannot borrow CUs): segment reduce 17.4 -> 19.1 us, bucket pass 19.2 -> 23.0 us.  The per-group segment regions
-// and the region walk (ln_csr.h) stay in place for a balanced (work-stealing) version.
+// ---- space-ordered slots ----------------------------------------------------------------------------------------------
+// A table may carry a kd partition of KEY space (LnTable.planes: heap-ordered split planes, level l compares key[l % d];
+// LnTable.plane_levels levels, 2^levels leaves; balanced ones come from the host's calibration).  The slot function then puts
+// the LEAF of a key into the high part of its slot and hashes only inside the leaf's slot range: the table is cut into
+// 2^levels runs of whole buckets, one per leaf.  Buckets are numbered in slot order and rows bucket by bucket, so ROWS follow
+// space: the vertices of one leaf own one contiguous row range, and with them the value rows every gather of the path reads
+// (9 neighbour rows per vertex in the convolutions, d+1 rows per point in the slice, the segment walks).  A MI355X dispatches
+// workgroup b to XCD b % 8 and each XCD has its own 4 MB L2: kernels that hand XCD x a contiguous eighth of the rows
+// (ln_xcd_chunk_tile) then fetch a value row into ~1.1 L2s instead of into 4.8 of the 8 (tools/probes/slot_order_model.py;
+// profiles/r6_pmc_traffic.json).  Only row ids are reference-visible (PyBridge exposes m_keys / m_nr_filled); retrieval uses
+// the same function, so "every vertex inserted, retrieve finds it" holds as with plain hashing (HashTableGPU.cuh:425-519).
+// The top three levels are the 8 regions of the segment lists (LnCsr): region = leaf >> (levels - 3).
+// Without planes (or with fewer than 2^3 buckets): h0 = hash % capacity, as the reference.
 LN_HD uint32_t ln_stir(uint32_t k) {
     k ^= k >> 15;
     k *= 2246822519u;
     k ^= k >> 13;
     return k;
 }
-template <int D>
-LN_HD uint32_t ln_cell_hash(const int* key) {
-    uint32_t k = 0;
+// levels of the partition that the slot function of a table with nbk buckets uses (0 = plain hashing): whole buckets per leaf
+LN_HD int ln_slot_levels(bool have_planes, int levels, int nbk) {
+    if (!have_planes || levels < 3) return 0;
+    if (levels > LN_MAX_PLANE_LEVELS) levels = LN_MAX_PLANE_LEVELS;
+    while (levels >= 3 && (nbk % (1 << levels)) != 0) --levels;
+    return levels >= 3 ? levels : 0;
+}
+// leaf of a key under the first `levels` levels of the kd partition (levels <= LN_MAX_PLANE_LEVELS; 0 -> leaf 0)
+template <int D, typename P>
+LN_HD int ln_leaf_of_key(const int* key, P planes, int levels) {
+    int node = 0;
 #pragma unroll
-    for (int i = 0; i < D; ++i) {
-        k += uint32_t(key[i] >> (LN_CELL_SHIFT < 0 ? 0 : LN_CELL_SHIFT));  // arithmetic shift: floor division for negative coordinates
-        k *= 2531011u;
-    }
-    return ln_stir(k);
+    for (int l = 0; l < LN_MAX_PLANE_LEVELS; ++l)
+        if (l < levels) node = 2 * node + 1 + ((key[l % D] >= planes[node]) ? 1 : 0);
+    return node - ((1 << levels) - 1);
 }
 struct LnProbe {
     int lo, size, off, cap;
@@ -241,9 +240,9 @@ struct LnProbe {
         size = (capacity - lo < sb) ? (capacity - lo) : sb;
         off = h0 - lo;
     }
-    // grouped form: `group_hash` picks the XCD group, `slot_hash` the starting slot inside the group's slot range
-    LN_HD LnProbe(uint32_t group_hash, uint32_t slot_hash, int capacity, int sb, int gs) {
-        const int glo = int(group_hash % uint32_t(LN_XCD_GROUPS)) * gs;
+    // space-ordered form: `leaf` picks the run of gs slots (whole buckets), `slot_hash` the starting slot inside it
+    LN_HD LnProbe(int leaf, uint32_t slot_hash, int capacity, int sb, int gs) {
+        const int glo = leaf * gs;
         const int gsz = (capacity - glo < gs) ? (capacity - glo) : gs;
         const int h0 = glo + int(slot_hash % uint32_t(gsz));
         cap = capacity;
@@ -251,17 +250,28 @@ struct LnProbe {
         size = (capacity - lo < sb) ? (capacity - lo) : sb;
         off = h0 - lo;
     }
-    template <int D>
-    static LN_HD LnProbe of_key(const int* key, int capacity, int sb) {
-        const int gs = ln_group_slots(capacity, sb);
-        if (gs == 0) return LnProbe(ln_hash<D>(key), capacity, sb);
+    // `planes` may point to a copy of LnTable.planes in LDS (k_point_keys)
+    template <int D, typename P>
+    static LN_HD LnProbe of_key(const int* key, int capacity, int sb, P planes, int plane_levels) {
+        const int nbk = (capacity + sb - 1) / sb;
+        const int lv = ln_slot_levels(planes != nullptr, plane_levels, nbk);
+        if (lv == 0) return LnProbe(ln_hash<D>(key), capacity, sb);
         // (the raw hash is a poor slot hash: 2531011 = 7 * 361573, and e.g. 511 = 7 * 73)
-        return LnProbe(ln_cell_hash<D>(key), ln_stir(ln_hash<D>(key)), capacity, sb, gs);
+        return LnProbe(ln_leaf_of_key<D>(key, planes, lv), ln_stir(ln_hash<D>(key)), capacity, sb, (nbk >> lv) * sb);
     }
-    // XCD group of slot h (0 when the table is not grouped)
-    static LN_HD int group_of_slot(int h, int capacity, int sb) {
-        const int gs = ln_group_slots(capacity, sb);
-        return gs ? h / gs : 0;
+    template <int D>
+    static LN_HD LnProbe of_key(const int* key, const LnTable& t, int sb) {
+        return of_key<D>(key, t.capacity, sb, t.planes, t.plane_levels);
+    }
+    // starting offset of `key` inside bucket b, for a caller that knows the key lives there (the bucket pass): no tree walk
+    template <int D>
+    static LN_HD int offset_in_bucket(const int* key, const LnTable& t, int sb, int b) {
+        const int nbk = (t.capacity + sb - 1) / sb;
+        const int lv = ln_slot_levels(t.planes != nullptr, t.plane_levels, nbk);
+        if (lv == 0) return int(ln_hash<D>(key) % uint32_t(t.capacity)) - b * sb;
+        const int bpl = nbk >> lv, gs = bpl * sb, glo = (b / bpl) * gs;
+        const int gsz = (t.capacity - glo < gs) ? (t.capacity - glo) : gs;
+        return glo + int(ln_stir(ln_hash<D>(key)) % uint32_t(gsz)) - b * sb;
     }
     LN_HD int slot(int i) const {
         if (i < size) {
@@ -274,16 +284,64 @@ struct LnProbe {
         return s;
     }
 };
+// segment region (XCD group) of bucket b of a space-ordered table
+LN_HD int ln_region_of_bucket(int b, int nbk) { return int((long long)b * LN_XCD_GROUPS / nbk); }
 
 // Region of a lattice key under the 3-level kd split of key space described at LnCsr.planes (include/latticenet_hip.h).
 template <int D>
 LN_HD int ln_region_of_key(const int* key, const int* planes) {
-    const int k0 = key[0], k1 = key[1 % D], k2 = key[2 % D];
-    int r = (k0 >= planes[0]) ? 1 : 0;
-    r = 2 * r + ((k1 >= planes[1 + r]) ? 1 : 0);
-    r = 2 * r + ((k2 >= planes[3 + r]) ? 1 : 0);
-    return r;
+    return ln_leaf_of_key<D>(key, planes, 3);
 }
+
+#if defined(__HIPCC__)
+// Workgroup -> tile map that hands every XCD ONE contiguous run of the G tiles of a launch (block b runs on XCD b % 8: observed
+// dispatch behaviour, used for speed only — any placement is correct).  Bijective for every G.
+__device__ __forceinline__ int ln_xcd_chunk_tile(int b, int G) {
+    const int q = G >> 3, r = G & 7, x = b & 7, j = b >> 3;
+    return x * q + (x < r ? x : r) + j;
+}
+// Workgroup -> row tile map of the vertex-tiled kernels over a space-ordered table.  `part` = LnTable.row_regions as the build
+// left it: part[r] = first row of region r (the kd regions own contiguous row ranges), part[8] = rows in total; nullptr = identity.
+// XCD x (workgroups b % 8 == x) takes the tiles of region x, so that the neighbour rows it gathers sit in ITS L2; regions hold
+// different numbers of vertices (the planes balance tokens), so the workgroups an XCD has left over take the tiles the fuller
+// regions have beyond their XCD's share, in a fixed order.  The boundaries are clamped into a monotone sequence first: whatever
+// `part` holds (a stale or half-written array after a build that was replayed on another path) the map is a bijection of [0, G).
+// All of it is wave-uniform scalar work (9 scalar loads, ~60 scalar instructions).
+__device__ __forceinline__ int ln_partition_tile(int b, int G, const int* __restrict__ part, int tile_rows) {
+    if (part == nullptr || G < 2 * LN_XCD_GROUPS) return b;
+    int s[LN_XCD_GROUPS + 1];
+    s[0] = 0;
+#pragma unroll
+    for (int r = 1; r < LN_XCD_GROUPS; ++r) {
+        int v = (part[r] + (tile_rows >> 1)) / tile_rows;
+        v = v < s[r - 1] ? s[r - 1] : v;
+        s[r] = v > G ? G : v;
+    }
+    s[LN_XCD_GROUPS] = G;
+    const int q = G >> 3, rem = G & 7, x = b & 7, j = b >> 3;
+    int spare = 0;  // rank of this workgroup among the left-over workgroups (XCD-major), valid when j >= tiles of region x
+    int mine = 0, first = 0;
+#pragma unroll
+    for (int y = 0; y < LN_XCD_GROUPS; ++y) {
+        const int wy = q + (y < rem ? 1 : 0), ty = s[y + 1] - s[y];
+        if (y < x) spare += wy > ty ? wy - ty : 0;
+        if (y == x) {
+            mine = ty;
+            first = s[y];
+        }
+    }
+    if (j < mine) return first + j;
+    spare += j - mine;
+#pragma unroll
+    for (int y = 0; y < LN_XCD_GROUPS; ++y) {
+        const int wy = q + (y < rem ? 1 : 0), ty = s[y + 1] - s[y];
+        const int over = ty > wy ? ty - wy : 0;
+        if (spare < over) return s[y] + wy + spare;
+        spare -= over;
+    }
+    return b;  // unreachable: the left-over workgroups and the left-over tiles are equally many
+}
+#endif
 
 #if defined(__HIPCC__)
 // HashTableGPU::retrieve (HashTableGPU.cuh:491-519) on packed slots: stop at an empty slot or
@@ -292,7 +350,7 @@ template <int D>
 __device__ __forceinline__ int ln_retrieve(const LnTable& t, const int* key) {
     if (!KeyPack<D>::in_range(key, t.key_format)) return -1;  // cannot have been inserted
     const uint64_t pk = KeyPack<D>::pack(key, t.key_format);
-    const LnProbe pr = LnProbe::of_key<D>(key, t.capacity, ln_bucket_slots(t.capacity));
+    const LnProbe pr = LnProbe::of_key<D>(key, t, ln_bucket_slots(t.capacity));
     const int limit = t.capacity < LN_MAX_RETRIEVE_CONFLICTS ? t.capacity : LN_MAX_RETRIEVE_CONFLICTS;
     for (int conflicts = 0; conflicts < limit; ++conflicts) {
         const int h = pr.slot(conflicts);

@@ -1337,6 +1337,13 @@ static int ln_conv_b3_subtiles(int m, int chunks) {
 // LN_CONV_BANK_READY of the call in progress: the workspace already holds the split bank of this filter (written by an earlier call
 // with the same sizes and flags), so the k_conv_split_bank launches are skipped
 static thread_local bool g_ln_bank_ready = false;
+// ln_conv_row_partition: LnTable.row_regions of the space-ordered table the next convolutions of this thread run over (device memory,
+// read by the kernels; nullptr = none).  A placement hint only — ln_partition_tile is a bijection whatever the array holds.
+static thread_local const int* g_ln_row_partition = nullptr;
+extern "C" int ln_conv_row_partition(const int* row_starts) {
+    g_ln_row_partition = row_starts;
+    return LN_OK;
+}
 // slab sum waiting for a split launch to ride in (set by ln_conv_backward around its value-gradient convolution)
 static thread_local LnSlabSum g_ln_slab_job = {nullptr, 0, 0, nullptr};
 static LnSlabSum ln_take_slab_job() {
@@ -1478,7 +1485,7 @@ static bool ln_conv_launch_v(int nr_filters, const int* nbr, const float* values
 template <int T>
 __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(T, T)))
     k_conv_forward_b3(const int* __restrict__ nbr, const float* __restrict__ values, const float* __restrict__ filter, int m,
-                      float* __restrict__ out) {
+                      float* __restrict__ out, const int* __restrict__ row_part) {
     constexpr int V = 32, F = 32, E = 9, KQ = 8, NT = 2;
     constexpr int THREADS = 256 * T;
     constexpr int FRAG16 = E * NT * 3 * 64;  // 16-byte fragments of the split bank (54 KB)
@@ -1499,7 +1506,8 @@ __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(T,
     const int lane = tid & 63;
     const int i = lane & 15;
     const int q = lane >> 4;
-    const int m0 = blockIdx.x * (64 * T) + (tid >> 6) * 16;
+    const int bx = ln_partition_tile(blockIdx.x, gridDim.x, row_part, 64 * T);  // space-ordered table: XCD x takes the tiles of kd region x
+    const int m0 = bx * (64 * T) + (tid >> 6) * 16;
     const int my_row = m0 + i;
     // bank staging: one item = (slot e, 8 consecutive rows v of W_e, column f) = ONE 16-byte fragment per split part.  The eight
     // loads of an item are 4 bytes each but consecutive lanes take consecutive columns, so every load instruction reads whole
@@ -1518,7 +1526,7 @@ __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(T,
     }
 #if LN_FWD_LINE
     {
-        const size_t g0 = (size_t)blockIdx.x * (64 * T) * E, g_end = (size_t)m * E;
+        const size_t g0 = (size_t)bx * (64 * T) * E, g_end = (size_t)m * E;
         for (int x = tid; x < 64 * T * E; x += THREADS) s_nbr[x] = (g0 + x < g_end) ? nbr[g0 + x] : -1;
     }
     {   // a tile without any neighbour (past the real rows of a static-rows launch: 257 tiles of 192 rows for 256 CUs) writes zeros and leaves
@@ -1526,7 +1534,7 @@ __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(T,
         for (int x = tid; x < 64 * T * E; x += THREADS) any |= s_nbr[x] >= 0;
         if (!__syncthreads_or(any)) {
             for (int x = tid; x < 64 * T * (F / 4); x += THREADS) {
-                const int row = blockIdx.x * (64 * T) + x / (F / 4);
+                const int row = bx * (64 * T) + x / (F / 4);
                 if (row < m) *reinterpret_cast<float4*>(out + (size_t)row * F + (x % (F / 4)) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
             }
             return;
@@ -1664,9 +1672,9 @@ static int ln_conv_dispatch(const int* nbr, const float* values_neigh, const flo
                 (reinterpret_cast<uintptr_t>(values_neigh) & 15) == 0) {
                 const int t = min(ln_bwd_subtiles(m), 3);
                 const dim3 grid_t(ln_div_up(m, 64 * t)), block_t(256 * t);
-                if (t == 1) LN_LAUNCH("k_conv_mfma", (k_conv_forward_b3<1>), grid_t, block_t, 0, st, nbr, values_neigh, filter, m, out);
-                else if (t == 2) LN_LAUNCH("k_conv_mfma", (k_conv_forward_b3<2>), grid_t, block_t, 0, st, nbr, values_neigh, filter, m, out);
-                else LN_LAUNCH("k_conv_mfma", (k_conv_forward_b3<3>), grid_t, block_t, 0, st, nbr, values_neigh, filter, m, out);
+                if (t == 1) LN_LAUNCH("k_conv_mfma", (k_conv_forward_b3<1>), grid_t, block_t, 0, st, nbr, values_neigh, filter, m, out, g_ln_row_partition);
+                else if (t == 2) LN_LAUNCH("k_conv_mfma", (k_conv_forward_b3<2>), grid_t, block_t, 0, st, nbr, values_neigh, filter, m, out, g_ln_row_partition);
+                else LN_LAUNCH("k_conv_mfma", (k_conv_forward_b3<3>), grid_t, block_t, 0, st, nbr, values_neigh, filter, m, out, g_ln_row_partition);
                 return ln_check_launch("ln_conv_forward");
             }
         }
@@ -2471,7 +2479,8 @@ extern "C" int ln_debug_dump(int* host, int n) {
 template <int T>
 __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(T, T)))
     k_conv_backward_fused_b3(const int* __restrict__ nbr, const float* __restrict__ values, const float* __restrict__ grad_out,
-                             const float* __restrict__ filter, int m, float* __restrict__ grad_values, float* __restrict__ slabs) {
+                             const float* __restrict__ filter, int m, float* __restrict__ grad_values, float* __restrict__ slabs,
+                             const int* __restrict__ row_part) {
     constexpr int V = 32, F = 32, E = 9, KQ = 8, NT = 2, FT = 2;
     constexpr int THREADS = 256 * T;
     constexpr int BANK = E * V * F;                      // floats of one slab (the parking area at the end)
@@ -2493,7 +2502,8 @@ __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(T,
     const int wave = t256 >> 6;
     const int i = lane & 15;
     const int q = lane >> 4;
-    const int sub0 = blockIdx.x * (64 * T) + sub * 64;
+    const int bx = ln_partition_tile(blockIdx.x, gridDim.x, row_part, 64 * T);  // space-ordered table: XCD x takes the tiles of kd region x
+    const int sub0 = bx * (64 * T) + sub * 64;
     const int m0 = sub0 + wave * 16;
     const int my_row = m0 + i;
 
@@ -2729,7 +2739,7 @@ extern "C" int ln_conv_backward(const int* nbr_q, const int* nbr_n, const float*
         if constexpr (TT <= 3) { /* bf16 matrix cores, exactly split operands (four sub-tiles of staging do not fit LDS) */             \
             if (ln_conv_b3_enabled() && !(ln_debug_mask() & 65536)) {                                                                  \
                 LN_LAUNCH("k_conv_backward_fused", (k_conv_backward_fused_b3<TT>), dim3(wgs), dim3(256 * TT), 0, st, nbr_n, values_neigh, grad_out, \
-                          filter, mn, grad_values, partial);                                                                           \
+                          filter, mn, grad_values, partial, g_ln_row_partition);                                                       \
                 break;                                                                                                                 \
             }                                                                                                                          \
         }                                                                                                                              \

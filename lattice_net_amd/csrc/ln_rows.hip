@@ -172,6 +172,123 @@ extern "C" int ln_slice_forward_prepare_backward(const float* values, const int*
     return ln_slice_forward_impl(values, idx, w, n, pos_dim, val_dim, out, grad_accumulator, grad_accumulator_elems, stream);
 }
 
+// ------------------------------------------------------------------------------------------
+// The same slice with the points taken in the order of the build's slot CSR instead of input order (round 6).
+// k_slice_forward walks the points as the caller stored them: on a shuffled cloud every workgroup touches value rows all over the
+// table, every XCD pulls the whole [M, V] table through its 4 MB L2 (C3: 23 MB fetched for 5.9 MB of rows).  The CSR of a bucketed
+// build lists the tokens bucket by bucket, and over a space-ordered table (LnTable.planes) bucket by bucket means region by region:
+// here a point is sliced by whoever meets its remainder-0 token in that list, the d+1 rows it reads are rows of the same region (its
+// simplex), and XCD x walks the x-th eighth of the list — a value row is then fetched by ~1.2 L2s instead of 3.3.
+// One wave takes 256 consecutive CSR entries (four coalesced loads), compacts the owners (token % (d+1) == 0) into a private LDS
+// list with ballots, and slices them LPP lanes per point; per point the arithmetic is that of k_slice_forward (same order, same
+// skips: bit-identical rows).  Points whose remainder-0 token never reached the CSR (key out of the packable range, a build that
+// overflowed) exist only when the table's status word is non-zero: then — and only then — every workgroup also scans its share of
+// idx[p * (d+1)] < 0 and slices those points the old way (a point met on both paths is written twice with the same row).
+template <int VEC, int DP1>
+__global__ void __launch_bounds__(256)
+    k_slice_forward_ordered(const float* __restrict__ values, const int* __restrict__ idx, const float* __restrict__ w, int n, int chunks,
+                            const int* __restrict__ csr_tok, const int* __restrict__ csr_len, const int* __restrict__ status,
+                            float* __restrict__ out, float* __restrict__ zero_fill, long long zero_elems) {
+    using T = typename VecT<VEC>::type;
+    __shared__ int s_list[4][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    {
+        const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+        if (zero_fill) {  // the accumulator the backward pass of this slice will scatter into, zeroed on the way
+            const long long threads = (long long)gridDim.x * blockDim.x;
+            for (long long i = g; i < zero_elems; i += threads) zero_fill[i] = 0.f;
+        }
+    }
+    const int lpp = chunks;               // lanes per point (a power of two <= 64: checked by the host)
+    const int ppw = 64 / lpp;             // points per wave and round
+    const int sub = lane / lpp, c = lane - sub * lpp;
+    auto slice_point = [&](int p) {
+        int rows[DP1];
+        float wt[DP1];
+#pragma unroll
+        for (int r = 0; r < DP1; ++r) {
+            rows[r] = idx[(size_t)p * DP1 + r];
+            wt[r] = w[(size_t)p * DP1 + r];
+        }
+        T v[DP1];
+#pragma unroll
+        for (int r = 0; r < DP1; ++r) v[r] = reinterpret_cast<const T*>(values)[(size_t)(rows[r] >= 0 ? rows[r] : 0) * chunks + c];
+        T acc = ln_zero(T());
+#pragma unroll
+        for (int r = 0; r < DP1; ++r)
+            if (rows[r] >= 0) acc = ln_add(acc, ln_mul(v[r], wt[r]));  // same order and the same skips as LatticeGPU.cuh:2567-2591
+        reinterpret_cast<T*>(out)[(size_t)p * chunks + c] = acc;
+    };
+    const int len = *csr_len;  // entries of the CSR (tokens the build placed)
+    const int tile = ln_xcd_chunk_tile(blockIdx.x, gridDim.x);  // XCD x walks the x-th eighth of the list
+    for (long long base = ((long long)tile * 4 + wave) * 256; base < len; base += (long long)gridDim.x * 1024) {
+        int cnt = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long long e = base + k * 64 + lane;
+            const int tk = e < len ? csr_tok[e] : -1;
+            const bool own = tk >= 0 && (tk % DP1) == 0;
+            const unsigned long long mask = __ballot(own);
+            if (own) s_list[wave][cnt + __popcll(mask & ((1ull << lane) - 1ull))] = tk / DP1;
+            cnt += __popcll(mask);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int j = sub; j < cnt; j += ppw) {
+            const int p = s_list[wave][j];
+            if (p < n) slice_point(p);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // (the list is rewritten by the next trip)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (*status != 0) {  // some token of the build never reached the CSR: find the points nobody has met
+        const int per = (n + (int)gridDim.x - 1) / (int)gridDim.x;
+        const int p0 = blockIdx.x * per, p1 = min(n, p0 + per);
+        for (int pb = p0 + wave * 64; pb < p1; pb += 256) {
+            const int p = pb + lane;
+            const bool orphan = p < p1 && idx[(size_t)p * DP1] < 0;
+            unsigned long long mask = __ballot(orphan);
+            while (mask) {  // wave-uniform
+                const int src = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                if (sub == 0) slice_point(pb + src);
+            }
+        }
+    }
+}
+
+#define LN_SLICE_ORD_CASE(DD)                                                                                                          \
+    case DD:                                                                                                                           \
+        LN_LAUNCH("k_slice_forward", (k_slice_forward_ordered<VEC, DD + 1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, values, idx, w, n, \
+                  chunks, csr->csr_tok, csr->grp_start + t->capacity, t->status, out, grad_accumulator, grad_accumulator_elems);       \
+        break;
+extern "C" int ln_slice_forward_ordered(const LnTable* t, const LnCsr* csr, const float* values, const int* idx, const float* w, int n,
+                                        int val_dim, float* out, float* grad_accumulator, long long grad_accumulator_elems, void* stream) {
+    LN_REQUIRE(t && csr && csr->csr_tok && csr->grp_start && t->status && t->capacity > 0, LN_ERR_ARG, "ln_slice_forward_ordered: null table / CSR");
+    const int pos_dim = t->pos_dim;
+    int rc = ln_check_rows("ln_slice_forward_ordered", values, idx, out, n, pos_dim, val_dim);
+    if (rc) return rc;
+    LN_REQUIRE(n == 0 || w, LN_ERR_ARG, "ln_slice_forward_ordered: null weights");
+    const int chunks4 = val_dim / 4;
+    // rows of 4 .. 256 floats whose float4 count is a power of two; everything else goes the plain way
+    if (n == 0 || (val_dim & 3) != 0 || chunks4 > 64 || (chunks4 & (chunks4 - 1)) != 0)
+        return ln_slice_forward_impl(values, idx, w, n, pos_dim, val_dim, out, grad_accumulator, grad_accumulator_elems, stream);
+    {
+        constexpr int VEC = 4;
+        const int chunks = chunks4;
+        const long long tokens = (long long)n * (pos_dim + 1);
+        // one workgroup per 1024 CSR entries, capped so that every XCD's share stays a multiple of whole workgroups per CU
+        int grid = ln_div_up(tokens, 1024);
+        if (grid > 4096) grid = 4096;
+        if (grid < 1) grid = 1;
+        switch (pos_dim) { LN_SLICE_ORD_CASE(1) LN_SLICE_ORD_CASE(2) LN_SLICE_ORD_CASE(3) LN_SLICE_ORD_CASE(4) LN_SLICE_ORD_CASE(5) LN_SLICE_ORD_CASE(6) }
+    }
+    return ln_check_launch("ln_slice_forward_ordered");
+}
+#undef LN_SLICE_ORD_CASE
+
 // fp16 lattice values -> fp16 sliced rows (fp32 arithmetic): thread = (point, HV channels), HV = 8 (16-byte words) when the width
 // allows.  As in k_slice_forward: all indices and weights first, then the d+1 row gathers together (the first version fetched
 // index -> row -> weight vertex after vertex: four dependent round trips, 52 us at C5 against 25 us now), same summation order;

@@ -329,7 +329,7 @@ __device__ __forceinline__ int ln_insert(const LnTable& t, const int* key, int& 
         return -1;
     }
     const uint64_t pk = KeyPack<D>::pack(key, t.key_format);
-    const LnProbe pr = LnProbe::of_key<D>(key, t.capacity, ln_bucket_slots(t.capacity));
+    const LnProbe pr = LnProbe::of_key<D>(key, t, ln_bucket_slots(t.capacity));
     for (int probes = 0; probes < t.capacity; ++probes) {
         const int h = pr.slot(probes);
         // Plain (cacheable) pre-check: a slot only ever changes EMPTY -> key, so a stale read can only
@@ -434,10 +434,13 @@ __global__ void __launch_bounds__(TH)
     __shared__ unsigned long long s_stage_pk[PTS_PER_BLOCK * (D + 1)];
     __shared__ int s_stage_tok[PTS_PER_BLOCK * (D + 1)];
     __shared__ int s_stage_dst[PTS_PER_BLOCK * (D + 1)];
+    __shared__ int s_planes[1 << LN_MAX_PLANE_LEVELS];  // the table's kd planes (space-ordered slots): d+1 walks of the tree per point
     int* cursor = t.slot_cnt;
     LN_STAMP(0);
     for (int b = threadIdx.x; b < nbk; b += TH) s_cnt[b] = 0;
-    ln_lds_barrier();
+    const int slot_levels = ln_slot_levels(t.planes != nullptr, t.plane_levels, nbk);
+    if (slot_levels && threadIdx.x < (1 << slot_levels) - 1) s_planes[threadIdx.x] = t.planes[threadIdx.x];
+    __syncthreads();
     LN_STAMP(1);
     unsigned long long pk[PTS][RH];
     int bkt[PTS][RH];
@@ -469,7 +472,7 @@ __global__ void __launch_bounds__(TH)
             const bool ok = lat_fmt ? KeyPack<D>::lattice_in_range(key, r) : KeyPack<D>::in_range(key, t.key_format);
             if (ok) {
                 pk[it][k] = lat_fmt ? KeyPack<D>::lattice_pack(key, r) : KeyPack<D>::pack(key, t.key_format);
-                bkt[it][k] = LnProbe::of_key<D>(key, t.capacity, sb).lo / sb;
+                bkt[it][k] = LnProbe::of_key<D>(key, t.capacity, sb, slot_levels ? s_planes : (const int*)nullptr, slot_levels).lo / sb;
                 rank[it][k] = atomicAdd(&s_cnt[bkt[it][k]], 1);
             } else {
                 bad_key = true;
@@ -667,7 +670,7 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
         if (valid) {
             int key[D];
             KeyPack<D>::unpack(pk, key, t.key_format);
-            int o = LnProbe::of_key<D>(key, t.capacity, sb).off;
+            int o = LnProbe::offset_in_bucket<D>(key, t, sb, b);
             for (int i = 0; i < size; ++i) {
                 unsigned long long cur = skeys[o];
                 if (cur == LN_EMPTY_KEY) {
@@ -811,10 +814,13 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
             if (scnt[i]) srow[i] = srank[srow[i]];  // (srow[i] held the slot's position in the compacted list)
     }
     LN_STAMP(11);
-    // Segment ids.  Without region planes: one contiguous run of region 0 per bucket.  With planes: every slot files its
-    // segments under the kd region of its key (sseg[i] becomes region << 28 | position among this bucket's segments of that
-    // region; one returning global atomic per (bucket, region)).
-    const int* planes = csr.planes;
+    // Segment ids.  Without region planes: one contiguous run of region 0 per bucket.  Space-ordered table (LnTable.planes): one
+    // contiguous run of the bucket's region.  Region planes over a hashed table: every slot files its segments under the kd region
+    // of its key (sseg[i] becomes region << 28 | position among this bucket's segments of that region; one returning global atomic
+    // per (bucket, region)).
+    const bool slot_ordered = ln_slot_levels(t.planes != nullptr, t.plane_levels, nbk) != 0;
+    const int bucket_region = (slot_ordered && csr.planes) ? ln_region_of_bucket(b, nbk) : 0;
+    const int* planes = slot_ordered ? nullptr : csr.planes;
     if (planes) {
         for (int i = tid; i < size; i += LN_BKT_THREADS) {
             const int c = scnt[i];
@@ -832,7 +838,7 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
     if (planes) {
         if (tid < LN_XCD_GROUPS && s_rcnt[tid]) seg_base_reg = atomicAdd(&csr.seg_count[tid], s_rcnt[tid]);
     } else if (tid == 0 && s_run_seg) {
-        seg_base_reg = atomicAdd(&csr.seg_count[0], s_run_seg);
+        seg_base_reg = atomicAdd(&csr.seg_count[bucket_region], s_run_seg);
     }
     LN_STAMP(15);
     // look-back: new vertices (and error flags) of every earlier bucket
@@ -867,6 +873,11 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
     }
     const int placed = s_run_tok;
     const int new_here = s_run_new;
+    if (t.row_regions && tid == 0 && slot_ordered) {  // first row of each kd region (the argument of ln_conv_row_partition)
+        const int bpr = nbk / LN_XCD_GROUPS;
+        if (b % bpr == 0) t.row_regions[b / bpr] = base_row;
+        if (b == nbk - 1) t.row_regions[LN_XCD_GROUPS] = base_row + new_here;
+    }
     LN_STAMP(12);
     for (int i = tid; i < size; i += LN_BKT_THREADS) {
         const int h = lo + i;
@@ -889,8 +900,8 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
 #pragma unroll
             for (int k = 0; k < D; ++k) t.keys[(size_t)row * D + k] = key[k];
         }
-        const int sr = planes ? (sseg[i] >> 28) : 0;
-        long long sid = (long long)sr * csr.seg_region + s_rbase[sr] + (planes ? (sseg[i] & 0x0FFFFFFF) : sseg[i]);
+        const int sr = planes ? (sseg[i] >> 28) : bucket_region;
+        long long sid = (long long)sr * csr.seg_region + s_rbase[planes ? sr : 0] + (planes ? (sseg[i] & 0x0FFFFFFF) : sseg[i]);
         for (int e = 0; e < c; e += LN_CSR_SEG, ++sid)
             reinterpret_cast<int4*>(csr.seg_desc)[sid] = make_int4(row, beg + e, c - e, e);  // {ROW, first entry, entries to the end, offset}
     }
@@ -1392,7 +1403,7 @@ __global__ void __launch_bounds__(256) k_rehash_rows(LnTable t) {
 #pragma unroll
     for (int i = 0; i < D; ++i) key[i] = t.keys[(size_t)r * D + i];
     const uint64_t pk = KeyPack<D>::pack(key, t.key_format);  // (it was packable when it was inserted)
-    const LnProbe pr = LnProbe::of_key<D>(key, t.capacity, ln_bucket_slots(t.capacity));
+    const LnProbe pr = LnProbe::of_key<D>(key, t, ln_bucket_slots(t.capacity));
     for (int probes = 0; probes < t.capacity; ++probes) {
         const int h = pr.slot(probes);
         if (atomicCAS(&t.slot_keys[h], (unsigned long long)LN_EMPTY_KEY, (unsigned long long)pk) == LN_EMPTY_KEY) {

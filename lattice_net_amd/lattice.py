@@ -24,10 +24,11 @@ import weakref
 from typing import Optional, Sequence
 
 import torch
+import torch.utils.weak
 
 from . import _lib
 
-__all__ = ["Lattice", "HashTable", "set_row_order", "get_row_order", "set_hash_capacity_policy"]
+__all__ = ["Lattice", "HashTable", "set_row_order", "get_row_order", "set_hash_capacity_policy", "set_slot_order", "set_bank_cache"]
 
 
 _SIZE_CACHE = {}
@@ -45,6 +46,24 @@ _ROW_ORDER = [os.environ.get("LATTICE_ROW_ORDER", "slot")]
 # builds that start from a cleared table, "full" = always the cfg's capacity (what the reference does).
 _HASH_POLICY = [os.environ.get("LATTICE_HASH_CAPACITY", "tokens")]
 _STATIC_SLOTS_PER_ROW = float(os.environ.get("LATTICE_STATIC_SLOTS_PER_ROW", "2.3"))  # static-rows mode: slots hashed into per bounded row
+
+
+# What kd region planes (Lattice.set_region_planes) steer:
+#   "space" (default) the SLOT function as well: a key starts probing in the run of buckets that belongs to its kd leaf, rows are
+#           numbered bucket by bucket, so the rows of the table follow space (LnTable.planes, csrc/ln_common.h) and the gathers of
+#           the convolutions / slice / segment walks stay inside one XCD's L2;
+#   "hash"  only which XCD walks which CSR segments (round 2-5 behaviour: slots stay hashed over the whole table).
+_SLOT_ORDER = [os.environ.get("LATTICE_SLOT_ORDER", "space")]
+_PLANES_KEEPALIVE = []
+_ORDERED_SLICE = [os.environ.get("LATTICE_ORDERED_SLICE", "1") != "0"]  # A/B switch: slice in CSR order over space-ordered tables
+
+
+def set_slot_order(order: str) -> str:
+    """Selects what region planes steer in subsequent builds ("space" or "hash"); returns the previous setting."""
+    if order not in ("space", "hash"):
+        raise ValueError(f"slot order must be 'space' or 'hash', got {order!r}")
+    prev, _SLOT_ORDER[0] = _SLOT_ORDER[0], order
+    return prev
 
 
 def set_hash_capacity_policy(policy: str) -> str:
@@ -116,7 +135,20 @@ def _require_cuda(t: torch.Tensor, name: str):
 
 
 _DENSE_TOKENS_PER_VERTEX = float(os.environ.get("LATTICE_DENSE_TOKENS_PER_VERTEX", "16"))  # LnCsr.dense from here on (0: always, 1e9: never)
-_BANK_CACHE = os.environ.get("LATTICE_BANK_CACHE", "1") != "0"  # keep the split bank of an unchanged filter (convolve_im2row_standalone)
+# Keep the split bank of an unchanged FROZEN filter between convolve_im2row_standalone calls.  Opt-in (LATTICE_BANK_CACHE=1 or
+# set_bank_cache(True)): the only change detector is (data_ptr, _version), which writes through `.data`, checkpoint patching and fused
+# optimizers do not move — a caller that enables it promises not to modify frozen filters behind torch's back.  Entries live in a
+# weak-keyed dictionary (nothing rides in Parameter.__dict__ into pickles) and remember the stream that produced them: a hit from
+# another stream is ignored (the bank may still be being written there).
+_BANK_CACHE = [os.environ.get("LATTICE_BANK_CACHE", "0") == "1"]
+_BANK_ENTRIES = torch.utils.weak.WeakTensorKeyDictionary()  # (keys compared by identity: `==` on tensors is elementwise)
+
+
+def set_bank_cache(on: bool) -> bool:
+    prev, _BANK_CACHE[0] = _BANK_CACHE[0], bool(on)
+    if not on:
+        _BANK_ENTRIES.clear()
+    return prev
 
 
 def _pad4(words: int) -> int:
@@ -162,7 +194,21 @@ class _TableStorage:
         self.nbr_cache = {}
         self.csr_cache = {}
         self.replay = None  # [rebuild on the atomic path, then the work queued behind the build], see Lattice._build
-        self.planes = None  # int32[8] device tensor: kd split planes of key space (LnCsr.planes), None = no regions
+        self.planes = None  # int32 device tensor, 2^levels entries (the last one padding): kd split planes of key space, None = no regions
+        self.slot_planes = None  # the planes the CONTENTS of the table were inserted under (LnTable.planes): adopted from `planes` by
+        self.slot_levels = 0     # every build that starts from a cleared table, kept by incremental builds and retrievals
+        self.row_regions = None  # int32[16] device tensor: first row of each kd region, written by bucketed builds over space-ordered slots
+        self.rows_follow_space = False  # the last build numbered the rows region by region (row_regions is current)
+
+    def adopt_planes(self):
+        """Called where the table is known to be empty (a clear, a build that clears first)."""
+        if self.planes is not None and _SLOT_ORDER[0] == "space":
+            self.slot_planes, self.slot_levels = self.planes, int(self.planes.numel()).bit_length() - 1
+            if self.row_regions is None:
+                self.row_regions = torch.zeros((16,), dtype=torch.int32, device=self.device)
+        else:
+            self.slot_planes, self.slot_levels = None, 0
+        self.rows_follow_space = False
 
     def hashed(self) -> int:
         return self.hash_capacity or self.capacity
@@ -184,6 +230,9 @@ class _TableStorage:
         s.csr_cache = {}
         s.replay = None
         s.planes = self.planes
+        s.slot_planes, s.slot_levels = self.slot_planes, self.slot_levels
+        s.row_regions = None if self.row_regions is None else self.row_regions.clone()
+        s.rows_follow_space = self.rows_follow_space
         return s
 
     def touch(self):
@@ -255,7 +304,7 @@ class HashTable:
                 self._pinned = torch.zeros((4,), dtype=torch.int32, pin_memory=True)
             self._pinned_np = self._pinned.numpy().view("int64")  # same memory: the host polls the build's 64-bit report word
             self._readback_event = torch.cuda.Event()
-        key = (s.uid, self._counters.data_ptr(), self._static_rows, s.hashed())
+        key = (s.uid, self._counters.data_ptr(), self._static_rows, s.hashed(), None if s.slot_planes is None else s.slot_planes.data_ptr())
         if getattr(self, "_c_table_key", None) == key:
             return self._c_table
         self._c_table_key = key
@@ -265,7 +314,8 @@ class HashTable:
     def _make_c_table(self, s) -> _lib.LnTable:
         return _lib.LnTable(s.hashed(), s.pos_dim, s.slot_keys.data_ptr(), s.slot_tok.data_ptr(), s.slot_cnt.data_ptr(), s.entries.data_ptr(),
                             s.keys.data_ptr(), self._counters.data_ptr(), self._counters.data_ptr() + 4, self._pinned.data_ptr(), 0,
-                            s.key_format, self._static_rows or 0)
+                            s.key_format, self._static_rows or 0, _lib.ptr(s.slot_planes), s.slot_levels,
+                            _lib.ptr(s.row_regions) if s.slot_planes is not None else None)
 
     def clear(self, lazy: bool = False):  # HashTable.cu:49-57, one launch instead of four fill_ kernels
         """`lazy=True` only records that a clear is due: the next build issues it inside its own C call (no host
@@ -284,6 +334,7 @@ class HashTable:
         if v is not None and not (v.is_contiguous() and v.data_ptr() % 16 == 0):
             v.zero_()
             v = None
+        self._storage.adopt_planes()  # the table is empty behind this launch: the slot function may change
         t = self.c_table()
         _lib.check(lib.ln_table_clear(C.byref(t), _lib.ptr(v), 0 if v is None else v.numel(),
                                       _lib.stream_ptr(self._storage.device)), "ln_table_clear")
@@ -539,6 +590,8 @@ class Lattice:
         tokens = n * (d + 1)
         st = ht._storage
         clear_vals, do_clear = ht.take_pending_clear()  # begin_splat's clear rides in the same C call
+        if do_clear:
+            st.adopt_planes()  # space-ordered slots: the kd planes are bound to the table's contents from here on
         self._choose_hash_capacity(tokens, fresh=do_clear)
         cap = st.hashed()
         csr_buf, csr, max_seg = self._alloc_csr(tokens, cap, st.planes)
@@ -576,6 +629,7 @@ class Lattice:
                                        cv, cn, self._stream())
                 _lib.check(rc, "ln_distribute")
             st.touch()
+            st.rows_follow_space = bool(st.slot_levels and do_clear and not (flags & (_lib.LN_BUILD_ATOMIC_PATH | _lib.LN_BUILD_CANONICAL_ROWS)))
             ht.m_nr_filled_is_dirty = True
             if n > 0 and ht._static_rows is None:
                 ht.start_count_readback()
@@ -900,6 +954,14 @@ class Lattice:
         sq.nbr_cache[key] = (nbr,)  # keyed by the neighbour storage's uid: no reference to it (a storage in its own cache is a cycle)
         return nbr
 
+    def _row_partition(self):
+        """Device pointer of LnTable.row_regions when the rows of this lattice follow space (bucketed build over space-ordered slots),
+        else None: the argument of ln_conv_row_partition for convolutions whose output rows are this lattice's."""
+        st = self.m_hash_table._storage
+        if st is None or not st.rows_follow_space or st.row_regions is None:
+            return None
+        return st.row_regions.data_ptr()
+
     def _check_filter_extent(self, filter_extent: int):
         if filter_extent != self.get_filter_extent(1):
             raise ValueError(f"filter extent should be {self.get_filter_extent(1)} (1-hop neighbourhood + centre), got {filter_extent}")
@@ -951,21 +1013,28 @@ class Lattice:
             ws = None
             key = None
             bank_b = int(lib.ln_conv_bank_workspace_bytes(m, filter_extent, v, nr_filters))
-            if bank_b > 0 and wsb == bank_b + 256 and _BANK_CACHE and not filter_bank.requires_grad and \
+            if bank_b > 0 and wsb == bank_b + 256 and _BANK_CACHE[0] and not filter_bank.requires_grad and \
                     not torch.cuda.is_current_stream_capturing():
-                key = (filter_bank.data_ptr(), filter_bank._version, m, filter_extent, v, nr_filters, flags)
-                hit = getattr(filter_bank, "_ln_split_bank", None)
+                key = (filter_bank.data_ptr(), filter_bank._version, m, filter_extent, v, nr_filters, flags, self._stream())
+                hit = _BANK_ENTRIES.get(filter_bank)
                 if hit is not None and hit[0] == key:
                     ws, flags = hit[1], flags | _lib.LN_CONV_BANK_READY
             if ws is None and wsb > 256:
                 ws = torch.empty((wsb,), dtype=torch.uint8, device=self._dev())
-            _lib.check(lib.ln_conv_forward_ws(_lib.ptr(nbr), _lib.ptr(vals), _lib.ptr(filter_bank), m, filter_extent, v, nr_filters, flags,
-                                              _lib.ptr(out), _lib.ptr(ws), 0 if ws is None else ws.numel(), self._stream()),
-                       "ln_conv_forward")
+            part = self._row_partition()
+            if part is not None:
+                lib.ln_conv_row_partition(part)
+            try:
+                _lib.check(lib.ln_conv_forward_ws(_lib.ptr(nbr), _lib.ptr(vals), _lib.ptr(filter_bank), m, filter_extent, v, nr_filters, flags,
+                                                  _lib.ptr(out), _lib.ptr(ws), 0 if ws is None else ws.numel(), self._stream()),
+                           "ln_conv_forward")
+            finally:
+                if part is not None:
+                    lib.ln_conv_row_partition(None)
             if key is not None and not (flags & _lib.LN_CONV_BANK_READY):
                 try:
-                    filter_bank._ln_split_bank = (key, ws)
-                except AttributeError:
+                    _BANK_ENTRIES[filter_bank] = (key, ws)
+                except TypeError:  # (not weak-referenceable)
                     pass
         conv = Lattice._clone_of(self)
         conv.m_name = "convolved_lattice"
@@ -1019,8 +1088,15 @@ class Lattice:
         # (Measured on MI355X: running the filter gradient on a second stream made the step SLOWER, 0.254 -> 0.286 ms:
         # both kernels already fill the chip and the event hand-offs cost more than the overlap.  What does pay is
         # putting the slab sum of the filter gradient into the value-gradient launch: ln_conv_backward.)
-        _lib.check(lib.ln_conv_backward(_lib.ptr(nbr_q), _lib.ptr(nbr_n), _lib.ptr(nb.values()), _lib.ptr(grad_out), _lib.ptr(filter_bank), mq,
-                                        mn, E, v, f, _lib.ptr(gvals), _lib.ptr(gf), _lib.ptr(ws), ws.numel(), main), "ln_conv_backward")
+        part = nb._row_partition() if q.m_hash_table._storage is nb.m_hash_table._storage else None
+        if part is not None:
+            lib.ln_conv_row_partition(part)
+        try:
+            _lib.check(lib.ln_conv_backward(_lib.ptr(nbr_q), _lib.ptr(nbr_n), _lib.ptr(nb.values()), _lib.ptr(grad_out), _lib.ptr(filter_bank), mq,
+                                            mn, E, v, f, _lib.ptr(gvals), _lib.ptr(gf), _lib.ptr(ws), ws.numel(), main), "ln_conv_backward")
+        finally:
+            if part is not None:
+                lib.ln_conv_row_partition(None)
         return gvals, gf
 
     def convolve_im2row_grad_filter(self, grad_out: torch.Tensor, dilation: int, lattice_neighbours: Optional["Lattice"],
@@ -1164,6 +1240,17 @@ class Lattice:
                                                                      self._stream()), "ln_slice_forward_f16_prepare_backward")
             return out
         out = torch.empty((n, self.val_dim()), dtype=torch.float32, device=self._dev())
+        # indices written by the last build of this table, whose rows follow space: take the points in the order of that build's CSR,
+        # so that the rows a workgroup gathers sit in one kd region / one XCD's L2 (ln_slice_forward_ordered; bit-identical rows)
+        st = self.m_hash_table._storage
+        hit = st.csr_cache.get((idx.data_ptr(), idx._version, idx.numel())) if (st is not None and st.rows_follow_space and _ORDERED_SLICE[0]) else None
+        if hit is not None and hit[3] is not None:
+            t = self.m_hash_table.c_table()
+            _lib.check(lib.ln_slice_forward_ordered(C.byref(t), C.byref(hit[1]), _lib.ptr(vals), _lib.ptr(idx), _lib.ptr(w), n, self.val_dim(),
+                                                    _lib.ptr(out), _lib.ptr(grad_accumulator),
+                                                    0 if grad_accumulator is None else grad_accumulator.numel(), self._stream()),
+                       "ln_slice_forward_ordered")
+            return out
         if grad_accumulator is None:
             _lib.check(lib.ln_slice_forward(_lib.ptr(vals), _lib.ptr(idx), _lib.ptr(w), n, self.pos_dim(), self.val_dim(), _lib.ptr(out),
                                             self._stream()), "ln_slice_forward")
@@ -1385,8 +1472,10 @@ class Lattice:
         ht._static_levels = None if coarse_bounds is None else {self.m_lvl + 1 + k: int(b) for k, b in enumerate(coarse_bounds)}
 
     def set_region_planes(self, planes):
-        """kd split planes of key space (7 ints, see LnCsr.planes) or None.  With planes, the builds of this lattice file the
-        CSR segments of every vertex under one of 8 compact regions and the scatter kernels let XCD r walk region r."""
+        """kd split planes of key space (2^levels - 1 ints in heap order, levels 3..6: see LnTable.planes) or None.  With planes, the
+        builds of this lattice file the CSR segments of every vertex under one of 8 compact regions (the top three levels) and the
+        scatter kernels let XCD r walk region r; under set_slot_order("space") (the default) the planes also order the SLOTS — and
+        with them the rows — of the table by space, from the next build that starts with a clear on (LnTable.planes)."""
         st = self.m_hash_table._storage
         if st is None:
             raise _lib.LatticeNetHipError("build the lattice once before setting region planes")
@@ -1394,18 +1483,26 @@ class Lattice:
             st.planes = None
             return
         p = torch.as_tensor(planes, dtype=torch.int32).reshape(-1)
-        if p.numel() != 7:
-            raise ValueError("region planes: 7 ints (1 + 2 + 4 thresholds)")
+        if p.numel() not in (7, 15, 31, 63):
+            raise ValueError("region planes: 2^levels - 1 ints in heap order (7 = 1 + 2 + 4 thresholds, ... 63), levels 3 to 6")
         st.planes = torch.cat([p, torch.zeros(1, dtype=torch.int32)]).to(self._dev())
+        _PLANES_KEEPALIVE.append(st.planes)  # captured graphs hold the raw pointer (a few hundred bytes per calibration)
 
-    def balanced_region_planes(self, idx: torch.Tensor):
-        """Planes that split the vertices of the CURRENT build into 8 regions of equal token load: weighted medians of
-        key[0], then key[1] inside each half, then key[2] inside each quarter (host-side calibration helper)."""
+    def balanced_region_planes(self, idx: torch.Tensor, levels: int = 3, vertex_weight: float = 0.0):
+        """Planes of a kd partition of the vertices of the CURRENT build into 2^levels leaves of equal load (host-side calibration
+        helper): weighted medians of key[0], then key[1 % d] inside each half, ... — level l splits on key[l % d].  The load of a
+        vertex is its token count + vertex_weight x the mean token count: 0 (default) balances tokens — what the bucket pass of the
+        build, the segment walks and the slice spend their time on; larger values trade that for equal vertex counts per leaf."""
+        import numpy as np
+        if not 3 <= int(levels) <= 6:
+            raise ValueError("levels must be 3 .. 6")
         m = self.nr_lattice_vertices()
         keys = self.m_hash_table._storage.keys[:m].cpu().numpy().astype("int64")
         wts = self.vertex_point_counts(idx).cpu().numpy().astype("float64")
-        import numpy as np
+        if vertex_weight > 0 and m > 0:
+            wts = wts + vertex_weight * float(wts.mean())
         d = keys.shape[1]
+        planes = [0] * ((1 << int(levels)) - 1)
 
         def wmedian(vals, w):
             if len(vals) == 0:
@@ -1414,16 +1511,16 @@ class Lattice:
             cs = np.cumsum(w[order])
             return int(vals[order][min(np.searchsorted(cs, cs[-1] / 2.0), len(vals) - 1)])  # region test is key >= plane
 
-        planes = [0] * 7
-        planes[0] = wmedian(keys[:, 0], wts)
-        half = (keys[:, 0] >= planes[0]).astype(int)
-        for h in range(2):
-            sel = half == h
-            planes[1 + h] = wmedian(keys[sel, 1 % d], wts[sel])
-        quarter = 2 * half + (keys[:, 1 % d] >= np.where(half == 1, planes[2], planes[1])).astype(int)
-        for q in range(4):
-            sel = quarter == q
-            planes[3 + q] = wmedian(keys[sel, 2 % d], wts[sel])
+        def split(sel, node, lvl):
+            if lvl == levels:
+                return
+            ax = lvl % d
+            planes[node] = wmedian(keys[sel, ax], wts[sel])
+            hi = keys[sel, ax] >= planes[node]
+            split(sel[~hi], 2 * node + 1, lvl + 1)
+            split(sel[hi], 2 * node + 2, lvl + 1)
+
+        split(np.arange(m), 0, 0)
         return planes
 
     def static_build_report(self):

@@ -30,10 +30,12 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 
 def test_struct_layout_matches_header():
-    # int, int, 8 pointers, int, int, int (+4 padding) -> 88 bytes on LP64
-    assert C.sizeof(_lib.LnTable) == 88
+    # int, int, 8 pointers, int, int, int (+4 padding), pointer, int (+4 padding), pointer -> 112 bytes on LP64
+    assert C.sizeof(_lib.LnTable) == 112
     assert [f[0] for f in _lib.LnTable._fields_] == ["capacity", "pos_dim", "slot_keys", "slot_tok", "slot_cnt", "entries", "keys",
-                                                     "nr_filled", "status", "host_counters", "host_seq", "key_format", "row_limit"]
+                                                     "nr_filled", "status", "host_counters", "host_seq", "key_format", "row_limit",
+                                                     "planes", "plane_levels", "row_regions"]
+    assert _lib.LnTable.planes.offset == 88 and _lib.LnTable.row_regions.offset == 104
     assert C.sizeof(_lib.LnCsr) == 56  # 4 pointers + seg_region + planes + the dense hint (int, padded)
 
 
