@@ -77,6 +77,9 @@ def compact_line(full: dict, details_file: str = "bench_details.json") -> dict:
         line["cpu_baseline"]["sample"] = line["cpu_baseline"]["sample"][:160]
     optional = []  # (key, value), most important first
     optional.append(("value_8d_one_pass_mpoints_per_s", full.get("value_8d_one_pass_mpoints_per_s")))
+    optional.append(("value_no_prewarm", full.get("value_no_prewarm")))
+    rc = full.get("roofline_chain")
+    optional.append(("roofline_chain", _pick(rc, ("algorithmic_bytes", "traffic_bytes", "frac_one_pass", "frac_in_flight")) if rc else None))
     st = full.get("stages") or {}
     ss = {}
     for key, short in (("splat_plus_slice", "one_scan"), ("splat_plus_slice_in_flight", "in_flight")):
@@ -88,7 +91,7 @@ def compact_line(full: dict, details_file: str = "bench_details.json") -> dict:
     lat = full.get("latency") or {}
     optional.append(("latency_us", _pick(lat, ("us_per_scan_median", "eager_us_per_scan")) or None))
     un = full.get("full_unet") or {}
-    unet = _pick(un, ("ms_per_step",))
+    unet = _pick(un, ("ms_per_step", "algorithmic_floor_ms"))
     if isinstance(un.get("graph"), dict) and "ms_per_step" in un["graph"]:
         unet["graph_ms_per_step"] = un["graph"]["ms_per_step"]
     optional.append(("full_unet_ms", unet or None))
@@ -203,7 +206,7 @@ KERNEL_GROUPS = {"hash_build": ["k_point_keys", "k_bucket_rows"]}  # launches th
 
 def pmc_traffic(kernel: str):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r<round>_pmc_traffic.json, newest round), or None."""
-    for rnd in (5, 4, 3, 2, 1):
+    for rnd in (6, 5, 4, 3, 2, 1):
         path = os.path.join(ROOT, "profiles", f"r{rnd}_pmc_traffic.json")
         try:
             with open(path) as f:
@@ -222,6 +225,34 @@ def pmc_traffic(kernel: str):
         if total is not None:
             return total
     return None
+
+
+CHAIN_KERNELS = ("k_point_keys", "k_bucket_rows", "k_reduce_and_neighbours", "k_conv_forward_b3", "k_slice_forward", "k_csr_reduce_segments",
+                 "k_conv_backward_fused_b3", "k_reduce_slabs4")
+
+
+def chain_traffic():
+    """(HBM bytes per C3 step summed over the 8 launches of the chain, file) from the newest committed PMC table, or (None, None)."""
+    for rnd in (6, 5, 4, 3):
+        path = os.path.join(ROOT, "profiles", f"r{rnd}_pmc_traffic.json")
+        try:
+            with open(path) as f:
+                table = json.load(f)
+        except OSError:
+            continue
+        vals = [(table.get(k) or {}).get("traffic_bytes") for k in CHAIN_KERNELS]
+        if all(x is not None for x in vals):
+            return int(sum(vals)), os.path.relpath(path, ROOT)
+    return None, None
+
+
+def chain_algorithmic_bytes(n, m, d, v, f, e):
+    """SURVEY 8(d) / BASELINE.md: splat fwd + neighbour list + conv fwd + slice fwd + slice bwd + conv bwd (2 x conv fwd): 118 MB at C3."""
+    splat = n * (4.0 * d + 4.0 * v + 8.0 * (d + 1)) + m * (4.0 * d + 4.0 * v)
+    slc = n * (8.0 * (d + 1) + 4.0 * v) + m * 4.0 * v
+    nbr = m * (4.0 * d + 4.0 * e)
+    conv = m * (4.0 * v + 4.0 * e + 4.0 * f) + 4.0 * e * v * f
+    return splat + nbr + 3.0 * conv + 2.0 * slc
 
 
 def cpu_baseline(cfg, seconds: float, threads: int = 0, min_steps: int = 3):
@@ -325,6 +356,14 @@ def full_unet_step(dev, n: int, steps: int = 10, warmup: int = 3, classes: int =
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
+    floor = None
+    try:  # what the lattice operators of this step would cost at their SURVEY 8(d) rooflines (tools/lattice_op_floor.py)
+        from tools import lattice_op_floor
+        traced = lattice_op_floor.trace(step, Lattice)
+        torch.cuda.synchronize()
+        floor = lattice_op_floor.price(traced, vertices_per_point_level=lattice.nr_lattice_vertices() if lattice.m_hash_table.is_initialized() else None)
+    except Exception as exc:  # a secondary figure
+        floor = {"error": f"{type(exc).__name__}: {exc}"[:200]}
     gc_was_on = gc.isenabled()
     gc.collect()
     gc.disable()  # generation-2 passes over the live module / autograd objects cost milliseconds per step otherwise
@@ -339,7 +378,9 @@ def full_unet_step(dev, n: int, steps: int = 10, warmup: int = 3, classes: int =
             gc.enable()
     out = {"what": "LNN training step (forward + NLL + backward + AdamW), reference SemanticKITTI model shape, same 120k-point scan",
            "ms_per_step": round(dt * 1e3, 3), "mpoints_per_s": round(n / dt / 1e6, 2), "parameters": sum(p.numel() for p in net.parameters()),
-           "steps": steps}
+           "steps": steps, "algorithmic_floor_ms": floor.get("floor_ms") if floor else None,
+           "algorithmic_floor": floor, "algorithmic_floor_what": "sum over the lattice operators of the step (SURVEY 8(a) rows: builds, distribute, convolutions "
+           "forward + backward, slice / gather / slice_classify) of max(8(d) bytes / 8 TB/s, flop / 157.3 TFLOP/s); GroupNorm, MLP, loss and optimizer are not in it"}
     # The same step with forward + loss + backward captured as ONE hipGraph (lattice_net_amd.CapturedNetworkStep: static row bounds
     # on every lattice level, GroupNorm over the device-side vertex count), timed by tools/bench_lnn.py in a CHILD
     # process: a secondary number must not be able to take the headline down with it.
@@ -398,10 +439,10 @@ def main():
     ap.add_argument("--regions", type=int, default=int(os.environ.get("LN_BENCH_REGIONS", "1")),
                     help="1 (default, graph mode): kd region planes (calibrated on a cloud OUTSIDE the pool) so that the scatter kernels walk "
                          "one compact region of the lattice per XCD")
-    ap.add_argument("--slot-order", default=os.environ.get("LATTICE_SLOT_ORDER", "space"), choices=["space", "hash"],
-                    help="space (default): the kd planes also order the SLOTS of the table, so that rows follow space (LnTable.planes: XCD-local "
-                         "gathers in the convolutions and the slice); hash: planes steer the segment walks only (rounds 2-5; A/B)")
-    ap.add_argument("--plane-levels", type=int, default=int(os.environ.get("LN_BENCH_PLANE_LEVELS", "3")), help="depth of the kd partition (3..6)")
+    ap.add_argument("--slot-order", default=os.environ.get("LATTICE_SLOT_ORDER", "hash"), choices=["space", "hash"],
+                    help="hash (default): the kd planes steer the segment walks only; space: they also order the SLOTS of the table, so that rows "
+                         "follow space (LnTable.slot_map: XCD-local gathers in the convolutions — 48 MB less HBM traffic per step and no gain in "
+                         "time, DESIGN.md 8; A/B)")
     ap.add_argument("--row-slack", type=float, default=0.06,
                     help="graph mode: static row bound = largest vertex count of the calibration clouds x (1 + slack), rounded up to 256")
     args = ap.parse_args()
@@ -426,7 +467,6 @@ def main():
     from lattice_net_amd.capture import CapturedStep, concurrent_streams
     from lattice_net_amd import lattice as _lattice_mod
     _lattice_mod.set_slot_order(args.slot_order)
-    os.environ["LATTICE_PLANE_LEVELS"] = str(args.plane_levels)
     lib = L.load_library()
     if not args.autograd_threads:
         # run backward on the calling thread: the hand-off to torch's per-device autograd worker costs tens of
@@ -556,6 +596,17 @@ def main():
         barrier()
         errs = [cs.check() for cs in sets]  # ... compared with the eager results before anything is timed
         graph_err = {k: max(er[k] for er in errs) for k in errs[0]}
+    value_no_prewarm = None
+    if args.prewarm_ms > 0 and graph_mode:  # the same W + K steps ONCE before the pre-warm (the driver's command on a chip that idled through set-up)
+        for i in range(max(args.warmup, in_flight)):
+            sets[i % in_flight].launch(i // in_flight)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            sets[i % in_flight].launch(i // in_flight)
+        barrier()
+        el0 = sharding.min_max_over_ranks(dist, time.perf_counter() - t0, dev)[1]
+        value_no_prewarm = round(n * world * args.steps / el0 / 1e6, 3)
     prewarm_steps = 0
     if args.prewarm_ms > 0:  # part of the set-up, like capture and validation: brings the GPU to the clocks of sustained load
         t_pre = time.perf_counter()
@@ -818,6 +869,15 @@ def main():
                 ops_table = ops_roofline.run(dev, reps=24)
             except Exception as exc:
                 ops_table = {"error": f"{type(exc).__name__}: {exc}"}
+        roofline_chain = None
+        if args.workload == "C3":
+            cb = chain_algorithmic_bytes(n, m, d, v, f, e)
+            tb, tfile = chain_traffic()
+            step_s = max_elapsed / args.steps
+            roofline_chain = {"algorithmic_bytes": int(cb), "traffic_bytes": tb, "traffic_from": tfile,
+                              "frac_in_flight": round(cb / step_s / 1e9 / HBM_PEAK_GBS, 4),
+                              "frac_one_pass": round(cb / (latency["us_per_scan_median"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if latency else None,
+                              "traffic_over_algorithmic": round(tb / cb, 2) if tb else None}
         exec_desc = (f"{in_flight} independent scan(s) in flight per GPU (own lattice, stream and {pool} clouds each); every step = one hipGraph "
                      f"replay of the whole forward + backward on the next cloud of the scan's pool; value = points of all K steps / wall time"
                      if graph_mode else "eager: one Python autograd pass per step")
@@ -834,12 +894,14 @@ def main():
             "value_definition": f"throughput: {in_flight} scan(s) in flight per GPU, hipGraph replays (config.workload); the SURVEY 8(d) number — one "
                                 "pass at a time, hipEvent median — is value_8d_one_pass_mpoints_per_s = latency.mpoints_per_s",
             "value_8d_one_pass_mpoints_per_s": latency["mpoints_per_s"] if latency else None,
+            "value_no_prewarm": value_no_prewarm,
+            "roofline_chain": roofline_chain,
             "config": {"workload": cfg["desc"] + f"; THROUGHPUT definition: {exec_desc}.  The latency of one scan alone is `latency`",
                        "points_per_gpu": n, "vertices": m, "val_dim": v, "nr_filters": f,
                        "sharding": f"{world} rank(s), independent clouds per GPU", "checksum": round(checksum, 3),
                        "scans_in_flight": in_flight, "clouds_per_scan_pool": pool,
                        "prewarm": f"{prewarm_steps} untimed replays ({args.prewarm_ms:g} ms) before the W warm-up steps" if prewarm_steps else None, "kd_regions": bool(args.regions and graph_mode),
-                       "slot_order": args.slot_order if (args.regions and graph_mode) else "hash", "plane_levels": args.plane_levels,
+                       "slot_order": args.slot_order if (args.regions and graph_mode) else "hash",
                        "row_bounds": [cs.cap.bounds[0] for cs in sets] if graph_mode else None,
                        "bounds_and_planes_calibrated_on": "2 clouds per scan that are not in its pool" if graph_mode else None,
                        "vertices_per_scan": m_all, "graph_vs_eager": graph_err},

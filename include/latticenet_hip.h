@@ -43,6 +43,7 @@ extern "C" {
                                        re-run it with LN_BUILD_ATOMIC_PATH (whose inserts spill past a full bucket) */
 
 #define LN_MAX_POS_DIM 6
+#define LN_SLOT_MAP_INTS 32 /* ints behind LnTable.slot_map */
 #define LN_KEYS_RAW 0     /* LnTable.key_format */
 #define LN_KEYS_LATTICE 1
 #define LN_NOT_VISITED (-2)          /* neighbour-list code: traversal never looks at this slot */
@@ -79,17 +80,21 @@ typedef struct LnTable {
                                       leaves vertices that would get a row >= row_limit un-inserted — idx = -1, no entries[] /
                                       keys[] row — so that no consumer can index past the host's tensors; nr_filled still
                                       counts them, which is how the host notices (nr_filled > row_limit) */
-    const int* planes;             /* NULL, or 2^plane_levels - 1 device ints: a kd partition of KEY space that orders the SLOTS (and
-                                      with them the rows) of this table by space.  Heap order: node i has the children 2i+1 (key below
-                                      the plane) and 2i+2 (key >= plane), level l compares key[l % pos_dim].  A key starts probing in
-                                      the run of whole buckets that belongs to its leaf (the hash picks the slot inside the run), rows
-                                      are numbered bucket by bucket, so the vertices of a leaf own one contiguous row range and the
-                                      gathers of the path (9 neighbour rows per vertex, d+1 rows per point) stay inside one XCD's L2.
-                                      The planes must stay what they were when the table's contents were inserted (retrieval uses the
-                                      same function); change them only in front of a build that starts with a clear.  Unbalanced planes
-                                      overfill buckets (LN_STATUS_BUCKET_OVERFLOW -> the atomic path, which spills); balanced ones
-                                      come from the host's calibration (Lattice.balanced_region_planes).  See csrc/ln_common.h */
-    int plane_levels;              /* 3 .. 6 (fewer levels are used when the bucket count is not a multiple of 2^plane_levels) */
+    const int* slot_map;           /* NULL (slots hashed over the whole table, as the reference), or LN_SLOT_MAP_INTS device ints that
+                                      order the SLOTS — and with them the rows — of this table by space:
+                                        [0..6]   planes of a 3-level kd partition of KEY space into 8 leaves, heap order (node i has the
+                                                 children 2i+1: key below the plane, 2i+2: key >= plane; level l compares key[l % pos_dim]);
+                                        [7]      buckets per leaf = ln_table_bucket_count(capacity) / 8;
+                                        [8..16]  first slot of each leaf's run of slots, then the end of the last run (<= capacity);
+                                        [17..24] slots per bucket inside each leaf (run length = [7] x this).
+                                      A key starts probing inside its leaf's run (the hash picks the slot), rows are numbered bucket by
+                                      bucket, so the vertices of a leaf own one contiguous row range and the gathers of the path (9
+                                      neighbour rows per vertex, d+1 rows per point) stay inside one XCD's L2.  The map must stay what it
+                                      was when the table's contents were inserted (retrieval uses the same function): change it only in
+                                      front of a build that starts with a clear.  A map whose leaves do not fit the cloud overfills
+                                      buckets (LN_STATUS_BUCKET_OVERFLOW -> rebuild on the atomic path, whose inserts spill); a fitting
+                                      one comes from the host's calibration (Lattice.balanced_region_planes).  csrc/ln_common.h */
+    int bucket_slots_max;          /* with a slot map: the largest of its slots-per-bucket entries (sizes the LDS of the bucket pass) */
     int* row_regions;              /* NULL, or LN_XCD_GROUPS + 1 device ints a bucketed build over a space-ordered table fills: the first row
                                       of each of the 8 top-level kd regions and the row count — the argument of ln_conv_row_partition */
 } LnTable;
@@ -116,7 +121,7 @@ typedef struct LnCsr {
                              build then files every vertex's segments under its region, and the scatter kernels let
                              XCD r walk region r: the d+1 gathers of a point row meet in ONE L2.  These planes only steer
                              work placement (any values are correct).  When the table itself is space-ordered
-                             (LnTable.planes) the region of a vertex is that of its bucket and this array is only a flag. */
+                             (LnTable.slot_map) the region of a vertex is that of its bucket and this array is only a flag. */
     int dense;            /* host-side hint for the segment reduces (any value is correct): non-zero = dense cloud, about 16 or more
                              tokens per vertex — most vertices then own several segments, and the reduce combines partial sums across
                              the waves of a workgroup before it resorts to atomics (C5: 104 -> 84 us; costs the sparse C3 scan 10 %) */
@@ -149,6 +154,10 @@ int ln_table_clear(const LnTable* t, float* values, long long values_elems, void
  * src/HashTable.cu:21-47): `arena` holds `words` 32-bit words; words [minus_begin, minus_end) are set to -1 (the entries), every
  * other word to 0 (keys, slot counters, the device counters, a placeholder values row — carved from the arena by the host). */
 int ln_arena_init(int* arena, long long words, long long minus_begin, long long minus_end, void* stream);
+
+/* Buckets (runs of consecutive slots, one workgroup of the bucketed build each) of a table that hashes into `capacity` slots: what a
+ * host needs to lay out LnTable.slot_map. */
+int ln_table_bucket_count(int capacity);
 
 /* Scratch needed by ln_build_splat / ln_distribute / ln_coarsen for `tokens` insertions. */
 size_t ln_build_workspace_bytes(long long tokens, int capacity);
@@ -312,7 +321,7 @@ int ln_slice_forward_prepare_backward(const float* values, const int* idx, const
                                       float* grad_accumulator, long long grad_accumulator_elems, void* stream);
 /* slice_with_precomputation for the indices a build of `t` wrote, with the points taken in the order of that build's slot CSR (`csr`,
  * as ln_build_splat / ln_distribute filled it; groups = hash slots) instead of input order: over a space-ordered table
- * (LnTable.planes) the d+1 value rows of the points a workgroup slices then sit in one kd region, i.e. in one XCD's L2.  Same
+ * (LnTable.slot_map) the d+1 value rows of the points a workgroup slices then sit in one kd region, i.e. in one XCD's L2.  Same
  * arithmetic per point, bit-identical output rows.  grad_accumulator (may be NULL) as ln_slice_forward_prepare_backward.  Widths the
  * ordered kernel does not cover run ln_slice_forward. */
 int ln_slice_forward_ordered(const LnTable* t, const LnCsr* csr, const float* values, const int* idx, const float* w, int n, int val_dim,

@@ -27,6 +27,7 @@ LN_MAX_POS_DIM = 6
 LN_KEYS_RAW = 0
 LN_KEYS_LATTICE = 1
 LN_XCD_GROUPS = 8
+LN_SLOT_MAP_INTS = 32
 
 
 class LnTable(C.Structure):
@@ -46,8 +47,8 @@ class LnTable(C.Structure):
         ("host_seq", C.c_int),
         ("key_format", C.c_int),
         ("row_limit", C.c_int),
-        ("planes", C.c_void_p),
-        ("plane_levels", C.c_int),
+        ("slot_map", C.c_void_p),
+        ("bucket_slots_max", C.c_int),
         ("row_regions", C.c_void_p),
     ]
 
@@ -86,6 +87,7 @@ SIGNATURES = {
     "ln_profile_end_table": (_i, [C.c_char_p, _i]),
     "ln_table_clear": (_i, [_T, _vp, _ll, _vp]),
     "ln_build_workspace_bytes": (_sz, [_ll, _i]),
+    "ln_table_bucket_count": (_i, [_i]),
     "ln_build_splat": (_i, [_T, _vp, _vp, _i, _vp, _vp, _i, _CSR, _vp, _sz, _vp, _ll, _vp]),
     "ln_rehash": (_i, [_T, _vp]),
     "ln_canonicalize": (_i, [_T, _vp, _ll, _CSR, _vp, _sz, _vp]),

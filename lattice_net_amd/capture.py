@@ -116,7 +116,7 @@ class CapturedStep:
             for li, lat in enumerate(self.lattices):
                 self.vertices[li] = max(self.vertices[li], lat.nr_lattice_vertices())
                 if ci == 0 and regions and region_indices is not None:
-                    lat.set_region_planes(lat.balanced_region_planes(region_indices(), levels=int(os.environ.get("LATTICE_PLANE_LEVELS", "3"))))
+                    lat.calibrate_regions(region_indices(), vertex_weight=float(os.environ.get("LATTICE_PLANE_VERTEX_WEIGHT", "0")))
         if calibration_steps or (regions and region_indices is not None):
             self.result = step()  # the eager reference result of `step` itself, with the regions in place
         torch.cuda.synchronize()

@@ -168,7 +168,6 @@ LN_HD uint32_t ln_hash(const int* key) {
 #endif
 #define LN_BKT_MAX 2048
 #define LN_XCD_GROUPS 8
-#define LN_MAX_PLANE_LEVELS 6
 // At least LN_BKT_MIN_COUNT buckets (one bucket = one workgroup of the build: fewer buckets than CUs leave CUs idle) as long
 // as they keep >= LN_BKT_MIN_SLOTS slots each.
 #ifndef LN_BKT_MIN_COUNT
@@ -197,39 +196,72 @@ LN_HD int ln_bucket_count(int capacity) {
     return (capacity + sb - 1) / sb;
 }
 // ---- space-ordered slots ----------------------------------------------------------------------------------------------
-// A table may carry a kd partition of KEY space (LnTable.planes: heap-ordered split planes, level l compares key[l % d];
-// LnTable.plane_levels levels, 2^levels leaves; balanced ones come from the host's calibration).  The slot function then puts
-// the LEAF of a key into the high part of its slot and hashes only inside the leaf's slot range: the table is cut into
-// 2^levels runs of whole buckets, one per leaf.  Buckets are numbered in slot order and rows bucket by bucket, so ROWS follow
-// space: the vertices of one leaf own one contiguous row range, and with them the value rows every gather of the path reads
-// (9 neighbour rows per vertex in the convolutions, d+1 rows per point in the slice, the segment walks).  A MI355X dispatches
-// workgroup b to XCD b % 8 and each XCD has its own 4 MB L2: kernels that hand XCD x a contiguous eighth of the rows
-// (ln_xcd_chunk_tile) then fetch a value row into ~1.1 L2s instead of into 4.8 of the 8 (tools/probes/slot_order_model.py;
-// profiles/r6_pmc_traffic.json).  Only row ids are reference-visible (PyBridge exposes m_keys / m_nr_filled); retrieval uses
-// the same function, so "every vertex inserted, retrieve finds it" holds as with plain hashing (HashTableGPU.cuh:425-519).
-// The top three levels are the 8 regions of the segment lists (LnCsr): region = leaf >> (levels - 3).
-// Without planes (or with fewer than 2^3 buckets): h0 = hash % capacity, as the reference.
+// A table may carry a SLOT MAP (LnTable.slot_map, LN_SLOT_MAP_INTS device ints written by the host's calibration):
+//   [0..6]   planes of a 3-level kd partition of KEY space into 8 leaves, heap order (node i: children 2i+1 below the plane, 2i+2
+//            at or above it; level l compares key[l % d]) — the same 8 regions the segment lists of LnCsr are filed under;
+//   [7]      buckets per leaf (bucket count / 8);
+//   [8..16]  first slot of each leaf's run of slots (+ the end of the last one: <= capacity, the few slots behind it stay empty);
+//   [17..24] slots per bucket inside each leaf.
+// The slot function then puts the LEAF of a key into the high part of its slot and hashes only inside the leaf's run: a key of
+// leaf r starts probing at start[r] + hash % (start[r + 1] - start[r]), inside the bucket that slot falls in.  Every leaf owns the
+// same NUMBER of buckets and the planes balance the TOKENS of the leaves, so the bucket workgroups of a build see equal token
+// loads; the leaves hold very different numbers of vertices (a LiDAR scan: a few hot vertices next to the sensor, thousands of
+// thin ones far out), so the SIZE of a leaf's buckets follows its vertex share and the load factor — what the probe lengths of
+// inserts and of every retrieval depend on — is the same everywhere.  (Measured with equal bucket sizes, round 6: token-balanced
+// planes left buckets 76 % full — hash build 35 -> 43 us, neighbour traversal 23 -> 45 us; vertex-balanced planes left buckets
+// with 4.5x the mean token count — build 45 us.)
+// Buckets are numbered in slot order and rows bucket by bucket, so ROWS follow space: the vertices of one leaf own one contiguous
+// row range, and with them the value rows every gather of the path reads (9 neighbour rows per vertex in the convolutions, d+1
+// rows per point in the slice).  A MI355X dispatches workgroup b to XCD b % 8 and each XCD has its own 4 MB L2: kernels that let
+// XCD x work on the rows of leaf x (ln_partition_tile) fetch a value row into ~1.1 L2s instead of into 4.8 of the 8
+// (tools/probes/slot_order_model.py; profiles/r6_pmc_traffic.json).  Only row ids are reference-visible (PyBridge exposes
+// m_keys / m_nr_filled); retrieval uses the same function, so "every vertex inserted, retrieve finds it" holds as with plain
+// hashing (HashTableGPU.cuh:425-519).  Without a map: h0 = hash % capacity, as the reference.
+// The map is 25 wave-uniform words: kernels load it with scalar loads into registers and walk the tree with selects — no
+// memory round trip stands between a key and its first probe.
 LN_HD uint32_t ln_stir(uint32_t k) {
     k ^= k >> 15;
     k *= 2246822519u;
     k ^= k >> 13;
     return k;
 }
-// levels of the partition that the slot function of a table with nbk buckets uses (0 = plain hashing): whole buckets per leaf
-LN_HD int ln_slot_levels(bool have_planes, int levels, int nbk) {
-    if (!have_planes || levels < 3) return 0;
-    if (levels > LN_MAX_PLANE_LEVELS) levels = LN_MAX_PLANE_LEVELS;
-    while (levels >= 3 && (nbk % (1 << levels)) != 0) --levels;
-    return levels >= 3 ? levels : 0;
-}
-// leaf of a key under the first `levels` levels of the kd partition (levels <= LN_MAX_PLANE_LEVELS; 0 -> leaf 0)
-template <int D, typename P>
-LN_HD int ln_leaf_of_key(const int* key, P planes, int levels) {
-    int node = 0;
+struct LnSlotMap {  // passed BY VALUE / reference through inlined code only: it has to stay in (scalar) registers
+    bool on;        // false: hashed table, nothing else is meaningful
+    int planes[7];
+    int bpl;
+    int start[LN_XCD_GROUPS + 1];
+    int sb[LN_XCD_GROUPS];
+};
+// p = LnTable.slot_map (nullptr: hashed table -> .on = false)
+LN_HD LnSlotMap ln_load_slot_map(const int* p) {
+    LnSlotMap m;
+    m.on = p != nullptr;
+    const int* q = m.on ? p : nullptr;
 #pragma unroll
-    for (int l = 0; l < LN_MAX_PLANE_LEVELS; ++l)
-        if (l < levels) node = 2 * node + 1 + ((key[l % D] >= planes[node]) ? 1 : 0);
-    return node - ((1 << levels) - 1);
+    for (int i = 0; i < 7; ++i) m.planes[i] = m.on ? q[i] : 0;
+    m.bpl = m.on ? q[7] : 1;
+#pragma unroll
+    for (int i = 0; i <= LN_XCD_GROUPS; ++i) m.start[i] = m.on ? q[8 + i] : 0;
+#pragma unroll
+    for (int i = 0; i < LN_XCD_GROUPS; ++i) m.sb[i] = m.on ? q[17 + i] : 1;
+    return m;
+}
+// a[leaf] for an array that lives in registers (a dynamic index would send it to scratch memory): three levels of selects
+LN_HD int ln_sel8(const int* a, int leaf) {
+    const int b0 = leaf & 1, b1 = leaf & 2, b2 = leaf & 4;
+    const int x0 = b0 ? a[1] : a[0], x1 = b0 ? a[3] : a[2], x2 = b0 ? a[5] : a[4], x3 = b0 ? a[7] : a[6];
+    const int y0 = b1 ? x1 : x0, y1 = b1 ? x3 : x2;
+    return b2 ? y1 : y0;
+}
+// leaf (= segment region) of a key under the 3-level kd partition `planes` (7 ints in registers, LDS or memory)
+template <int D, typename P>
+LN_HD int ln_leaf_of_key(const int* key, P planes) {
+    const int r0 = (key[0] >= planes[0]) ? 1 : 0;
+    const int p1 = r0 ? planes[2] : planes[1];
+    const int r1 = (key[1 % D] >= p1) ? 1 : 0;
+    const int p2a = r1 ? planes[4] : planes[3], p2b = r1 ? planes[6] : planes[5];
+    const int r2 = (key[2 % D] >= (r0 ? p2b : p2a)) ? 1 : 0;
+    return 4 * r0 + 2 * r1 + r2;
 }
 struct LnProbe {
     int lo, size, off, cap;
@@ -240,38 +272,34 @@ struct LnProbe {
         size = (capacity - lo < sb) ? (capacity - lo) : sb;
         off = h0 - lo;
     }
-    // space-ordered form: `leaf` picks the run of gs slots (whole buckets), `slot_hash` the starting slot inside it
-    LN_HD LnProbe(int leaf, uint32_t slot_hash, int capacity, int sb, int gs) {
-        const int glo = leaf * gs;
-        const int gsz = (capacity - glo < gs) ? (capacity - glo) : gs;
-        const int h0 = glo + int(slot_hash % uint32_t(gsz));
+    // space-ordered form: the key's leaf owns the slots [glo, glo + gsz) in buckets of sbl slots
+    LN_HD LnProbe(int glo, int gsz, int sbl, uint32_t slot_hash, int capacity) {
+        const int o = int(slot_hash % uint32_t(gsz));
         cap = capacity;
-        lo = (h0 / sb) * sb;
-        size = (capacity - lo < sb) ? (capacity - lo) : sb;
-        off = h0 - lo;
+        size = sbl;
+        off = o % sbl;
+        lo = glo + o - off;
     }
-    // `planes` may point to a copy of LnTable.planes in LDS (k_point_keys)
-    template <int D, typename P>
-    static LN_HD LnProbe of_key(const int* key, int capacity, int sb, P planes, int plane_levels) {
-        const int nbk = (capacity + sb - 1) / sb;
-        const int lv = ln_slot_levels(planes != nullptr, plane_levels, nbk);
-        if (lv == 0) return LnProbe(ln_hash<D>(key), capacity, sb);
+    // !m.on: plain hashing
+    template <int D>
+    static LN_HD LnProbe of_key(const int* key, int capacity, int sb, const LnSlotMap& m) {
+        if (!m.on) return LnProbe(ln_hash<D>(key), capacity, sb);
+        const int leaf = ln_leaf_of_key<D>(key, m.planes);
+        const int glo = ln_sel8(m.start, leaf), ghi = ln_sel8(m.start + 1, leaf);
         // (the raw hash is a poor slot hash: 2531011 = 7 * 361573, and e.g. 511 = 7 * 73)
-        return LnProbe(ln_leaf_of_key<D>(key, planes, lv), ln_stir(ln_hash<D>(key)), capacity, sb, (nbk >> lv) * sb);
+        return LnProbe(glo, ghi - glo, ln_sel8(m.sb, leaf), ln_stir(ln_hash<D>(key)), capacity);
     }
     template <int D>
     static LN_HD LnProbe of_key(const int* key, const LnTable& t, int sb) {
-        return of_key<D>(key, t.capacity, sb, t.planes, t.plane_levels);
+        return of_key<D>(key, t.capacity, sb, ln_load_slot_map(t.slot_map));
     }
-    // starting offset of `key` inside bucket b, for a caller that knows the key lives there (the bucket pass): no tree walk
+    // bucket of the key's first probe (the partition pass of the build): leaf * buckets per leaf + bucket inside the leaf
     template <int D>
-    static LN_HD int offset_in_bucket(const int* key, const LnTable& t, int sb, int b) {
-        const int nbk = (t.capacity + sb - 1) / sb;
-        const int lv = ln_slot_levels(t.planes != nullptr, t.plane_levels, nbk);
-        if (lv == 0) return int(ln_hash<D>(key) % uint32_t(t.capacity)) - b * sb;
-        const int bpl = nbk >> lv, gs = bpl * sb, glo = (b / bpl) * gs;
-        const int gsz = (t.capacity - glo < gs) ? (t.capacity - glo) : gs;
-        return glo + int(ln_stir(ln_hash<D>(key)) % uint32_t(gsz)) - b * sb;
+    static LN_HD int bucket_of_key(const int* key, int capacity, int sb, const LnSlotMap& m) {
+        if (!m.on) return int(ln_hash<D>(key) % uint32_t(capacity)) / sb;
+        const int leaf = ln_leaf_of_key<D>(key, m.planes);
+        const int glo = ln_sel8(m.start, leaf), ghi = ln_sel8(m.start + 1, leaf);
+        return leaf * m.bpl + int(ln_stir(ln_hash<D>(key)) % uint32_t(ghi - glo)) / ln_sel8(m.sb, leaf);
     }
     LN_HD int slot(int i) const {
         if (i < size) {
@@ -284,13 +312,40 @@ struct LnProbe {
         return s;
     }
 };
+// Slot range of bucket b (the unit one workgroup of the bucket pass stages in LDS) and the starting offset of a key inside it.
+struct LnBucket {
+    int lo, size, glo, gsz;  // slots [lo, lo + size); the leaf's run [glo, glo + gsz) (gsz = 0: hashed table)
+    // `map` = LnTable.slot_map (memory: b is uniform over the workgroup, so these are a handful of scalar loads; a register copy of the
+    // map indexed by a run-time leaf would be sent to scratch memory)
+    LN_HD LnBucket(int b, int capacity, int sb, const int* map) {
+        if (map == nullptr) {
+            lo = b * sb;
+            size = (capacity - lo < sb) ? (capacity - lo) : sb;
+            glo = 0;
+            gsz = 0;
+        } else {
+            const int bpl = map[7];
+            const int leaf = b / bpl;
+            glo = map[8 + leaf];
+            gsz = map[9 + leaf] - glo;
+            size = map[17 + leaf];
+            lo = glo + (b - leaf * bpl) * size;
+        }
+    }
+    // for a caller that knows the key lives in this bucket: no tree walk
+    template <int D>
+    LN_HD int offset_of(const int* key, int capacity) const {
+        if (gsz == 0) return int(ln_hash<D>(key) % uint32_t(capacity)) - lo;
+        return glo + int(ln_stir(ln_hash<D>(key)) % uint32_t(gsz)) - lo;
+    }
+};
 // segment region (XCD group) of bucket b of a space-ordered table
 LN_HD int ln_region_of_bucket(int b, int nbk) { return int((long long)b * LN_XCD_GROUPS / nbk); }
 
 // Region of a lattice key under the 3-level kd split of key space described at LnCsr.planes (include/latticenet_hip.h).
 template <int D>
 LN_HD int ln_region_of_key(const int* key, const int* planes) {
-    return ln_leaf_of_key<D>(key, planes, 3);
+    return ln_leaf_of_key<D>(key, planes);
 }
 
 #if defined(__HIPCC__)
@@ -346,12 +401,17 @@ __device__ __forceinline__ int ln_partition_tile(int b, int G, const int* __rest
 #if defined(__HIPCC__)
 // HashTableGPU::retrieve (HashTableGPU.cuh:491-519) on packed slots: stop at an empty slot or
 // after 300 mismatching probes.
+// `m`: the table's slot map, loaded by the caller at kernel entry (.on = false: hashed table) — the scalar loads of the map then overlap
+// with the loads in front of the lookup instead of standing between the key and its first probe
 template <int D>
-__device__ __forceinline__ int ln_retrieve(const LnTable& t, const int* key) {
+__device__ __forceinline__ int ln_retrieve(const LnTable& t, const int* key, const LnSlotMap& m) {
     if (!KeyPack<D>::in_range(key, t.key_format)) return -1;  // cannot have been inserted
     const uint64_t pk = KeyPack<D>::pack(key, t.key_format);
-    const LnProbe pr = LnProbe::of_key<D>(key, t, ln_bucket_slots(t.capacity));
+    const LnProbe pr = LnProbe::of_key<D>(key, t.capacity, ln_bucket_slots(t.capacity), m);
     const int limit = t.capacity < LN_MAX_RETRIEVE_CONFLICTS ? t.capacity : LN_MAX_RETRIEVE_CONFLICTS;
+    // One probe per round trip.  (Round 6 tried four slots per trip, examined in probe order: the traversal got SLOWER, 10.2 -> 13.1 us
+    // over hashed slots and 17.5 -> 18.2 us over stirred ones — finished lanes no longer drop out of the later loads, and the kernel
+    // pays per divergent memory access as much as per dependent round trip.)
     for (int conflicts = 0; conflicts < limit; ++conflicts) {
         const int h = pr.slot(conflicts);
         const uint64_t cur = t.slot_keys[h];
@@ -360,6 +420,10 @@ __device__ __forceinline__ int ln_retrieve(const LnTable& t, const int* key) {
         if (cur == pk) return row;
     }
     return -1;
+}
+template <int D>
+__device__ __forceinline__ int ln_retrieve(const LnTable& t, const int* key) {
+    return ln_retrieve<D>(t, key, ln_load_slot_map(t.slot_map));
 }
 #endif
 

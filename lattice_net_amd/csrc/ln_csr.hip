@@ -426,8 +426,13 @@ __global__ void __launch_bounds__(256)
     if ((int)blockIdx.x < reduce_blocks) {
         ln_reduce_body<VEC, HALF, WG>(blockIdx.x, reduce_blocks, a);
     } else {
-        const long long g = (long long)(blockIdx.x - reduce_blocks) * 256 + threadIdx.x;
-        ln_neighbours_body<D>(g, t, query_rows_upper, t, 1.0f, 1, 0, nbr);
+        // whole vertices per workgroup, and over a space-ordered table the vertices of kd region x on XCD x: the 9 lookups of a vertex
+        // land in the slot run of its own region, which then sits in ONE L2 instead of in all eight
+        constexpr int E = 2 * (D + 1) + 1, ROWS = 256 / E;
+        const LnSlotMap smap = ln_load_slot_map(t.slot_map);  // (first: its scalar loads travel with those of the partition)
+        const int tile = ln_partition_tile((int)blockIdx.x - reduce_blocks, (int)gridDim.x - reduce_blocks, t.row_regions, ROWS);
+        if ((int)threadIdx.x < ROWS * E)
+            ln_neighbours_body<D>((long long)tile * (ROWS * E) + threadIdx.x, t, query_rows_upper, t, 1.0f, 1, 0, nbr, smap);
     }
 }
 
@@ -509,7 +514,7 @@ static int ln_splat_tail_impl(const char* who, const LnCsr* csr, const int* grp_
     LN_REQUIRE(d >= 1 && d <= LN_MAX_POS_DIM, LN_ERR_UNSUPPORTED, "%s: pos_dim %d unsupported", who, d);
     hipStream_t st = (hipStream_t)stream;
     const int reduce_blocks = ln_seg_grid(max_segments, a.lanes_per_seg);  // a multiple of LN_XCD_GROUPS
-    const int nbr_blocks = ln_div_up((long long)query_rows_upper * (2 * (d + 1) + 1), 256);
+    const int nbr_blocks = ln_div_up(query_rows_upper, 256 / (2 * (d + 1) + 1));  // whole vertices per workgroup (k_reduce_and_neighbours)
     const dim3 grid(reduce_blocks + nbr_blocks), block(256);
 #define LN_FUSED_LAUNCH(VV, DD, HH)                                                                                                  \
     {                                                                                                                                \

@@ -9,10 +9,10 @@ __device__ __forceinline__ bool ln_coord_is_integer(float v) {
     return !(frac > 0.0001f);  // LatticeGPU.cuh:467
 }
 
-// g = global index over query_rows_upper * E (vertex-major, slot-minor)
+// g = global index over query_rows_upper * E (vertex-major, slot-minor); map_n = tn's slot map in registers (loaded at kernel entry), .on = false: hashed
 template <int D>
 __device__ __forceinline__ void ln_neighbours_body(long long g, const LnTable& tq, int query_rows_upper, const LnTable& tn, float scale,
-                                                   int dilation, int flip, int* __restrict__ nbr) {
+                                                   int dilation, int flip, int* __restrict__ nbr, const LnSlotMap& map_n) {
 #pragma clang fp contract(off)
     constexpr int E = 2 * (D + 1) + 1;
     const int m = int(g / E);
@@ -43,7 +43,7 @@ __device__ __forceinline__ void ln_neighbours_body(long long g, const LnTable& t
             int key[D + 1];
 #pragma unroll
             for (int i = 0; i <= D; ++i) key[i] = int(roundf(kf[i]));
-            result = ln_retrieve<D>(tn, key);
+            result = ln_retrieve<D>(tn, key, map_n);
         }
     } else {
         const bool check = (scale >= 1.0f) || !all_int;  // LatticeGPU.cuh:1547-1554
@@ -68,7 +68,7 @@ __device__ __forceinline__ void ln_neighbours_body(long long g, const LnTable& t
                 int key[D + 1];
 #pragma unroll
                 for (int i = 0; i <= D; ++i) key[i] = int(roundf(nf[i]));
-                result = ln_retrieve<D>(tn, key);
+                result = ln_retrieve<D>(tn, key, map_n);
             }
         }
     }

@@ -179,9 +179,10 @@ extern "C" int ln_slice_forward_prepare_backward(const float* values, const int*
 // build lists the tokens bucket by bucket, and over a space-ordered table (LnTable.planes) bucket by bucket means region by region:
 // here a point is sliced by whoever meets its remainder-0 token in that list, the d+1 rows it reads are rows of the same region (its
 // simplex), and XCD x walks the x-th eighth of the list — a value row is then fetched by ~1.2 L2s instead of 3.3.
-// One wave takes 256 consecutive CSR entries (four coalesced loads), compacts the owners (token % (d+1) == 0) into a private LDS
-// list with ballots, and slices them LPP lanes per point; per point the arithmetic is that of k_slice_forward (same order, same
-// skips: bit-identical rows).  Points whose remainder-0 token never reached the CSR (key out of the packable range, a build that
+// One workgroup takes 256 consecutive CSR entries (one coalesced load), compacts the owners (token % (d+1) == 0, ~64 of them) into
+// an LDS list with ballots, and slices them `chunks` lanes per point, two points per lane group in flight; per point the arithmetic
+// is that of k_slice_forward (same order, same skips: bit-identical rows).  (First version: one WAVE per 256 entries walking its ~64
+// points eight at a time — 1900 waves of eight dependent rounds: 28.6 us against 9.7 us for k_slice_forward.)  Points whose remainder-0 token never reached the CSR (key out of the packable range, a build that
 // overflowed) exist only when the table's status word is non-zero: then — and only then — every workgroup also scans its share of
 // idx[p * (d+1)] < 0 and slices those points the old way (a point met on both paths is written twice with the same row).
 template <int VEC, int DP1>
@@ -190,58 +191,65 @@ __global__ void __launch_bounds__(256)
                             const int* __restrict__ csr_tok, const int* __restrict__ csr_len, const int* __restrict__ status,
                             float* __restrict__ out, float* __restrict__ zero_fill, long long zero_elems) {
     using T = typename VecT<VEC>::type;
-    __shared__ int s_list[4][256];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ int s_list[256];
+    __shared__ int s_wcnt[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     {
-        const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+        const long long g = (long long)blockIdx.x * blockDim.x + tid;
         if (zero_fill) {  // the accumulator the backward pass of this slice will scatter into, zeroed on the way
             const long long threads = (long long)gridDim.x * blockDim.x;
             for (long long i = g; i < zero_elems; i += threads) zero_fill[i] = 0.f;
         }
     }
-    const int lpp = chunks;               // lanes per point (a power of two <= 64: checked by the host)
-    const int ppw = 64 / lpp;             // points per wave and round
-    const int sub = lane / lpp, c = lane - sub * lpp;
-    auto slice_point = [&](int p) {
-        int rows[DP1];
-        float wt[DP1];
+    const int lpp = chunks;      // lanes per point (a power of two <= 64: checked by the host)
+    const int G = 256 / lpp;     // points the workgroup slices side by side
+    const int grp = tid / lpp, c = tid - grp * lpp;
+    // two points per lane group and trip: both sets of d+1 (index, weight) pairs in one round trip, both sets of d+1 row gathers in the next
+    auto slice_two = [&](int p0, int p1) {
+        int rows[2][DP1];
+        float wt[2][DP1];
 #pragma unroll
         for (int r = 0; r < DP1; ++r) {
-            rows[r] = idx[(size_t)p * DP1 + r];
-            wt[r] = w[(size_t)p * DP1 + r];
+            rows[0][r] = idx[(size_t)p0 * DP1 + r];
+            wt[0][r] = w[(size_t)p0 * DP1 + r];
+            rows[1][r] = p1 >= 0 ? idx[(size_t)p1 * DP1 + r] : -1;
+            wt[1][r] = p1 >= 0 ? w[(size_t)p1 * DP1 + r] : 0.f;
         }
-        T v[DP1];
+        T v[2][DP1];
 #pragma unroll
-        for (int r = 0; r < DP1; ++r) v[r] = reinterpret_cast<const T*>(values)[(size_t)(rows[r] >= 0 ? rows[r] : 0) * chunks + c];
-        T acc = ln_zero(T());
+        for (int k = 0; k < 2; ++k)
 #pragma unroll
-        for (int r = 0; r < DP1; ++r)
-            if (rows[r] >= 0) acc = ln_add(acc, ln_mul(v[r], wt[r]));  // same order and the same skips as LatticeGPU.cuh:2567-2591
-        reinterpret_cast<T*>(out)[(size_t)p * chunks + c] = acc;
+            for (int r = 0; r < DP1; ++r) v[k][r] = reinterpret_cast<const T*>(values)[(size_t)(rows[k][r] >= 0 ? rows[k][r] : 0) * chunks + c];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            T acc = ln_zero(T());
+#pragma unroll
+            for (int r = 0; r < DP1; ++r)
+                if (rows[k][r] >= 0) acc = ln_add(acc, ln_mul(v[k][r], wt[k][r]));  // same order and the same skips as LatticeGPU.cuh:2567-2591
+            const int p = k ? p1 : p0;
+            if (p >= 0) reinterpret_cast<T*>(out)[(size_t)p * chunks + c] = acc;
+        }
     };
     const int len = *csr_len;  // entries of the CSR (tokens the build placed)
     const int tile = ln_xcd_chunk_tile(blockIdx.x, gridDim.x);  // XCD x walks the x-th eighth of the list
-    for (long long base = ((long long)tile * 4 + wave) * 256; base < len; base += (long long)gridDim.x * 1024) {
-        int cnt = 0;
+    for (long long base = (long long)tile * 256; base < len; base += (long long)gridDim.x * 256) {  // (one trip: the grid covers the list)
+        const long long e = base + tid;
+        const int tk = e < len ? csr_tok[e] : -1;
+        const bool own = tk >= 0 && (tk % DP1) == 0 && tk / DP1 < n;
+        const unsigned long long mask = __ballot(own);
+        if (lane == 0) s_wcnt[wave] = __popcll(mask);
+        __syncthreads();
+        int before = 0, total = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const long long e = base + k * 64 + lane;
-            const int tk = e < len ? csr_tok[e] : -1;
-            const bool own = tk >= 0 && (tk % DP1) == 0;
-            const unsigned long long mask = __ballot(own);
-            if (own) s_list[wave][cnt + __popcll(mask & ((1ull << lane) - 1ull))] = tk / DP1;
-            cnt += __popcll(mask);
+            const int cw = s_wcnt[k];
+            total += cw;
+            if (k < wave) before += cw;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        for (int j = sub; j < cnt; j += ppw) {
-            const int p = s_list[wave][j];
-            if (p < n) slice_point(p);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();  // (the list is rewritten by the next trip)
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (own) s_list[before + __popcll(mask & ((1ull << lane) - 1ull))] = tk / DP1;
+        __syncthreads();
+        for (int j = grp; j < total; j += 2 * G) slice_two(s_list[j], j + G < total ? s_list[j + G] : -1);
+        __syncthreads();  // (the list and the counts are rewritten by the next trip)
     }
     if (*status != 0) {  // some token of the build never reached the CSR: find the points nobody has met
         const int per = (n + (int)gridDim.x - 1) / (int)gridDim.x;
@@ -253,7 +261,23 @@ __global__ void __launch_bounds__(256)
             while (mask) {  // wave-uniform
                 const int src = __ffsll((long long)mask) - 1;
                 mask &= mask - 1;
-                if (sub == 0) slice_point(pb + src);
+                if ((lane / lpp) == 0) {
+                    // (lanes 0 .. lpp-1 of the wave take the point: c = lane for them only when the wave is a whole number of groups,
+                    // which lpp <= 64 guarantees)
+                    const int cc = lane;
+                    int rows[DP1];
+                    float wt[DP1];
+#pragma unroll
+                    for (int r = 0; r < DP1; ++r) {
+                        rows[r] = idx[(size_t)(pb + src) * DP1 + r];
+                        wt[r] = w[(size_t)(pb + src) * DP1 + r];
+                    }
+                    T acc = ln_zero(T());
+#pragma unroll
+                    for (int r = 0; r < DP1; ++r)
+                        if (rows[r] >= 0) acc = ln_add(acc, ln_mul(reinterpret_cast<const T*>(values)[(size_t)rows[r] * chunks + cc], wt[r]));
+                    reinterpret_cast<T*>(out)[(size_t)(pb + src) * chunks + cc] = acc;
+                }
             }
         }
     }
@@ -279,9 +303,9 @@ extern "C" int ln_slice_forward_ordered(const LnTable* t, const LnCsr* csr, cons
         constexpr int VEC = 4;
         const int chunks = chunks4;
         const long long tokens = (long long)n * (pos_dim + 1);
-        // one workgroup per 1024 CSR entries, capped so that every XCD's share stays a multiple of whole workgroups per CU
-        int grid = ln_div_up(tokens, 1024);
-        if (grid > 4096) grid = 4096;
+        // one workgroup per 256 CSR entries (~64 owners: two trips of the 32 lane groups at 32 channels)
+        int grid = ln_div_up(tokens, 256);
+        if (grid > 65536) grid = 65536;
         if (grid < 1) grid = 1;
         switch (pos_dim) { LN_SLICE_ORD_CASE(1) LN_SLICE_ORD_CASE(2) LN_SLICE_ORD_CASE(3) LN_SLICE_ORD_CASE(4) LN_SLICE_ORD_CASE(5) LN_SLICE_ORD_CASE(6) }
     }

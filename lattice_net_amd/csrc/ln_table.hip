@@ -434,13 +434,12 @@ __global__ void __launch_bounds__(TH)
     __shared__ unsigned long long s_stage_pk[PTS_PER_BLOCK * (D + 1)];
     __shared__ int s_stage_tok[PTS_PER_BLOCK * (D + 1)];
     __shared__ int s_stage_dst[PTS_PER_BLOCK * (D + 1)];
-    __shared__ int s_planes[1 << LN_MAX_PLANE_LEVELS];  // the table's kd planes (space-ordered slots): d+1 walks of the tree per point
     int* cursor = t.slot_cnt;
     LN_STAMP(0);
     for (int b = threadIdx.x; b < nbk; b += TH) s_cnt[b] = 0;
-    const int slot_levels = ln_slot_levels(t.planes != nullptr, t.plane_levels, nbk);
-    if (slot_levels && threadIdx.x < (1 << slot_levels) - 1) s_planes[threadIdx.x] = t.planes[threadIdx.x];
-    __syncthreads();
+    // space-ordered slots: the table's slot map in registers (25 wave-uniform words: scalar loads), walked d+1 times per point
+    const LnSlotMap smap = ln_load_slot_map(t.slot_map);
+    ln_lds_barrier();
     LN_STAMP(1);
     unsigned long long pk[PTS][RH];
     int bkt[PTS][RH];
@@ -472,7 +471,7 @@ __global__ void __launch_bounds__(TH)
             const bool ok = lat_fmt ? KeyPack<D>::lattice_in_range(key, r) : KeyPack<D>::in_range(key, t.key_format);
             if (ok) {
                 pk[it][k] = lat_fmt ? KeyPack<D>::lattice_pack(key, r) : KeyPack<D>::pack(key, t.key_format);
-                bkt[it][k] = LnProbe::of_key<D>(key, t.capacity, sb, slot_levels ? s_planes : (const int*)nullptr, slot_levels).lo / sb;
+                bkt[it][k] = LnProbe::bucket_of_key<D>(key, t.capacity, sb, smap);
                 rank[it][k] = atomicAdd(&s_cnt[bkt[it][k]], 1);
             } else {
                 bad_key = true;
@@ -626,8 +625,12 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
     }
     ln_lds_barrier();
     const int b = s_ticket;
-    const int lo = b * sb;
-    const int size = min(sb, t.capacity - lo);
+    // slot range of this bucket: b * sb for a hashed table; under a slot map the leaf's run cut into the leaf's own bucket size
+    // (`sb` is then the LARGEST bucket of the table: what the LDS arrays above are carved for)
+    const bool mapped = t.slot_map != nullptr;
+    const LnBucket bk(b, t.capacity, sb, t.slot_map);
+    const int lo = bk.lo;
+    const int size = bk.size;
     // CSR offset of this bucket = tokens of all buckets before it.  The cursors of the earlier buckets and the bucket's own are
     // fetched together (one round trip), the register-resident tokens behind them (fetching those unconditionally, 4 x 1024 entries
     // whatever the cursor says, saved the dependency and cost more in reads: 20.2 -> 21.3 us).
@@ -670,7 +673,7 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
         if (valid) {
             int key[D];
             KeyPack<D>::unpack(pk, key, t.key_format);
-            int o = LnProbe::offset_in_bucket<D>(key, t, sb, b);
+            int o = bk.offset_of<D>(key, t.capacity);
             for (int i = 0; i < size; ++i) {
                 unsigned long long cur = skeys[o];
                 if (cur == LN_EMPTY_KEY) {
@@ -818,7 +821,7 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
     // contiguous run of the bucket's region.  Region planes over a hashed table: every slot files its segments under the kd region
     // of its key (sseg[i] becomes region << 28 | position among this bucket's segments of that region; one returning global atomic
     // per (bucket, region)).
-    const bool slot_ordered = ln_slot_levels(t.planes != nullptr, t.plane_levels, nbk) != 0;
+    const bool slot_ordered = mapped;
     const int bucket_region = (slot_ordered && csr.planes) ? ln_region_of_bucket(b, nbk) : 0;
     const int* planes = slot_ordered ? nullptr : csr.planes;
     if (planes) {
@@ -906,6 +909,13 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
             reinterpret_cast<int4*>(csr.seg_desc)[sid] = make_int4(row, beg + e, c - e, e);  // {ROW, first entry, entries to the end, offset}
     }
     if (b == nbk - 1) {  // close the build
+        // (a slot map may leave a few slots behind its last run: they stay empty, and every slot array says so)
+        for (int h = lo + size + tid; h < t.capacity; h += LN_BKT_THREADS) {
+            csr.grp_start[h] = base + ntok;
+            t.slot_keys[h] = LN_EMPTY_KEY;
+            t.entries[h] = -1;
+            t.slot_tok[h] = LN_EMPTY_TOK;
+        }
         if (tid == 0) {
             csr.grp_start[t.capacity] = base + ntok;
             const int total = base_row + new_here;
@@ -1163,6 +1173,8 @@ static int ln_bucket_region(long long tokens, int capacity) {
     return int(capb);
 }
 
+extern "C" int ln_table_bucket_count(int capacity) { return capacity > 0 ? ln_bucket_count(capacity) : 0; }
+
 extern "C" size_t ln_build_workspace_bytes(long long tokens, int capacity) {
     if (tokens < 1) tokens = 1;
     if (capacity < 1) capacity = 1;
@@ -1320,7 +1332,8 @@ static int ln_build_points(const LnTable* t, const float* positions_raw, const f
     // the clearing itself (no k_table_clear launch).  Its cursors use the first nbk+1 words of slot_cnt.
     // Beyond LN_BKT_MAX buckets the buckets grow instead; one bucket's staging area has to fit the 160 KB of LDS of a gfx950 CU
     // (tables past ~8.7M slots — 36 bytes of LDS per slot of a bucket, LN_BKT_LDS_LIMIT — take the atomic path).
-    const size_t bucket_lds = (size_t)ln_bucket_slots(t->capacity) * LN_BKT_LDS_PER_SLOT + LN_BKT_LDS_EXTRA;
+    const int sb_lds = (t->slot_map && t->bucket_slots_max > 0) ? t->bucket_slots_max : ln_bucket_slots(t->capacity);  // largest bucket staged in LDS
+    const size_t bucket_lds = (size_t)sb_lds * LN_BKT_LDS_PER_SLOT + LN_BKT_LDS_EXTRA;
     const bool bucketed = n > 0 && (flags & LN_BUILD_CLEAR_FIRST) && !(flags & LN_BUILD_ATOMIC_PATH) &&
                           t->capacity > ln_bucket_count(t->capacity) && bucket_lds <= LN_BKT_LDS_LIMIT &&
                           (long long)ln_bucket_count(t->capacity) * ln_bucket_region(tokens, t->capacity) < 0x7FFFFFFFll;  // int region offsets
@@ -1335,8 +1348,9 @@ static int ln_build_points(const LnTable* t, const float* positions_raw, const f
     LN_DISPATCH_D(t->pos_dim, {
         LnScale<D> sc = ln_make_scale<D>(sigmas_host);
         if (bucketed) {
-            const int sb = ln_bucket_slots(t->capacity);
-            const int nbk = ln_bucket_count(t->capacity);
+            const int sb = sb_lds;  // (hashed table: THE bucket size; slot map: the largest one — the kernels take each bucket's size from the map)
+            // (slot map: 8 leaves x the same number of buckets — ln_bucket_count / 8 each, as the host laid the map out)
+            const int nbk = t->slot_map ? (ln_bucket_count(t->capacity) / LN_XCD_GROUPS) * LN_XCD_GROUPS : ln_bucket_count(t->capacity);
             const size_t lds = bucket_lds;
             int* dropped_idx = write_idx ? idx : (int*)nullptr;  // tokens that never reach a bucket get idx = -1 in pass 1
             // the same 512-point tile (the same number of cursor atomics) on 512 threads (a whole point each), 1024 (half a point each) or
@@ -1467,7 +1481,12 @@ extern "C" int ln_coarsen(const LnTable* fine, int fine_rows_upper, const LnTabl
 template <int D>
 __global__ void __launch_bounds__(256)
     k_neighbours(LnTable tq, int query_rows_upper, LnTable tn, float scale, int dilation, int flip, int* __restrict__ nbr) {
-    ln_neighbours_body<D>((long long)blockIdx.x * blockDim.x + threadIdx.x, tq, query_rows_upper, tn, scale, dilation, flip, nbr);
+    // whole vertices per workgroup; same table on both sides and space-ordered: the vertices of kd region x on XCD x (see k_reduce_and_neighbours)
+    constexpr int E = 2 * (D + 1) + 1, ROWS = 256 / E;
+    const LnSlotMap smap = ln_load_slot_map(tn.slot_map);  // (first: its scalar loads travel with those of the partition)
+    const int tile = ln_partition_tile((int)blockIdx.x, (int)gridDim.x, tq.entries == tn.entries ? tq.row_regions : nullptr, ROWS);
+    if ((int)threadIdx.x < ROWS * E)
+        ln_neighbours_body<D>((long long)tile * (ROWS * E) + threadIdx.x, tq, query_rows_upper, tn, scale, dilation, flip, nbr, smap);
 }
 
 extern "C" int ln_neighbours(const LnTable* query, int query_rows_upper, const LnTable* neigh, int lvl_query, int lvl_neigh,
@@ -1486,9 +1505,8 @@ extern "C" int ln_neighbours(const LnTable* query, int query_rows_upper, const L
     if (query_rows_upper <= 0) return LN_OK;
     const float scale = diff == 0 ? 1.0f : (diff > 0 ? 2.0f : 0.5f);  // pow(2, lvl_diff), LatticeGPU.cuh:1488
     const int E = 2 * (query->pos_dim + 1) + 1;
-    const long long work = (long long)query_rows_upper * E;
     LN_DISPATCH_D(query->pos_dim, {
-        LN_LAUNCH("k_neighbours", k_neighbours<D>, dim3(ln_div_up(work, 256)), dim3(256), 0, (hipStream_t)stream, *query,
+        LN_LAUNCH("k_neighbours", k_neighbours<D>, dim3(ln_div_up(query_rows_upper, 256 / E)), dim3(256), 0, (hipStream_t)stream, *query,
                            query_rows_upper, *neigh, scale, dilation, flip, nbr);
     });
     return ln_check_launch("ln_neighbours");

@@ -49,13 +49,60 @@ _STATIC_SLOTS_PER_ROW = float(os.environ.get("LATTICE_STATIC_SLOTS_PER_ROW", "2.
 
 
 # What kd region planes (Lattice.set_region_planes) steer:
-#   "space" (default) the SLOT function as well: a key starts probing in the run of buckets that belongs to its kd leaf, rows are
-#           numbered bucket by bucket, so the rows of the table follow space (LnTable.planes, csrc/ln_common.h) and the gathers of
-#           the convolutions / slice / segment walks stay inside one XCD's L2;
-#   "hash"  only which XCD walks which CSR segments (round 2-5 behaviour: slots stay hashed over the whole table).
-_SLOT_ORDER = [os.environ.get("LATTICE_SLOT_ORDER", "space")]
+#   "hash"  (default) which XCD walks which CSR segments; slots stay hashed over the whole table (rounds 2-5);
+#   "space" the SLOT function as well (LnTable.slot_map, csrc/ln_common.h): a key starts probing in the slot run of its kd region, rows
+#           are numbered bucket by bucket, so the rows of the table follow space, and the convolution kernels let XCD x work on the
+#           rows of region x.  Measured on the C3 chain (round 6, profiles/r6_pmc_traffic*.json): HBM traffic of the two convolutions
+#           37.9 -> 20.6 MB and 53.5 -> 36.2 MB, of the whole chain 310 -> 262 MB — and NO gain in time: the kernels are latency-bound
+#           chains, alone and with four scans in flight (1345 against 1391 Mpoints/s).  What it costs: the in-region hash has to be a
+#           stirred one (the reference's raw hash is a low-discrepancy sequence over lattice keys for SOME moduli — 1.89 probes per
+#           unsuccessful retrieval at load 0.47 where a random hash gives 2.26, p99 6 against 11 — and a poor one for others), and the
+#           neighbour traversal, half of whose lookups are for absent vertices, waits for the slowest lane of every wave: 10.3 -> 15.6 us.
+#           Kept as an option for workloads that ARE bound by HBM traffic (wide value rows, many scans in flight).
+_SLOT_ORDER = [os.environ.get("LATTICE_SLOT_ORDER", "hash")]
 _PLANES_KEEPALIVE = []
-_ORDERED_SLICE = [os.environ.get("LATTICE_ORDERED_SLICE", "1") != "0"]  # A/B switch: slice in CSR order over space-ordered tables
+_SLOT_MAPS = {}
+# share of the slots handed out equally to the 8 leaves whatever their calibrated vertex share (the rest follows the shares): slack for
+# clouds that differ from the calibration cloud.  0.3 left the two hot leaves of a LiDAR scan (1 % of the vertices each) at load 0.1 and
+# pushed the others from 0.47 to 0.51 — every unsuccessful retrieval pays for that (round 6: tools/probes/r6_probe_lengths.py).
+_SLOT_RUN_FLOOR = float(os.environ.get("LATTICE_SLOT_RUN_FLOOR", "0.08"))
+
+
+def _make_slot_map(planes, shares, capacity: int, device):
+    """(int32[LN_SLOT_MAP_INTS] device tensor, largest bucket) for LnTable.slot_map, or (None, 0) when the table has too few buckets: every
+    leaf gets the same number of buckets (the planes balance tokens, so the bucket workgroups of a build see equal loads) and a
+    bucket SIZE in proportion to the share of the vertices it is expected to hold, blended with an equal split so that a cloud that
+    differs from the calibration cloud still fits (equal load factor everywhere = equal probe lengths)."""
+    import numpy as np
+    nbk = int(_lib.load().ln_table_bucket_count(int(capacity)))
+    G = _lib.LN_XCD_GROUPS
+    if nbk < 2 * G:
+        return None, 0
+    bpl = nbk // G  # (the C side launches G * bpl bucket workgroups over a mapped table)
+    units = int(capacity) // bpl  # the bucket sizes of the 8 leaves may add up to this
+    sh = np.full((G,), 1.0 / G) if shares is None else np.asarray(shares, np.float64)
+    sh = (1.0 - _SLOT_RUN_FLOOR) * sh / max(sh.sum(), 1e-30) + _SLOT_RUN_FLOOR / G
+    sb = np.maximum(np.floor(sh * units).astype(np.int64), min(16, units // G))
+    while sb.sum() > units:
+        sb[int(np.argmax(sb))] -= 1
+    left = units - int(sb.sum())
+    sb[np.argsort(-sh)[:left]] += 1  # (left < 8)
+    if int(sb.min()) < 1:
+        return None, 0
+    m = np.zeros((_lib.LN_SLOT_MAP_INTS,), np.int32)
+    m[0:7] = np.asarray(planes, np.int64).astype(np.int32)
+    m[7] = bpl
+    m[8:8 + G + 1] = np.concatenate([[0], np.cumsum(sb * bpl)])
+    m[17:17 + G] = sb
+    t = torch.from_numpy(m).to(device)
+    _PLANES_KEEPALIVE.append(t)  # captured graphs hold the raw pointer (128 bytes per map)
+    return t, int(sb.max())
+# Slice in the order of the build's CSR over space-ordered tables (ln_slice_forward_ordered).  OFF by default: measured on the shuffled
+# C3 scan the value rows are then fetched 1.9x instead of 3.2x, but the (index, weight) pairs of a point — 16 + 16 bytes at a random
+# place of two arrays — cost a 64-byte sector each where the input-order walk reads them as streams: 28.5 MB fetched against 22.8 MB,
+# 15.0 us against 8.3 us (profiles/r6_pmc_traffic_slice_orders.json).  Worth switching on only for clouds whose input order is random AND
+# whose rows are wide (the value rows then dominate).
+_ORDERED_SLICE = [os.environ.get("LATTICE_ORDERED_SLICE", "0") == "1"]
 
 
 def set_slot_order(order: str) -> str:
@@ -194,21 +241,31 @@ class _TableStorage:
         self.nbr_cache = {}
         self.csr_cache = {}
         self.replay = None  # [rebuild on the atomic path, then the work queued behind the build], see Lattice._build
-        self.planes = None  # int32 device tensor, 2^levels entries (the last one padding): kd split planes of key space, None = no regions
-        self.slot_planes = None  # the planes the CONTENTS of the table were inserted under (LnTable.planes): adopted from `planes` by
-        self.slot_levels = 0     # every build that starts from a cleared table, kept by incremental builds and retrievals
+        self.planes = None  # int32[8] device tensor (7 planes + padding): kd split of key space for the NEXT build that clears, None = no regions
+        self.plane_values = None  # the same 7 ints on the host, and the calibrated share of the vertices each of the 8 leaves holds
+        self.leaf_shares = None
+        self.slot_map = None      # int32[LN_SLOT_MAP_INTS] device tensor the CONTENTS of the table were inserted under (LnTable.slot_map):
+        self.slot_map_sb_max = 0  # adopted by every build that starts from a cleared table, kept by incremental builds and retrievals
         self.row_regions = None  # int32[16] device tensor: first row of each kd region, written by bucketed builds over space-ordered slots
         self.rows_follow_space = False  # the last build numbered the rows region by region (row_regions is current)
 
     def adopt_planes(self):
-        """Called where the table is known to be empty (a clear, a build that clears first)."""
-        if self.planes is not None and _SLOT_ORDER[0] == "space":
-            self.slot_planes, self.slot_levels = self.planes, int(self.planes.numel()).bit_length() - 1
-            if self.row_regions is None:
-                self.row_regions = torch.zeros((16,), dtype=torch.int32, device=self.device)
-        else:
-            self.slot_planes, self.slot_levels = None, 0
+        """Called where the table is known to be empty (a clear, a build that clears first) and its hashed capacity is settled: the
+        slot map of the contents to come = the planes set last + a slot run per leaf in proportion to the leaf's calibrated vertex share."""
         self.rows_follow_space = False
+        if self.planes is None or _SLOT_ORDER[0] != "space":
+            self.slot_map, self.slot_map_sb_max = None, 0
+            return
+        key = (self.plane_values, self.leaf_shares, self.hashed())
+        hit = _SLOT_MAPS.get(key)
+        if hit is None:
+            hit = _make_slot_map(self.plane_values, self.leaf_shares, self.hashed(), self.device)
+            if len(_SLOT_MAPS) > 256:
+                _SLOT_MAPS.clear()  # (the tensors stay alive in _PLANES_KEEPALIVE: captured graphs hold raw pointers)
+            _SLOT_MAPS[key] = hit
+        self.slot_map, self.slot_map_sb_max = hit
+        if self.slot_map is not None and self.row_regions is None:
+            self.row_regions = torch.zeros((16,), dtype=torch.int32, device=self.device)
 
     def hashed(self) -> int:
         return self.hash_capacity or self.capacity
@@ -230,7 +287,8 @@ class _TableStorage:
         s.csr_cache = {}
         s.replay = None
         s.planes = self.planes
-        s.slot_planes, s.slot_levels = self.slot_planes, self.slot_levels
+        s.plane_values, s.leaf_shares = self.plane_values, self.leaf_shares
+        s.slot_map, s.slot_map_sb_max = self.slot_map, self.slot_map_sb_max
         s.row_regions = None if self.row_regions is None else self.row_regions.clone()
         s.rows_follow_space = self.rows_follow_space
         return s
@@ -304,7 +362,7 @@ class HashTable:
                 self._pinned = torch.zeros((4,), dtype=torch.int32, pin_memory=True)
             self._pinned_np = self._pinned.numpy().view("int64")  # same memory: the host polls the build's 64-bit report word
             self._readback_event = torch.cuda.Event()
-        key = (s.uid, self._counters.data_ptr(), self._static_rows, s.hashed(), None if s.slot_planes is None else s.slot_planes.data_ptr())
+        key = (s.uid, self._counters.data_ptr(), self._static_rows, s.hashed(), None if s.slot_map is None else s.slot_map.data_ptr())
         if getattr(self, "_c_table_key", None) == key:
             return self._c_table
         self._c_table_key = key
@@ -314,8 +372,8 @@ class HashTable:
     def _make_c_table(self, s) -> _lib.LnTable:
         return _lib.LnTable(s.hashed(), s.pos_dim, s.slot_keys.data_ptr(), s.slot_tok.data_ptr(), s.slot_cnt.data_ptr(), s.entries.data_ptr(),
                             s.keys.data_ptr(), self._counters.data_ptr(), self._counters.data_ptr() + 4, self._pinned.data_ptr(), 0,
-                            s.key_format, self._static_rows or 0, _lib.ptr(s.slot_planes), s.slot_levels,
-                            _lib.ptr(s.row_regions) if s.slot_planes is not None else None)
+                            s.key_format, self._static_rows or 0, _lib.ptr(s.slot_map), s.slot_map_sb_max,
+                            _lib.ptr(s.row_regions) if s.slot_map is not None else None)
 
     def clear(self, lazy: bool = False):  # HashTable.cu:49-57, one launch instead of four fill_ kernels
         """`lazy=True` only records that a clear is due: the next build issues it inside its own C call (no host
@@ -590,9 +648,9 @@ class Lattice:
         tokens = n * (d + 1)
         st = ht._storage
         clear_vals, do_clear = ht.take_pending_clear()  # begin_splat's clear rides in the same C call
-        if do_clear:
-            st.adopt_planes()  # space-ordered slots: the kd planes are bound to the table's contents from here on
         self._choose_hash_capacity(tokens, fresh=do_clear)
+        if do_clear:
+            st.adopt_planes()  # space-ordered slots: the slot map is bound to the table's contents from here on
         cap = st.hashed()
         csr_buf, csr, max_seg = self._alloc_csr(tokens, cap, st.planes)
         # HashTable::clear fills the whole tensor (HashTable.cu:49-57).  Here only the rows that can be non-zero are cleared: a build
@@ -610,6 +668,11 @@ class Lattice:
 
         def issue(force_atomic: bool):
             lib = _lib.load()
+            if force_atomic and st.slot_map is not None:
+                # replay of a bucketed build that overflowed under a slot map: the map does not fit this cloud (leaves fuller than their
+                # slot runs).  Spilling past full buckets would keep the table correct but push keys hundreds of probes away from where
+                # retrieval starts (its 300-probe cap, HashTableGPU.cuh:494, would lose them): the contents go back to hashed slots
+                st.slot_map, st.slot_map_sb_max = None, 0
             ws = self._workspace(_build_sizes(tokens, cap)[0])
             t = ht.c_table()
             flags = (_lib.LN_BUILD_WRITE_IDX if write else 0) | (_lib.LN_BUILD_CLEAR_FIRST if do_clear else 0)
@@ -629,7 +692,7 @@ class Lattice:
                                        cv, cn, self._stream())
                 _lib.check(rc, "ln_distribute")
             st.touch()
-            st.rows_follow_space = bool(st.slot_levels and do_clear and not (flags & (_lib.LN_BUILD_ATOMIC_PATH | _lib.LN_BUILD_CANONICAL_ROWS)))
+            st.rows_follow_space = bool(st.slot_map is not None and do_clear and not (flags & (_lib.LN_BUILD_ATOMIC_PATH | _lib.LN_BUILD_CANONICAL_ROWS)))
             ht.m_nr_filled_is_dirty = True
             if n > 0 and ht._static_rows is None:
                 ht.start_count_readback()
@@ -1471,38 +1534,43 @@ class Lattice:
         # coarse_bounds[k]: bound of the lattice k + 1 levels coarser than this one (create_coarse_verts hands them down)
         ht._static_levels = None if coarse_bounds is None else {self.m_lvl + 1 + k: int(b) for k, b in enumerate(coarse_bounds)}
 
-    def set_region_planes(self, planes):
-        """kd split planes of key space (2^levels - 1 ints in heap order, levels 3..6: see LnTable.planes) or None.  With planes, the
-        builds of this lattice file the CSR segments of every vertex under one of 8 compact regions (the top three levels) and the
-        scatter kernels let XCD r walk region r; under set_slot_order("space") (the default) the planes also order the SLOTS — and
-        with them the rows — of the table by space, from the next build that starts with a clear on (LnTable.planes)."""
+    def set_region_planes(self, planes, leaf_shares=None):
+        """kd split planes of key space (7 ints: 1 + 2 + 4 thresholds in heap order, see LnCsr.planes) or None.  With planes, the builds
+        of this lattice file the CSR segments of every vertex under one of 8 compact regions and the scatter kernels let XCD r walk
+        region r; under set_slot_order("space") (the default) the planes also order the SLOTS — and with them the rows — of the table
+        by space, from the next build that starts with a clear on (LnTable.slot_map).  `leaf_shares` (8 floats, optional): the share
+        of the vertices each region is expected to hold (balanced_region_planes(..., return_shares=True)): the slot run of a region is
+        sized with it; without it the regions get equal runs, which suits planes that balance VERTICES."""
         st = self.m_hash_table._storage
         if st is None:
             raise _lib.LatticeNetHipError("build the lattice once before setting region planes")
         if planes is None:
-            st.planes = None
+            st.planes = st.plane_values = st.leaf_shares = None
             return
         p = torch.as_tensor(planes, dtype=torch.int32).reshape(-1)
-        if p.numel() not in (7, 15, 31, 63):
-            raise ValueError("region planes: 2^levels - 1 ints in heap order (7 = 1 + 2 + 4 thresholds, ... 63), levels 3 to 6")
+        if p.numel() != 7:
+            raise ValueError("region planes: 7 ints (1 + 2 + 4 thresholds)")
+        if leaf_shares is not None and (len(leaf_shares) != 8 or min(leaf_shares) < 0 or sum(leaf_shares) <= 0):
+            raise ValueError("leaf_shares: 8 non-negative numbers")
         st.planes = torch.cat([p, torch.zeros(1, dtype=torch.int32)]).to(self._dev())
-        _PLANES_KEEPALIVE.append(st.planes)  # captured graphs hold the raw pointer (a few hundred bytes per calibration)
+        st.plane_values = tuple(int(x) for x in p.tolist())
+        st.leaf_shares = None if leaf_shares is None else tuple(float(x) for x in leaf_shares)
+        _PLANES_KEEPALIVE.append(st.planes)  # captured graphs hold the raw pointer (32 bytes per calibration)
 
-    def balanced_region_planes(self, idx: torch.Tensor, levels: int = 3, vertex_weight: float = 0.0):
-        """Planes of a kd partition of the vertices of the CURRENT build into 2^levels leaves of equal load (host-side calibration
-        helper): weighted medians of key[0], then key[1 % d] inside each half, ... — level l splits on key[l % d].  The load of a
-        vertex is its token count + vertex_weight x the mean token count: 0 (default) balances tokens — what the bucket pass of the
-        build, the segment walks and the slice spend their time on; larger values trade that for equal vertex counts per leaf."""
+    def balanced_region_planes(self, idx: torch.Tensor, vertex_weight: float = 0.0, return_shares: bool = False):
+        """Planes that split the vertices of the CURRENT build into 8 regions of equal load (host-side calibration helper): weighted
+        medians of key[0], then key[1 % d] inside each half, then key[2 % d] inside each quarter.  The load of a vertex is its token
+        count + vertex_weight x the mean token count: 0 (default) balances tokens — what the bucket pass of the build, the segment
+        walks and the slice spend their time on.  return_shares: also the share of the vertices in each region (for set_region_planes)."""
         import numpy as np
-        if not 3 <= int(levels) <= 6:
-            raise ValueError("levels must be 3 .. 6")
         m = self.nr_lattice_vertices()
         keys = self.m_hash_table._storage.keys[:m].cpu().numpy().astype("int64")
         wts = self.vertex_point_counts(idx).cpu().numpy().astype("float64")
         if vertex_weight > 0 and m > 0:
             wts = wts + vertex_weight * float(wts.mean())
         d = keys.shape[1]
-        planes = [0] * ((1 << int(levels)) - 1)
+        planes = [0] * 7
+        leaf = np.zeros((m,), np.int64)
 
         def wmedian(vals, w):
             if len(vals) == 0:
@@ -1512,7 +1580,8 @@ class Lattice:
             return int(vals[order][min(np.searchsorted(cs, cs[-1] / 2.0), len(vals) - 1)])  # region test is key >= plane
 
         def split(sel, node, lvl):
-            if lvl == levels:
+            if lvl == 3:
+                leaf[sel] = node - 7
                 return
             ax = lvl % d
             planes[node] = wmedian(keys[sel, ax], wts[sel])
@@ -1521,6 +1590,16 @@ class Lattice:
             split(sel[hi], 2 * node + 2, lvl + 1)
 
         split(np.arange(m), 0, 0)
+        if not return_shares:
+            return planes
+        shares = np.bincount(leaf, minlength=8).astype(np.float64) / max(m, 1)
+        return planes, [float(x) for x in shares]
+
+    def calibrate_regions(self, idx: torch.Tensor, vertex_weight: float = 0.0):
+        """balanced_region_planes + set_region_planes on the current build (whose splat indices are `idx`): the next build that clears
+        runs over token-balanced regions with slot runs sized by the regions' vertex shares."""
+        planes, shares = self.balanced_region_planes(idx, vertex_weight=vertex_weight, return_shares=True)
+        self.set_region_planes(planes, shares)
         return planes
 
     def static_build_report(self):

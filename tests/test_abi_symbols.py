@@ -34,8 +34,8 @@ def test_struct_layout_matches_header():
     assert C.sizeof(_lib.LnTable) == 112
     assert [f[0] for f in _lib.LnTable._fields_] == ["capacity", "pos_dim", "slot_keys", "slot_tok", "slot_cnt", "entries", "keys",
                                                      "nr_filled", "status", "host_counters", "host_seq", "key_format", "row_limit",
-                                                     "planes", "plane_levels", "row_regions"]
-    assert _lib.LnTable.planes.offset == 88 and _lib.LnTable.row_regions.offset == 104
+                                                     "slot_map", "bucket_slots_max", "row_regions"]
+    assert _lib.LnTable.slot_map.offset == 88 and _lib.LnTable.row_regions.offset == 104
     assert C.sizeof(_lib.LnCsr) == 56  # 4 pointers + seg_region + planes + the dense hint (int, padded)
 
 

@@ -4,7 +4,7 @@ With kd planes bound to a table, a key starts probing in the run of buckets of i
 bucket: the rows of the table follow space.  Nothing reference-visible may change: same vertex SET as the oracle, splat indices
 equal under the row permutation that matches the keys, weights / sliced rows / filter gradients equal as they are, retrieval
 (neighbour lists, slice_no_precomputation, incremental builds) finds every vertex — in the shipped numbering AND under the
-canonical relabelling, for balanced planes, deeper trees and deliberately useless ones.  Also here: the row partition the
+canonical relabelling, for token-balanced, mixed and vertex-balanced planes and deliberately useless ones.  Also here: the row partition the
 build hands the convolutions (LnTable.row_regions), the slice that walks the points in CSR order (bit-identical rows), and the
 workgroup -> tile map of the vertex-tiled kernels (a bijection whatever the partition array holds)."""
 import ctypes as C
@@ -51,25 +51,30 @@ def row_permutation(keys_gpu, keys_oracle):
     return perm
 
 
-def leaf_of_keys(keys, planes, levels):
+def leaf_of_keys(keys, planes):
     node = np.zeros(len(keys), np.int64)
     pl = np.asarray(planes, np.int64)
     d = keys.shape[1]
-    for lvl in range(levels):
+    for lvl in range(3):
         node = 2 * node + 1 + (keys[:, lvl % d] >= pl[node]).astype(np.int64)
-    return node - ((1 << levels) - 1)
+    return node - 7
 
 
-def build_space_ordered(pos_np, sigma, cap, levels=3, vertex_weight=0.0, planes=None):
-    """Lattice whose second build runs over planes calibrated on the first; returns (lattice, idx, w, planes)."""
+def build_space_ordered(pos_np, sigma, cap, vertex_weight=0.0, planes=None, shares=True):
+    """Lattice whose second build runs over a slot map calibrated on the first; returns (lattice, idx, w, planes).  shares=False: the
+    planes without the vertex shares of their leaves (equal slot runs)."""
     from lattice_net_amd import Lattice
     lat = Lattice(sigmas=[sigma] * pos_np.shape[1], capacity=cap, device=dev())
     lat.begin_splat()
     idx, w = lat.just_create_verts(T(pos_np), True)
     lat.nr_lattice_vertices()
-    if planes is None:
-        planes = lat.balanced_region_planes(idx, levels=levels, vertex_weight=vertex_weight)
-    lat.set_region_planes(planes)
+    if planes is not None:
+        lat.set_region_planes(planes)
+    elif shares:
+        planes = lat.calibrate_regions(idx, vertex_weight=vertex_weight)
+    else:
+        planes = lat.balanced_region_planes(idx, vertex_weight=vertex_weight)
+        lat.set_region_planes(planes)
     lat.begin_splat()
     idx, w = lat.just_create_verts(T(pos_np), True)
     return lat, idx, w, planes
@@ -84,14 +89,17 @@ def clouds():
     yield "planes200k", synthetic.planes_cloud(200000, 1), 0.08, 5000000
 
 
-@pytest.mark.parametrize("levels", [3, 5])
+@pytest.mark.parametrize("weights", ["tokens", "mixed", "vertices_equal_runs"])
 @pytest.mark.parametrize("case", list(clouds()), ids=lambda c: c[0])
-def test_space_ordered_build_equals_oracle_and_rows_follow_the_regions(case, levels):
+def test_space_ordered_build_equals_oracle_and_rows_follow_the_regions(case, weights):
     _, pos_np, sigma, cap = case
-    lat, idx, w, planes = build_space_ordered(pos_np, sigma, cap, levels=levels)
+    lat, idx, w, planes = build_space_ordered(pos_np, sigma, cap, vertex_weight={"tokens": 0.0, "mixed": 1.0, "vertices_equal_runs": 1e6}[weights],
+                                              shares=weights != "vertices_equal_runs")
     m = lat.nr_lattice_vertices()
     st = lat.m_hash_table._storage
-    assert st.slot_levels == levels and st.rows_follow_space
+    assert st.slot_map is not None and st.rows_follow_space, "the bucketed build over the calibrated slot map must not overflow"
+    smap = N(st.slot_map)
+    assert np.array_equal(smap[:7], planes) and smap[8] == 0 and smap[16] <= st.hashed() and np.all(smap[17:25] * smap[7] == np.diff(smap[8:17]))
     t = O.OracleHashTable(cap, 3)
     oidx, ow = O.build_splat(t, O.scale_positions(pos_np, np.full((3,), sigma, np.float32)))
     assert m == t.nr_filled
@@ -104,15 +112,13 @@ def test_space_ordered_build_equals_oracle_and_rows_follow_the_regions(case, lev
     assert np.array_equal(N(w), ow)
     ent = N(lat.m_hash_table.m_entries_tensor)
     assert np.array_equal(np.sort(ent[ent >= 0]), np.arange(m))
-    # rows follow space: the kd leaf of the key of row r never decreases with r — at the depth the slot function really used (whole
-    # buckets per leaf: fewer levels when the bucket count is not a multiple of 2^levels) — and the partition the build left says where
-    # each of the 8 top-level regions starts
-    leaf = leaf_of_keys(keys[:m].astype(np.int64), planes, levels)
-    used = levels
-    while used > 3 and np.any(np.diff(leaf >> (levels - used)) < 0):
-        used -= 1
-    assert np.all(np.diff(leaf >> (levels - used)) >= 0), "rows must be grouped by kd leaf"
-    region = leaf >> (levels - 3)
+    # rows follow space: the kd region of the key of row r never decreases with r, the partition the build left says where each of
+    # the 8 regions starts, and every vertex sits in the slot run of its region
+    region = leaf_of_keys(keys[:m].astype(np.int64), planes)
+    assert np.all(np.diff(region) >= 0), "rows must be grouped by kd region"
+    slot_of_row = np.empty(m, np.int64)
+    slot_of_row[ent[ent >= 0]] = np.nonzero(ent >= 0)[0]
+    assert np.all(slot_of_row >= smap[8:16][region]) and np.all(slot_of_row < smap[9:17][region])
     starts = N(st.row_regions)[:9]
     assert starts[0] == 0 and starts[8] == m
     for r in range(8):
@@ -124,7 +130,8 @@ def test_space_ordered_build_other_dimensions(d):
     rng = np.random.default_rng(100 + d)
     n, cap, sigma = 8000, 60000, 0.6
     pos_np = (rng.standard_normal((n, d)) * (3.0 if d < 5 else 1.2)).astype(np.float32)
-    lat, idx, w, planes = build_space_ordered(pos_np, sigma, cap, levels=4)
+    lat, idx, w, planes = build_space_ordered(pos_np, sigma, cap)
+    assert lat.m_hash_table._storage.rows_follow_space
     m = lat.nr_lattice_vertices()
     t = O.OracleHashTable(cap, d)
     oidx, ow = O.build_splat(t, O.scale_positions(pos_np, np.full((d,), sigma, np.float32)))
@@ -157,7 +164,7 @@ def test_space_ordered_chain_matches_oracle_and_the_hashed_chain():
         lv, wrap, idx, w = L.SplatLattice.apply(lat, pos, vals)
         lat.nr_lattice_vertices()
         if mode == "space":
-            lat.set_region_planes(lat.balanced_region_planes(idx))
+            lat.calibrate_regions(idx)
             lv, wrap, idx, w = L.SplatLattice.apply(lat, pos, vals)
             assert lat.m_hash_table._storage.rows_follow_space
         m = lat.nr_lattice_vertices()
@@ -267,7 +274,8 @@ def test_ordered_slice_reaches_points_whose_first_token_is_not_in_the_csr():
 
 def test_useless_planes_are_survived_in_eager_mode():
     """Planes that put every key into ONE leaf overfill that leaf's buckets: the bucketed build reports it and the eager path replays
-    the build (and what was queued behind it) on the atomic path, whose inserts spill over the bucket borders — same lattice."""
+    the build (and what was queued behind it) on the atomic path over HASHED slots — the map is dropped, because spilling past full
+    buckets would leave keys beyond the reach of the 300-probe retrieval (HashTableGPU.cuh:494).  Same lattice, retrieval included."""
     import lattice_net_amd as L
     from lattice_net_amd import synthetic
     n, v, sigma, cap = 20000, 32, 0.9, 40000
@@ -279,15 +287,22 @@ def test_useless_planes_are_survived_in_eager_mode():
     m = t.nr_filled
     ov = np.zeros((m, v), np.float32)
     O.splat_accumulate(ov, vals_np, oidx, ow)
-    for planes in ([10 ** 6] * 7, [-10 ** 6] * 15):
+    nbr = O.neighbour_rows(t.keys[:m], t, 1, 1, 1, False)
+    for planes in ([10 ** 6] * 7, [-10 ** 6] * 7):
         lat, _, _, _ = build_space_ordered(pos_np, sigma, cap, planes=planes)
         lv, _, idx, w = L.SplatLattice.apply(lat, T(pos_np), T(vals_np))
         assert lat.nr_lattice_vertices() == m
+        st = lat.m_hash_table._storage
+        assert st.slot_map is None and not st.rows_follow_space, "the map that did not fit must be gone after the replay"
         perm = row_permutation(N(lat.m_hash_table.m_keys_tensor)[:m], t.keys[:m])
         assert np.array_equal(perm[N(idx).astype(np.int64)], oidx)
         np.testing.assert_allclose(N(lv)[:m][np.argsort(perm)], ov, rtol=RTOL, atol=RTOL * float(np.abs(ov).max()))
-        out = lat.slice_standalone_no_precomputation(T(pos_np))[0]  # retrieval through the same (useless) slot function
-        np.testing.assert_allclose(N(out), O.slice_with_precomputation(ov, oidx, ow, n), rtol=RTOL, atol=RTOL * float(np.abs(ov).max()))
+        gn = N(lat.neighbours(lat, 1, False)).astype(np.int64)
+        assert np.array_equal(np.where(gn >= 0, perm[np.maximum(gn, 0)], gn)[np.argsort(perm)], nbr)
+        lat.set_values(lv[:m].contiguous())
+        out = lat.slice_standalone_no_precomputation(T(pos_np))[0]  # retrieval of every simplex vertex
+        np.testing.assert_allclose(N(out), O.slice_with_precomputation(ov[np.argsort(np.argsort(perm))] if False else N(lv)[:m][np.argsort(perm)], oidx, ow, n),
+                                   rtol=RTOL, atol=RTOL * float(np.abs(ov).max()))
 
 
 def test_incremental_build_and_retrieval_keep_the_planes_of_the_contents():
@@ -301,7 +316,7 @@ def test_incremental_build_and_retrieval_keep_the_planes_of_the_contents():
     m_a = lat.nr_lattice_vertices()
     lat.set_region_planes([5, -7, 9, 1, 2, 3, 4])  # for the NEXT fresh build
     st = lat.m_hash_table._storage
-    assert np.array_equal(N(st.slot_planes)[:7], np.asarray(planes))
+    assert np.array_equal(N(st.slot_map)[:7], np.asarray(planes))
     lat.begin_splat(reset_hashmap=False)
     idx_b, w_b = lat.just_create_verts(T(b_np), True)  # no clear in front of it: an incremental build (atomic path)
     m_ab = lat.nr_lattice_vertices()
@@ -318,7 +333,7 @@ def test_incremental_build_and_retrieval_keep_the_planes_of_the_contents():
     lat.begin_splat()
     lat.just_create_verts(T(a_np), True)
     assert lat.nr_lattice_vertices() == m_a
-    assert np.array_equal(N(st.slot_planes)[:7], np.asarray([5, -7, 9, 1, 2, 3, 4]))
+    assert np.array_equal(N(st.slot_map)[:7], np.asarray([5, -7, 9, 1, 2, 3, 4]))
 
 
 def test_canonical_numbering_over_space_ordered_slots_is_the_oracles():
@@ -327,9 +342,9 @@ def test_canonical_numbering_over_space_ordered_slots_is_the_oracles():
     from lattice_net_amd import lattice as LT, synthetic
     LT.set_row_order("canonical")
     pos_np, sigma, cap = synthetic.lidar_cloud(30000, 11), 0.9, 60000
-    lat, idx, w, _ = build_space_ordered(pos_np, sigma, cap, levels=4)
+    lat, idx, w, _ = build_space_ordered(pos_np, sigma, cap)
     m = lat.nr_lattice_vertices()
-    assert lat.m_hash_table._storage.slot_levels == 4 and lat._row_partition() is None
+    assert lat.m_hash_table._storage.slot_map is not None and lat._row_partition() is None
     t = O.OracleHashTable(cap, 3)
     oidx, ow = O.build_splat(t, O.scale_positions(pos_np, np.full((3,), sigma, np.float32)))
     assert m == t.nr_filled
@@ -388,7 +403,7 @@ def test_slot_order_switch_restores_hashed_slots():
     pos_np, sigma, cap = synthetic.lidar_cloud(20000, 17), 0.9, 40000
     lat, idx, w, _ = build_space_ordered(pos_np, sigma, cap)
     st = lat.m_hash_table._storage
-    assert st.slot_levels == 0 and st.slot_planes is None and not st.rows_follow_space and st.planes is not None
+    assert st.slot_map is None and not st.rows_follow_space and st.planes is not None
     m = lat.nr_lattice_vertices()
     t = O.OracleHashTable(cap, 3)
     oidx, ow = O.build_splat(t, O.scale_positions(pos_np, np.full((3,), sigma, np.float32)))
