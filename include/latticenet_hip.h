@@ -122,9 +122,11 @@ typedef struct LnCsr {
                              XCD r walk region r: the d+1 gathers of a point row meet in ONE L2.  These planes only steer
                              work placement (any values are correct).  When the table itself is space-ordered
                              (LnTable.slot_map) the region of a vertex is that of its bucket and this array is only a flag. */
-    int dense;            /* host-side hint for the segment reduces (any value is correct): non-zero = dense cloud, about 16 or more
+    int dense;            /* host-side hints for the segment reduces (any value is correct).  Bit 0 = dense cloud, about 16 or more
                              tokens per vertex — most vertices then own several segments, and the reduce combines partial sums across
-                             the waves of a workgroup before it resorts to atomics (C5: 104 -> 84 us; costs the sparse C3 scan 10 %) */
+                             the waves of a workgroup before it resorts to atomics (C5: 104 -> 84 us; costs the sparse C3 scan 10 %).
+                             Bit 1 = deterministic: one lane group walks a whole row in CSR order and stores it — no atomics, no
+                             combining; with LN_BUILD_SORTED_CSR the sums are identical run to run (slower on hot vertices) */
 } LnCsr;
 
 const char* ln_last_error_string(void);
@@ -183,6 +185,9 @@ size_t ln_build_workspace_bytes(long long tokens, int capacity);
 #define LN_BUILD_CLEAR_FIRST 2
 #define LN_BUILD_ATOMIC_PATH 4
 #define LN_BUILD_CANONICAL_ROWS 8 /* bucketed path: run ln_canonicalize behind the build (the atomic path numbers canonically anyway) */
+#define LN_BUILD_SORTED_CSR 16    /* rewrite every token list of `csr` in ascending token order behind the build: the order tokens arrive in
+                                     differs from run to run, and with it the last bits of every fp32 sum over them.  With LnCsr.dense & 2
+                                     in the reduces: run-to-run identical splat values / slice and gather gradients */
 int ln_build_splat(const LnTable* t, const float* positions_raw, const float* sigmas_host, int n, int* idx, float* w,
                    int flags, const LnCsr* csr, void* workspace, size_t workspace_bytes, float* clear_values,
                    long long clear_values_elems, void* stream);
@@ -226,6 +231,9 @@ int ln_csr_build(const int* idx, long long tokens, int groups_upper, const LnCsr
                  void* stream);
 int ln_csr_reduce_rows(const LnCsr* csr, const int* grp_row, long long max_segments, const float* src, const float* w, int val_dim,
                        int src_div, int src_stride, float* dst, void* stream);
+/* Rewrites every token list of a CSR (ln_csr_build's, or a build's: groups_upper = what it was built over) in ascending token order:
+ * what LN_BUILD_SORTED_CSR does behind a build.  workspace: `tokens` ints (tokens = what the CSR was sized for). */
+int ln_csr_sort(const LnCsr* csr, int groups_upper, void* workspace, size_t workspace_bytes, long long tokens, void* stream);
 
 /* The two launches that follow a splat build and do not depend on each other, as ONE launch: ln_csr_reduce_rows(csr,
  * grp_row, .., dst) (splatCacheNaive) in the first workgroups, ln_neighbours(table, query_rows_upper, table, same level,

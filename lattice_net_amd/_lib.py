@@ -19,6 +19,7 @@ LN_BUILD_WRITE_IDX = 1
 LN_BUILD_CLEAR_FIRST = 2
 LN_BUILD_ATOMIC_PATH = 4
 LN_BUILD_CANONICAL_ROWS = 8
+LN_BUILD_SORTED_CSR = 16
 LN_NOT_VISITED = -2
 LN_CONV_FLIP_NEIGHBOURS = 1
 LN_CONV_TRANSPOSED_FILTER = 2
@@ -96,6 +97,7 @@ SIGNATURES = {
     "ln_csr_max_segments": (_ll, [_ll, _i]),
     "ln_csr_build": (_i, [_vp, _ll, _i, _CSR, _vp, _sz, _vp]),
     "ln_csr_reduce_rows": (_i, [_CSR, _vp, _ll, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "ln_csr_sort": (_i, [_CSR, _i, _vp, _sz, _ll, _vp]),
     "ln_splat_accumulate_and_neighbours": (_i, [_CSR, _vp, _ll, _vp, _vp, _i, _i, _i, _vp, _T, _i, _vp, _vp]),
     "ln_csr_segment_max": (_i, [_CSR, _vp, _ll, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "ln_csr_group_sizes": (_i, [_CSR, _vp, _i, _i, _vp, _vp]),

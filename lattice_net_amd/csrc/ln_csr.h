@@ -13,6 +13,9 @@ size_t ln_csr_scan_workspace_bytes(int groups_upper);
 int ln_csr_from_counts(const int* tok_grp, const int* tok_pos, long long tokens, const int* grp_cnt, int groups_upper,
                        const LnCsr& csr, void* workspace, size_t workspace_bytes, hipStream_t st);
 
+// Rewrites every group's token list in ascending token order (deterministic sums; see ln_csr.hip).  scratch: one int per CSR token.
+int ln_csr_sort_groups(const LnCsr& csr, int groups, int* scratch, hipStream_t st);
+
 #if defined(__HIPCC__)
 // Which segments a workgroup works on.  Segment lists come in two layouts (LnCsr.seg_count[LN_XCD_GROUPS] says which):
 //   1 region : segments 0 .. seg_count[0]-1; workgroup b takes the blocks b, b + nblocks, ... of them;

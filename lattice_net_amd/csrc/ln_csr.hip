@@ -227,6 +227,53 @@ extern "C" int ln_csr_build(const int* idx, long long tokens, int groups_upper, 
     return ln_csr_from_counts(idx, pos, tokens, cnt, groups_upper, *csr, p, ln_csr_scan_workspace_bytes(groups_upper), st);
 }
 
+// ------------------------------------------------------------------------------------------
+// Deterministic token order (ln_csr_sort_groups): the position of a token inside its group's list comes from an atomic counter
+// (LDS in the bucket pass, global on the atomic path), i.e. from arrival order — a group's tokens are the same in every run, their
+// order is not, and fp32 sums over them differ in the last bits.  One wave per group rewrites the list in ascending token order:
+// rank of a token = tokens of the group that are smaller (all pairs, 64 at a time through shuffles), written through a scratch copy.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+    k_csr_sort_groups(const int* __restrict__ grp_start, int groups, const int* __restrict__ csr_tok, int* __restrict__ sorted) {
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (g >= groups) return;
+    const int beg = grp_start[g], end = grp_start[g + 1];
+    for (int i0 = beg; i0 < end; i0 += 64) {  // (wave-uniform trip counts)
+        const int mine = i0 + lane < end ? csr_tok[i0 + lane] : 0x7FFFFFFF;
+        int rank = 0;
+        for (int j0 = beg; j0 < end; j0 += 64) {
+            const int other = j0 + lane < end ? csr_tok[j0 + lane] : 0x7FFFFFFF;
+            const int n = min(64, end - j0);
+            for (int k = 0; k < n; ++k) {
+                const int o = __shfl(other, k, 64);
+                // ties (the -1 fillers behind an overflowed bucket) keep their relative order
+                rank += (o < mine || (o == mine && j0 + k < i0 + lane)) ? 1 : 0;
+            }
+        }
+        if (i0 + lane < end) sorted[beg + rank] = mine;
+    }
+}
+__global__ void __launch_bounds__(256) k_csr_copy_tokens(const int* __restrict__ src, const int* __restrict__ total, int* __restrict__ dst) {
+    const int n = *total;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) dst[i] = src[i];
+}
+
+// groups = the group count the CSR was built over; scratch: as many ints as the CSR has tokens
+int ln_csr_sort_groups(const LnCsr& csr, int groups, int* scratch, hipStream_t st) {
+    if (groups <= 0) return LN_OK;
+    LN_LAUNCH("k_csr_sort_groups", k_csr_sort_groups, dim3(ln_div_up(groups, 4)), dim3(256), 0, st, csr.grp_start, groups, csr.csr_tok, scratch);
+    LN_LAUNCH("k_csr_copy_tokens", k_csr_copy_tokens, dim3(1024), dim3(256), 0, st, scratch, csr.grp_start + groups, csr.csr_tok);
+    return ln_check_launch("ln_csr_sort_groups");
+}
+
+extern "C" int ln_csr_sort(const LnCsr* csr, int groups_upper, void* workspace, size_t workspace_bytes, long long tokens, void* stream) {
+    LN_REQUIRE(csr && csr->grp_start && csr->csr_tok && groups_upper >= 0 && tokens >= 0, LN_ERR_ARG, "ln_csr_sort: bad arguments");
+    LN_REQUIRE(tokens == 0 || (workspace && workspace_bytes >= (size_t)tokens * sizeof(int)), LN_ERR_WORKSPACE, "ln_csr_sort: workspace too small");
+    if (tokens == 0) return LN_OK;
+    return ln_csr_sort_groups(*csr, groups_upper, static_cast<int*>(workspace), (hipStream_t)stream);
+}
+
 // dst[row, j] += sum over the row's tokens t of src[(t / src_div) * src_stride + j] * w[t]   (j < V)
 // One lane group per segment; LN_SEG/U batches of U independent gathers per lane.  Segments of one
 // group have consecutive ids, so neighbouring lane groups of a wave often hold partial sums of the
@@ -244,6 +291,7 @@ struct LnReduceArgs {
     float* dst;
     long long seg_region;
     int dbg_plain;  // experiment: plain stores instead of atomics (wrong sums, timing only)
+    int deterministic;  // LnCsr.dense & 2: one lane group per ROW, tokens in CSR order, no atomics (run-to-run identical sums)
 };
 
 // one block of segments (256 threads).  Per segment: descriptor -> row -> batches of 4 tokens {4 ids} -> {4 weights, 4 row chunks}.
@@ -278,17 +326,24 @@ __device__ __forceinline__ void ln_reduce_chunk(const LnSegOfThread& so, const L
         cnt = min(LN_SEG, d.z);
         rbeg = beg - d.w;
         rend = beg + d.z;
+        if (a.deterministic) {  // the lane group of a row's FIRST segment walks the whole row, in CSR order; the others stand by
+            cnt = d.w == 0 ? d.z : 0;
+            if (d.w != 0) grp = -1 - grp;  // (never equal to a neighbour's group: no combining)
+        }
     }
     const int end = beg + cnt;
     // the descriptor names the row itself (bucketed build), a hash slot (row = entries[slot]) or a row-group (ln_csr_build)
-    if (active) row = (rows_in_desc || !grp_row) ? grp : grp_row[grp];
+    if (active) {
+        const int g0 = grp >= 0 ? grp : -1 - grp;
+        row = (rows_in_desc || !grp_row) ? g0 : grp_row[g0];
+    }
     const int V = chunks * VEC;
     const int nchunk_iter = (chunks + lanes_per_seg - 1) / lanes_per_seg;  // wave-uniform trip count (shuffles inside)
     const bool pow2 = (src_div & (src_div - 1)) == 0;
     const int shift = __ffs(src_div) - 1;
     for (int it = 0; it < nchunk_iter; ++it) {
         const int c = lc + it * lanes_per_seg;
-        const bool cok = active && row >= 0 && c < chunks;
+        const bool cok = active && row >= 0 && c < chunks && (!a.deterministic || cnt > 0);
         float acc[VEC];
 #pragma unroll
         for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
@@ -451,7 +506,7 @@ static int ln_reduce_args(const char* who, const LnCsr* csr, const int* grp_row,
     while (lanes < chunks && lanes < 64) lanes <<= 1;
     work = max_segments * lanes;
     if (max_segments > 0) a = LnReduceArgs{csr->grp_start, csr->csr_tok, reinterpret_cast<const int4*>(csr->seg_desc), csr->seg_count, grp_row, src, w, chunks, lanes,
-                                           src_div, src_stride, dst, csr->seg_region, (ln_debug_mask() & 128) ? 1 : 0};
+                                           src_div, src_stride, dst, csr->seg_region, (ln_debug_mask() & 128) ? 1 : 0, (csr->dense & 2) ? 1 : 0};
     return LN_OK;
 }
 
@@ -467,7 +522,7 @@ static int ln_csr_reduce_rows_impl(const char* who, const LnCsr* csr, const int*
     const dim3 grid(ln_seg_grid(max_segments, a.lanes_per_seg)), block(256);
     // dense cloud, or wide rows (16+ lanes per segment: a wave then holds four segments or fewer, so every second to fourth segment of a
     // row is cut by a wave boundary — at 96 fp32 channels on the C3 cloud 50.2 -> 42.4 us): combine across the waves of a workgroup
-    const bool wg = (csr->dense != 0 || a.lanes_per_seg >= 16) && vec >= 4;
+    const bool wg = ((csr->dense & 1) != 0 || a.lanes_per_seg >= 16) && vec >= 4 && !(csr->dense & 2);
 #define LN_REDUCE_LAUNCH(VV, HH)                                                                                                     \
     {                                                                                                                                \
         if (wg)                                                                                                                      \
@@ -533,7 +588,7 @@ static int ln_splat_tail_impl(const char* who, const LnCsr* csr, const int* grp_
         else if (vec == 4) LN_FUSED_LAUNCH(4, DD, false)                                                                             \
         else LN_FUSED_LAUNCH(1, DD, false)                                                                                           \
         break;
-    const bool wg = (csr->dense != 0 || a.lanes_per_seg >= 16) && vec >= 4;
+    const bool wg = ((csr->dense & 1) != 0 || a.lanes_per_seg >= 16) && vec >= 4 && !(csr->dense & 2);
     switch (d) { LN_FUSED_CASE(1) LN_FUSED_CASE(2) LN_FUSED_CASE(3) LN_FUSED_CASE(4) LN_FUSED_CASE(5) LN_FUSED_CASE(6) }
 #undef LN_FUSED_LAUNCH
 #undef LN_FUSED_CASE

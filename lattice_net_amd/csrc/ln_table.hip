@@ -92,7 +92,7 @@ LnProfEvents ln_prof_next(const char* name) {
     return ev;
 }
 
-extern "C" const char* ln_kernel_names(void) { return "k_bucket_rows,k_canon_idx,k_canon_mark,k_canon_segs,k_canon_slots,k_conv_backward_fused,k_conv_generic,k_conv_generic_f16,k_conv_mfma,k_conv_mfma_f16,k_conv_split_bank,k_conv_sum_partials,k_csr_count,k_csr_fill,k_csr_group_sizes,k_csr_reduce_segments,k_csr_scan_local,k_csr_scan_top,k_csr_segment_max,k_csr_segment_max_decode,k_distribute_centre,k_finalize,k_gather_backward,k_gather_forward,k_gn_apply,k_gn_backward_apply,k_gn_stats,k_grad_filter_f16,k_grad_filter_generic,k_grad_filter_mfma,k_grad_filter_mfma_f16,k_im2row,k_im2rowindices,k_insert_coarse,k_insert_points,k_linear_act_backward_w,k_linear_act_backward_x,k_linear_act_forward,k_linear_reduce_slabs,k_mark_first,k_max_centre_backward,k_max_centre_forward,k_max_centre_sum,k_neighbours,k_nll_backward,k_nll_finish,k_nll_partials,k_point_keys,k_pointnet_reduce_backward,k_pointnet_reduce_decode,k_reduce_and_neighbours,k_reduce_slabs,k_rehash_clear,k_rehash_rows,k_retrieve_points,k_row2im,k_sc_reduce_slabs,k_sc_scatter_atomic,k_scan_blocks,k_scatter_point_rows,k_seg_min,k_slice_classify_backward,k_slice_classify_forward,k_slice_forward,k_slice_forward_f16,k_table_clear,k_weight_norm_backward,k_weight_norm_forward,ln_k_arena_init"; }
+extern "C" const char* ln_kernel_names(void) { return "k_bucket_rows,k_canon_idx,k_canon_mark,k_canon_segs,k_canon_slots,k_conv_backward_fused,k_conv_generic,k_conv_generic_f16,k_conv_mfma,k_conv_mfma_f16,k_conv_split_bank,k_conv_sum_partials,k_csr_count,k_csr_fill,k_csr_group_sizes,k_csr_reduce_segments,k_csr_scan_local,k_csr_scan_top,k_csr_copy_tokens,k_csr_segment_max,k_csr_segment_max_decode,k_csr_sort_groups,k_distribute_centre,k_finalize,k_gather_backward,k_gather_forward,k_gn_apply,k_gn_backward_apply,k_gn_stats,k_grad_filter_f16,k_grad_filter_generic,k_grad_filter_mfma,k_grad_filter_mfma_f16,k_im2row,k_im2rowindices,k_insert_coarse,k_insert_points,k_linear_act_backward_w,k_linear_act_backward_x,k_linear_act_forward,k_linear_reduce_slabs,k_mark_first,k_max_centre_backward,k_max_centre_forward,k_max_centre_sum,k_neighbours,k_nll_backward,k_nll_finish,k_nll_partials,k_point_keys,k_pointnet_reduce_backward,k_pointnet_reduce_decode,k_reduce_and_neighbours,k_reduce_slabs,k_rehash_clear,k_rehash_rows,k_retrieve_points,k_row2im,k_sc_reduce_slabs,k_sc_scatter_atomic,k_scan_blocks,k_scatter_point_rows,k_seg_min,k_slice_classify_backward,k_slice_classify_forward,k_slice_forward,k_slice_forward_f16,k_table_clear,k_weight_norm_backward,k_weight_norm_forward,ln_k_arena_init"; }
 
 extern "C" int ln_profile_begin(const char* kernel_names, int max_samples) {
     LN_REQUIRE(kernel_names && strlen(kernel_names) + 3 < sizeof(g_prof.names) && max_samples > 0, LN_ERR_ARG, "ln_profile_begin: bad args");
@@ -1371,10 +1371,13 @@ static int ln_build_points(const LnTable* t, const float* positions_raw, const f
                       ws.part_tok, ws.part_pk, ws.part_slot, ws.part_pos, dropped_idx, *csr, ws.pub);
             rc = ln_check_launch(who);
             if (rc == LN_OK && (flags & LN_BUILD_CANONICAL_ROWS)) rc = ln_canonicalize_impl<D>(*t, dropped_idx, tokens, csr, ws, st);
+            if (rc == LN_OK && (flags & LN_BUILD_SORTED_CSR)) rc = ln_csr_sort_groups(*csr, t->capacity, ws.tok_slot, st);
         } else {
             LN_LAUNCH("k_insert_points", k_insert_points<D>, dim3(ln_div_up(tokens, 256)), dim3(256), 0, st, *t, positions_raw, sc, n, tok_slot,
                       ws.tok_pos, write_idx ? w : (float*)nullptr, vals, val_dim, distributed);
             rc = ln_rank_and_finalize<D>(*t, tok_slot, ws.tok_pos, write_idx ? idx : (int*)nullptr, tokens, ws, *csr, st);
+            // (tok_pos is free again behind the fill: the scratch of the sort; tok_slot may be the caller's idx)
+            if (rc == LN_OK && (flags & LN_BUILD_SORTED_CSR)) rc = ln_csr_sort_groups(*csr, t->capacity, ws.tok_pos, st);
         }
     });
     return rc;

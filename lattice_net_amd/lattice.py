@@ -28,7 +28,7 @@ import torch.utils.weak
 
 from . import _lib
 
-__all__ = ["Lattice", "HashTable", "set_row_order", "get_row_order", "set_hash_capacity_policy", "set_slot_order", "set_bank_cache"]
+__all__ = ["Lattice", "HashTable", "set_row_order", "get_row_order", "set_hash_capacity_policy", "set_slot_order", "set_bank_cache", "set_deterministic"]
 
 
 _SIZE_CACHE = {}
@@ -110,6 +110,19 @@ def set_slot_order(order: str) -> str:
     if order not in ("space", "hash"):
         raise ValueError(f"slot order must be 'space' or 'hash', got {order!r}")
     prev, _SLOT_ORDER[0] = _SLOT_ORDER[0], order
+    return prev
+
+
+# Run-to-run identical floating-point results of everything that sums over the tokens of a vertex (splat values, position means,
+# slice / gather / slice_classify gradients).  The default kernels are deterministic in WHAT they sum and free in the ORDER: a
+# token's place in its vertex's list comes from an atomic counter of the build, and rows with several segments combine through float
+# atomics.  With this switch every build sorts the token lists (LN_BUILD_SORTED_CSR) and every reduce walks a row with one lane
+# group in list order (LnCsr.dense & 2) — slower on hot vertices; meant for tests and for debugging a training run.
+_DETERMINISTIC = [os.environ.get("LATTICE_DETERMINISTIC", "0") == "1"]
+
+
+def set_deterministic(on: bool) -> bool:
+    prev, _DETERMINISTIC[0] = _DETERMINISTIC[0], bool(on)
     return prev
 
 
@@ -680,6 +693,8 @@ class Lattice:
                 flags |= _lib.LN_BUILD_ATOMIC_PATH
             if _ROW_ORDER[0] == "canonical":
                 flags |= _lib.LN_BUILD_CANONICAL_ROWS
+            if _DETERMINISTIC[0]:
+                flags |= _lib.LN_BUILD_SORTED_CSR
             cv, cn = _lib.ptr(clear_vals), clear_elems
             ht.arm_count_readback()  # t is ht's cached struct: the sequence number travels in it
             if distributed is None:
@@ -783,6 +798,8 @@ class Lattice:
         csr_buf, csr, max_seg = self._alloc_csr(tokens, rows_upper)
         ws = self._workspace(_build_sizes(tokens, rows_upper)[1])
         _lib.check(lib.ln_csr_build(_lib.ptr(idx), tokens, rows_upper, C.byref(csr), _lib.ptr(ws), ws.numel(), self._stream()), "ln_csr_build")
+        if _DETERMINISTIC[0]:
+            _lib.check(lib.ln_csr_sort(C.byref(csr), rows_upper, _lib.ptr(ws), ws.numel(), tokens, self._stream()), "ln_csr_sort")
         if len(st.csr_cache) >= 4:
             st.csr_cache.pop(next(iter(st.csr_cache)))
         entry = (csr_buf, csr, max_seg, None, idx)  # groups are rows: no indirection
@@ -794,7 +811,7 @@ class Lattice:
         by the vertex count of the last build this table reported — a fresh table answers 0; the hint only selects a kernel variant)."""
         ht = self.m_hash_table
         m = ht._static_rows if ht._static_rows is not None else ht.m_nr_filled
-        return 1 if (m is not None and m > 0 and tokens >= _DENSE_TOKENS_PER_VERTEX * m) else 0
+        return (1 if (m is not None and m > 0 and tokens >= _DENSE_TOKENS_PER_VERTEX * m) else 0) | (2 if _DETERMINISTIC[0] else 0)
 
     def _scatter_rows(self, src: torch.Tensor, idx: torch.Tensor, w: torch.Tensor, dst: torch.Tensor, val_dim: int, src_div: int,
                       src_stride: int):

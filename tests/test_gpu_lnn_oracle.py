@@ -177,7 +177,16 @@ def test_pointnet_rule_fewer_than_four_points_matches_oracle(tmp_path):
     assert rel(g_lv.cpu().numpy(), o_lv.numpy()) < 1e-5
 
 
-def test_semantic_kitti_network_at_full_size_matches_the_reference_networks_own_output():
+@pytest.fixture
+def deterministic_backend():
+    """lattice.set_deterministic(True): sorted token lists + one fixed summation order in every segment reduce."""
+    from lattice_net_amd import lattice as LT
+    prev = LT.set_deterministic(True)
+    yield
+    LT.set_deterministic(prev)
+
+
+def test_semantic_kitti_network_at_full_size_matches_the_reference_networks_own_output(deterministic_backend):
     """BASELINE.json configs[2] at its own size (120 000 points; 46.5 k / 11.4 k / 2.6 k lattice vertices): the GPU network against
     tests/golden/F12_reference_lnn_kitti.npz = the REFERENCE's own `LNN` Python with the model block of
     config/lnn_train_semantic_kitti.cfg:36-47 executed in float64 over the oracle lattice (make_reference_network_fixture.py --case
@@ -185,14 +194,15 @@ def test_semantic_kitti_network_at_full_size_matches_the_reference_networks_own_
     their flipped / transposed backward forms, k_grad_filter_b3, the fused 32-channel kernels at three sub-tiles, the level-crossing
     convolutions, the wave-tiled slice_classify.
 
-    What is asserted, and why not 1e-4 per entry as at 1500 points (F10): the network has ~10^8 kinks at this size (ReLU, the PointNet
-    maximum with the winner's barycentric weight) and the GPU run is not bitwise reproducible (atomics in the torch glue), so any
-    (seed, run) can land one decision on the other side — a LOCALISED O(1e-3) difference that the GroupNorm statistics and the receptive
-    field then spread thinly (tools/probes/f12_scale_probe.py; the fixture's seed showed none in three runs).  Asserted always: the
-    logits' checksum and the loss to 1e-4, median logit error <= 2e-5 of the largest logit, >= 50 % of the sampled points within 1e-4,
-    relative L2 error of the logits <= 2e-2, every gradient tensor's relative L2 error <= 0.15 and norm within 6e-2 (a wrong operand
-    in any kernel is O(1)).  Asserted when no decision flipped (every sampled logit within 1e-4 — the expected case): gradients to
-    2e-2 relative L2 / 1e-2 in norm (ReLU derivatives flip in the backward pass even then; the measured worst is 5e-3 / 2e-3)."""
+    The network has ~10^8 kinks at this size (ReLU, the PointNet maximum with the winner's barycentric weight): a float32 evaluation
+    can land ONE decision on the other side of the float64 reference — a localised O(1e-3) difference that the GroupNorm statistics
+    then spread thinly.  Until round 6 the GPU run was not reproducible (the summation order of a vertex's tokens came from atomic
+    counters), so the same seed flipped in one run and not in the next and this test had to recognise a flip instead of failing on it.
+    It now runs in the backend's deterministic mode — one fixed summation order, bitwise identical logits and gradients run to run
+    (test_network_is_bitwise_reproducible_in_deterministic_mode) — with a fixture seed whose deterministic evaluation flips nothing,
+    and asserts the no-flip bars unconditionally: the logits' checksum and the loss to 1e-4, EVERY sampled logit within 1e-4 of the
+    largest logit (measured: 4.2e-6), every gradient tensor to 2e-2 relative L2 and 1e-2 in norm (ReLU derivatives flip in the backward
+    pass even then; measured worst 5e-3 / 2e-3)."""
     import os
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
@@ -209,10 +219,7 @@ def test_semantic_kitti_network_at_full_size_matches_the_reference_networks_own_
     assert abs(float(loss.detach()) - float(fx["loss"])) <= TOL * abs(float(fx["loss"]))
     lg = logits.detach().cpu().double().numpy()[logits_sample_index(n, fx["logits"].shape[0])]
     err = np.abs(lg - fx["logits"]) / np.abs(fx["logits"]).max()
-    rel_l2 = float(np.linalg.norm(lg - fx["logits"]) / np.linalg.norm(fx["logits"]))
-    within = float((err.max(1) <= TOL).mean())
-    assert np.median(err) <= 2e-5 and within >= 0.5 and rel_l2 <= 2e-2, (float(np.median(err)), within, rel_l2, float(err.max()))
-    no_flip = bool(err.max() <= TOL)
+    assert err.max() <= TOL, (float(err.max()), float(np.median(err)), float((err.max(1) <= TOL).mean()))
     named = dict(net.named_parameters())
     gmax = float(np.nanmax(fx["grad_norms"]))
     worst_l2, worst_norm = (0.0, ""), (0.0, "")
@@ -228,5 +235,28 @@ def test_semantic_kitti_network_at_full_size_matches_the_reference_networks_own_
             ref, g = fx[f"grad_sample/{i}"], g[gradient_sample_index(g.size)]
         floor = 1e-3 * gmax * np.sqrt(ref.size / max(named[k].numel(), 1))
         worst_l2 = max(worst_l2, (float(np.linalg.norm(g - ref)) / max(float(np.linalg.norm(ref)), floor), k))
-    l2_bar, norm_bar = (2e-2, 1e-2) if no_flip else (0.15, 6e-2)
-    assert worst_l2[0] <= l2_bar and worst_norm[0] <= norm_bar, (no_flip, worst_l2, worst_norm, float(err.max()), within)
+    assert worst_l2[0] <= 2e-2 and worst_norm[0] <= 1e-2, (worst_l2, worst_norm, float(err.max()))
+
+
+def test_network_is_bitwise_reproducible_in_deterministic_mode(deterministic_backend):
+    """Five consecutive forward + backward passes of the SemanticKITTI-size network in deterministic mode: the logits and every parameter
+    gradient are bit for bit the same (in the default mode five runs give five different bit patterns — tools/probes/r6_determinism.py).
+    What the mode fixes: the order of the tokens in every vertex's list (LN_BUILD_SORTED_CSR) and the summation order of every segment
+    reduce (LnCsr.dense & 2: one lane group per row, no float atomics); the torch operators of the step are deterministic already."""
+    import hashlib
+    from tests.test_model_assembly import kitti_fixture_case
+    fx, net, lattice, pos, target = kitti_fixture_case(dev(), torch.float32)
+    n = pos.shape[0]
+    pos, target, vals = pos.to(dev()), target.to(dev()), torch.zeros((n, 1), device=dev())
+    seen = set()
+    for _ in range(5):
+        net.zero_grad(set_to_none=True)
+        logsoftmax, logits = net(lattice, pos, vals)
+        torch.nn.functional.nll_loss(logsoftmax, target).backward()
+        torch.cuda.synchronize()
+        h = hashlib.sha1(logits.detach().cpu().numpy().tobytes())
+        for p in net.parameters():
+            if p.grad is not None:
+                h.update(p.grad.detach().cpu().numpy().tobytes())
+        seen.add(h.hexdigest())
+    assert len(seen) == 1, f"{len(seen)} different results in 5 runs"
