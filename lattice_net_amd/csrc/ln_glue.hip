@@ -22,6 +22,8 @@
 //   g_dim == 1 (g per column): address k * C + j, K = R
 struct LnWnShape {
     int J, K, sj, sk;
+    int C, per_col;  // row width of v [R, C] and "g runs along the columns" — stated, not inferred from the strides (sj == 1 also holds for
+                     // g_dim 0 with one column)
 };
 
 __device__ __forceinline__ float ln_wn_block_sum(float x, float* s_red) {
@@ -49,11 +51,11 @@ __global__ void __launch_bounds__(LN_WN_THREADS)
     }
     const float n = sqrtf(ln_wn_block_sum(acc, s_red));
     if (threadIdx.x == 0) norm_out[0] = n;
-    // plain [R, C] walk: i = row * C + col; j = row (g_dim 0: sj = C) or col (g_dim 1: sj = 1)
-    const int C = s.sj == 1 ? s.J : s.K;
+    // plain [R, C] walk: i = row * C + col; j = row (g_dim 0) or col (g_dim 1)
+    const int C = s.C;
     for (long long i = threadIdx.x; i < total; i += LN_WN_THREADS) {
         const int row = int(i / C), col = int(i - (long long)row * C);
-        const int j = s.sj == 1 ? col : row;
+        const int j = s.per_col ? col : row;
         w[i] = v[i] * (g[j] / n);
     }
 }
@@ -87,17 +89,17 @@ __global__ void __launch_bounds__(LN_WN_THREADS)
     const float t = ln_wn_block_sum(mine, s_red);  // sum_j g[j] * dot[j]
     const float dn_over_n = -t / (n * n * n);       // (dL/dn) / n
     const long long total = (long long)s.J * s.K;
-    const int C = s.sj == 1 ? s.J : s.K;
+    const int C = s.C;
     for (long long i = threadIdx.x; i < total; i += LN_WN_THREADS) {
         const int row = int(i / C), col = int(i - (long long)row * C);
-        const int jj = s.sj == 1 ? col : row;
+        const int jj = s.per_col ? col : row;
         gv[i] = gw[i] * (g[jj] / n) + v[i] * dn_over_n;
     }
 }
 
 static int ln_wn_shape(const char* who, int rows, int cols, int g_dim, LnWnShape& s) {
     LN_REQUIRE(rows >= 1 && cols >= 1 && (g_dim == 0 || g_dim == 1), LN_ERR_ARG, "%s: bad sizes", who);
-    s = g_dim == 0 ? LnWnShape{rows, cols, cols, 1} : LnWnShape{cols, rows, 1, cols};
+    s = g_dim == 0 ? LnWnShape{rows, cols, cols, 1, cols, 0} : LnWnShape{cols, rows, 1, cols, cols, 1};
     LN_REQUIRE(s.J <= LN_WN_MAX_G, LN_ERR_UNSUPPORTED, "%s: at most %d magnitudes (got %d)", who, LN_WN_MAX_G, s.J);
     LN_REQUIRE((long long)rows * cols <= (1ll << 24), LN_ERR_UNSUPPORTED, "%s: parameter too large for the one-workgroup form", who);
     return LN_OK;

@@ -89,8 +89,10 @@ class _WeightNormed:
     @property
     def weight(self) -> torch.Tensor:
         v, g = self.weight_v, self.weight_g
+        # (the kernels read g[j] for j < v.shape[g_dim] and write grad_g with the same extent: a magnitude vector of any other length —
+        # a reshaped or hand-loaded parameter, a scalar g — takes the torch chain)
         if "weight_norm" in FUSED_GLUE and v.is_cuda and v.dtype == torch.float32 and g.dtype == torch.float32 and v.dim() == 2 and 1 <= g.numel() <= 1024 and \
-                0 < v.numel() <= (1 << 24) and getattr(self, "_g_dim", None) in (0, 1):
+                0 < v.numel() <= (1 << 24) and getattr(self, "_g_dim", None) in (0, 1) and g.numel() == v.shape[self._g_dim]:
             return WeightNormFunction.apply(v, g, self._g_dim)
         return v * (g / v.norm())
 
@@ -346,8 +348,10 @@ class PointNetModule(torch.nn.Module):  # lattice_modules.py:618-733 (the step r
         x = distributed[:, : distributed.shape[1] - 1]
         for layer in self.layers:  # linear + LeakyReLU(0.2) per token, fused (mods:669-671)
             x = linear_leaky_relu(x, layer.weight, layer.bias, self.act.negative_slope)
+        # (the fused reduction hands raw pointers of `indices` to the kernels and returns no gradient for `distributed`: a caller that
+        # wants gradients through the positions, or passes a strided index view, takes the torch chain below)
         if "pointnet" in FUSED_GLUE and x.is_cuda and x.dtype == torch.float32 and distributed.dtype == torch.float32 and \
-                distributed.is_contiguous() and not distributed.requires_grad and indices.dtype == torch.int32:
+                distributed.is_contiguous() and not distributed.requires_grad and indices.dtype == torch.int32 and indices.is_contiguous():
             # scatter_max + degrees + the winners' barycentric weights + both zeroing rules in three launches (mods:688-712)
             reduced = PointNetReduceFunction.apply(x, distributed, lattice_py, indices)
             lattice_py.set_values(reduced)

@@ -27,7 +27,13 @@ def init(backend: str, device=None):
         # whatever started it (one shell or ssh session per rank, container entrypoints): a fixed default, outside torchrun's own
         # 29500.  Two jobs side by side on one host have to be given different MASTER_PORTs by whoever starts them.
         # LATTICE_JOB_ID (any integer) moves the default so that two launcher-less jobs on one host do not meet in one store.
-        os.environ["MASTER_PORT"] = str(29511 + int(os.environ.get("LATTICE_JOB_ID", "0")) % 2000)
+        job = os.environ.get("LATTICE_JOB_ID", "0")
+        try:
+            offset = int(job) % 2000
+        except ValueError:  # (any string works: a stable hash of it)
+            import zlib
+            offset = zlib.crc32(job.encode()) % 2000
+        os.environ["MASTER_PORT"] = str(29511 + offset)
     import datetime
     kwargs["timeout"] = datetime.timedelta(seconds=int(os.environ.get("LATTICE_RENDEZVOUS_TIMEOUT_S", "600")))
     if backend == "nccl" and device is not None:
@@ -88,6 +94,16 @@ def pin_launch_thread(local_rank: int, local_world: int, sysfs_root: str = "/sys
         return have
     mine = None
     nodes = gpu_numa_nodes(sysfs_root)
+    # sysfs lists ALL AMD GPUs in PCI order; a job that was handed a subset (HIP_/ROCR_/CUDA_VISIBLE_DEVICES) sees them renumbered.
+    # Integer lists are mapped through (rank r uses physical GPU list[r]); anything else (UUIDs, several variables at once) is not
+    # trusted: contiguous slices of the allowed cores instead of the NUMA node of the WRONG GPUs.
+    visible = [os.environ.get(k) for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES") if os.environ.get(k)]
+    if visible:
+        try:
+            ids = [int(x) for x in visible[0].split(",")] if len(set(visible)) == 1 else None
+        except ValueError:
+            ids = None
+        nodes = [nodes[i] for i in ids] if (ids and all(0 <= i < len(nodes) for i in ids)) else []
     if len(nodes) >= local_world and all(n >= 0 for n in nodes[:local_world]):
         node = nodes[local_rank]
         try:
