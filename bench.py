@@ -714,7 +714,9 @@ def main():
                     "frac_of_instruction_peak": round(tf * mw[1] / ipeak, 4), "frac_fp32_equivalent_of_f32_peak": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
                     "instruction": "bf16 (fp32 operands split three ways, 6 products per fp32 product)" if mw[1] > 1.0 else
                                    ("f16" if half else "v_mfma_f32_16x16x4_f32")}
-        return {"bound": bound_kind, "achieved": round(achieved, 3), "peak": peak, "unit": unit, "frac": round(achieved / peak, 4), "mfma": mfma,
+        rule = ("convolutions: HBM-bound below 64 channels, matrix-bound from 64 on (SURVEY 8(d); rule of rounds 5+, rounds 1-4 switched at 128 — "
+                "fractions of 64..127-channel workloads are not comparable across that change)") if "conv" in kernel else None
+        return {"bound": bound_kind, "bound_rule": rule, "achieved": round(achieved, 3), "peak": peak, "unit": unit, "frac": round(achieved / peak, 4), "mfma": mfma,
                 "traffic": pmc_traffic(kernel) if args.workload == "C3" else None, "kernel": "+".join(names),
                 "avg_us": round(avg_s * 1e6, 2), "avg_us_in_flight": round(per_group(loaded) * 1e6, 2) if loaded else None,
                 "launches_timed": alone[1],

@@ -1263,6 +1263,51 @@ static int ln_conv_slots_per_split(int m, int E, int nr_filters) {
     if (nsplit > E) nsplit = E;
     return (E + nsplit - 1) / nsplit;  // slots per workgroup
 }
+#ifndef LN_CONV_WIDE_SPLIT_MIN_V
+#define LN_CONV_WIDE_SPLIT_MIN_V 128
+#endif
+#ifndef LN_CONV_B3_MIN_ROWS
+#define LN_CONV_B3_MIN_ROWS 4096
+#endif
+static size_t ln_conv_bank_bytes(int m, int E, int val_dim, int nr_filters);
+// Slot split of the WIDE form on mid-size lattices (0 / 1: not taken), from 128 gathered channels on where the 192-row workgroups of
+// the unsplit wide form would fill less than half the chip.  LN_CONV_WIDE_SPLIT=0 switches it off, =N forces N (A/B; read once).
+// Measured at 11.4 k rows (level 2 of the SemanticKITTI network; tools/conv_time.py --coarse 1, us per call incl. bank split and
+// partial sum): 128 -> 128 46.9 -> 35.7, 256 -> 256 296 -> 109, 192 -> 192 191 -> 76, 256 -> 128 157 -> 55, 128 -> 64 32.2 -> 26.3.
+template <int V>
+static int ln_conv_wide_split(int m, int E, int nr_filters, bool have_bank) {
+    static int knob = -2;
+    if (knob == -2) {
+        const char* e = getenv("LN_CONV_WIDE_SPLIT");
+        knob = e ? atoi(e) : -1;
+    }
+    if (knob == 0 || !have_bank || V % 32 != 0 || V < LN_CONV_WIDE_SPLIT_MIN_V || nr_filters % 32 != 0 || E < 3 || m < LN_CONV_B3_MIN_ROWS) return 0;
+    if ((long long)ln_div_up(m, 192) * ln_div_up(nr_filters, 128) >= LN_BWD_CUS / 2) return 0;  // the unsplit wide form already runs
+    if (knob > 1) return knob <= E ? knob : E;
+    // workgroups of the widest launch: the 128-column chunks go out together, a narrower rest as a launch of its own
+    const long long wgs = (long long)ln_div_up(m, 192) * (nr_filters >= 128 ? nr_filters / 128 : 1);
+    // rounds of one workgroup per CU x slots walked per workgroup; the smallest split among the cheapest (fewer partial slabs)
+    int best = 1;
+    long long best_cost = 1ll << 60;
+    for (int n = 2; n <= E; ++n) {
+        const long long cost = ((wgs * n + LN_BWD_CUS - 1) / LN_BWD_CUS) * ((E + n - 1) / n);
+        if (cost < best_cost) {
+            best = n;
+            best_cost = cost;
+        }
+    }
+    return best;
+}
+static int ln_conv_wide_split_rt(int m, int E, int val_dim, int nr_filters) {
+    const bool bank = ln_conv_bank_bytes(m, E, val_dim, nr_filters) > 0;
+    switch (val_dim) {
+        case 96: return ln_conv_wide_split<96>(m, E, nr_filters, bank);
+        case 128: return ln_conv_wide_split<128>(m, E, nr_filters, bank);
+        case 192: return ln_conv_wide_split<192>(m, E, nr_filters, bank);
+        case 256: return ln_conv_wide_split<256>(m, E, nr_filters, bank);
+        default: return 0;
+    }
+}
 static int ln_conv_slots_per_split_rt(int m, int E, int val_dim, int nr_filters) {
     switch (val_dim) {
         case 8: return ln_conv_slots_per_split<8>(m, E, nr_filters);
@@ -1312,7 +1357,9 @@ extern "C" size_t ln_conv_bank_workspace_bytes(int m, int filter_extent, int val
 
 extern "C" size_t ln_conv_forward_workspace_bytes(int m, int filter_extent, int val_dim, int nr_filters) {
     if (m <= 0 || nr_filters % 16 != 0) return 256;
-    const int e_per = ln_conv_slots_per_split_rt(m, filter_extent, val_dim, nr_filters);
+    int e_per = ln_conv_slots_per_split_rt(m, filter_extent, val_dim, nr_filters);
+    const int ws_ = ln_conv_wide_split_rt(m, filter_extent, val_dim, nr_filters);
+    if (ws_ > 1) e_per = (filter_extent + ws_ - 1) / ws_;
     const int nsplit = (filter_extent + e_per - 1) / e_per;
     // + the filter bank split into three bf16 parts (bf16x3 path of the per-slot kernel; not the small-filter fast path)
     const bool small_filter = filter_extent == 9 && (size_t)filter_extent * val_dim * nr_filters * 4 <= 64 * 1024 && val_dim <= 32;
@@ -1367,10 +1414,19 @@ static bool ln_conv_launch_v(int nr_filters, const int* nbr, const float* values
     const size_t slab_bytes = ws_ok ? workspace_bytes - (b3 ? bank_bytes : 0) : 0;
     int e_per = ln_conv_slots_per_split<V>(m, E, nr_filters);
     int nsplit = (E + e_per - 1) / e_per;
+    // Mid-size lattices with wide rows (coarse levels of a U-net: 5-30 k rows x 128+ channels): too few 192-row workgroups for the wide
+    // form, and the 16-row kernels re-gather every row once per column chunk.  There the wide form runs with the slots split over
+    // gridDim.z (its workgroups then fill the chip) and the partial sums are added by the launch behind it.
+    const int wide_split = ln_conv_wide_split<V>(m, E, nr_filters, bank_bytes > 0 && ws_ok && workspace_bytes >= bank_bytes);
+    if (wide_split > 1) {
+        e_per = (E + wide_split - 1) / wide_split;
+        nsplit = (E + e_per - 1) / e_per;
+    }
     if (nsplit > 1 && (!slab_ws || slab_bytes < (size_t)nsplit * m * nr_filters * sizeof(float))) {
         e_per = E;  // no room for the partial slabs: one workgroup walks all slots
         nsplit = 1;
     }
+    const bool wide_mid = wide_split > 1 && nsplit > 1;
     float* dst = nsplit > 1 ? reinterpret_cast<float*>(slab_ws) : out;
     int f_off = 0;
     size_t bank_off = 0;  // bf16 elements
@@ -1379,8 +1435,8 @@ static bool ln_conv_launch_v(int nr_filters, const int* nbr, const float* values
     if constexpr (V % 32 == 0) {
         // taken from 96 gathered channels on (below, the 16-row kernels' gathers are as fast: 64 x 64 27 vs 29 us at 46 k rows) and
         // while the 192-row workgroups alone fill half the chip (no slot split in this form)
-        if (b3 && nr_filters % 32 == 0 && V >= 96 && nsplit == 1 && (long long)ln_div_up(m, 192) * ln_div_up(nr_filters, 128) >= LN_BWD_CUS / 2 &&
-            ln_conv_rows32_enabled()) {
+        if (b3 && nr_filters % 32 == 0 && V >= 96 && ln_conv_rows32_enabled() &&
+            (wide_mid || (nsplit == 1 && (long long)ln_div_up(m, 192) * ln_div_up(nr_filters, 128) >= LN_BWD_CUS / 2))) {
 #define LN_CONV_R32SK(NTC, RTT)                                                                                                     \
     {                                                                                                                               \
         const int cnt = (nr_filters - f_off) / (32 * NTC);                                                                          \

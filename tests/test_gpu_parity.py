@@ -835,3 +835,47 @@ def test_c5_aggregated_scans_size():
     ref = rows.reshape(2000, -1) @ N(W).astype(np.float64)
     scale = float(np.max(np.abs(rows.reshape(2000, -1)) @ np.abs(N(W).astype(np.float64))))
     close(N(conv.values())[pick], ref, scale=scale)
+
+
+@pytest.mark.parametrize("v,f", [(128, 128), (256, 256), (192, 192), (256, 128), (128, 256), (128, 64), (96, 96)])
+def test_conv_on_a_mid_size_lattice_wide_form_with_slot_split(v, f):
+    """Coarse levels of a U-net (5-30 k rows, 128+ channels): the wide convolution form with the filter slots split over gridDim.z and
+    the partial sums added behind it (ln_conv_wide_split).  Forward, flipped forward and both gradients against fp64 with the
+    per-element bound, on level 2 of the SemanticKITTI lattice (11.4 k rows)."""
+    from lattice_net_amd import ConvIm2RowLattice
+    from lattice_net_amd.synthetic import lidar_cloud
+    pos_np = lidar_cloud(120000, 0)
+    lat = make_lattice(1.8, 100000)  # (sigma doubled: the level-2 lattice of the network, built directly)
+    lat.begin_splat()
+    lat.just_create_verts(T(pos_np), False)
+    m = lat.nr_lattice_vertices()
+    assert 8000 < m < 16000
+    t, _, _, _ = oracle_build(pos_np, 1.8, 100000, write=False)
+    assert t.nr_filled == m
+    rng = np.random.default_rng(v + f)
+    vals = torch.tensor(rng.standard_normal((m, v)).astype(np.float32), device=dev(), requires_grad=True)
+    W = torch.tensor((rng.standard_normal((9 * v, f)) / np.sqrt(9 * v)).astype(np.float32), device=dev(), requires_grad=True)
+    G = torch.tensor(rng.standard_normal((m, f)).astype(np.float32), device=dev())
+    lat.set_values(vals.detach())
+    nbr_np = O.neighbour_rows(t.keys[:m], t, 1, 1, 1, False)
+    nbr_f = O.neighbour_rows(t.keys[:m], t, 1, 1, 1, True)
+    rows_f = O.im2row(nbr_f, vals.detach().cpu().numpy()).astype(np.float64)
+    conv_f = lat.convolve_im2row_standalone(W.detach(), 1, lat, True)
+    close_terms(N(conv_f.values()), rows_f @ W.detach().cpu().double().numpy(), np.abs(rows_f) @ np.abs(W.detach().cpu().double().numpy()))
+    out, _ = ConvIm2RowLattice.apply(vals, lat, W, 1)
+    (out * G).sum().backward()
+    nbr = torch.from_numpy(nbr_np.astype(np.int64))
+
+    def graph(v64, w64, g64):
+        padded = torch.cat([v64, torch.zeros((1, v), dtype=torch.float64)], 0)
+        rows = padded[torch.where(nbr >= 0, nbr, torch.full_like(nbr, m))].reshape(m, 9 * v)
+        ref = rows @ w64
+        (ref * g64).sum().backward()
+        return ref.detach().numpy()
+    v64, w64 = vals.detach().cpu().double().requires_grad_(True), W.detach().cpu().double().requires_grad_(True)
+    ref = graph(v64, w64, G.cpu().double())
+    va, wa = vals.detach().cpu().double().abs().requires_grad_(True), W.detach().cpu().double().abs().requires_grad_(True)
+    ref_a = graph(va, wa, G.cpu().double().abs())
+    close_terms(N(out), ref, ref_a)
+    close_terms(N(vals.grad), v64.grad.numpy(), va.grad.numpy())
+    close_terms(N(W.grad), w64.grad.numpy(), wa.grad.numpy())
