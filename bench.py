@@ -380,7 +380,7 @@ def full_unet_step(dev, n: int, steps: int = 10, warmup: int = 3, classes: int =
            "ms_per_step": round(dt * 1e3, 3), "mpoints_per_s": round(n / dt / 1e6, 2), "parameters": sum(p.numel() for p in net.parameters()),
            "steps": steps, "algorithmic_floor_ms": floor.get("floor_ms") if floor else None,
            "algorithmic_floor": floor, "algorithmic_floor_what": "sum over the lattice operators of the step (SURVEY 8(a) rows: builds, distribute, convolutions "
-           "forward + backward, slice / gather / slice_classify) of max(8(d) bytes / 8 TB/s, flop / 157.3 TFLOP/s); GroupNorm, MLP, loss and optimizer are not in it"}
+           "forward + backward, slice / gather / slice_classify) of max(8(d) bytes / 8 TB/s, flop / (2.5 PFLOP/s bf16 / 6 products per fp32 product)); GroupNorm, MLP, loss and optimizer are not in it"}
     # The same step with forward + loss + backward captured as ONE hipGraph (lattice_net_amd.CapturedNetworkStep: static row bounds
     # on every lattice level, GroupNorm over the device-side vertex count), timed by tools/bench_lnn.py in a CHILD
     # process: a secondary number must not be able to take the headline down with it.

@@ -2,16 +2,17 @@
 """Algorithmic floor of the lattice operators inside a whole-network step (bench.py `full_unet_ms.algorithmic_floor_ms`).
 
 `trace(step)` runs `step()` once with the Lattice methods of the hot path wrapped, records (operator, sizes) of every call — forward and
-backward — and prices each with SURVEY.md 8(d)'s per-unit byte / flop figures at the chip's peaks (HBM 8 TB/s; dense fp32-input MFMA
-157.3 TFLOP/s for the contraction, which 8(d) calls matrix-bound from 64 channels on): floor of an operator = max(bytes / HBM peak,
-flop / MFMA peak).  The sum is what the lattice operators of the step would cost if every one of them ran at its roofline; GroupNorm,
+backward — and prices each with SURVEY.md 8(d)'s per-unit byte / flop figures at the chip's peaks: HBM 8 TB/s, and for the
+contraction the rate at which the matrix cores can deliver fp32-class products — the dense bf16 peak (2.5 PFLOP/s) divided by the 6
+bf16 products the exact 3-way operand split spends per fp32 product = 417 TFLOP/s (the fp32-input MFMA peak, 157 TFLOP/s, is LOWER
+than what the bf16x3 kernels already deliver and would not be a floor): floor of an operator = max(bytes / HBM peak, flop / 417 T).  The sum is what the lattice operators of the step would cost if every one of them ran at its roofline; GroupNorm,
 the PointNet MLP, the optimizer and the loss are outside 8(a) and not in it."""
 from __future__ import annotations
 
 import collections
 
 HBM = 8.0e12
-MFMA_F32 = 157.3e12
+MFMA_F32 = 2500.0e12 / 6.0  # fp32-class products on the bf16 pipe (bf16x3: 6 products each)
 
 
 def _floor(nbytes, flop=0.0):
