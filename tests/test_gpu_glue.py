@@ -176,9 +176,31 @@ def test_split_bank_of_an_unchanged_filter_is_reused_and_invalidated_by_in_place
         assert lib.ln_profile_end(C.byref(ms), C.byref(cnt)) == 0
         return y, cnt.value
 
+    from lattice_net_amd import lattice as LT
+    _, na = conv_and_count()
+    _, nb = conv_and_count()
+    assert na >= 1 and nb >= 1                                      # the cache is opt-in (round 6, advisor): off by default, every call splits
+    prev = LT.set_bank_cache(True)
+    try:
+        _bank_cache_checks(lat, bank, vals, lib, conv_and_count)
+    finally:
+        LT.set_bank_cache(prev)
+
+
+def _bank_cache_checks(lat, bank, vals, lib, conv_and_count):
+    import ctypes as C
     y0, n0 = conv_and_count()
     y1, n1 = conv_and_count()
     assert n0 >= 1 and n1 == 0 and torch.equal(y0, y1)             # second call: no split launch, same result
+    side = torch.cuda.Stream()                                       # an entry remembers the stream that produced it: a call on another
+    side.wait_stream(torch.cuda.current_stream())                    # stream does not take the hit (the bank may still be being written there)
+    with torch.cuda.stream(side):
+        _, ns = conv_and_count()
+    torch.cuda.current_stream().wait_stream(side)
+    assert ns >= 1
+    y0, _ = conv_and_count()                                         # (back on the first stream: the side stream's entry replaced ours)
+    _, n1 = conv_and_count()
+    assert n1 == 0
     bank.mul_(2.0)                                                   # in place: the version counter moves, the bank is split again
     y2, n2 = conv_and_count()
     assert n2 >= 1
