@@ -37,7 +37,8 @@ WORKLOADS = {
     "C3": dict(n=120000, v=32, f=32, sigma=0.9, capacity=100000, gen="lidar",
                desc="C3 SemanticKITTI-like scan: 120k pts, d=3, sigma 0.9, capacity 100k, V=F=32, splat->conv->slice fwd+bwd"),
     "C1": dict(n=1000, v=4, f=4, sigma=0.2, capacity=60000, gen="cube", desc="C1 1k-pt cube (parity-size case)"),
-    "C2": dict(n=2500, v=32, f=32, sigma=0.05, capacity=60000, gen="box", desc="C2 ShapeNet-like surface cloud: 2.5k pts, sigma 0.05, capacity 60k, V=F=32"),
+    "C2": dict(n=2500, v=32, f=32, sigma=0.05, capacity=60000, gen="box", batch=16,
+               desc="C2 ShapeNet-like surface cloud: 2.5k pts, sigma 0.05, capacity 60k, V=F=32"),
     "C4": dict(n=200000, v=32, f=32, sigma=0.08, capacity=5000000, gen="planes",
                desc="C4 ScanNet-like scene: 200k pts on planes, sigma 0.08, capacity 5M, V=F=32"),
     "C4probe": dict(n=200000, v=32, f=32, sigma=0.08, capacity=1600000, gen="planes",
@@ -64,7 +65,7 @@ def compact_line(full: dict, details_file: str = "bench_details.json") -> dict:
     line = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
                                      "scaling", "vs_baseline", "dtype", "data")}
     line["config"] = _pick(cfg, ("workload", "points_per_gpu", "vertices", "val_dim", "nr_filters", "scans_in_flight",
-                                 "clouds_per_scan_pool", "sharding", "checksum", "prewarm", "slot_order"))
+                                 "clouds_per_scan_pool", "clouds_per_step", "sharding", "checksum", "prewarm", "slot_order"))
     if isinstance(line["config"].get("workload"), str):
         line["config"]["workload"] = line["config"]["workload"][:240]
     line["roofline"] = (_pick(full.get("roofline"), ("bound", "kernel", "avg_us", "achieved", "peak", "unit", "frac", "traffic"))
@@ -443,6 +444,10 @@ def main():
                     help="hash (default): the kd planes steer the segment walks only; space: they also order the SLOTS of the table, so that rows "
                          "follow space (LnTable.slot_map: XCD-local gathers in the convolutions — 48 MB less HBM traffic per step and no gain in "
                          "time, DESIGN.md 8; A/B)")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="clouds per step (multi-cloud launch form, Lattice.set_cloud_batch): the step's positions are B independent clouds of the "
+                         "workload's size in ONE table (per-cloud lattices translated apart in key space), every kernel of the chain launched "
+                         "once for the batch; value counts all points.  0 = the workload's default (C2: 8, others: 1)")
     ap.add_argument("--row-slack", type=float, default=0.06,
                     help="graph mode: static row bound = largest vertex count of the calibration clouds x (1 + slack), rounded up to 256")
     args = ap.parse_args()
@@ -485,7 +490,12 @@ def main():
                   "config": {"workload": "C3 scan (120k LiDAR-like points, sigma 0.9, capacity 100k), SemanticKITTI network widths"},
                   **table}, os.path.join(ROOT, "bench_ops_details.json"))
         return
-    cfg = WORKLOADS[args.workload]
+    cfg = dict(WORKLOADS[args.workload])
+    batch = args.batch if args.batch > 0 else int(cfg.get("batch", 1))
+    n0 = cfg["n"]  # points per cloud
+    if batch > 1:  # B clouds per step: one table sized for all of them, the CPU baseline and the algorithmic byte counts per step likewise
+        cfg["n"], cfg["capacity"] = n0 * batch, cfg["capacity"] * batch
+        cfg["desc"] += f"; {batch} clouds per step (set_cloud_batch: one launch chain for the batch)"
     n, v, f, sigma, cap = cfg["n"], cfg["v"], cfg["f"], cfg["sigma"], cfg["capacity"]
     d, e = 3, 9
     half = bool(cfg.get("half"))
@@ -504,7 +514,8 @@ def main():
 
     def new_cloud(seed):
         rng = np.random.default_rng(10_000 + seed)
-        c = {"pos": torch.from_numpy(make_cloud(cfg["gen"], n, seed)).to(dev),
+        pos_np = make_cloud(cfg["gen"], n0, seed) if batch <= 1 else np.concatenate([make_cloud(cfg["gen"], n0, seed * batch + b) for b in range(batch)], 0)
+        c = {"pos": torch.from_numpy(np.ascontiguousarray(pos_np)).to(dev),
              "vals": torch.from_numpy(rng.standard_normal((n, v)).astype(np.float32)).to(dev),
              "G": torch.from_numpy(rng.standard_normal((n, f)).astype(np.float32)).to(dev), "state": {}}
         if half:
@@ -520,6 +531,8 @@ def main():
             self.clouds = [new_cloud(base + p) for p in range(pool)]
             self.calibration = [new_cloud(base + 32 + p) for p in range(2)] if graph_mode else []  # never replayed
             self.lat = L.Lattice(sigmas=[sigma] * d, capacity=cap, device=dev)
+            if batch > 1:
+                self.lat.set_cloud_batch(n0)
             self.stream = scan_streams[k] if k > 0 else None  # set 0 stays on the current stream
             self.cap = None
 
@@ -785,6 +798,8 @@ def main():
                 chains = []
                 for k in range(in_flight):
                     ch = {"lat": L.Lattice(sigmas=[sigma] * d, capacity=cap, device=dev), "clouds": sets[k].clouds, "cal": sets[k].calibration}
+                    if batch > 1:
+                        ch["lat"].set_cloud_batch(n0)
                     ch["lat"].prefetch_neighbours = False
 
                     def chain_on(c, ch=ch):
@@ -850,12 +865,13 @@ def main():
             # the CPU fallback with torch.set_num_threads(1) and with all cores.  index_add_ / scatter on many threads
             # contend (128 threads are SLOWER than one on this chain), so a 16-thread leg is timed too and `cpu_baseline` is the
             # fastest of the multi-threaded legs; `cpu_baseline_1thread` is always reported beside it.
-            legs = [cpu_baseline(cfg, args.cpu_seconds / 2, threads=0)]
+            cfg_cpu = WORKLOADS[args.workload]  # (one cloud of the workload's own size: a CPU has nothing to gain from a batch)
+            legs = [cpu_baseline(cfg_cpu, args.cpu_seconds / 2, threads=0)]
             if (os.cpu_count() or 1) > 16:
-                legs.append(cpu_baseline(cfg, args.cpu_seconds / 2, threads=16))
+                legs.append(cpu_baseline(cfg_cpu, args.cpu_seconds / 2, threads=16))
             cpu = max(legs, key=lambda leg: leg["value"])
             cpu["other_thread_counts"] = [{"cores": leg["cores"], "value": round(leg["value"], 4)} for leg in legs if leg is not cpu]
-            cpu1 = cpu_baseline(cfg, 0.0, threads=1, min_steps=3)
+            cpu1 = cpu_baseline(cfg_cpu, 0.0, threads=1, min_steps=3)
         unet = None
         if world == 1 and args.full_unet and args.workload == "C3" and extras:
             try:
@@ -901,7 +917,7 @@ def main():
             "config": {"workload": cfg["desc"] + f"; THROUGHPUT definition: {exec_desc}.  The latency of one scan alone is `latency`",
                        "points_per_gpu": n, "vertices": m, "val_dim": v, "nr_filters": f,
                        "sharding": f"{world} rank(s), independent clouds per GPU", "checksum": round(checksum, 3),
-                       "scans_in_flight": in_flight, "clouds_per_scan_pool": pool,
+                       "scans_in_flight": in_flight, "clouds_per_scan_pool": pool, "clouds_per_step": batch, "points_per_cloud": n0,
                        "prewarm": f"{prewarm_steps} untimed replays ({args.prewarm_ms:g} ms) before the W warm-up steps" if prewarm_steps else None, "kd_regions": bool(args.regions and graph_mode),
                        "slot_order": args.slot_order if (args.regions and graph_mode) else "hash",
                        "row_bounds": [cs.cap.bounds[0] for cs in sets] if graph_mode else None,

@@ -95,6 +95,14 @@ typedef struct LnTable {
                                       buckets (LN_STATUS_BUCKET_OVERFLOW -> rebuild on the atomic path, whose inserts spill); a fitting
                                       one comes from the host's calibration (Lattice.balanced_region_planes).  csrc/ln_common.h */
     int bucket_slots_max;          /* with a slot map: the largest of its slots-per-bucket entries (sizes the LDS of the bucket pass) */
+    int batch_points;              /* 0, or > 0: the positions handed to a build / retrieval of this table are a BATCH of independent clouds
+                                      of batch_points points each (cloud c = point index / batch_points).  Cloud c's lattice keys are then
+                                      shifted by c * batch_key_step on the first coordinate — a multiple of pos_dim + 1, i.e. a translation
+                                      of the lattice onto itself — so that the clouds' vertex sets are disjoint in ONE table and every kernel
+                                      of the path (neighbour lists, convolutions, slice, the scatters) runs over the batch in one launch with
+                                      per-cloud results (the multi-cloud launch form for clouds too small to fill the chip) */
+    int batch_key_step;            /* (pos_dim + 1) x the quotient distance between clouds; halved per coarser level so that the
+                                      level-crossing neighbour search (keys x 2^(lvl difference)) stays inside a cloud */
     int* row_regions;              /* NULL, or LN_XCD_GROUPS + 1 device ints a bucketed build over a space-ordered table fills: the first row
                                       of each of the 8 top-level kd regions and the row count — the argument of ln_conv_row_partition */
 } LnTable;

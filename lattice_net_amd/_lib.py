@@ -50,6 +50,8 @@ class LnTable(C.Structure):
         ("row_limit", C.c_int),
         ("slot_map", C.c_void_p),
         ("bucket_slots_max", C.c_int),
+        ("batch_points", C.c_int),
+        ("batch_key_step", C.c_int),
         ("row_regions", C.c_void_p),
     ]
 

@@ -104,6 +104,14 @@ LN_HD void ln_simplex(const float* pos_raw, const LnScale<D>& sc, LnSimplex<D>& 
     out.bary[0] = float(double(out.bary[0]) + (1.0 + double(out.bary[D + 1])));  // LatticeGPU.cuh:795
 }
 
+// Batch of independent clouds in one table (LnTable.batch_points / batch_key_step): the simplex of point p of cloud c = p / batch_points
+// is translated by c * step along the first lattice coordinate.  step is a multiple of D + 1, so the translated point is a lattice point
+// with the same remainder, ranks and barycentric weights: the cloud's lattice is the one a build of the cloud alone produces, moved.
+template <int D>
+LN_HD void ln_simplex_of_cloud(LnSimplex<D>& s, long long point, int batch_points, int batch_key_step) {
+    if (batch_points > 0) s.rem0[0] += int(point / batch_points) * batch_key_step;
+}
+
 // LatticeGPU.cuh:798-806: first d coordinates of simplex vertex `remainder`.
 template <int D>
 LN_HD void ln_vertex_key(const LnSimplex<D>& s, int remainder, int* key) {

@@ -367,6 +367,7 @@ __global__ void __launch_bounds__(256)
     for (int i = 0; i < D; ++i) pr[i] = pos_raw[(size_t)p * D + i];
     LnSimplex<D> s;
     ln_simplex<D>(pr, sc, s);
+    ln_simplex_of_cloud<D>(s, p, t.batch_points, t.batch_key_step);
     int key[D];
     ln_vertex_key<D>(s, r, key);
     int pos;
@@ -457,6 +458,7 @@ __global__ void __launch_bounds__(TH)
         for (int i = 0; i < D; ++i) pr[i] = pos_raw[(size_t)p * D + i];
         LnSimplex<D> s;
         ln_simplex<D>(pr, sc, s);
+        ln_simplex_of_cloud<D>(s, p, t.batch_points, t.batch_key_step);
 #pragma unroll
         for (int k = 0; k < RH; ++k) {
             const int r = r_first + k;
@@ -1529,6 +1531,7 @@ __global__ void __launch_bounds__(256)
     for (int i = 0; i < D; ++i) pr[i] = pos_raw[(size_t)p * D + i];
     LnSimplex<D> s;
     ln_simplex<D>(pr, sc, s);
+    ln_simplex_of_cloud<D>(s, p, t.batch_points, t.batch_key_step);
 #pragma unroll
     for (int r = 0; r <= D; ++r) {
         int key[D];

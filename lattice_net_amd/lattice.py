@@ -326,6 +326,7 @@ class HashTable:
         self._pos_dim_hint = -1  # dimensions known before any CAP-sized buffer exists
         self._val_dim_hint = 0
         self._static_rows = None  # capture-safe mode (Lattice.set_static_rows): fixed row bound instead of the host readback
+        self._batch = (0, 0)  # (points per cloud, key step) of a batch of independent clouds in this table (Lattice.set_cloud_batch)
 
     def flush(self):
         """Issues a deferred begin_splat clear, if any (every reader of table state goes through this)."""
@@ -375,7 +376,7 @@ class HashTable:
                 self._pinned = torch.zeros((4,), dtype=torch.int32, pin_memory=True)
             self._pinned_np = self._pinned.numpy().view("int64")  # same memory: the host polls the build's 64-bit report word
             self._readback_event = torch.cuda.Event()
-        key = (s.uid, self._counters.data_ptr(), self._static_rows, s.hashed(), None if s.slot_map is None else s.slot_map.data_ptr())
+        key = (s.uid, self._counters.data_ptr(), self._static_rows, s.hashed(), None if s.slot_map is None else s.slot_map.data_ptr(), self._batch)
         if getattr(self, "_c_table_key", None) == key:
             return self._c_table
         self._c_table_key = key
@@ -385,7 +386,7 @@ class HashTable:
     def _make_c_table(self, s) -> _lib.LnTable:
         return _lib.LnTable(s.hashed(), s.pos_dim, s.slot_keys.data_ptr(), s.slot_tok.data_ptr(), s.slot_cnt.data_ptr(), s.entries.data_ptr(),
                             s.keys.data_ptr(), self._counters.data_ptr(), self._counters.data_ptr() + 4, self._pinned.data_ptr(), 0,
-                            s.key_format, self._static_rows or 0, _lib.ptr(s.slot_map), s.slot_map_sb_max,
+                            s.key_format, self._static_rows or 0, _lib.ptr(s.slot_map), s.slot_map_sb_max, int(self._batch[0]), int(self._batch[1]),
                             _lib.ptr(s.row_regions) if s.slot_map is not None else None)
 
     def clear(self, lazy: bool = False):  # HashTable.cu:49-57, one launch instead of four fill_ kernels
@@ -573,6 +574,7 @@ class Lattice:
         ht._counters = oh._counters
         ht._pos_dim_hint, ht._val_dim_hint = oh.pos_dim(), oh.val_dim()
         ht._static_rows = oh._static_rows
+        ht._batch = oh._batch
         ht._static_levels = getattr(oh, "_static_levels", None)
         ht.m_nr_filled_is_dirty = oh.m_nr_filled_is_dirty
         ht.m_nr_filled = oh.m_nr_filled
@@ -1247,6 +1249,9 @@ class Lattice:
         coarse.m_sigmas = [s * 2.0 for s in self.m_sigmas]  # Lattice.cu:679-682 / 718-722
         coarse._sigmas_tensor = None
         ht = HashTable(capacity)
+        bp, step = self.m_hash_table._batch
+        # (a batch of clouds: the key step halves with every coarser level, so that fine key x 2^-1 lands in the same cloud's block)
+        ht._batch = (bp, (step // (2 * (d + 1))) * (d + 1)) if bp else (0, 0)
         ht._storage = _TableStorage(capacity, d, dev, spare_row_width=self.val_dim())
         # [1, val_dim] zeros: a placeholder until the coarse values exist
         ht.m_values_tensor = ht._storage.fresh_row if ht._storage.fresh_row is not None else torch.zeros((1, self.val_dim()), dtype=torch.float32, device=dev)
@@ -1550,6 +1555,27 @@ class Lattice:
         ht._static_rows = rows_bound
         # coarse_bounds[k]: bound of the lattice k + 1 levels coarser than this one (create_coarse_verts hands them down)
         ht._static_levels = None if coarse_bounds is None else {self.m_lvl + 1 + k: int(b) for k, b in enumerate(coarse_bounds)}
+
+    def set_cloud_batch(self, points_per_cloud: Optional[int], quotient_step: int = 1 << 13):
+        """The multi-cloud launch form for small clouds.  From now on the positions handed to this lattice are a BATCH of independent
+        clouds of `points_per_cloud` points each (cloud c = rows c * points_per_cloud ... of the positions tensor; None / 0 switches it
+        off).  The lattice of cloud c is translated by c * quotient_step lattice cells along the first coordinate (a translation of the
+        permutohedral lattice onto itself: same simplices, ranks and barycentric weights as a build of the cloud alone), so the clouds
+        share ONE table without sharing a vertex and every operator of the path — build, neighbour lists, convolutions forward and
+        backward, slice, gather, the scatters — runs over the whole batch in one launch with per-cloud results; filter gradients are the
+        sum over the clouds.  The clouds must stay within quotient_step / 2 lattice cells of the origin on the first axis (a cell is
+        ~0.8 (d + 1) sigma wide... see README 'Key range'; 8192 cells and 64 clouds fit the 2^20 cells of d <= 3).  Coarser levels
+        created from this lattice inherit the batch with the step halved per level.  GroupNorm-style statistics over the lattice values
+        would mix the clouds: this is for the operator path, not for the reference's batch-1 network semantics."""
+        d = self.pos_dim() if self.m_hash_table.is_initialized() else len(self.m_sigmas)
+        if not points_per_cloud:
+            self.m_hash_table._batch = (0, 0)
+        else:
+            if int(points_per_cloud) < 1 or int(quotient_step) < 2 or int(quotient_step) % (1 << 4):
+                raise ValueError("points_per_cloud >= 1 and a quotient_step that is a multiple of 16 (halved per coarser level)")
+            self.m_hash_table._batch = (int(points_per_cloud), int(quotient_step) * (d + 1))
+        if self.m_hash_table.is_initialized():
+            self.m_hash_table._storage.touch()
 
     def set_region_planes(self, planes, leaf_shares=None):
         """kd split planes of key space (7 ints: 1 + 2 + 4 thresholds in heap order, see LnCsr.planes) or None.  With planes, the builds

@@ -30,12 +30,12 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 
 def test_struct_layout_matches_header():
-    # int, int, 8 pointers, int, int, int (+4 padding), pointer, int (+4 padding), pointer -> 112 bytes on LP64
-    assert C.sizeof(_lib.LnTable) == 112
+    # int, int, 8 pointers, int, int, int (+4 padding), pointer, int, int, int (+4 padding), pointer -> 120 bytes on LP64
+    assert C.sizeof(_lib.LnTable) == 120
     assert [f[0] for f in _lib.LnTable._fields_] == ["capacity", "pos_dim", "slot_keys", "slot_tok", "slot_cnt", "entries", "keys",
                                                      "nr_filled", "status", "host_counters", "host_seq", "key_format", "row_limit",
-                                                     "slot_map", "bucket_slots_max", "row_regions"]
-    assert _lib.LnTable.slot_map.offset == 88 and _lib.LnTable.row_regions.offset == 104
+                                                     "slot_map", "bucket_slots_max", "batch_points", "batch_key_step", "row_regions"]
+    assert _lib.LnTable.slot_map.offset == 88 and _lib.LnTable.row_regions.offset == 112
     assert C.sizeof(_lib.LnCsr) == 56  # 4 pointers + seg_region + planes + the dense hint (int, padded)
 
 

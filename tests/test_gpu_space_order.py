@@ -409,3 +409,89 @@ def test_slot_order_switch_restores_hashed_slots():
     oidx, ow = O.build_splat(t, O.scale_positions(pos_np, np.full((3,), sigma, np.float32)))
     perm = row_permutation(N(lat.m_hash_table.m_keys_tensor)[:m], t.keys[:m])
     assert np.array_equal(perm[N(idx).astype(np.int64)], oidx)
+
+
+@pytest.mark.parametrize("order", ["slot", "canonical"])
+def test_batch_of_clouds_in_one_table_gives_every_clouds_own_lattice(order):
+    """Lattice.set_cloud_batch: B small clouds in ONE table, each cloud's lattice translated along the first key coordinate.  Per cloud:
+    the vertex set is the oracle's (moved by the cloud's key offset), splat indices equal through the key matching, weights bit for
+    bit; the whole chain splat -> conv -> slice forward + backward over the batch gives, cloud by cloud, what a lattice of that cloud
+    alone gives (filter gradient = the sum over the clouds); the coarse level and the level-crossing neighbour lists stay inside a cloud."""
+    import lattice_net_amd as L
+    from lattice_net_amd import lattice as LT, synthetic
+    LT.set_row_order(order)
+    LT.set_slot_order("hash")
+    B, n0, v, f, sigma, cap = 5, 2500, 32, 32, 0.05, 200000
+    rng = np.random.default_rng(11)
+    clouds = [synthetic.box_surface_cloud(n0, 100 + b) for b in range(B)]
+    pos_np = np.ascontiguousarray(np.concatenate(clouds, 0))
+    vals_np = rng.standard_normal((B * n0, v)).astype(np.float32)
+    g_np = rng.standard_normal((B * n0, f)).astype(np.float32)
+    w_np = (rng.standard_normal((9 * v, f)) / np.sqrt(9 * v)).astype(np.float32)
+    lat = L.Lattice(sigmas=[sigma] * 3, capacity=cap, device=dev())
+    lat.set_cloud_batch(n0)
+    step = lat.m_hash_table._batch[1]
+    W = T(w_np).requires_grad_(True)
+    lv, _, idx, w = L.SplatLattice.apply(lat, T(pos_np), T(vals_np))
+    m = lat.nr_lattice_vertices()
+    lvm = lv[:m].contiguous().requires_grad_(True)
+    cv, cw = L.ConvIm2RowLattice.apply(lvm, lat, W, 1)
+    out = L.SliceLattice.apply(cv, cw.lattice, T(pos_np), idx, w)
+    out.backward(T(g_np))
+    torch.cuda.synchronize()
+    keys = N(lat.m_hash_table.m_keys_tensor)[:m].astype(np.int64)
+    gi = N(idx).astype(np.int64).reshape(B, n0 * 4)
+    sig = np.full((3,), sigma, np.float32)
+    m_sum, gw_sum = 0, np.zeros((9 * v, f), np.float64)
+
+    def close(a, b):
+        np.testing.assert_allclose(np.asarray(a, np.float64), np.asarray(b, np.float64), rtol=RTOL, atol=RTOL * float(np.max(np.abs(b))))
+
+    for b in range(B):
+        t = O.OracleHashTable(cap, 3)
+        oidx, ow = O.build_splat(t, O.scale_positions(clouds[b], sig))
+        mb = t.nr_filled
+        m_sum += mb
+        okeys = t.keys[:mb].astype(np.int64).copy()
+        okeys[:, 0] += b * step
+        look = {tuple(k): r for r, k in enumerate(keys)}
+        rows_of = np.array([look[tuple(k)] for k in okeys])  # raises KeyError if a vertex of the cloud is missing from the batch table
+        assert np.array_equal(rows_of[oidx], gi[b])
+        assert np.array_equal(N(w).reshape(B, n0 * 4)[b], ow)
+        # the chain of the cloud ALONE (own lattice), against the batch's slice of it
+        Wb = T(w_np).requires_grad_(True)
+        lb = L.Lattice(sigmas=[sigma] * 3, capacity=cap, device=dev())
+        pb, vb = T(clouds[b]), T(vals_np[b * n0:(b + 1) * n0])
+        lvb, _, idxb, wb = L.SplatLattice.apply(lb, pb, vb)
+        mbg = lb.nr_lattice_vertices()
+        assert mbg == mb
+        lvbm = lvb[:mb].contiguous().requires_grad_(True)
+        cvb, cwb = L.ConvIm2RowLattice.apply(lvbm, lb, Wb, 1)
+        outb = L.SliceLattice.apply(cvb, cwb.lattice, pb, idxb, wb)
+        outb.backward(T(g_np[b * n0:(b + 1) * n0]))
+        close(N(out)[b * n0:(b + 1) * n0], N(outb))
+        gw_sum += N(Wb.grad).astype(np.float64)
+    assert m == m_sum, "the clouds of a batch must not share a vertex"
+    close(N(W.grad), gw_sum)
+    # coarse level from the positions (create_coarse_verts_naive) and both level-crossing neighbour lists: every neighbour a row of the same cloud
+    lat.set_values(lv[:m].contiguous())
+    coarse = lat.create_coarse_verts_naive(T(pos_np))
+    mc = coarse.nr_lattice_vertices()
+    ck = N(coarse.m_hash_table.m_keys_tensor)[:mc].astype(np.int64)
+    cstep = coarse.m_hash_table._batch[1]
+    assert cstep * 2 == step
+    cloud_f = np.floor_divide(keys[:, 0] + step // 2, step)
+    cloud_c = np.floor_divide(ck[:, 0] + cstep // 2, cstep)
+    assert set(cloud_f) == set(range(B)) and set(cloud_c) == set(range(B))
+    nb_cf = N(coarse.neighbours(lat, 1, False)).astype(np.int64)
+    ok = nb_cf >= 0
+    assert ok.sum() > mc and np.array_equal(cloud_f[nb_cf[ok]], np.broadcast_to(cloud_c[:, None], nb_cf.shape)[ok])
+    nb_fc = N(lat.neighbours(coarse, 1, False)).astype(np.int64)
+    ok = nb_fc >= 0
+    assert ok.sum() > m // 2 and np.array_equal(cloud_c[nb_fc[ok]], np.broadcast_to(cloud_f[:, None], nb_fc.shape)[ok])
+    mc_sum = 0
+    for b in range(B):
+        tc = O.OracleHashTable(cap, 3)
+        O.build_splat(tc, O.scale_positions(clouds[b], 2 * sig), write=False)
+        mc_sum += tc.nr_filled
+    assert mc == mc_sum
