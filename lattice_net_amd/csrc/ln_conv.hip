@@ -2541,7 +2541,19 @@ __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(T,
     constexpr int THREADS = 256 * T;
     constexpr int BANK = E * V * F;                      // floats of one slab (the parking area at the end)
     constexpr int FRAG16 = E * NT * 3 * 64;              // 16-byte fragments of the split bank
-    constexpr int RS = 40;                               // bf16 elements per staged G_e row: 32 + 8 of padding (80 bytes)
+#ifndef LN_BWD_SWZ
+#define LN_BWD_SWZ 1  // 0: the padded 80-byte rows of rounds 3-5 (A/B)
+#endif
+    // Staged G_e rows.  Rounds 3-5: 64 bytes + 16 of padding per row — conflict-free for the 16-byte staging stores but not for the
+    // transposing reads (rows r and r + 3 / r + 8 and r + 11 of a lane group overlap).  Round 6: no padding, the 16-byte piece p of row r
+    // sits at position p ^ swz(r), swz(r) = ((r >> 1) & 3) ^ (bit 3 of r) << 1, chosen against the lane groups of MI355X_MICROARCH.md §LDS:
+    //   ds_write_b128 — 8 adjacent lanes (rows 8a .. 8a + 7 of one quarter) over 128 bytes: even rows take positions q ^ {0, 1, 2, 3} of
+    //                   the first 64 bytes, odd rows of the second — eight different 16-byte columns;
+    //   ds_read_b64_tr_b16 — 32 lanes (rows R .. R + 3 and R + 8 .. R + 11, 32 bytes each) over 256 bytes: rows R + j and R + 8 + j share
+    //                   a 64-byte column and, bit 3 flipping the half, read its two different halves.
+    // 12 KB less LDS per sub-tile.
+    constexpr int RS = LN_BWD_SWZ ? 32 : 40;             // bf16 elements per staged G_e row
+    auto swz = [](int r) { return ((r >> 1) & 3) ^ ((r >> 2) & 2); };
     constexpr int PART = 64 * RS;                        // one part of one sub-tile's G_e
     constexpr int STAGE = 2 * 3 * PART;                  // double-buffered, three parts (bf16 elements)
     constexpr int LDS_BYTES_A = FRAG16 * 16 + T * STAGE * 2;
@@ -2616,7 +2628,12 @@ __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(T,
             unsigned int h[4], md[4], lo[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) ln_split3_bits(v4[j], h[j], md[j], lo[j]);
-            const int fr = (((e * NT + (v >> 4)) * 3) * 64 + (f0 >> 3) * 16 + (v & 15)) * 8 + (f0 & 7);
+            // (the 16-byte unit of (q = f0 >> 3, i = v & 15) sits at column i ^ 2q of its 16-unit row.  ds_write_b64 is served in groups
+            // of 16 adjacent lanes over 32 banks: here two v times (four q, two halves), whose columns i ^ 2q are distinct modulo 8, so a
+            // group covers the 128 bytes once; unswizzled the four q of one v sat 256 bytes apart on the same banks (4-way).  The
+            // fragment reads below — ds_read_b128, lane groups {0-3,12-15,20-27} ... over 64 banks — stay conflict-free under this XOR:
+            // masks 0/2 keep a lane's column inside its quarter pair, masks 4/6 swap both halves of a group together.)
+            const int fr = (((e * NT + (v >> 4)) * 3) * 64 + (f0 >> 3) * 16 + ((v & 15) ^ (2 * (f0 >> 3)))) * 8 + (f0 & 7);
             *reinterpret_cast<uint2*>(s_fh + fr) = make_uint2((h[0] >> 16) | h[1], (h[2] >> 16) | h[3]);
             *reinterpret_cast<uint2*>(s_fh + fr + 64 * 8) = make_uint2((md[0] >> 16) | md[1], (md[2] >> 16) | md[3]);
             *reinterpret_cast<uint2*>(s_fh + fr + 2 * 64 * 8) = make_uint2((lo[0] >> 16) | lo[1], (lo[2] >> 16) | lo[3]);
@@ -2647,7 +2664,7 @@ __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(T,
             p3[j] = (l0 >> 16) | l1;
         }
         {
-            unsigned short* dst = sg + (wave * 16 + i) * RS + q * KQ;
+            unsigned short* dst = sg + (wave * 16 + i) * RS + (LN_BWD_SWZ ? ((q ^ swz(wave * 16 + i)) * KQ) : q * KQ);
             *reinterpret_cast<u32x4*>(dst) = p1;
             *reinterpret_cast<u32x4*>(dst + PART) = p2;
             *reinterpret_cast<u32x4*>(dst + 2 * PART) = p3;
@@ -2655,14 +2672,14 @@ __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(T,
         __syncthreads();
 #ifdef LN_TR_CHECK
         {
-            const u32x4 rb = *reinterpret_cast<volatile u32x4*>(sg + (wave * 16 + i) * RS + q * KQ);
+            const u32x4 rb = *reinterpret_cast<volatile u32x4*>(sg + (wave * 16 + i) * RS + (LN_BWD_SWZ ? ((q ^ swz(wave * 16 + i)) * KQ) : q * KQ));
             if (rb[0] != p1[0] || rb[1] != p1[1] || rb[2] != p1[2] || rb[3] != p1[3]) atomicAdd(&ln_dbg[1], 1);
         }
 #endif
         const bf16x8 a1 = __builtin_bit_cast(bf16x8, p1), a2 = __builtin_bit_cast(bf16x8, p2), a3 = __builtin_bit_cast(bf16x8, p3);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const u32x4* pb = s_frag + ((e * NT + nt) * 3) * 64 + lane;
+            const u32x4* pb = s_frag + ((e * NT + nt) * 3) * 64 + q * 16 + (i ^ (2 * q));
             const bf16x8 b1 = __builtin_bit_cast(bf16x8, pb[0]), b2 = __builtin_bit_cast(bf16x8, pb[64]), b3 = __builtin_bit_cast(bf16x8, pb[128]);
 #ifdef LN_CONV_PROBE_NO_MFMA  // attribution build (wrong results): one matrix instruction instead of six
             asm volatile("" ::"v"(a2), "v"(a3), "v"(b2), "v"(b3));
@@ -2684,9 +2701,13 @@ __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(T,
             bf16x8 b[3];
 #pragma unroll
             for (int part = 0; part < 3; ++part) {
-                const unsigned short* base = sg + part * PART + (32 * st + 8 * q + (i >> 2)) * RS + ft * 16 + (i & 3) * 4;
+                // lane: 4 contiguous bf16 (half a 16-byte piece) of row r0 + (i >> 2), elements ft * 16 + 4 (i & 3) ..
+                const int r_lo = 32 * st + 8 * q + (i >> 2), r_hi = r_lo + 4;
+                const int piece = ft * 2 + ((i & 3) >> 1), inner = (i & 1) * 4;
+                const unsigned short* base = sg + part * PART + r_lo * RS + (LN_BWD_SWZ ? ((piece ^ swz(r_lo)) * 8 + inner) : (ft * 16 + (i & 3) * 4));
+                const unsigned short* base_hi = sg + part * PART + r_hi * RS + (LN_BWD_SWZ ? ((piece ^ swz(r_hi)) * 8 + inner) : (ft * 16 + (i & 3) * 4));
                 const short4v lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4v __attribute__((address_space(3)))*)(base));
-                const short4v hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4v __attribute__((address_space(3)))*)(base + 4 * RS));
+                const short4v hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4v __attribute__((address_space(3)))*)(base_hi));
                 u32x4 packed;
                 packed[0] = (unsigned int)(unsigned short)lo4[0] | ((unsigned int)(unsigned short)lo4[1] << 16);
                 packed[1] = (unsigned int)(unsigned short)lo4[2] | ((unsigned int)(unsigned short)lo4[3] << 16);
@@ -2698,7 +2719,8 @@ __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(T,
                     unsigned int badm = 0, ex2 = 0, got2 = 0;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const unsigned int ex = *(volatile unsigned short*)(sg + part * PART + (32 * st + 8 * q + j) * RS + ft * 16 + i);
+                        const int rr_ = 32 * st + 8 * q + j, ee_ = ft * 16 + i;
+                        const unsigned int ex = *(volatile unsigned short*)(sg + part * PART + rr_ * RS + (LN_BWD_SWZ ? ((((ee_ >> 3) ^ swz(rr_)) << 3) | (ee_ & 7)) : ee_));
                         const unsigned int got = (packed[j >> 1] >> (16 * (j & 1))) & 0xffffu;
                         if (ex != got) { badm |= 1u << j; ex2 = ex; got2 = got; }
                     }
@@ -2750,7 +2772,8 @@ __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(T,
 #pragma unroll
         for (int e = 0; e < E; ++e)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) park[(e * V + vt * 16 + q * 4 + r) * F + ft * 16 + i] = acc_w[e][r];
+            for (int r = 0; r < 4; ++r) park[((e * V + vt * 16 + q * 4 + r) * F + ft * 16 + i) ^ ((q & 1) << 4)] = acc_w[e][r];  // (lanes of
+        // quarters 0/1 and 2/3 are served together: their rows, 4 apart, would share the 16 banks of the column tile)
     }
     if constexpr (T > 1) __syncthreads();
     if (sub == 0) {
@@ -2762,7 +2785,7 @@ __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(T,
                 const int o = (e * V + vt * 16 + q * 4 + r) * F + ft * 16 + i;
                 float sum = acc_w[e][r];
 #pragma unroll
-                for (int k2 = 1; k2 < T; ++k2) sum += park_all[(size_t)(k2 - 1) * BANK + o];
+                for (int k2 = 1; k2 < T; ++k2) sum += park_all[(size_t)(k2 - 1) * BANK + (o ^ ((q & 1) << 4))];
                 dst[o] = sum;
             }
     }
