@@ -2544,6 +2544,9 @@ __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(T,
 #ifndef LN_BWD_SWZ
 #define LN_BWD_SWZ 1  // 0: the padded 80-byte rows of rounds 3-5 (A/B)
 #endif
+#ifndef LN_BWD_LINE
+#define LN_BWD_LINE LN_BWD_SWZ  // line-shaped gathers of the gradient rows (below); 0: the fragment-shaped ones of rounds 3-5 (A/B)
+#endif
     // Staged G_e rows.  Rounds 3-5: 64 bytes + 16 of padding per row — conflict-free for the 16-byte staging stores but not for the
     // transposing reads (rows r and r + 3 / r + 8 and r + 11 of a lane group overlap).  Round 6: no padding, the 16-byte piece p of row r
     // sits at position p ^ swz(r), swz(r) = ((r >> 1) & 3) ^ (bit 3 of r) << 1, chosen against the lane groups of MI355X_MICROARCH.md §LDS:
@@ -2553,7 +2556,11 @@ __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(T,
     //                   a 64-byte column and, bit 3 flipping the half, read its two different halves.
     // 12 KB less LDS per sub-tile.
     constexpr int RS = LN_BWD_SWZ ? 32 : 40;             // bf16 elements per staged G_e row
+#if LN_BWD_LINE
+    auto swz = [](int r) { return (0x78 >> (2 * ((r >> 2) & 3))) & 3; };  // {0, 2, 3, 1} by row quad (see the line-shaped gathers below)
+#else
     auto swz = [](int r) { return ((r >> 1) & 3) ^ ((r >> 2) & 2); };
+#endif
     constexpr int PART = 64 * RS;                        // one part of one sub-tile's G_e
     constexpr int STAGE = 2 * 3 * PART;                  // double-buffered, three parts (bf16 elements)
     constexpr int LDS_BYTES_A = FRAG16 * 16 + T * STAGE * 2;
@@ -2583,9 +2590,13 @@ __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(T,
         const int x4 = tid + s * THREADS;
         wv[s] = (x4 < N4) ? reinterpret_cast<const float4*>(filter)[x4] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+#if !LN_BWD_LINE
     int nb[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) nb[e] = (my_row < m) ? nbr[(size_t)my_row * E + (e < E - 1 ? (e ^ 1) : e)] : -1;
+#else
+    static_assert(LN_BWD_SWZ, "the line-shaped gathers stage unpadded, swizzled rows");
+#endif
     const int vt = wave / FT, ft = wave % FT;
     // A operand of the filter gradient, split: step s (32 rows), part p -> 8 bf16 = rows 32s + 8q + j of column vt*16 + i
     u32x4 va[2][3];
@@ -2609,11 +2620,39 @@ __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(T,
     }
     constexpr int DEPTH = 3;
     auto slot_of = [](int k) { return k == 0 ? E - 1 : k - 1; };
+#if LN_BWD_LINE
+    // Line-shaped gathers (round 6; the forward has them since round 5).  A load shaped like the MFMA fragment — lane (i, q) reads its
+    // 32-byte quarter of row i — touches 16 lines per wave-instruction, half of each; here lane l loads piece l & 7 (16 bytes) of the rows
+    // l >> 3 and 8 + (l >> 3) of the wave's 16: 8 whole lines per instruction.  The rows are staged for the filter gradient anyway; the lane
+    // splits ITS piece, stores 8 bytes per plane, and takes the A operand of the value gradient — its (i, q) quarter, all three parts —
+    // back from the staged rows behind the slot's barrier.  The swizzle {0, 2, 3, 1} by row quad serves all three access shapes:
+    //   ds_write_b64   (16 adjacent lanes = two whole rows, 64 bytes each, on the two halves of the 32 banks): any per-row permutation;
+    //   ds_read_b128   (lane groups {0-3, 12-15, 20-27} ...: quarter q of rows i, i + 12 and quarter q ^ 1 of rows i + 4, i + 8 share
+    //                   the 64-byte column i & 3): positions s(0), s(3), 1 ^ s(1), 1 ^ s(2) = 0, 1, 3, 2;
+    //   ds_read_b64_tr (rows R + j and R + 8 + j share a column and read one 32-byte half each): bit 1 of s differs between quads h, h ^ 2.
+    const int lr = lane >> 3, c8 = lane & 7;
+    int nb2[2][E];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < E; ++e) nb2[j][e] = (m0 + 8 * j + lr < m) ? nbr[(size_t)(m0 + 8 * j + lr) * E + (e < E - 1 ? (e ^ 1) : e)] : -1;
+    floatx4 a[DEPTH + 1][2];
+    auto gather = [&](int e, floatx4 (&dst)[2]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) dst[j] = *reinterpret_cast<const floatx4*>(grad_out + (size_t)(nb2[j][e] >= 0 ? nb2[j][e] : 0) * F + c8 * 4);
+    };
+#pragma unroll
+    for (int j = 0; j < 2; ++j)  // the centre slot is the row itself: no id to wait for
+        a[0][j] = *reinterpret_cast<const floatx4*>(grad_out + (size_t)(m0 + 8 * j + lr < m ? m0 + 8 * j + lr : 0) * F + c8 * 4);
+#pragma unroll
+    for (int k = 1; k < DEPTH && k < E; ++k) gather(slot_of(k), a[k % (DEPTH + 1)]);
+#else
     float a[DEPTH + 1][KQ];
     ln_load_quarter<KQ>(grad_out + (size_t)(my_row < m ? my_row : 0) * F + q * KQ, a[0]);
 #pragma unroll
     for (int k = 1; k < DEPTH && k < E; ++k)
         ln_load_quarter<KQ>(grad_out + (size_t)(nb[slot_of(k)] >= 0 ? nb[slot_of(k)] : 0) * F + q * KQ, a[k % (DEPTH + 1)]);
+#endif
     // bank -> split -> LDS fragments of W_e^T: x = (e*V + v)*F + f, four consecutive f = elements j..j+3 of ONE fragment
 #pragma unroll
     for (int s = 0; s < NST; ++s) {
@@ -2649,6 +2688,30 @@ __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(T,
     for (int k = 0; k < E; ++k) {
         const int e = slot_of(k);
         unsigned short* sg = s_stage + (size_t)sub * STAGE + (k & 1) * (3 * PART);
+#if LN_BWD_LINE
+        if (k + DEPTH < E) gather(slot_of(k + DEPTH), a[(k + DEPTH) % (DEPTH + 1)]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {  // this lane's piece of rows lr and 8 + lr: split once, staged for both gradients
+            const floatx4 x = a[k % (DEPTH + 1)][j];
+            const bool there = nb2[j][e] >= 0;
+            unsigned int h[4], md[4], lo[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) ln_split3_bits(there ? x[c] : 0.f, h[c], md[c], lo[c]);
+            const int row = wave * 16 + 8 * j + lr;
+            unsigned short* dst = sg + row * RS + (((c8 >> 1) ^ swz(row)) * 8 + (c8 & 1) * 4);
+            *reinterpret_cast<uint2*>(dst) = make_uint2((h[0] >> 16) | h[1], (h[2] >> 16) | h[3]);
+            *reinterpret_cast<uint2*>(dst + PART) = make_uint2((md[0] >> 16) | md[1], (md[2] >> 16) | md[3]);
+            *reinterpret_cast<uint2*>(dst + 2 * PART) = make_uint2((lo[0] >> 16) | lo[1], (lo[2] >> 16) | lo[3]);
+        }
+        __syncthreads();
+        u32x4 p1, p2, p3;
+        {
+            const unsigned short* src = sg + (wave * 16 + i) * RS + ((q ^ swz(wave * 16 + i)) * KQ);
+            p1 = *reinterpret_cast<const u32x4*>(src);
+            p2 = *reinterpret_cast<const u32x4*>(src + PART);
+            p3 = *reinterpret_cast<const u32x4*>(src + 2 * PART);
+        }
+#else
         float (&ae)[KQ] = a[k % (DEPTH + 1)];
         if (k + DEPTH < E)
             ln_load_quarter<KQ>(grad_out + (size_t)(nb[slot_of(k + DEPTH)] >= 0 ? nb[slot_of(k + DEPTH)] : 0) * F + q * KQ, a[(k + DEPTH) % (DEPTH + 1)]);
@@ -2675,6 +2738,7 @@ __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(T,
             const u32x4 rb = *reinterpret_cast<volatile u32x4*>(sg + (wave * 16 + i) * RS + (LN_BWD_SWZ ? ((q ^ swz(wave * 16 + i)) * KQ) : q * KQ));
             if (rb[0] != p1[0] || rb[1] != p1[1] || rb[2] != p1[2] || rb[3] != p1[3]) atomicAdd(&ln_dbg[1], 1);
         }
+#endif
 #endif
         const bf16x8 a1 = __builtin_bit_cast(bf16x8, p1), a2 = __builtin_bit_cast(bf16x8, p2), a3 = __builtin_bit_cast(bf16x8, p3);
 #pragma unroll
