@@ -33,9 +33,16 @@ static bool ln_bwd_fused_shape(int filter_extent, int val_dim, int nr_filters) {
     return filter_extent == 9 && val_dim == 32 && nr_filters == 32;
 }
 // 64-vertex sub-tiles per workgroup (1..4).  A workgroup takes a whole CU, so the launch runs in rounds of 256 workgroups and a
-// round costs about T: the T with the cheapest rounds(T) * T wins, larger T on ties (fewer slabs) — one round at C3 (T = 3; a
-// 257th workgroup would run after all the others: twice the time), 2 rounds of T = 4 at 129 k vertices.
+// round costs about T + 1: the T with the cheapest rounds(T) * (T + 1) wins, larger T on ties (fewer slabs) — one round at C3 (T = 3; a
+// 257th workgroup would run after all the others: twice the time), 3 rounds of T = 3 at 129 k vertices.
+static bool ln_conv_b3_enabled();
+#ifndef LN_BWD_B3_MAX_T
+#define LN_BWD_B3_MAX_T 3  // sub-tiles of the bf16x3 form: four fit the LDS since round 6 (unpadded staging) but need 148 registers of the 128 a
+                           // 1024-thread workgroup may have (20 spilled); the fp32 form at T = 4 was the slowest choice at 129 k vertices (65 us
+                           // against 55 for the bf16x3 form at T = 3: profiles/r6_kernel_stats_C4_one_in_flight.csv)
+#endif
 static int ln_bwd_subtiles(int m) {
+    const int max_t = (ln_conv_b3_enabled() && !(ln_debug_mask() & 65536)) ? LN_BWD_B3_MAX_T : LN_BWD_MAX_SUBTILES;
     {
         static int forced = -1;  // experiment knob: LN_BWD_T=1..4 forces the sub-tile count
         if (forced < 0) {
@@ -46,9 +53,10 @@ static int ln_bwd_subtiles(int m) {
     }
     const int s = (m + 63) / 64;
     int best = 1, best_cost = 1 << 30;
-    for (int t = 1; t <= LN_BWD_MAX_SUBTILES; ++t) {
+    for (int t = 1; t <= max_t; ++t) {
         const int wgs = (s + t - 1) / t;
-        const int cost = ((wgs + LN_BWD_CUS - 1) / LN_BWD_CUS) * t;
+        const int cost = ((wgs + LN_BWD_CUS - 1) / LN_BWD_CUS) * (t + 1);  // (+ 1: the bank staging and the slab epilogue of a workgroup — at 129 k
+                                                                           // vertices T = 2 / 3 run 4 / 3 rounds and measure 884 / 940 Mpoints/s)
         if (cost <= best_cost) {
             best = t;
             best_cost = cost;
@@ -2879,7 +2887,7 @@ extern "C" int ln_conv_backward(const int* nbr_q, const int* nbr_n, const float*
             const int wgs = ln_div_up(mn, 64 * bwd_t);
 #define LN_BWD_FUSED(TT)                                                                                                               \
     case TT:                                                                                                                           \
-        if constexpr (TT <= 3) { /* bf16 matrix cores, exactly split operands (four sub-tiles of staging do not fit LDS) */             \
+        if constexpr (TT <= LN_BWD_B3_MAX_T) { /* bf16 matrix cores, exactly split operands */                                         \
             if (ln_conv_b3_enabled() && !(ln_debug_mask() & 65536)) {                                                                  \
                 LN_LAUNCH("k_conv_backward_fused", (k_conv_backward_fused_b3<TT>), dim3(wgs), dim3(256 * TT), 0, st, nbr_n, values_neigh, grad_out, \
                           filter, mn, grad_values, partial, g_ln_row_partition);                                                       \
