@@ -2626,7 +2626,10 @@ __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(T,
             va[st][2][j] = (l0 >> 16) | l1;
         }
     }
-    constexpr int DEPTH = 3;
+#ifndef LN_BWD_DEPTH
+#define LN_BWD_DEPTH 2  // (round 6, line-shaped gathers: 1 / 2 / 3 / 4 / 5 -> 19.0 / 18.7 / 19.3 / 20.4 / 20.8 us on one box)
+#endif
+    constexpr int DEPTH = LN_BWD_DEPTH;  // gathers in flight per lane
     auto slot_of = [](int k) { return k == 0 ? E - 1 : k - 1; };
 #if LN_BWD_LINE
     // Line-shaped gathers (round 6; the forward has them since round 5).  A load shaped like the MFMA fragment — lane (i, q) reads its
