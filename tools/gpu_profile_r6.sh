@@ -3,7 +3,8 @@
 #   C3 chain under both slot orders: HBM traffic (FETCH_SIZE / WRITE_SIZE, separate --pmc passes with --kernel-trace only) and
 #   rocprofv3 kernel statistics one scan at a time and four in flight;
 #   kernel statistics of the C4 / C2 chains (one scan at a time) and of the SemanticKITTI / ScanNet / ShapeNet network steps;
-#   the bench lines (unprofiled) of C3 (default and the driver's command), C2, C4, C5.
+#   the bench lines (unprofiled) of C3 (default and the driver's command), C2, C4, C5;
+#   LDS counters (instructions, bank-conflict cycles, LDS-array cycles) of the C3 step's kernels and of the SemanticKITTI network step.
 set -u
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/prof_r6; rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp; cd /tmp
@@ -45,6 +46,8 @@ grep -h "^DETAILS " $OUT/bench_driver.log | tail -1 | cut -c9- > $OUT/bench_driv
 for t in kitti scannet shapenet; do python3 tools/bench_lnn.py --config $t --graph --steps 12 --warmup 4 2>&1 | tail -1; done > $OUT/lnn_graph_steps.txt
 python3 tools/conv_time.py > $OUT/conv_time.txt 2>&1
 python3 tools/conv_time.py --coarse 1 --shapes 64x64,128x128,128x64,96x96,192x192,256x256,256x128 > $OUT/conv_time_level2.txt 2>&1
+bash tools/pmc_lds_c3.sh > $OUT/pmc_lds_c3.txt 2>&1
+CONFIG=kitti bash tools/probes/r6_pmc_lds_unet.sh > $OUT/pmc_lds_kitti.txt 2>&1
 rm -f $OUT/*.log
 ls $OUT | head -60
 for f in $OUT/bench_*_line.json; do echo "== $f"; cut -c1-400 $f; done
