@@ -344,6 +344,9 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // T sub-tiles of 64 rows per workgroup (256 T threads) share ONE staging of the slot's bank slice: T = 3 (one workgroup per CU, the
 // shape of k_conv_forward_b3) re-reads the bank from L2 and writes it to LDS a third as often as T = 1 (three workgroups per CU) —
 // at 46 k rows x 64 channels the bank traffic of T = 1 (727 workgroups x 9 slices of 24 KB = 157 MB) exceeds the gathered rows (107 MB).
+#ifndef LN_MFMA_B3_LINE
+#define LN_MFMA_B3_LINE 1  // 0: fragment-shaped gathers at 64 channels too (A/B)
+#endif
 template <int V, int NT, bool FLIP, int T>
 __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(LN_CONV_B3_WAVES(V), LN_CONV_B3_WAVES(V))))
     k_conv_mfma_b3(const int* __restrict__ nbr, const float* __restrict__ values, const u32x4* __restrict__ bank, int m, int E,
@@ -373,6 +376,23 @@ __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(LN
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = floatx4{0.f, 0.f, 0.f, 0.f};
 
+    // Line-shaped gathers at 64 channels (round 6; k_conv_forward_b3 and the fused backward have them at 32): a load shaped like the MFMA
+    // fragment — lane (i, q) reads the 64-byte quarter of row i — touches 16 rows, 32 half-used lines, per wave-instruction; here lane l
+    // loads piece l & 15 (16 bytes) of rows (l >> 4) + 4 j: four whole 256-byte rows per instruction.  The wave's 16 x 64 floats change
+    // shape through a private 4 KB LDS region when they become the current slot's operand: piece p of row r sits at column
+    // p ^ ((r & 3) | ((r >> 2) & 1) << 3) of the row's 256 bytes (= the 64 banks) — conflict-free for the four lane groups of
+    // ds_read_b128 under the (i, q) mapping, whichever of its four pieces a lane reads (exhaustive search over the linear maps), and for
+    // the stores (8 adjacent lanes = half a row).  Taken where it measures faster (A/B of two builds on one box, tools/probes/r6_ab_conv64.sh):
+    // 64 -> 32 at 46.5 k rows 20.8 -> 18.2 us, 64 -> 64 at 11.4 k rows 13.8 -> 12.9; with three sub-tiles and 64 or 128 columns per
+    // chunk the kernel is bound by its bank slices and LDS reads, not by the gather: 23.5 -> 24.0 and 39.7 -> 40.3 us — left as they were.
+    constexpr bool LINE = LN_MFMA_B3_LINE && V == 64 && (NT <= 2 || (T == 1 && NT <= 4));
+    __shared__ floatx4 s_x[LINE ? 4 * T : 1][LINE ? 16 * 16 : 1];
+    const int lr = lane >> 4, pc = lane & 15;
+    auto fsw = [](int r) -> int { return (r & 3) | (((r >> 2) & 1) << 3); };
+    floatx4 l_nxt[4];
+    int nbl_nxt[4] = {-1, -1, -1, -1};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) l_nxt[j] = floatx4{0.f, 0.f, 0.f, 0.f};
     float a_cur[KQ], a_nxt[KQ];
     u32x4 w_nxt[W16];
 #pragma unroll
@@ -395,11 +415,37 @@ __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(LN
     // in place, 46 k rows, deferred vs at issue: 32 -> 64 16.1 vs 17.8 us, 64 x 64 30.6 vs 32.1, 96 x 96 2 x 38.7 vs 2 x 41.1,
     // 128 x 128 116-117 vs 115-118 (equal), 128 -> 64 62-63 vs 61 (the 32 extra selects per slot show).
     constexpr bool DEEP = LN_CONV_B3_DEEP(V);
-    auto issue = [&](int e, int nb, float (&a)[KQ]) {
-        ln_load_quarter<KQ>(values + (size_t)(nb >= 0 ? nb : 0) * V + q * KQ, a);
-        if (!DEEP && nb < 0) {
+    auto load_nbl = [&](int e, int (&dst)[4]) {
 #pragma unroll
-            for (int k = 0; k < KQ; ++k) a[k] = 0.f;
+        for (int j = 0; j < 4; ++j) dst[j] = e < e_end ? s_nbr[((tid >> 6) * 16 + 4 * j + lr) * E + slot_of(e)] : -1;
+    };
+    auto reshape = [&]() {  // the rows loaded for the next slot become a_cur (absent neighbours: zero rows, written by the lane that loaded them)
+        floatx4* xs = s_x[LINE ? (tid >> 6) : 0];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xs[(4 * j + lr) * 16 + (pc ^ fsw(4 * j + lr))] = nbl_nxt[j] >= 0 ? l_nxt[j] : floatx4{0.f, 0.f, 0.f, 0.f};
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const floatx4 x = xs[i * 16 + ((4 * q + jj) ^ fsw(i))];
+            a_cur[4 * jj] = x[0], a_cur[4 * jj + 1] = x[1], a_cur[4 * jj + 2] = x[2], a_cur[4 * jj + 3] = x[3];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    auto issue = [&](int e, int nb, float (&a)[KQ]) {
+        if constexpr (LINE) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                l_nxt[j] = *reinterpret_cast<const floatx4*>(values + (size_t)(nbl_nxt[j] >= 0 ? nbl_nxt[j] : 0) * V + pc * 4);
+        } else {
+            ln_load_quarter<KQ>(values + (size_t)(nb >= 0 ? nb : 0) * V + q * KQ, a);
+            if (!DEEP && nb < 0) {
+#pragma unroll
+                for (int k = 0; k < KQ; ++k) a[k] = 0.f;
+            }
         }
         const u32x4* src = bank + ((size_t)e * gridDim.y + blockIdx.y) * BANK16;
 #pragma unroll
@@ -415,18 +461,31 @@ __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(LN
             if (BANK16 % THREADS == 0 || x < BANK16) s_b[x] = w_nxt[s];
         }
     };
-    int nb_nxt = my_row < m ? nbr[(size_t)my_row * E + slot_of(e_begin)] : -1, nb_nn = -1;
+    int nb_nxt = -1, nb_nn = -1;
+    if constexpr (LINE) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) nbl_nxt[j] = (m0 + 4 * j + lr < m) ? nbr[(size_t)(m0 + 4 * j + lr) * E + slot_of(e_begin)] : -1;
+#pragma unroll
+        for (int k = 0; k < KQ; ++k) a_cur[k] = 0.f;
+    } else {
+        nb_nxt = my_row < m ? nbr[(size_t)my_row * E + slot_of(e_begin)] : -1;
+    }
     issue(e_begin, nb_nxt, a_cur);
-    if (nb_nxt < 0) {
+    if (!LINE && nb_nxt < 0) {
 #pragma unroll
         for (int k = 0; k < KQ; ++k) a_cur[k] = 0.f;
     }
     stage();
     __syncthreads();
-    nb_nxt = load_nb(e_begin + 1);
+    if constexpr (LINE) {
+        reshape();
+        load_nbl(e_begin + 1, nbl_nxt);
+    } else {
+        nb_nxt = load_nb(e_begin + 1);
+    }
     for (int e = e_begin; e < e_end; ++e) {
         if (e + 1 < e_end) {
-            nb_nn = load_nb(e + 2);
+            if constexpr (!LINE) nb_nn = load_nb(e + 2);
 #if LN_CONV_PROBE & 8
 #pragma unroll
             for (int k = 0; k < KQ; ++k) a_nxt[k] = a_cur[k] * 1.5f;
@@ -507,9 +566,14 @@ __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(LN
         }
         // unconditional (a_nxt is initialised): no register of a_cur is ever undefined on a path through the loop — with
         // undefined lanes in the loop-carried registers hipcc 7.2 has mis-assigned the operands of the split's pack instructions
+        if constexpr (LINE) {
+            reshape();
+            load_nbl(e + 2, nbl_nxt);  // (ids from LDS: read here, used at the top of the next trip — four more registers a slot ahead spill at T = 3)
+        } else {
 #pragma unroll
-        for (int k = 0; k < KQ; ++k) a_cur[k] = (!DEEP || nb_nxt >= 0) ? a_nxt[k] : 0.f;
-        nb_nxt = nb_nn;
+            for (int k = 0; k < KQ; ++k) a_cur[k] = (!DEEP || nb_nxt >= 0) ? a_nxt[k] : 0.f;
+            nb_nxt = nb_nn;
+        }
     }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
