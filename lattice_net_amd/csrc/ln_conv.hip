@@ -1798,7 +1798,15 @@ static int ln_conv_dispatch(const int* nbr, const float* values_neigh, const flo
         if constexpr (!FLIP && !WT) {  // V = F = 32 forward on the bf16 matrix cores (LN_DEBUG_MASK & 524288: fp32 form, A/B)
             if (val_dim == 32 && nr_filters == 32 && m >= LN_CONV_B3_MIN_ROWS && ln_conv_b3_enabled() && !(ln_debug_mask() & 524288) &&
                 (reinterpret_cast<uintptr_t>(values_neigh) & 15) == 0) {
-                const int t = min(ln_bwd_subtiles(m), 3);
+                int t = min(ln_bwd_subtiles(m), 3);
+                {
+                    static int forced = -1;  // experiment knob: LN_FWD_T=1..3 forces the forward's sub-tile count alone (read once)
+                    if (forced < 0) {
+                        const char* e = getenv("LN_FWD_T");
+                        forced = e ? atoi(e) : 0;
+                    }
+                    if (forced >= 1 && forced <= 3) t = forced;
+                }
                 const dim3 grid_t(ln_div_up(m, 64 * t)), block_t(256 * t);
                 if (t == 1) LN_LAUNCH("k_conv_mfma", (k_conv_forward_b3<1>), grid_t, block_t, 0, st, nbr, values_neigh, filter, m, out, g_ln_row_partition);
                 else if (t == 2) LN_LAUNCH("k_conv_mfma", (k_conv_forward_b3<2>), grid_t, block_t, 0, st, nbr, values_neigh, filter, m, out, g_ln_row_partition);

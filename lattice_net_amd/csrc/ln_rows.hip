@@ -115,6 +115,9 @@ __global__ void __launch_bounds__(256)
                     int chunks, float* __restrict__ out, float* __restrict__ zero_fill, long long zero_elems) {
     using T = typename VecT<VEC>::type;
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+#ifdef LN_PROBE_NO_CLEAR  // timing probe (wrong results): no zero fill
+    zero_fill = nullptr;
+#endif
     if (zero_fill) {  // the accumulator the backward pass of this slice will scatter into, zeroed on the way
         const long long threads = (long long)gridDim.x * blockDim.x;
         for (long long i = g; i < zero_elems; i += threads) zero_fill[i] = 0.f;

@@ -545,6 +545,9 @@ __global__ void __launch_bounds__(TH)
        // before it (1.6 us at C3 when they came first); here only the end of the kernel does.
         const long long stride = (long long)gridDim.x * TH;
         const long long g = (long long)blockIdx.x * TH + threadIdx.x;
+#ifdef LN_PROBE_NO_CLEAR  // timing probe (wrong results): the values are not cleared
+        clear_values = nullptr;
+#endif
         if (clear_values) {
             const long long n4 = clear_values_elems >> 2;
             float4* v4 = reinterpret_cast<float4*>(clear_values);
