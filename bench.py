@@ -502,6 +502,7 @@ def main():
     graph_mode = args.mode == "graph"
     in_flight = max(1, args.in_flight) if graph_mode else 1
     pool = max(1, args.pool) if graph_mode else 1
+    _lattice_mod.set_scans_in_flight(in_flight)  # builds that overlap with other scans' kernels take narrower bucket-pass workgroups (ln_build_concurrency)
     # independent clouds per rank (weak scaling); parameters broadcast from rank 0 over RCCL
     # LATTICE_BENCH_RANK_OFFSET=r (testing aid): a one-rank run works on the clouds rank r of a larger job would own
     rank_offset = int(os.environ.get("LATTICE_BENCH_RANK_OFFSET", "0"))

@@ -168,6 +168,11 @@ int ln_arena_init(int* arena, long long words, long long minus_begin, long long 
 /* Buckets (runs of consecutive slots, one workgroup of the bucketed build each) of a table that hashes into `capacity` slots: what a
  * host needs to lay out LnTable.slot_map. */
 int ln_table_bucket_count(int capacity);
+/* How many builds / scans the CALLING THREAD keeps in flight on this GPU (1 = one at a time, the default).  A speed hint for the builds
+ * it issues afterwards: with several in flight the bucket pass of a build over small buckets runs on 512-thread workgroups, which finish
+ * a bucket later but pack beside the other scans' kernels (ln_table.hip).  No effect on results.  (The reference has no counterpart: its
+ * build is one stream's work, Lattice.cu:196-241.) */
+int ln_build_concurrency(int scans_in_flight);
 
 /* Scratch needed by ln_build_splat / ln_distribute / ln_coarsen for `tokens` insertions. */
 size_t ln_build_workspace_bytes(long long tokens, int capacity);

@@ -91,6 +91,7 @@ SIGNATURES = {
     "ln_table_clear": (_i, [_T, _vp, _ll, _vp]),
     "ln_build_workspace_bytes": (_sz, [_ll, _i]),
     "ln_table_bucket_count": (_i, [_i]),
+    "ln_build_concurrency": (_i, [_i]),
     "ln_build_splat": (_i, [_T, _vp, _vp, _i, _vp, _vp, _i, _CSR, _vp, _sz, _vp, _ll, _vp]),
     "ln_rehash": (_i, [_T, _vp]),
     "ln_canonicalize": (_i, [_T, _vp, _ll, _CSR, _vp, _sz, _vp]),

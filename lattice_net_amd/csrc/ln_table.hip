@@ -585,6 +585,15 @@ __global__ void __launch_bounds__(TH)
 #define LN_BKT_THREADS 1024
 #endif
 #define LN_BKT_WAVES (LN_BKT_THREADS / 64)
+#ifndef LN_BKT_NARROW_TOKENS
+#define LN_BKT_NARROW_TOKENS 4096  // tokens per bucket up to which overlapping builds take 512-thread bucket workgroups
+#endif
+// ln_build_concurrency: how many builds / scans the caller keeps in flight on this GPU (thread-local, 1 = one at a time)
+static thread_local int g_ln_build_concurrency = 1;
+extern "C" int ln_build_concurrency(int scans_in_flight) {
+    g_ln_build_concurrency = scans_in_flight > 1 ? scans_in_flight : 1;
+    return LN_OK;
+}
 #define LN_BKT_LDS_LIMIT (150 * 1024)  // dynamic LDS one k_bucket_rows workgroup may ask for (160 KB per CU minus its static arrays)
 #define LN_BKT_LDS_PER_SLOT (sizeof(unsigned long long) + 7 * sizeof(int))
 #define LN_BKT_LDS_EXTRA 32  // alignment of the compacted token list + its padding to a multiple of four entries
@@ -592,8 +601,8 @@ __global__ void __launch_bounds__(TH)
 #define LN_PUB_READY 0x80000000u
 #define LN_PUB_ERR 0x40000000u
 #define LN_PUB_CNT 0x3FFFFFFFu
-template <int D>
-__global__ void __launch_bounds__(LN_BKT_THREADS)
+template <int D, int TH>
+__global__ void __launch_bounds__(TH)
     k_bucket_rows(LnTable t, int sb, int nbk, int capb, int* __restrict__ cursor, const int* __restrict__ part_tok,
                   const unsigned long long* __restrict__ part_pk, int* __restrict__ part_slot, int* __restrict__ part_pos,
                   int* __restrict__ idx_out, LnCsr csr, unsigned int* __restrict__ pub) {
@@ -623,7 +632,7 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
     // can fill one XCD each with workgroups that wait for a bucket whose workgroup has nowhere to go (measured: a 0.6 s stall).
     if (tid == 0) s_ticket = atomicAdd(reinterpret_cast<int*>(&pub[nbk]), 1);
     LN_STAMP(8);
-    for (int i = tid; i < sb; i += LN_BKT_THREADS) {  // (while the ticket is in flight)
+    for (int i = tid; i < sb; i += TH) {  // (while the ticket is in flight)
         skeys[i] = LN_EMPTY_KEY;  // the table was cleared by this build call
         scnt[i] = 0;
         smin[i] = LN_EMPTY_TOK;
@@ -641,14 +650,14 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
     // whatever the cursor says, saved the dependency and cost more in reads: 20.2 -> 21.3 us).
     const size_t in0 = (size_t)b * capb;
     int before = 0;
-    for (int i = tid; i < b; i += LN_BKT_THREADS) before += min(cursor[i], capb);
+    for (int i = tid; i < b; i += TH) before += min(cursor[i], capb);
     const int my_cursor = cursor[b];
     const int ntok = min(my_cursor, capb);
     int r_tk[LN_BKT_REG_TOK], r_ls[LN_BKT_REG_TOK], r_pos[LN_BKT_REG_TOK];
     unsigned long long r_pk[LN_BKT_REG_TOK];
 #pragma unroll
     for (int k = 0; k < LN_BKT_REG_TOK; ++k) {
-        const int j = tid + k * LN_BKT_THREADS;
+        const int j = tid + k * TH;
         r_ls[k] = -1;
         r_pos[k] = -1;
         r_tk[k] = j < ntok ? part_tok[in0 + j] : -1;
@@ -667,7 +676,7 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
     __syncthreads();  // (every cursor[] load of this workgroup has returned by now: the last bucket relies on it)
     int base = 0;
 #pragma unroll
-    for (int k = 0; k < LN_BKT_WAVES; ++k) base += s_wave_tok[k];
+    for (int k = 0; k < (TH / 64); ++k) base += s_wave_tok[k];
     ln_lds_barrier();  // s_wave_tok is reused by the scans below
     LN_STAMP(9);
 
@@ -721,7 +730,7 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
 #pragma unroll
     for (int k = 0; k < LN_BKT_REG_TOK; ++k)
         if (__ballot(r_tk[k] >= 0)) place(r_tk[k] >= 0, r_tk[k], r_pk[k], r_ls[k], r_pos[k]);  // (wave-uniform: the votes inside need whole waves)
-    for (int j0 = LN_BKT_REG_TOK * LN_BKT_THREADS; j0 < ntok; j0 += LN_BKT_THREADS) {
+    for (int j0 = LN_BKT_REG_TOK * TH; j0 < ntok; j0 += TH) {
         const int j = j0 + tid;
         const bool valid = j < ntok;
         int ls, pos;
@@ -734,7 +743,7 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
     ln_lds_barrier();
     LN_STAMP(10);
     // exclusive scans of the per-slot token counts, segment counts and occupancy (-> row of the slot inside the bucket)
-    for (int start = 0; start < size; start += LN_BKT_THREADS) {
+    for (int start = 0; start < size; start += TH) {
         const int i = start + tid;
         const int c = (i < size) ? scnt[i] : 0;
         const int g = (c + LN_CSR_SEG - 1) / LN_CSR_SEG;
@@ -750,7 +759,7 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
         ln_lds_barrier();
         int wt = 0, wg = 0, wn = 0;
 #pragma unroll
-        for (int k = 0; k < LN_BKT_WAVES; ++k) {  // all LDS reads issue together (a loop to `wave` waits for each in turn)
+        for (int k = 0; k < (TH / 64); ++k) {  // all LDS reads issue together (a loop to `wave` waits for each in turn)
             const int a = s_wave_tok[k], g2 = s_wave_seg[k], n2 = s_wave_new[k];
             if (k < wave) {
                 wt += a;
@@ -760,7 +769,7 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
         }
         // (a bucket of at most one trip starts from zero without reading the running totals: no barrier needed before the last
         // thread overwrites them)
-        const bool multi = size > LN_BKT_THREADS;
+        const bool multi = size > TH;
         const int rt = multi ? s_run_tok : 0, rg = multi ? s_run_seg : 0, rn = multi ? s_run_new : 0;
         if (i < size) {
             soff[i] = rt + wt + ic - c;
@@ -768,7 +777,7 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
             srow[i] = rn + wn + in_wave_new;
         }
         if (multi) ln_lds_barrier();  // (every thread has read the running totals of this trip)
-        if (tid == LN_BKT_THREADS - 1) {
+        if (tid == TH - 1) {
             s_run_tok = rt + wt + ic;
             s_run_seg = rg + wg + ig;
             s_run_new = rn + wn + __popcll(occ);
@@ -785,10 +794,10 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
     // (point, remainder) order among the bucket's vertices) — a pure function of the cloud, identical run to run.
     {
         const int nv = s_run_new;
-        for (int i = tid; i < size; i += LN_BKT_THREADS)
+        for (int i = tid; i < size; i += TH)
             if (scnt[i]) slist[srow[i]] = smin[i];
-        for (int j = nv + tid; j < ((nv + 3) & ~3); j += LN_BKT_THREADS) slist[j] = 0xFFFFFFFFu;  // pad to a multiple of 4
-        for (int j = tid; j < nv; j += LN_BKT_THREADS) srank[j] = 0;
+        for (int j = nv + tid; j < ((nv + 3) & ~3); j += TH) slist[j] = 0xFFFFFFFFu;  // pad to a multiple of 4
+        for (int j = tid; j < nv; j += TH) srank[j] = 0;
         ln_lds_barrier();
         LN_STAMP(17);
         const uint4* l4 = reinterpret_cast<const uint4*>(slist);
@@ -797,8 +806,8 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
         // (vertex, chunk) grid over the COMPACTED list: chunks = threads / nv, every thread counts over its share of the list with
         // four loads in flight (the lanes of a wave read the same words: LDS broadcast) and adds its partial count to its vertex
         // with one LDS add.  (Two lanes per SLOT, occupied or not, each walking half the list one load at a time: 2.3 us of the pass.)
-        const int chunks = max(1, min(LN_BKT_THREADS / max(nv, 1), nv4));
-        const int vpp = LN_BKT_THREADS / chunks;      // vertices per trip
+        const int chunks = max(1, min(TH / max(nv, 1), nv4));
+        const int vpp = TH / chunks;      // vertices per trip
         const int per = (nv4 + chunks - 1) / chunks;  // 16-byte words per chunk
         for (int v0 = 0; v0 < nv; v0 += vpp) {        // one trip unless the bucket holds more vertices than the workgroup has threads
             const int v = v0 + tid % vpp, ch = tid / vpp;
@@ -818,7 +827,7 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
             }
         }
         ln_lds_barrier();
-        for (int i = tid; i < size; i += LN_BKT_THREADS)
+        for (int i = tid; i < size; i += TH)
             if (scnt[i]) srow[i] = srank[srow[i]];  // (srow[i] held the slot's position in the compacted list)
     }
     LN_STAMP(11);
@@ -830,7 +839,7 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
     const int bucket_region = (slot_ordered && csr.planes) ? ln_region_of_bucket(b, nbk) : 0;
     const int* planes = slot_ordered ? nullptr : csr.planes;
     if (planes) {
-        for (int i = tid; i < size; i += LN_BKT_THREADS) {
+        for (int i = tid; i < size; i += TH) {
             const int c = scnt[i];
             if (c) {
                 int key[D];
@@ -852,7 +861,7 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
     // look-back: new vertices (and error flags) of every earlier bucket
     int rows_before = 0;
     unsigned int err_before = 0u;
-    for (int i = tid; i < b; i += LN_BKT_THREADS) {
+    for (int i = tid; i < b; i += TH) {
         unsigned int v = __hip_atomic_load(&pub[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         while (!(v & LN_PUB_READY)) {
             __builtin_amdgcn_s_sleep(2);
@@ -875,7 +884,7 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
     int base_row = 0;
     unsigned int err_all = s_err ? LN_PUB_ERR : 0u;
 #pragma unroll
-    for (int k = 0; k < LN_BKT_WAVES; ++k) {
+    for (int k = 0; k < (TH / 64); ++k) {
         base_row += s_wave_tok[k];
         err_all |= (unsigned int)s_wave_seg[k];
     }
@@ -887,7 +896,7 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
         if (b == nbk - 1) t.row_regions[LN_XCD_GROUPS] = base_row + new_here;
     }
     LN_STAMP(12);
-    for (int i = tid; i < size; i += LN_BKT_THREADS) {
+    for (int i = tid; i < size; i += TH) {
         const int h = lo + i;
         const int beg = base + soff[i];
         const int c = scnt[i];
@@ -915,7 +924,7 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
     }
     if (b == nbk - 1) {  // close the build
         // (a slot map may leave a few slots behind its last run: they stay empty, and every slot array says so)
-        for (int h = lo + size + tid; h < t.capacity; h += LN_BKT_THREADS) {
+        for (int h = lo + size + tid; h < t.capacity; h += TH) {
             csr.grp_start[h] = base + ntok;
             t.slot_keys[h] = LN_EMPTY_KEY;
             t.entries[h] = -1;
@@ -930,7 +939,7 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
             ln_report_to_host(t.host_counters, total, bits, t.host_seq);
         }
         __syncthreads();  // (tid 0 has read cursor[nbk])
-        for (int i = tid; i <= nbk; i += LN_BKT_THREADS) cursor[i] = 0;  // all-zero between builds; every reader has published
+        for (int i = tid; i <= nbk; i += TH) cursor[i] = 0;  // all-zero between builds; every reader has published
     }
     ln_lds_barrier();  // srow[] now holds the final row of every slot
     LN_STAMP(13);
@@ -940,13 +949,13 @@ __global__ void __launch_bounds__(LN_BKT_THREADS)
         if (r_ls[k] >= 0) csr.csr_tok[base + soff[r_ls[k]] + r_pos[k]] = r_tk[k];
         if (idx_out) idx_out[r_tk[k]] = r_ls[k] >= 0 ? srow[r_ls[k]] : -1;
     }
-    for (int j = tid + LN_BKT_REG_TOK * LN_BKT_THREADS; j < ntok; j += LN_BKT_THREADS) {
+    for (int j = tid + LN_BKT_REG_TOK * TH; j < ntok; j += TH) {
         const int ls = part_slot[in0 + j];
         const int tk = part_tok[in0 + j];
         if (ls >= 0) csr.csr_tok[base + soff[ls] + part_pos[in0 + j]] = tk;
         if (idx_out) idx_out[tk] = ls >= 0 ? srow[ls] : -1;
     }
-    for (int j = placed + tid; j < ntok; j += LN_BKT_THREADS)
+    for (int j = placed + tid; j < ntok; j += TH)
         csr.csr_tok[base + j] = -1;  // only after an overflow: keeps readers in bounds until the rebuild
     LN_STAMP(14);
 }
@@ -1372,7 +1381,22 @@ static int ln_build_points(const LnTable* t, const float* positions_raw, const f
                 LN_LAUNCH("k_point_keys", (k_point_keys<D, 256>), dim3(ln_div_up(n, LN_KEYS_PTS_PER_BLOCK)), dim3(256), 0, st, *t, positions_raw, sc, n, sb,
                           nbk, ws.capb, ws.part_tok, ws.part_pk, dropped_idx, write_idx ? w : (float*)nullptr, vals, val_dim, distributed,
                           csr->seg_count, csr->planes ? LN_XCD_GROUPS : 1, clear_values, clear_values_elems, ws.pub);
-            LN_LAUNCH("k_bucket_rows", k_bucket_rows<D>, dim3(nbk), dim3(LN_BKT_THREADS), lds, st, *t, sb, nbk, ws.capb, t->slot_cnt,
+            // Workgroup size of the bucket pass.  1024 threads finish a bucket soonest (C3, 256 buckets of 1 875 tokens: 19.9 us against 22.7
+            // on 512 threads), but one such workgroup takes half a CU's wave slots; with several scans in flight the narrower workgroups
+            // pack beside the other scans' kernels: C3 1407 -> 1441 Mpoints/s, C4 (3 100 tokens per bucket) 947 -> 980, C2 with 16 clouds
+            // per step 494 -> 508 — C5, 7 500 tokens per bucket, 1421 -> 1401 (LN_BKT_THREADS=512 builds, one box).  The caller says
+            // whether builds overlap with other work (ln_build_concurrency); alone, and on big buckets, 1024 stays.
+            static int narrow_ok = -1;  // LN_BKT_NARROW=0: 1024-thread bucket workgroups whatever the concurrency (A/B; read once)
+            if (narrow_ok < 0) {
+                const char* ev = getenv("LN_BKT_NARROW");
+                narrow_ok = (ev && ev[0] == '0') ? 0 : 1;
+            }
+            const bool narrow = narrow_ok && g_ln_build_concurrency > 1 && tokens <= (long long)LN_BKT_NARROW_TOKENS * nbk;
+            if (narrow)
+                LN_LAUNCH("k_bucket_rows", (k_bucket_rows<D, 512>), dim3(nbk), dim3(512), lds, st, *t, sb, nbk, ws.capb, t->slot_cnt,
+                      ws.part_tok, ws.part_pk, ws.part_slot, ws.part_pos, dropped_idx, *csr, ws.pub);
+            else
+                LN_LAUNCH("k_bucket_rows", (k_bucket_rows<D, LN_BKT_THREADS>), dim3(nbk), dim3(LN_BKT_THREADS), lds, st, *t, sb, nbk, ws.capb, t->slot_cnt,
                       ws.part_tok, ws.part_pk, ws.part_slot, ws.part_pos, dropped_idx, *csr, ws.pub);
             rc = ln_check_launch(who);
             if (rc == LN_OK && (flags & LN_BUILD_CANONICAL_ROWS)) rc = ln_canonicalize_impl<D>(*t, dropped_idx, tokens, csr, ws, st);

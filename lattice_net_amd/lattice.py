@@ -113,6 +113,17 @@ def set_slot_order(order: str) -> str:
     return prev
 
 
+# How many scans the caller keeps in flight on this GPU (own lattice and stream each: bench.py's throughput mode, a data loader that
+# builds ahead).  Passed to the library with every build (ln_build_concurrency): overlapping builds over small buckets take narrower
+# bucket-pass workgroups.  A speed hint only; a captured graph keeps what was set when it was captured.
+_SCANS_IN_FLIGHT = [max(1, int(os.environ.get("LATTICE_SCANS_IN_FLIGHT", "1")))]
+
+
+def set_scans_in_flight(n: int) -> int:
+    prev, _SCANS_IN_FLIGHT[0] = _SCANS_IN_FLIGHT[0], max(1, int(n))
+    return prev
+
+
 # Run-to-run identical floating-point results of everything that sums over the tokens of a vertex (splat values, position means,
 # slice / gather / slice_classify gradients).  The default kernels are deterministic in WHAT they sum and free in the ORDER: a
 # token's place in its vertex's list comes from an atomic counter of the build, and rows with several segments combine through float
@@ -698,6 +709,7 @@ class Lattice:
             if _DETERMINISTIC[0]:
                 flags |= _lib.LN_BUILD_SORTED_CSR
             cv, cn = _lib.ptr(clear_vals), clear_elems
+            lib.ln_build_concurrency(_SCANS_IN_FLIGHT[0])  # (thread-local in the library: an assignment)
             ht.arm_count_readback()  # t is ht's cached struct: the sequence number travels in it
             if distributed is None:
                 rc = lib.ln_build_splat(C.byref(t), _lib.ptr(positions_raw), self._sigmas_host(), n, _lib.ptr(idx), _lib.ptr(w), flags,

@@ -389,3 +389,35 @@ def test_cloud_far_beyond_the_static_bound_fills_the_shrunk_range_without_hangin
     oidx, _ = O.build_splat(t, O.scale_positions(big, np.full((3,), 0.3, np.float32)))
     assert m2 == t.nr_filled and m2 > 50 * bound
     np.testing.assert_array_equal(N(idx2), oidx)
+
+
+@pytest.mark.parametrize("d,n,sigma,cap", [(3, 120000, 0.9, 100000), (3, 2500, 0.05, 60000), (2, 40000, 0.3, 30000), (5, 6000, 0.4, 80000),
+                                           (3, 200000, 0.08, 5000000)])
+def test_bucket_pass_workgroup_size_is_invisible(d, n, sigma, cap, monkeypatch):
+    """ln_build_concurrency (lattice.set_scans_in_flight): with several scans in flight the bucket pass of a build over small buckets runs
+    on 512-thread workgroups instead of 1024 (ln_table.hip: k_bucket_rows<D, TH>).  Rows are numbered bucket by bucket either way: indices,
+    weights, keys, vertex count, the CSR's per-vertex token counts and the neighbour list must be identical bit for bit — and equal to the
+    oracle's in the canonical numbering."""
+    import lattice_net_amd.lattice as LM
+    from lattice_net_amd.synthetic import lidar_cloud
+    rng = np.random.default_rng(7 * d + n)
+    pos_np = lidar_cloud(n, 5) if (d == 3 and n == 120000) else (rng.random((n, d), dtype=np.float32) * 2 - 1).astype(np.float32)
+    res = []
+    for scans in (1, 4):
+        prev = LM.set_scans_in_flight(scans)
+        try:
+            lat, idx, w, m, status = build(pos_np, sigma, cap, False, monkeypatch)
+            res.append((idx.clone(), w.clone(), lat.hash_table().m_keys_tensor[:m].clone(), m, status,
+                        lat.vertex_point_counts(idx).clone(), lat.neighbours(None, 1, False).clone()))
+        finally:
+            LM.set_scans_in_flight(prev)
+    a, b = res
+    assert a[3] == b[3] and a[4] == b[4] == 0
+    for x, y in zip(a[:3] + a[5:], b[:3] + b[5:]):
+        assert torch.equal(x, y)
+    if n <= 40000:  # (the oracle's serial build: small cases only)
+        t = O.OracleHashTable(cap, d)
+        oidx, ow = O.build_splat(t, O.scale_positions(pos_np, np.full((d,), sigma, np.float32)))
+        assert b[3] == t.nr_filled
+        np.testing.assert_array_equal(N(b[0]), oidx)
+        np.testing.assert_array_equal(N(b[1]), ow)
