@@ -386,7 +386,8 @@ def test_conv_small_integer_operands_are_exact(v, f):
 @pytest.mark.parametrize("lo,hi", [(4096, 16384), (16385, 32768), (32769, 49152)])
 def test_fused_32_channel_kernels_exact_at_every_subtile_count(lo, hi):
     """k_conv_forward_b3<T> / k_conv_backward_fused_b3<T> (the headline chain's convolution, V = F = 32) are instantiated for T = 1, 2, 3
-    sub-tiles of 64 vertices per workgroup, chosen from the vertex count (ln_bwd_subtiles: <= 16 384 / <= 32 768 / above at 256 CUs).
+    sub-tiles of 64 vertices per workgroup, chosen from the vertex count (ln_bwd_subtiles, rounds of 256 workgroups x (T + 1): <= 16 384 /
+    <= 32 768 / above at 256 CUs).
     Small-integer operands: forward, value gradient and filter gradient must equal the float64 (exact) result bit for bit."""
     from lattice_net_amd import ConvIm2RowLattice
     from lattice_net_amd.synthetic import cube_cloud
