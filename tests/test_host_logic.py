@@ -254,3 +254,25 @@ def test_launch_thread_pinning_follows_the_numa_node_of_the_ranks_gpu(tmp_path):
         assert sharding.pin_launch_thread(1, 2, sysfs_root=str(tmp_path / "nothing_here")) == have[half:2 * half]  # no sysfs: contiguous slices
     finally:
         os.sched_setaffinity(0, have)
+
+
+def test_round6_switches_are_plain_host_state():
+    """Module-level switches of round 6 (no GPU needed to set them): the scans-in-flight hint handed to ln_build_concurrency with every
+    build, the slot order and the deterministic mode return the previous setting and reject nonsense."""
+    import pytest
+    from lattice_net_amd import lattice as LM
+    prev = LM.set_scans_in_flight(4)
+    try:
+        assert LM._SCANS_IN_FLIGHT[0] == 4
+        assert LM.set_scans_in_flight(0) == 4 and LM._SCANS_IN_FLIGHT[0] == 1  # (clamped: one scan at a time)
+    finally:
+        LM.set_scans_in_flight(prev)
+    order = LM.set_slot_order("space")
+    try:
+        assert LM.set_slot_order("hash") == "space"
+        with pytest.raises(ValueError):
+            LM.set_slot_order("morton")
+    finally:
+        LM.set_slot_order(order)
+    det = LM.set_deterministic(True)
+    assert LM.set_deterministic(det) is True
