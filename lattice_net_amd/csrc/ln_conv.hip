@@ -236,13 +236,18 @@ __global__ void __launch_bounds__(256) LN_CONV_WAVES_ATTR
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // x = hi + mid + lo exactly, each the top 16 bits of the remainder; returned as raw bf16 bit patterns in the HIGH half-words
+// (`lo` comes back UNMASKED — its low half-word is whatever is left below the third part: every user takes the high half-word only, by a
+// 16-bit shift or through ln_pack_hi)
 __device__ __forceinline__ void ln_split3_bits(float x, unsigned int& hi, unsigned int& mid, unsigned int& lo) {
     hi = __float_as_uint(x) & 0xFFFF0000u;
     const float r1 = x - __uint_as_float(hi);
     mid = __float_as_uint(r1) & 0xFFFF0000u;
     const float r2 = r1 - __uint_as_float(mid);
-    lo = __float_as_uint(r2) & 0xFFFF0000u;
+    lo = __float_as_uint(r2);
 }
+// two bf16 per dword: the HIGH half-word of `a` in the low half, the high half-word of `b` in the high half — one v_perm_b32 (round 6;
+// before: shift + or on masked words, 3 more vector-ALU instructions per pair of split values)
+__device__ __forceinline__ unsigned int ln_pack_hi(unsigned int a, unsigned int b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
 
 // One block of the slab sum (k_reduce_slabs4 below): 64 outputs as 16 float4 columns x 16 slab groups (every thread has its
 // <= ceil(nslabs / 16) float4 loads in flight at once), combined through LDS in a fixed order.  total % 64 == 0.
@@ -513,9 +518,9 @@ __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(LN
                 unsigned int h0, m0_, l0, h1, m1_, l1;
                 ln_split3_bits(a_cur[st * 8 + 2 * j], h0, m0_, l0);
                 ln_split3_bits(a_cur[st * 8 + 2 * j + 1], h1, m1_, l1);
-                p1[j] = (h0 >> 16) | h1;
-                p2[j] = (m0_ >> 16) | m1_;
-                p3[j] = (l0 >> 16) | l1;
+                p1[j] = ln_pack_hi(h0, h1);
+                p2[j] = ln_pack_hi(m0_, m1_);
+                p3[j] = ln_pack_hi(l0, l1);
             }
 #if LN_CONV_PROBE & 2
             p1 = u32x4{__float_as_uint(a_cur[st * 8]), __float_as_uint(a_cur[st * 8 + 1]), __float_as_uint(a_cur[st * 8 + 2]), __float_as_uint(a_cur[st * 8 + 3])};
@@ -1718,9 +1723,9 @@ __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(T,
 #pragma unroll
             for (int j = 0; j < 8; ++j) ln_split3_bits(wv[s][j], h[j], md[j], lo[j]);
             const int unit = ((e * NT + (f >> 4)) * 3) * 64 + vo * 16 + (f & 15);
-            s_frag_w[unit] = u32x4{(h[0] >> 16) | h[1], (h[2] >> 16) | h[3], (h[4] >> 16) | h[5], (h[6] >> 16) | h[7]};
-            s_frag_w[unit + 64] = u32x4{(md[0] >> 16) | md[1], (md[2] >> 16) | md[3], (md[4] >> 16) | md[5], (md[6] >> 16) | md[7]};
-            s_frag_w[unit + 128] = u32x4{(lo[0] >> 16) | lo[1], (lo[2] >> 16) | lo[3], (lo[4] >> 16) | lo[5], (lo[6] >> 16) | lo[7]};
+            s_frag_w[unit] = u32x4{ln_pack_hi(h[0], h[1]), ln_pack_hi(h[2], h[3]), ln_pack_hi(h[4], h[5]), ln_pack_hi(h[6], h[7])};
+            s_frag_w[unit + 64] = u32x4{ln_pack_hi(md[0], md[1]), ln_pack_hi(md[2], md[3]), ln_pack_hi(md[4], md[5]), ln_pack_hi(md[6], md[7])};
+            s_frag_w[unit + 128] = u32x4{ln_pack_hi(lo[0], lo[1]), ln_pack_hi(lo[2], lo[3]), ln_pack_hi(lo[4], lo[5]), ln_pack_hi(lo[6], lo[7])};
         }
     }
     floatx4 acc[NT];
@@ -1758,9 +1763,9 @@ __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(T,
             ln_split3_bits(nb[e] >= 0 ? ae[2 * j] : 0.f, h0, m0_, l0);
             ln_split3_bits(nb[e] >= 0 ? ae[2 * j + 1] : 0.f, h1, m1_, l1);
 #endif
-            p1[j] = (h0 >> 16) | h1;
-            p2[j] = (m0_ >> 16) | m1_;
-            p3[j] = (l0 >> 16) | l1;
+            p1[j] = ln_pack_hi(h0, h1);
+            p2[j] = ln_pack_hi(m0_, m1_);
+            p3[j] = ln_pack_hi(l0, l1);
         }
         const bf16x8 a1 = __builtin_bit_cast(bf16x8, p1), a2 = __builtin_bit_cast(bf16x8, p2), a3 = __builtin_bit_cast(bf16x8, p3);
 #pragma unroll
@@ -2165,9 +2170,9 @@ __global__ void __launch_bounds__(64 * WV * WF, (WV * WF) > 8 ? 1 : LN_GFB_WAVES
         ln_split3_bits(x.z, h[2], md[2], lo[2]);
         ln_split3_bits(x.w, h[3], md[3], lo[3]);
 #endif
-        *reinterpret_cast<uint2*>(dst) = make_uint2((h[0] >> 16) | h[1], (h[2] >> 16) | h[3]);
-        *reinterpret_cast<uint2*>(dst + plane) = make_uint2((md[0] >> 16) | md[1], (md[2] >> 16) | md[3]);
-        *reinterpret_cast<uint2*>(dst + 2 * plane) = make_uint2((lo[0] >> 16) | lo[1], (lo[2] >> 16) | lo[3]);
+        *reinterpret_cast<uint2*>(dst) = make_uint2(ln_pack_hi(h[0], h[1]), ln_pack_hi(h[2], h[3]));
+        *reinterpret_cast<uint2*>(dst + plane) = make_uint2(ln_pack_hi(md[0], md[1]), ln_pack_hi(md[2], md[3]));
+        *reinterpret_cast<uint2*>(dst + 2 * plane) = make_uint2(ln_pack_hi(lo[0], lo[1]), ln_pack_hi(lo[2], lo[3]));
     };
     auto frag = [&](const unsigned short* base, int rs) {  // 8 bf16 down the rows: rows 4q..4q+3 and 16+4q..16+4q+3 of the 32-row step
         // (the order of the contraction inside a step is free as long as both operands use the same one), one column
@@ -2693,9 +2698,9 @@ __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(T,
             unsigned int h0, m0_, l0, h1, m1_, l1;
             ln_split3_bits(x[2 * j], h0, m0_, l0);
             ln_split3_bits(x[2 * j + 1], h1, m1_, l1);
-            va[st][0][j] = (h0 >> 16) | h1;
-            va[st][1][j] = (m0_ >> 16) | m1_;
-            va[st][2][j] = (l0 >> 16) | l1;
+            va[st][0][j] = ln_pack_hi(h0, h1);
+            va[st][1][j] = ln_pack_hi(m0_, m1_);
+            va[st][2][j] = ln_pack_hi(l0, l1);
         }
     }
 #ifndef LN_BWD_DEPTH
@@ -2756,9 +2761,9 @@ __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(T,
             // fragment reads below — ds_read_b128, lane groups {0-3,12-15,20-27} ... over 64 banks — stay conflict-free under this XOR:
             // masks 0/2 keep a lane's column inside its quarter pair, masks 4/6 swap both halves of a group together.)
             const int fr = (((e * NT + (v >> 4)) * 3) * 64 + (f0 >> 3) * 16 + ((v & 15) ^ (2 * (f0 >> 3)))) * 8 + (f0 & 7);
-            *reinterpret_cast<uint2*>(s_fh + fr) = make_uint2((h[0] >> 16) | h[1], (h[2] >> 16) | h[3]);
-            *reinterpret_cast<uint2*>(s_fh + fr + 64 * 8) = make_uint2((md[0] >> 16) | md[1], (md[2] >> 16) | md[3]);
-            *reinterpret_cast<uint2*>(s_fh + fr + 2 * 64 * 8) = make_uint2((lo[0] >> 16) | lo[1], (lo[2] >> 16) | lo[3]);
+            *reinterpret_cast<uint2*>(s_fh + fr) = make_uint2(ln_pack_hi(h[0], h[1]), ln_pack_hi(h[2], h[3]));
+            *reinterpret_cast<uint2*>(s_fh + fr + 64 * 8) = make_uint2(ln_pack_hi(md[0], md[1]), ln_pack_hi(md[2], md[3]));
+            *reinterpret_cast<uint2*>(s_fh + fr + 2 * 64 * 8) = make_uint2(ln_pack_hi(lo[0], lo[1]), ln_pack_hi(lo[2], lo[3]));
         }
     }
     floatx4 acc_v[NT];
@@ -2782,9 +2787,9 @@ __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(T,
             for (int c = 0; c < 4; ++c) ln_split3_bits(there ? x[c] : 0.f, h[c], md[c], lo[c]);
             const int row = wave * 16 + 8 * j + lr;
             unsigned short* dst = sg + row * RS + (((c8 >> 1) ^ swz(row)) * 8 + (c8 & 1) * 4);
-            *reinterpret_cast<uint2*>(dst) = make_uint2((h[0] >> 16) | h[1], (h[2] >> 16) | h[3]);
-            *reinterpret_cast<uint2*>(dst + PART) = make_uint2((md[0] >> 16) | md[1], (md[2] >> 16) | md[3]);
-            *reinterpret_cast<uint2*>(dst + 2 * PART) = make_uint2((lo[0] >> 16) | lo[1], (lo[2] >> 16) | lo[3]);
+            *reinterpret_cast<uint2*>(dst) = make_uint2(ln_pack_hi(h[0], h[1]), ln_pack_hi(h[2], h[3]));
+            *reinterpret_cast<uint2*>(dst + PART) = make_uint2(ln_pack_hi(md[0], md[1]), ln_pack_hi(md[2], md[3]));
+            *reinterpret_cast<uint2*>(dst + 2 * PART) = make_uint2(ln_pack_hi(lo[0], lo[1]), ln_pack_hi(lo[2], lo[3]));
         }
         __syncthreads();
         u32x4 p1, p2, p3;
@@ -2805,9 +2810,9 @@ __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(T,
             unsigned int h0, m0_, l0, h1, m1_, l1;
             ln_split3_bits(nb[e] >= 0 ? ae[2 * j] : 0.f, h0, m0_, l0);
             ln_split3_bits(nb[e] >= 0 ? ae[2 * j + 1] : 0.f, h1, m1_, l1);
-            p1[j] = (h0 >> 16) | h1;
-            p2[j] = (m0_ >> 16) | m1_;
-            p3[j] = (l0 >> 16) | l1;
+            p1[j] = ln_pack_hi(h0, h1);
+            p2[j] = ln_pack_hi(m0_, m1_);
+            p3[j] = ln_pack_hi(l0, l1);
         }
         {
             unsigned short* dst = sg + (wave * 16 + i) * RS + (LN_BWD_SWZ ? ((q ^ swz(wave * 16 + i)) * KQ) : q * KQ);
