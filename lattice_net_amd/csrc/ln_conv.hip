@@ -2673,7 +2673,7 @@ __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(T,
 #pragma unroll
     for (int s = 0; s < NST; ++s) {
         const int x4 = tid + s * THREADS;
-        wv[s] = (x4 < N4) ? reinterpret_cast<const float4*>(filter)[x4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        wv[s] = (N4 % THREADS == 0 || x4 < N4) ? reinterpret_cast<const float4*>(filter)[x4] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #if !LN_BWD_LINE
     int nb[E];
@@ -2690,8 +2690,9 @@ __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(T,
         float x[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int row = sub0 + 32 * st + 8 * q + j;
-            x[j] = (row < m) ? values[(size_t)row * V + vt * 16 + i] : 0.f;
+            const int row = sub0 + 32 * st + 8 * q + j;  // (unconditional load of a clamped row + select: no branch around sixteen loads)
+            const float xv = values[(size_t)min(row, m - 1) * V + vt * 16 + i];
+            x[j] = (row < m) ? xv : 0.f;
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -2723,7 +2724,10 @@ __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(T,
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int e = 0; e < E; ++e) nb2[j][e] = (m0 + 8 * j + lr < m) ? nbr[(size_t)(m0 + 8 * j + lr) * E + (e < E - 1 ? (e ^ 1) : e)] : -1;
+        for (int e = 0; e < E; ++e) {  // (clamped row + select, as above)
+            const int id = nbr[(size_t)min(m0 + 8 * j + lr, m - 1) * E + (e < E - 1 ? (e ^ 1) : e)];
+            nb2[j][e] = (m0 + 8 * j + lr < m) ? id : -1;
+        }
     floatx4 a[DEPTH + 1][2];
     auto gather = [&](int e, floatx4 (&dst)[2]) {
 #pragma unroll
@@ -2745,7 +2749,7 @@ __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(T,
 #pragma unroll
     for (int s = 0; s < NST; ++s) {
         const int x4 = tid + s * THREADS;
-        if (x4 < N4) {
+        if (N4 % THREADS == 0 || x4 < N4) {
             const int x = x4 * 4;
             const int ev = x / F;
             const int f0 = x - ev * F;
@@ -2919,12 +2923,13 @@ __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(T,
     }
     __syncthreads();
     float* park_all = reinterpret_cast<float*>(s_raw);
+    const int colp = (ft * 16 + i) ^ ((q & 1) << 4);  // parked column (rows are multiples of 32 floats: the swizzle only ever touches the column)
     if (sub > 0) {
         float* park = park_all + (size_t)(sub - 1) * BANK;
 #pragma unroll
         for (int e = 0; e < E; ++e)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) park[((e * V + vt * 16 + q * 4 + r) * F + ft * 16 + i) ^ ((q & 1) << 4)] = acc_w[e][r];  // (lanes of
+            for (int r = 0; r < 4; ++r) park[(e * V + vt * 16 + q * 4 + r) * F + colp] = acc_w[e][r];  // (lanes of
         // quarters 0/1 and 2/3 are served together: their rows, 4 apart, would share the 16 banks of the column tile)
     }
     if constexpr (T > 1) __syncthreads();
@@ -2937,7 +2942,7 @@ __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(T,
                 const int o = (e * V + vt * 16 + q * 4 + r) * F + ft * 16 + i;
                 float sum = acc_w[e][r];
 #pragma unroll
-                for (int k2 = 1; k2 < T; ++k2) sum += park_all[(size_t)(k2 - 1) * BANK + (o ^ ((q & 1) << 4))];
+                for (int k2 = 1; k2 < T; ++k2) sum += park_all[(k2 - 1) * BANK + (e * V + vt * 16 + q * 4 + r) * F + colp];
                 dst[o] = sum;
             }
     }
