@@ -1651,11 +1651,11 @@ __global__ void __launch_bounds__(256 * T) __attribute__((amdgpu_waves_per_eu(T,
     float wv[NIT][8];
 #pragma unroll
     for (int s = 0; s < NIT; ++s) {
-        const int x = tid + s * THREADS;
-        const int f = x % F;
+        const int x = min(tid + s * THREADS, ITEMS - 1);  // (clamped: the loads of the last, partly used round stay unconditional — no branch
+        const int f = x % F;                              //  around eight loads; the staging below skips what lies beyond ITEMS)
         const int ev8 = x / F;  // e * (V / 8) + v / 8
 #pragma unroll
-        for (int j = 0; j < 8; ++j) wv[s][j] = (x < ITEMS) ? filter[(size_t)(ev8 * 8 + j) * F + f] : 0.f;
+        for (int j = 0; j < 8; ++j) wv[s][j] = filter[(ev8 * 8 + j) * F + f];
     }
 #if LN_FWD_LINE
     {
