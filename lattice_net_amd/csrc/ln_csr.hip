@@ -301,7 +301,9 @@ struct LnReduceArgs {
 // regions, LnCsr.planes): no change; 71 instead of 104 SGPRs (8 instead of 6 workgroups per CU admitted): no change.
 // WG: also combine runs across the wave boundaries of the workgroup (dense clouds: LnCsr.dense; two barriers per block and ten more
 // registers, which cost the sparse C3 scan 10 % — hence a variant of its own, chosen by the host)
-template <int VEC, bool HALF, bool WG>
+// L8 = 8: eight lanes per segment and eight chunks per row as COMPILE-TIME constants (32 fp32 channels on float4 lanes: the headline chain) —
+// the lane / group arithmetic becomes shifts, the chunk loop and the shuffle rounds unroll; 0: both from the arguments.
+template <int VEC, bool HALF, bool WG, int L8 = 0>
 __device__ __forceinline__ void ln_reduce_chunk(const LnSegOfThread& so, const LnReduceArgs& a) {
     const int* __restrict__ csr_tok = a.csr_tok;
     const int4* __restrict__ seg_desc = a.seg_desc;
@@ -310,7 +312,7 @@ __device__ __forceinline__ void ln_reduce_chunk(const LnSegOfThread& so, const L
     const _Float16* __restrict__ src16 = static_cast<const _Float16*>(a.src);
     const float* __restrict__ w = a.w;
     float* __restrict__ dst = a.dst;
-    const int chunks = a.chunks, lanes_per_seg = a.lanes_per_seg, src_div = a.src_div, src_stride = a.src_stride;
+    const int chunks = L8 ? L8 : a.chunks, lanes_per_seg = L8 ? L8 : a.lanes_per_seg, src_div = a.src_div, src_stride = a.src_stride;
     constexpr int U = 4;
     const int lc = so.lane_in_seg;
     const int lane = threadIdx.x & 63;
@@ -462,24 +464,24 @@ __device__ __forceinline__ void ln_reduce_chunk(const LnSegOfThread& so, const L
 }
 
 // body of the segment reduce for workgroup `block_x` of `nblocks`
-template <int VEC, bool HALF, bool WG>
+template <int VEC, bool HALF, bool WG, int L8 = 0>
 __device__ __forceinline__ void ln_reduce_body(int block_x, int nblocks, const LnReduceArgs& a) {
-    for (LnSegWalk wk(block_x, nblocks, a.lanes_per_seg, a.seg_count, a.seg_region); wk.more(); wk.next())
-        ln_reduce_chunk<VEC, HALF, WG>(wk.here(), a);
+    for (LnSegWalk wk(block_x, nblocks, L8 ? L8 : a.lanes_per_seg, a.seg_count, a.seg_region); wk.more(); wk.next())
+        ln_reduce_chunk<VEC, HALF, WG, L8>(wk.here(), a);
 }
 
-template <int VEC, bool HALF, bool WG>
-__global__ void __launch_bounds__(256) k_csr_reduce_segments(LnReduceArgs a) { ln_reduce_body<VEC, HALF, WG>(blockIdx.x, gridDim.x, a); }
+template <int VEC, bool HALF, bool WG, int L8 = 0>
+__global__ void __launch_bounds__(256) k_csr_reduce_segments(LnReduceArgs a) { ln_reduce_body<VEC, HALF, WG, L8>(blockIdx.x, gridDim.x, a); }
 
 // Horizontal fusion of the two launches that follow a splat build and do not depend on each other: workgroups
 // [0, reduce_blocks) accumulate the point features onto the vertices (segment reduce), the rest run the same-level
 // neighbour traversal.  One launch instead of two, and the traversal's short, latency-bound workgroups fill the CUs
 // the reduce's tail leaves idle.
-template <int VEC, int D, bool HALF, bool WG>
+template <int VEC, int D, bool HALF, bool WG, int L8 = 0>
 __global__ void __launch_bounds__(256)
     k_reduce_and_neighbours(LnReduceArgs a, int reduce_blocks, LnTable t, int query_rows_upper, int* __restrict__ nbr) {
     if ((int)blockIdx.x < reduce_blocks) {
-        ln_reduce_body<VEC, HALF, WG>(blockIdx.x, reduce_blocks, a);
+        ln_reduce_body<VEC, HALF, WG, L8>(blockIdx.x, reduce_blocks, a);
     } else {
         // whole vertices per workgroup, and over a space-ordered table the vertices of kd region x on XCD x: the 9 lookups of a vertex
         // land in the slot run of its own region, which then sits in ONE L2 instead of in all eight
@@ -491,6 +493,15 @@ __global__ void __launch_bounds__(256)
     }
 }
 
+// LN_REDUCE_L8=0: the general kernels for the 8-lane, 8-chunk shape too (A/B; read once)
+static bool ln_reduce_l8() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("LN_REDUCE_L8");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v == 1;
+}
 static int ln_reduce_args(const char* who, const LnCsr* csr, const int* grp_row, long long max_segments, const void* src, bool half,
                           const float* w, int val_dim, int src_div, int src_stride, float* dst, LnReduceArgs& a, int& vec, long long& work) {
     LN_REQUIRE(max_segments >= 0 && val_dim >= 1 && src_div >= 1 && src_stride >= val_dim, LN_ERR_ARG, "%s: bad sizes", who);
@@ -527,6 +538,8 @@ static int ln_csr_reduce_rows_impl(const char* who, const LnCsr* csr, const int*
     {                                                                                                                                \
         if (wg)                                                                                                                      \
             LN_LAUNCH("k_csr_reduce_segments", (k_csr_reduce_segments<VV, HH, (VV >= 4)>), grid, block, 0, st, a);                   \
+        else if (VV == 4 && !HH && a.lanes_per_seg == 8 && a.chunks == 8 && ln_reduce_l8())                                          \
+            LN_LAUNCH("k_csr_reduce_segments", (k_csr_reduce_segments<4, false, false, 8>), grid, block, 0, st, a);                  \
         else                                                                                                                         \
             LN_LAUNCH("k_csr_reduce_segments", (k_csr_reduce_segments<VV, HH, false>), grid, block, 0, st, a);                       \
     }
@@ -575,6 +588,9 @@ static int ln_splat_tail_impl(const char* who, const LnCsr* csr, const int* grp_
     {                                                                                                                                \
         if (wg)                                                                                                                      \
             LN_LAUNCH("k_reduce_and_neighbours", (k_reduce_and_neighbours<VV, DD, HH, (VV >= 4)>), grid, block, 0, st, a, reduce_blocks, \
+                      *table, query_rows_upper, nbr);                                                                                \
+        else if (VV == 4 && !HH && a.lanes_per_seg == 8 && a.chunks == 8 && ln_reduce_l8())                                          \
+            LN_LAUNCH("k_reduce_and_neighbours", (k_reduce_and_neighbours<4, DD, false, false, 8>), grid, block, 0, st, a, reduce_blocks, \
                       *table, query_rows_upper, nbr);                                                                                \
         else                                                                                                                         \
             LN_LAUNCH("k_reduce_and_neighbours", (k_reduce_and_neighbours<VV, DD, HH, false>), grid, block, 0, st, a, reduce_blocks,  \
