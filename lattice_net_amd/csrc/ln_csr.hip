@@ -536,7 +536,9 @@ static int ln_csr_reduce_rows_impl(const char* who, const LnCsr* csr, const int*
     const bool wg = ((csr->dense & 1) != 0 || a.lanes_per_seg >= 16) && vec >= 4 && !(csr->dense & 2);
 #define LN_REDUCE_LAUNCH(VV, HH)                                                                                                     \
     {                                                                                                                                \
-        if (wg)                                                                                                                      \
+        if (wg && VV == 8 && HH && a.lanes_per_seg == 8 && a.chunks == 8 && ln_reduce_l8())                                          \
+            LN_LAUNCH("k_csr_reduce_segments", (k_csr_reduce_segments<8, true, true, 8>), grid, block, 0, st, a);                    \
+        else if (wg)                                                                                                                 \
             LN_LAUNCH("k_csr_reduce_segments", (k_csr_reduce_segments<VV, HH, (VV >= 4)>), grid, block, 0, st, a);                   \
         else if (VV == 4 && !HH && a.lanes_per_seg == 8 && a.chunks == 8 && ln_reduce_l8())                                          \
             LN_LAUNCH("k_csr_reduce_segments", (k_csr_reduce_segments<4, false, false, 8>), grid, block, 0, st, a);                  \
@@ -586,7 +588,10 @@ static int ln_splat_tail_impl(const char* who, const LnCsr* csr, const int* grp_
     const dim3 grid(reduce_blocks + nbr_blocks), block(256);
 #define LN_FUSED_LAUNCH(VV, DD, HH)                                                                                                  \
     {                                                                                                                                \
-        if (wg)                                                                                                                      \
+        if (wg && VV == 8 && HH && a.lanes_per_seg == 8 && a.chunks == 8 && ln_reduce_l8())                                          \
+            LN_LAUNCH("k_reduce_and_neighbours", (k_reduce_and_neighbours<8, DD, true, true, 8>), grid, block, 0, st, a, reduce_blocks, \
+                      *table, query_rows_upper, nbr);                                                                                \
+        else if (wg)                                                                                                                 \
             LN_LAUNCH("k_reduce_and_neighbours", (k_reduce_and_neighbours<VV, DD, HH, (VV >= 4)>), grid, block, 0, st, a, reduce_blocks, \
                       *table, query_rows_upper, nbr);                                                                                \
         else if (VV == 4 && !HH && a.lanes_per_seg == 8 && a.chunks == 8 && ln_reduce_l8())                                          \
