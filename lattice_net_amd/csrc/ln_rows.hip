@@ -109,10 +109,13 @@ extern "C" int ln_slice_backward(const float* grad_sliced, const int* idx, const
 // ------------------------------------------------------------------------------------------
 // DP1 = d + 1 at compile time: the d+1 (index, weight) pairs of a point are fetched in one round trip and its d+1 row gathers
 // in a second one (with a runtime trip count the compiler kept the loop rolled: d+1 dependent {index -> row} pairs).
-template <int VEC, int DP1>
+// CH = 8: eight chunks per row as a compile-time constant (32 fp32 channels on float4 lanes: the headline chain) — the point / chunk split
+// of the thread index is a shift instead of a division by a run-time value (~20 instructions per thread); 0: `chunks` from the argument.
+template <int VEC, int DP1, int CH = 0>
 __global__ void __launch_bounds__(256)
     k_slice_forward(const float* __restrict__ values, const int* __restrict__ idx, const float* __restrict__ w, long long work,
-                    int chunks, float* __restrict__ out, float* __restrict__ zero_fill, long long zero_elems) {
+                    int chunks_arg, float* __restrict__ out, float* __restrict__ zero_fill, long long zero_elems) {
+    const int chunks = CH ? CH : chunks_arg;
     using T = typename VecT<VEC>::type;
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
 #ifdef LN_PROBE_NO_CLEAR  // timing probe (wrong results): no zero fill
@@ -144,6 +147,10 @@ __global__ void __launch_bounds__(256)
 
 #define LN_SLICE_CASE(DD)                                                                                                             \
     case DD:                                                                                                                          \
+        if (VEC == 4 && chunks == 8)                                                                                                  \
+            LN_LAUNCH("k_slice_forward", (k_slice_forward<4, DD + 1, 8>), dim3(ln_div_up(work, 256)), dim3(256), 0, (hipStream_t)stream,  \
+                      values, idx, w, work, chunks, out, zero_fill, zero_elems);                                                      \
+        else                                                                                                                          \
         LN_LAUNCH("k_slice_forward", (k_slice_forward<VEC, DD + 1>), dim3(ln_div_up(work, 256)), dim3(256), 0, (hipStream_t)stream, values, \
                   idx, w, work, chunks, out, zero_fill, zero_elems);                                                                  \
         break;
