@@ -327,10 +327,11 @@ extern "C" int ln_slice_forward_ordered(const LnTable* t, const LnCsr* csr, cons
 // allows.  As in k_slice_forward: all indices and weights first, then the d+1 row gathers together (the first version fetched
 // index -> row -> weight vertex after vertex: four dependent round trips, 52 us at C5 against 25 us now), same summation order;
 // `zero_fill`: the fp32 accumulator of this slice's backward pass, zeroed on the way.
-template <int DP1, int HV>
+template <int DP1, int HV, int CH = 0>  // CH = 8: eight chunks per row at compile time (64 fp16 channels), as in k_slice_forward
 __global__ void __launch_bounds__(256)
     k_slice_forward_f16(const _Float16* __restrict__ values, const int* __restrict__ idx, const float* __restrict__ w, long long work,
-                        int chunks, _Float16* __restrict__ out, float* __restrict__ zero_fill, long long zero_elems) {
+                        int chunks_arg, _Float16* __restrict__ out, float* __restrict__ zero_fill, long long zero_elems) {
+    const int chunks = CH ? CH : chunks_arg;
     typedef _Float16 hv __attribute__((ext_vector_type(HV)));
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (zero_fill) {
@@ -384,7 +385,10 @@ static int ln_slice_forward_f16_impl(const void* values_f16, const int* idx, con
     _Float16* oo = static_cast<_Float16*>(out_f16);
 #define LN_SLICE16_CASE(DD)                                                                                                            \
     case DD:                                                                                                                          \
-        if (wide)                                                                                                                     \
+        if (wide && chunks == 8)                                                                                                      \
+            LN_LAUNCH("k_slice_forward_f16", (k_slice_forward_f16<DD + 1, 8, 8>), dim3(ln_div_up(work, 256)), dim3(256), 0, st, vv, idx, w, work, \
+                      chunks, oo, zero_fill, zero_elems);                                                                             \
+        else if (wide)                                                                                                                \
             LN_LAUNCH("k_slice_forward_f16", (k_slice_forward_f16<DD + 1, 8>), dim3(ln_div_up(work, 256)), dim3(256), 0, st, vv, idx, w, work, \
                       chunks, oo, zero_fill, zero_elems);                                                                             \
         else                                                                                                                          \
