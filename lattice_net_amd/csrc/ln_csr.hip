@@ -351,19 +351,25 @@ __device__ __forceinline__ void ln_reduce_chunk(const LnSegOfThread& so, const L
         for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
         if (cok) {
             for (int e0 = beg; e0 < end; e0 += U) {
+                // No branch per entry (round 6): the entries of the last, partly filled batch re-read the segment's last entry with
+                // weight 0 (a row that is summed anyway), and an id of -1 (left behind by an overflowed build) reads row 0 with weight 0 —
+                // the 4 ids, then the 4 weights and 4 row chunks go out back to back instead of each behind its own exec-mask test.
                 int tk[U];
+                bool ok[U];
 #pragma unroll
-                for (int u = 0; u < U; ++u) tk[u] = (e0 + u < end) ? csr_tok[e0 + u] : -1;
+                for (int u = 0; u < U; ++u) {
+                    ok[u] = e0 + u < end;
+                    tk[u] = csr_tok[min(e0 + u, end - 1)];
+                }
                 float wt[U];
                 float x[U][VEC];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    const int t = tk[u];
-                    wt[u] = 0.f;
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k) x[u][k] = 0.f;
-                    if (t >= 0) {
-                        wt[u] = w[t];
+                    const bool valid = ok[u] && tk[u] >= 0;
+                    const int t = max(tk[u], 0);
+                    const float wl = w[t];
+                    wt[u] = valid ? wl : 0.f;
+                    {
                         const int srow = pow2 ? (t >> shift) : (t / src_div);
                         const size_t off = (size_t)srow * src_stride + c * VEC;
                         if constexpr (HALF) {
