@@ -597,7 +597,9 @@ extern "C" int ln_build_concurrency(int scans_in_flight) {
 #define LN_BKT_LDS_LIMIT (150 * 1024)  // dynamic LDS one k_bucket_rows workgroup may ask for (160 KB per CU minus its static arrays)
 #define LN_BKT_LDS_PER_SLOT (sizeof(unsigned long long) + 7 * sizeof(int))
 #define LN_BKT_LDS_EXTRA 32  // alignment of the compacted token list + its padding to a multiple of four entries
+#ifndef LN_BKT_REG_TOK
 #define LN_BKT_REG_TOK 4  // tokens per thread whose (token, slot, position) stay in registers between the two sweeps
+#endif
 #define LN_PUB_READY 0x80000000u
 #define LN_PUB_ERR 0x40000000u
 #define LN_PUB_CNT 0x3FFFFFFFu
